@@ -1,0 +1,283 @@
+"""Synthetic workloads for the hot path (numpy only, deterministic).
+
+The reference ships no datasets (its two .bag files are absent, SURVEY.md
+section 2 row 17) and publishes no benchmark inputs, so every workload here is
+generated from the recipes fixed in SURVEY.md section 8(d):
+
+* ``make_pose_graph``  -- C2: grid random walk, odometry + proximity closures,
+  information matrices as in src/slam/graph_slam.cpp:72-76.
+* ``make_scan_pairs``  -- C3: 1081-beam scans ray-cast in random rectilinear
+  rooms (laser geometry as built in src/ros_utils/ros_handler.cpp:92-93).
+* ``make_multi_robot`` -- C5: R robots, each a C2-style sub-graph with ids
+  ``robot*10000+k`` (src/slam/graph_slam.cpp:95,155; src/srslam.cpp:147).
+
+The generator is counter based (splitmix64 of ``seed`` and a stream/counter
+pair) so any element can be regenerated independently and results do not
+depend on numpy's bit-generator implementation.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_U64 = np.uint64
+_MASK = (1 << 64) - 1
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser on uint64 arrays (wraps modulo 2**64)."""
+    with np.errstate(over="ignore"):
+        x = (x + _U64(0x9E3779B97F4A7C15)).astype(_U64)
+        x = ((x ^ (x >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)).astype(_U64)
+        x = ((x ^ (x >> _U64(27))) * _U64(0x94D049BB133111EB)).astype(_U64)
+        return (x ^ (x >> _U64(31))).astype(_U64)
+
+
+def _stream_base(seed: int, stream: int) -> np.uint64:
+    s = _splitmix64(np.array([(seed * 0x632BE59BD9B4E019 + stream) & _MASK], dtype=_U64))
+    return s[0]
+
+
+def uniform(seed: int, stream: int, n: int, offset: int = 0) -> np.ndarray:
+    """n doubles in [0,1): element i depends only on (seed, stream, offset+i)."""
+    base = _stream_base(seed, stream)
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(offset, offset + n, dtype=_U64) * _U64(0xD1342543DE82EF95) + base).astype(_U64)
+    bits = _splitmix64(ctr)
+    return (bits >> _U64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def normal(seed: int, stream: int, n: int) -> np.ndarray:
+    """n standard normals (Box-Muller on two independent uniform streams)."""
+    u1 = uniform(seed, 2 * stream + 1000, n)
+    u2 = uniform(seed, 2 * stream + 1001, n)
+    u1 = np.maximum(u1, 1e-300)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+# --------------------------------------------------------------------------- SE2
+
+def normalize_theta(t):
+    """Wrap to (-pi, pi] the way g2o's normalize_theta does [g2o-recalled]."""
+    t = np.asarray(t, dtype=np.float64)
+    out = np.where((t >= -np.pi) & (t < np.pi), t, t - 2 * np.pi * np.floor((t + np.pi) / (2 * np.pi)))
+    return out
+
+
+def se2_compose(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """a*b for arrays of shape (...,3) holding (x, y, theta)."""
+    c, s = np.cos(a[..., 2]), np.sin(a[..., 2])
+    out = np.empty(np.broadcast(a, b).shape, dtype=np.float64)
+    out[..., 0] = a[..., 0] + c * b[..., 0] - s * b[..., 1]
+    out[..., 1] = a[..., 1] + s * b[..., 0] + c * b[..., 1]
+    out[..., 2] = normalize_theta(a[..., 2] + b[..., 2])
+    return out
+
+
+def se2_inverse(a: np.ndarray) -> np.ndarray:
+    c, s = np.cos(a[..., 2]), np.sin(a[..., 2])
+    out = np.empty_like(a, dtype=np.float64)
+    out[..., 0] = -(c * a[..., 0] + s * a[..., 1])
+    out[..., 1] = -(-s * a[..., 0] + c * a[..., 1])
+    out[..., 2] = -a[..., 2]
+    return out
+
+
+# ------------------------------------------------------------------ pose graphs
+
+ODOM_INFO = (100.0, 100.0, 1000.0)      # src/slam/graph_slam.cpp:72-73
+SM_INFO = (1000.0, 1000.0, 10000.0)     # src/slam/graph_slam.cpp:75-76
+
+
+def _diag_info_upper(d):
+    # upper-triangular row-major (I11 I12 I13 I22 I23 I33), the EDGE_SE2 order
+    return np.array([d[0], 0.0, 0.0, d[1], 0.0, d[2]], dtype=np.float64)
+
+
+def make_pose_graph(n_vertices: int = 10000, n_edges: int = 40000, seed: int = 12345,
+                    close_radius: float = 1.5, id_base: int = 0):
+    """C2 recipe.
+
+    Returns a dict of flat arrays: ``truth``/``poses`` (V,3) (initial guess =
+    odometry chain), ``fixed`` (V,) u8 with vertex 0 fixed, ``edge_from``,
+    ``edge_to`` (E,) int32 *indices*, ``meas`` (E,3), ``info`` (E,6),
+    ``ids`` (V,) int32 g2o vertex ids.
+    """
+    V = int(n_vertices)
+    n_odo = V - 1
+    n_lc = int(n_edges) - n_odo
+    if n_lc < 0:
+        raise ValueError("n_edges must be >= n_vertices-1")
+    # random walk on the unit grid: heading changes drawn from {0,0,0,+90,-90}
+    turn_choice = (uniform(seed, 1, V) * 5).astype(np.int64)
+    dturn = np.array([0, 0, 0, 1, -1], dtype=np.int64)[turn_choice]
+    heading = np.cumsum(dturn) - dturn[0]            # heading of pose k (quarter turns), pose 0 heads +x
+    hq = np.mod(heading, 4)
+    dxs = np.array([1, 0, -1, 0], dtype=np.int64)[hq]
+    dys = np.array([0, 1, 0, -1], dtype=np.int64)[hq]
+    # pose k+1 = pose k advanced one metre along heading k, then turned by dturn[k+1]
+    x = np.concatenate([[0], np.cumsum(dxs[:-1])]).astype(np.float64)
+    y = np.concatenate([[0], np.cumsum(dys[:-1])]).astype(np.float64)
+    th = normalize_theta(hq.astype(np.float64) * (np.pi / 2))
+    truth = np.stack([x, y, th], axis=1)
+
+    # candidate closures: pairs closer than close_radius with index gap > 1
+    ix = x.astype(np.int64)
+    iy = y.astype(np.int64)
+    key = (ix - ix.min()) * (iy.max() - iy.min() + 3) + (iy - iy.min())
+    stride = int(iy.max() - iy.min() + 3)
+    order = np.argsort(key, kind="stable")
+    skey = key[order]
+    cand_i = []
+    cand_j = []
+    r = int(np.ceil(close_radius))
+    for ddx in range(-r, r + 1):
+        for ddy in range(-r, r + 1):
+            if ddx * ddx + ddy * ddy >= close_radius * close_radius:
+                continue
+            nk = key + ddx * stride + ddy
+            lo = np.searchsorted(skey, nk, side="left")
+            hi = np.searchsorted(skey, nk, side="right")
+            cnt = hi - lo
+            src = np.repeat(np.arange(V), cnt)
+            # positions inside each run
+            run_start = np.repeat(lo, cnt)
+            within = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            dst = order[run_start + within]
+            m = dst > src + 1
+            cand_i.append(src[m])
+            cand_j.append(dst[m])
+    ci = np.concatenate(cand_i)
+    cj = np.concatenate(cand_j)
+    # canonical order so the sample does not depend on the neighbour sweep order
+    o = np.lexsort((cj, ci))
+    ci, cj = ci[o], cj[o]
+    if len(ci) < n_lc:
+        raise ValueError(f"only {len(ci)} closure candidates for {n_lc} requested")
+    # uniform sample without replacement: rank candidates by a counter-based key
+    rk = uniform(seed, 2, len(ci))
+    pick = np.sort(np.argsort(rk, kind="stable")[:n_lc])
+    li, lj = ci[pick], cj[pick]
+
+    e_from = np.concatenate([np.arange(V - 1), li]).astype(np.int32)
+    e_to = np.concatenate([np.arange(1, V), lj]).astype(np.int32)
+    E = len(e_from)
+    info_d = np.empty((E, 3))
+    info_d[:n_odo] = ODOM_INFO
+    info_d[n_odo:] = SM_INFO
+    rel = se2_compose(se2_inverse(truth[e_from]), truth[e_to])
+    noise = np.stack([normal(seed, 10 + k, E) for k in range(3)], axis=1) / np.sqrt(info_d)
+    meas = se2_compose(rel, noise)                     # noise composed on the right
+    info = np.zeros((E, 6))
+    info[:, 0] = info_d[:, 0]
+    info[:, 3] = info_d[:, 1]
+    info[:, 5] = info_d[:, 2]
+
+    # initial guess: chain the odometry measurements from the (fixed) first pose
+    poses = np.empty_like(truth)
+    poses[0] = truth[0]
+    for k in range(V - 1):
+        poses[k + 1] = se2_compose(poses[k], meas[k])
+    fixed = np.zeros(V, dtype=np.uint8)
+    fixed[0] = 1
+    ids = (id_base + np.arange(V)).astype(np.int32)
+    return dict(truth=truth, poses=poses, fixed=fixed, edge_from=e_from, edge_to=e_to,
+                meas=meas, info=info, ids=ids, n_odometry=n_odo)
+
+
+def make_multi_robot(n_robots: int = 8, n_vertices: int = 5000, n_edges: int = 20000,
+                     seed: int = 777, base_id: int = 10000, shared_every: int = 50):
+    """C5 recipe: ``n_robots`` independent sub-graphs + the inter-robot closure
+    lists (which of *my* vertices peer q has closed a loop against, i.e. the
+    ids q requests in its CondensedGraphMessage, src/mrslam/mr_graph_slam.cpp:614-624).
+
+    Every ``shared_every``-th vertex of robot r is declared shared with peer
+    ``(r + 1 + (k // shared_every) % (n_robots-1)) % n_robots``.
+    """
+    robots = []
+    for r in range(n_robots):
+        g = make_pose_graph(n_vertices, n_edges, seed=seed + 17 * r, id_base=r * base_id)
+        out_closures = {q: [] for q in range(n_robots) if q != r}
+        if n_robots > 1:
+            for k in range(shared_every, n_vertices, shared_every):
+                q = (r + 1 + (k // shared_every) % (n_robots - 1)) % n_robots
+                out_closures[q].append(k)
+        g["robot"] = r
+        g["out_closures"] = {q: np.asarray(v, dtype=np.int32) for q, v in out_closures.items()}
+        robots.append(g)
+    return robots
+
+
+# ------------------------------------------------------------------------ scans
+
+LASER_BEAMS = 1081
+LASER_ANGLE_MIN = -2.35619449
+LASER_ANGLE_INC = 0.00436332313
+LASER_MAX_RANGE = 30.0
+
+
+def _raycast_boxes(px, py, ang, boxes, max_range):
+    """Distance along each ray (px,py,ang) to the nearest wall segment of the
+    axis-aligned boxes ((x0,y0,x1,y1) rows).  Vectorised over rays."""
+    dx = np.cos(ang)
+    dy = np.sin(ang)
+    best = np.full(ang.shape, max_range * 2.0)
+    tiny = 1e-12
+    for (x0, y0, x1, y1) in boxes:
+        for xw in (x0, x1):                           # vertical walls
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (xw - px) / np.where(np.abs(dx) < tiny, np.nan, dx)
+            yy = py + t * dy
+            ok = (t > 1e-9) & (yy >= y0) & (yy <= y1)
+            best = np.where(ok & (t < best), t, best)
+        for yw in (y0, y1):                           # horizontal walls
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (yw - py) / np.where(np.abs(dy) < tiny, np.nan, dy)
+            xx = px + t * dx
+            ok = (t > 1e-9) & (xx >= x0) & (xx <= x1)
+            best = np.where(ok & (t < best), t, best)
+    return best
+
+
+def make_scan_pairs(n_pairs: int, seed: int = 4242, n_beams: int = LASER_BEAMS,
+                    range_noise: float = 0.01):
+    """C3 recipe.  Returns float32 ranges for the
+    reference and query scans, the initial guess (origin^-1 * current) and the
+    true relative pose, all as flat arrays."""
+    P = int(n_pairs)
+    ang0 = LASER_ANGLE_MIN + LASER_ANGLE_INC * np.arange(n_beams)
+    ref = np.empty((P, n_beams), dtype=np.float32)
+    qry = np.empty((P, n_beams), dtype=np.float32)
+    guess = np.empty((P, 3))
+    true_rel = np.empty((P, 3))
+    u = uniform(seed, 1, P * 32).reshape(P, 32)
+    for p in range(P):
+        w = 6.0 + 14.0 * u[p, 0]
+        h = 6.0 + 14.0 * u[p, 1]
+        boxes = [(-w / 2, -h / 2, w / 2, h / 2)]
+        nb = int(u[p, 2] * 5)
+        for b in range(nb):
+            bw = 0.5 + 1.5 * u[p, 3 + 4 * b]
+            bh = 0.5 + 1.5 * u[p, 4 + 4 * b]
+            cx = (u[p, 5 + 4 * b] - 0.5) * (w - bw - 1.0)
+            cy = (u[p, 6 + 4 * b] - 0.5) * (h - bh - 1.0)
+            boxes.append((cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2))
+        # first pose: somewhere in the middle third of the room, outside the interior boxes
+        for attempt in range(8):
+            ax = (u[p, 23] - 0.5 + 0.11 * attempt) % 1.0 - 0.5
+            ay = (u[p, 24] - 0.5 + 0.07 * attempt) % 1.0 - 0.5
+            p1 = np.array([ax * w / 3, ay * h / 3, (u[p, 25] - 0.5) * 2 * np.pi])
+            if all(not (bx0 - 0.6 < p1[0] < bx1 + 0.6 and by0 - 0.6 < p1[1] < by1 + 0.6)
+                   for (bx0, by0, bx1, by1) in boxes[1:]):
+                break
+        d = np.array([(u[p, 26] - 0.5) * 0.5, (u[p, 27] - 0.5) * 0.5, (u[p, 28] - 0.5) * 0.3])
+        p2 = se2_compose(p1, d)
+        g = se2_compose(d, np.array([(u[p, 29] - 0.5) * 0.1, (u[p, 30] - 0.5) * 0.1, (u[p, 31] - 0.5) * 0.04]))
+        for pose, out, st in ((p1, ref, 0), (p2, qry, 1)):
+            r = _raycast_boxes(pose[0], pose[1], pose[2] + ang0, boxes, LASER_MAX_RANGE)
+            r = r + range_noise * normal(seed + 1, 2 * p + st, n_beams)
+            out[p] = np.clip(r, 0.05, LASER_MAX_RANGE * 2).astype(np.float32)
+        guess[p] = g
+        true_rel[p] = d
+    return dict(ranges_ref=ref, ranges_qry=qry, guess=guess, true_rel=true_rel,
+                angle_min=LASER_ANGLE_MIN, angle_inc=LASER_ANGLE_INC, max_range=LASER_MAX_RANGE,
+                n_beams=n_beams)
