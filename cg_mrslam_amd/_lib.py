@@ -1,0 +1,159 @@
+"""ctypes binding of libcgmr.so (include/cgmr.h).  Fails loudly when the HIP library is
+missing -- there is deliberately no CPU path behind these calls."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+CGMR_E_CHOLESKY_BASE = -100
+
+
+class CgmrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"cgmr error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libcgmr.so")
+
+
+def build_library(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "-s", "clean"])
+    subprocess.check_call(["make", "-C", csrc, "-s", "-j8"])
+    return library_path()
+
+
+_SYMBOLS = [
+    "cgmr_version", "cgmr_ctx_create", "cgmr_ctx_destroy", "cgmr_last_error", "cgmr_ctx_synchronize",
+    "cgmr_gn_optimize", "cgmr_gn_optimize_dev", "cgmr_gn_symbolic_info", "cgmr_gn_last_timing",
+    "cgmr_set_profiling", "cgmr_gn_kernel_times",
+]
+
+
+def declared_symbols():
+    """Every entry point include/cgmr.h declares (parsed from the header)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "cgmr.h")
+    txt = open(hdr).read()
+    return sorted(set(re.findall(r"\b(cgmr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise CgmrError(-2, f"{path} not found: build it with __graft_entry__.build() "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    lib.cgmr_last_error.restype = C.c_char_p
+    lib.cgmr_ctx_destroy.restype = None
+    _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+class Context:
+    """One cgmr context = one HIP device + one stream (include/cgmr.h)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.cgmr_ctx_create(C.c_int(device), C.c_void_p(stream or 0), C.byref(h))
+        if rc != 0:
+            raise CgmrError(rc, "cgmr_ctx_create failed (no usable gfx950 device?)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cgmr_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow_cholesky=False):
+        if rc == 0:
+            return rc
+        if allow_cholesky and rc <= CGMR_E_CHOLESKY_BASE:
+            return rc
+        raise CgmrError(rc, self.lib.cgmr_last_error(self.h).decode())
+
+    def synchronize(self):
+        self._check(self.lib.cgmr_ctx_synchronize(self.h))
+
+    # ------------------------------------------------------------------ GN
+    def gn_optimize(self, poses, fixed, ef, et, meas, info, iters, raise_on_cholesky=True):
+        """Host arrays in, host arrays out.  Returns (status, poses, chi2[iters+1])."""
+        p = np.ascontiguousarray(poses, dtype=np.float64).copy()
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        ef = np.ascontiguousarray(ef, dtype=np.int32)
+        et = np.ascontiguousarray(et, dtype=np.int32)
+        meas = np.ascontiguousarray(meas, dtype=np.float64)
+        info = np.ascontiguousarray(info, dtype=np.float64)
+        chi = np.zeros(iters + 1)
+        rc = self.lib.cgmr_gn_optimize(self.h, C.c_int(p.shape[0]), _ptr(p), _ptr(fixed), C.c_int(len(ef)),
+                                       _ptr(ef), _ptr(et), _ptr(meas), _ptr(info), C.c_int(iters), _ptr(chi))
+        self._check(rc, allow_cholesky=not raise_on_cholesky)
+        return rc, p, chi
+
+    def gn_optimize_dev(self, d_poses_ptr, nV, fixed, ef, et, d_meas_ptr, d_info_ptr, iters,
+                        raise_on_cholesky=True):
+        """Device pointers (ints) for poses/meas/info, host numpy for the structure."""
+        chi = np.zeros(iters + 1)
+        rc = self.lib.cgmr_gn_optimize_dev(self.h, C.c_int(nV), C.c_void_p(d_poses_ptr), _ptr(fixed),
+                                           C.c_int(len(ef)), _ptr(ef), _ptr(et), C.c_void_p(d_meas_ptr),
+                                           C.c_void_p(d_info_ptr), C.c_int(iters), _ptr(chi))
+        self._check(rc, allow_cholesky=not raise_on_cholesky)
+        return rc, chi
+
+    def gn_last_timing(self):
+        out = np.zeros(5)
+        self._check(self.lib.cgmr_gn_last_timing(self.h, _ptr(out)))
+        return dict(zip(["order", "structure", "upload", "device", "total"], out.tolist()))
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.cgmr_set_profiling(self.h, C.c_int(1 if on else 0)))
+
+    def gn_kernel_times(self):
+        sec = np.zeros(8)
+        n = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.cgmr_gn_kernel_times(self.h, _ptr(sec), _ptr(n)))
+        names = ["linearize", "assemble", "chi2", "front_factor", "front_update", "solve_fwd", "solve_bwd", "update"]
+        return {k: (float(s), int(c)) for k, s, c in zip(names, sec, n)}
+
+
+def gn_symbolic_info(nV, fixed, ef, et, want_perm=False):
+    """Host-only ordering / symbolic analysis statistics (no GPU needed)."""
+    lib = load_library()
+    fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+    ef = np.ascontiguousarray(ef, dtype=np.int32)
+    et = np.ascontiguousarray(et, dtype=np.int32)
+    out = np.zeros(10, dtype=np.int64)
+    perm = np.zeros(nV, dtype=np.int32) if want_perm else None
+    rc = lib.cgmr_gn_symbolic_info(C.c_int(nV), _ptr(fixed), C.c_int(len(ef)), _ptr(ef), _ptr(et), _ptr(out),
+                                   _ptr(perm))
+    if rc != 0:
+        raise CgmrError(rc, "cgmr_gn_symbolic_info rejected the graph")
+    keys = ["free_poses", "offdiag_blocks", "fronts", "levels", "L_doubles", "U_doubles", "max_border",
+            "factor_flops", "order_us", "structure_us"]
+    info = dict(zip(keys, out.tolist()))
+    return (info, perm) if want_perm else info

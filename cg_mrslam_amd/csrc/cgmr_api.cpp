@@ -1,0 +1,348 @@
+// C ABI of libcgmr.so (include/cgmr.h): context management and the Gauss-Newton driver.
+// Compiled with hipcc; contains no kernels (those live in gn_kernels.hip / matcher_kernels.hip).
+#include "cgmr_ctx.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace cgmr {
+
+double wall_s() {
+  using namespace std::chrono;
+  return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
+}
+
+int set_err(cgmr_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) return set_err(ctx, CGMR_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes) {
+  if (bytes <= A.cap) return 0;
+  if (A.ptr) { hipStreamSynchronize(ctx->stream); hipFree(A.ptr); A.ptr = nullptr; A.cap = 0; }
+  size_t want = bytes + bytes / 4 + (1 << 20);
+  hipError_t e = hipMalloc((void**)&A.ptr, want);
+  if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+  A.cap = want;
+  return 0;
+}
+
+int pinned_reserve(cgmr_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_cap) return 0;
+  if (ctx->pinned) { hipStreamSynchronize(ctx->stream); hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+  size_t want = bytes + bytes / 4 + (1 << 16);
+  hipError_t e = hipHostMalloc((void**)&ctx->pinned, want, hipHostMallocDefault);
+  if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+  ctx->pinned_cap = want;
+  return 0;
+}
+
+namespace {
+
+struct BlobLayout {
+  size_t off = 0;
+  template <typename T>
+  size_t add(size_t count) {
+    off = (off + 15) & ~size_t(15);
+    size_t o = off;
+    off += count * sizeof(T);
+    return o;
+  }
+};
+
+// Lay out and upload the structure arrays; point GnDevice into the arena.
+int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t* et, int iters) {
+  GnDevice& D = ctx->gn;
+  D.nV = S.nV; D.nE = S.nE; D.nf = S.nf; D.nb = S.nb;
+  D.nfronts = (int)S.fronts.size();
+  D.nlevels = (int)S.level_ptr.size() - 1;
+  D.h_level_ptr = S.level_ptr;
+  // update tiles per level
+  std::vector<int32_t> tiles;
+  D.h_tile_ptr.assign(D.nlevels + 1, 0);
+  for (int l = 0; l < D.nlevels; l++) {
+    for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
+      int f = S.level_fronts[q];
+      int T = (3 * S.fronts[f].ns + 31) / 32;
+      for (int ti = 0; ti < T; ti++)
+        for (int tj = 0; tj <= ti; tj++) { tiles.push_back(f); tiles.push_back(ti); tiles.push_back(tj); }
+    }
+    D.h_tile_ptr[l + 1] = (int)tiles.size() / 3;
+  }
+  BlobLayout B;
+  size_t o_fronts = B.add<FrontDesc>(S.fronts.size());
+  size_t o_rows = B.add<int32_t>(S.rows.size());
+  size_t o_children = B.add<int32_t>(S.children.size());
+  size_t o_rel = B.add<int32_t>(S.rel.size());
+  size_t o_inv = B.add<int32_t>(S.inv.size());
+  size_t o_alist = B.add<int32_t>(S.alist.size());
+  size_t o_lf = B.add<int32_t>(S.level_fronts.size());
+  size_t o_tiles = B.add<int32_t>(tiles.size());
+  size_t o_asmp = B.add<int32_t>(S.asm_ptr.size());
+  size_t o_asms = B.add<int32_t>(S.asm_src.size());
+  size_t o_vperm = B.add<int32_t>(S.vperm.size());
+  size_t o_ef = B.add<int32_t>(S.nE);
+  size_t o_et = B.add<int32_t>(S.nE);
+  size_t blob_bytes = (B.off + 255) & ~size_t(255);
+  // numeric work space
+  BlobLayout N;
+  N.off = blob_bytes;
+  size_t o_term = N.add<double>((size_t)34 * S.nE);
+  size_t o_A = N.add<double>((size_t)9 * (S.nf + S.nb));
+  size_t o_b = N.add<double>((size_t)3 * S.nf);
+  size_t o_y = N.add<double>((size_t)3 * S.nf);
+  size_t o_x = N.add<double>((size_t)3 * S.nf);
+  size_t o_u = N.add<double>((size_t)3 * S.rows.size() + 3);
+  size_t o_L = N.add<double>((size_t)S.L_doubles + 1);
+  size_t o_U = N.add<double>((size_t)S.U_doubles + 1);
+  size_t o_chi = N.add<double>((size_t)iters + 2);
+  size_t o_status = N.add<int>(4);
+  size_t total = N.off + 256;
+  int rc = arena_reserve(ctx, ctx->gn_arena, total);
+  if (rc) return rc;
+  rc = pinned_reserve(ctx, blob_bytes);
+  if (rc) return rc;
+  char* h = ctx->pinned;
+  auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(h + off, src, bytes); };
+  put(o_fronts, S.fronts.data(), S.fronts.size() * sizeof(FrontDesc));
+  put(o_rows, S.rows.data(), S.rows.size() * 4);
+  put(o_children, S.children.data(), S.children.size() * 4);
+  put(o_rel, S.rel.data(), S.rel.size() * 4);
+  put(o_inv, S.inv.data(), S.inv.size() * 4);
+  put(o_alist, S.alist.data(), S.alist.size() * 4);
+  put(o_lf, S.level_fronts.data(), S.level_fronts.size() * 4);
+  put(o_tiles, tiles.data(), tiles.size() * 4);
+  put(o_asmp, S.asm_ptr.data(), S.asm_ptr.size() * 4);
+  put(o_asms, S.asm_src.data(), S.asm_src.size() * 4);
+  put(o_vperm, S.vperm.data(), S.vperm.size() * 4);
+  put(o_ef, ef, (size_t)S.nE * 4);
+  put(o_et, et, (size_t)S.nE * 4);
+  char* d = ctx->gn_arena.ptr;
+  HIP_TRY(ctx, hipMemcpyAsync(d, h, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+  D.fronts = (FrontDesc*)(d + o_fronts);
+  D.rows = (int32_t*)(d + o_rows);
+  D.children = (int32_t*)(d + o_children);
+  D.rel = (int32_t*)(d + o_rel);
+  D.inv = (int32_t*)(d + o_inv);
+  D.alist = (int32_t*)(d + o_alist);
+  D.level_fronts = (int32_t*)(d + o_lf);
+  D.tiles = (int32_t*)(d + o_tiles);
+  D.asm_ptr = (int32_t*)(d + o_asmp);
+  D.asm_src = (int32_t*)(d + o_asms);
+  D.vperm = (int32_t*)(d + o_vperm);
+  D.ef = (int32_t*)(d + o_ef);
+  D.et = (int32_t*)(d + o_et);
+  D.term = (double*)(d + o_term);
+  D.Ablk = (double*)(d + o_A);
+  D.bvec = (double*)(d + o_b);
+  D.yvec = (double*)(d + o_y);
+  D.xvec = (double*)(d + o_x);
+  D.uvec = (double*)(d + o_u);
+  D.Lbuf = (double*)(d + o_L);
+  D.Ubuf = (double*)(d + o_U);
+  D.chi2 = (double*)(d + o_chi);
+  D.status = (int*)(d + o_status);
+  HIP_TRY(ctx, hipMemsetAsync(D.status, 0, 16, ctx->stream));
+  return 0;
+}
+
+struct KTimer {   // optional per-launch-class timing (profiling mode only)
+  cgmr_ctx* ctx;
+  template <typename Fn>
+  void run(int cls, int nlaunch, Fn&& fn) {
+    if (!ctx->profiling) { fn(); return; }
+    hipEventRecord(ctx->ev_a, ctx->stream);
+    fn();
+    hipEventRecord(ctx->ev_b, ctx->stream);
+    hipEventSynchronize(ctx->ev_b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+    ctx->ksec[cls] += 1e-3 * ms;
+    ctx->klaunch[cls] += nlaunch;
+  }
+};
+
+int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE, const int32_t* ef,
+           const int32_t* et, const double* d_meas, const double* d_info, int iters, double* chi2_out) {
+  double t0 = wall_s();
+  Symbolic& S = ctx->sym;
+  int rc = analyze(nV, fixed, nE, ef, et, S);
+  if (rc) return set_err(ctx, CGMR_E_INVALID, "graph structure rejected (edge index out of range or self edge)");
+  double t1 = wall_s();
+  rc = gn_upload(ctx, S, ef, et, iters);
+  if (rc) return rc;
+  double t2 = wall_s();
+  GnDevice& D = ctx->gn;
+  hipStream_t st = ctx->stream;
+  KTimer T{ctx};
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+  for (int it = 0; it <= iters; it++) {
+    int last = (it == iters);
+    T.run(0, 1, [&] { launch_linearize(st, D, d_poses, D.ef, D.et, d_meas, d_info, last); });
+    T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
+    if (last || D.nf == 0) continue;
+    T.run(1, 1, [&] { launch_assemble(st, D); });
+    for (int l = 0; l < D.nlevels; l++) {
+      T.run(3, 1, [&] { launch_factor_level(st, D, l, it + 1); });
+      if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
+    }
+    for (int l = 0; l < D.nlevels; l++) T.run(5, 1, [&] { launch_fwd_level(st, D, l); });
+    for (int l = D.nlevels - 1; l >= 0; l--) T.run(6, 1, [&] { launch_bwd_level(st, D, l); });
+    T.run(7, 1, [&] { launch_update(st, D, d_poses); });
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+  // read back chi2 + status
+  std::vector<double> chi(iters + 1);
+  int status = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(chi.data(), D.chi2, sizeof(double) * (iters + 1), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&status, D.status, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipGetLastError());
+  float ms = 0;
+  hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  if (chi2_out) memcpy(chi2_out, chi.data(), sizeof(double) * (iters + 1));
+  ctx->timing[0] = S.t_order;
+  ctx->timing[1] = S.t_struct;
+  ctx->timing[2] = t2 - t1;
+  ctx->timing[3] = 1e-3 * ms;
+  ctx->timing[4] = wall_s() - t0;
+  if (status != 0)
+    return set_err(ctx, CGMR_E_CHOLESKY_BASE - (status - 1),
+                   "Cholesky failed (non-positive pivot) in GN iteration %d; poses left at the last good update",
+                   status - 1);
+  return CGMR_OK;
+}
+
+}  // namespace
+}  // namespace cgmr
+
+using namespace cgmr;
+
+extern "C" {
+
+int cgmr_version(void) { return 100; }
+
+int cgmr_ctx_create(int device, void* hip_stream, cgmr_ctx** out) {
+  if (!out) return CGMR_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CGMR_E_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return CGMR_E_NO_DEVICE;
+  cgmr_ctx* ctx = new cgmr_ctx();
+  ctx->device = device;
+  if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return CGMR_E_HIP; }
+    ctx->own_stream = true;
+  }
+  hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1); hipEventCreate(&ctx->ev_a); hipEventCreate(&ctx->ev_b);
+  *out = ctx;
+  return CGMR_OK;
+}
+
+void cgmr_ctx_destroy(cgmr_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->gn_arena.ptr) hipFree(ctx->gn_arena.ptr);
+  if (ctx->io_arena.ptr) hipFree(ctx->io_arena.ptr);
+  if (ctx->mt_arena.ptr) hipFree(ctx->mt_arena.ptr);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
+  hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1); hipEventDestroy(ctx->ev_a); hipEventDestroy(ctx->ev_b);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* cgmr_last_error(const cgmr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cgmr_ctx_synchronize(cgmr_ctx* ctx) {
+  if (!ctx) return CGMR_E_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CGMR_OK;
+}
+
+int cgmr_gn_optimize_dev(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
+                         const int32_t* from_idx, const int32_t* to_idx, const double* d_meas,
+                         const double* d_info, int iters, double* chi2_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (nV < 0 || nE < 0 || iters < 0 || (nV > 0 && (!d_poses || !fixed)) ||
+      (nE > 0 && (!from_idx || !to_idx || !d_meas || !d_info)))
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_gn_optimize: null or negative argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return gn_run(ctx, nV, d_poses, fixed, nE, from_idx, to_idx, d_meas, d_info, iters, chi2_out);
+}
+
+int cgmr_gn_optimize(cgmr_ctx* ctx, int nV, double* poses, const uint8_t* fixed, int nE, const int32_t* from_idx,
+                     const int32_t* to_idx, const double* meas, const double* info, int iters, double* chi2_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (nV < 0 || nE < 0 || iters < 0 || (nV > 0 && (!poses || !fixed)) ||
+      (nE > 0 && (!from_idx || !to_idx || !meas || !info)))
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_gn_optimize: null or negative argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t bp = sizeof(double) * 3 * (size_t)nV, bm = sizeof(double) * 3 * (size_t)nE, bi = sizeof(double) * 6 * (size_t)nE;
+  size_t op = 0, om = (bp + 255) & ~size_t(255), oi = (om + bm + 255) & ~size_t(255);
+  int rc = arena_reserve(ctx, ctx->io_arena, oi + bi + 256);
+  if (rc) return rc;
+  char* d = ctx->io_arena.ptr;
+  HIP_TRY(ctx, hipMemcpyAsync(d + op, poses, bp, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d + om, meas, bm, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d + oi, info, bi, hipMemcpyHostToDevice, ctx->stream));
+  rc = gn_run(ctx, nV, (double*)(d + op), fixed, nE, from_idx, to_idx, (const double*)(d + om),
+              (const double*)(d + oi), iters, chi2_out);
+  if (rc == CGMR_OK || rc <= CGMR_E_CHOLESKY_BASE) {
+    hipError_t e = hipMemcpyAsync(poses, d + op, bp, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return set_err(ctx, CGMR_E_HIP, "pose read-back: %s", hipGetErrorString(e));
+  }
+  return rc;
+}
+
+int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx, const int32_t* to_idx,
+                          int64_t out[10], int32_t* perm_out) {
+  if (nV < 0 || nE < 0 || !out) return CGMR_E_INVALID;
+  Symbolic S;
+  int rc = analyze(nV, fixed, nE, from_idx, to_idx, S);
+  if (rc) return CGMR_E_INVALID;
+  out[0] = S.nf; out[1] = S.nb; out[2] = (int64_t)S.fronts.size(); out[3] = (int64_t)S.level_ptr.size() - 1;
+  out[4] = S.L_doubles; out[5] = S.U_doubles; out[6] = S.max_ns; out[7] = (int64_t)S.flops;
+  out[8] = (int64_t)(1e6 * S.t_order); out[9] = (int64_t)(1e6 * S.t_struct);
+  if (perm_out) memcpy(perm_out, S.vperm.data(), sizeof(int32_t) * nV);
+  return CGMR_OK;
+}
+
+int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]) {
+  if (!ctx || !out) return CGMR_E_INVALID;
+  memcpy(out, ctx->timing, sizeof(double) * 5);
+  return CGMR_OK;
+}
+
+int cgmr_set_profiling(cgmr_ctx* ctx, int on) {
+  if (!ctx) return CGMR_E_INVALID;
+  ctx->profiling = on != 0;
+  memset(ctx->ksec, 0, sizeof ctx->ksec);
+  memset(ctx->klaunch, 0, sizeof ctx->klaunch);
+  return CGMR_OK;
+}
+
+int cgmr_gn_kernel_times(const cgmr_ctx* ctx, double seconds_out[8], int64_t launches_out[8]) {
+  if (!ctx || !seconds_out || !launches_out) return CGMR_E_INVALID;
+  memcpy(seconds_out, ctx->ksec, sizeof(double) * 8);
+  memcpy(launches_out, ctx->klaunch, sizeof(int64_t) * 8);
+  return CGMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// Internal definition of the opaque context (include/cgmr.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/cgmr.h"
+#include "gn_device.h"
+#include "gn_symbolic.h"
+
+namespace cgmr {
+struct Arena {
+  char* ptr = nullptr;
+  size_t cap = 0;
+};
+}  // namespace cgmr
+
+struct cgmr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  cgmr::Arena gn_arena;     // structure + numeric work space of the last analysed graph
+  cgmr::Arena io_arena;     // staging for the host-pointer entry points
+  cgmr::Arena mt_arena;     // matcher work space
+  char* pinned = nullptr;
+  size_t pinned_cap = 0;
+  cgmr::Symbolic sym;
+  cgmr::GnDevice gn;
+  double timing[5] = {0, 0, 0, 0, 0};
+  bool profiling = false;
+  double ksec[8] = {0};
+  int64_t klaunch[8] = {0};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_a = nullptr, ev_b = nullptr;
+};
+
+namespace cgmr {
+double wall_s();
+int set_err(cgmr_ctx* ctx, int code, const char* fmt, ...);
+int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes);
+int pinned_reserve(cgmr_ctx* ctx, size_t bytes);
+}  // namespace cgmr

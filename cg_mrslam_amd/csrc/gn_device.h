@@ -1,0 +1,39 @@
+// Device-side view of one analysed pose graph (pointers into the context's arena) plus the
+// small host-side copies the launch loop needs.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "gn_symbolic.h"
+
+namespace cgmr {
+
+struct GnDevice {
+  int nV = 0, nE = 0, nf = 0, nb = 0, nlevels = 0, nfronts = 0;
+  // structure (uploaded once per analyse)
+  FrontDesc* fronts = nullptr;
+  int32_t *rows = nullptr, *children = nullptr, *rel = nullptr, *inv = nullptr, *alist = nullptr;
+  int32_t *level_fronts = nullptr, *tiles = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;
+  int32_t *ef = nullptr, *et = nullptr;
+  // numeric work space
+  double *term = nullptr, *Ablk = nullptr, *bvec = nullptr, *yvec = nullptr, *xvec = nullptr, *uvec = nullptr;
+  double *Lbuf = nullptr, *Ubuf = nullptr;
+  double* chi2 = nullptr;   // iters+1 values
+  int* status = nullptr;
+  // host copies
+  std::vector<int32_t> h_level_ptr, h_tile_ptr;
+};
+
+void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const int32_t* ef, const int32_t* et,
+                      const double* meas, const double* info, int chi_only);
+void launch_chi2(hipStream_t st, const GnDevice& D, double* out);
+void launch_assemble(hipStream_t st, const GnDevice& D);
+void launch_factor_level(hipStream_t st, const GnDevice& D, int level, int iter_tag);
+void launch_update_level(hipStream_t st, const GnDevice& D, int level);
+void launch_fwd_level(hipStream_t st, const GnDevice& D, int level);
+void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
+void launch_update(hipStream_t st, const GnDevice& D, double* poses);
+
+}  // namespace cgmr

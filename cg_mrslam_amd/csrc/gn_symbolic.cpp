@@ -1,0 +1,356 @@
+// Host-side symbolic analysis (see gn_symbolic.h).  Plain C++17, no GPU calls, so it is
+// unit-testable on a CPU-only machine through cgmr_gn_symbolic_info().
+#include "gn_symbolic.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+namespace cgmr {
+namespace {
+
+double now_s() {
+  using namespace std::chrono;
+  return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------ nested dissection
+// Recursive bisection by breadth-first level structures: pick the level that splits the
+// subset most evenly among the thin ones, keep only its vertices that touch the next level
+// as the separator.  Output: `order` (position -> block index) with subsets laid out as
+// [part A][part B][separator], and `panel_start`, the positions at which a new front begins
+// (leaves and separators are cut into runs of at most kPanelW columns).
+struct NDCtx {
+  const std::vector<int32_t>& ap;     // adjacency CSR (block indices)
+  const std::vector<int32_t>& ai;
+  std::vector<int32_t>& order;        // in/out working permutation
+  std::vector<int32_t>& panel_start;
+  std::vector<int32_t> label;         // region id a vertex currently belongs to
+  std::vector<int32_t> dist;
+  std::vector<int32_t> queue;
+  std::vector<int32_t> tmp;
+  std::vector<int32_t> lvl_cnt;
+  int next_label = 1;
+};
+
+void emit_panels(NDCtx& C, int begin, int end) {
+  for (int p = begin; p < end; p += kPanelW) C.panel_start.push_back(p);
+}
+
+// BFS restricted to vertices with label == id; returns number reached, fills dist (by vertex)
+// and C.queue[0..reached) in visiting order.
+int bfs(NDCtx& C, int root, int id, int visited_id) {
+  int qh = 0, qt = 0;
+  C.queue[qt++] = root;
+  C.dist[root] = 0;
+  C.label[root] = visited_id;
+  while (qh < qt) {
+    int u = C.queue[qh++];
+    int du = C.dist[u];
+    for (int p = C.ap[u]; p < C.ap[u + 1]; p++) {
+      int w = C.ai[p];
+      if (C.label[w] != id) continue;
+      C.label[w] = visited_id;
+      C.dist[w] = du + 1;
+      C.queue[qt++] = w;
+    }
+  }
+  return qt;
+}
+
+void nd(NDCtx& C, int begin, int end) {
+  int n = end - begin;
+  if (n <= 0) return;
+  if (n <= kPanelW) { emit_panels(C, begin, end); return; }
+  int id = C.next_label++;
+  for (int p = begin; p < end; p++) C.label[C.order[p]] = id;
+  // first sweep: connectivity + a far vertex
+  int vis1 = C.next_label++;
+  int reached = bfs(C, C.order[begin], id, vis1);
+  if (reached < n) {
+    // disconnected: component first, then the rest (independent subtrees, no separator)
+    int k = begin;
+    for (int q = 0; q < reached; q++) C.tmp[k++] = C.queue[q];
+    for (int p = begin; p < end; p++) if (C.label[C.order[p]] == id) C.tmp[k++] = C.order[p];
+    std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
+    nd(C, begin, begin + reached);
+    nd(C, begin + reached, end);
+    return;
+  }
+  int far = C.queue[reached - 1];
+  // second sweep from the far vertex gives the level structure
+  int vis2 = C.next_label++;
+  bfs(C, far, vis1, vis2);
+  int nlev = C.dist[C.queue[n - 1]] + 1;
+  if (nlev <= 2) {  // clique-like: nothing to dissect
+    emit_panels(C, begin, end);
+    return;
+  }
+  if ((int)C.lvl_cnt.size() < nlev + 1) C.lvl_cnt.resize(nlev + 1);
+  std::fill(C.lvl_cnt.begin(), C.lvl_cnt.begin() + nlev + 1, 0);
+  for (int q = 0; q < n; q++) C.lvl_cnt[C.dist[C.queue[q]]]++;
+  // choose the separator level
+  int best = -1, best_sz = 1 << 30, fallback = 1, fb_bal = -1;
+  int cum = C.lvl_cnt[0];
+  for (int j = 1; j <= nlev - 2; j++) {
+    int a = cum, b = n - cum - C.lvl_cnt[j];
+    int bal = std::min(a, b);
+    if (bal > fb_bal) { fb_bal = bal; fallback = j; }
+    if (bal * 10 >= n * 3 && C.lvl_cnt[j] < best_sz) { best_sz = C.lvl_cnt[j]; best = j; }
+    cum += C.lvl_cnt[j];
+  }
+  int js = best >= 0 ? best : fallback;
+  // partition queue order into A (levels < js, plus level-js vertices not touching js+1), B, S
+  int na = 0, nb = 0, nsep = 0;
+  for (int q = 0; q < n; q++) {
+    int v = C.queue[q];
+    int d = C.dist[v];
+    if (d < js) na++;
+    else if (d > js) nb++;
+    else {
+      bool touches = false;
+      for (int p = C.ap[v]; p < C.ap[v + 1] && !touches; p++) {
+        int w = C.ai[p];
+        if (C.label[w] == vis2 && C.dist[w] == js + 1) touches = true;
+      }
+      if (touches) nsep++; else { na++; C.dist[v] = js - 1; }   // demote into A
+    }
+  }
+  int pa = begin, pb = begin + na, ps = begin + na + nb;
+  for (int q = 0; q < n; q++) {
+    int v = C.queue[q];
+    int d = C.dist[v];
+    if (d < js) C.tmp[pa++] = v;
+    else if (d > js) C.tmp[pb++] = v;
+    else C.tmp[ps++] = v;
+  }
+  std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
+  nd(C, begin, begin + na);
+  nd(C, begin + na, begin + na + nb);
+  emit_panels(C, begin + na + nb, end);
+}
+
+}  // namespace
+
+int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S) {
+  double t0 = now_s();
+  S = Symbolic();
+  S.nV = nV;
+  S.nE = nE;
+  for (int k = 0; k < nE; k++)
+    if (ef[k] < 0 || ef[k] >= nV || et[k] < 0 || et[k] >= nV) return -1;
+  // active free vertices
+  std::vector<uint8_t> active(nV, 0);
+  for (int k = 0; k < nE; k++) { active[ef[k]] = 1; active[et[k]] = 1; }
+  S.hidx.assign(nV, -1);
+  int nf = 0;
+  for (int v = 0; v < nV; v++) if (active[v] && !fixed[v]) S.hidx[v] = nf++;
+  S.nf = nf;
+  S.vperm.assign(nV, -1);
+  if (nf == 0) { S.level_ptr.assign(1, 0); return 0; }
+  // adjacency CSR over block indices (deduplicated, sorted)
+  std::vector<int32_t> ap(nf + 1, 0), ai;
+  for (int k = 0; k < nE; k++) {
+    int a = S.hidx[ef[k]], b = S.hidx[et[k]];
+    if (a < 0 || b < 0 || a == b) continue;
+    ap[a + 1]++; ap[b + 1]++;
+  }
+  for (int v = 0; v < nf; v++) ap[v + 1] += ap[v];
+  ai.resize(ap[nf]);
+  {
+    std::vector<int32_t> pos(ap.begin(), ap.end() - 1);
+    for (int k = 0; k < nE; k++) {
+      int a = S.hidx[ef[k]], b = S.hidx[et[k]];
+      if (a < 0 || b < 0 || a == b) continue;
+      ai[pos[a]++] = b; ai[pos[b]++] = a;
+    }
+    // sort + dedupe each row, compact in place
+    int w = 0;
+    for (int v = 0; v < nf; v++) {
+      int b = ap[v], e = ap[v + 1];
+      std::sort(ai.begin() + b, ai.begin() + e);
+      int start = w;
+      for (int p = b; p < e; p++) if (p == b || ai[p] != ai[p - 1]) ai[w++] = ai[p];
+      ap[v] = start;
+    }
+    ap[nf] = w;
+    ai.resize(w);
+  }
+  // nested dissection
+  std::vector<int32_t> order(nf), panel_start;
+  for (int v = 0; v < nf; v++) order[v] = v;
+  {
+    NDCtx C{ap, ai, order, panel_start, {}, {}, {}, {}, {}, 1};
+    C.label.assign(nf, 0);
+    C.dist.assign(nf, 0);
+    C.queue.assign(nf, 0);
+    C.tmp.assign(nf, 0);
+    nd(C, 0, nf);
+  }
+  std::sort(panel_start.begin(), panel_start.end());
+  std::vector<int32_t> iperm(nf);
+  for (int p = 0; p < nf; p++) iperm[order[p]] = p;
+  S.perm.assign(nf, -1);
+  for (int v = 0; v < nV; v++) if (S.hidx[v] >= 0) { S.vperm[v] = iperm[S.hidx[v]]; S.perm[S.vperm[v]] = v; }
+  S.t_order = now_s() - t0;
+  double t1 = now_s();
+
+  // adjacency in permuted indices, rows sorted
+  std::vector<int32_t> cp(nf + 1, 0), ci(ai.size());
+  for (int c = 0; c < nf; c++) cp[c + 1] = cp[c] + (ap[order[c] + 1] - ap[order[c]]);
+  for (int c = 0; c < nf; c++) {
+    int o = order[c], w = cp[c];
+    for (int p = ap[o]; p < ap[o + 1]; p++) ci[w++] = iperm[ai[p]];
+    std::sort(ci.begin() + cp[c], ci.begin() + cp[c + 1]);
+  }
+  // unique lower off-diagonal blocks: enumerate (c, r>c) column-major
+  std::vector<int32_t> offbase(nf + 1, 0);
+  for (int c = 0; c < nf; c++) {
+    int cnt = 0;
+    for (int p = cp[c]; p < cp[c + 1]; p++) if (ci[p] > c) cnt++;
+    offbase[c + 1] = offbase[c] + cnt;
+  }
+  S.nb = offbase[nf];
+  S.off_row.resize(S.nb);
+  S.off_col.resize(S.nb);
+  for (int c = 0; c < nf; c++) {
+    int k = offbase[c];
+    for (int p = cp[c]; p < cp[c + 1]; p++) if (ci[p] > c) { S.off_row[k] = ci[p]; S.off_col[k] = c; k++; }
+  }
+  auto off_id = [&](int r, int c) {   // r > c
+    int lo = cp[c], hi = cp[c + 1];
+    int first_gt = std::upper_bound(ci.begin() + lo, ci.begin() + hi, c) - ci.begin();
+    int pos = std::lower_bound(ci.begin() + first_gt, ci.begin() + hi, r) - ci.begin();
+    return offbase[c] + (pos - first_gt);
+  };
+  // assembly CSR: block -> contributing edge terms
+  S.asm_ptr.assign(nf + S.nb + 1, 0);
+  std::vector<int32_t> e_off(nE, -1);
+  for (int k = 0; k < nE; k++) {
+    int a = S.vperm[ef[k]], b = S.vperm[et[k]];
+    if (a >= 0) S.asm_ptr[a + 1]++;
+    if (b >= 0 && !(a == b && a >= 0)) S.asm_ptr[b + 1]++;
+    if (a >= 0 && b >= 0 && a != b) {
+      int id = a > b ? off_id(a, b) : off_id(b, a);
+      e_off[k] = id;
+      S.asm_ptr[nf + id + 1]++;
+    }
+  }
+  for (int q = 0; q < nf + S.nb; q++) S.asm_ptr[q + 1] += S.asm_ptr[q];
+  S.asm_src.resize(S.asm_ptr[nf + S.nb]);
+  {
+    std::vector<int32_t> pos(S.asm_ptr.begin(), S.asm_ptr.end() - 1);
+    for (int k = 0; k < nE; k++) {
+      int a = S.vperm[ef[k]], b = S.vperm[et[k]];
+      if (a >= 0) S.asm_src[pos[a]++] = 4 * k + 0;
+      if (b >= 0 && !(a == b && a >= 0)) S.asm_src[pos[b]++] = 4 * k + 1;
+      if (e_off[k] >= 0) S.asm_src[pos[nf + e_off[k]]++] = 4 * k + (a > b ? 2 : 3);
+      // a > b: lower block (row a = i, col b = j) is Hij as is; else (row b = j, col a = i) = Hij^T
+    }
+  }
+  // fronts
+  int nfr = (int)panel_start.size();
+  S.fronts.assign(nfr, FrontDesc());
+  S.col_front.assign(nf, 0);
+  for (int f = 0; f < nfr; f++) {
+    int c0 = panel_start[f], c1 = (f + 1 < nfr) ? panel_start[f + 1] : nf;
+    S.fronts[f].c0 = c0;
+    S.fronts[f].nc = c1 - c0;
+    S.fronts[f].parent = -1;
+    S.fronts[f].level = 0;
+    for (int c = c0; c < c1; c++) S.col_front[c] = f;
+  }
+  // border structure, bottom-up (children always have smaller ids than parents)
+  std::vector<int32_t> stamp(nf, -1);
+  std::vector<std::vector<int32_t>> kids(nfr);
+  S.rows.clear();
+  std::vector<int32_t> list;
+  for (int f = 0; f < nfr; f++) {
+    FrontDesc& F = S.fronts[f];
+    int last = F.c0 + F.nc - 1;
+    list.clear();
+    for (int c = F.c0; c <= last; c++)
+      for (int p = cp[c + 1] - 1; p >= cp[c] && ci[p] > last; p--)
+        if (stamp[ci[p]] != f) { stamp[ci[p]] = f; list.push_back(ci[p]); }
+    for (int ch : kids[f]) {
+      const FrontDesc& G = S.fronts[ch];
+      for (int q = 0; q < G.ns; q++) {
+        int r = S.rows[G.rows_off + q];
+        if (r > last && stamp[r] != f) { stamp[r] = f; list.push_back(r); }
+      }
+    }
+    std::sort(list.begin(), list.end());
+    F.rows_off = (int)S.rows.size();
+    F.ns = (int)list.size();
+    S.rows.insert(S.rows.end(), list.begin(), list.end());
+    if (F.ns > 0) {
+      int p = S.col_front[list[0]];
+      F.parent = p;
+      kids[p].push_back(f);
+      S.fronts[p].level = std::max(S.fronts[p].level, F.level + 1);
+    }
+    S.max_ns = std::max(S.max_ns, F.ns);
+  }
+  // children lists, rel / inv maps, A lists, offsets
+  std::vector<int32_t> posmap(nf, -1);
+  int64_t Loff = 0, Uoff = 0;
+  double flops = 0;
+  for (int f = 0; f < nfr; f++) {
+    FrontDesc& F = S.fronts[f];
+    F.child_off = (int)S.children.size();
+    F.nchild = (int)kids[f].size();
+    S.children.insert(S.children.end(), kids[f].begin(), kids[f].end());
+    for (int q = 0; q < F.ns; q++) posmap[S.rows[F.rows_off + q]] = q;
+    // maps of each child into this front
+    for (int ch : kids[f]) {
+      FrontDesc& G = S.fronts[ch];
+      G.rel_off = (int)S.rel.size();
+      G.inv_off = (int)S.inv.size();
+      S.inv.resize(S.inv.size() + F.ns, -1);
+      int na = 0;
+      for (int q = 0; q < G.ns; q++) {
+        int r = S.rows[G.rows_off + q];
+        if (r < F.c0 + F.nc) { S.rel.push_back(r - F.c0); na++; }
+        else { int p = posmap[r]; S.rel.push_back(F.nc + p); S.inv[G.inv_off + p] = q; }
+      }
+      G.na = na;
+    }
+    // A blocks of this front's columns
+    F.a_off = (int)S.alist.size() / 3;
+    for (int c = F.c0; c < F.c0 + F.nc; c++) {
+      int lc = c - F.c0;
+      S.alist.push_back(c); S.alist.push_back(lc); S.alist.push_back(lc);
+      int k = offbase[c];
+      for (int p = cp[c]; p < cp[c + 1]; p++) {
+        int r = ci[p];
+        if (r <= c) continue;
+        int lr = (r < F.c0 + F.nc) ? r - F.c0 : F.nc + posmap[r];
+        S.alist.push_back(nf + k); S.alist.push_back(lr); S.alist.push_back(lc);
+        k++;
+      }
+    }
+    F.a_cnt = (int)S.alist.size() / 3 - F.a_off;
+    int64_t w = 3 * (int64_t)F.nc, r = 3 * (int64_t)F.ns;
+    F.L_off = Loff; Loff += w * w + r * w;
+    F.U_off = Uoff; Uoff += r * r;
+    flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
+  }
+  S.L_doubles = Loff;
+  S.U_doubles = Uoff;
+  S.flops = flops;
+  // levels
+  int nlev = 0;
+  for (const FrontDesc& F : S.fronts) nlev = std::max(nlev, F.level + 1);
+  S.level_ptr.assign(nlev + 1, 0);
+  for (const FrontDesc& F : S.fronts) S.level_ptr[F.level + 1]++;
+  for (int l = 0; l < nlev; l++) S.level_ptr[l + 1] += S.level_ptr[l];
+  S.level_fronts.resize(nfr);
+  {
+    std::vector<int32_t> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
+    for (int f = 0; f < nfr; f++) S.level_fronts[pos[S.fronts[f].level]++] = f;
+  }
+  S.t_struct = now_s() - t1;
+  return 0;
+}
+
+}  // namespace cgmr

@@ -1,0 +1,67 @@
+// Host-side symbolic analysis for the supernodal multifrontal Cholesky that solves
+// the Gauss-Newton normal equations of an SE2 pose graph on the GPU.
+//
+// What g2o does for this step ([g2o-recalled]): BlockSolver::buildStructure
+// allocates the block pattern of Hpp and LinearSolverCSparse runs cs_schol (AMD ordering +
+// elimination tree + column counts) once per optimize() call
+// (reference call sites: src/slam/graph_slam.cpp:564-565, src/slam/graph_manipulator.cpp:117-123).
+// This module is the MI355X-native counterpart: it produces a nested-dissection ordering
+// whose elimination tree is short and wide (the GPU pays per tree level, not per flop),
+// groups columns into dense "fronts" of at most CGMR_PANEL_W poses, and emits flat index
+// arrays that the HIP kernels consume without any pointer chasing.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace cgmr {
+
+constexpr int kPanelW = 16;          // max poses (block columns) per front -> 48 scalar columns
+
+struct FrontDesc {                   // one per front, uploaded verbatim (all int32 / int64)
+  int32_t c0;         // first block column (permuted order)
+  int32_t nc;         // block columns owned by this front (<= kPanelW)
+  int32_t ns;         // block rows in the border ("struct") = rows of L21 / 3
+  int32_t rows_off;   // offset into rows[] of the ns border block rows (permuted indices, ascending)
+  int32_t parent;     // front id of the etree parent or -1
+  int32_t level;      // 0 = no children
+  int32_t child_off;  // offset into children[]
+  int32_t nchild;
+  int32_t rel_off;    // offset into rel[]: for k in [0,ns): position of border row k in the parent's row list
+                      //   (0..nc_p-1 = parent's own columns, nc_p.. = parent's border), block units
+  int32_t na;         // number of leading border rows that fall into the parent's own columns
+  int32_t inv_off;    // offset into inv[]: ns_parent entries, inv[p] = k such that rel[k]-nc_p == p, or -1
+  int32_t a_off;      // offset into alist[] (triples) of the A blocks assembled by this front
+  int32_t a_cnt;
+  int32_t pad;
+  int64_t L_off;      // offset (doubles) of this front's factor panel: L11 (w*w) then L21 (r*w), row-major
+  int64_t U_off;      // offset (doubles) of this front's update matrix (r*r, row-major, lower part valid)
+};
+
+struct Symbolic {
+  int nV = 0, nE = 0;
+  int nf = 0;                          // free active poses = block dimension of H
+  int nb = 0;                          // unique off-diagonal blocks of H (lower triangle)
+  std::vector<int32_t> hidx;           // vertex -> block index before permutation, -1 fixed/inactive
+  std::vector<int32_t> vperm;          // vertex -> permuted block column, -1 fixed/inactive
+  std::vector<int32_t> perm;           // permuted block column -> vertex index
+  // assembly of H blocks from edge terms (CSR over nf diagonal blocks then nb off-diagonal blocks)
+  std::vector<int32_t> asm_ptr;        // nf+nb+1
+  std::vector<int32_t> asm_src;        // edge*4 + code (0: Hii, 1: Hjj, 2: Hij, 3: Hij^T)
+  std::vector<int32_t> off_row, off_col;  // per off-diagonal block: permuted row > col
+  // fronts
+  std::vector<FrontDesc> fronts;
+  std::vector<int32_t> rows, children, rel, inv;
+  std::vector<int32_t> alist;          // triples (block id [0..nf) diag / nf+k offdiag, local row block, local col block)
+  std::vector<int32_t> level_ptr;      // nlevels+1, fronts sorted by level in level_fronts
+  std::vector<int32_t> level_fronts;
+  std::vector<int32_t> col_front;      // permuted block column -> owning front
+  int64_t L_doubles = 0, U_doubles = 0;
+  int max_ns = 0;
+  double flops = 0;                    // factorisation flops (dense fronts)
+  double t_order = 0, t_struct = 0;    // seconds spent in ordering / structure
+};
+
+// Builds everything above.  Returns 0, or a negative error (-1 bad index).
+int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S);
+
+}  // namespace cgmr
