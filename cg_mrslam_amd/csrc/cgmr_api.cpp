@@ -72,16 +72,22 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.nlevels = (int)S.level_ptr.size() - 1;
   D.h_level_ptr = S.level_ptr;
   // update tiles per level
-  std::vector<int32_t> tiles;
+  std::vector<int32_t> tiles, work;
   D.h_tile_ptr.assign(D.nlevels + 1, 0);
+  D.h_work_ptr.assign(D.nlevels + 1, 0);
   for (int l = 0; l < D.nlevels; l++) {
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
       int f = S.level_fronts[q];
-      int T = (3 * S.fronts[f].ns + 31) / 32;
+      int r = 3 * S.fronts[f].ns;
+      int nchunk = std::max(1, (r + kChunkRows - 1) / kChunkRows);
+      for (int c = 0; c < nchunk; c++) { work.push_back(f); work.push_back(c); }
+      if (r <= kFuseRows) continue;          // update matrix formed inside k_front_factor
+      int T = (r + 31) / 32;
       for (int ti = 0; ti < T; ti++)
         for (int tj = 0; tj <= ti; tj++) { tiles.push_back(f); tiles.push_back(ti); tiles.push_back(tj); }
     }
     D.h_tile_ptr[l + 1] = (int)tiles.size() / 3;
+    D.h_work_ptr[l + 1] = (int)work.size() / 2;
   }
   BlobLayout B;
   size_t o_fronts = B.add<FrontDesc>(S.fronts.size());
@@ -92,6 +98,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_alist = B.add<int32_t>(S.alist.size());
   size_t o_lf = B.add<int32_t>(S.level_fronts.size());
   size_t o_tiles = B.add<int32_t>(tiles.size());
+  size_t o_work = B.add<int32_t>(work.size());
   size_t o_asmp = B.add<int32_t>(S.asm_ptr.size());
   size_t o_asms = B.add<int32_t>(S.asm_src.size());
   size_t o_vperm = B.add<int32_t>(S.vperm.size());
@@ -126,6 +133,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   put(o_alist, S.alist.data(), S.alist.size() * 4);
   put(o_lf, S.level_fronts.data(), S.level_fronts.size() * 4);
   put(o_tiles, tiles.data(), tiles.size() * 4);
+  put(o_work, work.data(), work.size() * 4);
   put(o_asmp, S.asm_ptr.data(), S.asm_ptr.size() * 4);
   put(o_asms, S.asm_src.data(), S.asm_src.size() * 4);
   put(o_vperm, S.vperm.data(), S.vperm.size() * 4);
@@ -141,6 +149,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.alist = (int32_t*)(d + o_alist);
   D.level_fronts = (int32_t*)(d + o_lf);
   D.tiles = (int32_t*)(d + o_tiles);
+  D.work = (int32_t*)(d + o_work);
   D.asm_ptr = (int32_t*)(d + o_asmp);
   D.asm_src = (int32_t*)(d + o_asms);
   D.vperm = (int32_t*)(d + o_vperm);
@@ -165,12 +174,12 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
   template <typename Fn>
   void run(int cls, int nlaunch, Fn&& fn) {
     if (!ctx->profiling) { fn(); return; }
-    hipEventRecord(ctx->ev_a, ctx->stream);
+    (void)hipEventRecord(ctx->ev_a, ctx->stream);
     fn();
-    hipEventRecord(ctx->ev_b, ctx->stream);
-    hipEventSynchronize(ctx->ev_b);
+    (void)hipEventRecord(ctx->ev_b, ctx->stream);
+    (void)hipEventSynchronize(ctx->ev_b);
     float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+    (void)hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
     ctx->ksec[cls] += 1e-3 * ms;
     ctx->klaunch[cls] += nlaunch;
   }

@@ -15,7 +15,7 @@ struct GnDevice {
   // structure (uploaded once per analyse)
   FrontDesc* fronts = nullptr;
   int32_t *rows = nullptr, *children = nullptr, *rel = nullptr, *inv = nullptr, *alist = nullptr;
-  int32_t *level_fronts = nullptr, *tiles = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;
+  int32_t *level_fronts = nullptr, *tiles = nullptr, *work = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;
   int32_t *ef = nullptr, *et = nullptr;
   // numeric work space
   double *term = nullptr, *Ablk = nullptr, *bvec = nullptr, *yvec = nullptr, *xvec = nullptr, *uvec = nullptr;
@@ -23,7 +23,7 @@ struct GnDevice {
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
   // host copies
-  std::vector<int32_t> h_level_ptr, h_tile_ptr;
+  std::vector<int32_t> h_level_ptr, h_tile_ptr, h_work_ptr;
 };
 
 void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const int32_t* ef, const int32_t* et,

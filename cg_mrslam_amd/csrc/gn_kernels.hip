@@ -158,132 +158,349 @@ __global__ __launch_bounds__(1024) void k_chi2_reduce(int nE, const double* __re
 }
 
 // ------------------------------------------------------------------------- front factorise
-// One workgroup per front of the current level:
-//   1. assemble F11 (own columns) in LDS from the H blocks and the children's update
-//      matrices, zero/identity padded to 48x48;
-//   2. dense Cholesky F11 = L11 L11^T in LDS; a non-positive pivot records the GN iteration
-//      in *status (first failure wins) -- the update kernel then leaves the poses alone,
-//      which is g2o's "return on Cholesky failure";
-//   3. for each chunk of border rows: assemble F21 rows in LDS, L21 = F21 L11^-T (one
-//      thread per row), store.
+// Factor panel layout in Lbuf (doubles, all strides padded to W = 48 columns):
+//   [0, W*W)        L11 row-major   (lower triangle, zeros above)      -> backward solve
+//   [W*W, 2*W*W)    L11 column-major                                   -> forward solve
+//   [2*W*W, +W)     1 / diag(L11)
+//   [2*W*W+W, ...)  L21, r rows of W
+constexpr int kL11c = W * W;
+constexpr int kDinv = 2 * W * W;
+constexpr int kL21 = 2 * W * W + W;
+constexpr int FUSE_R = 96;
+#ifdef CGMR_PHASE_TIMING
+__device__ unsigned long long g_phase[64 * 8];
+#define PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PHASE(i)
+#endif           // fronts with r <= FUSE_R compute their update matrix in the factor kernel
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no FP64 divide / sqrt
+// expansion on the pivot chain, which is the critical path of the whole factorisation).
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+}
+
+constexpr int MAXC = 8;              // children whose maps are staged together
+// LDS plan of k_front_factor (bytes), one workgroup per CU:
+//   R    [CH][LDW] doubles   chunk of F21 / L21 rows
+//   Ls   [W][LDW]  doubles   F11, then L11 row-major          \
+//   LsT  [W][W]    doubles   L11 column-major (16-B aligned)   > reused as Uacc[FUSE_R][FUSE_R+1]
+//   pad                                                        /   by the fused update (phase D)
+//   lists: s_pos[FUSE_R+W] shorts (phase D), s_colinv[MAXC][W], s_src[MAXC][CH] shorts (phase A)
+constexpr int kOffR = 0;
+constexpr int kOffLs = kOffR + CH * LDW * 8;
+constexpr int kOffLsT = ((kOffLs + W * LDW * 8 + 15) / 16) * 16;
+constexpr int kUaccBytes = FUSE_R * (FUSE_R + 1) * 8;
+constexpr int kOffLists = kOffLs + (kUaccBytes > (kOffLsT - kOffLs) + W * W * 8 ? kUaccBytes : (kOffLsT - kOffLs) + W * W * 8);
+constexpr int kOffColinv = kOffLists + 2 * (W + FUSE_R);
+constexpr int kOffSrc = kOffColinv + 2 * MAXC * W;
+constexpr int kOffDinv = ((kOffSrc + 2 * MAXC * CH + 15) / 16) * 16;
+constexpr int kSmemBytes = kOffDinv + W * 8;
+static_assert(kSmemBytes <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
+
+// One workgroup per (front, chunk of CH border rows) of the current level:
+//   A. all threads assemble F11 (own columns, zero/identity padded to 48x48) and this chunk's
+//      rows of F21 in LDS from the H blocks and the children's update matrices.  For each
+//      child a (source row -> destination row) list is staged in LDS first, so the update
+//      matrix is then read as independent, coalesced row segments (8 loads in flight per lane);
+//   B. wavefront 0 factorises F11 = L11 L11^T entirely in registers (lane i owns row i; the
+//      pivot column is broadcast with v_readlane, no barriers).  A non-positive pivot
+//      records the GN iteration in *status (first failure wins); the pose update kernel
+//      then leaves the poses alone, which is g2o's "return on Cholesky failure";
+//   C. L21 = F21 L11^-T, one thread per border row held in registers, right-looking with the
+//      next pivot column prefetched from LDS while the current one is applied;
+//   D. small fronts (r <= FUSE_R) also form their update matrix U = ext_add - L21 L21^T:
+//      the children's trailing blocks are streamed into an LDS accumulator, then 4x4 register
+//      tiles subtract L21 L21^T and store.
 __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restrict__ fronts,
-                                                      const int32_t* __restrict__ level_fronts, int level_begin,
-                                                      const int32_t* __restrict__ children,
-                                                      const int32_t* __restrict__ rel, const int32_t* __restrict__ inv,
-                                                      const int32_t* __restrict__ alist, int nf,
-                                                      const double* __restrict__ Ablk, double* __restrict__ Lbuf,
-                                                      const double* __restrict__ Ubuf, int* __restrict__ status,
-                                                      int iter_tag) {
-  __shared__ double F11[W * LDW];
-  __shared__ double R[CH * LDW];
+                                                         const int32_t* __restrict__ work, int work_begin,
+                                                         const int32_t* __restrict__ children,
+                                                         const int32_t* __restrict__ rel,
+                                                         const int32_t* __restrict__ inv,
+                                                         const int32_t* __restrict__ alist,
+                                                         const double* __restrict__ Ablk, double* __restrict__ Lbuf,
+                                                         double* __restrict__ Ubuf, int* __restrict__ status,
+                                                         int iter_tag, int level_id) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* R = reinterpret_cast<double*>(smem + kOffR);
+  double* Ls = reinterpret_cast<double*>(smem + kOffLs);
+  double* LsT = reinterpret_cast<double*>(smem + kOffLsT);
+  double* Uacc = reinterpret_cast<double*>(smem + kOffLs);
+  short* s_pos = reinterpret_cast<short*>(smem + kOffLists);
+  short* s_colinv = reinterpret_cast<short*>(smem + kOffColinv);
+  short* s_src = reinterpret_cast<short*>(smem + kOffSrc);
+  double* Dinv = reinterpret_cast<double*>(smem + kOffDinv);
   const int tid = threadIdx.x;
-  const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
+  const int32_t* wk = work + 2 * (size_t)(work_begin + blockIdx.x);
+  const FrontDesc F = fronts[wk[0]];
+  const int chunk = wk[1];
   const int w = 3 * F.nc, r = 3 * F.ns;
-  // ---- 1. F11
+  const int r0 = chunk * CH;
+  const int nr = max(0, min(CH, r - r0));
+  PHASE(0);
+  // ---- A1. F11 (all threads): H blocks + leading blocks of the children's update matrices
   for (int q = tid; q < W * LDW; q += 256) {
     int i = q / LDW, j = q - i * LDW;
-    F11[q] = (i == j && i >= w) ? 1.0 : 0.0;
+    Ls[q] = (i == j && i >= w) ? 1.0 : 0.0;
   }
+  for (int q = tid; q < nr * LDW; q += 256) R[q] = 0.0;
   __syncthreads();
   for (int q = tid; q < F.a_cnt * 9; q += 256) {
     int a = q / 9, el = q - 9 * a;
     const int32_t* tr = alist + 3 * (size_t)(F.a_off + a);
     int lr = tr[1], lc = tr[2];
-    if (lr < F.nc) F11[(3 * lr + el / 3) * LDW + 3 * lc + el % 3] = Ablk[(size_t)tr[0] * 9 + el];
-  }
-  __syncthreads();
-  for (int ci = 0; ci < F.nchild; ci++) {
-    const FrontDesc G = fronts[children[F.child_off + ci]];
-    const int32_t* grel = rel + G.rel_off;
-    const double* U = Ubuf + G.U_off;
-    const int rg = 3 * G.ns, ra = 3 * G.na;
-    // lower part of the leading ra x ra block of U_child lands in F11
-    for (int q = tid; q < ra * ra; q += 256) {
-      int i = q / ra, j = q - i * ra;
-      if (j > i) continue;
-      int pi = 3 * grel[i / 3] + i % 3, pj = 3 * grel[j / 3] + j % 3;
-      F11[pi * LDW + pj] += U[(size_t)i * rg + j];
-    }
-    __syncthreads();
-  }
-  // ---- 2. Cholesky (right-looking, lower triangle)
-  for (int j = 0; j < W; j++) {
-    if (tid == 0) {
-      double d = F11[j * LDW + j];
-      if (!(d > 0.0)) { atomicCAS(status, 0, iter_tag); d = 1.0; }
-      F11[j * LDW + j] = sqrt(d);
-    }
-    __syncthreads();
-    double djj = F11[j * LDW + j];
-    for (int i = j + 1 + tid; i < W; i += 256) F11[i * LDW + j] /= djj;
-    __syncthreads();
-    int m = W - j - 1;
-    for (int q = tid; q < m * m; q += 256) {
-      int a = q / m, b = q - a * m;
-      if (b > a) continue;
-      int i = j + 1 + a, k = j + 1 + b;
-      F11[i * LDW + k] -= F11[i * LDW + j] * F11[k * LDW + j];
-    }
-    __syncthreads();
-  }
-  double* L11 = Lbuf + F.L_off;
-  for (int q = tid; q < w * w; q += 256) {
-    int i = q / w, j = q - i * w;
-    L11[q] = (j <= i) ? F11[i * LDW + j] : 0.0;
-  }
-  // ---- 3. border rows in chunks
-  double* L21 = L11 + (size_t)w * w;
-  for (int r0 = 0; r0 < r; r0 += CH) {
-    int nr = min(CH, r - r0);
-    __syncthreads();
-    for (int q = tid; q < nr * LDW; q += 256) R[q] = 0.0;
-    __syncthreads();
-    for (int q = tid; q < F.a_cnt * 9; q += 256) {
-      int a = q / 9, el = q - 9 * a;
-      const int32_t* tr = alist + 3 * (size_t)(F.a_off + a);
-      int lr = tr[1], lc = tr[2];
+    double v = Ablk[(size_t)tr[0] * 9 + el];
+    if (lr < F.nc) Ls[(3 * lr + el / 3) * LDW + 3 * lc + el % 3] = v;
+    else {
       int row = 3 * (lr - F.nc) + el / 3 - r0;
-      if (lr >= F.nc && row >= 0 && row < nr) R[row * LDW + 3 * lc + el % 3] = Ablk[(size_t)tr[0] * 9 + el];
+      if (row >= 0 && row < nr) R[row * LDW + 3 * lc + el % 3] = v;
+    }
+  }
+  // Children in batches of MAXC.  Per batch the child->parent maps are staged in LDS as *inverse*
+  // maps (parent column -> child column, chunk row -> child row), so that every target cell is
+  // owned by one thread which sums the children in a fixed order: no barriers between children,
+  // no read-modify-write races, bit-reproducible.  In the last batch wavefront 0 goes on to the
+  // Cholesky as soon as F11 is complete while wavefronts 1-3 finish this chunk's F21 rows.
+  const int nbatch = max(1, (F.nchild + MAXC - 1) / MAXC);
+  for (int bt = 0; bt < nbatch; bt++) {
+    const int c0 = bt * MAXC;
+    const int ncb = max(0, min(MAXC, F.nchild - c0));
+    __syncthreads();
+    for (int q = tid; q < ncb * W; q += 256) s_colinv[q] = -1;
+    __syncthreads();
+    for (int c = 0; c < ncb; c++) {
+      const FrontDesc G = fronts[children[F.child_off + c0 + c]];
+      const int ra = 3 * G.na;
+      if (tid < ra) s_colinv[c * W + 3 * rel[G.rel_off + tid / 3] + tid % 3] = (short)tid;
+      for (int t = tid; t < nr; t += 256) {
+        int pr = r0 + t;
+        int kb = inv[G.inv_off + pr / 3];
+        s_src[c * CH + t] = (short)(kb < 0 ? -1 : 3 * kb + pr % 3);
+      }
     }
     __syncthreads();
-    for (int ci = 0; ci < F.nchild; ci++) {
-      const FrontDesc G = fronts[children[F.child_off + ci]];
-      const int32_t* grel = rel + G.rel_off;
-      const int32_t* ginv = inv + G.inv_off;
-      const double* U = Ubuf + G.U_off;
-      const int rg = 3 * G.ns, ra = 3 * G.na;
-      if (ra > 0) {
-        for (int q = tid; q < nr * ra; q += 256) {
-          int row = q / ra, j = q - row * ra;
-          int p = r0 + row;                    // scalar border row of this front
-          int kb = ginv[p / 3];
-          if (kb < 0) continue;
-          int i = 3 * kb + p % 3;              // scalar row in the child's update matrix
-          int pj = 3 * grel[j / 3] + j % 3;
-          R[row * LDW + pj] += U[(size_t)i * rg + j];
+    // F11 cells (lower triangle), all threads
+    for (int q = tid; q < W * W; q += 256) {
+      int pi = q / W, pj = q - pi * W;
+      if (pj > pi) continue;
+      double acc = 0.0;
+      bool any = false;
+      for (int c = 0; c < ncb; c++) {
+        int i = s_colinv[c * W + pi], j = s_colinv[c * W + pj];
+        if (i >= 0 && j >= 0) {
+          const FrontDesc G = fronts[children[F.child_off + c0 + c]];
+          acc += Ubuf[G.U_off + (size_t)i * (3 * G.ns) + j];
+          any = true;
         }
       }
-      __syncthreads();
+      if (any) Ls[pi * LDW + pj] += acc;
     }
-    // L21 row = F21 row * L11^-T : forward substitution along the row
-    if (tid < nr) {
-      double* x = R + tid * LDW;
-      for (int j = 0; j < w; j++) {
-        double acc = x[j];
-        for (int k = 0; k < j; k++) acc -= x[k] * F11[j * LDW + k];
-        x[j] = acc / F11[j * LDW + j];
+    __syncthreads();
+    const bool last = (bt == nbatch - 1);
+    if (tid >= 64) {
+      // F21 rows of this chunk: thread owns parent column pc and rows n = rgp, rgp+4, ...
+      const int t2 = tid - 64;
+      const int pc = t2 % W, rgp = t2 / W;
+      for (int c = 0; c < ncb; c++) {
+        const int j = s_colinv[c * W + pc];
+        if (j < 0) continue;
+        const FrontDesc G = fronts[children[F.child_off + c0 + c]];
+        const double* U = Ubuf + G.U_off;
+        const int rg = 3 * G.ns;
+        const short* src = s_src + c * CH;
+        for (int base = rgp; base < nr; base += 32) {
+          double v[8];
+          int dst[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            int n = base + 4 * u;
+            int sr = (n < nr) ? src[n] : -1;
+            v[u] = (sr >= 0) ? U[(size_t)sr * rg + j] : 0.0;
+            dst[u] = (sr >= 0) ? n : -1;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (dst[u] >= 0) R[dst[u] * LDW + pc] += v[u];
+        }
+      }
+    } else if (last) {
+      PHASE(1);
+      // ---- B. blocked left-looking Cholesky on wavefront 0: lane i owns row i of F11 (in LDS);
+      // an 8-column panel lives in registers, earlier columns are applied with readlane broadcasts.
+      const int lane = tid;
+      const int lrow = min(lane, W - 1);
+      double* myrow = Ls + lrow * LDW;
+      double mydinv = 1.0;
+      int fail = 0;
+      for (int c = 0; c < W; c += 8) {
+        if (c >= w) break;
+        double pq[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) pq[q] = myrow[c + q];
+        double lit_next = myrow[0];
+        for (int t = 0; t < c; t++) {
+          double lit = lit_next;
+          lit_next = myrow[t + 1];
+#pragma unroll
+          for (int q = 0; q < 8; q++) pq[q] = fma(-lit, readlane_f64(lit, c + q), pq[q]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+          const int j = c + jj;
+          double d = readlane_f64(pq[jj], j);
+          if (!(d > 0.0)) { fail = 1; d = 1.0; }
+          double y = rsqrt_nr(d);
+          double lij = (lane == j) ? d * y : pq[jj] * y;
+          pq[jj] = lij;
+          if (lane == j) mydinv = y;
+#pragma unroll
+          for (int q = jj + 1; q < 8; q++) pq[q] = fma(-lij, readlane_f64(lij, c + q), pq[q]);
+        }
+        if (lane < W) {
+#pragma unroll
+          for (int q = 0; q < 8; q++) myrow[c + q] = (c + q <= lane) ? pq[q] : 0.0;
+        }
+      }
+      if (fail && lane == 0) atomicCAS(status, 0, iter_tag);
+      if (lane < W) {
+        for (int k = 0; k < W; k++) LsT[k * W + lane] = (k <= lane) ? myrow[k] : 0.0;
+        Dinv[lane] = mydinv;
+      }
+    }
+  }
+  __syncthreads();
+  PHASE(2);
+  double* P = Lbuf + F.L_off;
+  if (chunk == 0) {
+    for (int q = tid; q < W * W; q += 256) {
+      int i = q / W, k = q - i * W;
+      P[q] = Ls[i * LDW + k];
+      P[kL11c + q] = LsT[q];
+    }
+    if (tid < W) P[kDinv + tid] = Dinv[tid];
+  }
+  PHASE(3);
+  // ---- C. L21 rows: x = f * L11^-T, one thread per row, blocked left-looking (8-column panels in
+  // registers; earlier columns of the row come back from LDS, L11 columns are LDS broadcasts)
+  if (tid < nr) {
+    double* xr = R + tid * LDW;
+    for (int c = 0; c < W; c += 8) {
+      if (c >= w) break;
+      double xp[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) xp[q] = xr[c + q];
+      for (int t = 0; t < c; t++) {
+        double xt = xr[t];
+        const double2* Lc = reinterpret_cast<const double2*>(LsT + t * W + c);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          double2 l2 = Lc[q];
+          xp[2 * q] = fma(-xt, l2.x, xp[2 * q]);
+          xp[2 * q + 1] = fma(-xt, l2.y, xp[2 * q + 1]);
+        }
+      }
+      const double* Lp = LsT + c * W + c;
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) {
+        double xj = xp[jj] * Dinv[c + jj];
+        xp[jj] = xj;
+#pragma unroll
+        for (int q = jj + 1; q < 8; q++) xp[q] = fma(-xj, Lp[jj * W + q], xp[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) xr[c + q] = xp[q];
+    }
+  }
+  __syncthreads();
+  PHASE(4);
+  double* L21 = P + kL21;
+  for (int q = tid; q < nr * W; q += 256) {
+    int row = q / W, k = q - row * W;
+    L21[(size_t)(r0 + row) * W + k] = R[row * LDW + k];
+  }
+  PHASE(5);
+  // ---- D. fused update matrix for small fronts (single chunk: R holds all of L21)
+  if (r > 0 && r <= FUSE_R) {
+    constexpr int LDU = FUSE_R + 1;
+    for (int q = tid; q < r * LDU; q += 256) Uacc[q] = 0.0;      // Ls / LsT are dead from here on
+    for (int ci = 0; ci < F.nchild; ci++) {
+      const FrontDesc G = fronts[children[F.child_off + ci]];
+      const double* U = Ubuf + G.U_off;
+      const int rg = 3 * G.ns, ra = 3 * G.na;
+      const int nbb = rg - ra;                          // child border rows that land in my border
+      if (nbb <= 0) continue;
+      __syncthreads();
+      for (int q = tid; q < nbb; q += 256) {
+        int k = ra + q;
+        s_pos[q] = (short)(3 * (rel[G.rel_off + k / 3] - F.nc) + k % 3);   // my border row of child row k
+      }
+      __syncthreads();
+      // stream the lower triangle of the child's trailing block, 8 independent loads per lane
+      const int total = nbb * nbb;
+      for (int base = tid; base < total; base += 256 * 8) {
+        double v[8];
+        int tgt[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          int q = base + 256 * u;
+          int i = q / nbb, j = q - i * nbb;
+          bool ok = q < total && j <= i;
+          v[u] = ok ? U[(size_t)(ra + i) * rg + ra + j] : 0.0;
+          tgt[u] = ok ? s_pos[i] * LDU + s_pos[j] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (tgt[u] >= 0) Uacc[tgt[u]] += v[u];
       }
     }
     __syncthreads();
-    for (int q = tid; q < nr * w; q += 256) {
-      int row = q / w, j = q - row * w;
-      L21[(size_t)(r0 + row) * w + j] = R[row * LDW + j];
+    double* Uo = Ubuf + F.U_off;
+    const int T4 = (r + 3) / 4;
+    for (int q = tid; q < T4 * T4; q += 256) {
+      int bi = q / T4, bj = q - bi * T4;
+      if (bj > bi) continue;
+      double acc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+      const double* Ri = R + (4 * bi) * LDW;
+      const double* Rj = R + (4 * bj) * LDW;
+      for (int k = 0; k < w; k++) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { av[a] = Ri[a * LDW + k]; bv[a] = Rj[a * LDW + k]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          int gi = 4 * bi + a, gj = 4 * bj + b;
+          if (gi < r && gj <= gi) Uo[(size_t)gi * r + gj] = Uacc[gi * LDU + gj] - acc[a][b];
+        }
     }
   }
+#ifdef CGMR_PHASE_TIMING
+  __syncthreads();
+#endif
+  PHASE(6);
 }
 
 // --------------------------------------------------------------------------- front update
-// One workgroup per lower 32x32 tile of a front's update matrix:
+// Fronts with r > FUSE_R: one workgroup per lower 32x32 tile of the update matrix,
 //   U = extend_add(children's trailing blocks) - L21 L21^T
 __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restrict__ fronts,
                                                       const int32_t* __restrict__ tiles, int tile_begin,
@@ -296,18 +513,13 @@ __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restric
   const int32_t* tl = tiles + 3 * (size_t)(tile_begin + blockIdx.x);
   const FrontDesc F = fronts[tl[0]];
   const int ti = tl[1], tj = tl[2];
-  const int w = 3 * F.nc, r = 3 * F.ns;
-  const double* L21 = Lbuf + F.L_off + (size_t)w * w;
+  const int r = 3 * F.ns;
+  const double* L21 = Lbuf + F.L_off + kL21;
   const int i0 = ti * TS, j0 = tj * TS;
   for (int q = tid; q < TS * W; q += 256) {
     int row = q / W, k = q - row * W;
-    double vi = 0, vj = 0;
-    if (k < w) {
-      if (i0 + row < r) vi = L21[(size_t)(i0 + row) * w + k];
-      if (j0 + row < r) vj = L21[(size_t)(j0 + row) * w + k];
-    }
-    Ai[row * LDW + k] = vi;
-    Aj[row * LDW + k] = vj;
+    Ai[row * LDW + k] = (i0 + row < r) ? L21[(size_t)(i0 + row) * W + k] : 0.0;
+    Aj[row * LDW + k] = (j0 + row < r) ? L21[(size_t)(j0 + row) * W + k] : 0.0;
   }
   __syncthreads();
   // each thread: rows {ty, ty+16}, cols {tx, tx+16}
@@ -349,17 +561,29 @@ __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restric
 }
 
 // ------------------------------------------------------------------------------ solves
-// Forward (L y = b), one workgroup (64 threads = one wavefront) per front, bottom-up by level.
-__global__ __launch_bounds__(64) void k_solve_fwd(const FrontDesc* __restrict__ fronts,
-                                                  const int32_t* __restrict__ level_fronts, int level_begin,
-                                                  const int32_t* __restrict__ children,
-                                                  const int32_t* __restrict__ rel, const int32_t* __restrict__ inv,
-                                                  const double* __restrict__ Lbuf, const double* __restrict__ bvec,
-                                                  double* __restrict__ yvec, double* __restrict__ uvec) {
+// Forward (L y = b), one workgroup per front, bottom-up by level.  Wavefront 0 holds L11 (lane
+// i = row i, read coalesced from the column-major copy) and substitutes with readlane
+// broadcasts; then all threads form the border vector u = ext_add(children) - L21 y.
+__global__ __launch_bounds__(256) void k_solve_fwd(const FrontDesc* __restrict__ fronts,
+                                                   const int32_t* __restrict__ level_fronts, int level_begin,
+                                                   const int32_t* __restrict__ children,
+                                                   const int32_t* __restrict__ rel, const int32_t* __restrict__ inv,
+                                                   const double* __restrict__ Lbuf, const double* __restrict__ bvec,
+                                                   double* __restrict__ yvec, double* __restrict__ uvec) {
   __shared__ double t1[W];
+  __shared__ double ys[W];
   const int tid = threadIdx.x;
   const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
   const int w = 3 * F.nc, r = 3 * F.ns;
+  const double* P = Lbuf + F.L_off;
+  double Lrow[W];
+  double dv = 1.0;
+  if (tid < 64) {           // issue the L11 loads early; they do not depend on the children
+    const int lane = min(tid, W - 1);
+#pragma unroll
+    for (int k = 0; k < W; k++) Lrow[k] = P[kL11c + k * W + lane];
+    dv = P[kDinv + lane];
+  }
   if (tid < W) t1[tid] = (tid < w) ? bvec[3 * F.c0 + tid] : 0.0;
   __syncthreads();
   for (int ci = 0; ci < F.nchild; ci++) {
@@ -367,67 +591,90 @@ __global__ __launch_bounds__(64) void k_solve_fwd(const FrontDesc* __restrict__ 
     const double* ug = uvec + 3 * (size_t)G.rows_off;
     const int32_t* grel = rel + G.rel_off;
     int ra = 3 * G.na;
-    for (int q = tid; q < ra; q += 64) t1[3 * grel[q / 3] + q % 3] += ug[q];
+    for (int q = tid; q < ra; q += 256) t1[3 * grel[q / 3] + q % 3] += ug[q];
     __syncthreads();
   }
-  const double* L11 = Lbuf + F.L_off;
-  for (int j = 0; j < w; j++) {
-    double yj = t1[j] / L11[(size_t)j * w + j];
-    __syncthreads();
-    if (tid == 0) t1[j] = yj;
-    for (int i = j + 1 + tid; i < w; i += 64) t1[i] -= L11[(size_t)i * w + j] * yj;
-    __syncthreads();
+  if (tid < 64) {
+    const int lane = tid;
+    double t = t1[min(lane, W - 1)];
+    double yv = 0.0;
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      if (j < w) {
+        double yj = readlane_f64(t, j) * readlane_f64(dv, j);
+        if (lane == j) yv = yj;
+        t -= Lrow[j] * yj;
+      }
+    }
+    if (lane < W) ys[lane] = yv;
+    if (lane < w) yvec[3 * F.c0 + lane] = yv;
   }
-  if (tid < w) yvec[3 * F.c0 + tid] = t1[tid];
-  const double* L21 = L11 + (size_t)w * w;
+  __syncthreads();
+  const double* L21 = P + kL21;
   double* uf = uvec + 3 * (size_t)F.rows_off;
-  for (int p = tid; p < r; p += 64) {
+  for (int p = tid; p < r; p += 256) {
     double acc = 0;
     for (int ci = 0; ci < F.nchild; ci++) {
       const FrontDesc G = fronts[children[F.child_off + ci]];
       int kb = inv[G.inv_off + p / 3];
       if (kb >= 0) acc += uvec[3 * (size_t)G.rows_off + 3 * kb + p % 3];
     }
-    const double* row = L21 + (size_t)p * w;
+    const double2* row = reinterpret_cast<const double2*>(L21 + (size_t)p * W);
     double dot = 0;
-    for (int k = 0; k < w; k++) dot += row[k] * t1[k];
+#pragma unroll
+    for (int k = 0; k < W / 2; k++) {
+      double2 v = row[k];
+      dot += v.x * ys[2 * k];
+      dot += v.y * ys[2 * k + 1];
+    }
     uf[p] = acc - dot;
   }
 }
 
-// Backward (L^T x = y), one wavefront per front, top-down by level.
-__global__ __launch_bounds__(64) void k_solve_bwd(const FrontDesc* __restrict__ fronts,
-                                                  const int32_t* __restrict__ level_fronts, int level_begin,
-                                                  const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
-                                                  const double* __restrict__ yvec, double* __restrict__ xvec) {
-  __shared__ double t1[W];
-  __shared__ double part[64];
+// Backward (L^T x = y), one workgroup per front, top-down by level.
+__global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__ fronts,
+                                                   const int32_t* __restrict__ level_fronts, int level_begin,
+                                                   const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
+                                                   const double* __restrict__ yvec, double* __restrict__ xvec) {
+  constexpr int G5 = 5;
+  __shared__ double part[G5 * W];
   const int tid = threadIdx.x;
   const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
   const int w = 3 * F.nc, r = 3 * F.ns;
-  const double* L11 = Lbuf + F.L_off;
-  const double* L21 = L11 + (size_t)w * w;
-  // v = y - L21^T x_border ; thread j owns column j (coalesced across the wavefront)
-  if (tid < W) {
-    double acc = (tid < w) ? yvec[3 * F.c0 + tid] : 0.0;
-    if (tid < w) {
-      for (int p = 0; p < r; p++) {
-        double xb = xvec[3 * rows[F.rows_off + p / 3] + p % 3];
-        acc -= L21[(size_t)p * w + tid] * xb;
+  const double* P = Lbuf + F.L_off;
+  const double* L21 = P + kL21;
+  double Lcol[W];
+  double dv = 1.0;
+  if (tid < 64) {
+    const int lane = min(tid, W - 1);
+#pragma unroll
+    for (int k = 0; k < W; k++) Lcol[k] = P[k * W + lane];     // element (row k, col lane)
+    dv = P[kDinv + lane];
+  }
+  if (tid < G5 * W) {
+    int j = tid % W, g = tid / W;
+    double acc = 0;
+    for (int p = g; p < r; p += G5) acc += L21[(size_t)p * W + j] * xvec[3 * rows[F.rows_off + p / 3] + p % 3];
+    part[g * W + j] = acc;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int lane = tid;
+    const int lj = min(lane, W - 1);
+    double v = (lane < w) ? yvec[3 * F.c0 + lane] : 0.0;
+#pragma unroll
+    for (int g = 0; g < G5; g++) v -= part[g * W + lj];
+    double xv = 0.0;
+#pragma unroll
+    for (int i = W - 1; i >= 0; i--) {
+      if (i < w) {
+        double xi = readlane_f64(v, i) * readlane_f64(dv, i);
+        if (lane == i) xv = xi;
+        v -= Lcol[i] * xi;
       }
     }
-    t1[tid] = acc;
+    if (lane < w) xvec[3 * F.c0 + lane] = xv;
   }
-  (void)part;
-  __syncthreads();
-  for (int j = w - 1; j >= 0; j--) {
-    double xj = t1[j] / L11[(size_t)j * w + j];
-    __syncthreads();
-    if (tid == 0) t1[j] = xj;
-    for (int i = tid; i < j; i += 64) t1[i] -= L11[(size_t)j * w + i] * xj;
-    __syncthreads();
-  }
-  if (tid < w) xvec[3 * F.c0 + tid] = t1[tid];
 }
 
 // poses (+)= dx  (VertexSE2::oplusImpl: translation added in the global frame, angle wrapped)
@@ -465,8 +712,16 @@ void launch_assemble(hipStream_t st, const GnDevice& D) {
 
 void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag) {
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
-  hipLaunchKernelGGL(k_front_factor, dim3(nfr), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l],
-                     D.children, D.rel, D.inv, D.alist, D.nf, D.Ablk, D.Lbuf, D.Ubuf, D.status, iter_tag);
+  (void)nfr;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kSmemBytes);
+    attr_set = true;
+  }
+  int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
+  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), kSmemBytes, st, D.fronts, D.work, D.h_work_ptr[l], D.children,
+                     D.rel, D.inv, D.alist, D.Ablk, D.Lbuf, D.Ubuf, D.status, iter_tag, l);
 }
 
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
@@ -478,13 +733,13 @@ void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
 
 void launch_fwd_level(hipStream_t st, const GnDevice& D, int l) {
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
-  hipLaunchKernelGGL(k_solve_fwd, dim3(nfr), dim3(64), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l],
+  hipLaunchKernelGGL(k_solve_fwd, dim3(nfr), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l],
                      D.children, D.rel, D.inv, D.Lbuf, D.bvec, D.yvec, D.uvec);
 }
 
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
-  hipLaunchKernelGGL(k_solve_bwd, dim3(nfr), dim3(64), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l], D.rows,
+  hipLaunchKernelGGL(k_solve_bwd, dim3(nfr), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l], D.rows,
                      D.Lbuf, D.yvec, D.xvec);
 }
 
@@ -494,3 +749,9 @@ void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
 }
 
 }  // namespace cgmr
+
+#ifdef CGMR_PHASE_TIMING
+extern "C" int cgmr_debug_phase(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_phase), sizeof(unsigned long long) * 64 * 8);
+}
+#endif

@@ -101,7 +101,7 @@ void nd(NDCtx& C, int begin, int end) {
   }
   int js = best >= 0 ? best : fallback;
   // partition queue order into A (levels < js, plus level-js vertices not touching js+1), B, S
-  int na = 0, nb = 0, nsep = 0;
+  int na = 0, nb = 0;
   for (int q = 0; q < n; q++) {
     int v = C.queue[q];
     int d = C.dist[v];
@@ -113,7 +113,7 @@ void nd(NDCtx& C, int begin, int end) {
         int w = C.ai[p];
         if (C.label[w] == vis2 && C.dist[w] == js + 1) touches = true;
       }
-      if (touches) nsep++; else { na++; C.dist[v] = js - 1; }   // demote into A
+      if (!touches) { na++; C.dist[v] = js - 1; }   // demote into A
     }
   }
   int pa = begin, pb = begin + na, ps = begin + na + nb;
@@ -331,7 +331,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     }
     F.a_cnt = (int)S.alist.size() / 3 - F.a_off;
     int64_t w = 3 * (int64_t)F.nc, r = 3 * (int64_t)F.ns;
-    F.L_off = Loff; Loff += w * w + r * w;
+    F.L_off = Loff; Loff += kFactorHeader + r * kFrontW;
     F.U_off = Uoff; Uoff += r * r;
     flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
   }

@@ -16,6 +16,10 @@
 namespace cgmr {
 
 constexpr int kPanelW = 16;          // max poses (block columns) per front -> 48 scalar columns
+constexpr int kFrontW = 3 * kPanelW; // scalar columns per front (all panel strides are padded to this)
+constexpr int kFactorHeader = 2 * kFrontW * kFrontW + kFrontW;  // L11 row-major, L11 column-major, 1/diag
+constexpr int kChunkRows = 128;      // border rows handled by one k_front_factor workgroup
+constexpr int kFuseRows = 96;        // fronts with <= this many border rows form U inside k_front_factor
 
 struct FrontDesc {                   // one per front, uploaded verbatim (all int32 / int64)
   int32_t c0;         // first block column (permuted order)
@@ -33,7 +37,7 @@ struct FrontDesc {                   // one per front, uploaded verbatim (all in
   int32_t a_off;      // offset into alist[] (triples) of the A blocks assembled by this front
   int32_t a_cnt;
   int32_t pad;
-  int64_t L_off;      // offset (doubles) of this front's factor panel: L11 (w*w) then L21 (r*w), row-major
+  int64_t L_off;      // offset (doubles) of this front's factor panel: header (kFactorHeader) then L21 (r x kFrontW)
   int64_t U_off;      // offset (doubles) of this front's update matrix (r*r, row-major, lower part valid)
 };
 
