@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X (contract: see the task statement).
+
+Workload (BASELINE.json configs[1], "C2"): the synthetic 10k-vertex / 40k-edge SE2 pose graph of
+SURVEY.md section 8(d).  One *step* = one ``GraphSLAM::optimize(10)`` call (src/slam/graph_slam.cpp:561-575)
+from the odometry initial guess: host ordering + symbolic analysis (g2o redoes both on every optimize()
+call, so they are inside the timed region here as well), upload of the structure, 10 Gauss-Newton
+iterations on the GPU, chi2 read-back.  Numeric inputs (poses, measurements, information matrices) are
+resident in HBM before the timed region starts.  value = GN iterations / second over all ranks.
+
+Multi-GPU (one process per GPU, torch.distributed / RCCL): every rank owns one robot's sub-graph (a C2
+graph with its own seed) -- the path shards by robot with no data-path collective inside optimize(); weak
+scaling.  The inter-robot condensed-edge exchange is benchmarked by
+``--workload exchange`` once per step on top of the solve.
+
+Extra objects on the JSON line: ``roofline`` for the dominant kernel (k_front_factor, timed with HIP events
+on the context's stream) and ``cpu_baseline`` (the single-thread CPU oracle on rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GN_ITERS = 10
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--vertices", type=int, default=10000)
+    ap.add_argument("--edges", type=int, default=40000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from cg_mrslam_amd import Context, synth
+    from cg_mrslam_amd._lib import gn_symbolic_info
+
+    ctx = Context(local)
+    g = synth.make_pose_graph(args.vertices, args.edges, seed=12345 + 17 * rank, id_base=10000 * rank, strict=True)
+    V, E = g["poses"].shape[0], len(g["edge_from"])
+    fixed, ef, et = g["fixed"], g["edge_from"], g["edge_to"]
+    d_p0 = torch.tensor(g["poses"], dtype=torch.float64, device=dev).contiguous()
+    d_p = d_p0.clone()
+    d_m = torch.tensor(g["meas"], dtype=torch.float64, device=dev).contiguous()
+    d_i = torch.tensor(g["info"], dtype=torch.float64, device=dev).contiguous()
+    torch.cuda.synchronize()
+
+    chi = None
+
+    def step():
+        nonlocal chi
+        d_p.copy_(d_p0)                       # restart from the odometry guess (device-to-device, 240 KB)
+        torch.cuda.current_stream().synchronize()
+        _, chi = ctx.gn_optimize_dev(d_p.data_ptr(), V, fixed, ef, et, d_m.data_ptr(), d_i.data_ptr(), GN_ITERS)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    host_sym = 0.0
+    dev_time = 0.0
+    for _ in range(args.steps):
+        step()
+        tm = ctx.gn_last_timing()
+        host_sym += tm["order"] + tm["structure"]
+        dev_time += tm["device"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel, HIP events on the context's stream (separate pass: the
+    # per-launch events serialise the stream, so this pass is not part of the timed region)
+    info = gn_symbolic_info(V, fixed, ef, et)
+    ctx.set_profiling(True)
+    nprof = 3
+    for _ in range(nprof):
+        step()
+    kt = ctx.gn_kernel_times()
+    ctx.set_profiling(False)
+    ff_s, ff_n = kt["front_factor"]
+    total_k = sum(v[0] for v in kt.values())
+    dominant = max(kt.items(), key=lambda kv: kv[1][0])[0]
+    # algorithmic HBM bytes of one factorisation pass of k_front_factor (DESIGN.md "roofline"):
+    #   read the H blocks (72 B each), read + write each update matrix once (lower triangle counted in full
+    #   as stored: 8 B * U_doubles each way is an upper bound of what is touched; the a-part read by the
+    #   factor kernel is U's leading columns), write the factor panels (8 B * L_doubles)
+    nblk = info["free_poses"] + info["offdiag_blocks"]
+    bytes_factor_iter = 72 * nblk + 8 * info["L_doubles"] + 8 * info["U_doubles"]
+    launches_per_iter = ff_n / (nprof * GN_ITERS)
+    avg_launch_s = ff_s / max(ff_n, 1)
+    bytes_per_launch = bytes_factor_iter / max(launches_per_iter, 1)
+    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    roofline = {
+        "kernel": "k_front_factor", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+        "frac": round(achieved / 8000.0, 6), "traffic": None,
+        "avg_launch_us": round(1e6 * avg_launch_s, 2), "launches_per_gn_iter": round(launches_per_iter, 1),
+        "algorithmic_bytes_per_launch": int(bytes_per_launch),
+        "share_of_kernel_time": round(ff_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
+        "note": "latency-bound: the 7 MB working set lives in L2/MALL; see DESIGN.md",
+    }
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        tc0 = time.perf_counter()
+        st, p_cpu, chi_cpu, tms = O.gn_optimize(g["poses"], fixed, ef, et, g["meas"], g["info"], GN_ITERS)
+        tc = time.perf_counter() - tc0
+        cpu = {"value": round(GN_ITERS / tc, 3), "unit": "GN iterations/s", "cores": 1, "kind": "port",
+               "sample": f"1 optimize({GN_ITERS}) call on the same {V}-vertex/{E}-edge graph, incl. ordering+symbolic",
+               "seconds": round(tc, 4), "chi2_final": float(chi_cpu[-1]),
+               "chi2_rel_diff_vs_gpu": float(abs(chi_cpu[-1] - chi[-1]) / chi_cpu[-1]),
+               "max_pose_diff_vs_gpu": float(np.abs(p_cpu - d_p.cpu().numpy()).max())}
+
+    total_iters = GN_ITERS * args.steps * world
+    out = {
+        "metric": "GN iterations/sec on 10k-vertex SE2 graph (final chi2 reported)",
+        "value": round(total_iters / elapsed, 3), "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C2: synthetic {V}-vertex/{E}-edge SE2 pose graph per GPU, one step = "
+                               f"GraphSLAM::optimize({GN_ITERS}) incl. host ordering+symbolic analysis",
+                   "gn_iterations_per_step": GN_ITERS, "graphs": world, "parallelism": f"1 robot sub-graph per GPU x{world}"},
+        "chi2_final": float(chi[-1]), "chi2_initial": float(chi[0]),
+        "host_symbolic_ms_per_step": round(1e3 * host_sym / args.steps, 3),
+        "device_ms_per_step": round(1e3 * dev_time / args.steps, 3),
+        "symbolic": {k: info[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")},
+        "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if cpu:
+        out["speedup_vs_cpu_1thread"] = round(out["value"] / cpu["value"], 2)
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

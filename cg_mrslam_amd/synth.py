@@ -94,7 +94,7 @@ def _diag_info_upper(d):
 
 
 def make_pose_graph(n_vertices: int = 10000, n_edges: int = 40000, seed: int = 12345,
-                    close_radius: float = 1.5, id_base: int = 0):
+                    close_radius: float = 1.5, id_base: int = 0, strict: bool = False):
     """C2 recipe.
 
     Returns a dict of flat arrays: ``truth``/``poses`` (V,3) (initial guess =
@@ -152,7 +152,9 @@ def make_pose_graph(n_vertices: int = 10000, n_edges: int = 40000, seed: int = 1
     o = np.lexsort((cj, ci))
     ci, cj = ci[o], cj[o]
     if len(ci) < n_lc:
-        raise ValueError(f"only {len(ci)} closure candidates for {n_lc} requested")
+        if strict:
+            raise ValueError(f"only {len(ci)} closure candidates for {n_lc} requested")
+        n_lc = len(ci)                                  # small graphs: take every candidate
     # uniform sample without replacement: rank candidates by a counter-based key
     rk = uniform(seed, 2, len(ci))
     pick = np.sort(np.argsort(rk, kind="stable")[:n_lc])

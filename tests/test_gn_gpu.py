@@ -1,0 +1,145 @@
+"""GPU parity tests of the Gauss-Newton path: HIP (through the C ABI) vs the CPU oracle on the same
+seeded inputs, vs the committed golden fixtures, and at BASELINE.json's full size (C2).
+Tolerances: final chi2 within 1e-8 relative and final poses within 1e-6 m / 1e-7 rad of the oracle
+(tighter than the 1e-6 chi2 bar SURVEY.md 8d proposes); chi2 of the *transient* iterations within 1e-5:
+far from the optimum the GN trajectory amplifies rounding differences (FMA contraction, summation order)
+by cond(H) -- the two CPU implementations (C oracle vs numpy/SuperLU) differ from each other by the same
+amount there (measured 3e-6 on C2 at iteration 5, 3e-15 after convergence)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from cg_mrslam_amd import synth
+from cg_mrslam_amd.graph import GraphSLAM, PoseGraph
+
+pytestmark = pytest.mark.gpu
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "gn_*.npz")))
+CHI_RTOL = 1e-5        # transient iterations
+CHI_FINAL_RTOL = 1e-8  # last iteration
+POS_ATOL = 1e-6
+ANG_ATOL = 1e-7
+
+
+def _check(p_gpu, chi_gpu, p_ref, chi_ref):
+    np.testing.assert_allclose(chi_gpu, chi_ref, rtol=CHI_RTOL, atol=1e-18)
+    np.testing.assert_allclose(chi_gpu[-1], chi_ref[-1], rtol=CHI_FINAL_RTOL, atol=1e-18)
+    assert np.abs(p_gpu[:, :2] - p_ref[:, :2]).max() <= POS_ATOL
+    dth = np.abs(synth.normalize_theta(p_gpu[:, 2] - p_ref[:, 2])).max()
+    assert dth <= ANG_ATOL
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_gpu_matches_golden(ctx, path):
+    d = np.load(path)
+    rc, poses, chi2 = ctx.gn_optimize(d["poses0"], d["fixed"], d["edge_from"], d["edge_to"], d["meas"], d["info"],
+                                      int(d["iters"]))
+    assert rc == 0
+    _check(poses, chi2, d["poses"], d["chi2"])
+
+
+@pytest.mark.parametrize("V,E,iters,seed", [(2, 1, 3, 1), (5, 4, 4, 2), (33, 60, 6, 3), (500, 1500, 8, 4),
+                                            (2500, 9000, 8, 5)])
+def test_gpu_matches_oracle(ctx, oracle, V, E, iters, seed):
+    g = synth.make_pose_graph(V, E, seed=seed)
+    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+    rc, p, chi = ctx.gn_optimize(*a, iters)
+    st, p2, chi2, _ = oracle.gn_optimize(*a, iters)
+    assert rc == 0 and st == 0
+    _check(p, chi, p2, chi2)
+
+
+def test_gpu_full_size_c2(ctx, oracle):
+    """BASELINE.json configs[1]: 10k vertices / 40k edges, optimize(10)."""
+    g = synth.make_pose_graph(10000, 40000, seed=12345)
+    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+    rc, p, chi = ctx.gn_optimize(*a, 10)
+    st, p2, chi2, _ = oracle.gn_optimize(*a, 10)
+    assert rc == 0 and st == 0
+    _check(p, chi, p2, chi2)
+    dof = 3 * 40000 - 3 * 9999
+    assert abs(chi[-1] - dof) / dof < 0.02
+    # run-to-run bit reproducibility (no atomics anywhere in the solve)
+    rc, p3, chi3 = ctx.gn_optimize(*a, 10)
+    assert np.array_equal(p, p3) and np.array_equal(chi, chi3)
+
+
+def test_gpu_device_resident_entry_point(ctx, oracle):
+    import torch
+    g = synth.make_pose_graph(800, 2600, seed=6)
+    dev = torch.device("cuda:0")
+    d_p = torch.tensor(g["poses"], dtype=torch.float64, device=dev).contiguous()
+    d_m = torch.tensor(g["meas"], dtype=torch.float64, device=dev).contiguous()
+    d_i = torch.tensor(g["info"], dtype=torch.float64, device=dev).contiguous()
+    torch.cuda.synchronize()
+    rc, chi = ctx.gn_optimize_dev(d_p.data_ptr(), 800, g["fixed"], g["edge_from"], g["edge_to"], d_m.data_ptr(),
+                                  d_i.data_ptr(), 6)
+    st, p2, chi2, _ = oracle.gn_optimize(g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"], 6)
+    assert rc == 0
+    _check(d_p.cpu().numpy(), chi, p2, chi2)
+
+
+def test_multiple_fixed_duplicate_edges_and_isolated_vertices(ctx, oracle):
+    g = synth.make_pose_graph(120, 300, seed=7)
+    fixed = g["fixed"].copy()
+    fixed[[40, 119]] = 1
+    # duplicate some edges (g2o sums their quadratic forms) and append two vertices nobody references
+    ef = np.concatenate([g["edge_from"], g["edge_from"][:25]])
+    et = np.concatenate([g["edge_to"], g["edge_to"][:25]])
+    meas = np.concatenate([g["meas"], g["meas"][:25] + 0.01])
+    info = np.concatenate([g["info"], g["info"][:25]])
+    poses = np.concatenate([g["poses"], [[9.0, 9, 1], [-3, 2, 0.5]]])
+    fixed = np.concatenate([fixed, [0, 0]]).astype(np.uint8)
+    rc, p, chi = ctx.gn_optimize(poses, fixed, ef, et, meas, info, 6)
+    st, p2, chi2, _ = oracle.gn_optimize(poses, fixed, ef, et, meas, info, 6)
+    assert rc == 0 and st == 0
+    _check(p, chi, p2, chi2)
+    np.testing.assert_array_equal(p[-2:], poses[-2:])           # inactive vertices untouched
+    np.testing.assert_array_equal(p[[0, 40, 119]], poses[[0, 40, 119]])
+
+
+def test_zero_iterations_and_all_fixed(ctx, oracle):
+    g = synth.make_pose_graph(30, 60, seed=9)
+    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+    rc, p, chi = ctx.gn_optimize(*a, 0)
+    assert rc == 0 and len(chi) == 1
+    np.testing.assert_array_equal(p, g["poses"])
+    assert abs(chi[0] - oracle.chi2(g["poses"], *a[2:])) <= 1e-9 * chi[0]
+    rc, p, chi = ctx.gn_optimize(g["poses"], np.ones(30, np.uint8), *a[2:], 3)
+    assert rc == 0
+    np.testing.assert_array_equal(p, g["poses"])
+    np.testing.assert_allclose(chi, chi[0])
+
+
+def test_cholesky_failure_leaves_poses(ctx):
+    # no fixed vertex -> singular H.  g2o returns early; GraphSLAM::optimize swallows the status.
+    poses = np.array([[0.0, 0, 0], [1, 0, 0], [2, 0, 0]])
+    fixed = np.zeros(3, np.uint8)
+    ef = np.array([0, 1], np.int32)
+    et = np.array([1, 2], np.int32)
+    meas = np.array([[1.0, 0, 0], [1.0, 0, 0]]) + 0.1
+    info = np.tile([1.0, 0, 0, 1, 0, 1], (2, 1))
+    rc, p, chi = ctx.gn_optimize(poses, fixed, ef, et, meas, info, 3, raise_on_cholesky=False)
+    if rc == 0:
+        # a rank-deficient H can slip through Cholesky with tiny positive pivots; then the step is
+        # finite garbage in the gauge directions but chi2 must not increase
+        assert chi[-1] <= chi[0] * (1 + 1e-9)
+    else:
+        assert rc <= -100
+        np.testing.assert_array_equal(p, poses)
+    gs = GraphSLAM(PoseGraph(np.arange(3), poses, fixed, ef, et, meas, info), ctx=ctx)
+    gs.optimize(2)                                             # must not raise
+
+
+def test_graphslam_mirror_and_g2o_io(ctx, oracle, tmp_path):
+    g = synth.make_pose_graph(200, 600, seed=10, id_base=10000)
+    gs = GraphSLAM(PoseGraph.from_synth(g), ctx=ctx)
+    gs.optimize(5)
+    st, p2, chi2, _ = oracle.gn_optimize(g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"], 5)
+    _check(gs.graph.poses, gs.last_chi2, p2, chi2)
+    path = os.path.join(tmp_path, "robot-0.g2o")
+    assert gs.saveGraph(path)
+    gs2 = GraphSLAM(PoseGraph.load_g2o(path), ctx=ctx)
+    assert abs(gs2.chi2() - chi2[-1]) / chi2[-1] < 1e-2        # default .g2o precision is lossy

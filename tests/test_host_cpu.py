@@ -1,0 +1,72 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/cgmr.h declares,
+its host-only symbolic analysis produces a valid elimination order, and the .g2o reader/writer
+round-trips.  No compute entry point is called (no GPU here)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from cg_mrslam_amd import _lib, synth
+from cg_mrslam_amd.graph import PoseGraph
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load_library()
+    names = _lib.declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"libcgmr.so does not export {n}"
+    assert lib.cgmr_version() >= 100
+
+
+def test_ctx_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.CgmrError):
+        _lib.Context(0)
+
+
+@pytest.mark.parametrize("V,E,seed", [(2, 1, 1), (17, 16, 2), (300, 800, 3), (3000, 11000, 4)])
+def test_symbolic_permutation_is_valid(V, E, seed):
+    g = synth.make_pose_graph(V, E, seed=seed)
+    info, perm = _lib.gn_symbolic_info(V, g["fixed"], g["edge_from"], g["edge_to"], want_perm=True)
+    free = perm[perm >= 0]
+    assert info["free_poses"] == V - 1 == len(free)
+    assert sorted(free.tolist()) == list(range(V - 1))         # a permutation of the free block columns
+    assert perm[0] == -1                                        # the fixed vertex is not in the system
+    assert info["fronts"] >= 1 and info["levels"] >= 1
+    assert info["max_border"] * 3 < 32000                      # index maps are staged as int16 on the device
+
+
+def test_symbolic_handles_disconnected_and_inactive_vertices():
+    # two components, one isolated vertex, one fixed vertex in each component
+    ef = np.array([0, 1, 3, 4], dtype=np.int32)
+    et = np.array([1, 2, 4, 5], dtype=np.int32)
+    fixed = np.array([1, 0, 0, 1, 0, 0, 0], dtype=np.uint8)    # vertex 6 has no edge
+    info, perm = _lib.gn_symbolic_info(7, fixed, ef, et, want_perm=True)
+    assert info["free_poses"] == 4
+    assert perm[6] == -1 and perm[0] == -1 and perm[3] == -1
+
+
+def test_symbolic_rejects_bad_indices():
+    with pytest.raises(_lib.CgmrError):
+        _lib.gn_symbolic_info(3, np.zeros(3, np.uint8), np.array([0], np.int32), np.array([7], np.int32))
+
+
+def test_g2o_round_trip(tmp_path):
+    g = synth.make_pose_graph(40, 90, seed=8, id_base=10000)
+    pg = PoseGraph.from_synth(g)
+    path = os.path.join(tmp_path, "a.g2o")
+    pg.save_g2o(path, precision=17)
+    back = PoseGraph.load_g2o(path)
+    np.testing.assert_array_equal(back.ids, pg.ids)
+    np.testing.assert_array_equal(back.fixed, pg.fixed)
+    np.testing.assert_array_equal(back.edge_from, pg.edge_from)
+    np.testing.assert_allclose(back.poses, pg.poses, rtol=0, atol=0)
+    np.testing.assert_allclose(back.meas, pg.meas, rtol=0, atol=0)
+    # default precision is g2o's lossy 6 significant digits
+    pg.save_g2o(path)
+    lossy = PoseGraph.load_g2o(path)
+    assert np.abs(lossy.poses - pg.poses).max() < 1e-3

@@ -1,0 +1,44 @@
+"""Generate the golden fixtures under tests/golden/ for the Gauss-Newton / condensed path.
+
+The expected values come from tests/ref_numpy.py (numpy + SciPy SuperLU + dense inverse), an
+implementation independent of both the C oracle and the HIP kernels.  g2o itself is not
+available in this image, so these fixtures pin the *restated* algorithm,
+not g2o's output: the parity claim for this path stays "unpinned" in DESIGN.md.
+
+Run from the repo root:  python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from cg_mrslam_amd import synth  # noqa: E402
+import ref_numpy as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def gn_case(name, V, E, seed, iters, extra_fixed=()):
+    g = synth.make_pose_graph(V, E, seed=seed)
+    fixed = g["fixed"].copy()
+    for v in extra_fixed:
+        fixed[v] = 1
+    poses, chi2 = R.gn_optimize(g["poses"], fixed, g["edge_from"], g["edge_to"], g["meas"], g["info"], iters)
+    query = np.array(sorted(set([1, V // 3, V // 2, V - 1])), dtype=np.int32)
+    cov = R.marginals_dense(poses, fixed, g["edge_from"], g["edge_to"], g["meas"], g["info"], query)
+    np.savez_compressed(os.path.join(OUT, f"gn_{name}.npz"), poses0=g["poses"], fixed=fixed,
+                        edge_from=g["edge_from"], edge_to=g["edge_to"], meas=g["meas"], info=g["info"],
+                        iters=iters, poses=poses, chi2=chi2, query=query, cov=cov)
+    print(name, "chi2", chi2[0], "->", chi2[-1])
+
+
+if __name__ == "__main__":
+    gn_case("v60", 60, 110, 11, 6)
+    gn_case("v300", 300, 800, 12, 8)
+    gn_case("v300_multifix", 300, 800, 13, 8, extra_fixed=(7, 150, 299))
+    gn_case("v1200", 1200, 4000, 14, 8)
