@@ -59,6 +59,7 @@ def load_library():
     lib = C.CDLL(path)
     lib.cgmr_last_error.restype = C.c_char_p
     lib.cgmr_ctx_destroy.restype = None
+    lib.cgmr_matcher_config_close.restype = None
     _LIB = lib
     return lib
 

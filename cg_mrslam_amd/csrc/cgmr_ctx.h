@@ -29,6 +29,7 @@ struct cgmr_ctx {
   cgmr::Symbolic sym;
   cgmr::GnDevice gn;
   double timing[5] = {0, 0, 0, 0, 0};
+  double match_seconds = 0;
   bool profiling = false;
   double ksec[8] = {0};
   int64_t klaunch[8] = {0};

@@ -1,0 +1,36 @@
+// Parameters shared by the matcher kernels and their host launcher.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cgmr {
+
+constexpr int kMatchMaxPoints = 1088;        // beams per scan (1081 for the reference's laser), multiple of 64
+constexpr int kMatchMaxDir = 150 * 150;      // 8x8-cell tiles of the largest grid (1200 x 1200 cells)
+constexpr int kMatchTilesLds = 1440;         // tiles resident in LDS; the rest spills to HBM
+constexpr int kMatchMaxTheta = 80;           // search angles per region
+
+struct MatchParams {
+  int n_pairs, n_beams;
+  // grid (ScanMatcher::initializeGrid, src/matcher/scan_matcher.cpp:63-66; gridmap.h:196-214)
+  float ll_x, ll_y, res, inv_res;
+  int nx, ny;
+  int kscale, fill, kdim;                    // fill = K2 = int(kernelRange * kscale)
+  // laser (RobotLaser / LaserParameters) and the pose of the laser on the robot
+  double max_range, min_range;
+  double lp_c, lp_s, lp_x, lp_y;             // cos/sin of the laser pose angle (host libm), translation
+  // search (closeScanMatching: scan_matcher.cpp:148-151)
+  double win_x, win_y, win_t, theta_res, max_score, dx, dy, dth, sub_res;
+  int x_steps, y_steps;
+  int overflow_tiles;
+  size_t scratch_stride;
+};
+
+size_t match_smem_bytes();
+void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref,
+                              const float* ranges_qry, const double* guess, const double* beam_cos,
+                              const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
+                              double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err);
+
+}  // namespace cgmr

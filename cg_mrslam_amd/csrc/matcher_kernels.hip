@@ -1,0 +1,504 @@
+// HIP kernels (gfx950 / CDNA4) for the 2D correlative scan matcher.
+//
+// Reference behaviour being replaced (mtlazaro/cg_mrslam):
+//   ScanMatcher::closeScanMatching      src/matcher/scan_matcher.cpp:112-189
+//   ScanMatcher::resetGrid              src/matcher/scan_matcher.cpp:68-76
+//   CharGrid::addAndConvolvePoints      src/matcher/chargrid.h:205-216  (+ applyKernel chargrid.cpp:132-161)
+//   CharGrid::subsample                 src/matcher/chargrid.cpp:61-122
+//   CharGrid::greedySearch              src/matcher/chargrid.cpp:208-308 (+ addToPrunedMap 36-46)
+//   _GridMap::world2grid/grid2world     src/matcher/gridmap.h:24-48
+//
+// Design ("Matcher kernel"): one workgroup (256 threads) matches one scan pair end to end;
+// a persistent grid of workgroups strides over the batch.  The reference's 1200x1200-byte distance grid
+// (1.44 MB) does not fit the 160 KB LDS, but only cells within the kernel radius of a reference point
+// differ from the fill value, so the grid is held *sparsely*: a directory of 8x8-cell tiles (uint16 per
+// tile, 45 KB for 150x150 tiles) plus a pool of 64-byte tiles in LDS (overflow tiles spill to a per-
+// workgroup HBM pool, same format).  Stamping uses a compare-and-swap byte-min on 32-bit words; the
+// search assigns one wavefront per search angle and one lane per (x,y) offset, gathers bytes through the
+// directory, and keeps the per-bin minimum with a 64-bit LDS atomic-min on (score bits, visit order),
+// which reproduces addToPrunedMap's "first seen wins" exactly.  All arithmetic that decides a cell index
+// is done in the reference's types (double rotation without FMA contraction, float world2grid with
+// round-to-nearest-even), so results are bit-identical to the CPU restatement.
+//
+// This file must be compiled with -ffp-contract=off (see Makefile).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "matcher_device.h"
+
+namespace cgmr {
+
+namespace {
+
+// ------------------------------------------------------------------ portable sin / cos
+// Same routine as oracle/matcher_oracle.c (Cody-Waite reduction + classic minimax kernels): the
+// search-angle cos/sin must be bit-identical on host and device, libm and ocml are not.
+__device__ double k_sin(double x, double y, int iy) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = x * x;
+  double v = z * x;
+  double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  if (iy == 0) return x + v * (S1 + z * r);
+  return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+
+__device__ double k_cos(double x, double y) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = x * x;
+  double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  double ax = fabs(x);
+  if (ax < 0.3) return 1.0 - (0.5 * z - (z * r - x * y));
+  double qx;
+  if (ax > 0.78125) qx = 0.28125;
+  else {
+    unsigned long long u = (unsigned long long)__double_as_longlong(ax * 0.25);
+    u &= 0xffffffff00000000ULL;
+    qx = __longlong_as_double((long long)u);
+  }
+  double hz = 0.5 * z - qx;
+  double a = 1.0 - qx;
+  return a - (hz - (z * r - x * y));
+}
+
+__device__ int rem_pio2(double x, double* y0, double* y1) {
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+               pio2_1t = 6.07710050650619224932e-11, pio2_2 = 6.07710050630396597660e-11,
+               pio2_2t = 2.02226624879595063154e-21, pio2_3 = 2.02226624871116645580e-21,
+               pio2_3t = 8.47842766036889956997e-32;
+  double ax = fabs(x);
+  int n = (int)(ax * invpio2 + 0.5);
+  double fn = (double)n;
+  double r = ax - fn * pio2_1;
+  double w = fn * pio2_1t;
+  double a0 = r - w;
+  int ex = (int)(((unsigned long long)__double_as_longlong(ax) >> 52) & 0x7ff);
+  int ea = (int)(((unsigned long long)__double_as_longlong(a0) >> 52) & 0x7ff);
+  if (ex - ea > 16) {
+    double t = r;
+    w = fn * pio2_2;
+    r = t - w;
+    w = fn * pio2_2t - ((t - r) - w);
+    a0 = r - w;
+    ea = (int)(((unsigned long long)__double_as_longlong(a0) >> 52) & 0x7ff);
+    if (ex - ea > 49) {
+      t = r;
+      w = fn * pio2_3;
+      r = t - w;
+      w = fn * pio2_3t - ((t - r) - w);
+      a0 = r - w;
+    }
+  }
+  double a1 = (r - a0) - w;
+  if (x < 0) { *y0 = -a0; *y1 = -a1; return -n; }
+  *y0 = a0; *y1 = a1;
+  return n;
+}
+
+__device__ void portable_sincos(double x, double* s, double* c) {
+  if (fabs(x) <= 0.78539816339744830962) { *s = k_sin(x, 0.0, 0); *c = k_cos(x, 0.0); return; }
+  double y0, y1;
+  int n = rem_pio2(x, &y0, &y1);
+  double sn = k_sin(y0, y1, 1), cs = k_cos(y0, y1);
+  switch (n & 3) {
+    case 0: *s = sn; *c = cs; break;
+    case 1: *s = cs; *c = -sn; break;
+    case 2: *s = -sn; *c = -cs; break;
+    default: *s = -cs; *c = sn; break;
+  }
+}
+
+// ------------------------------------------------------------------ LDS plan
+constexpr int NT_LDS = kMatchTilesLds;       // tiles held in LDS
+constexpr int MAXPTS = kMatchMaxPoints;      // max beams / points per scan
+constexpr int NTH = 4;                       // search angles processed concurrently (one per wavefront)
+constexpr int CAND_U = 9;                    // candidates per lane per block (64*9 = 576 = 24x24)
+constexpr int MAXBINS = 512;
+constexpr int MAXTHETA = kMatchMaxTheta;
+
+struct Smem {
+  uint16_t dir[kMatchMaxDir];                // tile directory: 0xFFFF = untouched (all cells = fill)
+  uint32_t tiles[NT_LDS * 16];               // 64-byte tiles, cell (x&7, y&7) at byte (x&7)*8 + (y&7)
+  uint32_t plist[NTH][MAXPTS];               // per-angle point lists: int16 x | int16 y << 16
+  unsigned long long bins[MAXBINS];          // (score bits << 32 | visit order), min = best, first seen
+  double theta[MAXTHETA], cs[MAXTHETA], sn[MAXTHETA];
+  uint8_t kernel[1024];
+  int scan[260];
+  int misc[16];
+};
+static_assert(sizeof(Smem) <= 160 * 1024, "matcher LDS plan exceeds 160 KiB");
+
+__device__ __forceinline__ uint32_t bytemin4(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t x = (a >> (8 * k)) & 0xff, y = (b >> (8 * k)) & 0xff;
+    r |= (x < y ? x : y) << (8 * k);
+  }
+  return r;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns the exclusive prefix, total in *total
+__device__ int block_scan_excl(int v, int* sh, int* total) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int add = (tid >= off) ? sh[tid - off] : 0;
+    __syncthreads();
+    sh[tid] += add;
+    __syncthreads();
+  }
+  int incl = sh[tid];
+  *total = sh[255];
+  __syncthreads();
+  return incl - v;
+}
+
+}  // namespace
+
+// One workgroup per scan pair (persistent stride over the batch).
+__global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const float* __restrict__ ranges_ref,
+                                                           const float* __restrict__ ranges_qry,
+                                                           const double* __restrict__ guess,
+                                                           const double* __restrict__ beam_cos,
+                                                           const double* __restrict__ beam_sin,
+                                                           const uint8_t* __restrict__ kernel_lut,
+                                                           unsigned char* __restrict__ scratch,
+                                                           double* __restrict__ out_xyt, double* __restrict__ out_score,
+                                                           uint8_t* __restrict__ out_found, int* __restrict__ out_nres,
+                                                           int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& S = *reinterpret_cast<Smem*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int B = P.n_beams;
+  // per-workgroup HBM scratch: query points (double2 * MAXPTS), sort keys (u64 * 2048), overflow tiles
+  unsigned char* my = scratch + (size_t)blockIdx.x * P.scratch_stride;
+  double* qraw = reinterpret_cast<double*>(my);                           // 2 * MAXPTS
+  double* qpts = qraw + 2 * MAXPTS;                                       // 2 * MAXPTS
+  uint32_t* gtiles = reinterpret_cast<uint32_t*>(qpts + 2 * MAXPTS);      // overflow tiles
+  const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
+  const int ndir = ntx * nty;
+  const int K2 = P.fill;
+  const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
+  for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
+
+  for (int pair = blockIdx.x; pair < P.n_pairs; pair += gridDim.x) {
+    __syncthreads();
+    // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
+    // sort keys live in the (not yet used) tile pool: 2048 x u64
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(S.tiles);
+    const double ires = 1. / P.sub_res;
+    for (int i = tid; i < 2048; i += 256) {
+      unsigned long long key = ~0ULL;
+      if (i < B) {
+        double r = (double)ranges_qry[(size_t)pair * B + i];
+        if (r < P.max_range && r > P.min_range) {
+          double x = beam_cos[i] * r, y = beam_sin[i] * r;
+          qraw[2 * i] = x; qraw[2 * i + 1] = y;
+          int kx = (int)(ires * x), ky = (int)(ires * y);
+          key = ((unsigned long long)(unsigned)(kx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(ky + (1 << 20)) << 21) |
+                (unsigned long long)i;
+        }
+      }
+      keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= 2048; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < 2048; i += 256) {
+          int l = i ^ j;
+          if (l > i) {
+            unsigned long long a = keys[i], b = keys[l];
+            bool up = ((i & k) == 0);
+            if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // bucket leaders: sorted position i starts a bucket if its (kx,ky) differs from position i-1
+    int nlead = 0;
+    int lead_pos[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      int i = tid * 8 + u;                  // contiguous ranges so that the scan yields bucket ranks in order
+      unsigned long long a = keys[i];
+      bool lead = (a != ~0ULL) && (i == 0 || (keys[i - 1] >> 21) != (a >> 21));
+      lead_pos[u] = lead ? i : -1;
+      nlead += lead ? 1 : 0;
+    }
+    int nq;
+    int rank = block_scan_excl(nlead, S.scan, &nq);
+    {
+      const double lc = P.lp_c, ls = P.lp_s, ltx = P.lp_x, lty = P.lp_y;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int i = lead_pos[u];
+        if (i < 0) continue;
+        unsigned long long kk = keys[i] >> 21;
+        double ax = 0, ay = 0;
+        int cnt = 0;
+        for (int m = i; m < 2048 && (keys[m] >> 21) == kk && keys[m] != ~0ULL; m++) {
+          int idx = (int)(keys[m] & 0x1fffff);
+          ax += qraw[2 * idx];
+          ay += qraw[2 * idx + 1];
+          cnt++;
+        }
+        double wgt = 1. / (double)cnt;
+        double mx = ax * wgt, myy = ay * wgt;
+        qpts[2 * rank] = (lc * mx - ls * myy) + ltx;       // applyTransfToScan(laserPose, ...)
+        qpts[2 * rank + 1] = (ls * mx + lc * myy) + lty;
+        rank++;
+      }
+    }
+    __syncthreads();
+    // ---------------- reference scan -> cells; directory of touched tiles ---------------------------------
+    for (int q = tid; q < (ndir + 1) / 2; q += 256) reinterpret_cast<uint32_t*>(S.dir)[q] = 0;
+    uint32_t* rcell = S.plist[0];           // int16 x | int16 y << 16, 0x80008000 = invalid
+    const int ctr = (P.kdim - 1) / 2;
+    __syncthreads();
+    for (int i = tid; i < B; i += 256) {
+      uint32_t packed = 0x80008000u;
+      double r = (double)ranges_ref[(size_t)pair * B + i];
+      if (r < P.max_range && r > P.min_range) {
+        double x = beam_cos[i] * r, y = beam_sin[i] * r;
+        double wx = (P.lp_c * x - P.lp_s * y) + P.lp_x, wy = (P.lp_s * x + P.lp_c * y) + P.lp_y;
+        float fx = (float)wx, fy = (float)wy;
+        float gx = (fx - P.ll_x) * P.inv_res, gy = (fy - P.ll_y) * P.inv_res;
+        gx = fminf(fmaxf(gx, -30000.f), 30000.f);
+        gy = fminf(fmaxf(gy, -30000.f), 30000.f);
+        int rx = __float2int_rn(gx), ry = __float2int_rn(gy);
+        packed = ((uint32_t)(uint16_t)(int16_t)rx) | ((uint32_t)(uint16_t)(int16_t)ry << 16);
+        int x0 = max(rx - ctr, 0), x1 = min(rx + ctr, P.nx - 1), y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
+        if (x0 <= x1 && y0 <= y1)
+          for (int tx = x0 >> 3; tx <= (x1 >> 3); tx++)
+            for (int ty = y0 >> 3; ty <= (y1 >> 3); ty++) S.dir[tx * nty + ty] = 1;
+      }
+      rcell[i] = packed;
+    }
+    __syncthreads();
+    // assign tile indices in directory order
+    {
+      const int per = (ndir + 255) / 256;
+      const int b0 = tid * per, b1 = min(ndir, b0 + per);
+      int cnt = 0;
+      for (int q = b0; q < b1; q++) cnt += S.dir[q];
+      int ntile;
+      int base = block_scan_excl(cnt, S.scan, &ntile);
+      for (int q = b0; q < b1; q++) {
+        if (S.dir[q]) S.dir[q] = (uint16_t)base++;
+        else S.dir[q] = 0xFFFF;
+      }
+      if (tid == 0) S.misc[0] = ntile;
+      if (ntile > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
+    }
+    __syncthreads();
+    const int ntile = S.misc[0];
+    for (int q = tid; q < min(ntile, NT_LDS) * 16; q += 256) S.tiles[q] = fill4;
+    for (int q = tid; q < max(0, ntile - NT_LDS) * 16; q += 256) gtiles[q] = fill4;
+    __syncthreads();
+    // stamp: work item = (reference point, kernel row); byte-min through compare-and-swap on 32-bit words
+    for (int wi = tid; wi < B * P.kdim; wi += 256) {
+      int p = wi / P.kdim, ki = wi - p * P.kdim;
+      uint32_t packed = rcell[p];
+      if (packed == 0x80008000u) continue;
+      int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+      int x = rx + ki - ctr;
+      if (x < 0 || x >= P.nx) continue;
+      int y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
+      if (y0 > y1) continue;
+      for (int wy = y0 & ~3; wy <= y1; wy += 4) {        // aligned 4-cell words along y
+        uint32_t kv = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          int y = wy + b;
+          uint32_t v = (y >= y0 && y <= y1) ? S.kernel[(y - ry + ctr) * P.kdim + ki] : 0xffu;
+          kv |= v << (8 * b);
+        }
+        int d = S.dir[(x >> 3) * nty + (wy >> 3)];
+        int woff = (x & 7) * 2 + ((wy & 7) >> 2);
+        uint32_t* wp;
+        bool in_lds = d < NT_LDS;
+        if (in_lds) wp = &S.tiles[d * 16 + woff];
+        else wp = &gtiles[(size_t)(d - NT_LDS) * 16 + woff];
+        uint32_t old = *wp;
+        while (true) {
+          uint32_t nw = bytemin4(old, kv);
+          if (nw == old) break;
+          uint32_t seen = atomicCAS(wp, old, nw);
+          if (seen == old) break;
+          old = seen;
+        }
+      }
+    }
+    // ---------------- search window, angle table, bins -----------------------------------------------------
+    if (tid == 0) {
+      const double* g = guess + 3 * (size_t)pair;
+      float lo_xf = (float)(-P.win_x + g[0]), lo_yf = (float)(-P.win_y + g[1]), lo_tf = (float)(-P.win_t + g[2]);
+      float hi_xf = (float)(P.win_x + g[0]), hi_yf = (float)(P.win_y + g[1]), hi_tf = (float)(P.win_t + g[2]);
+      int lo_x = __float2int_rn((lo_xf - P.ll_x) * P.inv_res), lo_y = __float2int_rn((lo_yf - P.ll_y) * P.inv_res);
+      int hi_x = __float2int_rn((hi_xf - P.ll_x) * P.inv_res), hi_y = __float2int_rn((hi_yf - P.ll_y) * P.inv_res);
+      int nth = 0;
+      for (double t = (double)lo_tf; t < (double)hi_tf && nth < MAXTHETA; t += P.theta_res) S.theta[nth++] = t;
+      int ni = max(0, hi_x - lo_x), nj = max(0, hi_y - lo_y);
+      S.misc[1] = lo_x; S.misc[2] = lo_y; S.misc[3] = ni; S.misc[4] = nj; S.misc[5] = nth;
+      // bin ranges (DiscreteTriplet is monotone in each coordinate)
+      int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
+      if (ni > 0 && nj > 0 && nth > 0) {
+        float xa = P.ll_x + (P.res * (float)lo_x), xb = P.ll_x + (P.res * (float)(hi_x - 1));
+        float ya = P.ll_y + (P.res * (float)lo_y), yb = P.ll_y + (P.res * (float)(hi_y - 1));
+        bx0 = (int)((double)xa / P.dx); bx1 = (int)((double)xb / P.dx);
+        by0 = (int)((double)ya / P.dy); by1 = (int)((double)yb / P.dy);
+        bt0 = (int)(S.theta[0] / P.dth); bt1 = (int)(S.theta[nth - 1] / P.dth);
+      }
+      int nbx = bx1 - bx0 + 1, nby = by1 - by0 + 1, nbt = bt1 - bt0 + 1;
+      if (nbx * nby * nbt > MAXBINS || ni * nj > 64 * CAND_U * 64) { atomicExch(err, 3); nbx = nby = nbt = 0; S.misc[5] = 0; }
+      S.misc[6] = bx0; S.misc[7] = by0; S.misc[8] = bt0; S.misc[9] = nbx; S.misc[10] = nby; S.misc[11] = nbt;
+    }
+    __syncthreads();
+    const int lo_x = S.misc[1], lo_y = S.misc[2], ni = S.misc[3], nj = S.misc[4], nth = S.misc[5];
+    const int bx0 = S.misc[6], by0 = S.misc[7], bt0 = S.misc[8], nbx = S.misc[9], nby = S.misc[10], nbt = S.misc[11];
+    const int nbins = nbx * nby * nbt;
+    for (int q = tid; q < nbins; q += 256) S.bins[q] = ~0ULL;
+    for (int q = tid; q < nth; q += 256) {
+      double s, c;
+      portable_sincos(S.theta[q], &s, &c);
+      S.sn[q] = s; S.cs[q] = c;
+    }
+    __syncthreads();
+    const float ikscale = (float)(1. / (float)P.kscale);
+    const int ncand = ni * nj;
+    // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
+    for (int tb = 0; tb < nth; tb += NTH) {
+      const int ti = tb + wave;
+      int k = 0;
+      if (ti < nth) {
+        const double c = S.cs[ti], s = S.sn[ti];
+        uint32_t prev = 0x7fff7fffu;       // (-10000,-10000) can never match: use an impossible packed value
+        bool have_prev = false;
+        for (int base = 0; base < nq; base += 64) {
+          int q = base + lane;
+          uint32_t packed = 0;
+          bool valid = q < nq;
+          if (valid) {
+            double x = qpts[2 * q], y = qpts[2 * q + 1];
+            double px = c * x - s * y, py = s * x + c * y;
+            int ix = (int)(px * (double)P.inv_res), iy = (int)(py * (double)P.inv_res);
+            packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
+          }
+          uint32_t left = __shfl_up(packed, 1, 64);
+          if (lane == 0) left = prev;
+          bool keep = valid && (!(lane == 0 && !have_prev) ? (packed != left) : true);
+          unsigned long long mask = __ballot(keep);
+          int pos = k + __popcll(mask & ((1ULL << lane) - 1ULL));
+          if (keep) S.plist[wave][pos] = packed;
+          k += __popcll(mask);
+          int lastv = min(63, nq - base - 1);
+          prev = __shfl(packed, lastv, 64);
+          have_prev = true;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (ti < nth) {
+        for (int cb = 0; cb < ncand; cb += 64 * CAND_U) {
+          int ci[CAND_U], cj[CAND_U], sum[CAND_U];
+#pragma unroll
+          for (int u = 0; u < CAND_U; u++) {
+            int cidx = cb + u * 64 + lane;
+            int a = cidx / nj, b = cidx - a * nj;
+            ci[u] = lo_x + a * P.x_steps;
+            cj[u] = lo_y + b * P.y_steps;
+            sum[u] = 0;
+          }
+          for (int q = 0; q < k; q++) {
+            uint32_t packed = S.plist[wave][q];
+            int px = (int16_t)(packed & 0xffff), py = (int16_t)(packed >> 16);
+#pragma unroll
+            for (int u = 0; u < CAND_U; u++) {
+              int cx = px + ci[u], cy = py + cj[u];
+              if ((unsigned)cx < (unsigned)P.nx && (unsigned)cy < (unsigned)P.ny) {
+                int d = S.dir[(cx >> 3) * nty + (cy >> 3)];
+                int v = K2;
+                if (d != 0xFFFF) {
+                  int boff = (cx & 7) * 8 + (cy & 7);
+                  if (d < NT_LDS) v = reinterpret_cast<const uint8_t*>(S.tiles)[d * 64 + boff];
+                  else v = reinterpret_cast<const uint8_t*>(gtiles)[(size_t)(d - NT_LDS) * 64 + boff];
+                }
+                sum[u] += v;
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < CAND_U; u++) {
+            int cidx = cb + u * 64 + lane;
+            if (cidx >= ncand) continue;
+            float dsum = (float)sum[u] * ikscale;
+            dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
+            if ((double)dsum < P.max_score) {
+              float wx = P.ll_x + (P.res * (float)ci[u]);
+              float wyy = P.ll_y + (P.res * (float)cj[u]);
+              int bx = (int)((double)wx / P.dx) - bx0, by = (int)((double)wyy / P.dy) - by0;
+              int bt = (int)(S.theta[ti] / P.dth) - bt0;
+              unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
+                                       (unsigned long long)(unsigned)(ti * ncand + cidx);
+              atomicMin(&S.bins[(bx * nby + by) * nbt + bt], key);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---------------- result: lowest score, ties -> first bin in map order (ix, iy, ith) -------------------
+    if (tid == 0) {
+      unsigned long long best = ~0ULL;
+      int nres = 0;
+      for (int q = 0; q < nbins; q++) {
+        unsigned long long kq = S.bins[q];
+        if (kq == ~0ULL) continue;
+        nres++;
+        if ((kq >> 32) < (best >> 32) || best == ~0ULL) best = kq;
+      }
+      if (out_nres) out_nres[pair] = nres;
+      if (best != ~0ULL) {
+        unsigned ord = (unsigned)(best & 0xffffffffu);
+        int ti = ord / ncand, cidx = ord - ti * ncand;
+        int a = cidx / nj, b = cidx - a * nj;
+        float wx = P.ll_x + (P.res * (float)(lo_x + a * P.x_steps));
+        float wyy = P.ll_y + (P.res * (float)(lo_y + b * P.y_steps));
+        out_xyt[3 * (size_t)pair] = (double)wx;
+        out_xyt[3 * (size_t)pair + 1] = (double)wyy;
+        out_xyt[3 * (size_t)pair + 2] = S.theta[ti];
+        out_score[pair] = (double)__uint_as_float((unsigned)(best >> 32));
+        out_found[pair] = 1;
+      } else {
+        out_xyt[3 * (size_t)pair] = 0; out_xyt[3 * (size_t)pair + 1] = 0; out_xyt[3 * (size_t)pair + 2] = 0;
+        out_score[pair] = 0;
+        out_found[pair] = 0;
+      }
+    }
+  }
+}
+
+size_t match_smem_bytes() { return sizeof(Smem); }
+
+void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref,
+                              const float* ranges_qry, const double* guess, const double* beam_cos,
+                              const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
+                              double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_close_batch),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(256), sizeof(Smem), st, P, ranges_ref, ranges_qry, guess,
+                     beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err);
+}
+
+}  // namespace cgmr

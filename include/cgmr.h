@@ -97,6 +97,57 @@ int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]);
 int cgmr_set_profiling(cgmr_ctx* ctx, int on);
 int cgmr_gn_kernel_times(const cgmr_ctx* ctx, double seconds_out[8], int64_t launches_out[8]);
 
+/* ------------------------------------------------------------------------------------------
+ * Correlative scan matcher.
+ * Replaces: ScanMatcher::{initializeKernel, initializeGrid, resetGrid, closeScanMatching}
+ *           src/matcher/scan_matcher.h:45-53, src/matcher/scan_matcher.cpp:38-189
+ *           and underneath CharGrid::{addAndConvolvePoints, subsample, greedySearch}
+ *           src/matcher/chargrid.h:127-216, src/matcher/chargrid.cpp:61-308
+ * (there is no Matcher::match() in the reference).
+ *
+ * cgmr_matcher_config mirrors the state a ScanMatcher holds after GraphSLAM::init
+ * (src/slam/graph_slam.cpp:58-62) plus the laser description of RobotLaser / LaserParameters.
+ * cgmr_matcher_config_close() fills in the reference's close-matcher defaults:
+ * grid [-15,15]^2 at 0.025 m, kernel range 0.2 m, kscale 128, window +/-(0.3 m, 0.3 m, 0.2 rad),
+ * theta step 0.00625, result bins (0.5, 0.5, 0.2), query subsampling 0.1 m.                */
+typedef struct cgmr_matcher_config {
+  float grid_ll_x, grid_ll_y, grid_ur_x, grid_ur_y;   /* initializeGrid(lowerLeft, upperRight, res) */
+  double resolution;                                  /* grid resolution and kernel resolution      */
+  double kernel_range;                                /* initializeKernel(resolution, kernelRange)  */
+  int kscale;                                         /* 128 (scan_matcher.cpp:35)                  */
+  double win_x, win_y, win_theta;                     /* half widths of the search window           */
+  double theta_res;
+  double bin_x, bin_y, bin_theta;                     /* resultsDiscretization                      */
+  double subsample_res;
+  /* laser */
+  int n_beams;
+  double angle_min, angle_inc, max_range, min_range;
+  double laser_pose[3];                               /* laserParams().laserPose (x, y, theta)      */
+} cgmr_matcher_config;
+
+void cgmr_matcher_config_close(cgmr_matcher_config* cfg, int n_beams, double angle_min, double angle_inc,
+                               double max_range);
+
+/* Batched bool ScanMatcher::closeScanMatching(vset, origin, current, SE2* trel, double maxScore)
+ * (src/matcher/scan_matcher.cpp:112-189) for n_pairs independent (reference scan, current scan) pairs,
+ * each with a single-scan reference set whose vertex is the origin vertex:
+ *   ranges_ref / ranges_qry [n_pairs * n_beams] float32   raw laser ranges (sensor_msgs/LaserScan order)
+ *   guess_xyt  [n_pairs * 3]   origin^-1 * current (the odometry guess)
+ *   out_xyt    [n_pairs * 3]   matched relative pose (mresvec[0]); zeros when not found
+ *   out_score  [n_pairs]       score of that result
+ *   out_found  [n_pairs]       the bool return value
+ *   out_nresults (nullable) [n_pairs]  number of entries mresvec would have had
+ * Host-pointer variant copies in and out; the _dev variant takes device pointers for every array.   */
+int cgmr_match_close_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const float* ranges_ref,
+                           const float* ranges_qry, const double* guess_xyt, double max_score, double* out_xyt,
+                           double* out_score, uint8_t* out_found, int32_t* out_nresults);
+int cgmr_match_close_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs,
+                               const float* d_ranges_ref, const float* d_ranges_qry, const double* d_guess_xyt,
+                               double max_score, double* d_out_xyt, double* d_out_score, uint8_t* d_out_found,
+                               int32_t* d_out_nresults);
+/* Device time (HIP events on the context's stream) of the last matcher launch, seconds. */
+int cgmr_match_last_kernel_seconds(const cgmr_ctx* ctx, double* seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,3 +138,130 @@ def covariance_estimate(poses, ef, et, meas, info, gauge, query):
                                        _p(info, C.c_double), C.c_int(int(gauge)), C.c_int(len(query)),
                                        _p(query, C.c_int32), _p(cov, C.c_double))
     return st, cov
+
+
+# ---------------------------------------------------------------------------- matcher
+
+class _Result(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("theta", C.c_double), ("score", C.c_double)]
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def sincos(x):
+    s = C.c_double()
+    c = C.c_double()
+    lib().cmo_sincos(C.c_double(float(x)), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def make_kernel(resolution, kernel_range, kscale=128):
+    buf = np.zeros(64 * 64, dtype=np.uint8)
+    dim = lib().cmo_make_kernel(C.c_double(resolution), C.c_double(kernel_range), C.c_int(kscale), _p(buf, C.c_uint8),
+                                C.c_int(buf.size))
+    if dim < 0:
+        raise ValueError("kernel does not fit a signed char")
+    return buf[:dim * dim].reshape(dim, dim).copy()       # [col j][row i] == symmetric
+
+
+def grid_dims(ll, ur, res):
+    nx, ny, ir = C.c_int(), C.c_int(), C.c_float()
+    lib().cmo_grid_dims(C.c_float(ll[0]), C.c_float(ll[1]), C.c_float(ur[0]), C.c_float(ur[1]), C.c_float(res),
+                        C.byref(nx), C.byref(ny), C.byref(ir))
+    return nx.value, ny.value, ir.value
+
+
+def rasterize(ll, ur, res, kernel_res, kernel_range, pts, kscale=128):
+    pts = _f64(pts).reshape(-1, 2)
+    nx, ny, _ = grid_dims(ll, ur, res)
+    cells = np.zeros((nx, ny), dtype=np.uint8)
+    a, b = C.c_int(), C.c_int()
+    rc = lib().cmo_rasterize(C.c_float(ll[0]), C.c_float(ll[1]), C.c_float(ur[0]), C.c_float(ur[1]), C.c_float(res),
+                             C.c_double(kernel_res), C.c_double(kernel_range), C.c_int(kscale), C.c_int(len(pts)),
+                             _p(pts, C.c_double), _p(cells, C.c_uint8), C.byref(a), C.byref(b))
+    assert rc == 0
+    return cells
+
+
+def subsample(pts, res=0.1):
+    pts = _f64(pts).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    n = lib().cmo_subsample(C.c_int(len(pts)), _p(pts, C.c_double), C.c_double(res), _p(out, C.c_double))
+    return out[:n].copy()
+
+
+def cartesian(ranges, angle_min, angle_inc, max_range, min_range=0.0):
+    ranges = _f32(ranges)
+    out = np.zeros((len(ranges), 2))
+    n = lib().cmo_cartesian(C.c_int(len(ranges)), _p(ranges, C.c_float), C.c_double(angle_min), C.c_double(angle_inc),
+                            C.c_double(max_range), C.c_double(min_range), _p(out, C.c_double))
+    return out[:n].copy()
+
+
+def apply_transf(tr, pts):
+    tr, pts = _f64(tr), _f64(pts).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    lib().cmo_apply_transf(_p(tr, C.c_double), C.c_int(len(pts)), _p(pts, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def _grid_args(ll, ur, res, kernel_res, kernel_range, kscale):
+    return (C.c_float(ll[0]), C.c_float(ll[1]), C.c_float(ur[0]), C.c_float(ur[1]), C.c_float(res),
+            C.c_double(kernel_res), C.c_double(kernel_range), C.c_int(kscale))
+
+
+def _results(buf, n, cap):
+    n = min(n, cap)
+    return np.array([[buf[k].x, buf[k].y, buf[k].theta, buf[k].score] for k in range(n)]).reshape(-1, 4)
+
+
+def greedy_search(ll, ur, res, kernel_res, kernel_range, ref_pts, q_pts, regions, step_xy, theta_res, max_score,
+                  dx, dy, dth, kscale=128, cap=4096):
+    ref_pts, q_pts = _f64(ref_pts).reshape(-1, 2), _f64(q_pts).reshape(-1, 2)
+    regions = _f32(regions).reshape(-1, 6)
+    buf = (_Result * cap)()
+    n = lib().cmo_greedy_search(*_grid_args(ll, ur, res, kernel_res, kernel_range, kscale), C.c_int(len(ref_pts)),
+                                _p(ref_pts, C.c_double), C.c_int(len(q_pts)), _p(q_pts, C.c_double),
+                                C.c_int(len(regions)), _p(regions, C.c_float), C.c_double(step_xy), C.c_double(step_xy),
+                                C.c_double(theta_res), C.c_double(max_score), C.c_double(dx), C.c_double(dy),
+                                C.c_double(dth), buf, C.c_int(cap))
+    if n < 0:
+        raise ValueError("greedy_search failed")
+    return n, _results(buf, n, cap)
+
+
+def hierarchical_search(ll, ur, res, kernel_res, kernel_range, ref_pts, q_pts, regions, theta_res, max_score,
+                        dx, dy, dth, n_levels, kscale=128, cap=4096):
+    ref_pts, q_pts = _f64(ref_pts).reshape(-1, 2), _f64(q_pts).reshape(-1, 2)
+    regions = _f32(regions).reshape(-1, 6)
+    buf = (_Result * cap)()
+    n = lib().cmo_hierarchical_search(*_grid_args(ll, ur, res, kernel_res, kernel_range, kscale),
+                                      C.c_int(len(ref_pts)), _p(ref_pts, C.c_double), C.c_int(len(q_pts)),
+                                      _p(q_pts, C.c_double), C.c_int(len(regions)), _p(regions, C.c_float),
+                                      C.c_double(theta_res), C.c_double(max_score), C.c_double(dx), C.c_double(dy),
+                                      C.c_double(dth), C.c_int(n_levels), buf, C.c_int(cap))
+    if n < 0:
+        raise ValueError("hierarchical_search failed")
+    return n, _results(buf, n, cap)
+
+
+def close_scan_match_batch(ranges_ref, ranges_qry, angle_min, angle_inc, max_range, laser_pose, guess,
+                           resolution=0.025, kernel_range=0.2, max_score=0.15):
+    rr, rq = _f32(ranges_ref), _f32(ranges_qry)
+    if rr.ndim == 1:
+        rr, rq = rr[None], rq[None]
+    P, B = rr.shape
+    guess = _f64(guess).reshape(P, 3)
+    lp = _f64(laser_pose)
+    xyt = np.zeros((P, 3))
+    score = np.zeros(P)
+    found = np.zeros(P, dtype=np.uint8)
+    rc = lib().cmo_close_scan_match_batch(C.c_int(P), C.c_int(B), _p(rr, C.c_float), _p(rq, C.c_float),
+                                          C.c_double(angle_min), C.c_double(angle_inc), C.c_double(max_range),
+                                          _p(lp, C.c_double), _p(guess, C.c_double), C.c_double(resolution),
+                                          C.c_double(kernel_range), C.c_double(max_score), _p(xyt, C.c_double),
+                                          _p(score, C.c_double), _p(found, C.c_uint8))
+    assert rc == 0
+    return xyt, score, found
