@@ -56,6 +56,13 @@ def load_library():
     if not os.path.exists(path):
         raise CgmrError(-2, f"{path} not found: build it with __graft_entry__.build() "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process cannot both own the GPU
+    # ("No HIP GPUs are available" from whichever initialises second).  Importing torch first makes the
+    # dynamic loader resolve libcgmr.so's libamdhip64 dependency to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.cgmr_last_error.restype = C.c_char_p
     lib.cgmr_ctx_destroy.restype = None

@@ -1,5 +1,6 @@
 // C ABI of the scan matcher (include/cgmr.h): configuration, buffers, launch.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -60,7 +61,7 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const 
   P.nx = (int)((cfg->grid_ur_x - cfg->grid_ll_x) * P.inv_res);
   P.ny = (int)((cfg->grid_ur_y - cfg->grid_ll_y) * P.inv_res);
   int ntx = (P.nx + 7) / 8, nty = (P.ny + 7) / 8;
-  if (P.nx <= 0 || P.ny <= 0 || ntx * nty > kMatchMaxDir)
+  if (P.nx <= 0 || P.ny <= 0 || (ntx + 2) * (nty + 6) > kMatchMaxDir)
     return set_err(ctx, CGMR_E_INVALID, "grid %dx%d cells exceeds the %d-tile directory", P.nx, P.ny, kMatchMaxDir);
   P.kscale = cfg->kscale;
   std::vector<uint8_t> kern;

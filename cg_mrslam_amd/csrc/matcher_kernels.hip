@@ -115,21 +115,29 @@ __device__ void portable_sincos(double x, double* s, double* c) {
 constexpr int NT_LDS = kMatchTilesLds;       // tiles held in LDS
 constexpr int MAXPTS = kMatchMaxPoints;      // max beams / points per scan
 constexpr int NTH = 4;                       // search angles processed concurrently (one per wavefront)
+constexpr int PT = 4;                        // points gathered per inner iteration of the fast search path
 constexpr int CAND_U = 9;                    // candidates per lane per block (64*9 = 576 = 24x24)
 constexpr int MAXBINS = 512;
 constexpr int MAXTHETA = kMatchMaxTheta;
 
 struct Smem {
-  uint16_t dir[kMatchMaxDir];                // tile directory: 0xFFFF = untouched (all cells = fill)
-  uint32_t tiles[NT_LDS * 16];               // 64-byte tiles, cell (x&7, y&7) at byte (x&7)*8 + (y&7)
-  uint32_t plist[NTH][MAXPTS];               // per-angle point lists: int16 x | int16 y << 16
+  uint32_t tiles[NT_LDS * 16];               // 64-byte tiles, cell (x&7, y&7) at byte (x&7)*8 + (y&7)   (16-B aligned)
+  uint32_t plist[NTH][MAXPTS];               // per-angle point lists: int16 x | int16 y << 16           (16-B aligned)
   unsigned long long bins[MAXBINS];          // (score bits << 32 | visit order), min = best, first seen
   double theta[MAXTHETA], cs[MAXTHETA], sn[MAXTHETA];
   uint8_t kernel[1024];
   int scan[260];
   int misc[16];
+  uint16_t dir[kMatchMaxDir];                // tile directory: 0xFFFF = untouched (all cells = fill)
 };
 static_assert(sizeof(Smem) <= 160 * 1024, "matcher LDS plan exceeds 160 KiB");
+
+#ifdef CGMR_PHASE_TIMING
+__device__ unsigned long long g_mphase[16];
+#define MPHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mphase[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MPHASE(i)
+#endif
 
 __device__ __forceinline__ uint32_t bytemin4(uint32_t a, uint32_t b) {
   uint32_t r = 0;
@@ -182,13 +190,18 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
   double* qpts = qraw + 2 * MAXPTS;                                       // 2 * MAXPTS
   uint32_t* gtiles = reinterpret_cast<uint32_t*>(qpts + 2 * MAXPTS);      // overflow tiles
   const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
-  const int ndir = ntx * nty;
+  // directory with a guard band (1 tile row above/below, 3 tile columns left/right) so that the fast search
+  // path can look up cells outside the grid without a bounds test: guard entries point at the all-zero tile
+  const int DW = nty + 6;
+  const int ndir = (ntx + 2) * DW;
+#define DIRIDX(tx, ty) (((tx) + 1) * DW + (ty) + 3)
   const int K2 = P.fill;
   const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
   for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
 
   for (int pair = blockIdx.x; pair < P.n_pairs; pair += gridDim.x) {
     __syncthreads();
+    MPHASE(0);
     // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
     // sort keys live in the (not yet used) tile pool: 2048 x u64
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(S.tiles);
@@ -221,6 +234,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
         __syncthreads();
       }
     }
+    MPHASE(1);
     // bucket leaders: sorted position i starts a bucket if its (kx,ky) differs from position i-1
     int nlead = 0;
     int lead_pos[8];
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
       }
     }
     __syncthreads();
+    MPHASE(2);
     // ---------------- reference scan -> cells; directory of touched tiles ---------------------------------
     for (int q = tid; q < (ndir + 1) / 2; q += 256) reinterpret_cast<uint32_t*>(S.dir)[q] = 0;
     uint32_t* rcell = S.plist[0];           // int16 x | int16 y << 16, 0x80008000 = invalid
@@ -277,11 +292,12 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
         int x0 = max(rx - ctr, 0), x1 = min(rx + ctr, P.nx - 1), y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
         if (x0 <= x1 && y0 <= y1)
           for (int tx = x0 >> 3; tx <= (x1 >> 3); tx++)
-            for (int ty = y0 >> 3; ty <= (y1 >> 3); ty++) S.dir[tx * nty + ty] = 1;
+            for (int ty = y0 >> 3; ty <= (y1 >> 3); ty++) S.dir[DIRIDX(tx, ty)] = 1;
       }
       rcell[i] = packed;
     }
     __syncthreads();
+    MPHASE(3);
     // assign tile indices in directory order
     {
       const int per = (ndir + 255) / 256;
@@ -290,21 +306,36 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
       for (int q = b0; q < b1; q++) cnt += S.dir[q];
       int ntile;
       int base = block_scan_excl(cnt, S.scan, &ntile);
+      // fast path: every tile (plus an all-fill and an all-zero tile) is resident in LDS and the grid is a
+      // whole number of tiles, so the search can gather without branches: untouched directory entries
+      // point at the all-fill tile, cells outside the grid are redirected to the all-zero tile.
+      const bool fastp = (ntile + 2 <= NT_LDS) && ((P.nx & 7) == 0) && ((P.ny & 7) == 0) && P.x_steps == 1 &&
+                         P.y_steps == 1 && K2 * PT <= 255;
       for (int q = b0; q < b1; q++) {
+        const int row = q / DW, col = q - row * DW;
+        const bool guard = row == 0 || row == ntx + 1 || col < 3 || col >= nty + 3;
         if (S.dir[q]) S.dir[q] = (uint16_t)base++;
-        else S.dir[q] = 0xFFFF;
+        else S.dir[q] = fastp ? (uint16_t)(guard ? ntile + 1 : ntile) : (uint16_t)0xFFFF;
       }
-      if (tid == 0) S.misc[0] = ntile;
+      if (tid == 0) { S.misc[0] = ntile; S.misc[12] = fastp ? 1 : 0; }
       if (ntile > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
     }
     __syncthreads();
     const int ntile = S.misc[0];
+    const bool fast = S.misc[12] != 0;
+    const int T_FILL = ntile, T_ZERO = ntile + 1;
+    if (fast && tid < 16) { S.tiles[T_FILL * 16 + tid] = fill4; S.tiles[T_ZERO * 16 + tid] = 0u; }
     for (int q = tid; q < min(ntile, NT_LDS) * 16; q += 256) S.tiles[q] = fill4;
     for (int q = tid; q < max(0, ntile - NT_LDS) * 16; q += 256) gtiles[q] = fill4;
     __syncthreads();
+    MPHASE(4);
     // stamp: work item = (reference point, kernel row); byte-min through compare-and-swap on 32-bit words
-    for (int wi = tid; wi < B * P.kdim; wi += 256) {
-      int p = wi / P.kdim, ki = wi - p * P.kdim;
+    // neighbouring beams stamp overlapping cells; spread concurrently processed items over far-apart
+    // beams (stride 67 modulo a prime-ish count) so that the compare-and-swap rarely has to retry
+    const int Bp = B | 1;                                  // odd => 64 | 67 strides visit every residue
+    for (int wi = tid; wi < Bp * P.kdim; wi += 256) {
+      int ki = wi / Bp, p = (int)(((long long)(wi - ki * Bp) * 67) % Bp);
+      if (p >= B) continue;
       uint32_t packed = rcell[p];
       if (packed == 0x80008000u) continue;
       int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
@@ -320,7 +351,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
           uint32_t v = (y >= y0 && y <= y1) ? S.kernel[(y - ry + ctr) * P.kdim + ki] : 0xffu;
           kv |= v << (8 * b);
         }
-        int d = S.dir[(x >> 3) * nty + (wy >> 3)];
+        int d = S.dir[DIRIDX(x >> 3, wy >> 3)];
         int woff = (x & 7) * 2 + ((wy & 7) >> 2);
         uint32_t* wp;
         bool in_lds = d < NT_LDS;
@@ -336,6 +367,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
         }
       }
     }
+    MPHASE(5);
     // ---------------- search window, angle table, bins -----------------------------------------------------
     if (tid == 0) {
       const double* g = guess + 3 * (size_t)pair;
@@ -373,6 +405,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     __syncthreads();
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
+    MPHASE(6);
     // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
     for (int tb = 0; tb < nth; tb += NTH) {
       const int ti = tb + wave;
@@ -402,9 +435,98 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
           prev = __shfl(packed, lastv, 64);
           have_prev = true;
         }
+        if (lane < PT) S.plist[wave][k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
       }
       __builtin_amdgcn_wave_barrier();
-      if (ti < nth) {
+      if (ti < nth && fast) {
+        // ---- fast path: lane = (x-row a, segment of 12 consecutive y offsets) ----
+        const int nseg = (nj + 11) / 12;
+        const int njobs = ni * nseg;
+        const int flush_every = 255 / K2;                 // packed-byte partial sums cannot overflow before this
+        const uint8_t* tb = reinterpret_cast<const uint8_t*>(S.tiles);
+        for (int job = lane; job < njobs; job += 64) {
+          const int a = job / nseg, seg = job - a * nseg;
+          const int b0 = seg * 12;
+          const int ncell = min(12, nj - b0);
+          const int offx = lo_x + a, offy = lo_y + b0;
+          uint32_t part0 = 0, part1 = 0, part2 = 0;
+          int acc[12];
+#pragma unroll
+          for (int c = 0; c < 12; c++) acc[c] = 0;
+          int npart = 0;
+          const uint32_t m2 = ncell >= 12 ? 0xffffffffu : (ncell <= 8 ? 0u : (0xffffffffu >> (8 * (12 - ncell))));
+          const uint32_t m1 = ncell >= 8 ? 0xffffffffu : (ncell <= 4 ? 0u : (0xffffffffu >> (8 * (8 - ncell))));
+          const uint32_t m0 = ncell >= 4 ? 0xffffffffu : (0xffffffffu >> (8 * (4 - ncell)));
+          const int flush_iters = max(1, flush_every / PT);
+          const int cxlo = -8, cxhi = P.nx + 7, cylo = -24, cyhi = P.ny;
+          for (int q = 0; q < k; q += PT) {
+            const uint4 pk4 = *reinterpret_cast<const uint4*>(&S.plist[wave][q]);
+            const uint32_t pk[PT] = {pk4.x, pk4.y, pk4.z, pk4.w};
+            int d[PT][3], rowoff[PT], o[PT];
+#pragma unroll
+            for (int u = 0; u < PT; u++) {
+              // clamp into the guard band: anything beyond it reads the all-zero tile anyway
+              const int cx = min(max((int)(int16_t)(pk[u] & 0xffff) + offx, cxlo), cxhi);
+              const int cy0 = min(max((int)(int16_t)(pk[u] >> 16) + offy, cylo), cyhi);
+              const uint16_t* dp = &S.dir[((cx >> 3) + 1) * DW + (cy0 >> 3) + 3];
+              d[u][0] = dp[0]; d[u][1] = dp[1]; d[u][2] = dp[2];
+              o[u] = cy0 & 7;
+              rowoff[u] = (cx & 7) * 8;
+            }
+            uint32_t D[PT][6];
+#pragma unroll
+            for (int u = 0; u < PT; u++)
+#pragma unroll
+              for (int t = 0; t < 3; t++) {
+                const uint2 w = *reinterpret_cast<const uint2*>(tb + d[u][t] * 64 + rowoff[u]);
+                D[u][2 * t] = w.x;
+                D[u][2 * t + 1] = w.y;
+              }
+#pragma unroll
+            for (int u = 0; u < PT; u++) {
+              const bool hi = o[u] >= 4;
+              const uint32_t E0 = hi ? D[u][1] : D[u][0], E1 = hi ? D[u][2] : D[u][1], E2 = hi ? D[u][3] : D[u][2],
+                             E3 = hi ? D[u][4] : D[u][3];
+              const uint32_t sh = (uint32_t)(o[u] & 3);
+              part0 += __builtin_amdgcn_alignbyte(E1, E0, sh) & m0;
+              part1 += __builtin_amdgcn_alignbyte(E2, E1, sh) & m1;
+              part2 += __builtin_amdgcn_alignbyte(E3, E2, sh) & m2;
+            }
+            if (++npart == flush_iters) {
+#pragma unroll
+              for (int c = 0; c < 4; c++) {
+                acc[c] += (part0 >> (8 * c)) & 0xff;
+                acc[4 + c] += (part1 >> (8 * c)) & 0xff;
+                acc[8 + c] += (part2 >> (8 * c)) & 0xff;
+              }
+              part0 = part1 = part2 = 0;
+              npart = 0;
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            acc[c] += (part0 >> (8 * c)) & 0xff;
+            acc[4 + c] += (part1 >> (8 * c)) & 0xff;
+            acc[8 + c] += (part2 >> (8 * c)) & 0xff;
+          }
+#pragma unroll
+          for (int c = 0; c < 12; c++) {
+            if (c >= ncell) continue;
+            const int cidx = a * nj + b0 + c;
+            float dsum = (float)acc[c] * ikscale;
+            dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
+            if ((double)dsum < P.max_score) {
+              float wx = P.ll_x + (P.res * (float)offx);
+              float wyy = P.ll_y + (P.res * (float)(offy + c));
+              int bx = (int)((double)wx / P.dx) - bx0, by = (int)((double)wyy / P.dy) - by0;
+              int bt = (int)(S.theta[ti] / P.dth) - bt0;
+              unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
+                                       (unsigned long long)(unsigned)(ti * ncand + cidx);
+              atomicMin(&S.bins[(bx * nby + by) * nbt + bt], key);
+            }
+          }
+        }
+      } else if (ti < nth) {
         for (int cb = 0; cb < ncand; cb += 64 * CAND_U) {
           int ci[CAND_U], cj[CAND_U], sum[CAND_U];
 #pragma unroll
@@ -422,7 +544,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
             for (int u = 0; u < CAND_U; u++) {
               int cx = px + ci[u], cy = py + cj[u];
               if ((unsigned)cx < (unsigned)P.nx && (unsigned)cy < (unsigned)P.ny) {
-                int d = S.dir[(cx >> 3) * nty + (cy >> 3)];
+                int d = S.dir[DIRIDX(cx >> 3, cy >> 3)];
                 int v = K2;
                 if (d != 0xFFFF) {
                   int boff = (cx & 7) * 8 + (cy & 7);
@@ -454,6 +576,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    MPHASE(7);
     // ---------------- result: lowest score, ties -> first bin in map order (ix, iy, ith) -------------------
     if (tid == 0) {
       unsigned long long best = ~0ULL;
@@ -482,6 +605,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
         out_found[pair] = 0;
       }
     }
+    MPHASE(8);
   }
 }
 
@@ -502,3 +626,9 @@ void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P,
 }
 
 }  // namespace cgmr
+
+#ifdef CGMR_PHASE_TIMING
+extern "C" int cgmr_debug_mphase(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_mphase), sizeof(unsigned long long) * 16);
+}
+#endif

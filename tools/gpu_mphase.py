@@ -1,0 +1,17 @@
+import sys, os, ctypes as C, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cg_mrslam_amd import synth, Context, load_library
+from cg_mrslam_amd.matcher import ScanMatcher
+ctx = Context(0)
+sp = synth.make_scan_pairs(8, seed=5)
+m = ScanMatcher(ctx, sp["n_beams"], sp["angle_min"], sp["angle_inc"], sp["max_range"])
+for r in range(2):
+    found, xyt, score = m.closeScanMatching(sp["ranges_ref"], sp["ranges_qry"], sp["guess"])
+print("kernel s", m.last_kernel_seconds())
+out = np.zeros(16, dtype=np.uint64)
+print(load_library().cgmr_debug_mphase(C.c_void_p(out.ctypes.data)))
+o = out.astype(np.int64)
+names = ["qry cartesian+sort", "subsample means", "ref cells+dir", "dir scan+tile init", "stamp", "window/theta", "search", "result"]
+for i, n in enumerate(names):
+    print(f"{n:22s} {o[i+1]-o[i]:>10d}")
+print("total", o[8]-o[0])

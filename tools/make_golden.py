@@ -37,8 +37,22 @@ def gn_case(name, V, E, seed, iters, extra_fixed=()):
     print(name, "chi2", chi2[0], "->", chi2[-1])
 
 
+def match_case(name, n_pairs, seed):
+    """Matcher golden vectors: inputs + the C oracle's outputs (oracle/matcher_oracle.c).  The reference's own
+    matcher cannot be built here (needs Eigen), so these pin the restatement, not the reference binary."""
+    from oracle import oracle as O
+    sp = synth.make_scan_pairs(n_pairs, seed=seed)
+    xyt, score, found = O.close_scan_match_batch(sp["ranges_ref"], sp["ranges_qry"], sp["angle_min"], sp["angle_inc"],
+                                                 sp["max_range"], [0, 0, 0], sp["guess"])
+    np.savez_compressed(os.path.join(OUT, f"match_{name}.npz"), ranges_ref=sp["ranges_ref"], ranges_qry=sp["ranges_qry"],
+                        guess=sp["guess"], true_rel=sp["true_rel"], angle_min=sp["angle_min"], angle_inc=sp["angle_inc"],
+                        max_range=sp["max_range"], xyt=xyt, score=score, found=found)
+    print(name, "found", int(found.sum()), "/", n_pairs)
+
+
 if __name__ == "__main__":
     gn_case("v60", 60, 110, 11, 6)
     gn_case("v300", 300, 800, 12, 8)
     gn_case("v300_multifix", 300, 800, 13, 8, extra_fixed=(7, 150, 299))
     gn_case("v1200", 1200, 4000, 14, 8)
+    match_case("close12", 12, 101)
