@@ -133,6 +133,52 @@ class Context:
         self._check(rc, allow_cholesky=not raise_on_cholesky)
         return rc, chi
 
+    # ------------------------------------------------------------------ marginals / condensed graph
+    @staticmethod
+    def _graph_args(poses, ef, et, meas, info):
+        return (np.ascontiguousarray(poses, dtype=np.float64), np.ascontiguousarray(ef, dtype=np.int32),
+                np.ascontiguousarray(et, dtype=np.int32), np.ascontiguousarray(meas, dtype=np.float64),
+                np.ascontiguousarray(info, dtype=np.float64))
+
+    def marginals(self, poses, fixed, ef, et, meas, info, query):
+        """3x3 blocks of H^-1 (H linearised at ``poses``) for the query vertex indices."""
+        poses, ef, et, meas, info = self._graph_args(poses, ef, et, meas, info)
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        query = np.ascontiguousarray(query, dtype=np.int32)
+        cov = np.zeros((len(query), 3, 3))
+        rc = self.lib.cgmr_marginals(self.h, C.c_int(poses.shape[0]), _ptr(poses), _ptr(fixed), C.c_int(len(ef)),
+                                     _ptr(ef), _ptr(et), _ptr(meas), _ptr(info), C.c_int(len(query)), _ptr(query),
+                                     _ptr(cov))
+        self._check(rc)
+        return cov
+
+    def covariance_estimate(self, poses, ef, et, meas, info, gauge, query):
+        """CovarianceEstimator::compute + getCovariance (src/slam/graph_manipulator.cpp:128-157)."""
+        poses, ef, et, meas, info = self._graph_args(poses, ef, et, meas, info)
+        query = np.ascontiguousarray(query, dtype=np.int32)
+        cov = np.zeros((len(query), 3, 3))
+        rc = self.lib.cgmr_covariance_estimate(self.h, C.c_int(poses.shape[0]), _ptr(poses), C.c_int(len(ef)), _ptr(ef),
+                                               _ptr(et), _ptr(meas), _ptr(info), C.c_int(int(gauge)),
+                                               C.c_int(len(query)), _ptr(query), _ptr(cov))
+        self._check(rc)
+        return cov
+
+    def condense(self, poses, ef, et, meas, info, gauge, query):
+        """CondensedGraphCreator::compute: returns (to[n], est[n,3], info_upper[n,6], cov[n,3,3])."""
+        poses, ef, et, meas, info = self._graph_args(poses, ef, et, meas, info)
+        query = np.ascontiguousarray(query, dtype=np.int32)
+        n = max(len(query), 1)
+        to = np.zeros(n, dtype=np.int32)
+        est = np.zeros((n, 3))
+        iu = np.zeros((n, 6))
+        cov = np.zeros((n, 3, 3))
+        rc = self.lib.cgmr_condense(self.h, C.c_int(poses.shape[0]), _ptr(poses), C.c_int(len(ef)), _ptr(ef), _ptr(et),
+                                    _ptr(meas), _ptr(info), C.c_int(int(gauge)), C.c_int(len(query)), _ptr(query),
+                                    _ptr(to), _ptr(est), _ptr(iu), _ptr(cov))
+        if rc < 0:
+            self._check(rc)
+        return to[:rc].copy(), est[:rc].copy(), iu[:rc].copy(), cov[:rc].copy()
+
     def gn_last_timing(self):
         out = np.zeros(5)
         self._check(self.lib.cgmr_gn_last_timing(self.h, _ptr(out)))

@@ -6,7 +6,9 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace cgmr {
 
@@ -185,6 +187,26 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
   }
 };
 
+// one Gauss-Newton pass on the uploaded structure: linearise + chi2 [+ assemble + factor [+ solve + update]]
+void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double* d_info, int it, bool chi_only,
+             bool solve_and_update) {
+  GnDevice& D = ctx->gn;
+  hipStream_t st = ctx->stream;
+  KTimer T{ctx};
+  T.run(0, 1, [&] { launch_linearize(st, D, d_poses, D.ef, D.et, d_meas, d_info, chi_only ? 1 : 0); });
+  T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
+  if (chi_only || D.nf == 0) return;
+  T.run(1, 1, [&] { launch_assemble(st, D); });
+  for (int l = 0; l < D.nlevels; l++) {
+    T.run(3, 1, [&] { launch_factor_level(st, D, l, it + 1); });
+    if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
+  }
+  if (!solve_and_update) return;
+  for (int l = 0; l < D.nlevels; l++) T.run(5, 1, [&] { launch_fwd_level(st, D, l); });
+  for (int l = D.nlevels - 1; l >= 0; l--) T.run(6, 1, [&] { launch_bwd_level(st, D, l); });
+  T.run(7, 1, [&] { launch_update(st, D, d_poses); });
+}
+
 int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE, const int32_t* ef,
            const int32_t* et, const double* d_meas, const double* d_info, int iters, double* chi2_out) {
   double t0 = wall_s();
@@ -197,22 +219,8 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   double t2 = wall_s();
   GnDevice& D = ctx->gn;
   hipStream_t st = ctx->stream;
-  KTimer T{ctx};
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-  for (int it = 0; it <= iters; it++) {
-    int last = (it == iters);
-    T.run(0, 1, [&] { launch_linearize(st, D, d_poses, D.ef, D.et, d_meas, d_info, last); });
-    T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
-    if (last || D.nf == 0) continue;
-    T.run(1, 1, [&] { launch_assemble(st, D); });
-    for (int l = 0; l < D.nlevels; l++) {
-      T.run(3, 1, [&] { launch_factor_level(st, D, l, it + 1); });
-      if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
-    }
-    for (int l = 0; l < D.nlevels; l++) T.run(5, 1, [&] { launch_fwd_level(st, D, l); });
-    for (int l = D.nlevels - 1; l >= 0; l--) T.run(6, 1, [&] { launch_bwd_level(st, D, l); });
-    T.run(7, 1, [&] { launch_update(st, D, d_poses); });
-  }
+  for (int it = 0; it <= iters; it++) gn_pass(ctx, d_poses, d_meas, d_info, it, it == iters, true);
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
   // read back chi2 + status
   std::vector<double> chi(iters + 1);
@@ -222,7 +230,7 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
   float ms = 0;
-  hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   if (chi2_out) memcpy(chi2_out, chi.data(), sizeof(double) * (iters + 1));
   ctx->timing[0] = S.t_order;
   ctx->timing[1] = S.t_struct;
@@ -233,6 +241,129 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
     return set_err(ctx, CGMR_E_CHOLESKY_BASE - (status - 1),
                    "Cholesky failed (non-positive pivot) in GN iteration %d; poses left at the last good update",
                    status - 1);
+  return CGMR_OK;
+}
+
+// SparseOptimizer::computeInitialGuess with unit edge cost [g2o-recalled]: breadth-first from the fixed
+// vertices over the given edges (edge order breaks ties), x_to = x_from * z or x_from = x_to * z^-1.
+void initial_guess_host(int nV, double* poses, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et,
+                        const double* meas) {
+  auto norm = [](double t) {
+    const double pi = 3.14159265358979323846;
+    if (t >= -pi && t < pi) return t;
+    return t - 2 * pi * std::floor((t + pi) / (2 * pi));
+  };
+  std::vector<int> deg(nV + 1, 0);
+  for (int k = 0; k < nE; k++) { deg[ef[k] + 1]++; deg[et[k] + 1]++; }
+  for (int v = 0; v < nV; v++) deg[v + 1] += deg[v];
+  std::vector<int> inc(2 * (size_t)nE + 1), pos(deg.begin(), deg.end() - 1);
+  for (int k = 0; k < nE; k++) { inc[pos[ef[k]]++] = k; inc[pos[et[k]]++] = k; }
+  std::vector<uint8_t> seen(nV, 0);
+  std::vector<int> queue;
+  queue.reserve(nV);
+  for (int v = 0; v < nV; v++) if (fixed[v] && deg[v + 1] > deg[v]) { seen[v] = 1; queue.push_back(v); }
+  for (size_t qh = 0; qh < queue.size(); qh++) {
+    int u = queue[qh];
+    for (int p = deg[u]; p < deg[u + 1]; p++) {
+      int k = inc[p];
+      int w = (ef[k] == u) ? et[k] : ef[k];
+      if (seen[w]) continue;
+      seen[w] = 1;
+      const double* a = poses + 3 * (size_t)u;
+      double z[3] = {meas[3 * k], meas[3 * k + 1], meas[3 * k + 2]};
+      if (ef[k] != u) {   // z^-1
+        double c = std::cos(z[2]), s = std::sin(z[2]);
+        double ix = -(c * z[0] + s * z[1]), iy = -(-s * z[0] + c * z[1]);
+        z[0] = ix; z[1] = iy; z[2] = -z[2];
+      }
+      double c = std::cos(a[2]), s = std::sin(a[2]);
+      double* o = poses + 3 * (size_t)w;
+      o[0] = a[0] + c * z[0] - s * z[1];
+      o[1] = a[1] + s * z[0] + c * z[1];
+      o[2] = norm(a[2] + z[2]);
+      queue.push_back(w);
+    }
+  }
+}
+
+// Shared driver of cgmr_marginals / cgmr_covariance_estimate / cgmr_condense (host pointers).
+//   mode 0: marginals at `poses` with `fixed`;  mode 1: covariance estimate (gauge);  mode 2: condense (gauge)
+int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const uint8_t* fixed_in, int nE,
+                    const int32_t* ef, const int32_t* et, const double* meas, const double* info, int gauge, int nK,
+                    const int32_t* query, int32_t* to_out, double* est_out, double* info_out, double* cov_out) {
+  if (nV <= 0 || nE < 0 || nK < 0 || !poses || (nE > 0 && (!ef || !et || !meas || !info)) || (nK > 0 && !query))
+    return set_err(ctx, CGMR_E_INVALID, "marginals: null or negative argument");
+  if (mode != 0 && (gauge < 0 || gauge >= nV)) return set_err(ctx, CGMR_E_INVALID, "gauge index out of range");
+  for (int k = 0; k < nK; k++)
+    if (query[k] < 0 || query[k] >= nV) return set_err(ctx, CGMR_E_INVALID, "query index out of range");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<uint8_t> fixed(nV, 0);
+  std::vector<double> work(poses, poses + 3 * (size_t)nV);             // pushState: the caller's poses stay untouched
+  if (mode == 0) { if (!fixed_in) return set_err(ctx, CGMR_E_INVALID, "fixed flags missing"); fixed.assign(fixed_in, fixed_in + nV); }
+  else {
+    fixed[gauge] = 1;                                                   // fixGauge: every other vertex is freed
+    initial_guess_host(nV, work.data(), fixed.data(), nE, ef, et, meas);
+  }
+  // query list (condense: everything but the gauge)
+  std::vector<int32_t> q;
+  for (int k = 0; k < nK; k++) if (mode != 2 || query[k] != gauge) q.push_back(query[k]);
+  const int nq = (int)q.size();
+  if (cov_out && mode != 2) memset(cov_out, 0, sizeof(double) * 9 * (size_t)nK);
+  Symbolic& S = ctx->sym;
+  int rc = analyze(nV, fixed.data(), nE, ef, et, S);
+  if (rc) return set_err(ctx, CGMR_E_INVALID, "graph structure rejected");
+  rc = gn_upload(ctx, S, ef, et, 1);
+  if (rc) return rc;
+  GnDevice& D = ctx->gn;
+  hipStream_t st = ctx->stream;
+  if (D.nf == 0 || nq == 0) { HIP_TRY(ctx, hipStreamSynchronize(st)); return mode == 2 ? 0 : CGMR_OK; }
+  const int m = ((3 * nq + 15) / 16) * 16;
+  const int n = 3 * D.nf;
+  const int chunk = 2048, nchunk = (n + chunk - 1) / chunk;
+  // staging: poses | meas | info | qcol | qvert | Y | Uv | part | G | cov | est | info_out | flags
+  struct L2 { size_t off = 0; size_t add(size_t b) { off = (off + 255) & ~size_t(255); size_t o = off; off += b; return o; } } L;
+  size_t o_p = L.add(24 * (size_t)nV), o_m = L.add(24 * (size_t)nE), o_i = L.add(48 * (size_t)nE), o_qc = L.add(4 * (size_t)nq),
+         o_qv = L.add(4 * (size_t)nq), o_Y = L.add(8 * (size_t)n * m), o_U = L.add(8 * ((size_t)3 * S.rows.size() + 3) * m),
+         o_part = L.add(8 * (size_t)nchunk * m * m), o_G = L.add(8 * (size_t)m * m), o_cov = L.add(72 * (size_t)nq),
+         o_est = L.add(24 * (size_t)nq), o_io = L.add(48 * (size_t)nq), o_fl = L.add(4 * (size_t)nq);
+  rc = arena_reserve(ctx, ctx->io_arena, L.off + 256);
+  if (rc) return rc;
+  char* d = ctx->io_arena.ptr;
+  std::vector<int32_t> qcol(nq);
+  for (int k = 0; k < nq; k++) qcol[k] = S.vperm[q[k]];
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_p, work.data(), 24 * (size_t)nV, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_m, meas, 24 * (size_t)nE, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_i, info, 48 * (size_t)nE, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_qc, qcol.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_qv, q.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, st));
+  double* dp = (double*)(d + o_p);
+  // the Hessian of this iteration (linearised at the initial guess) is what computeMarginals sees [g2o-recalled];
+  // for the condensed graph the iteration is completed first: the factor stays valid, the poses move on
+  gn_pass(ctx, dp, (const double*)(d + o_m), (const double*)(d + o_i), 0, false, mode == 2);
+  launch_marginals(st, D, nq, (const int32_t*)(d + o_qc), m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part),
+                   (double*)(d + o_G), (double*)(d + o_cov), chunk, nchunk);
+  if (mode == 2)
+    launch_label(st, nq, (const int32_t*)(d + o_qv), gauge, dp, (const double*)(d + o_cov), (double*)(d + o_est),
+                 (double*)(d + o_io), (int*)(d + o_fl));
+  int status = 0;
+  std::vector<double> cov(9 * (size_t)nq);
+  HIP_TRY(ctx, hipMemcpyAsync(cov.data(), d + o_cov, 72 * (size_t)nq, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&status, D.status, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (mode == 2) {
+    HIP_TRY(ctx, hipMemcpyAsync(est_out, d + o_est, 24 * (size_t)nq, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(info_out, d + o_io, 48 * (size_t)nq, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipGetLastError());
+  if (status != 0) return set_err(ctx, CGMR_E_CHOLESKY_BASE, "Cholesky failed while computing marginals");
+  if (mode == 2) {
+    for (int k = 0; k < nq; k++) to_out[k] = q[k];
+    if (cov_out) memcpy(cov_out, cov.data(), 72 * (size_t)nq);
+    return nq;
+  }
+  // scatter back in query order; fixed / inactive queries keep zeros
+  for (int k = 0; k < nq; k++)
+    if (qcol[k] >= 0) memcpy(cov_out + 9 * (size_t)k, cov.data() + 9 * (size_t)k, 72);
   return CGMR_OK;
 }
 
@@ -331,6 +462,27 @@ int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* f
   out[8] = (int64_t)(1e6 * S.t_order); out[9] = (int64_t)(1e6 * S.t_struct);
   if (perm_out) memcpy(perm_out, S.vperm.data(), sizeof(int32_t) * nV);
   return CGMR_OK;
+}
+
+int cgmr_marginals(cgmr_ctx* ctx, int nV, const double* poses, const uint8_t* fixed, int nE, const int32_t* ef,
+                   const int32_t* et, const double* meas, const double* info, int nK, const int32_t* query,
+                   double* cov_out) {
+  if (!ctx || !cov_out) return CGMR_E_INVALID;
+  return marginal_driver(ctx, 0, nV, poses, fixed, nE, ef, et, meas, info, -1, nK, query, nullptr, nullptr, nullptr, cov_out);
+}
+
+int cgmr_covariance_estimate(cgmr_ctx* ctx, int nV, const double* poses, int nE, const int32_t* ef, const int32_t* et,
+                             const double* meas, const double* info, int gauge, int nK, const int32_t* query,
+                             double* cov_out) {
+  if (!ctx || !cov_out) return CGMR_E_INVALID;
+  return marginal_driver(ctx, 1, nV, poses, nullptr, nE, ef, et, meas, info, gauge, nK, query, nullptr, nullptr, nullptr, cov_out);
+}
+
+int cgmr_condense(cgmr_ctx* ctx, int nV, const double* poses, int nE, const int32_t* ef, const int32_t* et,
+                  const double* meas, const double* info, int gauge, int nK, const int32_t* query, int32_t* to_out,
+                  double* est_out, double* info_out, double* cov_out) {
+  if (!ctx || !to_out || !est_out || !info_out) return CGMR_E_INVALID;
+  return marginal_driver(ctx, 2, nV, poses, nullptr, nE, ef, et, meas, info, gauge, nK, query, to_out, est_out, info_out, cov_out);
 }
 
 int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]) {

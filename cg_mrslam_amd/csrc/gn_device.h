@@ -35,5 +35,10 @@ void launch_update_level(hipStream_t st, const GnDevice& D, int level);
 void launch_fwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);
+// marginals_kernels.hip
+void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* d_qcol, int m, double* Y, double* Uv,
+                      double* part, double* G, double* cov, int chunk, int nchunk);
+void launch_label(hipStream_t st, int nK, const int32_t* d_qvert, int gauge, const double* poses, const double* cov,
+                  double* est, double* info, int* flags);
 
 }  // namespace cgmr

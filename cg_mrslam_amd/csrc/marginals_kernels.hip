@@ -1,0 +1,243 @@
+// HIP kernels for the marginal-covariance / condensed-measurement step.
+//
+// Reference behaviour being replaced:
+//   CovarianceEstimator::compute -> SparseOptimizer::computeMarginals    src/slam/graph_manipulator.cpp:128-145
+//   CondensedGraphCreator::compute -> EdgeLabeler::labelEdges           src/mrslam/condensed_graph/condensed_graph_creator.cpp:33-66
+// g2o evaluates the requested entries of H^-1 with the memoised Takahashi recursion on the Cholesky
+// factor [g2o-recalled]; on the GPU the same blocks come out of
+//       Y = L^-1 E   (E = unit columns of the K query poses, multi right-hand-side forward solve
+//                     through the supernodal factor of gn_kernels.hip, level by level)
+//       Sigma = Y^T Y (dense contraction over the n = 3 * poses rows: the one GEMM-shaped piece of the
+//                     whole path; v_mfma_f64_16x16x4_f64, K split over workgroups, fixed-order reduction)
+// followed by one thread per condensed edge for the unscented transform (7 sigma points, alpha 1e-3,
+// beta 2, lambda = alpha^2 n) and the 3x3 inverse.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gn_device.h"
+#include "gn_symbolic.h"
+
+namespace cgmr {
+
+namespace {
+constexpr int W = kFrontW;
+constexpr int kL11c = W * W;
+constexpr int kDinv = 2 * W * W;
+constexpr int kL21 = 2 * W * W + W;
+constexpr int MB = 16;            // right-hand sides per workgroup in the multi-RHS forward solve
+
+__device__ __forceinline__ double d_norm_theta(double t) {
+  const double pi = 3.14159265358979323846;
+  if (t >= -pi && t < pi) return t;
+  return t - 2 * pi * floor((t + pi) / (2 * pi));
+}
+}  // namespace
+
+// E[3*vperm[q]+a][3k+a] = 1 for query k (others zero); Y is n x m row-major (m padded to 16)
+__global__ void k_marg_init_rhs(int nK, const int32_t* __restrict__ qcol, int m, double* __restrict__ Y) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nK) return;
+  int c = qcol[k];
+  if (c < 0) return;
+#pragma unroll
+  for (int a = 0; a < 3; a++) Y[(size_t)(3 * c + a) * m + 3 * k + a] = 1.0;
+}
+
+// Forward solve L Y = E for MB right-hand sides at a time: grid (fronts of the level, m / MB).
+// thread = (column c = tid % 16, row lane g = tid / 16)
+__global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __restrict__ fronts,
+                                                         const int32_t* __restrict__ level_fronts, int level_begin,
+                                                         const int32_t* __restrict__ children,
+                                                         const int32_t* __restrict__ rel, const int32_t* __restrict__ inv,
+                                                         const double* __restrict__ Lbuf, int m,
+                                                         double* __restrict__ Y, double* __restrict__ Uv) {
+  __shared__ double t1[W][MB + 1];
+  const int tid = threadIdx.x;
+  const int c = tid & 15, g = tid >> 4;
+  const int col = blockIdx.y * MB + c;
+  const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
+  const int w = 3 * F.nc, r = 3 * F.ns;
+  const double* P = Lbuf + F.L_off;
+  for (int j = g; j < W; j += 16) t1[j][c] = (j < w) ? Y[(size_t)(3 * F.c0 + j) * m + col] : 0.0;
+  __syncthreads();
+  for (int ci = 0; ci < F.nchild; ci++) {
+    const FrontDesc G = fronts[children[F.child_off + ci]];
+    const double* ug = Uv + (size_t)3 * G.rows_off * m;
+    const int ra = 3 * G.na;
+    for (int q = g; q < ra; q += 16) t1[3 * rel[G.rel_off + q / 3] + q % 3][c] += ug[(size_t)q * m + col];
+    __syncthreads();
+  }
+  for (int j = 0; j < w; j++) {
+    double yj = t1[j][c] * P[kDinv + j];
+    __syncthreads();
+    if (g == 0) t1[j][c] = yj;
+    for (int i = j + 1 + g; i < w; i += 16) t1[i][c] -= P[kL11c + j * W + i] * yj;
+    __syncthreads();
+  }
+  for (int j = g; j < w; j += 16) Y[(size_t)(3 * F.c0 + j) * m + col] = t1[j][c];
+  const double* L21 = P + kL21;
+  double* uf = Uv + (size_t)3 * F.rows_off * m;
+  for (int p = g; p < r; p += 16) {
+    double acc = 0;
+    for (int ci = 0; ci < F.nchild; ci++) {
+      const FrontDesc G = fronts[children[F.child_off + ci]];
+      int kb = inv[G.inv_off + p / 3];
+      if (kb >= 0) acc += Uv[((size_t)3 * G.rows_off + 3 * kb + p % 3) * m + col];
+    }
+    const double* row = L21 + (size_t)p * W;
+    double dot = 0;
+    for (int k = 0; k < w; k++) dot += row[k] * t1[k][c];
+    uf[(size_t)p * m + col] = acc - dot;
+  }
+}
+
+// Partial Gram matrices: workgroup (tile pair, K-chunk); each of the 4 wavefronts accumulates a 16x16 tile of
+// Y^T Y over its quarter of the chunk with v_mfma_f64_16x16x4_f64, then the four are summed in a fixed order.
+//   A operand (16 x 4): lane l holds A[i = l & 15][k = l >> 4] = Y[k0 + (l >> 4)][16 I + (l & 15)]
+//   B operand (4 x 16): lane l holds B[k = l >> 4][j = l & 15] = Y[k0 + (l >> 4)][16 J + (l & 15)]
+//   C/D: 4 doubles per lane, element (row = (l >> 4) + 4 * reg, col = l & 15)
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_gram_partial(int n, int m, int chunk, const double* __restrict__ Y,
+                                                      double* __restrict__ part) {
+  __shared__ double red[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = m / 16;
+  const int I = blockIdx.x / T, J = blockIdx.x - I * T;
+  const int k_begin = blockIdx.y * chunk, k_end = min(n, k_begin + chunk);
+  const int per = (k_end - k_begin + 3) / 4;
+  const int w0 = k_begin + wave * per, w1 = min(k_end, w0 + per);
+  double4_t acc = {0, 0, 0, 0};
+  const int kk = lane >> 4, ii = lane & 15;
+  for (int k0 = w0; k0 < w1; k0 += 4) {
+    int k = k0 + kk;
+    double a = 0, b = 0;
+    if (k < w1) {
+      a = Y[(size_t)k * m + 16 * I + ii];
+      b = Y[(size_t)k * m + 16 * J + ii];
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) red[wave][((lane >> 4) + 4 * rg) * 16 + (lane & 15)] = acc[rg];
+  __syncthreads();
+  double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  int row = tid >> 4, colj = tid & 15;
+  part[((size_t)blockIdx.y * m + 16 * I + row) * m + 16 * J + colj] = s;
+}
+
+__global__ void k_gram_reduce(int m, int nchunk, const double* __restrict__ part, double* __restrict__ G) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m * m) return;
+  double s = 0;
+  for (int c = 0; c < nchunk; c++) s += part[(size_t)c * m * m + q];
+  G[q] = s;
+}
+
+// cov_out[k] = 3x3 diagonal block k of the Gram matrix
+__global__ void k_marg_extract(int nK, int m, const double* __restrict__ G, double* __restrict__ cov) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nK * 9) return;
+  int k = q / 9, e = q - 9 * k;
+  cov[q] = G[(size_t)(3 * k + e / 3) * m + 3 * k + e % 3];
+}
+
+// EdgeLabeler::labelEdge for star edges gauge -> v (SURVEY.md Appendix A [g2o-recalled]); one thread per edge.
+__global__ void k_label_edges(int nK, const int32_t* __restrict__ qvert, int gauge, const double* __restrict__ poses,
+                              const double* __restrict__ cov, double* __restrict__ est, double* __restrict__ info,
+                              int* __restrict__ flags) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nK) return;
+  const double* xg = poses + 3 * (size_t)gauge;
+  const double* xv = poses + 3 * (size_t)qvert[k];
+  const double* S = cov + 9 * (size_t)k;
+  const double alpha = 1e-3, beta = 2.0;
+  const int dim = 3;
+  const double lambda = alpha * alpha * dim;
+  const double wi = 1.0 / (2.0 * (dim + lambda));
+  const double wm0 = lambda / (dim + lambda);
+  const double wc0 = wm0 + (1.0 - alpha * alpha + beta);
+  // measurement := xg^-1 * xv (setMeasurementFromState)
+  double cg = cos(xg[2]), sg = sin(xg[2]);
+  double dx = xv[0] - xg[0], dy = xv[1] - xg[1];
+  double z0 = cg * dx + sg * dy, z1 = -sg * dx + cg * dy, z2 = d_norm_theta(xv[2] - xg[2]);
+  est[3 * k] = z0; est[3 * k + 1] = z1; est[3 * k + 2] = z2;
+  // LLT of (dim + lambda) * Sigma
+  double A[9], L[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = 0; q < 9; q++) A[q] = S[q] * (dim + lambda);
+  bool ok = true;
+  for (int j = 0; j < 3 && ok; j++) {
+    double d = A[3 * j + j];
+    for (int q = 0; q < j; q++) d -= L[3 * j + q] * L[3 * j + q];
+    if (!(d > 0)) { ok = false; break; }
+    L[3 * j + j] = sqrt(d);
+    for (int i = j + 1; i < 3; i++) {
+      double s = A[3 * i + j];
+      for (int q = 0; q < j; q++) s -= L[3 * i + q] * L[3 * j + q];
+      L[3 * i + j] = s / L[3 * j + j];
+    }
+  }
+  double* iu = info + 6 * (size_t)k;
+  if (!ok) {   // g2o leaves the edge unlabeled: identity information
+    iu[0] = 1; iu[1] = 0; iu[2] = 0; iu[3] = 1; iu[4] = 0; iu[5] = 1;
+    flags[k] = 1;
+    return;
+  }
+  double err[7][3], wm[7], wc[7];
+  const double czz = cos(z2), szz = sin(z2);
+  for (int q = 0; q < 7; q++) {
+    double px = 0, py = 0, pt = 0;
+    if (q > 0) {
+      int i = (q - 1) >> 1;
+      double sgn = ((q - 1) & 1) ? -1.0 : 1.0;
+      px = sgn * L[0 + i]; py = sgn * L[3 + i]; pt = sgn * L[6 + i];
+    }
+    wm[q] = q ? wi : wm0;
+    wc[q] = q ? wi : wc0;
+    double sx = xv[0] + px, sy = xv[1] + py, st = d_norm_theta(xv[2] + pt);
+    double ddx = sx - xg[0], ddy = sy - xg[1];
+    double rx = cg * ddx + sg * ddy, ry = -sg * ddx + cg * ddy, rth = d_norm_theta(st - xg[2]);
+    double tx = rx - z0, ty = ry - z1;
+    err[q][0] = czz * tx + szz * ty;
+    err[q][1] = -szz * tx + czz * ty;
+    err[q][2] = d_norm_theta(rth - z2);
+  }
+  double mean[3] = {0, 0, 0}, C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = 0; q < 7; q++)
+    for (int a = 0; a < 3; a++) mean[a] += wm[q] * err[q][a];
+  for (int q = 0; q < 7; q++) {
+    double d[3] = {err[q][0] - mean[0], err[q][1] - mean[1], err[q][2] - mean[2]};
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) C[3 * a + b] += wc[q] * d[a] * d[b];
+  }
+  double a = C[0], b = C[1], c = C[2], d = C[3], e = C[4], f = C[5], g = C[6], h = C[7], i = C[8];
+  double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  double id = 1.0 / det;
+  iu[0] = (e * i - f * h) * id; iu[1] = (c * h - b * i) * id; iu[2] = (b * f - c * e) * id;
+  iu[3] = (a * i - c * g) * id; iu[4] = (c * d - a * f) * id; iu[5] = (a * e - b * d) * id;
+  flags[k] = 0;
+}
+
+// ----------------------------------------------------------------------------------- launchers
+void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* d_qcol, int m, double* Y, double* Uv,
+                      double* part, double* G, double* cov, int chunk, int nchunk) {
+  (void)hipMemsetAsync(Y, 0, sizeof(double) * (size_t)3 * D.nf * m, st);
+  hipLaunchKernelGGL(k_marg_init_rhs, dim3((nK + 127) / 128), dim3(128), 0, st, nK, d_qcol, m, Y);
+  for (int l = 0; l < D.nlevels; l++) {
+    int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
+    hipLaunchKernelGGL(k_solve_fwd_multi, dim3(nfr, m / MB), dim3(256), 0, st, D.fronts, D.level_fronts,
+                       D.h_level_ptr[l], D.children, D.rel, D.inv, D.Lbuf, m, Y, Uv);
+  }
+  int T = m / 16;
+  hipLaunchKernelGGL(k_gram_partial, dim3(T * T, nchunk), dim3(256), 0, st, 3 * D.nf, m, chunk, Y, part);
+  hipLaunchKernelGGL(k_gram_reduce, dim3((m * m + 255) / 256), dim3(256), 0, st, m, nchunk, part, G);
+  hipLaunchKernelGGL(k_marg_extract, dim3((nK * 9 + 255) / 256), dim3(256), 0, st, nK, m, G, cov);
+}
+
+void launch_label(hipStream_t st, int nK, const int32_t* d_qvert, int gauge, const double* poses, const double* cov,
+                  double* est, double* info, int* flags) {
+  if (nK <= 0) return;
+  hipLaunchKernelGGL(k_label_edges, dim3((nK + 63) / 64), dim3(64), 0, st, nK, d_qvert, gauge, poses, cov, est, info, flags);
+}
+
+}  // namespace cgmr

@@ -148,6 +148,35 @@ int cgmr_match_close_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
 /* Device time (HIP events on the context's stream) of the last matcher launch, seconds. */
 int cgmr_match_last_kernel_seconds(const cgmr_ctx* ctx, double* seconds);
 
+/* ------------------------------------------------------------------------------------------
+ * Marginal covariances and condensed measurements.
+ *
+ * cgmr_marginals: 3x3 diagonal blocks of H^-1 for the query vertices, H linearised at poses_xyt with
+ * the given fixed flags.  Replaces SparseOptimizer::computeMarginals(spinv, {(h,h)}) as called at
+ * src/slam/graph_manipulator.cpp:134-142.  Fixed / inactive query vertices get zeros.  cov_out [nK*9].
+ *
+ * cgmr_covariance_estimate: CovarianceEstimator::{setVertices,setGauge,compute,getCovariance}
+ * (src/slam/graph_manipulator.cpp:128-157; caller GraphSLAM::checkCovariance, src/slam/graph_slam.cpp:311-354):
+ * push state, fix exactly the gauge, spanning-tree initial guess over all edges, one GN iteration, marginals
+ * of that iteration's Hessian, pop state (the caller's poses are never modified).
+ *
+ * cgmr_condense: CondensedGraphCreator::{setVertices,setGauge,setEdges,compute,getCondensedGraph}
+ * (src/mrslam/condensed_graph/condensed_graph_creator.cpp:33-66): the same manipulation restricted to the
+ * given (own) edges, then one star edge gauge -> v per other query vertex, labelled by g2o_hierarchical's
+ * EdgeLabeler: measurement = relative pose after the iteration, information = inverse of the unscented-
+ * transformed marginal covariance.  query_idx holds nK vertex indices *including* the gauge; outputs are
+ * written for the nK-1 others in query order: to_out [nK-1], est_out [(nK-1)*3], info_upper_out [(nK-1)*6],
+ * cov_out (nullable) [(nK-1)*9].  Returns the number of edges (>= 0) or an error (< 0).            */
+int cgmr_marginals(cgmr_ctx* ctx, int nV, const double* poses_xyt, const uint8_t* fixed, int nE,
+                   const int32_t* from_idx, const int32_t* to_idx, const double* meas_xyt, const double* info_upper,
+                   int nK, const int32_t* query_idx, double* cov_out);
+int cgmr_covariance_estimate(cgmr_ctx* ctx, int nV, const double* poses_xyt, int nE, const int32_t* from_idx,
+                             const int32_t* to_idx, const double* meas_xyt, const double* info_upper, int gauge_idx,
+                             int nK, const int32_t* query_idx, double* cov_out);
+int cgmr_condense(cgmr_ctx* ctx, int nV, const double* poses_xyt, int nE, const int32_t* from_idx,
+                  const int32_t* to_idx, const double* meas_xyt, const double* info_upper, int gauge_idx, int nK,
+                  const int32_t* query_idx, int32_t* to_out, double* est_out, double* info_upper_out, double* cov_out);
+
 #ifdef __cplusplus
 }
 #endif
