@@ -94,7 +94,8 @@ def _diag_info_upper(d):
 
 
 def make_pose_graph(n_vertices: int = 10000, n_edges: int = 40000, seed: int = 12345,
-                    close_radius: float = 1.5, id_base: int = 0, strict: bool = False):
+                    close_radius: float = 1.5, id_base: int = 0, strict: bool = False,
+                    start=(0, 0, 0)):
     """C2 recipe.
 
     Returns a dict of flat arrays: ``truth``/``poses`` (V,3) (initial guess =
@@ -110,13 +111,13 @@ def make_pose_graph(n_vertices: int = 10000, n_edges: int = 40000, seed: int = 1
     # random walk on the unit grid: heading changes drawn from {0,0,0,+90,-90}
     turn_choice = (uniform(seed, 1, V) * 5).astype(np.int64)
     dturn = np.array([0, 0, 0, 1, -1], dtype=np.int64)[turn_choice]
-    heading = np.cumsum(dturn) - dturn[0]            # heading of pose k (quarter turns), pose 0 heads +x
+    heading = np.cumsum(dturn) - dturn[0] + int(start[2])   # heading of pose k (quarter turns)
     hq = np.mod(heading, 4)
     dxs = np.array([1, 0, -1, 0], dtype=np.int64)[hq]
     dys = np.array([0, 1, 0, -1], dtype=np.int64)[hq]
     # pose k+1 = pose k advanced one metre along heading k, then turned by dturn[k+1]
-    x = np.concatenate([[0], np.cumsum(dxs[:-1])]).astype(np.float64)
-    y = np.concatenate([[0], np.cumsum(dys[:-1])]).astype(np.float64)
+    x = (int(start[0]) + np.concatenate([[0], np.cumsum(dxs[:-1])])).astype(np.float64)
+    y = (int(start[1]) + np.concatenate([[0], np.cumsum(dys[:-1])])).astype(np.float64)
     th = normalize_theta(hq.astype(np.float64) * (np.pi / 2))
     truth = np.stack([x, y, th], axis=1)
 
@@ -186,26 +187,88 @@ def make_pose_graph(n_vertices: int = 10000, n_edges: int = 40000, seed: int = 1
                 meas=meas, info=info, ids=ids, n_odometry=n_odo)
 
 
-def make_multi_robot(n_robots: int = 8, n_vertices: int = 5000, n_edges: int = 20000,
-                     seed: int = 777, base_id: int = 10000, shared_every: int = 50):
-    """C5 recipe: ``n_robots`` independent sub-graphs + the inter-robot closure
-    lists (which of *my* vertices peer q has closed a loop against, i.e. the
-    ids q requests in its CondensedGraphMessage, src/mrslam/mr_graph_slam.cpp:614-624).
+INTER_ROBOT_INFO = (100.0, 100.0, 1000.0)   # src/mrslam/mr_graph_slam.cpp:234-236,310-312
 
-    Every ``shared_every``-th vertex of robot r is declared shared with peer
-    ``(r + 1 + (k // shared_every) % (n_robots-1)) % n_robots``.
+
+def make_multi_robot(n_robots: int = 8, n_vertices: int = 5000, n_edges: int = 20000, seed: int = 777,
+                     base_id: int = 10000, max_shared: int = 60, spread: int = 12):
+    """C5 recipe: ``n_robots`` robots walk the same world (grid random walks from different start cells).
+
+    Robot q's graph holds its own ``n_vertices`` poses (ids ``q*base_id + k``, src/slam/graph_slam.cpp:95,155)
+    plus *foreign* vertices: copies of peers' poses it has closed a loop against, attached by inter-robot
+    closure edges (own -> foreign, information diag(100,100,1000), src/mrslam/mr_graph_slam.cpp:234-236).
+    ``out_closures[p]`` of robot r lists r's own vertex indices that peer p holds, i.e. the ids p requests in
+    its CondensedGraphMessage (src/mrslam/mr_graph_slam.cpp:614-624); ``in_closures[p]`` are the foreign ids
+    this robot requests from p.  At most ``max_shared`` closures per ordered robot pair.
     """
     robots = []
     for r in range(n_robots):
-        g = make_pose_graph(n_vertices, n_edges, seed=seed + 17 * r, id_base=r * base_id)
-        out_closures = {q: [] for q in range(n_robots) if q != r}
-        if n_robots > 1:
-            for k in range(shared_every, n_vertices, shared_every):
-                q = (r + 1 + (k // shared_every) % (n_robots - 1)) % n_robots
-                out_closures[q].append(k)
+        u = uniform(seed, 500 + r, 3)
+        start = (int((u[0] - 0.5) * 2 * spread), int((u[1] - 0.5) * 2 * spread), int(u[2] * 4))
+        g = make_pose_graph(n_vertices, n_edges, seed=seed + 17 * r, id_base=r * base_id, start=start)
         g["robot"] = r
-        g["out_closures"] = {q: np.asarray(v, dtype=np.int32) for q, v in out_closures.items()}
+        g["n_own"] = n_vertices
         robots.append(g)
+    # inter-robot closures: robot q's vertex i against robot r's vertex j, truth distance < 1.5 m
+    for q in range(n_robots):
+        gq = robots[q]
+        ids = [gq["ids"]]
+        poses = [gq["poses"]]
+        truth = [gq["truth"]]
+        ef, et, meas, info = [gq["edge_from"]], [gq["edge_to"]], [gq["meas"]], [gq["info"]]
+        gq["in_closures"] = {}
+        nxt = n_vertices
+        for r in range(n_robots):
+            if r == q:
+                continue
+            gr = robots[r]
+            # lattice join on integer cell keys
+            kq = gq["truth"][:n_vertices, 0].astype(np.int64) * 100003 + gq["truth"][:n_vertices, 1].astype(np.int64)
+            kr = gr["truth"][:gr["n_own"], 0].astype(np.int64) * 100003 + gr["truth"][:gr["n_own"], 1].astype(np.int64)
+            order = np.argsort(kr, kind="stable")
+            pos = np.searchsorted(kr[order], kq)
+            pos = np.minimum(pos, len(kr) - 1)
+            hit = kr[order][pos] == kq
+            qi = np.flatnonzero(hit)
+            rj = order[pos[hit]]
+            if len(qi) == 0:
+                continue
+            rk = uniform(seed + 1000 * q + r, 600, len(qi))
+            sel = np.sort(np.argsort(rk, kind="stable")[:max_shared])
+            qi, rj = qi[sel], rj[sel]
+            rj_unique, inv = np.unique(rj, return_inverse=True)
+            nf = len(rj_unique)
+            E = len(qi)
+            rel = se2_compose(se2_inverse(gq["truth"][qi]), gr["truth"][rj])
+            noise = np.stack([normal(seed + 31 * q + r, 700 + k, E) for k in range(3)], axis=1) / np.sqrt(INTER_ROBOT_INFO)
+            z = se2_compose(rel, noise)
+            # foreign vertex estimate: first closure that mentions it, composed from the own vertex' estimate
+            fpose = np.zeros((nf, 3))
+            seen = np.zeros(nf, dtype=bool)
+            for e in range(E):
+                if not seen[inv[e]]:
+                    fpose[inv[e]] = se2_compose(gq["poses"][qi[e]], z[e])
+                    seen[inv[e]] = True
+            ids.append((r * base_id + rj_unique).astype(np.int32))
+            poses.append(fpose)
+            truth.append(gr["truth"][rj_unique])
+            ef.append(qi.astype(np.int32))
+            et.append((nxt + inv).astype(np.int32))
+            meas.append(z)
+            inf = np.zeros((E, 6))
+            inf[:, 0], inf[:, 3], inf[:, 5] = INTER_ROBOT_INFO
+            info.append(inf)
+            gq["in_closures"][r] = (r * base_id + rj_unique).astype(np.int32)
+            nxt += nf
+        gq["ids"] = np.concatenate(ids).astype(np.int32)
+        gq["poses_all"] = np.concatenate(poses)
+        gq["truth_all"] = np.concatenate(truth)
+        gq["ef_all"], gq["et_all"] = np.concatenate(ef), np.concatenate(et)
+        gq["meas_all"], gq["info_all"] = np.concatenate(meas), np.concatenate(info)
+        gq["fixed_all"] = np.concatenate([gq["fixed"], np.zeros(nxt - n_vertices, dtype=np.uint8)])
+    for r in range(n_robots):
+        robots[r]["out_closures"] = {q: (robots[q]["in_closures"][r] - r * base_id).astype(np.int32)
+                                     for q in range(n_robots) if q != r and r in robots[q]["in_closures"]}
     return robots
 
 
