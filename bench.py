@@ -10,8 +10,10 @@ resident in HBM before the timed region starts.  value = GN iterations / second 
 
 Multi-GPU (one process per GPU, torch.distributed / RCCL): every rank owns one robot's sub-graph (a C2
 graph with its own seed) -- the path shards by robot with no data-path collective inside optimize(); weak
-scaling.  The inter-robot condensed-edge exchange is benchmarked by
-``--workload exchange`` once per step on top of the solve.
+scaling.  For N > 1 one inter-robot round (condensed graphs for every peer + the RCCL all-gather of the
+44-byte/edge payload) is timed after the headline region and reported under ``exchange``.
+The second half of BASELINE.json's metric, scan-match pairs/s (config C3), is measured on rank 0 after the
+timed region and reported under ``matcher``.
 
 Extra objects on the JSON line: ``roofline`` for the dominant kernel (k_front_factor, timed with HIP events
 on the context's stream) and ``cpu_baseline`` (the single-thread CPU oracle on rank 0, N=1 only).
@@ -40,7 +42,92 @@ def parse():
     ap.add_argument("--vertices", type=int, default=10000)
     ap.add_argument("--edges", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--match-pairs", type=int, default=32768, help="scan pairs for the matcher leg (0 = skip)")
     return ap.parse_args()
+
+
+def matcher_leg(ctx, dev, args, with_cpu):
+    """C3: batched closeScanMatching on synthetic 1081-beam scan pairs resident in HBM."""
+    import torch
+    from cg_mrslam_amd import synth
+    from cg_mrslam_amd.matcher import ScanMatcher
+    base = 256
+    sp = synth.make_scan_pairs(base, seed=4242)
+    P = max(base, (args.match_pairs // base) * base)
+    rep = P // base
+    d_ref = torch.tensor(sp["ranges_ref"], device=dev).repeat(rep, 1).contiguous()
+    d_qry = torch.tensor(sp["ranges_qry"], device=dev).repeat(rep, 1).contiguous()
+    d_g = torch.tensor(sp["guess"], dtype=torch.float64, device=dev).repeat(rep, 1).contiguous()
+    d_xyt = torch.zeros(P, 3, dtype=torch.float64, device=dev)
+    d_score = torch.zeros(P, dtype=torch.float64, device=dev)
+    d_found = torch.zeros(P, dtype=torch.uint8, device=dev)
+    m = ScanMatcher(ctx, sp["n_beams"], sp["angle_min"], sp["angle_inc"], sp["max_range"])
+    torch.cuda.synchronize()
+    args_dev = (d_ref.data_ptr(), d_qry.data_ptr(), d_g.data_ptr(), P, d_xyt.data_ptr(), d_score.data_ptr(), d_found.data_ptr())
+    m.closeScanMatching_dev(*args_dev)                     # warm-up
+    t0 = time.perf_counter()
+    m.closeScanMatching_dev(*args_dev)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ksec = m.last_kernel_seconds()                         # HIP events on the context's stream
+    xyt = d_xyt[:base].cpu().numpy()
+    found = d_found[:base].cpu().numpy().astype(bool)
+    err = np.abs(xyt - sp["true_rel"])
+    ok = found & (err[:, 0] < 0.04) & (err[:, 1] < 0.04) & (err[:, 2] < 0.013)
+    out = {"metric": "scan-match pairs/sec (closeScanMatching, 1081 beams)", "value": round(P / wall, 1),
+           "unit": "pairs/s", "n_pairs": P, "distinct_pairs": base, "kernel_ms": round(1e3 * ksec, 3),
+           "wall_ms": round(1e3 * wall, 3), "recovered_truth_frac": round(float(ok.mean()), 4),
+           "roofline": {"kernel": "k_match_close_batch", "bound": "hbm", "achieved": round(P * 8.7e3 / ksec / 1e9, 3),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(P * 8.7e3 / ksec / 1e9 / 8000.0, 7), "traffic": None,
+                        "note": "8.7 KB compulsory HBM bytes per pair; the binding resource is LDS/VALU issue "
+                                "(sparse-tile byte gathers), see DESIGN.md"}}
+    if with_cpu:
+        from oracle import oracle as O
+        n = 64
+        tc0 = time.perf_counter()
+        xo, so, fo = O.close_scan_match_batch(sp["ranges_ref"][:n], sp["ranges_qry"][:n], sp["angle_min"], sp["angle_inc"],
+                                              sp["max_range"], [0, 0, 0], sp["guess"][:n])
+        tc = time.perf_counter() - tc0
+        out["cpu_baseline"] = {"value": round(n / tc, 2), "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} pairs of the same workload, single thread",
+                               "bit_identical_to_gpu": bool(np.array_equal(xo, xyt[:n]) and np.array_equal(fo.astype(bool), found[:n]))}
+    return out
+
+
+def exchange_round(ctx, rank, world, dev, args):
+    """One round of the multi-robot protocol on the C5-style world (every rank = one robot)."""
+    import torch
+    import torch.distributed as dist
+    from cg_mrslam_amd import synth
+    from cg_mrslam_amd.condensed import CondensedGraphBuffer
+    from cg_mrslam_amd.graph import GraphSLAM, PoseGraph
+    R = synth.make_multi_robot(world, args.vertices // 2, args.edges // 2, seed=777)
+    gr = R[rank]
+    pg = PoseGraph(gr["ids"], gr["poses_all"], gr["fixed_all"], gr["ef_all"], gr["et_all"], gr["meas_all"], gr["info_all"])
+    buf = CondensedGraphBuffer(pg, rank, world, ctx=ctx)
+    for q, ids in gr["in_closures"].items():
+        buf.insertInClosure(q, ids)
+    slam = GraphSLAM(pg, ctx=ctx)
+    slam.optimize(5)
+    buf.exchange(device=dev if dev.type == "cuda" else None)   # round 0: requests travel
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    n_edges = 0
+    for q in range(world):
+        if q != rank and q in buf.out_closures:
+            n_edges += len(buf.computeCondensedGraph(q))
+    t1 = time.perf_counter()
+    nbytes = buf.exchange(device=dev if dev.type == "cuda" else None)
+    torch.cuda.synchronize(); dist.barrier()
+    t2 = time.perf_counter()
+    slam.optimize(5)
+    t = torch.tensor([t1 - t0, t2 - t1, float(n_edges), float((buf.in_edge_src >= 0).sum())], dtype=torch.float64, device=dev)
+    tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    return {"robots": world, "vertices_per_robot": int(pg.n_vertices), "condense_ms_max": round(1e3 * float(tmax[0]), 3),
+            "allgather_ms_max": round(1e3 * float(tmax[1]), 3), "bytes_gathered_per_rank": int(nbytes),
+            "condensed_edges_sent_total": int(tsum[2]), "condensed_edges_received_total": int(tsum[3]),
+            "wire_bytes_per_edge": 44, "chi2_after": float(slam.last_chi2[-1]), "status": int(slam.last_status)}
 
 
 def main():
@@ -53,11 +140,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # CGMR_BENCH_BACKEND=gloo + CGMR_BENCH_SINGLE_DEVICE=1 is a dry-run mode for 1-GPU boxes: all ranks share
+    # cuda:0 and the collectives run over gloo on host tensors; the driver's runs use the default (nccl = RCCL)
+    backend = os.environ.get("CGMR_BENCH_BACKEND", "nccl")
+    if os.environ.get("CGMR_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from cg_mrslam_amd import Context, synth
     from cg_mrslam_amd._lib import gn_symbolic_info
@@ -101,9 +197,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- one inter-robot round (N > 1): condensed graph for every peer that asked + all-gather (RCCL)
+    exchange = None
+    if world > 1:
+        exchange = exchange_round(ctx, rank, world, cdev, args)
 
     if rank != 0:
         if world > 1:
@@ -154,6 +255,8 @@ def main():
                "chi2_rel_diff_vs_gpu": float(abs(chi_cpu[-1] - chi[-1]) / chi_cpu[-1]),
                "max_pose_diff_vs_gpu": float(np.abs(p_cpu - d_p.cpu().numpy()).max())}
 
+    matcher = matcher_leg(ctx, dev, args, with_cpu=(world == 1 and not args.no_cpu_baseline)) if args.match_pairs > 0 else None
+
     total_iters = GN_ITERS * args.steps * world
     out = {
         "metric": "GN iterations/sec on 10k-vertex SE2 graph (final chi2 reported)",
@@ -168,7 +271,7 @@ def main():
         "device_ms_per_step": round(1e3 * dev_time / args.steps, 3),
         "symbolic": {k: info[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")},
         "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "matcher": matcher, "exchange": exchange,
     }
     if cpu:
         out["speedup_vs_cpu_1thread"] = round(out["value"] / cpu["value"], 2)
