@@ -3,8 +3,11 @@
 #include "gn_symbolic.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace cgmr {
 namespace {
@@ -24,86 +27,86 @@ struct NDCtx {
   const std::vector<int32_t>& ap;     // adjacency CSR (block indices)
   const std::vector<int32_t>& ai;
   std::vector<int32_t>& order;        // in/out working permutation
-  std::vector<int32_t>& panel_start;
-  std::vector<int32_t> label;         // region id a vertex currently belongs to
-  std::vector<int32_t> dist;
-  std::vector<int32_t> queue;
-  std::vector<int32_t> tmp;
-  std::vector<int32_t> lvl_cnt;
-  int next_label = 1;
+  std::vector<uint8_t>& pstart;       // pstart[pos] = 1 if a front begins at position pos
+  std::vector<int32_t> label;         // region id a vertex currently belongs to (indexed by vertex)
+  std::vector<int32_t> dist;          // BFS depth (indexed by vertex)
+  std::vector<int32_t> queue;         // BFS order, indexed by *position*: a call only touches [begin, end)
+  std::vector<int32_t> tmp;           // partition scratch, indexed by position
+  std::atomic<int> next_label{1};
+  int max_par_depth = 0;              // recursion levels that fork a thread for one half
 };
 
 void emit_panels(NDCtx& C, int begin, int end) {
-  for (int p = begin; p < end; p += kPanelW) C.panel_start.push_back(p);
+  for (int p = begin; p < end; p += kPanelW) C.pstart[p] = 1;
 }
 
 // BFS restricted to vertices with label == id; returns number reached, fills dist (by vertex)
-// and C.queue[0..reached) in visiting order.
-int bfs(NDCtx& C, int root, int id, int visited_id) {
+// and q[0..reached) in visiting order (q = the caller's slice of C.queue).
+int bfs(NDCtx& C, int32_t* q, int root, int id, int visited_id) {
   int qh = 0, qt = 0;
-  C.queue[qt++] = root;
+  q[qt++] = root;
   C.dist[root] = 0;
   C.label[root] = visited_id;
   while (qh < qt) {
-    int u = C.queue[qh++];
+    int u = q[qh++];
     int du = C.dist[u];
     for (int p = C.ap[u]; p < C.ap[u + 1]; p++) {
       int w = C.ai[p];
       if (C.label[w] != id) continue;
       C.label[w] = visited_id;
       C.dist[w] = du + 1;
-      C.queue[qt++] = w;
+      q[qt++] = w;
     }
   }
   return qt;
 }
 
-void nd(NDCtx& C, int begin, int end) {
+void nd(NDCtx& C, int begin, int end, int depth) {
   int n = end - begin;
   if (n <= 0) return;
   if (n <= kPanelW) { emit_panels(C, begin, end); return; }
-  int id = C.next_label++;
+  int32_t* Q = C.queue.data() + begin;                  // this call's slice of the BFS queue
+  int id = C.next_label.fetch_add(3);
   for (int p = begin; p < end; p++) C.label[C.order[p]] = id;
   // first sweep: connectivity + a far vertex
-  int vis1 = C.next_label++;
-  int reached = bfs(C, C.order[begin], id, vis1);
+  int vis1 = id + 1;
+  int reached = bfs(C, Q, C.order[begin], id, vis1);
   if (reached < n) {
     // disconnected: component first, then the rest (independent subtrees, no separator)
     int k = begin;
-    for (int q = 0; q < reached; q++) C.tmp[k++] = C.queue[q];
+    for (int q = 0; q < reached; q++) C.tmp[k++] = Q[q];
     for (int p = begin; p < end; p++) if (C.label[C.order[p]] == id) C.tmp[k++] = C.order[p];
     std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
-    nd(C, begin, begin + reached);
-    nd(C, begin + reached, end);
+    nd(C, begin, begin + reached, depth);
+    nd(C, begin + reached, end, depth);
     return;
   }
-  int far = C.queue[reached - 1];
+  int far = Q[reached - 1];
   // second sweep from the far vertex gives the level structure
-  int vis2 = C.next_label++;
-  bfs(C, far, vis1, vis2);
-  int nlev = C.dist[C.queue[n - 1]] + 1;
+  int vis2 = id + 2;
+  bfs(C, Q, far, vis1, vis2);
+  int nlev = C.dist[Q[n - 1]] + 1;
   if (nlev <= 2) {  // clique-like: nothing to dissect
     emit_panels(C, begin, end);
     return;
   }
-  if ((int)C.lvl_cnt.size() < nlev + 1) C.lvl_cnt.resize(nlev + 1);
-  std::fill(C.lvl_cnt.begin(), C.lvl_cnt.begin() + nlev + 1, 0);
-  for (int q = 0; q < n; q++) C.lvl_cnt[C.dist[C.queue[q]]]++;
+  std::vector<int32_t> lvl_cnt(nlev + 1, 0);
+  for (int q = 0; q < n; q++) lvl_cnt[C.dist[Q[q]]]++;
   // choose the separator level
   int best = -1, best_sz = 1 << 30, fallback = 1, fb_bal = -1;
-  int cum = C.lvl_cnt[0];
+  int cum = lvl_cnt[0];
   for (int j = 1; j <= nlev - 2; j++) {
-    int a = cum, b = n - cum - C.lvl_cnt[j];
+    int a = cum, b = n - cum - lvl_cnt[j];
     int bal = std::min(a, b);
     if (bal > fb_bal) { fb_bal = bal; fallback = j; }
-    if (bal * 10 >= n * 3 && C.lvl_cnt[j] < best_sz) { best_sz = C.lvl_cnt[j]; best = j; }
-    cum += C.lvl_cnt[j];
+    if (bal * 10 >= n * 3 && lvl_cnt[j] < best_sz) { best_sz = lvl_cnt[j]; best = j; }
+    cum += lvl_cnt[j];
   }
   int js = best >= 0 ? best : fallback;
   // partition queue order into A (levels < js, plus level-js vertices not touching js+1), B, S
   int na = 0, nb = 0;
   for (int q = 0; q < n; q++) {
-    int v = C.queue[q];
+    int v = Q[q];
     int d = C.dist[v];
     if (d < js) na++;
     else if (d > js) nb++;
@@ -118,16 +121,47 @@ void nd(NDCtx& C, int begin, int end) {
   }
   int pa = begin, pb = begin + na, ps = begin + na + nb;
   for (int q = 0; q < n; q++) {
-    int v = C.queue[q];
+    int v = Q[q];
     int d = C.dist[v];
     if (d < js) C.tmp[pa++] = v;
     else if (d > js) C.tmp[pb++] = v;
     else C.tmp[ps++] = v;
   }
   std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
-  nd(C, begin, begin + na);
-  nd(C, begin + na, begin + na + nb);
   emit_panels(C, begin + na + nb, end);
+  // the two halves touch disjoint vertices and disjoint position ranges: fork one of them near the top
+  if (depth < C.max_par_depth && na > 512 && nb > 512) {
+    std::thread t([&C, begin, na, depth] { nd(C, begin, begin + na, depth + 1); });
+    nd(C, begin + na, begin + na + nb, depth + 1);
+    t.join();
+  } else {
+    nd(C, begin, begin + na, depth + 1);
+    nd(C, begin + na, begin + na + nb, depth + 1);
+  }
+}
+
+// run fn(lo, hi) over [0, n) on up to nthreads threads (static split)
+template <typename Fn>
+void parallel_for(int n, int nthreads, Fn&& fn) {
+  if (nthreads <= 1 || n < 4096) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  int per = (n + nthreads - 1) / nthreads;
+  for (int t = 1; t < nthreads; t++) {
+    int lo = t * per, hi = std::min(n, lo + per);
+    if (lo < hi) th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+  }
+  fn(0, std::min(n, per));
+  for (auto& x : th) x.join();
+}
+
+int host_threads() {
+  static int n = [] {
+    const char* e = getenv("CGMR_HOST_THREADS");
+    int v = e ? atoi(e) : 0;
+    if (v <= 0) { unsigned hc = std::thread::hardware_concurrency(); v = hc >= 8 ? 4 : (hc >= 4 ? 2 : 1); }
+    return std::max(1, std::min(v, 16));
+  }();
+  return n;
 }
 
 }  // namespace
@@ -177,17 +211,20 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     ai.resize(w);
   }
   // nested dissection
+  const int NT = host_threads();
   std::vector<int32_t> order(nf), panel_start;
   for (int v = 0; v < nf; v++) order[v] = v;
   {
-    NDCtx C{ap, ai, order, panel_start, {}, {}, {}, {}, {}, 1};
+    std::vector<uint8_t> pstart(nf, 0);
+    NDCtx C{ap, ai, order, pstart};
     C.label.assign(nf, 0);
     C.dist.assign(nf, 0);
     C.queue.assign(nf, 0);
     C.tmp.assign(nf, 0);
-    nd(C, 0, nf);
+    C.max_par_depth = NT >= 8 ? 3 : (NT >= 4 ? 2 : (NT >= 2 ? 1 : 0));
+    nd(C, 0, nf, 0);
+    for (int p = 0; p < nf; p++) if (pstart[p]) panel_start.push_back(p);
   }
-  std::sort(panel_start.begin(), panel_start.end());
   std::vector<int32_t> iperm(nf);
   for (int p = 0; p < nf; p++) iperm[order[p]] = p;
   S.perm.assign(nf, -1);
@@ -198,11 +235,13 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   // adjacency in permuted indices, rows sorted
   std::vector<int32_t> cp(nf + 1, 0), ci(ai.size());
   for (int c = 0; c < nf; c++) cp[c + 1] = cp[c] + (ap[order[c] + 1] - ap[order[c]]);
-  for (int c = 0; c < nf; c++) {
-    int o = order[c], w = cp[c];
-    for (int p = ap[o]; p < ap[o + 1]; p++) ci[w++] = iperm[ai[p]];
-    std::sort(ci.begin() + cp[c], ci.begin() + cp[c + 1]);
-  }
+  parallel_for(nf, NT, [&](int lo, int hi) {
+    for (int c = lo; c < hi; c++) {
+      int o = order[c], w = cp[c];
+      for (int p = ap[o]; p < ap[o + 1]; p++) ci[w++] = iperm[ai[p]];
+      std::sort(ci.begin() + cp[c], ci.begin() + cp[c + 1]);
+    }
+  });
   // unique lower off-diagonal blocks: enumerate (c, r>c) column-major
   std::vector<int32_t> offbase(nf + 1, 0);
   for (int c = 0; c < nf; c++) {
@@ -226,15 +265,17 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   // assembly CSR: block -> contributing edge terms
   S.asm_ptr.assign(nf + S.nb + 1, 0);
   std::vector<int32_t> e_off(nE, -1);
+  parallel_for(nE, NT, [&](int lo, int hi) {
+    for (int k = lo; k < hi; k++) {
+      int a = S.vperm[ef[k]], b = S.vperm[et[k]];
+      if (a >= 0 && b >= 0 && a != b) e_off[k] = a > b ? off_id(a, b) : off_id(b, a);
+    }
+  });
   for (int k = 0; k < nE; k++) {
     int a = S.vperm[ef[k]], b = S.vperm[et[k]];
     if (a >= 0) S.asm_ptr[a + 1]++;
     if (b >= 0 && !(a == b && a >= 0)) S.asm_ptr[b + 1]++;
-    if (a >= 0 && b >= 0 && a != b) {
-      int id = a > b ? off_id(a, b) : off_id(b, a);
-      e_off[k] = id;
-      S.asm_ptr[nf + id + 1]++;
-    }
+    if (e_off[k] >= 0) S.asm_ptr[nf + e_off[k] + 1]++;
   }
   for (int q = 0; q < nf + S.nb; q++) S.asm_ptr[q + 1] += S.asm_ptr[q];
   S.asm_src.resize(S.asm_ptr[nf + S.nb]);
