@@ -1,4 +1,5 @@
 // C ABI of the scan matcher (include/cgmr.h): configuration, buffers, launch.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -44,17 +45,9 @@ struct Layout {
   size_t add(size_t bytes) { off = (off + 255) & ~size_t(255); size_t o = off; off += bytes; return o; }
 };
 
-int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const float* d_ref, const float* d_qry,
-              const double* d_guess, double max_score, double* d_xyt, double* d_score, uint8_t* d_found,
-              int32_t* d_nres) {
-  if (!cfg || n_pairs < 0) return set_err(ctx, CGMR_E_INVALID, "cgmr_match_close_batch: bad argument");
-  if (cfg->n_beams <= 0 || cfg->n_beams > kMatchMaxPoints)
-    return set_err(ctx, CGMR_E_INVALID, "n_beams %d outside (0, %d]", cfg->n_beams, kMatchMaxPoints);
-  MatchParams P;
+// grid geometry + kernel of a ScanMatcher (initializeGrid / initializeKernel)
+int setup_geometry(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, MatchParams& P, std::vector<uint8_t>& kern) {
   memset(&P, 0, sizeof P);
-  P.n_pairs = n_pairs;
-  P.n_beams = cfg->n_beams;
-  // _GridMap(lowerLeft, upperRight, res): float resolution, inverse via double division (gridmap.h:196-206)
   P.ll_x = cfg->grid_ll_x; P.ll_y = cfg->grid_ll_y;
   P.res = (float)cfg->resolution;
   P.inv_res = (float)(1. / P.res);
@@ -64,10 +57,25 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const 
   if (P.nx <= 0 || P.ny <= 0 || (ntx + 2) * (nty + 6) > kMatchMaxDir)
     return set_err(ctx, CGMR_E_INVALID, "grid %dx%d cells exceeds the %d-tile directory", P.nx, P.ny, kMatchMaxDir);
   P.kscale = cfg->kscale;
-  std::vector<uint8_t> kern;
   P.kdim = make_kernel(cfg->resolution, cfg->kernel_range, cfg->kscale, kern);
   if (P.kdim < 0) return set_err(ctx, CGMR_E_INVALID, "kernel (range %g, res %g) not representable", cfg->kernel_range, cfg->resolution);
   P.fill = (int)(cfg->kernel_range * cfg->kscale);
+  P.overflow_tiles = ntx * nty;
+  P.x_steps = 1; P.y_steps = 1;
+  return CGMR_OK;
+}
+
+int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const float* d_ref, const float* d_qry,
+              const double* d_guess, double max_score, double* d_xyt, double* d_score, uint8_t* d_found,
+              int32_t* d_nres) {
+  if (!cfg || n_pairs < 0) return set_err(ctx, CGMR_E_INVALID, "cgmr_match_close_batch: bad argument");
+  if (cfg->n_beams <= 0 || cfg->n_beams > kMatchMaxPoints)
+    return set_err(ctx, CGMR_E_INVALID, "n_beams %d outside (0, %d]", cfg->n_beams, kMatchMaxPoints);
+  MatchParams P;
+  std::vector<uint8_t> kern;
+  { int rc0 = setup_geometry(ctx, cfg, P, kern); if (rc0) return rc0; }
+  P.n_pairs = n_pairs;
+  P.n_beams = cfg->n_beams;
   P.max_range = cfg->max_range; P.min_range = cfg->min_range;
   P.lp_c = std::cos(cfg->laser_pose[2]); P.lp_s = std::sin(cfg->laser_pose[2]);
   P.lp_x = cfg->laser_pose[0]; P.lp_y = cfg->laser_pose[1];
@@ -75,10 +83,8 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const 
   P.theta_res = cfg->theta_res; P.max_score = max_score;
   P.dx = cfg->bin_x; P.dy = cfg->bin_y; P.dth = cfg->bin_theta;
   P.sub_res = cfg->subsample_res;
-  P.x_steps = 1; P.y_steps = 1;
   if ((2 * cfg->win_theta) / cfg->theta_res + 2 > kMatchMaxTheta)
     return set_err(ctx, CGMR_E_INVALID, "more than %d search angles", kMatchMaxTheta);
-  P.overflow_tiles = ntx * nty;
   P.scratch_stride = ((size_t)4 * kMatchMaxPoints * sizeof(double) + (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
   if (n_pairs == 0) return CGMR_OK;
   hipDeviceProp_t prop;
@@ -172,6 +178,185 @@ int cgmr_match_close_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_
   HIP_TRY(ctx, hipMemcpyAsync(out_found, d + o_f, n_pairs, hipMemcpyDeviceToHost, ctx->stream));
   if (out_nres) HIP_TRY(ctx, hipMemcpyAsync(out_nres, d + o_n, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CGMR_OK;
+}
+
+int cgmr_scan_cartesian(int n_beams, const float* ranges, double angle_min, double angle_inc, double max_range,
+                        double min_range, double* pts_out) {
+  if (n_beams < 0 || !ranges || !pts_out) return CGMR_E_INVALID;
+  int n = 0;
+  for (int i = 0; i < n_beams; i++) {
+    double r = (double)ranges[i];
+    if (r < max_range && r > min_range) {
+      double alpha = angle_min + i * angle_inc;
+      pts_out[2 * n] = std::cos(alpha) * r;
+      pts_out[2 * n + 1] = std::sin(alpha) * r;
+      n++;
+    }
+  }
+  return n;
+}
+
+int cgmr_subsample(int n, const double* pts, double res, double* out) {
+  if (n < 0 || (n > 0 && (!pts || !out))) return CGMR_E_INVALID;
+  double ires = 1. / res;
+  struct Key { int kx, ky, idx; };
+  std::vector<Key> keys(n);
+  for (int i = 0; i < n; i++) keys[i] = {(int)(ires * pts[2 * i]), (int)(ires * pts[2 * i + 1]), i};
+  std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+    if (a.kx != b.kx) return a.kx < b.kx;
+    if (a.ky != b.ky) return a.ky < b.ky;
+    return a.idx < b.idx;
+  });
+  int m = 0;
+  for (int i = 0; i < n;) {
+    int j = i, cnt = 0;
+    double ax = 0, ay = 0;
+    while (j < n && keys[j].kx == keys[i].kx && keys[j].ky == keys[i].ky) {
+      ax += pts[2 * keys[j].idx]; ay += pts[2 * keys[j].idx + 1]; cnt++; j++;
+    }
+    double w = 1. / (double)cnt;
+    out[2 * m] = ax * w; out[2 * m + 1] = ay * w;
+    m++;
+    i = j;
+  }
+  return m;
+}
+
+int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts, int n_qry,
+                      const double* qry_pts, int n_regions, const float* regions, double step_x, double step_y,
+                      double theta_res, double max_score, double dx, double dy, double dth,
+                      cgmr_match_result* results_out, int cap, int* n_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || n_ref < 0 || n_qry < 0 || n_regions < 0 || cap < 0 || !n_out || (n_ref > 0 && !ref_pts) ||
+      (n_qry > 0 && !qry_pts) || (n_regions > 0 && !regions) || (cap > 0 && !results_out) || !(theta_res > 0) ||
+      !(dx > 0) || !(dy > 0) || !(dth > 0))
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_match_greedy: bad argument");
+  if (n_ref > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d reference points", kMatchMaxRef);
+  *n_out = 0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MatchParams P;
+  std::vector<uint8_t> kern;
+  int rc = setup_geometry(ctx, cfg, P, kern);
+  if (rc) return rc;
+  P.max_score = max_score; P.dx = dx; P.dy = dy; P.dth = dth; P.theta_res = theta_res;
+  P.n_ref = n_ref; P.n_qry = n_qry; P.n_regions = n_regions;
+  // chargrid.cpp:214-221
+  int xs = (int)(step_x / P.res), ys = (int)(step_y / P.res);
+  if (xs <= 0) xs = 1;
+  if (ys <= 0) ys = 1;
+  P.x_steps = xs; P.y_steps = ys;
+  if (n_regions == 0) return CGMR_OK;
+  // regions -> descriptors, exactly like the reference walks them (chargrid.cpp:223-239)
+  const int num_threads = std::min(n_regions, 4);
+  const int chunk = n_regions / num_threads;
+  std::vector<RegionDesc> R(n_regions);
+  std::vector<double> theta;
+  std::vector<int32_t> items;
+  std::vector<uint32_t> next_order(num_threads, 0);
+  bool any = false;
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
+  auto w2g = [&](float w, float ll) { return (int)std::lrint((w - ll) * P.inv_res); };
+  for (int r = 0; r < n_regions; r++) {
+    const float* g = regions + 6 * r;
+    RegionDesc& D = R[r];
+    D.lo_x = w2g(g[0], P.ll_x); D.lo_y = w2g(g[1], P.ll_y);
+    int hi_x = w2g(g[3], P.ll_x), hi_y = w2g(g[4], P.ll_y);
+    D.ni = hi_x > D.lo_x ? (hi_x - D.lo_x + xs - 1) / xs : 0;
+    D.nj = hi_y > D.lo_y ? (hi_y - D.lo_y + ys - 1) / ys : 0;
+    D.th_off = (int)theta.size();
+    for (double t = g[2]; t < g[5]; t += theta_res) {
+      theta.push_back(t);
+      if (theta.size() - D.th_off > 100000) return set_err(ctx, CGMR_E_INVALID, "too many search angles in a region");
+    }
+    D.nth = (int)theta.size() - D.th_off;
+    D.thread = std::min(r / chunk, num_threads - 1);
+    D.order_base = next_order[D.thread];
+    unsigned long long cnt = (unsigned long long)D.nth * D.ni * D.nj;
+    if (next_order[D.thread] + cnt > 0xffffffffULL) return set_err(ctx, CGMR_E_INVALID, "search space exceeds 2^32 candidates per result map");
+    next_order[D.thread] += (uint32_t)cnt;
+    if (cnt == 0) continue;
+    for (int ti = 0; ti < D.nth; ti++) { items.push_back(r); items.push_back(ti); }
+    float xa = P.ll_x + (P.res * (float)D.lo_x), xb = P.ll_x + (P.res * (float)(D.lo_x + (D.ni - 1) * xs));
+    float ya = P.ll_y + (P.res * (float)D.lo_y), yb = P.ll_y + (P.res * (float)(D.lo_y + (D.nj - 1) * ys));
+    int a0 = (int)((double)xa / dx), a1 = (int)((double)xb / dx), c0 = (int)((double)ya / dy), c1 = (int)((double)yb / dy);
+    int e0 = (int)(theta[D.th_off] / dth), e1 = (int)(theta[D.th_off + D.nth - 1] / dth);
+    if (!any) { bx0 = a0; bx1 = a1; by0 = c0; by1 = c1; bt0 = e0; bt1 = e1; any = true; }
+    else { bx0 = std::min(bx0, a0); bx1 = std::max(bx1, a1); by0 = std::min(by0, c0); by1 = std::max(by1, c1);
+           bt0 = std::min(bt0, e0); bt1 = std::max(bt1, e1); }
+  }
+  if (!any) return CGMR_OK;
+  P.bx0 = bx0; P.by0 = by0; P.bt0 = bt0; P.nbx = bx1 - bx0 + 1; P.nby = by1 - by0 + 1; P.nbt = bt1 - bt0 + 1;
+  const size_t nbins = (size_t)P.nbx * P.nby * P.nbt;
+  if (nbins * num_threads > (size_t)1 << 26) return set_err(ctx, CGMR_E_INVALID, "result discretisation too fine for the search volume");
+  P.n_items = (int)items.size() / 2;
+  int nblocks = std::max(1, std::min(128, P.n_items / 8));
+  P.scratch_stride = ((size_t)4 * kMatchMaxRef + (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
+  Layout L;
+  size_t o_ref = L.add(16 * (size_t)std::max(n_ref, 1)), o_q = L.add(16 * (size_t)std::max(n_qry, 1)),
+         o_reg = L.add(sizeof(RegionDesc) * R.size()), o_th = L.add(8 * theta.size()), o_it = L.add(4 * items.size()),
+         o_kern = L.add(kern.size()), o_err = L.add(16);
+  size_t hbytes = L.off;
+  size_t o_bins = L.add(8 * nbins * num_threads), o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
+  rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
+  if (rc) return rc;
+  rc = pinned_reserve(ctx, std::max(hbytes, 8 * nbins * num_threads));
+  if (rc) return rc;
+  char* h = ctx->pinned;
+  if (n_ref) memcpy(h + o_ref, ref_pts, 16 * (size_t)n_ref);
+  if (n_qry) memcpy(h + o_q, qry_pts, 16 * (size_t)n_qry);
+  memcpy(h + o_reg, R.data(), sizeof(RegionDesc) * R.size());
+  memcpy(h + o_th, theta.data(), 8 * theta.size());
+  memcpy(h + o_it, items.data(), 4 * items.size());
+  memcpy(h + o_kern, kern.data(), kern.size());
+  memset(h + o_err, 0, 16);
+  char* d = ctx->mt_arena.ptr;
+  HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d + o_bins, 0xff, 8 * nbins * num_threads, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  launch_match_greedy(ctx->stream, nblocks, P, (const double*)(d + o_ref), (const double*)(d + o_q),
+                      (const RegionDesc*)(d + o_reg), (const double*)(d + o_th), (const int32_t*)(d + o_it),
+                      (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch), (unsigned long long*)(d + o_bins),
+                      (int*)(d + o_err));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  int err = 0;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer is reused for the read-back below
+  HIP_TRY(ctx, hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h, d + o_bins, 8 * nbins * num_threads, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->match_seconds = 1e-3 * ms;
+  if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", err);
+  // decode: thread maps in thread order, each in (ix, iy, ith) order; then a stable sort on the score
+  const unsigned long long* bins = (const unsigned long long*)h;
+  std::vector<cgmr_match_result> res;
+  for (int th = 0; th < num_threads; th++)
+    for (size_t q = 0; q < nbins; q++) {
+      unsigned long long key = bins[(size_t)th * nbins + q];
+      if (key == ~0ULL) continue;
+      uint32_t ord = (uint32_t)(key & 0xffffffffu);
+      int reg = -1;
+      for (int r = 0; r < n_regions; r++)
+        if (R[r].thread == th && (unsigned long long)R[r].nth * R[r].ni * R[r].nj > 0 && ord >= R[r].order_base &&
+            ord - R[r].order_base < (unsigned long long)R[r].nth * R[r].ni * R[r].nj) { reg = r; break; }
+      if (reg < 0) return set_err(ctx, CGMR_E_INVALID, "corrupt result key");
+      const RegionDesc& D = R[reg];
+      uint32_t local = ord - D.order_base;
+      int ncand = D.ni * D.nj;
+      int ti = (int)(local / ncand), cidx = (int)(local % ncand);
+      int a = cidx / D.nj, b = cidx % D.nj;
+      float wx = P.ll_x + (P.res * (float)(D.lo_x + a * xs));
+      float wy = P.ll_y + (P.res * (float)(D.lo_y + b * ys));
+      uint32_t sb = (uint32_t)(key >> 32);
+      float sc;
+      memcpy(&sc, &sb, 4);
+      res.push_back({(double)wx, (double)wy, theta[D.th_off + ti], (double)sc});
+    }
+  std::stable_sort(res.begin(), res.end(), [](const cgmr_match_result& a, const cgmr_match_result& b) { return a.score < b.score; });
+  *n_out = (int)res.size();
+  for (int k = 0; k < (int)res.size() && k < cap; k++) results_out[k] = res[k];
   return CGMR_OK;
 }
 

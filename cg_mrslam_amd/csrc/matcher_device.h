@@ -25,9 +25,25 @@ struct MatchParams {
   int x_steps, y_steps;
   int overflow_tiles;
   size_t scratch_stride;
+  // generic multi-region search (k_match_greedy)
+  int n_ref, n_qry, n_regions, n_items;
+  int bx0, by0, bt0, nbx, nby, nbt;          // bounding box of the result bins over all regions
+};
+
+constexpr int kMatchMaxRef = 16384;          // reference points of one generic search (several scans)
+
+struct RegionDesc {                          // one search region, precomputed on the host exactly like
+  int32_t lo_x, lo_y;                        //   CharGrid::greedySearch does (chargrid.cpp:235-239)
+  int32_t ni, nj;                            // candidates along x / y
+  int32_t nth, th_off;                       // angles of this region: theta[th_off .. th_off + nth)
+  int32_t thread;                            // which of the reference's <= 4 OpenMP result maps it feeds
+  uint32_t order_base;                       // visit order of its first candidate inside that map
 };
 
 size_t match_smem_bytes();
+void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const double* ref_pts, const double* qry_pts,
+                         const RegionDesc* regions, const double* theta, const int32_t* items, const uint8_t* kernel_lut,
+                         unsigned char* scratch, unsigned long long* bins, int* err);
 void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,

@@ -166,6 +166,118 @@ __device__ int block_scan_excl(int v, int* sh, int* total) {
   return incl - v;
 }
 
+
+// addAndConvolvePoints' cell of a world point: double -> float, world2grid in float, lrint (chargrid.h:205-216)
+__device__ __forceinline__ uint32_t world_to_packed_cell(const MatchParams& P, double wx, double wy) {
+  float fx = (float)wx, fy = (float)wy;
+  float gx = (fx - P.ll_x) * P.inv_res, gy = (fy - P.ll_y) * P.inv_res;
+  gx = fminf(fmaxf(gx, -30000.f), 30000.f);
+  gy = fminf(fmaxf(gy, -30000.f), 30000.f);
+  int rx = __float2int_rn(gx), ry = __float2int_rn(gy);
+  return ((uint32_t)(uint16_t)(int16_t)rx) | ((uint32_t)(uint16_t)(int16_t)ry << 16);
+}
+
+// resetGrid + addAndConvolvePoints for n packed reference cells: directory marking, tile slot assignment (block
+// scan), tile initialisation, compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
+__device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
+                           int* err) {
+  const int tid = threadIdx.x;
+  const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
+  const int DW = nty + 6;
+  const int ndir = (ntx + 2) * DW;
+  const int K2 = P.fill;
+  const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
+  const int ctr = (P.kdim - 1) / 2;
+  for (int q = tid; q < (ndir + 1) / 2; q += 256) reinterpret_cast<uint32_t*>(S.dir)[q] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    uint32_t packed = rcell[i];
+    if (packed == 0x80008000u) continue;
+    int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+    int x0 = max(rx - ctr, 0), x1 = min(rx + ctr, P.nx - 1), y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
+    if (x0 <= x1 && y0 <= y1)
+      for (int tx = x0 >> 3; tx <= (x1 >> 3); tx++)
+        for (int ty = y0 >> 3; ty <= (y1 >> 3); ty++) S.dir[(tx + 1) * DW + ty + 3] = 1;
+  }
+  __syncthreads();
+  MPHASE(3);
+  {
+    const int per = (ndir + 255) / 256;
+    const int b0 = tid * per, b1 = min(ndir, b0 + per);
+    int cnt = 0;
+    for (int q = b0; q < b1; q++) cnt += S.dir[q];
+    int ntile;
+    int base = block_scan_excl(cnt, S.scan, &ntile);
+    // fast path: every tile (plus an all-fill and an all-zero tile) is resident in LDS and the grid is a
+    // whole number of tiles, so the search can gather without branches: untouched directory entries
+    // point at the all-fill tile, cells outside the grid are redirected to the all-zero tile.
+    const bool fastp = allow_fast && (ntile + 2 <= NT_LDS) && ((P.nx & 7) == 0) && ((P.ny & 7) == 0) &&
+                       P.x_steps == 1 && P.y_steps == 1 && K2 * PT <= 255;
+    for (int q = b0; q < b1; q++) {
+      const int row = q / DW, col = q - row * DW;
+      const bool guard = row == 0 || row == ntx + 1 || col < 3 || col >= nty + 3;
+      if (S.dir[q]) S.dir[q] = (uint16_t)base++;
+      else S.dir[q] = fastp ? (uint16_t)(guard ? ntile + 1 : ntile) : (uint16_t)0xFFFF;
+    }
+    if (tid == 0) { S.misc[0] = ntile; S.misc[12] = fastp ? 1 : 0; }
+    if (ntile > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
+  }
+  __syncthreads();
+  const int ntile = S.misc[0];
+  const bool fast = S.misc[12] != 0;
+  if (fast && tid < 16) { S.tiles[ntile * 16 + tid] = fill4; S.tiles[(ntile + 1) * 16 + tid] = 0u; }
+  for (int q = tid; q < min(ntile, NT_LDS) * 16; q += 256) S.tiles[q] = fill4;
+  for (int q = tid; q < max(0, ntile - NT_LDS) * 16; q += 256) gtiles[q] = fill4;
+  __syncthreads();
+  MPHASE(4);
+  // stamp: work item = (reference point, kernel row); byte-min through compare-and-swap on 32-bit words.
+  // Neighbouring beams stamp overlapping cells; spread concurrently processed items over far-apart points
+  // (stride 67 modulo an odd count) so that the compare-and-swap rarely has to retry.
+  const int np = n | 1;
+  for (int wi = tid; wi < np * P.kdim; wi += 256) {
+    int ki = wi / np, p = (int)(((long long)(wi - ki * np) * 67) % np);
+    if (p >= n) continue;
+    uint32_t packed = rcell[p];
+    if (packed == 0x80008000u) continue;
+    int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+    int x = rx + ki - ctr;
+    if (x < 0 || x >= P.nx) continue;
+    int y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
+    if (y0 > y1) continue;
+    for (int wy = y0 & ~3; wy <= y1; wy += 4) {        // aligned 4-cell words along y
+      uint32_t kv = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        int y = wy + b;
+        uint32_t v = (y >= y0 && y <= y1) ? S.kernel[(y - ry + ctr) * P.kdim + ki] : 0xffu;
+        kv |= v << (8 * b);
+      }
+      int d = S.dir[((x >> 3) + 1) * DW + (wy >> 3) + 3];
+      int woff = (x & 7) * 2 + ((wy & 7) >> 2);
+      uint32_t* wp = (d < NT_LDS) ? &S.tiles[d * 16 + woff] : &gtiles[(size_t)(d - NT_LDS) * 16 + woff];
+      uint32_t old = *wp;
+      while (true) {
+        uint32_t nw = bytemin4(old, kv);
+        if (nw == old) break;
+        uint32_t seen = atomicCAS(wp, old, nw);
+        if (seen == old) break;
+        old = seen;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// one grid cell through the directory, any tile location, with the reference's isInside test (generic path)
+__device__ __forceinline__ int grid_cell(const Smem& S, const MatchParams& P, const uint32_t* gtiles, int DW, int cx, int cy) {
+  if ((unsigned)cx >= (unsigned)P.nx || (unsigned)cy >= (unsigned)P.ny) return 0;
+  int d = S.dir[((cx >> 3) + 1) * DW + (cy >> 3) + 3];
+  if (d == 0xFFFF) return P.fill;
+  int boff = (cx & 7) * 8 + (cy & 7);
+  if (d < NT_LDS) return reinterpret_cast<const uint8_t*>(S.tiles)[d * 64 + boff];
+  return reinterpret_cast<const uint8_t*>(gtiles)[(size_t)(d - NT_LDS) * 64 + boff];
+}
+
 }  // namespace
 
 // One workgroup per scan pair (persistent stride over the batch).
@@ -272,101 +384,23 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     }
     __syncthreads();
     MPHASE(2);
-    // ---------------- reference scan -> cells; directory of touched tiles ---------------------------------
-    for (int q = tid; q < (ndir + 1) / 2; q += 256) reinterpret_cast<uint32_t*>(S.dir)[q] = 0;
+    // ---------------- reference scan -> cells -----------------------------------------------------------------
     uint32_t* rcell = S.plist[0];           // int16 x | int16 y << 16, 0x80008000 = invalid
-    const int ctr = (P.kdim - 1) / 2;
-    __syncthreads();
     for (int i = tid; i < B; i += 256) {
       uint32_t packed = 0x80008000u;
       double r = (double)ranges_ref[(size_t)pair * B + i];
       if (r < P.max_range && r > P.min_range) {
         double x = beam_cos[i] * r, y = beam_sin[i] * r;
         double wx = (P.lp_c * x - P.lp_s * y) + P.lp_x, wy = (P.lp_s * x + P.lp_c * y) + P.lp_y;
-        float fx = (float)wx, fy = (float)wy;
-        float gx = (fx - P.ll_x) * P.inv_res, gy = (fy - P.ll_y) * P.inv_res;
-        gx = fminf(fmaxf(gx, -30000.f), 30000.f);
-        gy = fminf(fmaxf(gy, -30000.f), 30000.f);
-        int rx = __float2int_rn(gx), ry = __float2int_rn(gy);
-        packed = ((uint32_t)(uint16_t)(int16_t)rx) | ((uint32_t)(uint16_t)(int16_t)ry << 16);
-        int x0 = max(rx - ctr, 0), x1 = min(rx + ctr, P.nx - 1), y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
-        if (x0 <= x1 && y0 <= y1)
-          for (int tx = x0 >> 3; tx <= (x1 >> 3); tx++)
-            for (int ty = y0 >> 3; ty <= (y1 >> 3); ty++) S.dir[DIRIDX(tx, ty)] = 1;
+        packed = world_to_packed_cell(P, wx, wy);
       }
       rcell[i] = packed;
     }
     __syncthreads();
-    MPHASE(3);
-    // assign tile indices in directory order
-    {
-      const int per = (ndir + 255) / 256;
-      const int b0 = tid * per, b1 = min(ndir, b0 + per);
-      int cnt = 0;
-      for (int q = b0; q < b1; q++) cnt += S.dir[q];
-      int ntile;
-      int base = block_scan_excl(cnt, S.scan, &ntile);
-      // fast path: every tile (plus an all-fill and an all-zero tile) is resident in LDS and the grid is a
-      // whole number of tiles, so the search can gather without branches: untouched directory entries
-      // point at the all-fill tile, cells outside the grid are redirected to the all-zero tile.
-      const bool fastp = (ntile + 2 <= NT_LDS) && ((P.nx & 7) == 0) && ((P.ny & 7) == 0) && P.x_steps == 1 &&
-                         P.y_steps == 1 && K2 * PT <= 255;
-      for (int q = b0; q < b1; q++) {
-        const int row = q / DW, col = q - row * DW;
-        const bool guard = row == 0 || row == ntx + 1 || col < 3 || col >= nty + 3;
-        if (S.dir[q]) S.dir[q] = (uint16_t)base++;
-        else S.dir[q] = fastp ? (uint16_t)(guard ? ntile + 1 : ntile) : (uint16_t)0xFFFF;
-      }
-      if (tid == 0) { S.misc[0] = ntile; S.misc[12] = fastp ? 1 : 0; }
-      if (ntile > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
-    }
-    __syncthreads();
+    build_grid(S, P, rcell, B, gtiles, /*allow_fast=*/true, err);
     const int ntile = S.misc[0];
     const bool fast = S.misc[12] != 0;
-    const int T_FILL = ntile, T_ZERO = ntile + 1;
-    if (fast && tid < 16) { S.tiles[T_FILL * 16 + tid] = fill4; S.tiles[T_ZERO * 16 + tid] = 0u; }
-    for (int q = tid; q < min(ntile, NT_LDS) * 16; q += 256) S.tiles[q] = fill4;
-    for (int q = tid; q < max(0, ntile - NT_LDS) * 16; q += 256) gtiles[q] = fill4;
-    __syncthreads();
-    MPHASE(4);
-    // stamp: work item = (reference point, kernel row); byte-min through compare-and-swap on 32-bit words
-    // neighbouring beams stamp overlapping cells; spread concurrently processed items over far-apart
-    // beams (stride 67 modulo a prime-ish count) so that the compare-and-swap rarely has to retry
-    const int Bp = B | 1;                                  // odd => 64 | 67 strides visit every residue
-    for (int wi = tid; wi < Bp * P.kdim; wi += 256) {
-      int ki = wi / Bp, p = (int)(((long long)(wi - ki * Bp) * 67) % Bp);
-      if (p >= B) continue;
-      uint32_t packed = rcell[p];
-      if (packed == 0x80008000u) continue;
-      int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
-      int x = rx + ki - ctr;
-      if (x < 0 || x >= P.nx) continue;
-      int y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
-      if (y0 > y1) continue;
-      for (int wy = y0 & ~3; wy <= y1; wy += 4) {        // aligned 4-cell words along y
-        uint32_t kv = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          int y = wy + b;
-          uint32_t v = (y >= y0 && y <= y1) ? S.kernel[(y - ry + ctr) * P.kdim + ki] : 0xffu;
-          kv |= v << (8 * b);
-        }
-        int d = S.dir[DIRIDX(x >> 3, wy >> 3)];
-        int woff = (x & 7) * 2 + ((wy & 7) >> 2);
-        uint32_t* wp;
-        bool in_lds = d < NT_LDS;
-        if (in_lds) wp = &S.tiles[d * 16 + woff];
-        else wp = &gtiles[(size_t)(d - NT_LDS) * 16 + woff];
-        uint32_t old = *wp;
-        while (true) {
-          uint32_t nw = bytemin4(old, kv);
-          if (nw == old) break;
-          uint32_t seen = atomicCAS(wp, old, nw);
-          if (seen == old) break;
-          old = seen;
-        }
-      }
-    }
+    const int T_ZERO = ntile + 1;
     MPHASE(5);
     // ---------------- search window, angle table, bins -----------------------------------------------------
     if (tid == 0) {
@@ -609,7 +643,130 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
   }
 }
 
+
+// Generic CharGrid::greedySearch over a set of regions (chargrid.cpp:208-308) on a grid rasterised from the given
+// reference points: used by the loop-closure and hierarchical/global matchers (scanMatchingLC, globalMatching,
+// scan_matcher.cpp:201-294,366-428).  Every workgroup rasterises the grid, then takes (region, angle) work items
+// round-robin, one per wavefront; the pruned result maps are one global table of 64-bit keys updated with
+// atomicMin (score bits << 32 | visit order inside the reference's per-thread map), decoded on the host.
+// Any grid size / step; cell reads go through the bounds-checked directory lookup.
+__global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const double* __restrict__ ref_pts,
+                                                      const double* __restrict__ qry_pts,
+                                                      const RegionDesc* __restrict__ regions,
+                                                      const double* __restrict__ theta,
+                                                      const int32_t* __restrict__ items,
+                                                      const uint8_t* __restrict__ kernel_lut,
+                                                      unsigned char* __restrict__ scratch,
+                                                      unsigned long long* __restrict__ bins, int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& S = *reinterpret_cast<Smem*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  unsigned char* my = scratch + (size_t)blockIdx.x * P.scratch_stride;
+  uint32_t* rcell = reinterpret_cast<uint32_t*>(my);                               // kMatchMaxRef packed cells
+  uint32_t* gtiles = rcell + kMatchMaxRef;
+  const int nty = (P.ny + 7) >> 3;
+  const int DW = nty + 6;
+  for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
+  for (int i = tid; i < P.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
+  __syncthreads();
+  build_grid(S, P, rcell, P.n_ref, gtiles, /*allow_fast=*/false, err);
+  const float ikscale = (float)(1. / (float)P.kscale);
+  const int nbins = P.nbx * P.nby * P.nbt;
+  for (int it0 = blockIdx.x * NTH; it0 < P.n_items; it0 += gridDim.x * NTH) {
+    const int it = it0 + wave;
+    if (it >= P.n_items) continue;
+    const RegionDesc R = regions[items[2 * it]];
+    const int ti = items[2 * it + 1];
+    const double t = theta[R.th_off + ti];
+    double sn, cs;
+    portable_sincos(t, &sn, &cs);
+    const int ncand = R.ni * R.nj;
+    for (int cb = 0; cb < ncand; cb += 64 * CAND_U) {
+      int ci[CAND_U], cj[CAND_U], sum[CAND_U];
+#pragma unroll
+      for (int u = 0; u < CAND_U; u++) {
+        int cidx = cb + u * 64 + lane;
+        int a = cidx / R.nj, b = cidx - a * R.nj;
+        ci[u] = R.lo_x + a * P.x_steps;
+        cj[u] = R.lo_y + b * P.y_steps;
+        sum[u] = 0;
+      }
+      // the point list is rebuilt in chunks of at most MAXPTS - 4 kept points
+      int k = 0;
+      uint32_t prev = 0;
+      bool have_prev = false;
+      for (int c0 = 0; c0 < P.n_qry; c0 += MAXPTS - 64) {
+        const int c1 = min(P.n_qry, c0 + MAXPTS - 64);
+        int kc = 0;
+        for (int base = c0; base < c1; base += 64) {
+          int q = base + lane;
+          uint32_t packed = 0;
+          bool valid = q < c1;
+          if (valid) {
+            double x = qry_pts[2 * q], y = qry_pts[2 * q + 1];
+            double px = cs * x - sn * y, py = sn * x + cs * y;
+            int ix = (int)(px * (double)P.inv_res), iy = (int)(py * (double)P.inv_res);
+            ix = min(max(ix, -32000), 32000);
+            iy = min(max(iy, -32000), 32000);
+            packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
+          }
+          uint32_t left = __shfl_up(packed, 1, 64);
+          if (lane == 0) left = prev;
+          bool keep = valid && ((lane == 0 && !have_prev) ? true : (packed != left));
+          unsigned long long mask = __ballot(keep);
+          int pos = kc + __popcll(mask & ((1ULL << lane) - 1ULL));
+          if (keep) S.plist[wave][pos] = packed;
+          kc += __popcll(mask);
+          int lastv = min(63, c1 - base - 1);
+          prev = __shfl(packed, lastv, 64);
+          have_prev = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < kc; q++) {
+          uint32_t packed = S.plist[wave][q];
+          int px = (int16_t)(packed & 0xffff), py = (int16_t)(packed >> 16);
+#pragma unroll
+          for (int u = 0; u < CAND_U; u++) sum[u] += grid_cell(S, P, gtiles, DW, px + ci[u], py + cj[u]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        k += kc;
+      }
+#pragma unroll
+      for (int u = 0; u < CAND_U; u++) {
+        int cidx = cb + u * 64 + lane;
+        if (cidx >= ncand) continue;
+        float dsum = (float)sum[u] * ikscale;
+        dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
+        if ((double)dsum < P.max_score) {
+          float wx = P.ll_x + (P.res * (float)ci[u]);
+          float wyy = P.ll_y + (P.res * (float)cj[u]);
+          int bx = (int)((double)wx / P.dx) - P.bx0, by = (int)((double)wyy / P.dy) - P.by0;
+          int bt = (int)(t / P.dth) - P.bt0;
+          if (bx < 0 || bx >= P.nbx || by < 0 || by >= P.nby || bt < 0 || bt >= P.nbt) { atomicExch(err, 4); continue; }
+          unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
+                                   (unsigned long long)(R.order_base + (unsigned)(ti * ncand + cidx));
+          atomicMin(&bins[(size_t)R.thread * nbins + (bx * P.nby + by) * P.nbt + bt], key);
+        }
+      }
+    }
+  }
+}
+
 size_t match_smem_bytes() { return sizeof(Smem); }
+
+void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const double* ref_pts, const double* qry_pts,
+                         const RegionDesc* regions, const double* theta, const int32_t* items, const uint8_t* kernel_lut,
+                         unsigned char* scratch, unsigned long long* bins, int* err) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_greedy), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sizeof(Smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_match_greedy, dim3(nblocks), dim3(256), sizeof(Smem), st, P, ref_pts, qry_pts, regions, theta, items,
+                     kernel_lut, scratch, bins, err);
+}
 
 void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref,
                               const float* ranges_qry, const double* guess, const double* beam_cos,

@@ -89,6 +89,155 @@ class ScanMatcher:
         return s.value
 
 
+class MatchResult(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("theta", C.c_double), ("score", C.c_double)]
+
+
+def _se2_mul(a, b):
+    """g2o SE2 product: translation a.t + R(a.theta) b.t, angle normalised [g2o-recalled]."""
+    import math
+    c, s = math.cos(a[2]), math.sin(a[2])
+    t = a[2] + b[2]
+    if not (-math.pi <= t < math.pi):
+        t = t - 2 * math.pi * math.floor((t + math.pi) / (2 * math.pi))
+    return np.array([a[0] + (c * b[0] - s * b[1]), a[1] + (s * b[0] + c * b[1]), t])
+
+
+def _se2_inv(a):
+    import math
+    c, s = math.cos(a[2]), math.sin(a[2])
+    return np.array([-(c * a[0] + s * a[1]), -(-s * a[0] + c * a[1]), -a[2]])
+
+
+def normalize_theta(t):
+    import math
+    if -math.pi <= t < math.pi:
+        return t
+    return t - 2 * math.pi * math.floor((t + math.pi) / (2 * math.pi))
+
+
+class LCScanMatcher(ScanMatcher):
+    """The loop-closure matcher of GraphSLAM::init (src/slam/graph_slam.cpp:61-62): kernel (0.1, 0.5), grid
+    [-35,35]^2 at 0.1 m -- plus the generic searches every ScanMatcher can run.  Scans are passed as
+    ``(ranges, vertex_pose)`` pairs, the flat-array form of a g2o VertexSet with RobotLaser user data."""
+
+    def __init__(self, ctx, n_beams, angle_min, angle_inc, max_range, laser_pose=(0.0, 0.0, 0.0)):
+        super().__init__(ctx, n_beams, angle_min, angle_inc, max_range, laser_pose, resolution=0.1, kernel_range=0.5)
+        self.initializeGrid((-35, -35), (35, 35), 0.1)
+
+    # ---- host helpers with the reference's arithmetic (libcgmr.so, no GPU) -----------------------------------
+    def cartesian(self, ranges):
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        out = np.zeros((len(r), 2))
+        n = self.ctx.lib.cgmr_scan_cartesian(C.c_int(len(r)), C.c_void_p(r.ctypes.data), C.c_double(self.cfg.angle_min),
+                                             C.c_double(self.cfg.angle_inc), C.c_double(self.cfg.max_range),
+                                             C.c_double(self.cfg.min_range), C.c_void_p(out.ctypes.data))
+        return out[:n].copy()
+
+    def subsample(self, pts, res=0.1):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+        out = np.zeros_like(pts)
+        n = self.ctx.lib.cgmr_subsample(C.c_int(len(pts)), C.c_void_p(pts.ctypes.data), C.c_double(res),
+                                        C.c_void_p(out.ctypes.data))
+        return out[:n].copy()
+
+    @staticmethod
+    def applyTransfToScan(transf, pts):   # noqa: N802  (scan_matcher.cpp:78-87)
+        import math
+        c, s = math.cos(transf[2]), math.sin(transf[2])
+        pts = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+        return np.stack([(c * pts[:, 0] - s * pts[:, 1]) + transf[0], (s * pts[:, 0] + c * pts[:, 1]) + transf[1]], axis=1)
+
+    def transformPointsFromVSet(self, scans, ref_index):   # noqa: N802  (scan_matcher.cpp:89-110)
+        """scans: list of (ranges, pose) in the caller's (id-ordered) iteration order; ref_index: the reference vertex."""
+        lp = np.array([self.cfg.laser_pose[k] for k in range(3)])
+        ref_pose = np.asarray(scans[ref_index][1], dtype=np.float64)
+        out = []
+        for k, (ranges, pose) in enumerate(scans):
+            v = self.cartesian(ranges)
+            if k == ref_index:
+                out.append(self.applyTransfToScan(lp, v))
+            else:
+                trel = _se2_mul(_se2_inv(ref_pose), np.asarray(pose, dtype=np.float64))
+                out.append(self.applyTransfToScan(_se2_mul(trel, lp), v))
+        return np.concatenate(out) if out else np.zeros((0, 2))
+
+    # ---- CharGrid::greedySearch / hierarchicalSearch on the GPU ---------------------------------------------
+    def greedySearch(self, ref_pts, qry_pts, regions, thetaRes, maxScore, dx, dy, dth, step=None, cap=65536):   # noqa: N802,N803
+        ref = np.ascontiguousarray(ref_pts, dtype=np.float64).reshape(-1, 2)
+        qry = np.ascontiguousarray(qry_pts, dtype=np.float64).reshape(-1, 2)
+        reg = np.ascontiguousarray(regions, dtype=np.float32).reshape(-1, 6)
+        step = float(np.float32(self.cfg.resolution)) if step is None else float(step)
+        buf = (MatchResult * cap)()
+        n = C.c_int(0)
+        rc = self.ctx.lib.cgmr_match_greedy(self.ctx.h, C.byref(self.cfg), C.c_int(len(ref)), C.c_void_p(ref.ctypes.data),
+                                            C.c_int(len(qry)), C.c_void_p(qry.ctypes.data), C.c_int(len(reg)),
+                                            C.c_void_p(reg.ctypes.data), C.c_double(step), C.c_double(step),
+                                            C.c_double(thetaRes), C.c_double(maxScore), C.c_double(dx), C.c_double(dy),
+                                            C.c_double(dth), buf, C.c_int(cap), C.byref(n))
+        self.ctx._check(rc)
+        m = min(n.value, cap)
+        return np.array([[buf[k].x, buf[k].y, buf[k].theta, buf[k].score] for k in range(m)]).reshape(-1, 4)
+
+    def hierarchicalSearch(self, ref_pts, qry_pts, regions, thetaRes, maxScore, dx, dy, dth, nLevels):   # noqa: N802,N803
+        """chargrid.cpp:310-344 + 376-400: coarse-to-fine, every surviving result seeds a region of the next level."""
+        res_f = float(np.float32(self.cfg.resolution))
+        cur = np.ascontiguousarray(regions, dtype=np.float32).reshape(-1, 6)
+        out = np.zeros((0, 4))
+        for lv in range(nLevels):
+            i = nLevels - 1 - lv
+            m = 2 ** i
+            mtheta = m if m // 2 < 1 else m // 2
+            last = lv == nLevels - 1
+            if last and len(out) == 0:
+                break                                   # the last level only runs if the previous one found something
+            out = self.greedySearch(ref_pts, qry_pts, cur, mtheta * thetaRes, maxScore, dx * m, dy * m, dth * m,
+                                    step=float(np.float32(m) * np.float32(res_f)))
+            if last or len(out) == 0:
+                break
+            half = np.array([dx * m, dy * m, dth * m]) * .5
+            cur = np.concatenate([(-half + out[:, :3]).astype(np.float32), (half + out[:, :3]).astype(np.float32)], axis=1)
+        return out
+
+    # ---- ScanMatcher::scanMatchingLC (scan_matcher.cpp:201-294) ---------------------------------------------
+    def scanMatchingLC(self, ref_scans, ref_index, cur_scans, cur_index, maxScore):   # noqa: N802,N803
+        """Returns the list of SE2 (x, y, theta) the reference pushes into ``trel`` (0-2 entries)."""
+        ref_pts = self.transformPointsFromVSet(ref_scans, ref_index)
+        qry = self.subsample(self.transformPointsFromVSet(cur_scans, cur_index), 0.1)
+        ref_pose = np.asarray(ref_scans[ref_index][1], dtype=np.float64)
+        regions, regionspi = [], []
+        for k, (_, pose) in enumerate(ref_scans):
+            rel = np.zeros(3) if k == ref_index else _se2_mul(_se2_inv(ref_pose), np.asarray(pose, dtype=np.float64))
+            lower = np.array([-.5 + rel[0], -1.5 + rel[1], -0.8 + rel[2]], dtype=np.float32)
+            upper = np.array([.5 + rel[0], 1.5 + rel[1], 0.8 + rel[2]], dtype=np.float32)
+            regions.append(np.concatenate([lower, upper]))
+            lower2, upper2 = lower.copy(), upper.copy()
+            lower2[2] += np.float32(np.pi)           # Vector3f += M_PI: float arithmetic
+            upper2[2] += np.float32(np.pi)
+            regionspi.append(np.concatenate([lower2, upper2]))
+        theta_res, dx, dy, dth = 0.025, 0.5, 0.5, 0.2
+        merged = {}
+        for regs in (regions, regionspi):
+            res = self.greedySearch(ref_pts, qry, np.array(regs), theta_res, maxScore, dx, dy, dth)
+            if len(res):
+                best = res[0].copy()
+                best[2] = normalize_theta(best[2])
+                key = (int(best[0] / dx), int(best[1] / dy), int(best[2] / dth))
+                if key not in merged or merged[key][3] > best[3]:     # addToPrunedMap
+                    merged[key] = best
+        return [merged[k][:3].copy() for k in sorted(merged)]
+
+    # ---- ScanMatcher::globalMatching (scan_matcher.cpp:366-428) ---------------------------------------------
+    def globalMatching(self, ref_scans, ref_index, cur_scans, cur_index, maxScore):   # noqa: N802,N803
+        ref_pts = self.transformPointsFromVSet(ref_scans, ref_index)
+        qry = self.subsample(self.transformPointsFromVSet(cur_scans, cur_index), 0.1)
+        region = np.array([[-10, -5, np.float32(-np.pi), 10, 5, np.float32(np.pi)]], dtype=np.float32)
+        res = self.hierarchicalSearch(ref_pts, qry, region, 0.025, maxScore, 0.5, 0.5, 0.2, 4)
+        if len(res):
+            return True, res[0, :3].copy()
+        return False, None
+
+
 def smoke(ctx, oracle) -> None:
     """Tiny invocation checked against the oracle (used by __graft_entry__.smoke)."""
     from . import synth

@@ -177,6 +177,33 @@ int cgmr_condense(cgmr_ctx* ctx, int nV, const double* poses_xyt, int nE, const 
                   const int32_t* to_idx, const double* meas_xyt, const double* info_upper, int gauge_idx, int nK,
                   const int32_t* query_idx, int32_t* to_out, double* est_out, double* info_upper_out, double* cov_out);
 
+/* ------------------------------------------------------------------------------------------
+ * Generic correlative search (loop-closure / hierarchical / global matching).
+ *
+ * cgmr_match_greedy replaces CharGrid::greedySearch(mresvec, points, regions, params)
+ * (src/matcher/chargrid.cpp:208-308) preceded by resetGrid + addAndConvolvePoints of the reference points
+ * (src/matcher/scan_matcher.cpp:206-210): the building block of ScanMatcher::scanMatchingLC (scan_matcher.cpp:201-294),
+ * CharGrid::hierarchicalSearch (chargrid.cpp:310-413) and ScanMatcher::globalMatching (scan_matcher.cpp:366-428),
+ * whose region bookkeeping is host logic (cg_mrslam_amd/matcher.py mirrors it).
+ *   cfg            grid geometry + kernel (e.g. the LC matcher: [-35,35]^2 at 0.1 m, kernel range 0.5, graph_slam.cpp:61-62)
+ *   ref_pts_xy     [n_ref*2]  reference points already in the reference vertex' frame (transformPointsFromVSet)
+ *   qry_pts_xy     [n_qry*2]  query points (already subsampled, scan_matcher.cpp:216-217)
+ *   regions        [n_regions*6] float32: lower (x, y, theta), upper (x, y, theta)  (struct Region, chargrid.h:87-91)
+ *   step_x/step_y  searchStep; theta_res; max_score; dx/dy/dth resultsDiscretization (MatchingParameters, chargrid.h:94-99)
+ *   results_out    up to cap results {x, y, theta, score}, ascending score (ties: result-map order); *n_out = total found
+ * The reference's <= 4 per-thread result maps are reproduced (a bin can appear once per map).            */
+typedef struct cgmr_match_result { double x, y, theta, score; } cgmr_match_result;
+int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts_xy, int n_qry,
+                      const double* qry_pts_xy, int n_regions, const float* regions, double step_x, double step_y,
+                      double theta_res, double max_score, double dx, double dy, double dth,
+                      cgmr_match_result* results_out, int cap, int* n_out);
+
+/* Host helpers with the reference's exact arithmetic (no GPU): RawLaser::cartesian [g2o-recalled] and
+ * CharGrid::subsample (src/matcher/chargrid.cpp:61-122).  Both return the number of points written. */
+int cgmr_scan_cartesian(int n_beams, const float* ranges, double angle_min, double angle_inc, double max_range,
+                        double min_range, double* pts_out);
+int cgmr_subsample(int n, const double* pts_xy, double res, double* pts_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,3 +104,93 @@ def test_rejects_bad_configuration(ctx):
     m.initializeGrid((-100, -100), (100, 100), 0.025)      # 8000x8000 cells: beyond the tile directory
     with pytest.raises(CgmrError):
         m.closeScanMatching(sp["ranges_ref"], sp["ranges_qry"], sp["guess"])
+
+
+# ----------------------------------------------------------------------- generic searches (LC / hierarchical)
+
+def _lc(ctx, sp):
+    from cg_mrslam_amd.matcher import LCScanMatcher
+    return LCScanMatcher(ctx, sp["n_beams"], sp["angle_min"], sp["angle_inc"], sp["max_range"])
+
+
+def test_greedy_multi_region_matches_oracle(ctx, oracle):
+    """CharGrid::greedySearch with 1..9 regions (more than the 4 per-thread result maps), full sorted result list."""
+    sp = synth.make_scan_pairs(2, seed=90)
+    m = _lc(ctx, sp)
+    for p in range(2):
+        ref = m.cartesian(sp["ranges_ref"][p])
+        q = m.subsample(m.cartesian(sp["ranges_qry"][p]))
+        assert np.array_equal(ref, oracle.cartesian(sp["ranges_ref"][p], sp["angle_min"], sp["angle_inc"], sp["max_range"]))
+        assert np.array_equal(q, oracle.subsample(oracle.cartesian(sp["ranges_qry"][p], sp["angle_min"], sp["angle_inc"], sp["max_range"])))
+        g = sp["guess"][p]
+        base = np.array([-.5 + g[0], -1.5 + g[1], -.8 + g[2], .5 + g[0], 1.5 + g[1], .8 + g[2]])
+        rng = np.random.default_rng(p)
+        for nreg in (1, 3, 9):
+            regs = np.array([base + np.tile(rng.uniform(-0.4, 0.4, 3), 2) for _ in range(nreg)], dtype=np.float32)
+            regs[0] = base
+            got = m.greedySearch(ref, q, regs, 0.025, 0.3, 0.5, 0.5, 0.2)
+            n, want = oracle.greedy_search((-35, -35), (35, 35), 0.1, 0.1, 0.5, ref, q, regs, 0.1, 0.025, 0.3, 0.5, 0.5, 0.2)
+            assert len(got) == n > 0
+            assert np.array_equal(got, want)
+    # degenerate inputs: empty region (upper < lower), no query points
+    empty = np.array([[0.5, 0.5, 0.1, 0.2, 0.2, 0.0]], dtype=np.float32)
+    assert len(m.greedySearch(ref, q, empty, 0.025, 0.3, 0.5, 0.5, 0.2)) == 0
+    assert len(m.greedySearch(ref, np.zeros((0, 2)), regs, 0.025, 0.3, 0.5, 0.5, 0.2)) == 0
+
+
+def test_hierarchical_and_global_matching(ctx, oracle):
+    sp = synth.make_scan_pairs(2, seed=91)
+    m = _lc(ctx, sp)
+    region = np.array([[-10, -5, np.float32(-np.pi), 10, 5, np.float32(np.pi)]], dtype=np.float32)
+    for p in range(2):
+        ref = m.cartesian(sp["ranges_ref"][p])
+        q = m.subsample(m.cartesian(sp["ranges_qry"][p]))
+        got = m.hierarchicalSearch(ref, q, region, 0.025, 0.2, 0.5, 0.5, 0.2, 4)
+        n, want = oracle.hierarchical_search((-35, -35), (35, 35), 0.1, 0.1, 0.5, ref, q, region, 0.025, 0.2, 0.5, 0.5, 0.2, 4)
+        assert len(got) == n and np.array_equal(got, want)
+        assert len(m.hierarchicalSearch(ref, q, region, 0.025, 0.2, 0.5, 0.5, 0.2, 1)) == 0      # reference quirk
+        ok, trel = m.globalMatching([(sp["ranges_ref"][p], np.zeros(3))], 0, [(sp["ranges_qry"][p], sp["guess"][p])], 0, 0.2)
+        assert ok
+        err = np.abs(trel - sp["true_rel"][p])
+        assert err[0] < 0.15 and err[1] < 0.15 and err[2] < 0.06          # LC grid is 0.1 m, theta step 0.025
+
+
+def test_scan_matching_lc_multi_scan_reference_set(ctx, oracle):
+    """scanMatchingLC (scan_matcher.cpp:201-294) with a 3-scan reference set: the host-side region/merge logic
+    around the GPU search is checked against the same flow driven by the oracle's greedy search."""
+    ang = synth.LASER_ANGLE_MIN + synth.LASER_ANGLE_INC * np.arange(1081)
+    boxes = [(-6.0, -4.5, 6.0, 4.5), (1.0, 1.0, 2.2, 2.0)]
+    poses = [np.array([0.0, 0.0, 0.1]), np.array([0.5, 0.1, 0.2]), np.array([-0.4, 0.3, -0.1])]
+    scans = [(synth._raycast_boxes(p[0], p[1], p[2] + ang, boxes, 30.0).astype(np.float32), p) for p in poses]
+    true_cur = np.array([0.8, -0.6, 0.35])
+    cur = [(synth._raycast_boxes(true_cur[0], true_cur[1], true_cur[2] + ang, boxes, 30.0).astype(np.float32),
+            true_cur + [0.2, -0.3, 0.1])]                               # odometry estimate of the current vertex
+    sp = dict(n_beams=1081, angle_min=synth.LASER_ANGLE_MIN, angle_inc=synth.LASER_ANGLE_INC, max_range=30.0)
+    m = _lc(ctx, sp)
+    res = m.scanMatchingLC(scans, 0, cur, 0, 0.15)
+    assert 1 <= len(res) <= 2
+    rel_true = synth.se2_compose(synth.se2_inverse(poses[0]), true_cur)
+    best = min(res, key=lambda r: np.abs(r[:2] - rel_true[:2]).sum())
+    assert np.abs(best[:2] - rel_true[:2]).max() < 0.15 and abs(synth.normalize_theta(best[2] - rel_true[2])) < 0.06
+    # same flow with the oracle's search in place of the GPU's
+    ref_pts = m.transformPointsFromVSet(scans, 0)
+    qry = m.subsample(m.transformPointsFromVSet(cur, 0), 0.1)
+    from cg_mrslam_amd.matcher import _se2_inv, _se2_mul, normalize_theta
+    merged = {}
+    for shift in (0.0, 1.0):
+        regs = []
+        for k, (_, pose) in enumerate(scans):
+            rel = np.zeros(3) if k == 0 else _se2_mul(_se2_inv(poses[0]), pose)
+            lo = np.array([-.5 + rel[0], -1.5 + rel[1], -0.8 + rel[2]], dtype=np.float32)
+            up = np.array([.5 + rel[0], 1.5 + rel[1], 0.8 + rel[2]], dtype=np.float32)
+            if shift:
+                lo[2] += np.float32(np.pi); up[2] += np.float32(np.pi)
+            regs.append(np.concatenate([lo, up]))
+        n, r = oracle.greedy_search((-35, -35), (35, 35), 0.1, 0.1, 0.5, ref_pts, qry, np.array(regs), 0.1, 0.025, 0.15, 0.5, 0.5, 0.2)
+        if n:
+            b = r[0].copy(); b[2] = normalize_theta(b[2])
+            key = (int(b[0] / 0.5), int(b[1] / 0.5), int(b[2] / 0.2))
+            if key not in merged or merged[key][3] > b[3]:
+                merged[key] = b
+    want = [merged[k][:3] for k in sorted(merged)]
+    assert len(want) == len(res) and all(np.array_equal(a, b) for a, b in zip(res, want))
