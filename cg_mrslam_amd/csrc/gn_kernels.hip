@@ -27,7 +27,7 @@ namespace {
 
 constexpr int W = 3 * kPanelW;       // 48 scalar columns per front (zero / identity padded)
 constexpr int LDW = W + 1;           // LDS row stride (doubles), odd => conflict-free b64 column access
-constexpr int CH = 128;              // border rows staged per chunk in k_front_factor
+constexpr int CH = kChunkRows;       // border rows per k_front_factor workgroup (waves 1-3, one row per lane)
 constexpr int TS = 32;               // tile edge of k_front_update
 
 __device__ __forceinline__ double d_normalize_theta(double t) {
@@ -169,7 +169,7 @@ constexpr int kL21 = 2 * W * W + W;
 constexpr int FUSE_R = 96;
 #ifdef CGMR_PHASE_TIMING
 __device__ unsigned long long g_phase[64 * 8];
-#define PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); } while (0)
+#define PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
 #else
 #define PHASE(i)
 #endif           // fronts with r <= FUSE_R compute their update matrix in the factor kernel
@@ -191,20 +191,20 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 
 constexpr int MAXC = 8;              // children whose maps are staged together
 // LDS plan of k_front_factor (bytes), one workgroup per CU:
-//   R    [CH][LDW] doubles   chunk of F21 / L21 rows
-//   Ls   [W][LDW]  doubles   F11, then L11 row-major          \
-//   LsT  [W][W]    doubles   L11 column-major (16-B aligned)   > reused as Uacc[FUSE_R][FUSE_R+1]
-//   pad                                                        /   by the fused update (phase D)
+//   R    [CH][LDW] doubles   chunk of F21 (assembly), later L21 rows for the fused update
+//   Ls   [W][LDW]  doubles   F11 (assembly)                      \  reused as Uacc[FUSE_R][FUSE_R+1]
+//   pad                                                          /  by the fused update (phase D)
 //   lists: s_pos[FUSE_R+W] shorts (phase D), s_colinv[MAXC][W], s_src[MAXC][CH] shorts (phase A)
+//   Dinv [W], Pan[2][W][8] doubles: the published 8-column panel of L11 (double buffered)
 constexpr int kOffR = 0;
 constexpr int kOffLs = kOffR + CH * LDW * 8;
-constexpr int kOffLsT = ((kOffLs + W * LDW * 8 + 15) / 16) * 16;
 constexpr int kUaccBytes = FUSE_R * (FUSE_R + 1) * 8;
-constexpr int kOffLists = kOffLs + (kUaccBytes > (kOffLsT - kOffLs) + W * W * 8 ? kUaccBytes : (kOffLsT - kOffLs) + W * W * 8);
+constexpr int kOffLists = kOffLs + (kUaccBytes > W * LDW * 8 ? kUaccBytes : W * LDW * 8);
 constexpr int kOffColinv = kOffLists + 2 * (W + FUSE_R);
 constexpr int kOffSrc = kOffColinv + 2 * MAXC * W;
 constexpr int kOffDinv = ((kOffSrc + 2 * MAXC * CH + 15) / 16) * 16;
-constexpr int kSmemBytes = kOffDinv + W * 8;
+constexpr int kOffPan = kOffDinv + W * 8;
+constexpr int kSmemBytes = kOffPan + 2 * W * 8 * 8;
 static_assert(kSmemBytes <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
 
 // One workgroup per (front, chunk of CH border rows) of the current level:
@@ -233,12 +233,12 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* R = reinterpret_cast<double*>(smem + kOffR);
   double* Ls = reinterpret_cast<double*>(smem + kOffLs);
-  double* LsT = reinterpret_cast<double*>(smem + kOffLsT);
   double* Uacc = reinterpret_cast<double*>(smem + kOffLs);
   short* s_pos = reinterpret_cast<short*>(smem + kOffLists);
   short* s_colinv = reinterpret_cast<short*>(smem + kOffColinv);
   short* s_src = reinterpret_cast<short*>(smem + kOffSrc);
   double* Dinv = reinterpret_cast<double*>(smem + kOffDinv);
+  double* Pan = reinterpret_cast<double*>(smem + kOffPan);
   const int tid = threadIdx.x;
   const int32_t* wk = work + 2 * (size_t)(work_begin + blockIdx.x);
   const FrontDesc F = fronts[wk[0]];
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
   // owned by one thread which sums the children in a fixed order: no barriers between children,
   // no read-modify-write races, bit-reproducible.  In the last batch wavefront 0 goes on to the
   // Cholesky as soon as F11 is complete while wavefronts 1-3 finish this chunk's F21 rows.
-  const int nbatch = max(1, (F.nchild + MAXC - 1) / MAXC);
+  const int nbatch = (F.nchild + MAXC - 1) / MAXC;
   for (int bt = 0; bt < nbatch; bt++) {
     const int c0 = bt * MAXC;
     const int ncb = max(0, min(MAXC, F.nchild - c0));
@@ -288,145 +288,153 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
       }
     }
     __syncthreads();
-    // F11 cells (lower triangle), all threads
-    for (int q = tid; q < W * W; q += 256) {
-      int pi = q / W, pj = q - pi * W;
-      if (pj > pi) continue;
-      double acc = 0.0;
-      bool any = false;
-      for (int c = 0; c < ncb; c++) {
-        int i = s_colinv[c * W + pi], j = s_colinv[c * W + pj];
-        if (i >= 0 && j >= 0) {
-          const FrontDesc G = fronts[children[F.child_off + c0 + c]];
-          acc += Ubuf[G.U_off + (size_t)i * (3 * G.ns) + j];
-          any = true;
-        }
-      }
-      if (any) Ls[pi * LDW + pj] += acc;
-    }
-    __syncthreads();
-    const bool last = (bt == nbatch - 1);
-    if (tid >= 64) {
-      // F21 rows of this chunk: thread owns parent column pc and rows n = rgp, rgp+4, ...
-      const int t2 = tid - 64;
-      const int pc = t2 % W, rgp = t2 / W;
-      for (int c = 0; c < ncb; c++) {
-        const int j = s_colinv[c * W + pc];
-        if (j < 0) continue;
-        const FrontDesc G = fronts[children[F.child_off + c0 + c]];
-        const double* U = Ubuf + G.U_off;
-        const int rg = 3 * G.ns;
-        const short* src = s_src + c * CH;
-        for (int base = rgp; base < nr; base += 32) {
-          double v[8];
-          int dst[8];
+    // Child-outer loops: within one child every thread issues all of its loads before using any of them
+    // (one memory round trip per child); a cell is always owned by the same thread, so children are summed
+    // in a fixed order without barriers in between.
+    for (int c = 0; c < ncb; c++) {
+      const FrontDesc G = fronts[children[F.child_off + c0 + c]];
+      const double* U = Ubuf + G.U_off;
+      const int rg = 3 * G.ns;
+      const short* cinv = s_colinv + c * W;
+      // F11 cells (lower triangle): cells q = tid + 256 u, u < 9
+      {
+        double v[9];
+        int at[9];
 #pragma unroll
-          for (int u = 0; u < 8; u++) {
-            int n = base + 4 * u;
-            int sr = (n < nr) ? src[n] : -1;
-            v[u] = (sr >= 0) ? U[(size_t)sr * rg + j] : 0.0;
-            dst[u] = (sr >= 0) ? n : -1;
+        for (int u = 0; u < 9; u++) {
+          const int q = tid + 256 * u;
+          const int pi = q / W, pj = q - pi * W;
+          int i = cinv[pi], j = cinv[pj];
+          const bool ok = (pj <= pi) && i >= 0 && j >= 0;
+          v[u] = ok ? U[(size_t)i * rg + j] : 0.0;
+          at[u] = ok ? pi * LDW + pj : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 9; u++)
+          if (at[u] >= 0) Ls[at[u]] += v[u];
+      }
+      // F21 rows of this chunk: thread owns parent column pc and rows n = rgp, rgp + 5, ...
+      if (tid < 5 * W && nr > 0) {
+        const int pc = tid % W, rgp = tid / W;
+        const int j = cinv[pc];
+        if (j >= 0) {
+          const short* src = s_src + c * CH;
+          for (int base = rgp; base < nr; base += 100) {
+            double v[20];
+            int dst[20];
+#pragma unroll
+            for (int u = 0; u < 20; u++) {
+              int n = base + 5 * u;
+              int sr = (n < nr) ? src[n] : -1;
+              v[u] = (sr >= 0) ? U[(size_t)sr * rg + j] : 0.0;
+              dst[u] = (sr >= 0) ? n : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 20; u++)
+              if (dst[u] >= 0) R[dst[u] * LDW + pc] += v[u];
           }
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-            if (dst[u] >= 0) R[dst[u] * LDW + pc] += v[u];
         }
       }
-    } else if (last) {
-      PHASE(1);
-      // ---- B. blocked left-looking Cholesky on wavefront 0: lane i owns row i of F11 (in LDS);
-      // an 8-column panel lives in registers, earlier columns are applied with readlane broadcasts.
-      const int lane = tid;
-      const int lrow = min(lane, W - 1);
-      double* myrow = Ls + lrow * LDW;
-      double mydinv = 1.0;
-      int fail = 0;
-      for (int c = 0; c < W; c += 8) {
-        if (c >= w) break;
-        double pq[8];
+    }
+  }
+  __syncthreads();
+  PHASE(1);
+  // ---- B+C. right-looking tall-panel factorisation: every row of [F11; F21 chunk] lives in the registers of
+  // one lane (wave 0: the 48 rows of F11, waves 1-3: one border row per lane).  Per 8-column panel: wave 0
+  // factors the panel for the F11 rows (pivot broadcast with v_readlane, 1/sqrt by rsqrt + 2 Newton steps),
+  // publishes the panel columns L[k][c..c+7] and the reciprocals through LDS (double buffered: one barrier per
+  // panel); the border rows solve against the 8x8 diagonal block; then all rows apply the rank-8 update to
+  // their trailing columns with LDS broadcast reads.  A non-positive pivot records the GN iteration in *status
+  // (first failure wins); the pose update kernel then leaves the poses alone -- g2o's early return.
+  double x[W];
+  const bool isF11 = tid < 64;
+  {
+    const double* src = isF11 ? (Ls + min(tid, W - 1) * LDW) : ((nr > 0) ? (R + min(tid - 64, nr - 1) * LDW) : Ls);
 #pragma unroll
-        for (int q = 0; q < 8; q++) pq[q] = myrow[c + q];
-        double lit_next = myrow[0];
-        for (int t = 0; t < c; t++) {
-          double lit = lit_next;
-          lit_next = myrow[t + 1];
+    for (int k = 0; k < W; k++) x[k] = src[k];
+  }
+  double mydinv = 1.0;
+  int fail = 0;
 #pragma unroll
-          for (int q = 0; q < 8; q++) pq[q] = fma(-lit, readlane_f64(lit, c + q), pq[q]);
-        }
+  for (int c = 0; c < W; c += 8) {
+    if (c < w) {
+      double* pan = Pan + ((c >> 3) & 1) * (W * 8);
+      if (isF11) {
+        const int lane = tid;
 #pragma unroll
         for (int jj = 0; jj < 8; jj++) {
           const int j = c + jj;
-          double d = readlane_f64(pq[jj], j);
+          double d = readlane_f64(x[j], j);
           if (!(d > 0.0)) { fail = 1; d = 1.0; }
           double y = rsqrt_nr(d);
-          double lij = (lane == j) ? d * y : pq[jj] * y;
-          pq[jj] = lij;
+          double lij = (lane == j) ? d * y : x[j] * y;
+          x[j] = lij;
           if (lane == j) mydinv = y;
 #pragma unroll
-          for (int q = jj + 1; q < 8; q++) pq[q] = fma(-lij, readlane_f64(lij, c + q), pq[q]);
+          for (int q = jj + 1; q < 8; q++) x[c + q] = fma(-lij, readlane_f64(lij, c + q), x[c + q]);
         }
         if (lane < W) {
 #pragma unroll
-          for (int q = 0; q < 8; q++) myrow[c + q] = (c + q <= lane) ? pq[q] : 0.0;
+          for (int q = 0; q < 8; q++) pan[lane * 8 + q] = x[c + q];
+          if (lane >= c && lane < c + 8) Dinv[lane] = mydinv;
         }
       }
-      if (fail && lane == 0) atomicCAS(status, 0, iter_tag);
-      if (lane < W) {
-        for (int k = 0; k < W; k++) LsT[k * W + lane] = (k <= lane) ? myrow[k] : 0.0;
-        Dinv[lane] = mydinv;
+      __syncthreads();
+      if (!isF11) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+          double xj = x[c + jj];
+#pragma unroll
+          for (int q = 0; q < jj; q++) xj = fma(-x[c + q], pan[(c + jj) * 8 + q], xj);
+          x[c + jj] = xj * Dinv[c + jj];
+        }
+      }
+#pragma unroll
+      for (int k = c + 8; k < W; k++) {
+        if (k < w) {
+          const double2* lk = reinterpret_cast<const double2*>(pan + k * 8);
+          double acc = x[k];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            double2 l2 = lk[q];
+            acc = fma(-x[c + 2 * q], l2.x, acc);
+            acc = fma(-x[c + 2 * q + 1], l2.y, acc);
+          }
+          x[k] = acc;
+        }
       }
     }
   }
-  __syncthreads();
+  if (isF11 && fail && tid == 0) atomicCAS(status, 0, iter_tag);
   PHASE(2);
   double* P = Lbuf + F.L_off;
+  if (isF11) {
+    if (chunk == 0 && tid < W) {               // stage L11 in LDS (the F11 buffer is dead) for coalesced copies
+#pragma unroll
+      for (int k = 0; k < W; k++) Ls[tid * LDW + k] = (k <= tid) ? x[k] : 0.0;
+      P[kDinv + tid] = mydinv;
+    }
+  } else if (tid - 64 < nr) {
+    double* dst = P + kL21 + (size_t)(r0 + tid - 64) * W;
+#pragma unroll
+    for (int k = 0; k < W; k += 2) *reinterpret_cast<double2*>(dst + k) = make_double2(x[k], x[k + 1]);
+    if (r <= FUSE_R) {
+      double* rr = R + (tid - 64) * LDW;
+#pragma unroll
+      for (int k = 0; k < W; k++) rr[k] = x[k];
+    }
+  }
+  __syncthreads();
   if (chunk == 0) {
     for (int q = tid; q < W * W; q += 256) {
       int i = q / W, k = q - i * W;
-      P[q] = Ls[i * LDW + k];
-      P[kL11c + q] = LsT[q];
-    }
-    if (tid < W) P[kDinv + tid] = Dinv[tid];
-  }
-  PHASE(3);
-  // ---- C. L21 rows: x = f * L11^-T, one thread per row, blocked left-looking (8-column panels in
-  // registers; earlier columns of the row come back from LDS, L11 columns are LDS broadcasts)
-  if (tid < nr) {
-    double* xr = R + tid * LDW;
-    for (int c = 0; c < W; c += 8) {
-      if (c >= w) break;
-      double xp[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) xp[q] = xr[c + q];
-      for (int t = 0; t < c; t++) {
-        double xt = xr[t];
-        const double2* Lc = reinterpret_cast<const double2*>(LsT + t * W + c);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          double2 l2 = Lc[q];
-          xp[2 * q] = fma(-xt, l2.x, xp[2 * q]);
-          xp[2 * q + 1] = fma(-xt, l2.y, xp[2 * q + 1]);
-        }
-      }
-      const double* Lp = LsT + c * W + c;
-#pragma unroll
-      for (int jj = 0; jj < 8; jj++) {
-        double xj = xp[jj] * Dinv[c + jj];
-        xp[jj] = xj;
-#pragma unroll
-        for (int q = jj + 1; q < 8; q++) xp[q] = fma(-xj, Lp[jj * W + q], xp[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; q++) xr[c + q] = xp[q];
+      P[q] = Ls[i * LDW + k];                   // row-major copy (backward solve)
+      P[kL11c + q] = Ls[k * LDW + i];           // column-major copy (forward solve): element (row k, col i)
     }
   }
   __syncthreads();
+  PHASE(3);
   PHASE(4);
-  double* L21 = P + kL21;
-  for (int q = tid; q < nr * W; q += 256) {
-    int row = q / W, k = q - row * W;
-    L21[(size_t)(r0 + row) * W + k] = R[row * LDW + k];
-  }
   PHASE(5);
   // ---- D. fused update matrix for small fronts (single chunk: R holds all of L21)
   if (r > 0 && r <= FUSE_R) {

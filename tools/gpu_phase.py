@@ -9,6 +9,9 @@ for r in range(2):
 out = np.zeros(64*8, dtype=np.uint64)
 print(load_library().cgmr_debug_phase(C.c_void_p(out.ctypes.data)))
 out = out.reshape(64, 8).astype(np.int64)
+print("level: [assemble, chol(+F21 wait), L11 copy, TRSM, L21 store, fused U] total | realtime ticks (100 MHz) -> shader GHz")
 for l in range(22):
     d = np.diff(out[l,:7])
-    print(l, d.tolist(), 'total', out[l,6]-out[l,0])
+    tot = out[l,6]-out[l,0]
+    rt = out[l,7]
+    print(l, d.tolist(), 'total', tot, '| rt', rt, 'GHz %.2f' % (tot / max(rt,1) / 10.0))
