@@ -202,7 +202,7 @@ void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double*
     if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
   }
   if (!solve_and_update) return;
-  for (int l = 0; l < D.nlevels; l++) T.run(5, 1, [&] { launch_fwd_level(st, D, l); });
+  // (the forward solve L y = b rides through k_front_factor as an extra row of every front)
   for (int l = D.nlevels - 1; l >= 0; l--) T.run(6, 1, [&] { launch_bwd_level(st, D, l); });
   T.run(7, 1, [&] { launch_update(st, D, d_poses); });
 }

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int W = 3 * kPanelW;       // 48 scalar columns per front (zero / identity padded)
 constexpr int LDW = W + 1;           // LDS row stride (doubles), odd => conflict-free b64 column access
-constexpr int CH = kChunkRows;       // border rows per k_front_factor workgroup (waves 1-3, one row per lane)
+constexpr int CH = kChunkRows + 1;   // rows of the LDS staging area: border rows of the chunk + the rhs row
 constexpr int TS = 32;               // tile edge of k_front_update
 
 __device__ __forceinline__ double d_normalize_theta(double t) {
@@ -204,7 +204,8 @@ constexpr int kOffColinv = kOffLists + 2 * (W + FUSE_R);
 constexpr int kOffSrc = kOffColinv + 2 * MAXC * W;
 constexpr int kOffDinv = ((kOffSrc + 2 * MAXC * CH + 15) / 16) * 16;
 constexpr int kOffPan = kOffDinv + W * 8;
-constexpr int kSmemBytes = kOffPan + 2 * W * 8 * 8;
+constexpr int kOffYs = kOffPan + 2 * W * 8 * 8;
+constexpr int kSmemBytes = kOffYs + W * 8;
 static_assert(kSmemBytes <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
 
 // One workgroup per (front, chunk of CH border rows) of the current level:
@@ -228,8 +229,9 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
                                                          const int32_t* __restrict__ inv,
                                                          const int32_t* __restrict__ alist,
                                                          const double* __restrict__ Ablk, double* __restrict__ Lbuf,
-                                                         double* __restrict__ Ubuf, int* __restrict__ status,
-                                                         int iter_tag, int level_id) {
+                                                         double* __restrict__ Ubuf, const double* __restrict__ bvec,
+                                                         double* __restrict__ yvec, double* __restrict__ uvec,
+                                                         int* __restrict__ status, int iter_tag, int level_id) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* R = reinterpret_cast<double*>(smem + kOffR);
   double* Ls = reinterpret_cast<double*>(smem + kOffLs);
@@ -239,21 +241,23 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
   short* s_src = reinterpret_cast<short*>(smem + kOffSrc);
   double* Dinv = reinterpret_cast<double*>(smem + kOffDinv);
   double* Pan = reinterpret_cast<double*>(smem + kOffPan);
+  double* Ys = reinterpret_cast<double*>(smem + kOffYs);
   const int tid = threadIdx.x;
   const int32_t* wk = work + 2 * (size_t)(work_begin + blockIdx.x);
   const FrontDesc F = fronts[wk[0]];
   const int chunk = wk[1];
   const int w = 3 * F.nc, r = 3 * F.ns;
-  const int r0 = chunk * CH;
-  const int nr = max(0, min(CH, r - r0));
+  const int r0 = chunk * kChunkRows;
+  const int nr = max(0, min(kChunkRows, r - r0));   // border rows of this chunk; staging row nr carries the rhs
   PHASE(0);
   // ---- A1. F11 (all threads): H blocks + leading blocks of the children's update matrices
   for (int q = tid; q < W * LDW; q += 256) {
     int i = q / LDW, j = q - i * LDW;
     Ls[q] = (i == j && i >= w) ? 1.0 : 0.0;
   }
-  for (int q = tid; q < nr * LDW; q += 256) R[q] = 0.0;
+  for (int q = tid; q < (nr + 1) * LDW; q += 256) R[q] = 0.0;
   __syncthreads();
+  if (tid < w) R[nr * LDW + tid] = bvec[3 * F.c0 + tid];      // rhs row: b of my columns (+ children below)
   for (int q = tid; q < F.a_cnt * 9; q += 256) {
     int a = q / 9, el = q - 9 * a;
     const int32_t* tr = alist + 3 * (size_t)(F.a_off + a);
@@ -313,6 +317,14 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
         for (int u = 0; u < 9; u++)
           if (at[u] >= 0) Ls[at[u]] += v[u];
       }
+      // forward-solve inputs: the rhs row gathers the child's border vector entries that land in my columns,
+      // staging column W gathers those that land in this chunk's border rows
+      const double* uc = uvec + (size_t)3 * G.rows_off;
+      if (tid < W && cinv[tid] >= 0) R[nr * LDW + tid] += uc[cinv[tid]];
+      if (tid < nr) {                                   // thread n owns staging cell (n, W)
+        int sr = s_src[c * CH + tid];
+        if (sr >= 0) R[tid * LDW + W] += uc[sr];
+      }
       // F21 rows of this chunk: thread owns parent column pc and rows n = rgp, rgp + 5, ...
       if (tid < 5 * W && nr > 0) {
         const int pc = tid % W, rgp = tid / W;
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
   double x[W];
   const bool isF11 = tid < 64;
   {
-    const double* src = isF11 ? (Ls + min(tid, W - 1) * LDW) : ((nr > 0) ? (R + min(tid - 64, nr - 1) * LDW) : Ls);
+    const double* src = isF11 ? (Ls + min(tid, W - 1) * LDW) : (R + min(tid - 64, nr) * LDW);
 #pragma unroll
     for (int k = 0; k < W; k++) x[k] = src[k];
   }
@@ -423,6 +435,15 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
 #pragma unroll
       for (int k = 0; k < W; k++) rr[k] = x[k];
     }
+  } else if (tid - 64 == nr) {
+    // the rhs row went through the same solve / trailing updates as a border row: it now holds y = L11^-1 t
+#pragma unroll
+    for (int k = 0; k < W; k++) Ys[k] = x[k];
+    if (chunk == 0) {
+#pragma unroll
+      for (int k = 0; k < W; k++)
+        if (k < w) yvec[3 * F.c0 + k] = x[k];
+    }
   }
   __syncthreads();
   if (chunk == 0) {
@@ -431,6 +452,12 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
       P[q] = Ls[i * LDW + k];                   // row-major copy (backward solve)
       P[kL11c + q] = Ls[k * LDW + i];           // column-major copy (forward solve): element (row k, col i)
     }
+  }
+  if (!isF11 && tid - 64 < nr) {                // border vector handed to the parent: u = ext_add(children) - L21 y
+    double dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; k++) dot = fma(x[k], Ys[k], dot);
+    uvec[(size_t)3 * F.rows_off + r0 + tid - 64] = R[(tid - 64) * LDW + W] - dot;
   }
   __syncthreads();
   PHASE(3);
@@ -729,7 +756,7 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag)
   }
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
   hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), kSmemBytes, st, D.fronts, D.work, D.h_work_ptr[l], D.children,
-                     D.rel, D.inv, D.alist, D.Ablk, D.Lbuf, D.Ubuf, D.status, iter_tag, l);
+                     D.rel, D.inv, D.alist, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, iter_tag, l);
 }
 
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {

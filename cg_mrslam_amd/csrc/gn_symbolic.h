@@ -18,7 +18,8 @@ namespace cgmr {
 constexpr int kPanelW = 16;          // max poses (block columns) per front -> 48 scalar columns
 constexpr int kFrontW = 3 * kPanelW; // scalar columns per front (all panel strides are padded to this)
 constexpr int kFactorHeader = 2 * kFrontW * kFrontW + kFrontW;  // L11 row-major, L11 column-major, 1/diag
-constexpr int kChunkRows = 192;      // border rows handled by one k_front_factor workgroup (3 wavefronts)
+constexpr int kChunkRows = 191;      // border rows per k_front_factor workgroup: 3 wavefronts minus the lane that
+                                     // carries the right-hand side through the factorisation
 constexpr int kFuseRows = 96;        // fronts with <= this many border rows form U inside k_front_factor
 
 struct FrontDesc {                   // one per front, uploaded verbatim (all int32 / int64)
