@@ -300,51 +300,57 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
       const double* U = Ubuf + G.U_off;
       const int rg = 3 * G.ns;
       const short* cinv = s_colinv + c * W;
-      // F11 cells (lower triangle): cells q = tid + 256 u, u < 9
-      {
-        double v[9];
-        int at[9];
+      // ---- issue every load of this child first (F11 cells, rhs entry, border-vector entry, F21 rows) ...
+      double vF[9];
+      int atF[9];
 #pragma unroll
-        for (int u = 0; u < 9; u++) {
-          const int q = tid + 256 * u;
-          const int pi = q / W, pj = q - pi * W;
-          int i = cinv[pi], j = cinv[pj];
-          const bool ok = (pj <= pi) && i >= 0 && j >= 0;
-          v[u] = ok ? U[(size_t)i * rg + j] : 0.0;
-          at[u] = ok ? pi * LDW + pj : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < 9; u++)
-          if (at[u] >= 0) Ls[at[u]] += v[u];
+      for (int u = 0; u < 9; u++) {
+        const int q = tid + 256 * u;
+        const int pi = q / W, pj = q - pi * W;
+        int i = cinv[pi], j = cinv[pj];
+        const bool ok = (pj <= pi) && i >= 0 && j >= 0;
+        vF[u] = ok ? U[(size_t)i * rg + j] : 0.0;
+        atF[u] = ok ? pi * LDW + pj : -1;
       }
-      // forward-solve inputs: the rhs row gathers the child's border vector entries that land in my columns,
-      // staging column W gathers those that land in this chunk's border rows
       const double* uc = uvec + (size_t)3 * G.rows_off;
-      if (tid < W && cinv[tid] >= 0) R[nr * LDW + tid] += uc[cinv[tid]];
-      if (tid < nr) {                                   // thread n owns staging cell (n, W)
-        int sr = s_src[c * CH + tid];
-        if (sr >= 0) R[tid * LDW + W] += uc[sr];
+      const bool has_rhs = tid < W && cinv[tid] >= 0;
+      const double vRhs = has_rhs ? uc[cinv[tid]] : 0.0;
+      const int srU = (tid < nr) ? s_src[c * CH + tid] : -1;
+      const double vCol = (srU >= 0) ? uc[srU] : 0.0;
+      // F21 rows of this chunk: thread owns parent column pc and rows n = rgp, rgp + 5, ... (<= 39 of them)
+      const int pc = tid % W, rgp = tid / W;
+      const int jF = (tid < 5 * W) ? cinv[pc] : -1;
+      double v21[20];
+      int dst21[20];
+      const short* src21 = s_src + c * CH;
+#pragma unroll
+      for (int u = 0; u < 20; u++) {
+        int n = rgp + 5 * u;
+        int sr = (jF >= 0 && n < nr) ? src21[n] : -1;
+        v21[u] = (sr >= 0) ? U[(size_t)sr * rg + jF] : 0.0;
+        dst21[u] = (sr >= 0) ? n : -1;
       }
-      // F21 rows of this chunk: thread owns parent column pc and rows n = rgp, rgp + 5, ...
-      if (tid < 5 * W && nr > 0) {
-        const int pc = tid % W, rgp = tid / W;
-        const int j = cinv[pc];
-        if (j >= 0) {
-          const short* src = s_src + c * CH;
-          for (int base = rgp; base < nr; base += 100) {
-            double v[20];
-            int dst[20];
+      // ---- ... then consume them (every cell is owned by one thread: plain read-modify-write in LDS)
 #pragma unroll
-            for (int u = 0; u < 20; u++) {
-              int n = base + 5 * u;
-              int sr = (n < nr) ? src[n] : -1;
-              v[u] = (sr >= 0) ? U[(size_t)sr * rg + j] : 0.0;
-              dst[u] = (sr >= 0) ? n : -1;
-            }
+      for (int u = 0; u < 9; u++)
+        if (atF[u] >= 0) Ls[atF[u]] += vF[u];
+      if (has_rhs) R[nr * LDW + tid] += vRhs;
+      if (srU >= 0) R[tid * LDW + W] += vCol;
 #pragma unroll
-            for (int u = 0; u < 20; u++)
-              if (dst[u] >= 0) R[dst[u] * LDW + pc] += v[u];
+      for (int u = 0; u < 20; u++)
+        if (dst21[u] >= 0) R[dst21[u] * LDW + pc] += v21[u];
+      if (jF >= 0 && nr > 100) {                         // rows 100.. of the chunk (second batch)
+        for (int base = rgp + 100; base < nr; base += 100) {
+#pragma unroll
+          for (int u = 0; u < 20; u++) {
+            int n = base + 5 * u;
+            int sr = (n < nr) ? src21[n] : -1;
+            v21[u] = (sr >= 0) ? U[(size_t)sr * rg + jF] : 0.0;
+            dst21[u] = (sr >= 0) ? n : -1;
           }
+#pragma unroll
+          for (int u = 0; u < 20; u++)
+            if (dst21[u] >= 0) R[dst21[u] * LDW + pc] += v21[u];
         }
       }
     }
@@ -568,24 +574,35 @@ __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restric
   }
   double acc[4] = {-c00, -c01, -c10, -c11};
   int gi[2] = {i0 + ty, i0 + ty + 16}, gj[2] = {j0 + tx, j0 + tx + 16};
+  // child rows feeding this tile: staged once per child (scalar row index or -1), then 4 independent loads
+  __shared__ short s_ki[TS], s_kj[TS];
   for (int ci = 0; ci < F.nchild; ci++) {
     const FrontDesc G = fronts[children[F.child_off + ci]];
     const int32_t* ginv = inv + G.inv_off;
     const double* U = Ubuf + G.U_off;
     const int rg = 3 * G.ns;
+    __syncthreads();
+    if (tid < TS) {
+      int p = i0 + tid;
+      int kb = (p < r) ? ginv[p / 3] : -1;
+      s_ki[tid] = (short)(kb < 0 ? -1 : 3 * kb + p % 3);
+    } else if (tid < 2 * TS) {
+      int p = j0 + tid - TS;
+      int kb = (p < r) ? ginv[p / 3] : -1;
+      s_kj[tid - TS] = (short)(kb < 0 ? -1 : 3 * kb + p % 3);
+    }
+    __syncthreads();
+    const int ki[2] = {s_ki[ty], s_ki[ty + 16]}, kj[2] = {s_kj[tx], s_kj[tx + 16]};
+    double v[4];
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      if (gi[a] >= r) continue;
-      int ki = ginv[gi[a] / 3];
-      if (ki < 0) continue;
+    for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int b = 0; b < 2; b++) {
-        if (gj[b] >= r || gj[b] > gi[a]) continue;
-        int kj = ginv[gj[b] / 3];
-        if (kj < 0) continue;
-        acc[2 * a + b] += U[(size_t)(3 * ki + gi[a] % 3) * rg + 3 * kj + gj[b] % 3];
+        bool ok = ki[a] >= 0 && kj[b] >= 0 && gj[b] <= gi[a];
+        v[2 * a + b] = ok ? U[(size_t)ki[a] * rg + kj[b]] : 0.0;
       }
-    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] += v[q];
   }
   double* Uo = Ubuf + F.U_off;
 #pragma unroll
@@ -666,13 +683,16 @@ __global__ __launch_bounds__(256) void k_solve_fwd(const FrontDesc* __restrict__
   }
 }
 
-// Backward (L^T x = y), one workgroup per front, top-down by level.
+// Backward (L^T x = y), one workgroup per front, top-down by level.  The border part of x is staged in LDS
+// first (its gather chains two dependent global loads per row, which must not sit inside the reduction loop).
+constexpr int XB_CAP = 1536;         // border rows staged per pass
 __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__ fronts,
                                                    const int32_t* __restrict__ level_fronts, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
                                                    const double* __restrict__ yvec, double* __restrict__ xvec) {
   constexpr int G5 = 5;
   __shared__ double part[G5 * W];
+  __shared__ double xb[XB_CAP];
   const int tid = threadIdx.x;
   const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
   const int w = 3 * F.nc, r = 3 * F.ns;
@@ -686,19 +706,37 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__
     for (int k = 0; k < W; k++) Lcol[k] = P[k * W + lane];     // element (row k, col lane)
     dv = P[kDinv + lane];
   }
-  if (tid < G5 * W) {
-    int j = tid % W, g = tid / W;
-    double acc = 0;
-    for (int p = g; p < r; p += G5) acc += L21[(size_t)p * W + j] * xvec[3 * rows[F.rows_off + p / 3] + p % 3];
-    part[g * W + j] = acc;
+  const int j = tid % W, g = tid / W;
+  double acc = 0;
+  for (int p0 = 0; p0 < r; p0 += XB_CAP) {
+    const int np = min(XB_CAP, r - p0);
+    __syncthreads();
+    for (int p = tid; p < np; p += 256) xb[p] = xvec[3 * rows[F.rows_off + (p0 + p) / 3] + (p0 + p) % 3];
+    __syncthreads();
+    if (tid < G5 * W) {
+      for (int base = g; base < np; base += G5 * 8) {
+        double l[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          int p = base + G5 * u;
+          l[u] = (p < np) ? L21[(size_t)(p0 + p) * W + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          int p = base + G5 * u;
+          if (p < np) acc = fma(l[u], xb[p], acc);
+        }
+      }
+    }
   }
+  if (tid < G5 * W) part[g * W + j] = acc;
   __syncthreads();
   if (tid < 64) {
     const int lane = tid;
     const int lj = min(lane, W - 1);
     double v = (lane < w) ? yvec[3 * F.c0 + lane] : 0.0;
 #pragma unroll
-    for (int g = 0; g < G5; g++) v -= part[g * W + lj];
+    for (int gg = 0; gg < G5; gg++) v -= part[gg * W + lj];
     double xv = 0.0;
 #pragma unroll
     for (int i = W - 1; i >= 0; i--) {
