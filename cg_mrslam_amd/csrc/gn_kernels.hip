@@ -373,32 +373,55 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
   }
   double mydinv = 1.0;
   int fail = 0;
+  // wave 0: factor the 8-column panel starting at column c for the F11 rows and publish it
+#define FACTOR_PANEL(c)                                                                                      \
+  do {                                                                                                       \
+    double* pan_ = Pan + (((c) >> 3) & 1) * (W * 8);                                                         \
+    _Pragma("unroll") for (int jj = 0; jj < 8; jj++) {                                                       \
+      const int j = (c) + jj;                                                                                \
+      double d = readlane_f64(x[j], j);                                                                      \
+      if (!(d > 0.0)) { fail = 1; d = 1.0; }                                                                 \
+      double y = rsqrt_nr(d);                                                                                \
+      double lij = (tid == j) ? d * y : x[j] * y;                                                            \
+      x[j] = lij;                                                                                            \
+      if (tid == j) mydinv = y;                                                                              \
+      _Pragma("unroll") for (int q = jj + 1; q < 8; q++) x[(c) + q] = fma(-lij, readlane_f64(lij, (c) + q), x[(c) + q]); \
+    }                                                                                                        \
+    if (tid < W) {                                                                                           \
+      _Pragma("unroll") for (int q = 0; q < 8; q++) pan_[tid * 8 + q] = x[(c) + q];                          \
+      if (tid >= (c) && tid < (c) + 8) Dinv[tid] = mydinv;                                                   \
+    }                                                                                                        \
+  } while (0)
+  // rank-8 update of column k of my row with panel c
+#define TRAIL_COL(c, k)                                                                                      \
+  do {                                                                                                       \
+    const double2* lk_ = reinterpret_cast<const double2*>(Pan + (((c) >> 3) & 1) * (W * 8) + (k) * 8);       \
+    double acc_ = x[k];                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                          \
+      double2 l2_ = lk_[q];                                                                                  \
+      acc_ = fma(-x[(c) + 2 * q], l2_.x, acc_);                                                              \
+      acc_ = fma(-x[(c) + 2 * q + 1], l2_.y, acc_);                                                          \
+    }                                                                                                        \
+    x[k] = acc_;                                                                                             \
+  } while (0)
+  if (isF11) FACTOR_PANEL(0);
 #pragma unroll
   for (int c = 0; c < W; c += 8) {
     if (c < w) {
-      double* pan = Pan + ((c >> 3) & 1) * (W * 8);
+      const double* pan = Pan + ((c >> 3) & 1) * (W * 8);
+      __syncthreads();                                   // panel c is published
       if (isF11) {
-        const int lane = tid;
+        // look-ahead: bring the next panel's columns up to date, factor and publish it (into the other buffer)
+        // while the border rows are still busy with panel c, then finish my own trailing columns
+        if (c + 8 < w) {
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-          const int j = c + jj;
-          double d = readlane_f64(x[j], j);
-          if (!(d > 0.0)) { fail = 1; d = 1.0; }
-          double y = rsqrt_nr(d);
-          double lij = (lane == j) ? d * y : x[j] * y;
-          x[j] = lij;
-          if (lane == j) mydinv = y;
-#pragma unroll
-          for (int q = jj + 1; q < 8; q++) x[c + q] = fma(-lij, readlane_f64(lij, c + q), x[c + q]);
+          for (int k = c + 8; k < c + 16 && k < W; k++) TRAIL_COL(c, k);
+          if (c + 8 < W) FACTOR_PANEL(c + 8 < W ? c + 8 : 0);
         }
-        if (lane < W) {
 #pragma unroll
-          for (int q = 0; q < 8; q++) pan[lane * 8 + q] = x[c + q];
-          if (lane >= c && lane < c + 8) Dinv[lane] = mydinv;
-        }
-      }
-      __syncthreads();
-      if (!isF11) {
+        for (int k = c + 16; k < W; k++)
+          if (k < w) TRAIL_COL(c, k);
+      } else {
 #pragma unroll
         for (int jj = 0; jj < 8; jj++) {
           double xj = x[c + jj];
@@ -406,23 +429,14 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
           for (int q = 0; q < jj; q++) xj = fma(-x[c + q], pan[(c + jj) * 8 + q], xj);
           x[c + jj] = xj * Dinv[c + jj];
         }
-      }
 #pragma unroll
-      for (int k = c + 8; k < W; k++) {
-        if (k < w) {
-          const double2* lk = reinterpret_cast<const double2*>(pan + k * 8);
-          double acc = x[k];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            double2 l2 = lk[q];
-            acc = fma(-x[c + 2 * q], l2.x, acc);
-            acc = fma(-x[c + 2 * q + 1], l2.y, acc);
-          }
-          x[k] = acc;
-        }
+        for (int k = c + 8; k < W; k++)
+          if (k < w) TRAIL_COL(c, k);
       }
     }
   }
+#undef FACTOR_PANEL
+#undef TRAIL_COL
   if (isF11 && fail && tid == 0) atomicCAS(status, 0, iter_tag);
   PHASE(2);
   double* P = Lbuf + F.L_off;
