@@ -8,4 +8,4 @@ for r in range(10):
     i = gn_symbolic_info(10000, g["fixed"], g["edge_from"], g["edge_to"])
     t = (i["order_us"], i["structure_us"])
     best = t if best is None or sum(t) < sum(best) else best
-print(os.environ.get("CGMR_HOST_THREADS"), "order_us", best[0], "structure_us", best[1], "levels", i["levels"], "fronts", i["fronts"])
+print(os.environ.get("CGMR_HOST_THREADS"), os.environ.get("CGMR_ND_SINGLE_SWEEP"), "order_us", best[0], "structure_us", best[1], "levels", i["levels"], "fronts", i["fronts"], "flops", i["factor_flops"], "maxborder", i["max_border"], "Udoubles", i["U_doubles"])
