@@ -360,6 +360,52 @@ int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, 
   return CGMR_OK;
 }
 
+int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, const double* pts2, int n1, const double* pts1,
+                      double nonmatched_score, const float lower_xy[2], const float upper_xy[2], double* score_out,
+                      int* n_nonmatched_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || n1 < 0 || n2 < 0 || (n1 > 0 && !pts1) || (n2 > 0 && !pts2) || !lower_xy || !upper_xy || !score_out)
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_match_verify: bad argument");
+  if (n1 > kMatchMaxRef || n2 > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d points", kMatchMaxRef);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MatchParams P;
+  std::vector<uint8_t> kern;
+  int rc = setup_geometry(ctx, cfg, P, kern);
+  if (rc) return rc;
+  P.n_ref = n2; P.n_qry = n1;
+  auto w2g = [&](float w, float ll) { return (int)std::lrint((w - ll) * P.inv_res); };
+  int lo_x = w2g(lower_xy[0], P.ll_x), lo_y = w2g(lower_xy[1], P.ll_y), hi_x = w2g(upper_xy[0], P.ll_x), hi_y = w2g(upper_xy[1], P.ll_y);
+  Layout L;
+  size_t o2 = L.add(16 * (size_t)std::max(n2, 1)), o1 = L.add(16 * (size_t)std::max(n1, 1)), o_kern = L.add(kern.size()),
+         o_err = L.add(16);
+  size_t hbytes = L.off;
+  size_t o_out = L.add(16), o_scratch = L.add((size_t)8 * kMatchMaxRef + (size_t)P.overflow_tiles * 64 + 256);
+  rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
+  if (rc) return rc;
+  rc = pinned_reserve(ctx, hbytes);
+  if (rc) return rc;
+  char* h = ctx->pinned;
+  if (n2) memcpy(h + o2, pts2, 16 * (size_t)n2);
+  if (n1) memcpy(h + o1, pts1, 16 * (size_t)n1);
+  memcpy(h + o_kern, kern.data(), kern.size());
+  memset(h + o_err, 0, 16);
+  char* d = ctx->mt_arena.ptr;
+  HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
+  launch_match_verify(ctx->stream, P, (const double*)(d + o2), (const double*)(d + o1), nonmatched_score, lo_x, lo_y, hi_x, hi_y,
+                      (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch), (double*)(d + o_out), (int*)(d + o_out + 8),
+                      (int*)(d + o_err));
+  struct { double score; int nnm; int pad; } out;
+  int err = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&out, d + o_out, 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", err);
+  *score_out = out.score;
+  if (n_nonmatched_out) *n_nonmatched_out = out.nnm;
+  return CGMR_OK;
+}
+
 int cgmr_match_last_kernel_seconds(const cgmr_ctx* ctx, double* seconds) {
   if (!ctx || !seconds) return CGMR_E_INVALID;
   *seconds = ctx->match_seconds;

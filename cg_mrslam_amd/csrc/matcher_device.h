@@ -41,6 +41,9 @@ struct RegionDesc {                          // one search region, precomputed o
 };
 
 size_t match_smem_bytes();
+void launch_match_verify(hipStream_t st, const MatchParams& P, const double* pts2, const double* pts1, double nonmatched_score,
+                         int lo_x, int lo_y, int hi_x, int hi_y, const uint8_t* kernel_lut, unsigned char* scratch,
+                         double* score_out, int* nnm_out, int* err);
 void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const double* ref_pts, const double* qry_pts,
                          const RegionDesc* regions, const double* theta, const int32_t* items, const uint8_t* kernel_lut,
                          unsigned char* scratch, unsigned long long* bins, int* err);

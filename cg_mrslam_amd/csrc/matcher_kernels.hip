@@ -753,7 +753,78 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
   }
 }
 
+
+// Numeric core of ScanMatcher::verifyMatching (scan_matcher.cpp:430-505) in one workgroup: grid from pts2, the
+// points of pts1 the grid does not explain, a second grid from those, mean cell value over a window.
+__global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const double* __restrict__ pts2,
+                                                      const double* __restrict__ pts1, double nonmatched_score,
+                                                      int lo_x, int lo_y, int hi_x, int hi_y,
+                                                      const uint8_t* __restrict__ kernel_lut,
+                                                      unsigned char* __restrict__ scratch, double* __restrict__ score_out,
+                                                      int* __restrict__ nnm_out, int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& S = *reinterpret_cast<Smem*>(smem_raw);
+  const int tid = threadIdx.x;
+  uint32_t* rcell = reinterpret_cast<uint32_t*>(scratch);            // kMatchMaxRef packed cells
+  uint32_t* rcell2 = rcell + kMatchMaxRef;                           // cells of the unexplained points
+  uint32_t* gtiles = rcell2 + kMatchMaxRef;
+  const int DW = ((P.ny + 7) >> 3) + 6;
+  for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
+  for (int i = tid; i < P.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, pts2[2 * i], pts2[2 * i + 1]);
+  __syncthreads();
+  build_grid(S, P, rcell, P.n_ref, gtiles, /*allow_fast=*/false, err);
+  const float ikscale = (float)(1. / (float)P.kscale);
+  // unexplained points: ordered compaction (the stamp is order independent, the count is reported)
+  int base = 0;
+  for (int i0 = 0; i0 < P.n_qry; i0 += 256) {
+    int i = i0 + tid;
+    uint32_t packed = 0x80008000u;
+    int keep = 0;
+    if (i < P.n_qry) {
+      packed = world_to_packed_cell(P, pts1[2 * i], pts1[2 * i + 1]);
+      int gx = (int16_t)(packed & 0xffff), gy = (int16_t)(packed >> 16);
+      if ((unsigned)gx < (unsigned)P.nx && (unsigned)gy < (unsigned)P.ny) {
+        double value = (float)grid_cell(S, P, gtiles, DW, gx, gy) * ikscale;
+        keep = value > nonmatched_score;
+      }
+    }
+    int total;
+    int pos = block_scan_excl(keep, S.scan, &total);
+    if (keep) rcell2[base + pos] = packed;
+    base += total;
+  }
+  __syncthreads();
+  const int nnm = base;
+  build_grid(S, P, rcell2, nnm, gtiles, /*allow_fast=*/false, err);
+  int isum = 0;
+  const int ni = max(0, hi_x - lo_x), nj = max(0, hi_y - lo_y);
+  for (int q = tid; q < ni * nj; q += 256) {
+    int a = q / nj, b = q - a * nj;
+    isum += grid_cell(S, P, gtiles, DW, lo_x + a, lo_y + b);
+  }
+  int total;
+  block_scan_excl(isum, S.scan, &total);
+  if (tid == 0) {
+    int visited = (hi_x - lo_x) * (hi_y - lo_y);
+    *score_out = (double)((float)total / (float)visited);
+    *nnm_out = nnm;
+  }
+}
+
 size_t match_smem_bytes() { return sizeof(Smem); }
+
+void launch_match_verify(hipStream_t st, const MatchParams& P, const double* pts2, const double* pts1, double nonmatched_score,
+                         int lo_x, int lo_y, int hi_x, int hi_y, const uint8_t* kernel_lut, unsigned char* scratch,
+                         double* score_out, int* nnm_out, int* err) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_verify), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sizeof(Smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_match_verify, dim3(1), dim3(256), sizeof(Smem), st, P, pts2, pts1, nonmatched_score, lo_x, lo_y, hi_x,
+                     hi_y, kernel_lut, scratch, score_out, nnm_out, err);
+}
 
 void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const double* ref_pts, const double* qry_pts,
                          const RegionDesc* regions, const double* theta, const int32_t* items, const uint8_t* kernel_lut,

@@ -24,71 +24,6 @@ class MatcherConfig(C.Structure):
                 ("min_range", C.c_double), ("laser_pose", C.c_double * 3)]
 
 
-class ScanMatcher:
-    """The close-range matcher the reference builds in GraphSLAM::init (src/slam/graph_slam.cpp:58-59):
-    ``initializeKernel(resolution, kernelRadius)`` + ``initializeGrid((-15,-15),(15,15), resolution)``."""
-
-    def __init__(self, ctx: Context, n_beams: int, angle_min: float, angle_inc: float, max_range: float,
-                 laser_pose=(0.0, 0.0, 0.0), resolution: float = 0.025, kernel_range: float = 0.2):
-        self.ctx = ctx
-        self.cfg = MatcherConfig()
-        ctx.lib.cgmr_matcher_config_close(C.byref(self.cfg), C.c_int(n_beams), C.c_double(angle_min),
-                                          C.c_double(angle_inc), C.c_double(max_range))
-        self.initializeKernel(resolution, kernel_range)
-        for k in range(3):
-            self.cfg.laser_pose[k] = float(laser_pose[k])
-
-    # reference spellings ----------------------------------------------------------------------
-    def initializeKernel(self, resolution, kernelRange):   # noqa: N802,N803
-        self.cfg.resolution = float(resolution)
-        self.cfg.kernel_range = float(kernelRange)
-
-    def initializeGrid(self, lowerLeft, upperRight, resolution):   # noqa: N802,N803
-        self.cfg.grid_ll_x, self.cfg.grid_ll_y = float(lowerLeft[0]), float(lowerLeft[1])
-        self.cfg.grid_ur_x, self.cfg.grid_ur_y = float(upperRight[0]), float(upperRight[1])
-        self.cfg.resolution = float(resolution)
-
-    def closeScanMatching(self, ranges_ref, ranges_cur, guess, maxScore=0.15, want_nresults=False):   # noqa: N802,N803
-        """Batched ``closeScanMatching``.  ``ranges_*``: (P, n_beams) float32; ``guess``: (P, 3)
-        = origin^-1 * current.  Returns (found[P] bool, trel[P,3], score[P])."""
-        rr = np.ascontiguousarray(ranges_ref, dtype=np.float32)
-        rq = np.ascontiguousarray(ranges_cur, dtype=np.float32)
-        single = rr.ndim == 1
-        if single:
-            rr, rq = rr[None], rq[None]
-        P, B = rr.shape
-        if B != self.cfg.n_beams or rq.shape != rr.shape:
-            raise ValueError("ranges must be (n_pairs, n_beams)")
-        g = np.ascontiguousarray(guess, dtype=np.float64).reshape(P, 3)
-        xyt = np.zeros((P, 3))
-        score = np.zeros(P)
-        found = np.zeros(P, dtype=np.uint8)
-        nres = np.zeros(P, dtype=np.int32)
-        rc = self.ctx.lib.cgmr_match_close_batch(self.ctx.h, C.byref(self.cfg), C.c_int(P), C.c_void_p(rr.ctypes.data),
-                                                 C.c_void_p(rq.ctypes.data), C.c_void_p(g.ctypes.data),
-                                                 C.c_double(maxScore), C.c_void_p(xyt.ctypes.data),
-                                                 C.c_void_p(score.ctypes.data), C.c_void_p(found.ctypes.data),
-                                                 C.c_void_p(nres.ctypes.data))
-        self.ctx._check(rc)
-        if want_nresults:
-            return found.astype(bool), xyt, score, nres
-        return found.astype(bool), xyt, score
-
-    def closeScanMatching_dev(self, d_ranges_ref, d_ranges_cur, d_guess, n_pairs, d_xyt, d_score, d_found,   # noqa: N802
-                              maxScore=0.15, d_nres=0):   # noqa: N803
-        """Device-pointer variant (ints from ``tensor.data_ptr()``)."""
-        rc = self.ctx.lib.cgmr_match_close_batch_dev(self.ctx.h, C.byref(self.cfg), C.c_int(n_pairs),
-                                                     C.c_void_p(d_ranges_ref), C.c_void_p(d_ranges_cur),
-                                                     C.c_void_p(d_guess), C.c_double(maxScore), C.c_void_p(d_xyt),
-                                                     C.c_void_p(d_score), C.c_void_p(d_found), C.c_void_p(d_nres))
-        self.ctx._check(rc)
-
-    def last_kernel_seconds(self) -> float:
-        s = C.c_double()
-        self.ctx._check(self.ctx.lib.cgmr_match_last_kernel_seconds(self.ctx.h, C.byref(s)))
-        return s.value
-
-
 class MatchResult(C.Structure):
     _fields_ = [("x", C.c_double), ("y", C.c_double), ("theta", C.c_double), ("score", C.c_double)]
 
@@ -116,14 +51,9 @@ def normalize_theta(t):
     return t - 2 * math.pi * math.floor((t + math.pi) / (2 * math.pi))
 
 
-class LCScanMatcher(ScanMatcher):
-    """The loop-closure matcher of GraphSLAM::init (src/slam/graph_slam.cpp:61-62): kernel (0.1, 0.5), grid
-    [-35,35]^2 at 0.1 m -- plus the generic searches every ScanMatcher can run.  Scans are passed as
+class _GenericSearch:
+    """Searches every ScanMatcher can run (grid/kernel taken from ``self.cfg``).  Scans are passed as
     ``(ranges, vertex_pose)`` pairs, the flat-array form of a g2o VertexSet with RobotLaser user data."""
-
-    def __init__(self, ctx, n_beams, angle_min, angle_inc, max_range, laser_pose=(0.0, 0.0, 0.0)):
-        super().__init__(ctx, n_beams, angle_min, angle_inc, max_range, laser_pose, resolution=0.1, kernel_range=0.5)
-        self.initializeGrid((-35, -35), (35, 35), 0.1)
 
     # ---- host helpers with the reference's arithmetic (libcgmr.so, no GPU) -----------------------------------
     def cartesian(self, ranges):
@@ -236,6 +166,124 @@ class LCScanMatcher(ScanMatcher):
         if len(res):
             return True, res[0, :3].copy()
         return False, None
+
+
+
+    # ---- ScanMatcher::closeScanMatching with a multi-scan reference set (scan_matcher.cpp:112-189) ---------------
+    def closeScanMatchingVSet(self, ref_scans, origin_index, cur_ranges, cur_pose, maxScore=0.15):   # noqa: N802,N803
+        """The reference's call shape: up to 6 reference scans (graph_slam.cpp:230-241) rasterised in the frame of the
+        origin vertex, the current scan subsampled, window around origin^-1 * current.  Returns (found, trel)."""
+        ref_pts = self.transformPointsFromVSet(ref_scans, origin_index)
+        lp = np.array([self.cfg.laser_pose[k] for k in range(3)])
+        qry = self.applyTransfToScan(lp, self.subsample(self.cartesian(cur_ranges), 0.1))
+        g = _se2_mul(_se2_inv(np.asarray(ref_scans[origin_index][1], dtype=np.float64)), np.asarray(cur_pose, dtype=np.float64))
+        region = np.array([[-.3 + g[0], -.3 + g[1], -0.2 + g[2], .3 + g[0], .3 + g[1], 0.2 + g[2]]], dtype=np.float32)
+        res = self.greedySearch(ref_pts, qry, region, 0.0125 * .5, maxScore, 0.5, 0.5, 0.2)
+        if len(res):
+            return True, res[0, :3].copy()
+        return False, None
+
+    # ---- ScanMatcher::verifyMatching (scan_matcher.cpp:430-505) --------------------------------------------------
+    def verifyMatching(self, scans1, ref1_index, scans2, ref2_index, trel12, threshold=40.0):   # noqa: N802
+        """Returns (accepted, score).  ``trel12``: pose of reference vertex 2 in the frame of reference vertex 1."""
+        lp = np.array([self.cfg.laser_pose[k] for k in range(3)])
+        trel12 = np.asarray(trel12, dtype=np.float64)
+        ref2_pose = np.asarray(scans2[ref2_index][1], dtype=np.float64)
+        pts2 = []
+        for k, (ranges, pose) in enumerate(scans2):
+            v = self.cartesian(ranges)
+            if k == ref2_index:
+                pts2.append(self.applyTransfToScan(_se2_mul(trel12, lp), v))
+            else:
+                t = _se2_mul(_se2_mul(trel12, _se2_mul(_se2_inv(ref2_pose), np.asarray(pose, dtype=np.float64))), lp)
+                pts2.append(self.applyTransfToScan(t, v))
+        pts2 = np.ascontiguousarray(np.concatenate(pts2))
+        pts1 = np.ascontiguousarray(self.transformPointsFromVSet(scans1, ref1_index))
+        lower = np.array([-.3 + trel12[0], -.3 + trel12[1]], dtype=np.float32)
+        upper = np.array([.3 + trel12[0], .3 + trel12[1]], dtype=np.float32)
+        score = C.c_double()
+        nnm = C.c_int()
+        rc = self.ctx.lib.cgmr_match_verify(self.ctx.h, C.byref(self.cfg), C.c_int(len(pts2)), C.c_void_p(pts2.ctypes.data),
+                                            C.c_int(len(pts1)), C.c_void_p(pts1.ctypes.data), C.c_double(0.3),
+                                            C.c_void_p(lower.ctypes.data), C.c_void_p(upper.ctypes.data), C.byref(score),
+                                            C.byref(nnm))
+        self.ctx._check(rc)
+        return score.value <= threshold, score.value
+
+
+class ScanMatcher(_GenericSearch):
+    """The close-range matcher the reference builds in GraphSLAM::init (src/slam/graph_slam.cpp:58-59):
+    ``initializeKernel(resolution, kernelRadius)`` + ``initializeGrid((-15,-15),(15,15), resolution)``."""
+
+    def __init__(self, ctx: Context, n_beams: int, angle_min: float, angle_inc: float, max_range: float,
+                 laser_pose=(0.0, 0.0, 0.0), resolution: float = 0.025, kernel_range: float = 0.2):
+        self.ctx = ctx
+        self.cfg = MatcherConfig()
+        ctx.lib.cgmr_matcher_config_close(C.byref(self.cfg), C.c_int(n_beams), C.c_double(angle_min),
+                                          C.c_double(angle_inc), C.c_double(max_range))
+        self.initializeKernel(resolution, kernel_range)
+        for k in range(3):
+            self.cfg.laser_pose[k] = float(laser_pose[k])
+
+    # reference spellings ----------------------------------------------------------------------
+    def initializeKernel(self, resolution, kernelRange):   # noqa: N802,N803
+        self.cfg.resolution = float(resolution)
+        self.cfg.kernel_range = float(kernelRange)
+
+    def initializeGrid(self, lowerLeft, upperRight, resolution):   # noqa: N802,N803
+        self.cfg.grid_ll_x, self.cfg.grid_ll_y = float(lowerLeft[0]), float(lowerLeft[1])
+        self.cfg.grid_ur_x, self.cfg.grid_ur_y = float(upperRight[0]), float(upperRight[1])
+        self.cfg.resolution = float(resolution)
+
+    def closeScanMatching(self, ranges_ref, ranges_cur, guess, maxScore=0.15, want_nresults=False):   # noqa: N802,N803
+        """Batched ``closeScanMatching``.  ``ranges_*``: (P, n_beams) float32; ``guess``: (P, 3)
+        = origin^-1 * current.  Returns (found[P] bool, trel[P,3], score[P])."""
+        rr = np.ascontiguousarray(ranges_ref, dtype=np.float32)
+        rq = np.ascontiguousarray(ranges_cur, dtype=np.float32)
+        single = rr.ndim == 1
+        if single:
+            rr, rq = rr[None], rq[None]
+        P, B = rr.shape
+        if B != self.cfg.n_beams or rq.shape != rr.shape:
+            raise ValueError("ranges must be (n_pairs, n_beams)")
+        g = np.ascontiguousarray(guess, dtype=np.float64).reshape(P, 3)
+        xyt = np.zeros((P, 3))
+        score = np.zeros(P)
+        found = np.zeros(P, dtype=np.uint8)
+        nres = np.zeros(P, dtype=np.int32)
+        rc = self.ctx.lib.cgmr_match_close_batch(self.ctx.h, C.byref(self.cfg), C.c_int(P), C.c_void_p(rr.ctypes.data),
+                                                 C.c_void_p(rq.ctypes.data), C.c_void_p(g.ctypes.data),
+                                                 C.c_double(maxScore), C.c_void_p(xyt.ctypes.data),
+                                                 C.c_void_p(score.ctypes.data), C.c_void_p(found.ctypes.data),
+                                                 C.c_void_p(nres.ctypes.data))
+        self.ctx._check(rc)
+        if want_nresults:
+            return found.astype(bool), xyt, score, nres
+        return found.astype(bool), xyt, score
+
+    def closeScanMatching_dev(self, d_ranges_ref, d_ranges_cur, d_guess, n_pairs, d_xyt, d_score, d_found,   # noqa: N802
+                              maxScore=0.15, d_nres=0):   # noqa: N803
+        """Device-pointer variant (ints from ``tensor.data_ptr()``)."""
+        rc = self.ctx.lib.cgmr_match_close_batch_dev(self.ctx.h, C.byref(self.cfg), C.c_int(n_pairs),
+                                                     C.c_void_p(d_ranges_ref), C.c_void_p(d_ranges_cur),
+                                                     C.c_void_p(d_guess), C.c_double(maxScore), C.c_void_p(d_xyt),
+                                                     C.c_void_p(d_score), C.c_void_p(d_found), C.c_void_p(d_nres))
+        self.ctx._check(rc)
+
+    def last_kernel_seconds(self) -> float:
+        s = C.c_double()
+        self.ctx._check(self.ctx.lib.cgmr_match_last_kernel_seconds(self.ctx.h, C.byref(s)))
+        return s.value
+
+
+class LCScanMatcher(ScanMatcher):
+    """The loop-closure matcher of GraphSLAM::init (src/slam/graph_slam.cpp:61-62): kernel (0.1, 0.5), grid
+    [-35,35]^2 at 0.1 m -- plus the generic searches every ScanMatcher can run.  Scans are passed as
+    ``(ranges, vertex_pose)`` pairs, the flat-array form of a g2o VertexSet with RobotLaser user data."""
+
+    def __init__(self, ctx, n_beams, angle_min, angle_inc, max_range, laser_pose=(0.0, 0.0, 0.0)):
+        super().__init__(ctx, n_beams, angle_min, angle_inc, max_range, laser_pose, resolution=0.1, kernel_range=0.5)
+        self.initializeGrid((-35, -35), (35, 35), 0.1)
 
 
 def smoke(ctx, oracle) -> None:

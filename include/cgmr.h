@@ -204,6 +204,16 @@ int cgmr_scan_cartesian(int n_beams, const float* ranges, double angle_min, doub
                         double min_range, double* pts_out);
 int cgmr_subsample(int n, const double* pts_xy, double res, double* pts_out);
 
+/* Numeric core of bool ScanMatcher::verifyMatching(vset1, ref1, vset2, ref2, trel12, double* score)
+ * (src/matcher/scan_matcher.cpp:430-505): rasterise pts2 (vset2 moved into the frame of reference vertex 1 by
+ * trel12), collect the points of pts1 the map does not explain (cell/kscale > nonmatched_score, 0.3 in the
+ * reference; CharGrid::searchNonMatchedPoints chargrid.cpp:444-455), rasterise those into a fresh grid and average
+ * its cells over the window [lower, upper) (CharGrid::countPoints chargrid.cpp:417-441).  The caller applies the
+ * reference's threshold (score <= 40).  *n_nonmatched_out (nullable) receives the number of unexplained points. */
+int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, const double* pts2_xy, int n1,
+                      const double* pts1_xy, double nonmatched_score, const float lower_xy[2], const float upper_xy[2],
+                      double* score_out, int* n_nonmatched_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -517,3 +517,44 @@ int cmo_close_scan_match_batch(int npairs, int nbeams, const float *ranges_ref, 
   }
   return 0;
 }
+
+/* ScanMatcher::verifyMatching numeric core (scan_matcher.cpp:430-505 with CharGrid::searchNonMatchedPoints,
+ * chargrid.cpp:444-455, and CharGrid::countPoints, chargrid.cpp:417-441):
+ *   grid  := reset + addAndConvolvePoints(pts2)            (local map of vset2 in the frame of reference vertex 1)
+ *   nonmatched := points of pts1 inside the grid whose cell * (1/kscale) > nonmatched_score (0.3 in the reference)
+ *   aux   := reset + addAndConvolvePoints(nonmatched)
+ *   score := (float) sum of aux cells over [world2grid(lower), world2grid(upper)) / (float) visited cells
+ * Returns the number of non-matched points; *score_out as the reference computes it (float -> double). */
+int cmo_verify(float ll_x, float ll_y, float ur_x, float ur_y, float res, double kernel_res, double kernel_range,
+               int kscale, int n2, const double *pts2, int n1, const double *pts1, double nonmatched_score,
+               const float *lower_xy, const float *upper_xy, double *score_out) {
+  cmo_grid g;
+  grid_init(&g, ll_x, ll_y, ur_x, ur_y, res, kscale);
+  uint8_t kernel[64 * 64];
+  int kdim = cmo_make_kernel(kernel_res, kernel_range, kscale, kernel, sizeof kernel);
+  if (kdim < 0) { free(g.cells); return -1; }
+  rasterize(&g, kernel, kdim, kernel_range, n2, pts2);
+  double *nm = (double *)malloc(sizeof(double) * 2 * (n1 ? n1 : 1));
+  int nnm = 0;
+  float ikscale = (float)(1. / (float)kscale);
+  for (int i = 0; i < n1; i++) {
+    int gx, gy;
+    world2grid(&g, (float)pts1[2 * i], (float)pts1[2 * i + 1], &gx, &gy);
+    if (is_inside(&g, gx, gy)) {
+      double value = (float)g.cells[(size_t)gx * g.ny + gy] * ikscale;
+      if (value > nonmatched_score) { nm[2 * nnm] = pts1[2 * i]; nm[2 * nnm + 1] = pts1[2 * i + 1]; nnm++; }
+    }
+  }
+  rasterize(&g, kernel, kdim, kernel_range, nnm, nm);       /* auxGrid: reset + stamp the unexplained points */
+  int lx, ly, ux, uy;
+  world2grid(&g, lower_xy[0], lower_xy[1], &lx, &ly);
+  world2grid(&g, upper_xy[0], upper_xy[1], &ux, &uy);
+  int isum = 0;
+  for (int i = lx; i < ux; i++)
+    for (int j = ly; j < uy; j++)
+      if (is_inside(&g, i, j)) isum += g.cells[(size_t)i * g.ny + j];
+  int visited = (ux - lx) * (uy - ly);
+  *score_out = (double)((float)isum / (float)visited);
+  free(nm); free(g.cells);
+  return nnm;
+}

@@ -265,3 +265,13 @@ def close_scan_match_batch(ranges_ref, ranges_qry, angle_min, angle_inc, max_ran
                                           _p(score, C.c_double), _p(found, C.c_uint8))
     assert rc == 0
     return xyt, score, found
+
+
+def verify(ll, ur, res, kernel_res, kernel_range, pts2, pts1, lower_xy, upper_xy, nonmatched_score=0.3, kscale=128):
+    pts2, pts1 = _f64(pts2).reshape(-1, 2), _f64(pts1).reshape(-1, 2)
+    lo, up = _f32(lower_xy), _f32(upper_xy)
+    score = C.c_double()
+    n = lib().cmo_verify(*_grid_args(ll, ur, res, kernel_res, kernel_range, kscale), C.c_int(len(pts2)),
+                         _p(pts2, C.c_double), C.c_int(len(pts1)), _p(pts1, C.c_double), C.c_double(nonmatched_score),
+                         _p(lo, C.c_float), _p(up, C.c_float), C.byref(score))
+    return n, score.value

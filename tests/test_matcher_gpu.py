@@ -194,3 +194,56 @@ def test_scan_matching_lc_multi_scan_reference_set(ctx, oracle):
                 merged[key] = b
     want = [merged[k][:3] for k in sorted(merged)]
     assert len(want) == len(res) and all(np.array_equal(a, b) for a, b in zip(res, want))
+
+
+def test_verify_matching_core_matches_oracle(ctx, oracle):
+    """cgmr_match_verify (numeric core of verifyMatching) against the oracle: same non-matched count, same score."""
+    sp = synth.make_scan_pairs(3, seed=92)
+    m = _lc(ctx, sp)
+    import ctypes as C
+    for p in range(3):
+        pts2 = m.cartesian(sp["ranges_ref"][p])
+        pts1 = m.applyTransfToScan(sp["true_rel"][p] + [0.4 * p, -0.2 * p, 0.05 * p], m.cartesian(sp["ranges_qry"][p]))
+        for (lo, up) in (((-0.3, -0.3), (0.3, 0.3)), ((1.0, -2.0), (1.6, -1.4)), ((34.8, 34.8), (35.4, 35.4))):
+            lo32, up32 = np.array(lo, dtype=np.float32), np.array(up, dtype=np.float32)
+            score, nnm = C.c_double(), C.c_int()
+            rc = ctx.lib.cgmr_match_verify(ctx.h, C.byref(m.cfg), C.c_int(len(pts2)), C.c_void_p(pts2.ctypes.data), C.c_int(len(pts1)),
+                                           C.c_void_p(np.ascontiguousarray(pts1).ctypes.data), C.c_double(0.3),
+                                           C.c_void_p(lo32.ctypes.data), C.c_void_p(up32.ctypes.data), C.byref(score), C.byref(nnm))
+            assert rc == 0
+            n_o, s_o = oracle.verify((-35, -35), (35, 35), 0.1, 0.1, 0.5, pts2, pts1, lo32, up32)
+            assert nnm.value == n_o
+            assert score.value == s_o or (np.isnan(score.value) and np.isnan(s_o))
+    # well aligned scans explain each other: (almost) nothing unexplained near the origin -> the window stays at fill
+    ok, sc = m.verifyMatching([(sp["ranges_qry"][0], sp["true_rel"][0])], 0, [(sp["ranges_ref"][0], np.zeros(3))], 0,
+                              synth.se2_inverse(sp["true_rel"][0]))
+    assert sc > 40.0 and not ok      # reference semantics: a *low* mean (unexplained points nearby) passes the <= 40 test
+
+
+def test_close_matching_with_multi_scan_reference_set(ctx, oracle):
+    """closeScanMatching as the reference calls it (up to 6 reference scans, graph_slam.cpp:230-241) through the generic
+    search, against the oracle's greedy search on the same points, and against the batched single-scan kernel."""
+    ang = synth.LASER_ANGLE_MIN + synth.LASER_ANGLE_INC * np.arange(1081)
+    boxes = [(-5.0, -4.0, 5.0, 4.0)]
+    poses = [np.array([0.1 * k, -0.05 * k, 0.03 * k]) for k in range(4)]
+    scans = [(synth._raycast_boxes(p[0], p[1], p[2] + ang, boxes, 30.0).astype(np.float32), p) for p in poses]
+    cur_true = np.array([0.55, -0.2, 0.18])
+    cur_r = synth._raycast_boxes(cur_true[0], cur_true[1], cur_true[2] + ang, boxes, 30.0).astype(np.float32)
+    from cg_mrslam_amd.matcher import ScanMatcher
+    m = ScanMatcher(ctx, 1081, synth.LASER_ANGLE_MIN, synth.LASER_ANGLE_INC, 30.0)
+    found, trel = m.closeScanMatchingVSet(scans, 3, cur_r, cur_true + [0.05, 0.04, -0.02], 0.15)
+    assert found
+    rel_true = synth.se2_compose(synth.se2_inverse(poses[3]), cur_true)
+    assert np.abs(trel[:2] - rel_true[:2]).max() < 0.03 and abs(trel[2] - rel_true[2]) < 0.0126
+    # oracle on the same points / window
+    ref_pts = m.transformPointsFromVSet(scans, 3)
+    qry = m.subsample(m.cartesian(cur_r), 0.1)
+    from cg_mrslam_amd.matcher import _se2_inv, _se2_mul
+    g = _se2_mul(_se2_inv(poses[3]), cur_true + [0.05, 0.04, -0.02])
+    region = np.array([[-.3 + g[0], -.3 + g[1], -0.2 + g[2], .3 + g[0], .3 + g[1], 0.2 + g[2]]], dtype=np.float32)
+    n, want = oracle.greedy_search((-15, -15), (15, 15), 0.025, 0.025, 0.2, ref_pts, qry, region, 0.025, 0.0125 * .5, 0.15, 0.5, 0.5, 0.2)
+    assert n > 0 and np.array_equal(trel, want[0, :3])
+    # single-scan reference set: identical to the batched kernel
+    f1, t1 = m.closeScanMatchingVSet([scans[3]], 0, cur_r, cur_true + [0.05, 0.04, -0.02], 0.15)
+    fb, tb, sb = m.closeScanMatching(scans[3][0], cur_r, g)
+    assert f1 and fb[0] and np.array_equal(t1, tb[0])
