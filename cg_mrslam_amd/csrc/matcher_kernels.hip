@@ -8,7 +8,7 @@
 //   CharGrid::greedySearch              src/matcher/chargrid.cpp:208-308 (+ addToPrunedMap 36-46)
 //   _GridMap::world2grid/grid2world     src/matcher/gridmap.h:24-48
 //
-// Design ("Matcher kernel"): one workgroup (256 threads) matches one scan pair end to end;
+// Design ("Matcher kernel"): one workgroup (512 threads, 2 wavefronts per SIMD) matches one scan pair end to end;
 // a persistent grid of workgroups strides over the batch.  The reference's 1200x1200-byte distance grid
 // (1.44 MB) does not fit the 160 KB LDS, but only cells within the kernel radius of a reference point
 // differ from the fill value, so the grid is held *sparsely*: a directory of 8x8-cell tiles (uint16 per
@@ -114,7 +114,10 @@ __device__ void portable_sincos(double x, double* s, double* c) {
 // ------------------------------------------------------------------ LDS plan
 constexpr int NT_LDS = kMatchTilesLds;       // tiles held in LDS
 constexpr int MAXPTS = kMatchMaxPoints;      // max beams / points per scan
-constexpr int NTH = 4;                       // search angles processed concurrently (one per wavefront)
+constexpr int NTH = 8;                       // search angles processed concurrently (one per wavefront, 512 threads)
+constexpr int CB_THREADS = 64 * NTH;            // workgroup size of k_match_close_batch
+constexpr int GR_WAVES = 4;                  // wavefronts of the generic kernels (256 threads)
+constexpr int LISTCAP = 704;                 // kept points per angle on the fast path (more -> generic path)
 constexpr int PT = 4;                        // points gathered per inner iteration of the fast search path
 constexpr int CAND_U = 9;                    // candidates per lane per block (64*9 = 576 = 24x24)
 constexpr int MAXBINS = 512;
@@ -122,11 +125,11 @@ constexpr int MAXTHETA = kMatchMaxTheta;
 
 struct Smem {
   uint32_t tiles[NT_LDS * 16];               // 64-byte tiles, cell (x&7, y&7) at byte (x&7)*8 + (y&7)   (16-B aligned)
-  uint32_t plist[NTH][MAXPTS];               // per-angle point lists: int16 x | int16 y << 16           (16-B aligned)
+  uint32_t plist[NTH][LISTCAP];              // per-angle point lists: int16 x | int16 y << 16           (16-B aligned)
   unsigned long long bins[MAXBINS];          // (score bits << 32 | visit order), min = best, first seen
   double theta[MAXTHETA], cs[MAXTHETA], sn[MAXTHETA];
   uint8_t kernel[1024];
-  int scan[260];
+  int scan[516];
   int misc[16];
   uint16_t dir[kMatchMaxDir];                // tile directory: 0xFFFF = untouched (all cells = fill)
 };
@@ -149,19 +152,20 @@ __device__ __forceinline__ uint32_t bytemin4(uint32_t a, uint32_t b) {
   return r;
 }
 
-// block-wide exclusive scan of one int per thread (256 threads); returns the exclusive prefix, total in *total
+// block-wide exclusive scan of one int per thread (any power-of-two block size <= 512); returns the exclusive prefix, total in *total
 __device__ int block_scan_excl(int v, int* sh, int* total) {
   const int tid = threadIdx.x;
   sh[tid] = v;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
+  const int nthr = blockDim.x;
+  for (int off = 1; off < nthr; off <<= 1) {
     int add = (tid >= off) ? sh[tid - off] : 0;
     __syncthreads();
     sh[tid] += add;
     __syncthreads();
   }
   int incl = sh[tid];
-  *total = sh[255];
+  *total = sh[nthr - 1];
   __syncthreads();
   return incl - v;
 }
@@ -182,15 +186,16 @@ __device__ __forceinline__ uint32_t world_to_packed_cell(const MatchParams& P, d
 __device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
                            int* err) {
   const int tid = threadIdx.x;
+  const int NTHR = blockDim.x;
   const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
   const int DW = nty + 6;
   const int ndir = (ntx + 2) * DW;
   const int K2 = P.fill;
   const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
   const int ctr = (P.kdim - 1) / 2;
-  for (int q = tid; q < (ndir + 1) / 2; q += 256) reinterpret_cast<uint32_t*>(S.dir)[q] = 0;
+  for (int q = tid; q < (ndir + 1) / 2; q += NTHR) reinterpret_cast<uint32_t*>(S.dir)[q] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += NTHR) {
     uint32_t packed = rcell[i];
     if (packed == 0x80008000u) continue;
     int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
@@ -202,7 +207,7 @@ __device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell,
   __syncthreads();
   MPHASE(3);
   {
-    const int per = (ndir + 255) / 256;
+    const int per = (ndir + NTHR - 1) / NTHR;
     const int b0 = tid * per, b1 = min(ndir, b0 + per);
     int cnt = 0;
     for (int q = b0; q < b1; q++) cnt += S.dir[q];
@@ -226,15 +231,15 @@ __device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell,
   const int ntile = S.misc[0];
   const bool fast = S.misc[12] != 0;
   if (fast && tid < 16) { S.tiles[ntile * 16 + tid] = fill4; S.tiles[(ntile + 1) * 16 + tid] = 0u; }
-  for (int q = tid; q < min(ntile, NT_LDS) * 16; q += 256) S.tiles[q] = fill4;
-  for (int q = tid; q < max(0, ntile - NT_LDS) * 16; q += 256) gtiles[q] = fill4;
+  for (int q = tid; q < min(ntile, NT_LDS) * 16; q += NTHR) S.tiles[q] = fill4;
+  for (int q = tid; q < max(0, ntile - NT_LDS) * 16; q += NTHR) gtiles[q] = fill4;
   __syncthreads();
   MPHASE(4);
   // stamp: work item = (reference point, kernel row); byte-min through compare-and-swap on 32-bit words.
   // Neighbouring beams stamp overlapping cells; spread concurrently processed items over far-apart points
   // (stride 67 modulo an odd count) so that the compare-and-swap rarely has to retry.
   const int np = n | 1;
-  for (int wi = tid; wi < np * P.kdim; wi += 256) {
+  for (int wi = tid; wi < np * P.kdim; wi += NTHR) {
     int ki = wi / np, p = (int)(((long long)(wi - ki * np) * 67) % np);
     if (p >= n) continue;
     uint32_t packed = rcell[p];
@@ -281,7 +286,7 @@ __device__ __forceinline__ int grid_cell(const Smem& S, const MatchParams& P, co
 }  // namespace
 
 // One workgroup per scan pair (persistent stride over the batch).
-__global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const float* __restrict__ ranges_ref,
+__global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P, const float* __restrict__ ranges_ref,
                                                            const float* __restrict__ ranges_qry,
                                                            const double* __restrict__ guess,
                                                            const double* __restrict__ beam_cos,
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
 #define DIRIDX(tx, ty) (((tx) + 1) * DW + (ty) + 3)
   const int K2 = P.fill;
   const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
-  for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
+  for (int q = tid; q < P.kdim * P.kdim; q += CB_THREADS) S.kernel[q] = kernel_lut[q];
 
   for (int pair = blockIdx.x; pair < P.n_pairs; pair += gridDim.x) {
     __syncthreads();
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     // sort keys live in the (not yet used) tile pool: 2048 x u64
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(S.tiles);
     const double ires = 1. / P.sub_res;
-    for (int i = tid; i < 2048; i += 256) {
+    for (int i = tid; i < 2048; i += CB_THREADS) {
       unsigned long long key = ~0ULL;
       if (i < B) {
         double r = (double)ranges_qry[(size_t)pair * B + i];
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     __syncthreads();
     for (int k = 2; k <= 2048; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < 2048; i += 256) {
+        for (int i = tid; i < 2048; i += CB_THREADS) {
           int l = i ^ j;
           if (l > i) {
             unsigned long long a = keys[i], b = keys[l];
@@ -349,10 +354,11 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     MPHASE(1);
     // bucket leaders: sorted position i starts a bucket if its (kx,ky) differs from position i-1
     int nlead = 0;
-    int lead_pos[8];
+    constexpr int LPT = 2048 / CB_THREADS;     // sorted positions per thread
+    int lead_pos[LPT];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      int i = tid * 8 + u;                  // contiguous ranges so that the scan yields bucket ranks in order
+    for (int u = 0; u < LPT; u++) {
+      int i = tid * LPT + u;                  // contiguous ranges so that the scan yields bucket ranks in order
       unsigned long long a = keys[i];
       bool lead = (a != ~0ULL) && (i == 0 || (keys[i - 1] >> 21) != (a >> 21));
       lead_pos[u] = lead ? i : -1;
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     {
       const double lc = P.lp_c, ls = P.lp_s, ltx = P.lp_x, lty = P.lp_y;
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < LPT; u++) {
         int i = lead_pos[u];
         if (i < 0) continue;
         unsigned long long kk = keys[i] >> 21;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     MPHASE(2);
     // ---------------- reference scan -> cells -----------------------------------------------------------------
     uint32_t* rcell = S.plist[0];           // int16 x | int16 y << 16, 0x80008000 = invalid
-    for (int i = tid; i < B; i += 256) {
+    for (int i = tid; i < B; i += CB_THREADS) {
       uint32_t packed = 0x80008000u;
       double r = (double)ranges_ref[(size_t)pair * B + i];
       if (r < P.max_range && r > P.min_range) {
@@ -430,8 +436,8 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     const int lo_x = S.misc[1], lo_y = S.misc[2], ni = S.misc[3], nj = S.misc[4], nth = S.misc[5];
     const int bx0 = S.misc[6], by0 = S.misc[7], bt0 = S.misc[8], nbx = S.misc[9], nby = S.misc[10], nbt = S.misc[11];
     const int nbins = nbx * nby * nbt;
-    for (int q = tid; q < nbins; q += 256) S.bins[q] = ~0ULL;
-    for (int q = tid; q < nth; q += 256) {
+    for (int q = tid; q < nbins; q += CB_THREADS) S.bins[q] = ~0ULL;
+    for (int q = tid; q < nth; q += CB_THREADS) {
       double s, c;
       portable_sincos(S.theta[q], &s, &c);
       S.sn[q] = s; S.cs[q] = c;
@@ -439,10 +445,14 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
     __syncthreads();
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
+    // a scan with more subsampled points than one list holds: half the wavefronts search, with two lists each
+    const bool wide = nq > LISTCAP - PT;
+    const int nsearch = wide ? NTH / 2 : NTH;
+    uint32_t* const pl = &S.plist[0][0] + (wide ? 2 * wave : wave) * LISTCAP;
     MPHASE(6);
     // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
-    for (int tb = 0; tb < nth; tb += NTH) {
-      const int ti = tb + wave;
+    for (int tb = 0; tb < nth; tb += nsearch) {
+      const int ti = (wave < nsearch) ? tb + wave : nth;
       int k = 0;
       if (ti < nth) {
         const double c = S.cs[ti], s = S.sn[ti];
@@ -463,13 +473,13 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
           bool keep = valid && (!(lane == 0 && !have_prev) ? (packed != left) : true);
           unsigned long long mask = __ballot(keep);
           int pos = k + __popcll(mask & ((1ULL << lane) - 1ULL));
-          if (keep) S.plist[wave][pos] = packed;
+          if (keep) pl[pos] = packed;
           k += __popcll(mask);
           int lastv = min(63, nq - base - 1);
           prev = __shfl(packed, lastv, 64);
           have_prev = true;
         }
-        if (lane < PT) S.plist[wave][k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
+        if (lane < PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
       }
       __builtin_amdgcn_wave_barrier();
       if (ti < nth && fast) {
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
           const int flush_iters = max(1, flush_every / PT);
           const int cxlo = -8, cxhi = P.nx + 7, cylo = -24, cyhi = P.ny;
           for (int q = 0; q < k; q += PT) {
-            const uint4 pk4 = *reinterpret_cast<const uint4*>(&S.plist[wave][q]);
+            const uint4 pk4 = *reinterpret_cast<const uint4*>(&pl[q]);
             const uint32_t pk[PT] = {pk4.x, pk4.y, pk4.z, pk4.w};
             int d[PT][3], rowoff[PT], o[PT];
 #pragma unroll
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(256) void k_match_close_batch(MatchParams P, const 
             sum[u] = 0;
           }
           for (int q = 0; q < k; q++) {
-            uint32_t packed = S.plist[wave][q];
+            uint32_t packed = pl[q];
             int px = (int16_t)(packed & 0xffff), py = (int16_t)(packed >> 16);
 #pragma unroll
             for (int u = 0; u < CAND_U; u++) {
@@ -673,7 +683,8 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
   build_grid(S, P, rcell, P.n_ref, gtiles, /*allow_fast=*/false, err);
   const float ikscale = (float)(1. / (float)P.kscale);
   const int nbins = P.nbx * P.nby * P.nbt;
-  for (int it0 = blockIdx.x * NTH; it0 < P.n_items; it0 += gridDim.x * NTH) {
+  uint32_t* const pl = &S.plist[0][0] + wave * (2 * LISTCAP);     // 4 wavefronts: two lists each
+  for (int it0 = blockIdx.x * GR_WAVES; it0 < P.n_items; it0 += gridDim.x * GR_WAVES) {
     const int it = it0 + wave;
     if (it >= P.n_items) continue;
     const RegionDesc R = regions[items[2 * it]];
@@ -716,7 +727,7 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
           bool keep = valid && ((lane == 0 && !have_prev) ? true : (packed != left));
           unsigned long long mask = __ballot(keep);
           int pos = kc + __popcll(mask & ((1ULL << lane) - 1ULL));
-          if (keep) S.plist[wave][pos] = packed;
+          if (keep) pl[pos] = packed;
           kc += __popcll(mask);
           int lastv = min(63, c1 - base - 1);
           prev = __shfl(packed, lastv, 64);
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
         }
         __builtin_amdgcn_wave_barrier();
         for (int q = 0; q < kc; q++) {
-          uint32_t packed = S.plist[wave][q];
+          uint32_t packed = pl[q];
           int px = (int16_t)(packed & 0xffff), py = (int16_t)(packed >> 16);
 #pragma unroll
           for (int u = 0; u < CAND_U; u++) sum[u] += grid_cell(S, P, gtiles, DW, px + ci[u], py + cj[u]);
@@ -849,7 +860,7 @@ void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(256), sizeof(Smem), st, P, ranges_ref, ranges_qry, guess,
+  hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(CB_THREADS), sizeof(Smem), st, P, ranges_ref, ranges_qry, guess,
                      beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err);
 }
 
