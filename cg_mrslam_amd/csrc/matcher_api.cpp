@@ -54,7 +54,7 @@ int setup_geometry(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, MatchParams& P
   P.nx = (int)((cfg->grid_ur_x - cfg->grid_ll_x) * P.inv_res);
   P.ny = (int)((cfg->grid_ur_y - cfg->grid_ll_y) * P.inv_res);
   int ntx = (P.nx + 7) / 8, nty = (P.ny + 7) / 8;
-  if (P.nx <= 0 || P.ny <= 0 || (ntx + 2) * (nty + 6) > kMatchMaxDir)
+  if (P.nx <= 0 || P.ny <= 0 || (ntx + 2) * (nty + kMatchDirGuardY) > kMatchMaxDir)
     return set_err(ctx, CGMR_E_INVALID, "grid %dx%d cells exceeds the %d-tile directory", P.nx, P.ny, kMatchMaxDir);
   P.kscale = cfg->kscale;
   P.kdim = make_kernel(cfg->resolution, cfg->kernel_range, cfg->kscale, kern);

@@ -152,6 +152,16 @@ __device__ __forceinline__ uint32_t bytemin4(uint32_t a, uint32_t b) {
   return r;
 }
 
+typedef volatile __attribute__((address_space(3))) uint16_t lds_vu16;   // keeps 2-byte LDS loads from being merged
+
+template <int LO>
+__device__ __forceinline__ int clamp_med3(int x, int hi) {     // min(max(x, LO), hi) for LO <= hi (hi wave-uniform), one instruction
+  int r;
+  const int lo = LO;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+  return r;
+}
+
 // block-wide exclusive scan of one int per thread (any power-of-two block size <= 512); returns the exclusive prefix, total in *total
 __device__ int block_scan_excl(int v, int* sh, int* total) {
   const int tid = threadIdx.x;
@@ -181,6 +191,18 @@ __device__ __forceinline__ uint32_t world_to_packed_cell(const MatchParams& P, d
   return ((uint32_t)(uint16_t)(int16_t)rx) | ((uint32_t)(uint16_t)(int16_t)ry << 16);
 }
 
+// byte-wise min of kv into *wp through compare-and-swap
+__device__ __forceinline__ void stamp_word(uint32_t* wp, uint32_t kv) {
+  uint32_t old = *wp;
+  while (true) {
+    uint32_t nw = bytemin4(old, kv);
+    if (nw == old) break;
+    uint32_t seen = atomicCAS(wp, old, nw);
+    if (seen == old) break;
+    old = seen;
+  }
+}
+
 // resetGrid + addAndConvolvePoints for n packed reference cells: directory marking, tile slot assignment (block
 // scan), tile initialisation, compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
 __device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
@@ -188,7 +210,7 @@ __device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell,
   const int tid = threadIdx.x;
   const int NTHR = blockDim.x;
   const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
-  const int DW = nty + 6;
+  const int DW = nty + kMatchDirGuardY;
   const int ndir = (ntx + 2) * DW;
   const int K2 = P.fill;
   const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
@@ -259,18 +281,20 @@ __device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell,
       }
       int d = S.dir[((x >> 3) + 1) * DW + (wy >> 3) + 3];
       int woff = (x & 7) * 2 + ((wy & 7) >> 2);
-      uint32_t* wp = (d < NT_LDS) ? &S.tiles[d * 16 + woff] : &gtiles[(size_t)(d - NT_LDS) * 16 + woff];
-      uint32_t old = *wp;
-      while (true) {
-        uint32_t nw = bytemin4(old, kv);
-        if (nw == old) break;
-        uint32_t seen = atomicCAS(wp, old, nw);
-        if (seen == old) break;
-        old = seen;
-      }
+      // two separate loops so that each keeps its address space (no flat pointers)
+      if (d < NT_LDS) stamp_word(&S.tiles[d * 16 + woff], kv);
+      else stamp_word(&gtiles[(size_t)(d - NT_LDS) * 16 + woff], kv);
     }
   }
   __syncthreads();
+}
+
+// one byte of tile d (LDS pool or HBM overflow).  The LDS read is unconditional (clamped index) and the HBM read
+// conditional, so that neither becomes a flat access through a merged pointer.
+__device__ __forceinline__ int tile_byte(const Smem& S, const uint32_t* gtiles, int d, int boff) {
+  int v = reinterpret_cast<const uint8_t*>(S.tiles)[min(d, NT_LDS - 1) * 64 + boff];
+  if (d >= NT_LDS) v = reinterpret_cast<const uint8_t*>(gtiles)[(size_t)(d - NT_LDS) * 64 + boff];
+  return v;
 }
 
 // one grid cell through the directory, any tile location, with the reference's isInside test (generic path)
@@ -279,8 +303,7 @@ __device__ __forceinline__ int grid_cell(const Smem& S, const MatchParams& P, co
   int d = S.dir[((cx >> 3) + 1) * DW + (cy >> 3) + 3];
   if (d == 0xFFFF) return P.fill;
   int boff = (cx & 7) * 8 + (cy & 7);
-  if (d < NT_LDS) return reinterpret_cast<const uint8_t*>(S.tiles)[d * 64 + boff];
-  return reinterpret_cast<const uint8_t*>(gtiles)[(size_t)(d - NT_LDS) * 64 + boff];
+  return tile_byte(S, gtiles, d, boff);
 }
 
 }  // namespace
@@ -309,7 +332,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
   const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
   // directory with a guard band (1 tile row above/below, 3 tile columns left/right) so that the fast search
   // path can look up cells outside the grid without a bounds test: guard entries point at the all-zero tile
-  const int DW = nty + 6;
+  const int DW = nty + kMatchDirGuardY;
   const int ndir = (ntx + 2) * DW;
 #define DIRIDX(tx, ty) (((tx) + 1) * DW + (ty) + 3)
   const int K2 = P.fill;
@@ -446,7 +469,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
     // a scan with more subsampled points than one list holds: half the wavefronts search, with two lists each
-    const bool wide = nq > LISTCAP - PT;
+    const bool wide = nq > LISTCAP - 2 * PT;
     const int nsearch = wide ? NTH / 2 : NTH;
     uint32_t* const pl = &S.plist[0][0] + (wide ? 2 * wave : wave) * LISTCAP;
     MPHASE(6);
@@ -479,49 +502,52 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
           prev = __shfl(packed, lastv, 64);
           have_prev = true;
         }
-        if (lane < PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
+        if (lane < 2 * PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
       }
       __builtin_amdgcn_wave_barrier();
       if (ti < nth && fast) {
-        // ---- fast path: lane = (x-row a, segment of 12 consecutive y offsets) ----
-        const int nseg = (nj + 11) / 12;
+        // ---- fast path: lane = (half h of the wavefront, x-row a, segment of 24 consecutive y offsets).
+        // Both halves work on the same 32 (row, segment) jobs; half h takes points 8i+4h .. 8i+4h+3 of the list,
+        // the two partial sums are added at the end.  Per point a lane fetches the 4 tile rows that hold its
+        // 24 (+7 alignment) cells and adds them as packed bytes.
+        const int nseg = (nj + 23) / 24;
         const int njobs = ni * nseg;
-        const int flush_every = 255 / K2;                 // packed-byte partial sums cannot overflow before this
+        const int half = lane >> 5, jl = lane & 31;
+        const int flush_iters = max(1, (255 / K2) / PT);  // packed-byte partial sums cannot overflow before this
         const uint8_t* tb = reinterpret_cast<const uint8_t*>(S.tiles);
-        for (int job = lane; job < njobs; job += 64) {
+        const int cxhi = P.nx + 7, cyhi = P.ny;              // lower clamps: -8 and -24 (guard band)
+        for (int j0 = 0; j0 < njobs; j0 += 32) {
+          const int job = min(j0 + jl, njobs - 1);          // surplus lanes repeat the last job and stay silent
           const int a = job / nseg, seg = job - a * nseg;
-          const int b0 = seg * 12;
-          const int ncell = min(12, nj - b0);
+          const int b0 = seg * 24;
+          const int ncell = min(24, nj - b0);
           const int offx = lo_x + a, offy = lo_y + b0;
-          uint32_t part0 = 0, part1 = 0, part2 = 0;
-          int acc[12];
+          uint32_t part[6];
+          int acc[24];
 #pragma unroll
-          for (int c = 0; c < 12; c++) acc[c] = 0;
+          for (int c = 0; c < 6; c++) part[c] = 0;
+#pragma unroll
+          for (int c = 0; c < 24; c++) acc[c] = 0;
           int npart = 0;
-          const uint32_t m2 = ncell >= 12 ? 0xffffffffu : (ncell <= 8 ? 0u : (0xffffffffu >> (8 * (12 - ncell))));
-          const uint32_t m1 = ncell >= 8 ? 0xffffffffu : (ncell <= 4 ? 0u : (0xffffffffu >> (8 * (8 - ncell))));
-          const uint32_t m0 = ncell >= 4 ? 0xffffffffu : (0xffffffffu >> (8 * (4 - ncell)));
-          const int flush_iters = max(1, flush_every / PT);
-          const int cxlo = -8, cxhi = P.nx + 7, cylo = -24, cyhi = P.ny;
-          for (int q = 0; q < k; q += PT) {
+          for (int q = 4 * half; q < k; q += 2 * PT) {
             const uint4 pk4 = *reinterpret_cast<const uint4*>(&pl[q]);
             const uint32_t pk[PT] = {pk4.x, pk4.y, pk4.z, pk4.w};
-            int d[PT][3], rowoff[PT], o[PT];
+            int d[PT][4], rowoff[PT], o[PT];
 #pragma unroll
             for (int u = 0; u < PT; u++) {
               // clamp into the guard band: anything beyond it reads the all-zero tile anyway
-              const int cx = min(max((int)(int16_t)(pk[u] & 0xffff) + offx, cxlo), cxhi);
-              const int cy0 = min(max((int)(int16_t)(pk[u] >> 16) + offy, cylo), cyhi);
-              const uint16_t* dp = &S.dir[((cx >> 3) + 1) * DW + (cy0 >> 3) + 3];
-              d[u][0] = dp[0]; d[u][1] = dp[1]; d[u][2] = dp[2];
+              const int cx = clamp_med3<-8>((int)(int16_t)(pk[u] & 0xffff) + offx, cxhi);
+              const int cy0 = clamp_med3<-24>((int)(int16_t)(pk[u] >> 16) + offy, cyhi);
+              const lds_vu16* dp = (const lds_vu16*)&S.dir[__mul24(cx >> 3, DW) + (cy0 >> 3) + DW + 3];
+              d[u][0] = dp[0]; d[u][1] = dp[1]; d[u][2] = dp[2]; d[u][3] = dp[3];   // 2-byte loads: no unaligned LDS access
               o[u] = cy0 & 7;
               rowoff[u] = (cx & 7) * 8;
             }
-            uint32_t D[PT][6];
+            uint32_t D[PT][8];
 #pragma unroll
             for (int u = 0; u < PT; u++)
 #pragma unroll
-              for (int t = 0; t < 3; t++) {
+              for (int t = 0; t < 4; t++) {
                 const uint2 w = *reinterpret_cast<const uint2*>(tb + d[u][t] * 64 + rowoff[u]);
                 D[u][2 * t] = w.x;
                 D[u][2 * t + 1] = w.y;
@@ -529,44 +555,52 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 #pragma unroll
             for (int u = 0; u < PT; u++) {
               const bool hi = o[u] >= 4;
-              const uint32_t E0 = hi ? D[u][1] : D[u][0], E1 = hi ? D[u][2] : D[u][1], E2 = hi ? D[u][3] : D[u][2],
-                             E3 = hi ? D[u][4] : D[u][3];
+              uint32_t E[7];
+#pragma unroll
+              for (int t = 0; t < 7; t++) E[t] = hi ? D[u][t + 1] : D[u][t];
               const uint32_t sh = (uint32_t)(o[u] & 3);
-              part0 += __builtin_amdgcn_alignbyte(E1, E0, sh) & m0;
-              part1 += __builtin_amdgcn_alignbyte(E2, E1, sh) & m1;
-              part2 += __builtin_amdgcn_alignbyte(E3, E2, sh) & m2;
+#pragma unroll
+              for (int t = 0; t < 6; t++) part[t] += __builtin_amdgcn_alignbyte(E[t + 1], E[t], sh);
             }
             if (++npart == flush_iters) {
 #pragma unroll
-              for (int c = 0; c < 4; c++) {
-                acc[c] += (part0 >> (8 * c)) & 0xff;
-                acc[4 + c] += (part1 >> (8 * c)) & 0xff;
-                acc[8 + c] += (part2 >> (8 * c)) & 0xff;
+              for (int t = 0; t < 6; t++) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[4 * t + c] += (part[t] >> (8 * c)) & 0xff;
+                part[t] = 0;
               }
-              part0 = part1 = part2 = 0;
               npart = 0;
             }
           }
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
-            acc[c] += (part0 >> (8 * c)) & 0xff;
-            acc[4 + c] += (part1 >> (8 * c)) & 0xff;
-            acc[8 + c] += (part2 >> (8 * c)) & 0xff;
-          }
+          for (int t = 0; t < 6; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[4 * t + c] += (part[t] >> (8 * c)) & 0xff;
+          // add the other half's partial sums; afterwards half h reports cells 12h .. 12h+11 of the segment
+          int tot[12];
 #pragma unroll
           for (int c = 0; c < 12; c++) {
-            if (c >= ncell) continue;
-            const int cidx = a * nj + b0 + c;
-            float dsum = (float)acc[c] * ikscale;
-            dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
-            if ((double)dsum < P.max_score) {
-              float wx = P.ll_x + (P.res * (float)offx);
-              float wyy = P.ll_y + (P.res * (float)(offy + c));
-              int bx = (int)((double)wx / P.dx) - bx0, by = (int)((double)wyy / P.dy) - by0;
-              int bt = (int)(S.theta[ti] / P.dth) - bt0;
-              unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
-                                       (unsigned long long)(unsigned)(ti * ncand + cidx);
-              atomicMin(&S.bins[(bx * nby + by) * nbt + bt], key);
+            const int mine = half ? acc[c] : acc[12 + c];          // what the other half reports
+            const int theirs = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, mine);
+            tot[c] = (half ? acc[12 + c] : acc[c]) + theirs;
+          }
+          if (j0 + jl < njobs) {
+#pragma unroll
+            for (int c = 0; c < 12; c++) {
+              const int cc = 12 * half + c;
+              if (cc >= ncell) continue;
+              const int cidx = a * nj + b0 + cc;
+              float dsum = (float)tot[c] * ikscale;
+              dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
+              if ((double)dsum < P.max_score) {
+                float wx = P.ll_x + (P.res * (float)offx);
+                float wyy = P.ll_y + (P.res * (float)(offy + cc));
+                int bx = (int)((double)wx / P.dx) - bx0, by = (int)((double)wyy / P.dy) - by0;
+                int bt = (int)(S.theta[ti] / P.dth) - bt0;
+                unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
+                                         (unsigned long long)(unsigned)(ti * ncand + cidx);
+                atomicMin(&S.bins[(bx * nby + by) * nbt + bt], key);
+              }
             }
           }
         }
@@ -592,8 +626,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
                 int v = K2;
                 if (d != 0xFFFF) {
                   int boff = (cx & 7) * 8 + (cy & 7);
-                  if (d < NT_LDS) v = reinterpret_cast<const uint8_t*>(S.tiles)[d * 64 + boff];
-                  else v = reinterpret_cast<const uint8_t*>(gtiles)[(size_t)(d - NT_LDS) * 64 + boff];
+                  v = tile_byte(S, gtiles, d, boff);
                 }
                 sum[u] += v;
               }
@@ -676,7 +709,7 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
   uint32_t* rcell = reinterpret_cast<uint32_t*>(my);                               // kMatchMaxRef packed cells
   uint32_t* gtiles = rcell + kMatchMaxRef;
   const int nty = (P.ny + 7) >> 3;
-  const int DW = nty + 6;
+  const int DW = nty + kMatchDirGuardY;
   for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
   for (int i = tid; i < P.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
   __syncthreads();
@@ -779,7 +812,7 @@ __global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const doubl
   uint32_t* rcell = reinterpret_cast<uint32_t*>(scratch);            // kMatchMaxRef packed cells
   uint32_t* rcell2 = rcell + kMatchMaxRef;                           // cells of the unexplained points
   uint32_t* gtiles = rcell2 + kMatchMaxRef;
-  const int DW = ((P.ny + 7) >> 3) + 6;
+  const int DW = ((P.ny + 7) >> 3) + kMatchDirGuardY;
   for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
   for (int i = tid; i < P.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, pts2[2 * i], pts2[2 * i + 1]);
   __syncthreads();
