@@ -109,6 +109,7 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const 
   }
   memcpy(ctx->pinned + o_kern, kern.data(), kern.size());
   memset(ctx->pinned + o_err, 0, 16);
+  ((int*)(ctx->pinned + o_err))[1] = nblocks;     // work counter: the first nblocks pairs are taken by blockIdx
   char* d = ctx->mt_arena.ptr;
   HIP_TRY(ctx, hipMemcpyAsync(d, ctx->pinned, hbytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));

@@ -9,7 +9,7 @@ namespace cgmr {
 constexpr int kMatchMaxPoints = 1088;        // beams per scan (1081 for the reference's laser), multiple of 64
 constexpr int kMatchDirGuardY = 7;           // directory guard band along y: 3 tile columns below, 4 above
 constexpr int kMatchMaxDir = 152 * 157;      // 8x8-cell tiles of the largest grid (1200 x 1200 cells) + guard band
-constexpr int kMatchTilesLds = 1136;         // tiles resident in LDS; the rest spills to HBM
+constexpr int kMatchTilesLds = 1408;         // tiles resident in LDS; the rest spills to HBM
 constexpr int kMatchMaxTheta = 80;           // search angles per region
 
 struct MatchParams {

@@ -120,19 +120,21 @@ constexpr int GR_WAVES = 4;                  // wavefronts of the generic kernel
 constexpr int LISTCAP = 704;                 // kept points per angle on the fast path (more -> generic path)
 constexpr int PT = 4;                        // points gathered per inner iteration of the fast search path
 constexpr int CAND_U = 9;                    // candidates per lane per block (64*9 = 576 = 24x24)
-constexpr int MAXBINS = 512;
+constexpr int MAXBINS = 128;                  // close matching: 0.6 m / 0.5 m bins x 0.4 rad / 0.2 rad -> at most 27
 constexpr int MAXTHETA = kMatchMaxTheta;
 
 struct Smem {
   uint32_t tiles[NT_LDS * 16];               // 64-byte tiles, cell (x&7, y&7) at byte (x&7)*8 + (y&7)   (16-B aligned)
   uint32_t plist[NTH][LISTCAP];              // per-angle point lists: int16 x | int16 y << 16           (16-B aligned)
   unsigned long long bins[MAXBINS];          // (score bits << 32 | visit order), min = best, first seen
-  double theta[MAXTHETA], cs[MAXTHETA], sn[MAXTHETA];
+  double theta[MAXTHETA];
   uint8_t kernel[1024];
-  int scan[516];
   int misc[16];
   uint16_t dir[kMatchMaxDir];                // tile directory: 0xFFFF = untouched (all cells = fill)
 };
+// block_scan_excl scratch (one int per thread + total): the last point list, idle whenever a scan runs
+__device__ __forceinline__ int* scan_scratch(Smem& S) { return reinterpret_cast<int*>(S.plist[NTH - 1]); }
+static_assert(LISTCAP >= 516, "scan scratch needs 516 ints");
 static_assert(sizeof(Smem) <= 160 * 1024, "matcher LDS plan exceeds 160 KiB");
 
 #ifdef CGMR_PHASE_TIMING
@@ -234,7 +236,7 @@ __device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell,
     int cnt = 0;
     for (int q = b0; q < b1; q++) cnt += S.dir[q];
     int ntile;
-    int base = block_scan_excl(cnt, S.scan, &ntile);
+    int base = block_scan_excl(cnt, scan_scratch(S), &ntile);
     // fast path: every tile (plus an all-fill and an all-zero tile) is resident in LDS and the grid is a
     // whole number of tiles, so the search can gather without branches: untouched directory entries
     // point at the all-fill tile, cells outside the grid are redirected to the all-zero tile.
@@ -339,7 +341,9 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
   const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
   for (int q = tid; q < P.kdim * P.kdim; q += CB_THREADS) S.kernel[q] = kernel_lut[q];
 
-  for (int pair = blockIdx.x; pair < P.n_pairs; pair += gridDim.x) {
+  // pairs are handed out through a counter (err[1], starts at gridDim.x): a slow pair (generic path) does not
+  // hold up the pairs a static stride would have queued behind it
+  for (int pair = blockIdx.x; pair < P.n_pairs;) {
     __syncthreads();
     MPHASE(0);
     // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       nlead += lead ? 1 : 0;
     }
     int nq;
-    int rank = block_scan_excl(nlead, S.scan, &nq);
+    int rank = block_scan_excl(nlead, scan_scratch(S), &nq);
     {
       const double lc = P.lp_c, ls = P.lp_s, ltx = P.lp_x, lty = P.lp_y;
 #pragma unroll
@@ -460,11 +464,6 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     const int bx0 = S.misc[6], by0 = S.misc[7], bt0 = S.misc[8], nbx = S.misc[9], nby = S.misc[10], nbt = S.misc[11];
     const int nbins = nbx * nby * nbt;
     for (int q = tid; q < nbins; q += CB_THREADS) S.bins[q] = ~0ULL;
-    for (int q = tid; q < nth; q += CB_THREADS) {
-      double s, c;
-      portable_sincos(S.theta[q], &s, &c);
-      S.sn[q] = s; S.cs[q] = c;
-    }
     __syncthreads();
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
@@ -478,7 +477,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       const int ti = (wave < nsearch) ? tb + wave : nth;
       int k = 0;
       if (ti < nth) {
-        const double c = S.cs[ti], s = S.sn[ti];
+        double c, s;
+        portable_sincos(S.theta[ti], &s, &c);
         uint32_t prev = 0x7fff7fffu;       // (-10000,-10000) can never match: use an impossible packed value
         bool have_prev = false;
         for (int base = 0; base < nq; base += 64) {
@@ -683,6 +683,10 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       }
     }
     MPHASE(8);
+    __syncthreads();
+    if (tid == 0) S.misc[13] = atomicAdd(err + 1, 1);
+    __syncthreads();
+    pair = S.misc[13];
   }
 }
 
@@ -833,7 +837,7 @@ __global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const doubl
       }
     }
     int total;
-    int pos = block_scan_excl(keep, S.scan, &total);
+    int pos = block_scan_excl(keep, scan_scratch(S), &total);
     if (keep) rcell2[base + pos] = packed;
     base += total;
   }
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const doubl
     isum += grid_cell(S, P, gtiles, DW, lo_x + a, lo_y + b);
   }
   int total;
-  block_scan_excl(isum, S.scan, &total);
+  block_scan_excl(isum, scan_scratch(S), &total);
   if (tid == 0) {
     int visited = (hi_x - lo_x) * (hi_y - lo_y);
     *score_out = (double)((float)total / (float)visited);
