@@ -74,7 +74,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.nlevels = (int)S.level_ptr.size() - 1;
   D.h_level_ptr = S.level_ptr;
   // update tiles per level
-  std::vector<int32_t> tiles, work;
+  std::vector<int32_t> tiles;
+  std::vector<WorkRec> work;
   D.h_tile_ptr.assign(D.nlevels + 1, 0);
   D.h_work_ptr.assign(D.nlevels + 1, 0);
   for (int l = 0; l < D.nlevels; l++) {
@@ -82,14 +83,35 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
       int f = S.level_fronts[q];
       int r = 3 * S.fronts[f].ns;
       int nchunk = std::max(1, (r + kChunkRows - 1) / kChunkRows);
-      for (int c = 0; c < nchunk; c++) { work.push_back(f); work.push_back(c); }
+      for (int c = 0; c < nchunk; c++) {
+        WorkRec wr;
+        memset(&wr, 0, sizeof wr);
+        wr.F = S.fronts[f];
+        wr.front = f;
+        wr.chunk = c;
+        for (int k = 0; k < std::min<int>(wr.F.nchild, kWorkChildren); k++) {
+          const FrontDesc& G = S.fronts[S.children[wr.F.child_off + k]];
+          WorkChild& wc = wr.ch[k];
+          wc.U_off = G.U_off; wc.ns = G.ns; wc.na = G.na;
+          wc.rel_off = G.rel_off; wc.inv_off = G.inv_off; wc.rows_off = G.rows_off;
+        }
+        work.push_back(wr);
+      }
       if (r <= kFuseRows) continue;          // update matrix formed inside k_front_factor
       int T = (r + 31) / 32;
       for (int ti = 0; ti < T; ti++)
         for (int tj = 0; tj <= ti; tj++) { tiles.push_back(f); tiles.push_back(ti); tiles.push_back(tj); }
     }
     D.h_tile_ptr[l + 1] = (int)tiles.size() / 3;
-    D.h_work_ptr[l + 1] = (int)work.size() / 2;
+    D.h_work_ptr[l + 1] = (int)work.size();
+  }
+  // H blocks are stored in the order their fronts assemble them (alist order): k_assemble writes block b to
+  // slot blk_slot[b]; apack[slot] = local row block | local column block << 16
+  const size_t nblk = S.alist.size() / 3;
+  std::vector<int32_t> apack(nblk), blk_slot(nblk);
+  for (size_t q = 0; q < nblk; q++) {
+    apack[q] = S.alist[3 * q + 1] | (S.alist[3 * q + 2] << 16);
+    blk_slot[S.alist[3 * q]] = (int32_t)q;
   }
   BlobLayout B;
   size_t o_fronts = B.add<FrontDesc>(S.fronts.size());
@@ -97,10 +119,11 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_children = B.add<int32_t>(S.children.size());
   size_t o_rel = B.add<int32_t>(S.rel.size());
   size_t o_inv = B.add<int32_t>(S.inv.size());
-  size_t o_alist = B.add<int32_t>(S.alist.size());
+  size_t o_apack = B.add<int32_t>(nblk);
+  size_t o_slot = B.add<int32_t>(nblk);
   size_t o_lf = B.add<int32_t>(S.level_fronts.size());
   size_t o_tiles = B.add<int32_t>(tiles.size());
-  size_t o_work = B.add<int32_t>(work.size());
+  size_t o_work = B.add<WorkRec>(work.size());
   size_t o_asmp = B.add<int32_t>(S.asm_ptr.size());
   size_t o_asms = B.add<int32_t>(S.asm_src.size());
   size_t o_vperm = B.add<int32_t>(S.vperm.size());
@@ -132,10 +155,11 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   put(o_children, S.children.data(), S.children.size() * 4);
   put(o_rel, S.rel.data(), S.rel.size() * 4);
   put(o_inv, S.inv.data(), S.inv.size() * 4);
-  put(o_alist, S.alist.data(), S.alist.size() * 4);
+  put(o_apack, apack.data(), nblk * 4);
+  put(o_slot, blk_slot.data(), nblk * 4);
   put(o_lf, S.level_fronts.data(), S.level_fronts.size() * 4);
   put(o_tiles, tiles.data(), tiles.size() * 4);
-  put(o_work, work.data(), work.size() * 4);
+  put(o_work, work.data(), work.size() * sizeof(WorkRec));
   put(o_asmp, S.asm_ptr.data(), S.asm_ptr.size() * 4);
   put(o_asms, S.asm_src.data(), S.asm_src.size() * 4);
   put(o_vperm, S.vperm.data(), S.vperm.size() * 4);
@@ -148,10 +172,11 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.children = (int32_t*)(d + o_children);
   D.rel = (int32_t*)(d + o_rel);
   D.inv = (int32_t*)(d + o_inv);
-  D.alist = (int32_t*)(d + o_alist);
+  D.apack = (int32_t*)(d + o_apack);
+  D.blk_slot = (int32_t*)(d + o_slot);
   D.level_fronts = (int32_t*)(d + o_lf);
   D.tiles = (int32_t*)(d + o_tiles);
-  D.work = (int32_t*)(d + o_work);
+  D.work = (WorkRec*)(d + o_work);
   D.asm_ptr = (int32_t*)(d + o_asmp);
   D.asm_src = (int32_t*)(d + o_asms);
   D.vperm = (int32_t*)(d + o_vperm);
@@ -189,7 +214,7 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
 
 // one Gauss-Newton pass on the uploaded structure: linearise + chi2 [+ assemble + factor [+ solve + update]]
 void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double* d_info, int it, bool chi_only,
-             bool solve_and_update) {
+             bool solve_and_update, bool write_l11c = false) {
   GnDevice& D = ctx->gn;
   hipStream_t st = ctx->stream;
   KTimer T{ctx};
@@ -198,7 +223,7 @@ void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double*
   if (chi_only || D.nf == 0) return;
   T.run(1, 1, [&] { launch_assemble(st, D); });
   for (int l = 0; l < D.nlevels; l++) {
-    T.run(3, 1, [&] { launch_factor_level(st, D, l, it + 1); });
+    T.run(3, 1, [&] { launch_factor_level(st, D, l, it + 1, write_l11c); });
     if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
   }
   if (!solve_and_update) return;
@@ -339,7 +364,7 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   double* dp = (double*)(d + o_p);
   // the Hessian of this iteration (linearised at the initial guess) is what computeMarginals sees [g2o-recalled];
   // for the condensed graph the iteration is completed first: the factor stays valid, the poses move on
-  gn_pass(ctx, dp, (const double*)(d + o_m), (const double*)(d + o_i), 0, false, mode == 2);
+  gn_pass(ctx, dp, (const double*)(d + o_m), (const double*)(d + o_i), 0, false, mode == 2, /*write_l11c=*/true);
   launch_marginals(st, D, nq, (const int32_t*)(d + o_qc), m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part),
                    (double*)(d + o_G), (double*)(d + o_cov), chunk, nchunk);
   if (mode == 2)
@@ -452,7 +477,7 @@ int cgmr_gn_optimize(cgmr_ctx* ctx, int nV, double* poses, const uint8_t* fixed,
 }
 
 int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx, const int32_t* to_idx,
-                          int64_t out[10], int32_t* perm_out) {
+                          int64_t out[12], int32_t* perm_out) {
   if (nV < 0 || nE < 0 || !out) return CGMR_E_INVALID;
   Symbolic S;
   int rc = analyze(nV, fixed, nE, from_idx, to_idx, S);
@@ -460,6 +485,11 @@ int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* f
   out[0] = S.nf; out[1] = S.nb; out[2] = (int64_t)S.fronts.size(); out[3] = (int64_t)S.level_ptr.size() - 1;
   out[4] = S.L_doubles; out[5] = S.U_doubles; out[6] = S.max_ns; out[7] = (int64_t)S.flops;
   out[8] = (int64_t)(1e6 * S.t_order); out[9] = (int64_t)(1e6 * S.t_struct);
+  out[10] = out[11] = 0;
+  for (const FrontDesc& F : S.fronts) {
+    out[10] = std::max<int64_t>(out[10], F.nchild);
+    if (F.ns >= 1 && F.ns <= 32) out[11] = std::max<int64_t>(out[11], F.nchild);
+  }
   if (perm_out) memcpy(perm_out, S.vperm.data(), sizeof(int32_t) * nV);
   return CGMR_OK;
 }

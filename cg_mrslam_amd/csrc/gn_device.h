@@ -14,8 +14,9 @@ struct GnDevice {
   int nV = 0, nE = 0, nf = 0, nb = 0, nlevels = 0, nfronts = 0;
   // structure (uploaded once per analyse)
   FrontDesc* fronts = nullptr;
-  int32_t *rows = nullptr, *children = nullptr, *rel = nullptr, *inv = nullptr, *alist = nullptr;
-  int32_t *level_fronts = nullptr, *tiles = nullptr, *work = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;
+  int32_t *rows = nullptr, *children = nullptr, *rel = nullptr, *inv = nullptr;
+  WorkRec* work = nullptr;          // (front, chunk) work items of k_front_factor, level by level
+  int32_t *level_fronts = nullptr, *tiles = nullptr, *apack = nullptr, *blk_slot = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;
   int32_t *ef = nullptr, *et = nullptr;
   // numeric work space
   double *term = nullptr, *Ablk = nullptr, *bvec = nullptr, *yvec = nullptr, *xvec = nullptr, *uvec = nullptr;
@@ -30,9 +31,8 @@ void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, co
                       const double* meas, const double* info, int chi_only);
 void launch_chi2(hipStream_t st, const GnDevice& D, double* out);
 void launch_assemble(hipStream_t st, const GnDevice& D);
-void launch_factor_level(hipStream_t st, const GnDevice& D, int level, int iter_tag);
+void launch_factor_level(hipStream_t st, const GnDevice& D, int level, int iter_tag, bool write_l11c);
 void launch_update_level(hipStream_t st, const GnDevice& D, int level);
-void launch_fwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);
 // marginals_kernels.hip

@@ -5,7 +5,8 @@
 // SURVEY.md 3.2 / Appendix A [g2o-recalled]):
 //   computeActiveErrors + BlockSolver::buildSystem  -> k_linearize, k_assemble
 //   LinearSolverCSparse::solve (Cholesky + 2 solves) -> k_front_factor, k_front_update,
-//                                                       k_solve_fwd, k_solve_bwd
+//                                                       k_solve_bwd (the forward solve rides through
+//                                                       k_front_factor as an extra row of every front)
 //   SparseOptimizer::update (VertexSE2::oplusImpl)   -> k_update_poses
 //
 // Design ("GN kernels"): the factorisation is a supernodal multifrontal Cholesky.
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, const double* __restr
 // list of contributing edge terms in a fixed order (deterministic sums).
 __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const int32_t* __restrict__ asm_ptr,
                                                   const int32_t* __restrict__ asm_src,
+                                                  const int32_t* __restrict__ blk_slot,
                                                   const double* __restrict__ term, double* __restrict__ Ablk,
                                                   double* __restrict__ bvec) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
       int comp = code == 0 ? el : code == 1 ? 18 + el : code == 2 ? 9 + el : 9 + elT;
       acc += term[(size_t)comp * E + edge];
     }
-    Ablk[t] = acc;
+    Ablk[(size_t)blk_slot[blk] * 9 + el] = acc;      // stored in the order the owning front assembles its blocks
     return;
   }
   t -= nblk * 9;
@@ -189,174 +191,339 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 
-constexpr int MAXC = 8;              // children whose maps are staged together
+constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record / whose maps are staged together
+constexpr int kRecInts = (int)(sizeof(WorkRec) / 4);
+constexpr int TRI_U = 19;            // trailing-block cells per thread and child (lower triangle of 96 x 96 over 256 threads)
+constexpr int MAPW = 256;            // child rows per staged block of the row map (one per thread)
+constexpr int SU = 24;               // double2 loads per thread and block: 256 rows x 48 columns of a child's leading slab
+// Update matrix of a front with r border rows, the first ra of which fall into its parent's own columns
+// (Ubuf + U_off, U_off even):
+//   slab A  [r][ra2]       columns 0..ra-1 of every row (rows < ra: lower triangle valid),
+//                          row stride ra2 = ra rounded up to even                           -> parent's F11 / F21
+//   slab B  [r-ra][r-ra]   the trailing block, lower triangle valid                          -> parent's update matrix
+// Both are read front to back by the parent: contiguous 16-byte loads instead of a gather.
+__device__ __forceinline__ int even_up(int v) { return (v + 1) & ~1; }
+__device__ __forceinline__ size_t uidx(int gi, int gj, int r, int ra) {
+  const int ra2 = even_up(ra);      // row stride of slab A: rows start on 16-byte boundaries
+  return gj < ra ? (size_t)gi * ra2 + gj : (size_t)r * ra2 + (size_t)(gi - ra) * (r - ra) + (gj - ra);
+}
 // LDS plan of k_front_factor (bytes), one workgroup per CU:
-//   R    [CH][LDW] doubles   chunk of F21 (assembly), later L21 rows for the fused update
-//   Ls   [W][LDW]  doubles   F11 (assembly)                      \  reused as Uacc[FUSE_R][FUSE_R+1]
-//   pad                                                          /  by the fused update (phase D)
-//   lists: s_pos[FUSE_R+W] shorts (phase D), s_colinv[MAXC][W], s_src[MAXC][CH] shorts (phase A)
-//   Dinv [W], Pan[2][W][8] doubles: the published 8-column panel of L11 (double buffered)
-constexpr int kOffR = 0;
-constexpr int kOffLs = kOffR + CH * LDW * 8;
+//   Ls   [W][LDW]  doubles   F11 (assembly), later the staging buffer of L11 for coalesced copies
+//   R    [CH][LDW] doubles   chunk of F21 + the rhs row (assembly), later L21 rows for the fused update
+//   Uacc [FUSE_R][FUSE_R+1]  extend-add accumulator of the fused update; starts behind row FUSE_R of R
+//                            (only fronts with r <= FUSE_R use it, and those use rows 0..FUSE_R of R only)
+//   maps: s_rmap[MAXC][MAPW] (child row -> position in my row list), s_cmap[MAXC][W] shorts; the work record
+//   Dinv [W], Pan[2][W][8] doubles: the published 8-column panel of L11 (double buffered), Ys[W]
+constexpr int kOffLs = 0;
+constexpr int kOffR = kOffLs + W * LDW * 8;
+constexpr int kOffUacc = kOffR + (FUSE_R + 1) * LDW * 8;
 constexpr int kUaccBytes = FUSE_R * (FUSE_R + 1) * 8;
-constexpr int kOffLists = kOffLs + (kUaccBytes > W * LDW * 8 ? kUaccBytes : W * LDW * 8);
-constexpr int kOffColinv = kOffLists + 2 * (W + FUSE_R);
-constexpr int kOffSrc = kOffColinv + 2 * MAXC * W;
-constexpr int kOffDinv = ((kOffSrc + 2 * MAXC * CH + 15) / 16) * 16;
+constexpr int kEndR = kOffR + CH * LDW * 8;
+constexpr int kOffRmap = (kEndR > kOffUacc + kUaccBytes) ? kEndR : (kOffUacc + kUaccBytes);
+constexpr int kOffCmap = kOffRmap + 2 * MAXC * MAPW;
+constexpr int kOffRec = ((kOffCmap + 2 * MAXC * W + 15) / 16) * 16;
+constexpr int kOffDinv = ((kOffRec + 4 * kRecInts + 15) / 16) * 16;
 constexpr int kOffPan = kOffDinv + W * 8;
 constexpr int kOffYs = kOffPan + 2 * W * 8 * 8;
 constexpr int kSmemBytes = kOffYs + W * 8;
 static_assert(kSmemBytes <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
+static_assert(kOffR == kOffLs + W * LDW * 8, "slab_scatter addresses R through Ls");
 
-// One workgroup per (front, chunk of CH border rows) of the current level:
-//   A. all threads assemble F11 (own columns, zero/identity padded to 48x48) and this chunk's
-//      rows of F21 in LDS from the H blocks and the children's update matrices.  For each
-//      child a (source row -> destination row) list is staged in LDS first, so the update
-//      matrix is then read as independent, coalesced row segments (8 loads in flight per lane);
-//   B. wavefront 0 factorises F11 = L11 L11^T entirely in registers (lane i owns row i; the
-//      pivot column is broadcast with v_readlane, no barriers).  A non-positive pivot
-//      records the GN iteration in *status (first failure wins); the pose update kernel
-//      then leaves the poses alone, which is g2o's "return on Cholesky failure";
-//   C. L21 = F21 L11^-T, one thread per border row held in registers, right-looking with the
-//      next pivot column prefetched from LDS while the current one is applied;
-//   D. small fronts (r <= FUSE_R) also form their update matrix U = ext_add - L21 L21^T:
-//      the children's trailing blocks are streamed into an LDS accumulator, then 4x4 register
-//      tiles subtract L21 L21^T and store.
-__global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restrict__ fronts,
-                                                         const int32_t* __restrict__ work, int work_begin,
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long rfl64(long long v) {
+  return ((long long)rfl((int)(v >> 32)) << 32) | (unsigned)rfl((int)v);
+}
+
+// LDS += without a return value: one ds_add_f64, nothing to wait for.  The cells written by one call site never
+// collide (see slab_scatter), so this is not used for atomicity but because plain read-modify-writes through
+// possibly aliasing pointers are serialised by the compiler (one LDS round trip per element).
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __builtin_amdgcn_ds_atomic_fadd_f64((lds_double*)p, v);
+}
+
+// One block of a child's leading slab plus the matching piece of its border vector, as loaded by one thread.
+// Thread = (column pair cp, row lane rr): it owns columns 2cp, 2cp+1 of rows rr, rr + rpp, rr + 2 rpp, ... of the
+// block, so one column-map lookup and one row-map lookup per load.  Everything is issued by slab_issue() before
+// slab_scatter() touches any of it.
+struct SlabLoads {
+  double2 v[SU];
+  double u;
+};
+struct SlabGeom {
+  int cpw, rpp, rr, cp, rows;         // column pairs per row, rows per pass, my row lane / column pair, rows per block
+};
+__device__ __forceinline__ SlabGeom slab_geom(int tid, int ra) {
+  SlabGeom g;
+  g.cpw = max((ra + 1) >> 1, 1);
+  g.rpp = 256 / g.cpw;
+  g.rr = tid / g.cpw;
+  g.cp = tid - g.rr * g.cpw;
+  g.rows = min(MAPW, g.rpp * SU);
+  return g;
+}
+
+__device__ __forceinline__ void slab_issue(SlabLoads& S, const SlabGeom& g, int tid, const double* __restrict__ U,
+                                           const double* __restrict__ uc, int rg, int ra2, int row0) {
+  const int rend = min(rg, row0 + g.rows);
+#pragma unroll
+  for (int u = 0; u < SU; u++) {
+    const int row = row0 + g.rr + g.rpp * u;
+    const bool ok = g.rr < g.rpp && row < rend;
+    S.v[u] = *reinterpret_cast<const double2*>(U + (ok ? (size_t)row * ra2 + 2 * g.cp : 0));   // idle lanes re-read element 0
+  }
+  S.u = uc[min(row0 + tid, rg - 1)];
+}
+
+// Add the block into F11 (Ls), this chunk's F21 rows and rhs row / border-vector column (R, which directly
+// follows Ls in LDS: one index space, R row p at W + p).  rmap[k] = position of child row row0 + k in my row list
+// (0..w-1 own columns, w.. border), cmap = the same map for rows 0..ra-1.  A child never sends two elements to the
+// same cell, so the adds of one call do not collide; calls for different children are separated by a barrier.
+__device__ __forceinline__ void slab_scatter(const SlabLoads& S, const SlabGeom& g, int tid, int rg, int ra, int row0,
+                                             const short* rmap, const short* cmap, int w, int r0, int nr, double* Ls) {
+  const int rend = min(rg, row0 + g.rows);
+  // every map lookup first ...
+  int prow[SU];
+#pragma unroll
+  for (int u = 0; u < SU; u++) prow[u] = rmap[min(g.rr + g.rpp * u, g.rows - 1)];
+  const int col0 = 2 * g.cp, col1 = 2 * g.cp + 1;
+  const int pc0 = cmap[min(col0, max(ra - 1, 0))], pc1 = cmap[min(col1, max(ra - 1, 0))];
+  const int prowu = rmap[min(tid, g.rows - 1)];
+  // ... then the targets, then the adds
+  int dst[SU];
+#pragma unroll
+  for (int u = 0; u < SU; u++) {
+    const int row = row0 + g.rr + g.rpp * u;
+    const bool ok = g.rr < g.rpp && row < rend;
+    const int pr = prow[u] - w - r0;
+    dst[u] = !ok ? -1 : prow[u] < w ? prow[u] * LDW : (pr >= 0 && pr < nr) ? (W + pr) * LDW : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < SU; u++) {
+    const int row = row0 + g.rr + g.rpp * u;
+    if (dst[u] < 0) continue;
+    // rows of the leading block (row < ra) hold their lower triangle only
+    if (col0 < ra && (row >= ra || col0 <= row)) lds_add(Ls + dst[u] + pc0, S.v[u].x);
+    if (col1 < ra && (row >= ra || col1 <= row)) lds_add(Ls + dst[u] + pc1, S.v[u].y);
+  }
+  if (tid < g.rows && row0 + tid < rg) {                         // border vector of the child
+    const int pr = prowu - w - r0;
+    if (prowu < w) lds_add(Ls + (W + nr) * LDW + prowu, S.u);
+    else if (pr >= 0 && pr < nr) lds_add(Ls + (W + pr) * LDW + W, S.u);
+  }
+}
+
+// cell t of a row-major packed lower triangle -> (i, j), j <= i
+__device__ __forceinline__ void tri_cell(int t, int& i, int& j) {
+  i = (int)((__builtin_amdgcn_sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);     // estimate, corrected below
+  while (i * (i + 1) / 2 > t) i--;
+  while ((i + 1) * (i + 2) / 2 <= t) i++;
+  j = t - i * (i + 1) / 2;
+}
+
+// child ci of the front: descriptor from the work record (first MAXC children) or from the front table
+__device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDesc* __restrict__ fronts,
+                                               const int32_t* __restrict__ children, int child_off, int ci) {
+  if (ci < MAXC) return WR->ch[ci];
+  const FrontDesc G = fronts[children[child_off + ci]];
+  WorkChild c;
+  c.U_off = G.U_off; c.ns = G.ns; c.na = G.na; c.rel_off = G.rel_off; c.inv_off = G.inv_off; c.rows_off = G.rows_off;
+  c.pad = 0;
+  return c;
+}
+
+// One workgroup per (front, chunk of CH border rows) of the current level.  A lone workgroup pulls cold data at
+// 10-25 bytes per clock and pays ~2500 clocks per dependent round trip (tools/ubench/cu_read_ubench.hip), so the
+// assembly is organised around few round trips and contiguous wide loads:
+//   (1) the work record -- front descriptor plus the descriptors of its first MAXC children -- into LDS while
+//       LDS is being cleared;
+//   (2) everything addressed by the record: the rhs, this front's H blocks (stored contiguously in assembly
+//       order), the children's row maps (child row -> position in my row list);
+//   (3) the children's leading slabs, streamed front to back with 16-byte loads, two children in flight, and
+//       scattered into LDS through the maps.  Children are added in a fixed order with a barrier in between:
+//       no atomics, bit-reproducible.
+// Then
+//   B+C. right-looking tall-panel factorisation (see below);
+//   D.   small fronts (r <= FUSE_R) also form their update matrix U = ext_add - L21 L21^T: the trailing
+//        blocks of the first two children are fetched before B+C starts and consumed after it.
+__global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
+                                                         const FrontDesc* __restrict__ fronts,
                                                          const int32_t* __restrict__ children,
                                                          const int32_t* __restrict__ rel,
-                                                         const int32_t* __restrict__ inv,
-                                                         const int32_t* __restrict__ alist,
+                                                         const int32_t* __restrict__ apack,
                                                          const double* __restrict__ Ablk, double* __restrict__ Lbuf,
                                                          double* __restrict__ Ubuf, const double* __restrict__ bvec,
                                                          double* __restrict__ yvec, double* __restrict__ uvec,
-                                                         int* __restrict__ status, int iter_tag, int level_id) {
+                                                         int* __restrict__ status, int iter_tag, int level_id,
+                                                         int write_l11c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* R = reinterpret_cast<double*>(smem + kOffR);
   double* Ls = reinterpret_cast<double*>(smem + kOffLs);
-  double* Uacc = reinterpret_cast<double*>(smem + kOffLs);
-  short* s_pos = reinterpret_cast<short*>(smem + kOffLists);
-  short* s_colinv = reinterpret_cast<short*>(smem + kOffColinv);
-  short* s_src = reinterpret_cast<short*>(smem + kOffSrc);
+  double* R = reinterpret_cast<double*>(smem + kOffR);
+  double* Uacc = reinterpret_cast<double*>(smem + kOffUacc);
+  short* s_rmap = reinterpret_cast<short*>(smem + kOffRmap);
+  short* s_cmap = reinterpret_cast<short*>(smem + kOffCmap);
+  int* s_rec = reinterpret_cast<int*>(smem + kOffRec);
   double* Dinv = reinterpret_cast<double*>(smem + kOffDinv);
   double* Pan = reinterpret_cast<double*>(smem + kOffPan);
   double* Ys = reinterpret_cast<double*>(smem + kOffYs);
   const int tid = threadIdx.x;
-  const int32_t* wk = work + 2 * (size_t)(work_begin + blockIdx.x);
-  const FrontDesc F = fronts[wk[0]];
-  const int chunk = wk[1];
-  const int w = 3 * F.nc, r = 3 * F.ns;
+  PHASE(0);
+  // ---- round 1: the work record; LDS is cleared while it is in flight
+  {
+    const int* g = reinterpret_cast<const int*>(work + work_begin + blockIdx.x);
+    if (tid < kRecInts) s_rec[tid] = g[tid];
+  }
+  for (int q = tid; q < W * LDW; q += 256) Ls[q] = 0.0;
+  for (int q = tid; q < CH * LDW; q += 256) R[q] = 0.0;
+  __syncthreads();
+  PHASE(1);
+  const WorkRec* WR = reinterpret_cast<const WorkRec*>(s_rec);
+  const int c0 = rfl(WR->F.c0), nc = rfl(WR->F.nc), ns = rfl(WR->F.ns), rows_off = rfl(WR->F.rows_off);
+  const int child_off = rfl(WR->F.child_off), nchild = rfl(WR->F.nchild), my_na = rfl(WR->F.na);
+  const int a_off = rfl(WR->F.a_off), a_cnt = rfl(WR->F.a_cnt), chunk = rfl(WR->chunk);
+  const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off);
+  const int w = 3 * nc, r = 3 * ns;
   const int r0 = chunk * kChunkRows;
   const int nr = max(0, min(kChunkRows, r - r0));   // border rows of this chunk; staging row nr carries the rhs
-  PHASE(0);
-  // ---- A1. F11 (all threads): H blocks + leading blocks of the children's update matrices
-  for (int q = tid; q < W * LDW; q += 256) {
-    int i = q / LDW, j = q - i * LDW;
-    Ls[q] = (i == j && i >= w) ? 1.0 : 0.0;
+  const bool fused = r > 0 && r <= FUSE_R;
+  constexpr int LDU = FUSE_R + 1;
+  // ---- round 2: rhs, H blocks, the children's row maps (first batch, first block) -- every load first ...
+  const int ncb0 = min(nchild, MAXC);
+  const double bv = (tid < w) ? bvec[3 * c0 + tid] : 0.0;
+  constexpr int AU = 4;
+  const int na9 = a_cnt * 9;
+  double av[AU];
+  int apk[AU];
+#pragma unroll
+  for (int u = 0; u < AU; u++) {
+    const int q = tid + 256 * u;
+    const bool ok = q < na9;
+    apk[u] = ok ? apack[a_off + q / 9] : -1;
+    av[u] = ok ? Ablk[(size_t)a_off * 9 + q] : 0.0;
   }
-  for (int q = tid; q < (nr + 1) * LDW; q += 256) R[q] = 0.0;
-  __syncthreads();
-  if (tid < w) R[nr * LDW + tid] = bvec[3 * F.c0 + tid];      // rhs row: b of my columns (+ children below)
-  for (int q = tid; q < F.a_cnt * 9; q += 256) {
-    int a = q / 9, el = q - 9 * a;
-    const int32_t* tr = alist + 3 * (size_t)(F.a_off + a);
-    int lr = tr[1], lc = tr[2];
-    double v = Ablk[(size_t)tr[0] * 9 + el];
-    if (lr < F.nc) Ls[(3 * lr + el / 3) * LDW + 3 * lc + el % 3] = v;
+  int relv[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    const int cs = min(c, max(ncb0 - 1, 0));             // surplus slots repeat a valid child and are ignored below
+    const int rg = 3 * WR->ch[cs].ns;
+    relv[c] = rel[WR->ch[cs].rel_off + min(tid, max(rg - 1, 0)) / 3];
+  }
+  // ... then the LDS writes
+  if (tid >= w && tid < W) Ls[tid * LDW + tid] = 1.0;        // identity padding of the unused columns
+  if (tid < w) R[nr * LDW + tid] = bv;                        // rhs row: b of my columns (+ children below)
+  if (fused)
+    for (int q = tid; q < r * LDU; q += 256) Uacc[q] = 0.0;
+#pragma unroll
+  for (int u = 0; u < AU; u++) {
+    if (apk[u] < 0) continue;
+    const int el = (tid + 256 * u) % 9, lr = apk[u] & 0xffff, lc = apk[u] >> 16;
+    if (lr < nc) Ls[(3 * lr + el / 3) * LDW + 3 * lc + el % 3] = av[u];
     else {
-      int row = 3 * (lr - F.nc) + el / 3 - r0;
+      int row = 3 * (lr - nc) + el / 3 - r0;
+      if (row >= 0 && row < nr) R[row * LDW + 3 * lc + el % 3] = av[u];
+    }
+  }
+  for (int q = tid + 256 * AU; q < na9; q += 256) {           // fronts with more than 113 H blocks
+    const int pk = apack[a_off + q / 9], el = q % 9, lr = pk & 0xffff, lc = pk >> 16;
+    const double v = Ablk[(size_t)a_off * 9 + q];
+    if (lr < nc) Ls[(3 * lr + el / 3) * LDW + 3 * lc + el % 3] = v;
+    else {
+      int row = 3 * (lr - nc) + el / 3 - r0;
       if (row >= 0 && row < nr) R[row * LDW + 3 * lc + el % 3] = v;
     }
   }
-  // Children in batches of MAXC.  Per batch the child->parent maps are staged in LDS as *inverse*
-  // maps (parent column -> child column, chunk row -> child row), so that every target cell is
-  // owned by one thread which sums the children in a fixed order: no barriers between children,
-  // no read-modify-write races, bit-reproducible.  In the last batch wavefront 0 goes on to the
-  // Cholesky as soon as F11 is complete while wavefronts 1-3 finish this chunk's F21 rows.
-  const int nbatch = (F.nchild + MAXC - 1) / MAXC;
-  for (int bt = 0; bt < nbatch; bt++) {
-    const int c0 = bt * MAXC;
-    const int ncb = max(0, min(MAXC, F.nchild - c0));
-    __syncthreads();
-    for (int q = tid; q < ncb * W; q += 256) s_colinv[q] = -1;
-    __syncthreads();
-    for (int c = 0; c < ncb; c++) {
-      const FrontDesc G = fronts[children[F.child_off + c0 + c]];
-      const int ra = 3 * G.na;
-      if (tid < ra) s_colinv[c * W + 3 * rel[G.rel_off + tid / 3] + tid % 3] = (short)tid;
-      for (int t = tid; t < nr; t += 256) {
-        int pr = r0 + t;
-        int kb = inv[G.inv_off + pr / 3];
-        s_src[c * CH + t] = (short)(kb < 0 ? -1 : 3 * kb + pr % 3);
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    if (c < ncb0) {
+      const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
+      const short pos = (short)(3 * relv[c] + tid % 3);
+      if (tid < rg) s_rmap[c * MAPW + tid] = pos;
+      if (tid < ra) s_cmap[c * W + tid] = pos;
+    }
+  }
+  __syncthreads();
+  PHASE(2);
+  // ---- round 3: the children's leading slabs, two children in flight
+  for (int cb = 0; cb < ncb0; cb += 2) {
+    SlabLoads S0, S1;
+    const bool two = cb + 1 < ncb0;
+    const int cb1 = two ? cb + 1 : cb;
+    const int rg0 = 3 * WR->ch[cb].ns, ra0 = 3 * WR->ch[cb].na;
+    const int rg1 = 3 * WR->ch[cb1].ns, ra1 = 3 * WR->ch[cb1].na;
+    const SlabGeom g0 = slab_geom(tid, ra0), g1 = slab_geom(tid, ra1);
+    const double* U0 = Ubuf + WR->ch[cb].U_off;
+    const double* U1 = Ubuf + WR->ch[cb1].U_off;
+    const double* uc0 = uvec + (size_t)3 * WR->ch[cb].rows_off;
+    const double* uc1 = uvec + (size_t)3 * WR->ch[cb1].rows_off;
+    slab_issue(S0, g0, tid, U0, uc0, rg0, even_up(ra0), 0);
+    if (two) slab_issue(S1, g1, tid, U1, uc1, rg1, even_up(ra1), 0);
+    if (cb > 0) __syncthreads();
+    slab_scatter(S0, g0, tid, rg0, ra0, 0, s_rmap + cb * MAPW, s_cmap + cb * W, w, r0, nr, Ls);
+    if (two) {
+      __syncthreads();
+      slab_scatter(S1, g1, tid, rg1, ra1, 0, s_rmap + cb1 * MAPW, s_cmap + cb1 * W, w, r0, nr, Ls);
+    }
+    // children with more border rows than one block: the remaining row blocks, maps staged per block
+    for (int cc = cb; cc <= cb1; cc++) {
+      const int rg = 3 * WR->ch[cc].ns, ra = 3 * WR->ch[cc].na;
+      const SlabGeom g = slab_geom(tid, ra);
+      for (int row0 = g.rows; row0 < rg; row0 += g.rows) {
+        __syncthreads();
+        if (tid < g.rows && row0 + tid < rg)
+          s_rmap[cc * MAPW + tid] = (short)(3 * rel[WR->ch[cc].rel_off + (row0 + tid) / 3] + (row0 + tid) % 3);
+        __syncthreads();
+        slab_issue(S0, g, tid, Ubuf + WR->ch[cc].U_off, uvec + (size_t)3 * WR->ch[cc].rows_off, rg, even_up(ra), row0);
+        slab_scatter(S0, g, tid, rg, ra, row0, s_rmap + cc * MAPW, s_cmap + cc * W, w, r0, nr, Ls);
       }
     }
-    __syncthreads();
-    // Child-outer loops: within one child every thread issues all of its loads before using any of them
-    // (one memory round trip per child); a cell is always owned by the same thread, so children are summed
-    // in a fixed order without barriers in between.
-    for (int c = 0; c < ncb; c++) {
-      const FrontDesc G = fronts[children[F.child_off + c0 + c]];
-      const double* U = Ubuf + G.U_off;
-      const int rg = 3 * G.ns;
-      const short* cinv = s_colinv + c * W;
-      // ---- issue every load of this child first (F11 cells, rhs entry, border-vector entry, F21 rows) ...
-      double vF[9];
-      int atF[9];
-#pragma unroll
-      for (int u = 0; u < 9; u++) {
-        const int q = tid + 256 * u;
-        const int pi = q / W, pj = q - pi * W;
-        int i = cinv[pi], j = cinv[pj];
-        const bool ok = (pj <= pi) && i >= 0 && j >= 0;
-        vF[u] = ok ? U[(size_t)i * rg + j] : 0.0;
-        atF[u] = ok ? pi * LDW + pj : -1;
+  }
+  // fronts with more than MAXC children: one at a time through map slot 0
+  for (int ci = MAXC; ci < nchild; ci++) {
+    const WorkChild G = get_child(WR, fronts, children, child_off, ci);
+    const int rg = 3 * G.ns, ra = 3 * G.na;
+    const SlabGeom g = slab_geom(tid, ra);
+    for (int row0 = 0; row0 < rg; row0 += g.rows) {
+      __syncthreads();
+      if (tid < g.rows && row0 + tid < rg) {
+        const short pos = (short)(3 * rel[G.rel_off + (row0 + tid) / 3] + (row0 + tid) % 3);
+        s_rmap[tid] = pos;
+        if (row0 == 0 && tid < ra) s_cmap[tid] = pos;
       }
-      const double* uc = uvec + (size_t)3 * G.rows_off;
-      const bool has_rhs = tid < W && cinv[tid] >= 0;
-      const double vRhs = has_rhs ? uc[cinv[tid]] : 0.0;
-      const int srU = (tid < nr) ? s_src[c * CH + tid] : -1;
-      const double vCol = (srU >= 0) ? uc[srU] : 0.0;
-      // F21 rows of this chunk: thread owns parent column pc and rows n = rgp, rgp + 5, ... (<= 39 of them)
-      const int pc = tid % W, rgp = tid / W;
-      const int jF = (tid < 5 * W) ? cinv[pc] : -1;
-      double v21[20];
-      int dst21[20];
-      const short* src21 = s_src + c * CH;
+      __syncthreads();
+      SlabLoads S0;
+      slab_issue(S0, g, tid, Ubuf + G.U_off, uvec + (size_t)3 * G.rows_off, rg, even_up(ra), row0);
+      slab_scatter(S0, g, tid, rg, ra, row0, s_rmap, s_cmap, w, r0, nr, Ls);
+    }
+  }
+  // ---- D (prefetch): trailing blocks of the first two children for the fused update, consumed after B+C.
+  // (fused fronts: r <= FUSE_R, so every child has fewer than MAPW rows and its whole map sits in s_rmap;
+  //  with more than MAXC children map slot 0 was overwritten above: those fronts take the streamed path)
+  const bool pre = fused && ncb0 > 0 && nchild <= MAXC;
+  double vT[2][TRI_U];
+  int tij[TRI_U];                                        // cell t = tid + 256 u of a packed lower triangle: i << 8 | j
+  if (pre) {
 #pragma unroll
-      for (int u = 0; u < 20; u++) {
-        int n = rgp + 5 * u;
-        int sr = (jF >= 0 && n < nr) ? src21[n] : -1;
-        v21[u] = (sr >= 0) ? U[(size_t)sr * rg + jF] : 0.0;
-        dst21[u] = (sr >= 0) ? n : -1;
-      }
-      // ---- ... then consume them (every cell is owned by one thread: plain read-modify-write in LDS)
+    for (int u = 0; u < TRI_U; u++) {
+      int i, j;
+      tri_cell(tid + 256 * u, i, j);
+      tij[u] = (i << 8) | j;
+    }
 #pragma unroll
-      for (int u = 0; u < 9; u++)
-        if (atF[u] >= 0) Ls[atF[u]] += vF[u];
-      if (has_rhs) R[nr * LDW + tid] += vRhs;
-      if (srU >= 0) R[tid * LDW + W] += vCol;
+    for (int cc = 0; cc < 2; cc++) {
+      const int ci = min(cc, ncb0 - 1);
+      const int rg = 3 * WR->ch[ci].ns, ra = 3 * WR->ch[ci].na;
+      const int nbb = (cc < ncb0) ? rg - ra : 0;                // child border rows that land in my border
+      const int ncell = nbb * (nbb + 1) / 2;
+      const double* B = Ubuf + WR->ch[ci].U_off + (size_t)rg * even_up(ra);
 #pragma unroll
-      for (int u = 0; u < 20; u++)
-        if (dst21[u] >= 0) R[dst21[u] * LDW + pc] += v21[u];
-      if (jF >= 0 && nr > 100) {                         // rows 100.. of the chunk (second batch)
-        for (int base = rgp + 100; base < nr; base += 100) {
-#pragma unroll
-          for (int u = 0; u < 20; u++) {
-            int n = base + 5 * u;
-            int sr = (n < nr) ? src21[n] : -1;
-            v21[u] = (sr >= 0) ? U[(size_t)sr * rg + jF] : 0.0;
-            dst21[u] = (sr >= 0) ? n : -1;
-          }
-#pragma unroll
-          for (int u = 0; u < 20; u++)
-            if (dst21[u] >= 0) R[dst21[u] * LDW + pc] += v21[u];
-        }
+      for (int u = 0; u < TRI_U; u++) {
+        const bool ok = tid + 256 * u < ncell;
+        vT[cc][u] = B[ok ? (size_t)(tij[u] >> 8) * nbb + (tij[u] & 255) : 0];
       }
     }
   }
   __syncthreads();
-  PHASE(1);
+  PHASE(3);
   // ---- B+C. right-looking tall-panel factorisation: every row of [F11; F21 chunk] lives in the registers of
   // one lane (wave 0: the 48 rows of F11, waves 1-3: one border row per lane).  Per 8-column panel: wave 0
   // factors the panel for the F11 rows (pivot broadcast with v_readlane, 1/sqrt by rsqrt + 2 Newton steps),
@@ -438,8 +605,8 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
 #undef FACTOR_PANEL
 #undef TRAIL_COL
   if (isF11 && fail && tid == 0) atomicCAS(status, 0, iter_tag);
-  PHASE(2);
-  double* P = Lbuf + F.L_off;
+  PHASE(4);
+  double* P = Lbuf + L_off;
   if (isF11) {
     if (chunk == 0 && tid < W) {               // stage L11 in LDS (the F11 buffer is dead) for coalesced copies
 #pragma unroll
@@ -450,7 +617,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
     double* dst = P + kL21 + (size_t)(r0 + tid - 64) * W;
 #pragma unroll
     for (int k = 0; k < W; k += 2) *reinterpret_cast<double2*>(dst + k) = make_double2(x[k], x[k + 1]);
-    if (r <= FUSE_R) {
+    if (fused) {
       double* rr = R + (tid - 64) * LDW;
 #pragma unroll
       for (int k = 0; k < W; k++) rr[k] = x[k];
@@ -462,7 +629,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
     if (chunk == 0) {
 #pragma unroll
       for (int k = 0; k < W; k++)
-        if (k < w) yvec[3 * F.c0 + k] = x[k];
+        if (k < w) yvec[3 * c0 + k] = x[k];
     }
   }
   __syncthreads();
@@ -470,55 +637,79 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
     for (int q = tid; q < W * W; q += 256) {
       int i = q / W, k = q - i * W;
       P[q] = Ls[i * LDW + k];                   // row-major copy (backward solve)
-      P[kL11c + q] = Ls[k * LDW + i];           // column-major copy (forward solve): element (row k, col i)
     }
+    if (write_l11c)                             // column-major copy: only the multi-rhs forward solve of the marginals reads it
+      for (int q = tid; q < W * W; q += 256) {
+        int i = q / W, k = q - i * W;
+        P[kL11c + q] = Ls[k * LDW + i];
+      }
   }
   if (!isF11 && tid - 64 < nr) {                // border vector handed to the parent: u = ext_add(children) - L21 y
     double dot = 0.0;
 #pragma unroll
     for (int k = 0; k < W; k++) dot = fma(x[k], Ys[k], dot);
-    uvec[(size_t)3 * F.rows_off + r0 + tid - 64] = R[(tid - 64) * LDW + W] - dot;
+    uvec[(size_t)3 * rows_off + r0 + tid - 64] = R[(tid - 64) * LDW + W] - dot;
   }
-  __syncthreads();
-  PHASE(3);
-  PHASE(4);
   PHASE(5);
   // ---- D. fused update matrix for small fronts (single chunk: R holds all of L21)
-  if (r > 0 && r <= FUSE_R) {
-    constexpr int LDU = FUSE_R + 1;
-    for (int q = tid; q < r * LDU; q += 256) Uacc[q] = 0.0;      // Ls / LsT are dead from here on
-    for (int ci = 0; ci < F.nchild; ci++) {
-      const FrontDesc G = fronts[children[F.child_off + ci]];
-      const double* U = Ubuf + G.U_off;
-      const int rg = 3 * G.ns, ra = 3 * G.na;
-      const int nbb = rg - ra;                          // child border rows that land in my border
-      if (nbb <= 0) continue;
-      __syncthreads();
-      for (int q = tid; q < nbb; q += 256) {
-        int k = ra + q;
-        s_pos[q] = (short)(3 * (rel[G.rel_off + k / 3] - F.nc) + k % 3);   // my border row of child row k
+  if (fused) {
+    // children in order: the prefetched trailing blocks of the first two, then any further ones streamed
+    if (pre) {
+#pragma unroll
+      for (int cc = 0; cc < 2; cc++) {
+        if (cc < ncb0) {
+          const int rg = 3 * WR->ch[cc].ns, ra = 3 * WR->ch[cc].na;
+          const int nbb = rg - ra;
+          const int ncell = nbb * (nbb + 1) / 2;
+          const short* pos = s_rmap + cc * MAPW + ra;          // position of trailing row i in my row list (>= w)
+          int tg[TRI_U];
+#pragma unroll
+          for (int u = 0; u < TRI_U; u++) {
+            const bool ok = tid + 256 * u < ncell;
+            tg[u] = ok ? (pos[tij[u] >> 8] - w) * LDU + pos[tij[u] & 255] - w : -1;
+          }
+#pragma unroll
+          for (int u = 0; u < TRI_U; u++)
+            if (tg[u] >= 0) lds_add(&Uacc[tg[u]], vT[cc][u]);
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      // stream the lower triangle of the child's trailing block, 8 independent loads per lane
-      const int total = nbb * nbb;
-      for (int base = tid; base < total; base += 256 * 8) {
+    }
+    for (int ci = pre ? 2 : 0; ci < nchild; ci++) {
+      const WorkChild G = get_child(WR, fronts, children, child_off, ci);
+      const int rg = 3 * G.ns, ra = 3 * G.na;
+      const int nbb = rg - ra;
+      if (nbb <= 0) continue;
+      const double* B = Ubuf + G.U_off + (size_t)rg * even_up(ra);
+      short* pos = s_rmap + (pre ? ci : 0) * MAPW;
+      if (!pre) {                                          // maps not resident: stage the trailing rows' positions
+        __syncthreads();
+        for (int q = tid; q < nbb; q += 256) {
+          int k = ra + q;
+          pos[q] = (short)(3 * rel[G.rel_off + k / 3] + k % 3);
+        }
+        __syncthreads();
+      } else pos += ra;
+      const int ncell = nbb * (nbb + 1) / 2;
+      for (int t0 = 0; t0 < ncell; t0 += 256 * 8) {
         double v[8];
-        int tgt[8];
+        int tg[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-          int q = base + 256 * u;
-          int i = q / nbb, j = q - i * nbb;
-          bool ok = q < total && j <= i;
-          v[u] = ok ? U[(size_t)(ra + i) * rg + ra + j] : 0.0;
-          tgt[u] = ok ? s_pos[i] * LDU + s_pos[j] : -1;
+          const int t = t0 + tid + 256 * u;
+          int i, j;
+          tri_cell(min(t, ncell - 1), i, j);
+          v[u] = B[(size_t)i * nbb + j];
+          tg[u] = (t < ncell) ? (pos[i] - w) * LDU + pos[j] - w : -1;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++)
-          if (tgt[u] >= 0) Uacc[tgt[u]] += v[u];
+          if (tg[u] >= 0) lds_add(&Uacc[tg[u]], v[u]);
       }
+      __syncthreads();
     }
-    __syncthreads();
-    double* Uo = Ubuf + F.U_off;
+    double* Uo = Ubuf + U_off;
+    const int my_ra = 3 * my_na;
     const int T4 = (r + 3) / 4;
     for (int q = tid; q < T4 * T4; q += 256) {
       int bi = q / T4, bj = q - bi * T4;
@@ -544,7 +735,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const FrontDesc* __restric
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           int gi = 4 * bi + a, gj = 4 * bj + b;
-          if (gi < r && gj <= gi) Uo[(size_t)gi * r + gj] = Uacc[gi * LDU + gj] - acc[a][b];
+          if (gi < r && gj <= gi) Uo[uidx(gi, gj, r, my_ra)] = Uacc[gi * LDU + gj] - acc[a][b];
         }
     }
   }
@@ -593,8 +784,8 @@ __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restric
   for (int ci = 0; ci < F.nchild; ci++) {
     const FrontDesc G = fronts[children[F.child_off + ci]];
     const int32_t* ginv = inv + G.inv_off;
-    const double* U = Ubuf + G.U_off;
-    const int rg = 3 * G.ns;
+    const int rg = 3 * G.ns, rga = 3 * G.na, nbb = rg - rga;
+    const double* B = Ubuf + G.U_off + (size_t)rg * even_up(rga);      // the child's trailing block (slab B)
     __syncthreads();
     if (tid < TS) {
       int p = i0 + tid;
@@ -613,7 +804,7 @@ __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restric
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         bool ok = ki[a] >= 0 && kj[b] >= 0 && gj[b] <= gi[a];
-        v[2 * a + b] = ok ? U[(size_t)ki[a] * rg + kj[b]] : 0.0;
+        v[2 * a + b] = ok ? B[(size_t)(ki[a] - rga) * nbb + (kj[b] - rga)] : 0.0;
       }
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] += v[q];
@@ -623,80 +814,10 @@ __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restric
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++)
-      if (gi[a] < r && gj[b] <= gi[a]) Uo[(size_t)gi[a] * r + gj[b]] = acc[2 * a + b];
+      if (gi[a] < r && gj[b] <= gi[a]) Uo[uidx(gi[a], gj[b], r, 3 * F.na)] = acc[2 * a + b];
 }
 
 // ------------------------------------------------------------------------------ solves
-// Forward (L y = b), one workgroup per front, bottom-up by level.  Wavefront 0 holds L11 (lane
-// i = row i, read coalesced from the column-major copy) and substitutes with readlane
-// broadcasts; then all threads form the border vector u = ext_add(children) - L21 y.
-__global__ __launch_bounds__(256) void k_solve_fwd(const FrontDesc* __restrict__ fronts,
-                                                   const int32_t* __restrict__ level_fronts, int level_begin,
-                                                   const int32_t* __restrict__ children,
-                                                   const int32_t* __restrict__ rel, const int32_t* __restrict__ inv,
-                                                   const double* __restrict__ Lbuf, const double* __restrict__ bvec,
-                                                   double* __restrict__ yvec, double* __restrict__ uvec) {
-  __shared__ double t1[W];
-  __shared__ double ys[W];
-  const int tid = threadIdx.x;
-  const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
-  const int w = 3 * F.nc, r = 3 * F.ns;
-  const double* P = Lbuf + F.L_off;
-  double Lrow[W];
-  double dv = 1.0;
-  if (tid < 64) {           // issue the L11 loads early; they do not depend on the children
-    const int lane = min(tid, W - 1);
-#pragma unroll
-    for (int k = 0; k < W; k++) Lrow[k] = P[kL11c + k * W + lane];
-    dv = P[kDinv + lane];
-  }
-  if (tid < W) t1[tid] = (tid < w) ? bvec[3 * F.c0 + tid] : 0.0;
-  __syncthreads();
-  for (int ci = 0; ci < F.nchild; ci++) {
-    const FrontDesc G = fronts[children[F.child_off + ci]];
-    const double* ug = uvec + 3 * (size_t)G.rows_off;
-    const int32_t* grel = rel + G.rel_off;
-    int ra = 3 * G.na;
-    for (int q = tid; q < ra; q += 256) t1[3 * grel[q / 3] + q % 3] += ug[q];
-    __syncthreads();
-  }
-  if (tid < 64) {
-    const int lane = tid;
-    double t = t1[min(lane, W - 1)];
-    double yv = 0.0;
-#pragma unroll
-    for (int j = 0; j < W; j++) {
-      if (j < w) {
-        double yj = readlane_f64(t, j) * readlane_f64(dv, j);
-        if (lane == j) yv = yj;
-        t -= Lrow[j] * yj;
-      }
-    }
-    if (lane < W) ys[lane] = yv;
-    if (lane < w) yvec[3 * F.c0 + lane] = yv;
-  }
-  __syncthreads();
-  const double* L21 = P + kL21;
-  double* uf = uvec + 3 * (size_t)F.rows_off;
-  for (int p = tid; p < r; p += 256) {
-    double acc = 0;
-    for (int ci = 0; ci < F.nchild; ci++) {
-      const FrontDesc G = fronts[children[F.child_off + ci]];
-      int kb = inv[G.inv_off + p / 3];
-      if (kb >= 0) acc += uvec[3 * (size_t)G.rows_off + 3 * kb + p % 3];
-    }
-    const double2* row = reinterpret_cast<const double2*>(L21 + (size_t)p * W);
-    double dot = 0;
-#pragma unroll
-    for (int k = 0; k < W / 2; k++) {
-      double2 v = row[k];
-      dot += v.x * ys[2 * k];
-      dot += v.y * ys[2 * k + 1];
-    }
-    uf[p] = acc - dot;
-  }
-}
-
 // Backward (L^T x = y), one workgroup per front, top-down by level.  The border part of x is staged in LDS
 // first (its gather chains two dependent global loads per row, which must not sit inside the reduction loop).
 constexpr int XB_CAP = 1536;         // border rows staged per pass
@@ -794,10 +915,10 @@ void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
 void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
   hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.term, D.Ablk, D.bvec);
+                     D.asm_src, D.blk_slot, D.term, D.Ablk, D.bvec);
 }
 
-void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag) {
+void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag, bool write_l11c) {
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   (void)nfr;
   static bool attr_set = false;
@@ -807,8 +928,9 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag)
     attr_set = true;
   }
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
-  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), kSmemBytes, st, D.fronts, D.work, D.h_work_ptr[l], D.children,
-                     D.rel, D.inv, D.alist, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, iter_tag, l);
+  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), kSmemBytes, st, D.work, D.h_work_ptr[l], D.fronts, D.children,
+                     D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, iter_tag, l,
+                     write_l11c ? 1 : 0);
 }
 
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
@@ -816,12 +938,6 @@ void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
   if (nt > 0)
     hipLaunchKernelGGL(k_front_update, dim3(nt), dim3(256), 0, st, D.fronts, D.tiles, D.h_tile_ptr[l], D.children,
                        D.inv, D.Lbuf, D.Ubuf);
-}
-
-void launch_fwd_level(hipStream_t st, const GnDevice& D, int l) {
-  int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
-  hipLaunchKernelGGL(k_solve_fwd, dim3(nfr), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l],
-                     D.children, D.rel, D.inv, D.Lbuf, D.bvec, D.yvec, D.uvec);
 }
 
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {

@@ -373,7 +373,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     F.a_cnt = (int)S.alist.size() / 3 - F.a_off;
     int64_t w = 3 * (int64_t)F.nc, r = 3 * (int64_t)F.ns;
     F.L_off = Loff; Loff += kFactorHeader + r * kFrontW;
-    F.U_off = Uoff; Uoff += r * r;
+    F.U_off = Uoff; Uoff += (r * r + r + 3) & ~int64_t(1);      // even offsets: the update matrices are read with 16-byte loads
     flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
   }
   S.L_doubles = Loff;

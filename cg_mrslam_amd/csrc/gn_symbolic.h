@@ -42,6 +42,22 @@ struct FrontDesc {                   // one per front, uploaded verbatim (all in
   int64_t U_off;      // offset (doubles) of this front's update matrix (r*r, row-major, lower part valid)
 };
 
+// Work item of the factorisation kernel: the front, its chunk, and the fields of its first children that the
+// kernel needs -- one record, one memory round trip (uploaded verbatim).
+constexpr int kWorkChildren = 8;
+struct WorkChild {
+  int64_t U_off;      // child's update matrix
+  int32_t ns, na;     // child's border block rows / leading ones inside the parent's own columns
+  int32_t rel_off, inv_off, rows_off;
+  int32_t pad;
+};
+struct WorkRec {
+  FrontDesc F;
+  int32_t front, chunk, pad[2];
+  WorkChild ch[kWorkChildren];
+};
+static_assert(sizeof(WorkChild) == 32 && sizeof(WorkRec) % 8 == 0, "WorkRec layout");
+
 struct Symbolic {
   int nV = 0, nE = 0;
   int nf = 0;                          // free active poses = block dimension of H

@@ -187,6 +187,40 @@ def make_pose_graph(n_vertices: int = 10000, n_edges: int = 40000, seed: int = 1
                 meas=meas, info=info, ids=ids, n_odometry=n_odo)
 
 
+def make_hub_graph(n_chains: int = 40, chain_len: int = 30, n_hubs: int = 3, seed: int = 99):
+    """Elimination-tree stress case: ``n_hubs`` hub poses in a row, ``n_chains`` odometry chains of ``chain_len``
+    poses, every chain tied to every hub.  The hubs separate the chains, so the ordering produces fronts with
+    dozens of children (more than the 8 whose descriptors ride in a work record) and borders of several hundred
+    rows.  The last pose is fixed; the initial guess is the truth plus noise (a few GN iterations converge)."""
+    K, Lc, H = n_chains, chain_len, n_hubs
+    V = H + K * Lc
+    ef, et = [], []
+    for h in range(H - 1):
+        ef.append(h); et.append(h + 1)
+    for k in range(K):
+        base = H + k * Lc
+        for h in range(H):
+            ef.append(h); et.append(base + (h % Lc))
+        for i in range(Lc - 1):
+            ef.append(base + i); et.append(base + i + 1)
+    e_from = np.asarray(ef, dtype=np.int32)
+    e_to = np.asarray(et, dtype=np.int32)
+    E = len(e_from)
+    truth = np.stack([20.0 * uniform(seed, 1, V) - 10.0, 20.0 * uniform(seed, 2, V) - 10.0,
+                      2.0 * np.pi * uniform(seed, 3, V) - np.pi], axis=1)
+    rel = se2_compose(se2_inverse(truth[e_from]), truth[e_to])
+    info_d = np.tile(np.asarray(SM_INFO, dtype=np.float64), (E, 1))
+    noise = np.stack([normal(seed, 10 + k, E) for k in range(3)], axis=1) / np.sqrt(info_d)
+    meas = se2_compose(rel, noise)
+    info = np.zeros((E, 6))
+    info[:, 0], info[:, 3], info[:, 5] = info_d[:, 0], info_d[:, 1], info_d[:, 2]
+    poses = truth + 0.02 * np.stack([normal(seed, 20 + k, V) for k in range(3)], axis=1)
+    poses[V - 1] = truth[V - 1]
+    fixed = np.zeros(V, dtype=np.uint8)
+    fixed[V - 1] = 1
+    return dict(truth=truth, poses=poses, fixed=fixed, edge_from=e_from, edge_to=e_to, meas=meas, info=info)
+
+
 INTER_ROBOT_INFO = (100.0, 100.0, 1000.0)   # src/mrslam/mr_graph_slam.cpp:234-236,310-312
 
 

@@ -51,6 +51,21 @@ def test_gpu_matches_oracle(ctx, oracle, V, E, iters, seed):
     _check(p, chi, p2, chi2)
 
 
+@pytest.mark.parametrize("K,Lc,H", [(40, 30, 1), (40, 30, 3), (60, 20, 2), (24, 40, 4)])
+def test_fronts_with_many_children_and_wide_borders(ctx, oracle, K, Lc, H):
+    """Hub graphs: fronts with up to 75 children (the work record carries 8; the rest take the streamed path),
+    fused fronts with more than 8 children, borders beyond one 191-row chunk."""
+    from cg_mrslam_amd._lib import gn_symbolic_info
+    g = synth.make_hub_graph(K, Lc, H)
+    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+    info = gn_symbolic_info(len(g["poses"]), g["fixed"], g["edge_from"], g["edge_to"])
+    assert info["max_children"] > 8
+    rc, p, chi = ctx.gn_optimize(*a, 5)
+    st, p2, chi2, _ = oracle.gn_optimize(*a, 5)
+    assert rc == 0 and st == 0
+    _check(p, chi, p2, chi2)
+
+
 def test_gpu_full_size_c2(ctx, oracle):
     """BASELINE.json configs[1]: 10k vertices / 40k edges, optimize(10)."""
     g = synth.make_pose_graph(10000, 40000, seed=12345)

@@ -146,3 +146,16 @@ def test_condense_matches_numpy_marginals(oracle):
     p_init = oracle.initial_guess(p, fixed, g["edge_from"], g["edge_to"], g["meas"])
     want = R.marginals_dense(p_init, fixed, g["edge_from"], g["edge_to"], g["meas"], g["info"], to)
     np.testing.assert_allclose(cov, want, rtol=1e-6, atol=1e-14)
+
+
+def test_hub_graph_oracle_vs_numpy(oracle):
+    """The elimination-tree stress graph of the GPU tests (fronts with dozens of children): the C oracle and the
+    independent numpy / SuperLU restatement agree on it."""
+    g = synth.make_hub_graph(24, 20, 3)
+    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+    st, p, chi, _ = oracle.gn_optimize(*a, 5)
+    p2, chi2 = R.gn_optimize(*a, 5)
+    assert st == 0
+    np.testing.assert_allclose(chi, chi2, rtol=1e-6)
+    np.testing.assert_allclose(chi[-1], chi2[-1], rtol=1e-9)
+    assert np.abs(p[:, :2] - p2[:, :2]).max() < 1e-8

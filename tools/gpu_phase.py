@@ -9,7 +9,7 @@ for r in range(2):
 out = np.zeros(64*8, dtype=np.uint64)
 print(load_library().cgmr_debug_phase(C.c_void_p(out.ctypes.data)))
 out = out.reshape(64, 8).astype(np.int64)
-print("level: [assemble, chol(+F21 wait), L11 copy, TRSM, L21 store, fused U] total | realtime ticks (100 MHz) -> shader GHz")
+print("level: [record+clear, round 2 (rhs/H/maps), round 3 (children), factor B+C, stores, fused U] total | realtime ticks (100 MHz) -> shader GHz")
 for l in range(22):
     d = np.diff(out[l,:7])
     tot = out[l,6]-out[l,0]
