@@ -51,7 +51,7 @@ def matcher_leg(ctx, dev, args, with_cpu):
     import torch
     from cg_mrslam_amd import synth
     from cg_mrslam_amd.matcher import ScanMatcher
-    base = 256
+    base = min(4096, max(256, args.match_pairs))          # distinct synthetic pairs (tiled up to --match-pairs)
     sp = synth.make_scan_pairs(base, seed=4242)
     P = max(base, (args.match_pairs // base) * base)
     rep = P // base
