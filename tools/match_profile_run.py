@@ -6,8 +6,8 @@ from cg_mrslam_amd import synth, Context
 from cg_mrslam_amd.matcher import ScanMatcher
 ctx = Context(0)
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-sp = synth.make_scan_pairs(32, seed=5)
-rr = np.tile(sp["ranges_ref"], (P // 32, 1)); rq = np.tile(sp["ranges_qry"], (P // 32, 1)); g = np.tile(sp["guess"], (P // 32, 1))
+sp = synth.make_scan_pairs(256, seed=5)
+rr = np.tile(sp["ranges_ref"], (P // 256, 1)); rq = np.tile(sp["ranges_qry"], (P // 256, 1)); g = np.tile(sp["guess"], (P // 256, 1))
 m = ScanMatcher(ctx, sp["n_beams"], sp["angle_min"], sp["angle_inc"], sp["max_range"])
 for r in range(2):
     found, xyt, score = m.closeScanMatching(rr, rq, g)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
+#   kernel-trace + stats of bench.py, PMC passes (each its own run, kernel-trace only) for the GN and matcher kernels.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_round
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/bench --output-format csv -- python $R/bench.py > $O/bench.log 2>&1
+tail -1 $O/bench.log > $O/bench_line.json
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $c | tr ' ' '_')
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/gn_$n --output-format csv -- python $R/tools/gn_profile_run.py > $O/gn_$n.log 2>&1
+done
+i=0
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" \
+         "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" \
+         "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/match_$i --output-format csv -- python $R/tools/match_profile_run.py 4096 > $O/match_$i.log 2>&1
+done
+cd $R
+python tools/pmc_summarise.py $(find $O -name "*counter_collection.csv") > $O/pmc_summary.txt
+find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
+cat $O/pmc_summary.txt | head -60
