@@ -292,7 +292,8 @@ int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, 
   if (nbins * num_threads > (size_t)1 << 26) return set_err(ctx, CGMR_E_INVALID, "result discretisation too fine for the search volume");
   P.n_items = (int)items.size() / 2;
   int nblocks = std::max(1, std::min(128, P.n_items / 8));
-  P.scratch_stride = ((size_t)4 * kMatchMaxRef + (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
+  P.ref_cap = (std::max(n_ref, 1) + 63) & ~63;
+  P.scratch_stride = ((size_t)4 * P.ref_cap + (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
   Layout L;
   size_t o_ref = L.add(16 * (size_t)std::max(n_ref, 1)), o_q = L.add(16 * (size_t)std::max(n_qry, 1)),
          o_reg = L.add(sizeof(RegionDesc) * R.size()), o_th = L.add(8 * theta.size()), o_it = L.add(4 * items.size()),
@@ -374,13 +375,14 @@ int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, con
   int rc = setup_geometry(ctx, cfg, P, kern);
   if (rc) return rc;
   P.n_ref = n2; P.n_qry = n1;
+  P.ref_cap = (std::max(std::max(n1, n2), 1) + 63) & ~63;
   auto w2g = [&](float w, float ll) { return (int)std::lrint((w - ll) * P.inv_res); };
   int lo_x = w2g(lower_xy[0], P.ll_x), lo_y = w2g(lower_xy[1], P.ll_y), hi_x = w2g(upper_xy[0], P.ll_x), hi_y = w2g(upper_xy[1], P.ll_y);
   Layout L;
   size_t o2 = L.add(16 * (size_t)std::max(n2, 1)), o1 = L.add(16 * (size_t)std::max(n1, 1)), o_kern = L.add(kern.size()),
          o_err = L.add(16);
   size_t hbytes = L.off;
-  size_t o_out = L.add(16), o_scratch = L.add((size_t)8 * kMatchMaxRef + (size_t)P.overflow_tiles * 64 + 256);
+  size_t o_out = L.add(16), o_scratch = L.add((size_t)8 * P.ref_cap + (size_t)P.overflow_tiles * 64 + 256);
   rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
   if (rc) return rc;
   rc = pinned_reserve(ctx, hbytes);

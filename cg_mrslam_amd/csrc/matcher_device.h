@@ -28,10 +28,11 @@ struct MatchParams {
   size_t scratch_stride;
   // generic multi-region search (k_match_greedy)
   int n_ref, n_qry, n_regions, n_items;
+  int ref_cap;                               // packed-cell slots per point list in the HBM scratch (>= n_ref, n_qry)
   int bx0, by0, bt0, nbx, nby, nbt;          // bounding box of the result bins over all regions
 };
 
-constexpr int kMatchMaxRef = 16384;          // reference points of one generic search (several scans)
+constexpr int kMatchMaxRef = 1 << 22;        // sanity limit on the points of one generic search (any number of scans)
 
 struct RegionDesc {                          // one search region, precomputed on the host exactly like
   int32_t lo_x, lo_y;                        //   CharGrid::greedySearch does (chargrid.cpp:235-239)

@@ -710,8 +710,8 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   unsigned char* my = scratch + (size_t)blockIdx.x * P.scratch_stride;
-  uint32_t* rcell = reinterpret_cast<uint32_t*>(my);                               // kMatchMaxRef packed cells
-  uint32_t* gtiles = rcell + kMatchMaxRef;
+  uint32_t* rcell = reinterpret_cast<uint32_t*>(my);                               // P.ref_cap packed cells
+  uint32_t* gtiles = rcell + P.ref_cap;
   const int nty = (P.ny + 7) >> 3;
   const int DW = nty + kMatchDirGuardY;
   for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
@@ -813,9 +813,9 @@ __global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const doubl
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
-  uint32_t* rcell = reinterpret_cast<uint32_t*>(scratch);            // kMatchMaxRef packed cells
-  uint32_t* rcell2 = rcell + kMatchMaxRef;                           // cells of the unexplained points
-  uint32_t* gtiles = rcell2 + kMatchMaxRef;
+  uint32_t* rcell = reinterpret_cast<uint32_t*>(scratch);            // P.ref_cap packed cells
+  uint32_t* rcell2 = rcell + P.ref_cap;                              // cells of the unexplained points
+  uint32_t* gtiles = rcell2 + P.ref_cap;
   const int DW = ((P.ny + 7) >> 3) + kMatchDirGuardY;
   for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
   for (int i = tid; i < P.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, pts2[2 * i], pts2[2 * i + 1]);

@@ -380,3 +380,50 @@ def make_scan_pairs(n_pairs: int, seed: int = 4242, n_beams: int = LASER_BEAMS,
     return dict(ranges_ref=ref, ranges_qry=qry, guess=guess, true_rel=true_rel,
                 angle_min=LASER_ANGLE_MIN, angle_inc=LASER_ANGLE_INC, max_range=LASER_MAX_RANGE,
                 n_beams=n_beams)
+
+
+def make_trajectory(n_steps: int = 400, seed: int = 31, n_beams: int = LASER_BEAMS, range_noise: float = 0.01,
+                    odom_noise=(0.004, 0.004, 0.002), laps: float = 1.25):
+    """A robot driving ``laps`` rounds of a rectangular corridor loop inside a room with pillars: true poses,
+    drifting odometry (what ``rh.getOdom()`` would return, srslam.cpp:195) and one 1081-beam scan per step.
+    Revisiting the start after one lap gives the front end loop-closure candidates."""
+    T = int(n_steps)
+    outer = (-9.0, -6.0, 9.0, 6.0)
+    inner = (-5.5, -2.5, 5.5, 2.5)                      # the block the corridor goes around
+    pillars = [(-8.2, 4.6, -7.6, 5.2), (7.4, -5.3, 8.1, -4.7), (-0.4, 4.4, 0.5, 5.3), (2.8, -5.4, 3.4, -4.6),
+               (-8.4, -1.0, -7.9, 0.2)]
+    boxes = [outer, inner] + pillars
+    # centre line of the corridor: rectangle through the middle of the ring, traversed counter-clockwise
+    cx0, cy0, cx1, cy1 = -7.25, -4.25, 7.25, 4.25
+    per = 2 * ((cx1 - cx0) + (cy1 - cy0))
+    s = np.linspace(0.0, laps * per, T) % per
+    truth = np.empty((T, 3))
+    for k, sk in enumerate(s):
+        if sk < (cx1 - cx0):
+            truth[k] = (cx0 + sk, cy0, 0.0)
+        elif sk < (cx1 - cx0) + (cy1 - cy0):
+            truth[k] = (cx1, cy0 + (sk - (cx1 - cx0)), np.pi / 2)
+        elif sk < 2 * (cx1 - cx0) + (cy1 - cy0):
+            truth[k] = (cx1 - (sk - (cx1 - cx0) - (cy1 - cy0)), cy1, np.pi)
+        else:
+            truth[k] = (cx0, cy1 - (sk - 2 * (cx1 - cx0) - (cy1 - cy0)), -np.pi / 2)
+    # smooth the heading around the corners (blend over ~1 m) so that consecutive scans overlap
+    th = np.unwrap(truth[:, 2])
+    kern = np.ones(9) / 9.0
+    th = np.convolve(np.pad(th, 4, mode="edge"), kern, mode="valid")
+    truth[:, 2] = normalize_theta(th)
+    # odometry = integrated noisy increments
+    odom = np.empty_like(truth)
+    odom[0] = truth[0]
+    nz = np.stack([normal(seed, 40 + c, T) * odom_noise[c] for c in range(3)], axis=1)
+    for k in range(1, T):
+        rel = se2_compose(se2_inverse(truth[k - 1][None, :]), truth[k][None, :])[0]
+        odom[k] = se2_compose(odom[k - 1][None, :], (rel + nz[k])[None, :])[0]
+    ang0 = LASER_ANGLE_MIN + LASER_ANGLE_INC * np.arange(n_beams)
+    scans = np.empty((T, n_beams), dtype=np.float32)
+    for k in range(T):
+        r = _raycast_boxes(truth[k, 0], truth[k, 1], truth[k, 2] + ang0, boxes, LASER_MAX_RANGE)
+        r = r + range_noise * normal(seed + 1, k, n_beams)
+        scans[k] = np.clip(r, 0.05, LASER_MAX_RANGE * 2).astype(np.float32)
+    return dict(truth=truth, odom=odom, scans=scans, angle_min=LASER_ANGLE_MIN, angle_inc=LASER_ANGLE_INC,
+                max_range=LASER_MAX_RANGE, n_beams=n_beams)
