@@ -18,6 +18,55 @@ ODOM_INFO = (100.0, 100.0, 1000.0)      # _odominf, src/slam/graph_slam.cpp:72-7
 SM_INFO = (1000.0, 1000.0, 10000.0)     # _SMinf,   src/slam/graph_slam.cpp:75-76
 
 
+class RobotLaser:
+    """The ``ROBOTLASER1`` data element g2o attaches to a vertex (RobotLaser::read/write [g2o-recalled], SURVEY.md
+    Appendix D): laser parameters, ranges, remissions, odometry pose and the laser's pose on the robot."""
+
+    def __init__(self, ranges, first_beam_angle, angular_step, max_range, odom_pose=(0.0, 0.0, 0.0),
+                 laser_pose=(0.0, 0.0, 0.0), laser_type=0, accuracy=0.1, remission_mode=0, fov=None, remissions=(),
+                 tail=("0", "0", "0", "0", "0"), timestamp="0", hostname="hostname", logger_timestamp="0"):
+        self.ranges = np.ascontiguousarray(ranges, dtype=np.float32)
+        self.first_beam_angle, self.angular_step, self.max_range = float(first_beam_angle), float(angular_step), float(max_range)
+        self.fov = float(angular_step) * len(self.ranges) if fov is None else float(fov)     # LaserParameters ctor
+        self.laser_type, self.accuracy, self.remission_mode = int(laser_type), float(accuracy), int(remission_mode)
+        self.remissions = np.ascontiguousarray(remissions, dtype=np.float64)
+        self.odom_pose = np.asarray(odom_pose, dtype=np.float64).copy()
+        self.laser_pose = np.asarray(laser_pose, dtype=np.float64).copy()                      # laser in the robot frame
+        self.tail = tuple(str(v) for v in tail)               # laserTv laserRv forwardSafetyDist sideSafetyDist turnAxis
+        self.timestamp, self.hostname, self.logger_timestamp = str(timestamp), str(hostname), str(logger_timestamp)
+
+    def write(self, fmt="%g"):
+        from .matcher import _se2_mul
+        w = _se2_mul(self.odom_pose, self.laser_pose)         # laser pose in the world
+        tok = ["ROBOTLASER1", str(self.laser_type), fmt % self.first_beam_angle, fmt % self.fov, fmt % self.angular_step,
+               fmt % self.max_range, fmt % self.accuracy, str(self.remission_mode), str(len(self.ranges))]
+        tok += [fmt % float(r) for r in self.ranges]
+        tok.append(str(len(self.remissions)))
+        tok += [fmt % float(r) for r in self.remissions]
+        tok += [fmt % v for v in (*w, *self.odom_pose)]
+        tok += [*self.tail, self.timestamp, self.hostname, self.logger_timestamp]
+        return " ".join(tok)
+
+    @classmethod
+    def read(cls, tok):
+        """``tok``: the whitespace-split line including the leading ROBOTLASER1 tag."""
+        from .matcher import _se2_inv, _se2_mul
+        laser_type, first, fov, step, max_range, acc = int(tok[1]), *(float(v) for v in tok[2:7])
+        rem_mode = int(tok[7])
+        nb = int(tok[8])
+        ranges = np.array([float(v) for v in tok[9:9 + nb]], dtype=np.float32)
+        q = 9 + nb
+        nr = int(tok[q])
+        rem = [float(v) for v in tok[q + 1:q + 1 + nr]]
+        q += 1 + nr
+        world = np.array([float(v) for v in tok[q:q + 3]])
+        odom = np.array([float(v) for v in tok[q + 3:q + 6]])
+        q += 6
+        return cls(ranges, first, step, max_range, odom_pose=odom, laser_pose=_se2_mul(_se2_inv(odom), world),
+                   laser_type=laser_type, accuracy=acc, remission_mode=rem_mode, fov=fov, remissions=rem,
+                   tail=tok[q:q + 5], timestamp=tok[q + 5], hostname=tok[q + 6], logger_timestamp=tok[q + 7])
+
+
 class PoseGraph:
     def __init__(self, ids, poses, fixed, edge_from, edge_to, meas, info, edge_level=None):
         self.ids = np.ascontiguousarray(ids, dtype=np.int64)
@@ -31,6 +80,7 @@ class PoseGraph:
         # (src/mrslam/condensed_graph/condensed_graph_buffer.cpp:469-473)
         self.edge_level = (np.zeros(len(self.edge_from), dtype=np.int32) if edge_level is None
                            else np.ascontiguousarray(edge_level, dtype=np.int32))
+        self.lasers = {}          # vertex index -> RobotLaser (user data; written/read as ROBOTLASER1 lines)
 
     @property
     def n_vertices(self):
@@ -51,13 +101,15 @@ class PoseGraph:
 
     # ---------------------------------------------------------------- .g2o text format
     def save_g2o(self, path, precision=None):
-        """VERTEX_SE2 / FIX / EDGE_SE2 lines.  ``precision=None`` reproduces g2o's default ostream
-        precision (6 significant digits, lossy -- SURVEY.md section 5); pass 17 for round trips."""
+        """VERTEX_SE2 (+ ROBOTLASER1 data) / FIX / EDGE_SE2 lines.  ``precision=None`` reproduces g2o's default
+        ostream precision (6 significant digits, lossy -- SURVEY.md section 5); pass 17 for round trips."""
         fmt = "%g" if precision is None else f"%.{precision}g"
         with open(path, "w") as f:
             for k in range(self.n_vertices):
                 x, y, t = self.poses[k]
                 f.write(f"VERTEX_SE2 {int(self.ids[k])} {fmt % x} {fmt % y} {fmt % t}\n")
+                if k in self.lasers:
+                    f.write(self.lasers[k].write(fmt) + "\n")      # saveUserData: the data lines follow their vertex
                 if self.fixed[k]:
                     f.write(f"FIX {int(self.ids[k])}\n")
             for k in range(self.n_edges):
@@ -71,6 +123,7 @@ class PoseGraph:
     @classmethod
     def load_g2o(cls, path):
         ids, poses, fixed_ids, ef, et, meas, info = [], [], set(), [], [], [], []
+        lasers = {}               # vertex id -> RobotLaser
         with open(path) as f:
             for line in f:
                 tok = line.split()
@@ -86,7 +139,8 @@ class PoseGraph:
                     et.append(int(tok[2]))
                     meas.append([float(v) for v in tok[3:6]])
                     info.append([float(v) for v in tok[6:12]])
-                # data lines (ROBOTLASER1 ...) belong to the preceding vertex and are not part of the solve
+                elif tok[0] == "ROBOTLASER1" and ids:
+                    lasers[ids[-1]] = RobotLaser.read(tok)     # data lines belong to the preceding vertex
         ids = np.asarray(ids, dtype=np.int64)
         order = np.argsort(ids, kind="stable")          # g2o keeps vertices in an id-ordered map
         ids = ids[order]
@@ -95,7 +149,9 @@ class PoseGraph:
         fixed = np.array([1 if int(v) in fixed_ids else 0 for v in ids], dtype=np.uint8)
         efi = np.array([index[v] for v in ef], dtype=np.int32)
         eti = np.array([index[v] for v in et], dtype=np.int32)
-        return cls(ids, poses, fixed, efi, eti, np.asarray(meas).reshape(-1, 3), np.asarray(info).reshape(-1, 6))
+        g = cls(ids, poses, fixed, efi, eti, np.asarray(meas).reshape(-1, 3), np.asarray(info).reshape(-1, 6))
+        g.lasers = {index[v]: l for v, l in lasers.items()}
+        return g
 
 
 class GraphSLAM:

@@ -21,7 +21,7 @@ import math
 
 import numpy as np
 
-from .graph import GraphSLAM, PoseGraph
+from .graph import GraphSLAM, PoseGraph, RobotLaser
 from .matcher import _se2_inv, _se2_mul, normalize_theta
 
 MAX_GRAPH_DIST_SM = 2.0     # vertices_finder.h:91-93
@@ -258,6 +258,15 @@ class GraphSLAMDriver(GraphSLAM):
     def _scans(self, vset):
         order = sorted(vset, key=lambda q: self.g.ids[q])
         return order, [(self.lasers[v], self.g.poses[v].copy()) for v in order]
+
+    def saveGraph(self, filename, precision=None):   # noqa: N802  (graph_slam.cpp:620-623: vertices carry their RobotLaser)
+        cfg = self.close_matcher.cfg
+        lp = [float(cfg.laser_pose[k]) for k in range(3)]
+        for idx, r in self.lasers.items():                       # optimize() leaves odomPose = the vertex estimate (:569-574)
+            self.g.lasers[idx] = RobotLaser(r, cfg.angle_min, cfg.angle_inc, cfg.max_range, odom_pose=self.g.poses[idx],
+                                            laser_pose=lp)
+        self.g.save_g2o(filename, precision)
+        return True
 
     # ------------------------------------------------------------------ graph_slam.cpp:87-122
     def setInitialData(self, initialOdom, ranges):   # noqa: N802,N803

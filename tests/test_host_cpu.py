@@ -70,3 +70,39 @@ def test_g2o_round_trip(tmp_path):
     pg.save_g2o(path)
     lossy = PoseGraph.load_g2o(path)
     assert np.abs(lossy.poses - pg.poses).max() < 1e-3
+
+
+def test_g2o_robotlaser1_lines(tmp_path):
+    """ROBOTLASER1 data lines (SURVEY.md Appendix D, RobotLaser::read/write [g2o-recalled]): parse a line laid out
+    by hand from the format, round-trip a graph with scans, and keep the solve arrays unaffected."""
+    from cg_mrslam_amd.graph import PoseGraph, RobotLaser
+    line = ("ROBOTLASER1 0 -1.5708 3.14159 0.785398 30 0.1 0 5 1.5 2 2.5 3 81.91 0 "
+            "1.2 0.4 0.6 1 0.3 0.6 0 0 0 0 0 1234.5 robot1 1234.6")
+    l = RobotLaser.read(line.split())
+    assert l.laser_type == 0 and len(l.ranges) == 5 and l.ranges[4] == np.float32(81.91) and len(l.remissions) == 0
+    assert l.first_beam_angle == -1.5708 and l.fov == 3.14159 and l.angular_step == 0.785398 and l.max_range == 30
+    np.testing.assert_allclose(l.odom_pose, [1, 0.3, 0.6])
+    # laser pose on the robot = odom^-1 * world pose: a pure forward offset of 0.2236... rotated back
+    c, s = np.cos(0.6), np.sin(0.6)
+    np.testing.assert_allclose(l.laser_pose, [c * 0.2 + s * 0.1, -s * 0.2 + c * 0.1, 0.0], atol=1e-12)
+    assert l.hostname == "robot1" and l.timestamp == "1234.5"
+    assert l.write().split()[:9] == line.split()[:9]
+
+    g = synth.make_pose_graph(12, 20, seed=3)
+    pg = PoseGraph.from_synth(g)
+    rng = np.random.default_rng(0)
+    for k in (0, 3, 11):
+        pg.lasers[k] = RobotLaser(rng.uniform(0.5, 20, size=181).astype(np.float32), -1.57, 0.0174533, 30.0,
+                                  odom_pose=pg.poses[k], laser_pose=(0.1, 0.0, 0.02))
+    path = tmp_path / "with_lasers.g2o"
+    pg.save_g2o(path, precision=17)
+    back = PoseGraph.load_g2o(path)
+    np.testing.assert_array_equal(back.poses, pg.poses)
+    np.testing.assert_array_equal(back.meas, pg.meas)
+    assert sorted(back.lasers) == [0, 3, 11]
+    for k in (0, 3, 11):
+        np.testing.assert_array_equal(back.lasers[k].ranges, pg.lasers[k].ranges)
+        np.testing.assert_allclose(back.lasers[k].laser_pose, [0.1, 0.0, 0.02], atol=1e-15)
+        np.testing.assert_allclose(back.lasers[k].odom_pose, pg.poses[k], atol=0)
+    text = open(path).read().splitlines()
+    assert text[0].startswith("VERTEX_SE2") and text[1].startswith("ROBOTLASER1") and text[2].startswith("FIX")

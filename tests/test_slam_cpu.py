@@ -88,7 +88,7 @@ def test_loop_closure_checker_separates_consistent_from_outlier():
     assert chi[0] < 2.0 and chi[1] < 2.0 and chi[2] > 2.0
 
 
-def test_driver_on_oracle_backend_short_run(oracle):
+def test_driver_on_oracle_backend_short_run(oracle, tmp_path):
     tr = synth.make_trajectory(60, laps=0.15)
     la = (tr["n_beams"], tr["angle_min"], tr["angle_inc"], tr["max_range"])
     slam = GraphSLAMDriver(OB.OracleContext(), OB.close_matcher(la), OB.lc_matcher(la))
@@ -101,3 +101,10 @@ def test_driver_on_oracle_backend_short_run(oracle):
     tp = tr["truth"]
     err = max(np.min(np.hypot(tp[:, 0] - p[0], tp[:, 1] - p[1])) for p in g.poses)
     assert err < 0.15
+    # saveGraph writes every vertex with its ROBOTLASER1 line (graph_slam.cpp:620-623); the scans survive a round trip
+    out = tmp_path / "robot-0-run.g2o"
+    slam.saveGraph(out, precision=17)
+    back = PoseGraph.load_g2o(out)
+    assert len(back.lasers) == n
+    np.testing.assert_array_equal(back.lasers[n - 1].ranges, slam.lasers[n - 1])
+    np.testing.assert_array_equal(back.poses, g.poses)
