@@ -215,6 +215,35 @@ int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, con
                       const double* pts1_xy, double nonmatched_score, const float lower_xy[2], const float upper_xy[2],
                       double* score_out, int* n_nonmatched_out);
 
+/* ------------------------------------------------------------------ occupancy map
+ * cgmr_occupancy_map replaces, for all scans of a graph at once, FrequencyMap::integrateScan + fillRobotPose
+ * (src/ros_map_publisher/frequency_map.cpp:27-103) over GridLineTraversal::gridLine
+ * (src/ros_map_publisher/grid_line_traversal.cpp:31-154) -- the loop of Graph2occupancy::computeMap
+ * (src/ros_map_publisher/graph2occupancy.cpp:120-122) -- and the frequency -> image conversion (:128-147).
+ * The map geometry (bounding box, size, offset; graph2occupancy.cpp:44-118) is host logic, see
+ * cg_mrslam_amd/occupancy.py.
+ *   cfg              FrequencyMap(resolution, offset, size); integrateScan's maxRange / usableRange /
+ *                    infinityFillingRange / gain / squareSize (negative ranges take the reference's defaults);
+ *                    LaserParameters (first beam angle, angular step, max range, laser pose on the robot);
+ *                    occupied / free thresholds
+ *   ranges           [n_scans * n_beams] float32
+ *   robot_poses_xyt  [n_scans * 3]       the (base-transformed) vertex estimates
+ *   hits_out, misses_out  [rows * cols] int32, cell (x, y) at x * cols + y (nullable)
+ *   image_out        [rows * cols] uint8: 0 free, 100 occupied, 255 unknown (nullable)
+ *   kernel_seconds_out    HIP-event time of the two kernels (nullable)                                      */
+typedef struct cgmr_occupancy_config {
+  float resolution, offset_x, offset_y;
+  int32_t rows, cols;
+  float max_range, usable_range, infinity_filling_range;
+  int32_t gain, square_size;
+  double first_beam_angle, angular_step, laser_max_range;
+  double laser_pose[3];
+  float threshold, free_threshold;
+} cgmr_occupancy_config;
+int cgmr_occupancy_map(cgmr_ctx* ctx, const cgmr_occupancy_config* cfg, int n_scans, int n_beams, const float* ranges,
+                       const double* robot_poses_xyt, int32_t* hits_out, int32_t* misses_out, uint8_t* image_out,
+                       double* kernel_seconds_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,3 +275,41 @@ def verify(ll, ur, res, kernel_res, kernel_range, pts2, pts1, lower_xy, upper_xy
                          _p(pts2, C.c_double), C.c_int(len(pts1)), _p(pts1, C.c_double), C.c_double(nonmatched_score),
                          _p(lo, C.c_float), _p(up, C.c_float), C.byref(score))
     return n, score.value
+
+
+# ---------------------------------------------------------------------------- occupancy map (occupancy_oracle.c)
+
+def grid_line(sx, sy, ex, ey, cap=65536):
+    px = np.zeros(cap, dtype=np.int32)
+    py = np.zeros(cap, dtype=np.int32)
+    n = lib().cfo_grid_line(C.c_int(sx), C.c_int(sy), C.c_int(ex), C.c_int(ey), _p(px, C.c_int), _p(py, C.c_int), C.c_int(cap))
+    return np.stack([px[:n], py[:n]], axis=1)
+
+
+def occupancy_integrate(rows, cols, resolution, offset, scans, poses, first_beam_angle, angular_step, laser_max_range,
+                        laser_pose=(0.0, 0.0, 0.0), max_range=-1.0, usable_range=-1.0, infinity_filling_range=-1.0, gain=1,
+                        square_size=1):
+    """Sequential FrequencyMap::integrateScan over all (scan, pose) pairs; returns (hits, misses) [rows, cols]."""
+    scans = _f32(scans)
+    poses = _f64(poses).reshape(-1, 3)
+    hits = np.zeros((rows, cols), dtype=np.int32)
+    misses = np.zeros((rows, cols), dtype=np.int32)
+    lp = _f64(laser_pose)
+    for k in range(len(scans)):
+        r = np.ascontiguousarray(scans[k])
+        p = np.ascontiguousarray(poses[k])
+        lib().cfo_integrate_scan(C.c_int(rows), C.c_int(cols), C.c_float(resolution), C.c_float(offset[0]), C.c_float(offset[1]),
+                                 C.c_int(len(r)), _p(r, C.c_float), C.c_double(first_beam_angle), C.c_double(angular_step),
+                                 C.c_double(laser_max_range), _p(lp, C.c_double), _p(p, C.c_double), C.c_float(max_range),
+                                 C.c_float(usable_range), C.c_float(infinity_filling_range), C.c_int(gain), C.c_int(square_size),
+                                 _p(hits, C.c_int32), _p(misses, C.c_int32))
+    return hits, misses
+
+
+def occupancy_image(hits, misses, threshold, free_threshold):
+    hits = np.ascontiguousarray(hits, dtype=np.int32)
+    misses = np.ascontiguousarray(misses, dtype=np.int32)
+    img = np.zeros(hits.shape, dtype=np.uint8)
+    lib().cfo_image(C.c_int(hits.shape[0]), C.c_int(hits.shape[1]), _p(hits, C.c_int32), _p(misses, C.c_int32),
+                    C.c_float(threshold), C.c_float(free_threshold), _p(img, C.c_uint8))
+    return img

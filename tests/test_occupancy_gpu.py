@@ -1,0 +1,73 @@
+"""Occupancy-map ray casting on the GPU (cgmr_occupancy_map) against the oracle: hits, misses and the image are
+integer / byte arrays and must match exactly, at test sizes and on a whole trajectory."""
+import numpy as np
+import pytest
+
+from cg_mrslam_amd import synth
+from cg_mrslam_amd.occupancy import Graph2occupancy
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_map(oracle, g2o, tposes, size, offset):
+    h, m = oracle.occupancy_integrate(size[0], size[1], float(g2o.resolution), (float(offset[0]), float(offset[1])), g2o.scans,
+                                      tposes, g2o.first_beam_angle, g2o.angular_step, g2o.laser_max_range,
+                                      laser_pose=g2o.laser_pose, max_range=float(g2o.max_range),
+                                      usable_range=float(g2o.usable_range),
+                                      infinity_filling_range=float(g2o.infinity_filling_range), gain=g2o.gain,
+                                      square_size=g2o.square_size)
+    return h, m, oracle.occupancy_image(h, m, float(g2o.threshold), float(g2o.free_threshold))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(squareSize=1, infinityFillingRange=-1.0, usableRange=6.0, angle=0.3),
+                                dict(rows=200, cols=180, gain=1, usableRange=4.0)])
+def test_map_matches_oracle(ctx, oracle, kw):
+    tr = synth.make_trajectory(40, laps=0.12, n_beams=361)
+    poses = tr["truth"][::4] + 0.01
+    scans = tr["scans"][::4].copy()
+    scans[3, 10:20] = 45.0                                    # out-of-range beams (infinity filling / skipped)
+    scans[5, 100] = 0.0
+    fixed = np.zeros(len(poses), dtype=bool)
+    fixed[0] = True
+    g = Graph2occupancy(ctx, poses, scans, -np.pi / 2, np.pi / 360, 30.0, laser_pose=(0.12, -0.03, 0.05), fixed=fixed, **kw)
+    assert g.computeMap()
+    tposes, size, offset = g.geometry()
+    h, m, img = _oracle_map(oracle, g, tposes, size, offset)
+    np.testing.assert_array_equal(g.hits, h)
+    np.testing.assert_array_equal(g.misses, m)
+    np.testing.assert_array_equal(g.image, img)
+    assert set(np.unique(g.image)) <= {0, 100, 255} and (g.image == 0).sum() > 500
+    if g.gain >= 3:                                           # with gain 1 the end cell's own miss keeps hits/(hits+misses) <= 1/2
+        assert (g.image == 100).sum() > 20
+
+
+def test_full_trajectory_properties(ctx, oracle):
+    """A whole lap (400 scans x 1081 beams): parity on a sample of scans is covered above; here size-independent
+    properties at full size -- integrating the scans in two halves and adding equals integrating them at once
+    (integer sums commute), and the count of misses equals the number of ray cells inside the map."""
+    tr = synth.make_trajectory(400, laps=1.0)
+    kw = dict(rows=700, cols=520, angle=0.0, infinityFillingRange=5.0, usableRange=8.0)
+    a = Graph2occupancy(ctx, tr["truth"], tr["scans"], tr["angle_min"], tr["angle_inc"], tr["max_range"], **kw)
+    assert a.computeMap()
+    # the halves share the geometry: same poses, explicit rows / cols
+    half = len(tr["truth"]) // 2
+    ranges1 = tr["scans"].copy(); ranges1[half:] = -1.0        # r <= 0 and no infinity filling -> skipped beams
+    ranges2 = tr["scans"].copy(); ranges2[:half] = -1.0
+    kw2 = dict(kw, infinityFillingRange=-1.0)
+    full = Graph2occupancy(ctx, tr["truth"], tr["scans"], tr["angle_min"], tr["angle_inc"], tr["max_range"], **kw2)
+    p1 = Graph2occupancy(ctx, tr["truth"], ranges1, tr["angle_min"], tr["angle_inc"], tr["max_range"], **kw2)
+    p2 = Graph2occupancy(ctx, tr["truth"], ranges2, tr["angle_min"], tr["angle_inc"], tr["max_range"], **kw2)
+    assert full.computeMap() and p1.computeMap() and p2.computeMap()
+    robot = 81 * len(tr["truth"])                               # fillRobotPose is done for every scan in all three
+    np.testing.assert_array_equal(full.hits, p1.hits + p2.hits)
+    assert int(full.misses.sum()) + robot == int(p1.misses.sum()) + int(p2.misses.sum())
+    # a sample of 12 scans against the oracle at full beam count
+    idx = np.arange(0, 400, 35)
+    s = Graph2occupancy(ctx, tr["truth"][idx], tr["scans"][idx], tr["angle_min"], tr["angle_inc"], tr["max_range"], **kw)
+    assert s.computeMap()
+    tposes, size, offset = s.geometry()
+    h, m, img = _oracle_map(oracle, s, tposes, size, offset)
+    np.testing.assert_array_equal(s.hits, h)
+    np.testing.assert_array_equal(s.misses, m)
+    np.testing.assert_array_equal(s.image, img)
+    print(f"400 scans x 1081 beams -> {size[0]}x{size[1]} map: kernels {a.kernel_seconds * 1e3:.2f} ms")
