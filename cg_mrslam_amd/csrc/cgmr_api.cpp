@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -200,6 +201,14 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
   cgmr_ctx* ctx;
   template <typename Fn>
   void run(int cls, int nlaunch, Fn&& fn) {
+    static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;      // debugging aid: name every launch, sync after it
+    if (trace) {
+      fprintf(stderr, "[cgmr] launch class %d (0 lin 1 asm 2 chi2 3 factor 4 update 6 bwd 7 poses)\n", cls);
+      fn();
+      hipError_t e = hipStreamSynchronize(ctx->stream);
+      fprintf(stderr, "[cgmr]   done: %s\n", hipGetErrorString(e));
+      return;
+    }
     if (!ctx->profiling) { fn(); return; }
     (void)hipEventRecord(ctx->ev_a, ctx->stream);
     fn();
@@ -222,7 +231,29 @@ void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double*
   T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
   if (chi_only || D.nf == 0) return;
   T.run(1, 1, [&] { launch_assemble(st, D); });
+  static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;
+  if (trace)
+    fprintf(stderr, "[cgmr] arena %p .. %p; work %p rel %p apack %p Ablk %p bvec %p yvec %p uvec %p Lbuf %p Ubuf %p chi2 %p\n",
+            (void*)ctx->gn_arena.ptr, (void*)(ctx->gn_arena.ptr + ctx->gn_arena.cap), (void*)D.work, (void*)D.rel, (void*)D.apack,
+            (void*)D.Ablk, (void*)D.bvec, (void*)D.yvec, (void*)D.uvec, (void*)D.Lbuf, (void*)D.Ubuf, (void*)D.chi2);
   for (int l = 0; l < D.nlevels; l++) {
+    if (trace) {
+      int maxr = 0, maxc = 0;
+      for (int q = D.h_level_ptr[l]; q < D.h_level_ptr[l + 1]; q++) {
+        const FrontDesc& F = ctx->sym.fronts[ctx->sym.level_fronts[q]];
+        maxr = std::max(maxr, 3 * F.ns);
+        for (int k = 0; k < F.nchild; k++) maxc = std::max(maxc, 3 * ctx->sym.fronts[ctx->sym.children[F.child_off + k]].ns);
+      }
+      if (D.h_level_ptr[l + 1] - D.h_level_ptr[l] <= 2)
+        for (int q = D.h_level_ptr[l]; q < D.h_level_ptr[l + 1]; q++) {
+          const FrontDesc& F = ctx->sym.fronts[ctx->sym.level_fronts[q]];
+          fprintf(stderr, "[cgmr]   front nc %d ns %d na %d nchild %d a_cnt %d L_off %lld U_off %lld:", F.nc, F.ns, F.na, F.nchild, F.a_cnt, (long long)F.L_off, (long long)F.U_off);
+          for (int k = 0; k < F.nchild; k++) { const FrontDesc& G = ctx->sym.fronts[ctx->sym.children[F.child_off + k]]; fprintf(stderr, " child(ns %d na %d U_off %lld)", G.ns, G.na, (long long)G.U_off); }
+          fprintf(stderr, "\n");
+        }
+      fprintf(stderr, "[cgmr] level %d: %d fronts, %d work items, max r %d, max child rows %d\n", l,
+              D.h_level_ptr[l + 1] - D.h_level_ptr[l], D.h_work_ptr[l + 1] - D.h_work_ptr[l], maxr, maxc);
+    }
     T.run(3, 1, [&] { launch_factor_level(st, D, l, it + 1, write_l11c); });
     if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
   }

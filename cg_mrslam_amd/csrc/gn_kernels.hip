@@ -171,7 +171,7 @@ constexpr int kL21 = 2 * W * W + W;
 constexpr int FUSE_R = 96;
 #ifdef CGMR_PHASE_TIMING
 __device__ unsigned long long g_phase[64 * 8];
-#define PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
+#define PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && level_id < 64) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
 #else
 #define PHASE(i)
 #endif           // fronts with r <= FUSE_R compute their update matrix in the factor kernel

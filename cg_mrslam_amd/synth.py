@@ -427,3 +427,29 @@ def make_trajectory(n_steps: int = 400, seed: int = 31, n_beams: int = LASER_BEA
         scans[k] = np.clip(r, 0.05, LASER_MAX_RANGE * 2).astype(np.float32)
     return dict(truth=truth, odom=odom, scans=scans, angle_min=LASER_ANGLE_MIN, angle_inc=LASER_ANGLE_INC,
                 max_range=LASER_MAX_RANGE, n_beams=n_beams)
+
+
+def make_lattice_graph(n: int = 60, seed: int = 5, spacing: float = 1.0):
+    """N x N lattice of poses with 4-neighbour edges: every nested-dissection separator is a line of ~N poses, so the
+    elimination tree has borders of several hundred rows at moderate vertex counts (multi-chunk fronts, children
+    with more rows than one staged map block, update matrices of thousands of rows)."""
+    V = n * n
+    ii, jj = np.divmod(np.arange(V), n)
+    truth = np.stack([spacing * jj.astype(np.float64), spacing * ii.astype(np.float64),
+                      2.0 * np.pi * uniform(seed, 1, V) - np.pi], axis=1)
+    right = np.flatnonzero(jj < n - 1)
+    down = np.flatnonzero(ii < n - 1)
+    e_from = np.concatenate([right, down]).astype(np.int32)
+    e_to = np.concatenate([right + 1, down + n]).astype(np.int32)
+    E = len(e_from)
+    rel = se2_compose(se2_inverse(truth[e_from]), truth[e_to])
+    info_d = np.tile(np.asarray(SM_INFO, dtype=np.float64), (E, 1))
+    noise = np.stack([normal(seed, 10 + k, E) for k in range(3)], axis=1) / np.sqrt(info_d)
+    meas = se2_compose(rel, noise)
+    info = np.zeros((E, 6))
+    info[:, 0], info[:, 3], info[:, 5] = info_d[:, 0], info_d[:, 1], info_d[:, 2]
+    poses = truth + 0.02 * np.stack([normal(seed, 20 + k, V) for k in range(3)], axis=1)
+    poses[0] = truth[0]
+    fixed = np.zeros(V, dtype=np.uint8)
+    fixed[0] = 1
+    return dict(truth=truth, poses=poses, fixed=fixed, edge_from=e_from, edge_to=e_to, meas=meas, info=info)

@@ -66,6 +66,21 @@ def test_fronts_with_many_children_and_wide_borders(ctx, oracle, K, Lc, H):
     _check(p, chi, p2, chi2)
 
 
+@pytest.mark.parametrize("n", [40, 80, 120])
+def test_lattice_wide_borders(ctx, oracle, n):
+    """N x N lattices: separators of ~N poses -> borders up to 180 poses (540 rows): fronts split into several
+    191-row chunks, children with more rows than one staged map block, update matrices on the tile kernel."""
+    from cg_mrslam_amd._lib import gn_symbolic_info
+    g = synth.make_lattice_graph(n)
+    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+    info = gn_symbolic_info(n * n, g["fixed"], g["edge_from"], g["edge_to"])
+    assert info["max_border"] >= n
+    rc, p, chi = ctx.gn_optimize(*a, 4)
+    st, p2, chi2, _ = oracle.gn_optimize(*a, 4)
+    assert rc == 0 and st == 0
+    _check(p, chi, p2, chi2)
+
+
 def test_gpu_full_size_c2(ctx, oracle):
     """BASELINE.json configs[1]: 10k vertices / 40k edges, optimize(10)."""
     g = synth.make_pose_graph(10000, 40000, seed=12345)
