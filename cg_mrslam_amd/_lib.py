@@ -191,8 +191,8 @@ class Context:
         sec = np.zeros(8)
         n = np.zeros(8, dtype=np.int64)
         self._check(self.lib.cgmr_gn_kernel_times(self.h, _ptr(sec), _ptr(n)))
-        names = ["linearize", "assemble", "chi2", "front_factor", "front_update", "solve_fwd", "solve_bwd", "update"]
-        return {k: (float(s), int(c)) for k, s, c in zip(names, sec, n)}
+        names = ["linearize", "assemble", "chi2", "front_factor", "front_update", "unused", "solve_bwd", "update"]
+        return {k: (float(s), int(c)) for k, s, c in zip(names, sec, n) if k != "unused"}
 
 
 def gn_symbolic_info(nV, fixed, ef, et, want_perm=False):

@@ -36,7 +36,7 @@ int set_err(cgmr_ctx* ctx, int code, const char* fmt, ...) {
 
 int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes) {
   if (bytes <= A.cap) return 0;
-  if (A.ptr) { hipStreamSynchronize(ctx->stream); hipFree(A.ptr); A.ptr = nullptr; A.cap = 0; }
+  if (A.ptr) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(A.ptr); A.ptr = nullptr; A.cap = 0; }
   size_t want = bytes + bytes / 4 + (1 << 20);
   hipError_t e = hipMalloc((void**)&A.ptr, want);
   if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
@@ -46,7 +46,7 @@ int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes) {
 
 int pinned_reserve(cgmr_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->pinned_cap) return 0;
-  if (ctx->pinned) { hipStreamSynchronize(ctx->stream); hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+  if (ctx->pinned) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
   size_t want = bytes + bytes / 4 + (1 << 16);
   hipError_t e = hipHostMalloc((void**)&ctx->pinned, want, hipHostMallocDefault);
   if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
@@ -445,21 +445,27 @@ int cgmr_ctx_create(int device, void* hip_stream, cgmr_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return CGMR_E_HIP; }
     ctx->own_stream = true;
   }
-  hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1); hipEventCreate(&ctx->ev_a); hipEventCreate(&ctx->ev_b);
+  if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipEventCreate(&ctx->ev_a) != hipSuccess || hipEventCreate(&ctx->ev_b) != hipSuccess) {
+    cgmr_ctx_destroy(ctx);
+    return CGMR_E_HIP;
+  }
   *out = ctx;
   return CGMR_OK;
 }
 
 void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  if (ctx->gn_arena.ptr) hipFree(ctx->gn_arena.ptr);
-  if (ctx->io_arena.ptr) hipFree(ctx->io_arena.ptr);
-  if (ctx->mt_arena.ptr) hipFree(ctx->mt_arena.ptr);
-  if (ctx->pinned) hipHostFree(ctx->pinned);
-  hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1); hipEventDestroy(ctx->ev_a); hipEventDestroy(ctx->ev_b);
-  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  // teardown: nothing useful can be done with a failing free, the statuses are dropped on purpose
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->gn_arena.ptr) (void)hipFree(ctx->gn_arena.ptr);
+  if (ctx->io_arena.ptr) (void)hipFree(ctx->io_arena.ptr);
+  if (ctx->mt_arena.ptr) (void)hipFree(ctx->mt_arena.ptr);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_a, ctx->ev_b})
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 

@@ -253,14 +253,12 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
   double* qraw = reinterpret_cast<double*>(my);                           // 2 * MAXPTS
   double* qpts = qraw + 2 * MAXPTS;                                       // 2 * MAXPTS
   uint32_t* gtiles = reinterpret_cast<uint32_t*>(qpts + 2 * MAXPTS);      // overflow tiles
-  const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
-  // directory with a guard band (1 tile row above/below, 3 tile columns left/right) so that the fast search
+  const int nty = (P.ny + 7) >> 3;
+  // directory with a guard band (1 tile row left/right, 3 tile columns below and 4 above) so that the fast search
   // path can look up cells outside the grid without a bounds test: guard entries point at the all-zero tile
   const int DW = nty + kMatchDirGuardY;
-  const int ndir = (ntx + 2) * DW;
 #define DIRIDX(tx, ty) (((tx) + 1) * DW + (ty) + 3)
   const int K2 = P.fill;
-  const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
   for (int q = tid; q < P.kdim * P.kdim; q += CB_THREADS) S.kernel[q] = kernel_lut[q];
 
   // pairs are handed out through a counter (err[1], starts at gridDim.x): a slow pair (generic path) does not
@@ -353,9 +351,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     }
     __syncthreads();
     build_grid(S, P, rcell, B, gtiles, /*allow_fast=*/true, err);
-    const int ntile = S.misc[0];
     const bool fast = S.misc[12] != 0;
-    const int T_ZERO = ntile + 1;
     MPHASE(5);
     // ---------------- search window, angle table, bins -----------------------------------------------------
     if (tid == 0) {

@@ -93,7 +93,8 @@ int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]);
 
 /* Per-kernel-class device time of GN runs made while profiling is on (HIP events around every
  * launch; slows the run down -- bench.py uses it only for the roofline figure).
- * classes: 0 linearize 1 assemble 2 chi2 3 front_factor 4 front_update 5 solve_fwd 6 solve_bwd 7 update
+ * classes: 0 linearize 1 assemble 2 chi2 3 front_factor 4 front_update 5 (unused: the forward solve rides
+ * through front_factor) 6 solve_bwd 7 update
  * seconds_out[8], launches_out[8] are accumulated since profiling was switched on.       */
 int cgmr_set_profiling(cgmr_ctx* ctx, int on);
 int cgmr_gn_kernel_times(const cgmr_ctx* ctx, double seconds_out[8], int64_t launches_out[8]);
