@@ -69,6 +69,9 @@ struct BlobLayout {
 
 // Lay out and upload the structure arrays; point GnDevice into the arena.
 int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t* et, int iters) {
+  // the factor kernels keep row positions (own columns + border rows) in 16-bit LDS maps
+  if (3 * (int64_t)S.max_ns + kFrontW > 32767)
+    return set_err(ctx, CGMR_E_INVALID, "a front has %d border poses; at most %d are supported", S.max_ns, (32767 - kFrontW) / 3);
   GnDevice& D = ctx->gn;
   D.nV = S.nV; D.nE = S.nE; D.nf = S.nf; D.nb = S.nb;
   D.nfronts = (int)S.fronts.size();
