@@ -83,6 +83,25 @@ def test_small_scans_and_single_pair(ctx, oracle):
     assert np.array_equal(got1[1][0], got[1][0])
 
 
+def test_scattered_scans_take_the_overflow_paths(ctx, oracle):
+    """Scans whose points do not lie on walls: (a) a reference scan that touches more tiles than the LDS pool holds
+    (tiles spill to HBM, the pair takes the bounds-checked search), (b) a query scan with more subsampled points
+    than one point list holds (half the wavefronts search with two lists each), (c) both at once.  Results must
+    still be bit-identical to the oracle."""
+    sp = synth.make_scan_pairs(4, seed=82)
+    rng = np.random.default_rng(5)
+    scattered = lambda: rng.uniform(1.0, 14.0, size=sp["n_beams"]).astype(np.float32)   # noqa: E731
+    rr, rq, g = sp["ranges_ref"].copy(), sp["ranges_qry"].copy(), sp["guess"].copy()
+    rr[0] = scattered()                        # (a)
+    rq[1] = scattered()                        # (b)
+    rr[2] = scattered(); rq[2] = rr[2] + rng.normal(scale=0.01, size=sp["n_beams"]).astype(np.float32)   # (c), matchable
+    g[2] = 0.0
+    m = _matcher(ctx, sp)
+    got = m.closeScanMatching(rr, rq, g, maxScore=0.3)
+    _assert_same(got, _oracle(oracle, sp, rr, rq, g, max_score=0.3))
+    assert got[0][2] and np.abs(got[1][2]).max() < 0.05       # the scattered scan matches itself at the origin
+
+
 def test_batch_recovers_truth_and_is_order_independent(ctx):
     """Size-independent properties on a larger batch: the match recovers the true motion to within a cell /
     angle step for the vast majority of pairs, and a pair's result does not depend on its position in the batch."""
