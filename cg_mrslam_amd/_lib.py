@@ -21,7 +21,8 @@ class CgmrError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libcgmr.so")
+    # CGMR_LIB: load another build of the same library (A/B runs of kernel variants); default = the in-tree build
+    return os.environ.get("CGMR_LIB") or os.path.join(_HERE, "libcgmr.so")
 
 
 def build_library(force: bool = False) -> str:

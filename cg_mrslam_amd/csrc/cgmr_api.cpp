@@ -577,3 +577,20 @@ int cgmr_gn_kernel_times(const cgmr_ctx* ctx, double seconds_out[8], int64_t lau
 }
 
 }  // extern "C"
+
+// Debugging aid: the (front, chunk) of every work item of the last analysed graph, and each front's parent / level.
+extern "C" int cgmr_debug_worklist(const cgmr_ctx* ctx, int32_t* front_out, int32_t* chunk_out, int cap, int32_t* parent_out,
+                                   int32_t* level_out, int32_t* ns_out, int fcap) {
+  if (!ctx) return -1;
+  const Symbolic& S = ctx->sym;
+  int n = 0;
+  for (int l = 0; l + 1 < (int)S.level_ptr.size(); l++)
+    for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
+      int f = S.level_fronts[q];
+      int r = 3 * S.fronts[f].ns;
+      int nchunk = std::max(1, (r + kChunkRows - 1) / kChunkRows);
+      for (int c = 0; c < nchunk; c++) { if (n < cap) { front_out[n] = f; chunk_out[n] = c; } n++; }
+    }
+  for (int f = 0; f < (int)S.fronts.size() && f < fcap; f++) { parent_out[f] = S.fronts[f].parent; level_out[f] = S.fronts[f].level; ns_out[f] = S.fronts[f].ns; }
+  return n;
+}

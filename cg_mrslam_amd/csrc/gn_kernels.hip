@@ -168,13 +168,14 @@ __global__ __launch_bounds__(1024) void k_chi2_reduce(int nE, const double* __re
 constexpr int kL11c = W * W;
 constexpr int kDinv = 2 * W * W;
 constexpr int kL21 = 2 * W * W + W;
-constexpr int FUSE_R = 96;
 #ifdef CGMR_PHASE_TIMING
 __device__ unsigned long long g_phase[64 * 8];
+__device__ unsigned long long g_wtime[2 * 8192];          // per work item of k_front_factor: start / end (100 MHz)
+__device__ unsigned long long g_utime[2 * 64];             // per level of k_front_update: min start / max end
 #define PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && level_id < 64) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
 #else
 #define PHASE(i)
-#endif           // fronts with r <= FUSE_R compute their update matrix in the factor kernel
+#endif
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -193,7 +194,6 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 
 constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record / whose maps are staged together
 constexpr int kRecInts = (int)(sizeof(WorkRec) / 4);
-constexpr int TRI_U = 19;            // trailing-block cells per thread and child (lower triangle of 96 x 96 over 256 threads)
 constexpr int MAPW = 256;            // child rows per staged block of the row map (one per thread)
 constexpr int SU = 24;               // double2 loads per thread and block: 256 rows x 48 columns of a child's leading slab
 // Update matrix of a front with r border rows, the first ra of which fall into its parent's own columns
@@ -209,17 +209,12 @@ __device__ __forceinline__ size_t uidx(int gi, int gj, int r, int ra) {
 }
 // LDS plan of k_front_factor (bytes), one workgroup per CU:
 //   Ls   [W][LDW]  doubles   F11 (assembly), later the staging buffer of L11 for coalesced copies
-//   R    [CH][LDW] doubles   chunk of F21 + the rhs row (assembly), later L21 rows for the fused update
-//   Uacc [FUSE_R][FUSE_R+1]  extend-add accumulator of the fused update; starts behind row FUSE_R of R
-//                            (only fronts with r <= FUSE_R use it, and those use rows 0..FUSE_R of R only)
+//   R    [CH][LDW] doubles   chunk of F21 + the rhs row (assembly)
 //   maps: s_rmap[MAXC][MAPW] (child row -> position in my row list), s_cmap[MAXC][W] shorts; the work record
 //   Dinv [W], Pan[2][W][8] doubles: the published 8-column panel of L11 (double buffered), Ys[W]
 constexpr int kOffLs = 0;
 constexpr int kOffR = kOffLs + W * LDW * 8;
-constexpr int kOffUacc = kOffR + (FUSE_R + 1) * LDW * 8;
-constexpr int kUaccBytes = FUSE_R * (FUSE_R + 1) * 8;
-constexpr int kEndR = kOffR + CH * LDW * 8;
-constexpr int kOffRmap = (kEndR > kOffUacc + kUaccBytes) ? kEndR : (kOffUacc + kUaccBytes);
+constexpr int kOffRmap = kOffR + CH * LDW * 8;
 constexpr int kOffCmap = kOffRmap + 2 * MAXC * MAPW;
 constexpr int kOffRec = ((kOffCmap + 2 * MAXC * W + 15) / 16) * 16;
 constexpr int kOffDinv = ((kOffRec + 4 * kRecInts + 15) / 16) * 16;
@@ -313,14 +308,6 @@ __device__ __forceinline__ void slab_scatter(const SlabLoads& S, const SlabGeom&
   }
 }
 
-// cell t of a row-major packed lower triangle -> (i, j), j <= i
-__device__ __forceinline__ void tri_cell(int t, int& i, int& j) {
-  i = (int)((__builtin_amdgcn_sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);     // estimate, corrected below
-  while (i * (i + 1) / 2 > t) i--;
-  while ((i + 1) * (i + 2) / 2 <= t) i++;
-  j = t - i * (i + 1) / 2;
-}
-
 // child ci of the front: descriptor from the work record (first MAXC children) or from the front table
 __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDesc* __restrict__ fronts,
                                                const int32_t* __restrict__ children, int child_off, int ci) {
@@ -342,10 +329,9 @@ __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDes
 //   (3) the children's leading slabs, streamed front to back with 16-byte loads, two children in flight, and
 //       scattered into LDS through the maps.  Children are added in a fixed order with a barrier in between:
 //       no atomics, bit-reproducible.
-// Then
-//   B+C. right-looking tall-panel factorisation (see below);
-//   D.   small fronts (r <= FUSE_R) also form their update matrix U = ext_add - L21 L21^T: the trailing
-//        blocks of the first two children are fetched before B+C starts and consumed after it.
+// Then the right-looking tall-panel factorisation (see below) and the stores.  The update matrix
+// U = ext_add - L21 L21^T of every front is formed by k_front_update, whose tiles spread over the idle CUs: forming
+// it here (tried for fronts of up to 96 border rows) made those fronts the slowest workgroup of their level.
 __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
                                                          const FrontDesc* __restrict__ fronts,
                                                          const int32_t* __restrict__ children,
@@ -359,7 +345,6 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* Ls = reinterpret_cast<double*>(smem + kOffLs);
   double* R = reinterpret_cast<double*>(smem + kOffR);
-  double* Uacc = reinterpret_cast<double*>(smem + kOffUacc);
   short* s_rmap = reinterpret_cast<short*>(smem + kOffRmap);
   short* s_cmap = reinterpret_cast<short*>(smem + kOffCmap);
   int* s_rec = reinterpret_cast<int*>(smem + kOffRec);
@@ -367,6 +352,9 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   double* Pan = reinterpret_cast<double*>(smem + kOffPan);
   double* Ys = reinterpret_cast<double*>(smem + kOffYs);
   const int tid = threadIdx.x;
+#ifdef CGMR_PHASE_TIMING
+  if (tid == 0 && work_begin + (int)blockIdx.x < 8192) g_wtime[2 * (work_begin + blockIdx.x)] = __builtin_amdgcn_s_memrealtime();
+#endif
   PHASE(0);
   // ---- round 1: the work record; LDS is cleared while it is in flight
   {
@@ -379,14 +367,12 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   PHASE(1);
   const WorkRec* WR = reinterpret_cast<const WorkRec*>(s_rec);
   const int c0 = rfl(WR->F.c0), nc = rfl(WR->F.nc), ns = rfl(WR->F.ns), rows_off = rfl(WR->F.rows_off);
-  const int child_off = rfl(WR->F.child_off), nchild = rfl(WR->F.nchild), my_na = rfl(WR->F.na);
+  const int child_off = rfl(WR->F.child_off), nchild = rfl(WR->F.nchild);
   const int a_off = rfl(WR->F.a_off), a_cnt = rfl(WR->F.a_cnt), chunk = rfl(WR->chunk);
-  const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off);
+  const long long L_off = rfl64(WR->F.L_off);
   const int w = 3 * nc, r = 3 * ns;
   const int r0 = chunk * kChunkRows;
   const int nr = max(0, min(kChunkRows, r - r0));   // border rows of this chunk; staging row nr carries the rhs
-  const bool fused = r > 0 && r <= FUSE_R;
-  constexpr int LDU = FUSE_R + 1;
   // ---- round 2: rhs, H blocks, the children's row maps (first batch, first block) -- every load first ...
   const int ncb0 = min(nchild, MAXC);
   const double bv = (tid < w) ? bvec[3 * c0 + tid] : 0.0;
@@ -411,8 +397,6 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   // ... then the LDS writes
   if (tid >= w && tid < W) Ls[tid * LDW + tid] = 1.0;        // identity padding of the unused columns
   if (tid < w) R[nr * LDW + tid] = bv;                        // rhs row: b of my columns (+ children below)
-  if (fused)
-    for (int q = tid; q < r * LDU; q += 256) Uacc[q] = 0.0;
 #pragma unroll
   for (int u = 0; u < AU; u++) {
     if (apk[u] < 0) continue;
@@ -493,33 +477,6 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
       SlabLoads S0;
       slab_issue(S0, g, tid, Ubuf + G.U_off, uvec + (size_t)3 * G.rows_off, rg, even_up(ra), row0);
       slab_scatter(S0, g, tid, rg, ra, row0, s_rmap, s_cmap, w, r0, nr, Ls);
-    }
-  }
-  // ---- D (prefetch): trailing blocks of the first two children for the fused update, consumed after B+C.
-  // (fused fronts: r <= FUSE_R, so every child has fewer than MAPW rows and its whole map sits in s_rmap;
-  //  with more than MAXC children map slot 0 was overwritten above: those fronts take the streamed path)
-  const bool pre = fused && ncb0 > 0 && nchild <= MAXC;
-  double vT[2][TRI_U];
-  int tij[TRI_U];                                        // cell t = tid + 256 u of a packed lower triangle: i << 8 | j
-  if (pre) {
-#pragma unroll
-    for (int u = 0; u < TRI_U; u++) {
-      int i, j;
-      tri_cell(tid + 256 * u, i, j);
-      tij[u] = (i << 8) | j;
-    }
-#pragma unroll
-    for (int cc = 0; cc < 2; cc++) {
-      const int ci = min(cc, ncb0 - 1);
-      const int rg = 3 * WR->ch[ci].ns, ra = 3 * WR->ch[ci].na;
-      const int nbb = (cc < ncb0) ? rg - ra : 0;                // child border rows that land in my border
-      const int ncell = nbb * (nbb + 1) / 2;
-      const double* B = Ubuf + WR->ch[ci].U_off + (size_t)rg * even_up(ra);
-#pragma unroll
-      for (int u = 0; u < TRI_U; u++) {
-        const bool ok = tid + 256 * u < ncell;
-        vT[cc][u] = B[ok ? (size_t)(tij[u] >> 8) * nbb + (tij[u] & 255) : 0];
-      }
     }
   }
   __syncthreads();
@@ -617,11 +574,6 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
     double* dst = P + kL21 + (size_t)(r0 + tid - 64) * W;
 #pragma unroll
     for (int k = 0; k < W; k += 2) *reinterpret_cast<double2*>(dst + k) = make_double2(x[k], x[k + 1]);
-    if (fused) {
-      double* rr = R + (tid - 64) * LDW;
-#pragma unroll
-      for (int k = 0; k < W; k++) rr[k] = x[k];
-    }
   } else if (tid - 64 == nr) {
     // the rhs row went through the same solve / trailing updates as a border row: it now holds y = L11^-1 t
 #pragma unroll
@@ -651,102 +603,15 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
     uvec[(size_t)3 * rows_off + r0 + tid - 64] = R[(tid - 64) * LDW + W] - dot;
   }
   PHASE(5);
-  // ---- D. fused update matrix for small fronts (single chunk: R holds all of L21)
-  if (fused) {
-    // children in order: the prefetched trailing blocks of the first two, then any further ones streamed
-    if (pre) {
-#pragma unroll
-      for (int cc = 0; cc < 2; cc++) {
-        if (cc < ncb0) {
-          const int rg = 3 * WR->ch[cc].ns, ra = 3 * WR->ch[cc].na;
-          const int nbb = rg - ra;
-          const int ncell = nbb * (nbb + 1) / 2;
-          const short* pos = s_rmap + cc * MAPW + ra;          // position of trailing row i in my row list (>= w)
-          int tg[TRI_U];
-#pragma unroll
-          for (int u = 0; u < TRI_U; u++) {
-            const bool ok = tid + 256 * u < ncell;
-            tg[u] = ok ? (pos[tij[u] >> 8] - w) * LDU + pos[tij[u] & 255] - w : -1;
-          }
-#pragma unroll
-          for (int u = 0; u < TRI_U; u++)
-            if (tg[u] >= 0) lds_add(&Uacc[tg[u]], vT[cc][u]);
-        }
-        __syncthreads();
-      }
-    }
-    for (int ci = pre ? 2 : 0; ci < nchild; ci++) {
-      const WorkChild G = get_child(WR, fronts, children, child_off, ci);
-      const int rg = 3 * G.ns, ra = 3 * G.na;
-      const int nbb = rg - ra;
-      if (nbb <= 0) continue;
-      const double* B = Ubuf + G.U_off + (size_t)rg * even_up(ra);
-      short* pos = s_rmap + (pre ? ci : 0) * MAPW;
-      if (!pre) {                                          // maps not resident: stage the trailing rows' positions
-        __syncthreads();
-        for (int q = tid; q < nbb; q += 256) {
-          int k = ra + q;
-          pos[q] = (short)(3 * rel[G.rel_off + k / 3] + k % 3);
-        }
-        __syncthreads();
-      } else pos += ra;
-      const int ncell = nbb * (nbb + 1) / 2;
-      for (int t0 = 0; t0 < ncell; t0 += 256 * 8) {
-        double v[8];
-        int tg[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int t = t0 + tid + 256 * u;
-          int i, j;
-          tri_cell(min(t, ncell - 1), i, j);
-          v[u] = B[(size_t)i * nbb + j];
-          tg[u] = (t < ncell) ? (pos[i] - w) * LDU + pos[j] - w : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (tg[u] >= 0) lds_add(&Uacc[tg[u]], v[u]);
-      }
-      __syncthreads();
-    }
-    double* Uo = Ubuf + U_off;
-    const int my_ra = 3 * my_na;
-    const int T4 = (r + 3) / 4;
-    for (int q = tid; q < T4 * T4; q += 256) {
-      int bi = q / T4, bj = q - bi * T4;
-      if (bj > bi) continue;
-      double acc[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
-      const double* Ri = R + (4 * bi) * LDW;
-      const double* Rj = R + (4 * bj) * LDW;
-      for (int k = 0; k < w; k++) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) { av[a] = Ri[a * LDW + k]; bv[a] = Rj[a * LDW + k]; }
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int b = 0; b < 4; b++) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-      }
-#pragma unroll
-      for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          int gi = 4 * bi + a, gj = 4 * bj + b;
-          if (gi < r && gj <= gi) Uo[uidx(gi, gj, r, my_ra)] = Uacc[gi * LDU + gj] - acc[a][b];
-        }
-    }
-  }
 #ifdef CGMR_PHASE_TIMING
   __syncthreads();
+  if (tid == 0 && work_begin + (int)blockIdx.x < 8192) g_wtime[2 * (work_begin + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
   PHASE(6);
 }
 
 // --------------------------------------------------------------------------- front update
-// Fronts with r > FUSE_R: one workgroup per lower 32x32 tile of the update matrix,
+// Every front with a border: one workgroup per lower 32x32 tile of the update matrix,
 //   U = extend_add(children's trailing blocks) - L21 L21^T
 __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restrict__ fronts,
                                                       const int32_t* __restrict__ tiles, int tile_begin,
@@ -954,6 +819,9 @@ void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
 }  // namespace cgmr
 
 #ifdef CGMR_PHASE_TIMING
+extern "C" int cgmr_debug_worktimes(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_wtime), sizeof(unsigned long long) * 2 * 8192);
+}
 extern "C" int cgmr_debug_phase(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_phase), sizeof(unsigned long long) * 64 * 8);
 }
