@@ -87,6 +87,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
       int f = S.level_fronts[q];
       int r = 3 * S.fronts[f].ns;
       int nchunk = std::max(1, (r + kChunkRows - 1) / kChunkRows);
+      const int rec0 = (int)work.size();      // the front's first work record: the update tiles address the front through it
       for (int c = 0; c < nchunk; c++) {
         WorkRec wr;
         memset(&wr, 0, sizeof wr);
@@ -101,10 +102,10 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
         }
         work.push_back(wr);
       }
-      if (r <= kFuseRows) continue;          // update matrix formed inside k_front_factor
+      if (r == 0) continue;                   // a root: no update matrix
       int T = (r + 31) / 32;
       for (int ti = 0; ti < T; ti++)
-        for (int tj = 0; tj <= ti; tj++) { tiles.push_back(f); tiles.push_back(ti); tiles.push_back(tj); }
+        for (int tj = 0; tj <= ti; tj++) { tiles.push_back(rec0); tiles.push_back(ti); tiles.push_back(tj); }
     }
     D.h_tile_ptr[l + 1] = (int)tiles.size() / 3;
     D.h_work_ptr[l + 1] = (int)work.size();

@@ -613,28 +613,86 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
 // --------------------------------------------------------------------------- front update
 // Every front with a border: one workgroup per lower 32x32 tile of the update matrix,
 //   U = extend_add(children's trailing blocks) - L21 L21^T
-__global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restrict__ fronts,
+// Like the factor kernel this one is a chain of memory round trips, kept to four: tile entry -> the front's work
+// record (front + first MAXC children) -> the two 32-row slices of L21 and, for every child, the rows of its
+// trailing block that feed this tile (inv maps) -> the children's values; the product runs while they are in
+// flight.  Children are added in child order after the product: same sums as a sequential extend-add.
+__global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict__ work,
                                                       const int32_t* __restrict__ tiles, int tile_begin,
+                                                      const FrontDesc* __restrict__ fronts,
                                                       const int32_t* __restrict__ children,
                                                       const int32_t* __restrict__ inv,
                                                       const double* __restrict__ Lbuf, double* __restrict__ Ubuf) {
   __shared__ double Ai[TS * LDW];
   __shared__ double Aj[TS * LDW];
+  __shared__ __attribute__((aligned(8))) int s_rec[kRecInts];
+  __shared__ short s_k[MAXC][2 * TS];                        // per child: child row of tile row i / tile column j, or -1
   const int tid = threadIdx.x;
   const int32_t* tl = tiles + 3 * (size_t)(tile_begin + blockIdx.x);
-  const FrontDesc F = fronts[tl[0]];
-  const int ti = tl[1], tj = tl[2];
-  const int r = 3 * F.ns;
-  const double* L21 = Lbuf + F.L_off + kL21;
+  const int rec = tl[0], ti = tl[1], tj = tl[2];
+  if (tid < kRecInts) s_rec[tid] = reinterpret_cast<const int*>(work + rec)[tid];
+  __syncthreads();
+  const WorkRec* WR = reinterpret_cast<const WorkRec*>(s_rec);
+  const int r = 3 * rfl(WR->F.ns), my_ra = 3 * rfl(WR->F.na), nchild = rfl(WR->F.nchild), child_off = rfl(WR->F.child_off);
+  const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off);
+  const int ncb = min(nchild, MAXC);
+  const double* L21 = Lbuf + L_off + kL21;
   const int i0 = ti * TS, j0 = tj * TS;
-  for (int q = tid; q < TS * W; q += 256) {
-    int row = q / W, k = q - row * W;
-    Ai[row * LDW + k] = (i0 + row < r) ? L21[(size_t)(i0 + row) * W + k] : 0.0;
-    Aj[row * LDW + k] = (j0 + row < r) ? L21[(size_t)(j0 + row) * W + k] : 0.0;
+  // ---- the two L21 slices and every child's row lookups: all loads first, then the LDS writes
+  constexpr int LQ = TS * W / 256;                            // 6 elements of each slice per thread
+  double li[LQ], lj[LQ];
+#pragma unroll
+  for (int u = 0; u < LQ; u++) {
+    const int q = tid + 256 * u;
+    const int row = q / W, k = q - row * W;
+    li[u] = (i0 + row < r) ? L21[(size_t)(i0 + row) * W + k] : 0.0;
+    lj[u] = (j0 + row < r) ? L21[(size_t)(j0 + row) * W + k] : 0.0;
+  }
+  int kb[MAXC];
+  const int pq = (tid < TS) ? i0 + tid : j0 + tid - TS;       // threads 0..31: tile rows, 32..63: tile columns
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    const int cs = min(c, max(ncb - 1, 0));
+    kb[c] = (tid < 2 * TS && pq < r && c < ncb) ? inv[WR->ch[cs].inv_off + pq / 3] : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < LQ; u++) {
+    const int q = tid + 256 * u;
+    const int row = q / W, k = q - row * W;
+    Ai[row * LDW + k] = li[u];
+    Aj[row * LDW + k] = lj[u];
+  }
+  if (tid < 2 * TS) {
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) s_k[c][tid] = (short)(kb[c] < 0 ? -1 : 3 * kb[c] + pq % 3);
   }
   __syncthreads();
   // each thread: rows {ty, ty+16}, cols {tx, tx+16}
   const int tx = tid & 15, ty = tid >> 4;
+  const int gi[2] = {i0 + ty, i0 + ty + 16}, gj[2] = {j0 + tx, j0 + tx + 16};
+  // ---- the children's values for my 4 cells (issued before the product, used after it)
+  double v[MAXC][4];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[c][q] = 0.0;
+  if (ncb > 0) {                                              // (leaves: nothing to fetch)
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    const int cs = min(c, max(ncb - 1, 0));
+    const int rg = 3 * WR->ch[cs].ns, rga = 3 * WR->ch[cs].na, nbb = rg - rga;
+    const double* B = Ubuf + WR->ch[cs].U_off + (size_t)rg * even_up(rga);      // the child's trailing block (slab B)
+    const int ki[2] = {s_k[c][ty], s_k[c][ty + 16]}, kj[2] = {s_k[c][TS + tx], s_k[c][TS + tx + 16]};
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const bool ok = c < ncb && ki[a] >= 0 && kj[b] >= 0 && gj[b] <= gi[a];
+        const double val = B[ok ? (size_t)(ki[a] - rga) * nbb + (kj[b] - rga) : 0];
+        v[c][2 * a + b] = ok ? val : 0.0;
+      }
+  }
+  }
   double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
 #pragma unroll 8
   for (int k = 0; k < W; k++) {
@@ -643,43 +701,37 @@ __global__ __launch_bounds__(256) void k_front_update(const FrontDesc* __restric
     c00 += a0 * b0; c01 += a0 * b1; c10 += a1 * b0; c11 += a1 * b1;
   }
   double acc[4] = {-c00, -c01, -c10, -c11};
-  int gi[2] = {i0 + ty, i0 + ty + 16}, gj[2] = {j0 + tx, j0 + tx + 16};
-  // child rows feeding this tile: staged once per child (scalar row index or -1), then 4 independent loads
-  __shared__ short s_ki[TS], s_kj[TS];
-  for (int ci = 0; ci < F.nchild; ci++) {
-    const FrontDesc G = fronts[children[F.child_off + ci]];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] += v[c][q];            // absent children contribute +0.0
+  // fronts with more than MAXC children: the rest one at a time (descriptor chain through the front table)
+  for (int ci = MAXC; ci < nchild; ci++) {
+    const FrontDesc G = fronts[children[child_off + ci]];
     const int32_t* ginv = inv + G.inv_off;
     const int rg = 3 * G.ns, rga = 3 * G.na, nbb = rg - rga;
-    const double* B = Ubuf + G.U_off + (size_t)rg * even_up(rga);      // the child's trailing block (slab B)
+    const double* B = Ubuf + G.U_off + (size_t)rg * even_up(rga);
     __syncthreads();
-    if (tid < TS) {
-      int p = i0 + tid;
-      int kb = (p < r) ? ginv[p / 3] : -1;
-      s_ki[tid] = (short)(kb < 0 ? -1 : 3 * kb + p % 3);
-    } else if (tid < 2 * TS) {
-      int p = j0 + tid - TS;
-      int kb = (p < r) ? ginv[p / 3] : -1;
-      s_kj[tid - TS] = (short)(kb < 0 ? -1 : 3 * kb + p % 3);
+    if (tid < 2 * TS) {
+      int kq = (pq < r) ? ginv[pq / 3] : -1;
+      s_k[0][tid] = (short)(kq < 0 ? -1 : 3 * kq + pq % 3);
     }
     __syncthreads();
-    const int ki[2] = {s_ki[ty], s_ki[ty + 16]}, kj[2] = {s_kj[tx], s_kj[tx + 16]};
-    double v[4];
+    const int ki[2] = {s_k[0][ty], s_k[0][ty + 16]}, kj[2] = {s_k[0][TS + tx], s_k[0][TS + tx + 16]};
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         bool ok = ki[a] >= 0 && kj[b] >= 0 && gj[b] <= gi[a];
-        v[2 * a + b] = ok ? B[(size_t)(ki[a] - rga) * nbb + (kj[b] - rga)] : 0.0;
+        acc[2 * a + b] += ok ? B[(size_t)(ki[a] - rga) * nbb + (kj[b] - rga)] : 0.0;
       }
-#pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] += v[q];
   }
-  double* Uo = Ubuf + F.U_off;
+  double* Uo = Ubuf + U_off;
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++)
-      if (gi[a] < r && gj[b] <= gi[a]) Uo[uidx(gi[a], gj[b], r, 3 * F.na)] = acc[2 * a + b];
+      if (gi[a] < r && gj[b] <= gi[a]) Uo[uidx(gi[a], gj[b], r, my_ra)] = acc[2 * a + b];
 }
 
 // ------------------------------------------------------------------------------ solves
@@ -801,7 +853,7 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag,
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
   int nt = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
   if (nt > 0)
-    hipLaunchKernelGGL(k_front_update, dim3(nt), dim3(256), 0, st, D.fronts, D.tiles, D.h_tile_ptr[l], D.children,
+    hipLaunchKernelGGL(k_front_update, dim3(nt), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children,
                        D.inv, D.Lbuf, D.Ubuf);
 }
 

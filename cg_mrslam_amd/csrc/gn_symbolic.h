@@ -20,8 +20,6 @@ constexpr int kFrontW = 3 * kPanelW; // scalar columns per front (all panel stri
 constexpr int kFactorHeader = 2 * kFrontW * kFrontW + kFrontW;  // L11 row-major, L11 column-major, 1/diag
 constexpr int kChunkRows = 191;      // border rows per k_front_factor workgroup: 3 wavefronts minus the lane that
                                      // carries the right-hand side through the factorisation
-constexpr int kFuseRows = 0;         // (historic) fronts with <= this many border rows formed U inside k_front_factor;
-                                     // measured best at 0: the tile kernel spreads that work over the idle CUs
 
 struct FrontDesc {                   // one per front, uploaded verbatim (all int32 / int64)
   int32_t c0;         // first block column (permuted order)

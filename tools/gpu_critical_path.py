@@ -24,7 +24,7 @@ nf = int(front[:n].max()) + 1
 fdur = np.zeros(nf)
 for k in range(n):
     fdur[front[k]] = max(fdur[front[k]], dur[k])          # chunks of a front run in parallel
-upd = np.where(3 * ns[:nf] > 96, 8.0, 0.0)                 # flat charge for the update-tile kernel of big fronts
+upd = np.where(ns[:nf] > 0, 8.0, 0.0)                 # flat charge for the update-tile kernel of big fronts
 lev = level[:nf]
 per_level = [fdur[lev == l].max() + upd[lev == l].max() for l in range(lev.max() + 1)]
 finish = np.zeros(nf)
