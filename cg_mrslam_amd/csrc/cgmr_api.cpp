@@ -82,11 +82,13 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   std::vector<WorkRec> work;
   D.h_tile_ptr.assign(D.nlevels + 1, 0);
   D.h_work_ptr.assign(D.nlevels + 1, 0);
+  D.h_level_chrows.assign(D.nlevels, 1);
   for (int l = 0; l < D.nlevels; l++) {
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
       int f = S.level_fronts[q];
       int r = 3 * S.fronts[f].ns;
       int nchunk = std::max(1, (r + kChunkRows - 1) / kChunkRows);
+      D.h_level_chrows[l] = std::max(D.h_level_chrows[l], std::min(r, kChunkRows) + 1);
       const int rec0 = (int)work.size();      // the front's first work record: the update tiles address the front through it
       for (int c = 0; c < nchunk; c++) {
         WorkRec wr;

@@ -25,6 +25,7 @@ struct GnDevice {
   int* status = nullptr;
   // host copies
   std::vector<int32_t> h_level_ptr, h_tile_ptr, h_work_ptr;
+  std::vector<int32_t> h_level_chrows;   // per level: rows of the factor kernel's F21 staging area (max chunk rows + rhs row)
 };
 
 void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const int32_t* ef, const int32_t* et,

@@ -209,20 +209,21 @@ __device__ __forceinline__ size_t uidx(int gi, int gj, int r, int ra) {
 }
 // LDS plan of k_front_factor (bytes), one workgroup per CU:
 //   Ls   [W][LDW]  doubles   F11 (assembly), later the staging buffer of L11 for coalesced copies
-//   R    [CH][LDW] doubles   chunk of F21 + the rhs row (assembly)
+//   R    [ch_rows][LDW] doubles   chunk of F21 + the rhs row (assembly); ch_rows <= CH is the level's maximum
 //   maps: s_rmap[MAXC][MAPW] (child row -> position in my row list), s_cmap[MAXC][W] shorts; the work record
 //   Dinv [W], Pan[2][W][8] doubles: the published 8-column panel of L11 (double buffered), Ys[W]
 constexpr int kOffLs = 0;
-constexpr int kOffR = kOffLs + W * LDW * 8;
-constexpr int kOffRmap = kOffR + CH * LDW * 8;
+constexpr int kOffRmap = kOffLs + W * LDW * 8;
 constexpr int kOffCmap = kOffRmap + 2 * MAXC * MAPW;
 constexpr int kOffRec = ((kOffCmap + 2 * MAXC * W + 15) / 16) * 16;
 constexpr int kOffDinv = ((kOffRec + 4 * kRecInts + 15) / 16) * 16;
 constexpr int kOffPan = kOffDinv + W * 8;
 constexpr int kOffYs = kOffPan + 2 * W * 8 * 8;
-constexpr int kSmemBytes = kOffYs + W * 8;
+constexpr int kOffR = ((kOffYs + W * 8 + 15) / 16) * 16;     // R comes last: a level whose fronts have few border rows is
+                                                              // launched with less LDS, so that two workgroups share a CU
+constexpr int kRIdx = (kOffR - kOffLs) / 8;                  // R[0] as an index from Ls (slab_scatter uses one index space)
+constexpr int kSmemBytes = kOffR + CH * LDW * 8;
 static_assert(kSmemBytes <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
-static_assert(kOffR == kOffLs + W * LDW * 8, "slab_scatter addresses R through Ls");
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ long long rfl64(long long v) {
@@ -271,7 +272,7 @@ __device__ __forceinline__ void slab_issue(SlabLoads& S, const SlabGeom& g, int 
 }
 
 // Add the block into F11 (Ls), this chunk's F21 rows and rhs row / border-vector column (R, which directly
-// follows Ls in LDS: one index space, R row p at W + p).  rmap[k] = position of child row row0 + k in my row list
+// lies kRIdx doubles behind Ls in LDS: one index space).  rmap[k] = position of child row row0 + k in my row list
 // (0..w-1 own columns, w.. border), cmap = the same map for rows 0..ra-1.  A child never sends two elements to the
 // same cell, so the adds of one call do not collide; calls for different children are separated by a barrier.
 __device__ __forceinline__ void slab_scatter(const SlabLoads& S, const SlabGeom& g, int tid, int rg, int ra, int row0,
@@ -291,7 +292,7 @@ __device__ __forceinline__ void slab_scatter(const SlabLoads& S, const SlabGeom&
     const int row = row0 + g.rr + g.rpp * u;
     const bool ok = g.rr < g.rpp && row < rend;
     const int pr = prow[u] - w - r0;
-    dst[u] = !ok ? -1 : prow[u] < w ? prow[u] * LDW : (pr >= 0 && pr < nr) ? (W + pr) * LDW : -1;
+    dst[u] = !ok ? -1 : prow[u] < w ? prow[u] * LDW : (pr >= 0 && pr < nr) ? kRIdx + pr * LDW : -1;
   }
 #pragma unroll
   for (int u = 0; u < SU; u++) {
@@ -303,8 +304,8 @@ __device__ __forceinline__ void slab_scatter(const SlabLoads& S, const SlabGeom&
   }
   if (tid < g.rows && row0 + tid < rg) {                         // border vector of the child
     const int pr = prowu - w - r0;
-    if (prowu < w) lds_add(Ls + (W + nr) * LDW + prowu, S.u);
-    else if (pr >= 0 && pr < nr) lds_add(Ls + (W + pr) * LDW + W, S.u);
+    if (prowu < w) lds_add(Ls + kRIdx + nr * LDW + prowu, S.u);
+    else if (pr >= 0 && pr < nr) lds_add(Ls + kRIdx + pr * LDW + W, S.u);
   }
 }
 
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
                                                          double* __restrict__ Ubuf, const double* __restrict__ bvec,
                                                          double* __restrict__ yvec, double* __restrict__ uvec,
                                                          int* __restrict__ status, int iter_tag, int level_id,
-                                                         int write_l11c) {
+                                                         int write_l11c, int ch_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* Ls = reinterpret_cast<double*>(smem + kOffLs);
   double* R = reinterpret_cast<double*>(smem + kOffR);
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
     if (tid < kRecInts) s_rec[tid] = g[tid];
   }
   for (int q = tid; q < W * LDW; q += 256) Ls[q] = 0.0;
-  for (int q = tid; q < CH * LDW; q += 256) R[q] = 0.0;
+  for (int q = tid; q < ch_rows * LDW; q += 256) R[q] = 0.0;
   __syncthreads();
   PHASE(1);
   const WorkRec* WR = reinterpret_cast<const WorkRec*>(s_rec);
@@ -845,9 +846,10 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag,
     attr_set = true;
   }
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
-  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), kSmemBytes, st, D.work, D.h_work_ptr[l], D.fronts, D.children,
+  const int ch_rows = std::min(CH, D.h_level_chrows[l]);
+  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), kOffR + ch_rows * LDW * 8, st, D.work, D.h_work_ptr[l], D.fronts, D.children,
                      D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, iter_tag, l,
-                     write_l11c ? 1 : 0);
+                     write_l11c ? 1 : 0, ch_rows);
 }
 
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
