@@ -170,9 +170,10 @@ constexpr int kDinv = 2 * W * W;
 constexpr int kL21 = 2 * W * W + W;
 #ifdef CGMR_PHASE_TIMING
 __device__ unsigned long long g_phase[64 * 8];
+__device__ unsigned long long g_wphase[8 * 8192];          // per work item: cycle counter at PHASE(0..6)
 __device__ unsigned long long g_wtime[2 * 8192];          // per work item of k_front_factor: start / end (100 MHz)
 __device__ unsigned long long g_utime[2 * 64];             // per level of k_front_update: min start / max end
-#define PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && level_id < 64) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
+#define PHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_wphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0 && level_id < 64) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
 #else
 #define PHASE(i)
 #endif
@@ -873,6 +874,9 @@ void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
 }  // namespace cgmr
 
 #ifdef CGMR_PHASE_TIMING
+extern "C" int cgmr_debug_workphases(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_wphase), sizeof(unsigned long long) * 8 * 8192);
+}
 extern "C" int cgmr_debug_worktimes(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_wtime), sizeof(unsigned long long) * 2 * 8192);
 }

@@ -37,3 +37,15 @@ print("work items", n, "fronts", nf, "levels", lev.max() + 1)
 print("sum over levels of the slowest work item (+8 us update where needed): %.0f us" % sum(per_level))
 print("critical path with dependency-driven start: %.0f us" % finish.max())
 print("per level max / median duration (us):", [(round(fdur[lev == l].max(), 1), round(float(np.median(fdur[lev == l])), 1)) for l in range(lev.max() + 1)])
+
+# phase split (cycles) of the slowest work item of every level
+ph = np.zeros(8 * 8192, dtype=np.uint64)
+lib.cgmr_debug_workphases(C.c_void_p(ph.ctypes.data))
+ph = ph.astype(np.int64).reshape(-1, 8)[:n]
+print("slowest work item per level: [record+clear, round 2, round 3 (children), factor B+C, stores] cycles | r, chunk, children rows")
+for l in range(lev.max() + 1):
+    items = [k for k in range(n) if lev[front[k]] == l]
+    k = max(items, key=lambda q: dur[q])
+    d = np.diff(ph[k, :6])
+    f = front[k]
+    print(l, d.tolist(), "| r", 3 * ns[f], "chunk", chunk[k], "kids", [3 * ns[c] for c in kids[f]], "dur %.1f us" % dur[k])
