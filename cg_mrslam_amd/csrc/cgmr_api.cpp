@@ -203,6 +203,15 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   return 0;
 }
 
+// profiling mode: add up the event pairs of the launches since the last collection (call after a stream sync)
+void profile_collect(cgmr_ctx* ctx) {
+  for (size_t k = 0; k < ctx->ev_cls.size(); k++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev_pool[2 * k], ctx->ev_pool[2 * k + 1]) == hipSuccess) ctx->ksec[ctx->ev_cls[k]] += 1e-3 * ms;
+  }
+  ctx->ev_cls.clear();
+}
+
 struct KTimer {   // optional per-launch-class timing (profiling mode only)
   cgmr_ctx* ctx;
   template <typename Fn>
@@ -215,14 +224,12 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
       fprintf(stderr, "[cgmr]   done: %s\n", hipGetErrorString(e));
       return;
     }
-    if (!ctx->profiling) { fn(); return; }
-    (void)hipEventRecord(ctx->ev_a, ctx->stream);
+    if (!ctx->profiling || 2 * (ctx->ev_cls.size() + 1) > ctx->ev_pool.size()) { fn(); return; }
+    const size_t k = ctx->ev_cls.size();
+    (void)hipEventRecord(ctx->ev_pool[2 * k], ctx->stream);
     fn();
-    (void)hipEventRecord(ctx->ev_b, ctx->stream);
-    (void)hipEventSynchronize(ctx->ev_b);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
-    ctx->ksec[cls] += 1e-3 * ms;
+    (void)hipEventRecord(ctx->ev_pool[2 * k + 1], ctx->stream);
+    ctx->ev_cls.push_back(cls);
     ctx->klaunch[cls] += nlaunch;
   }
 };
@@ -291,6 +298,7 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   HIP_TRY(ctx, hipMemcpyAsync(&status, D.status, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
+  if (ctx->profiling) profile_collect(ctx);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   if (chi2_out) memcpy(chi2_out, chi.data(), sizeof(double) * (iters + 1));
@@ -471,6 +479,7 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_a, ctx->ev_b})
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -569,6 +578,13 @@ int cgmr_set_profiling(cgmr_ctx* ctx, int on) {
   ctx->profiling = on != 0;
   memset(ctx->ksec, 0, sizeof ctx->ksec);
   memset(ctx->klaunch, 0, sizeof ctx->klaunch);
+  ctx->ev_cls.clear();
+  if (on && ctx->ev_pool.empty()) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->ev_pool.resize(2 * 2048);              // enough for optimize(~30) on a 21-level tree; further launches go untimed
+    for (hipEvent_t& e : ctx->ev_pool)
+      if (hipEventCreate(&e) != hipSuccess) { ctx->ev_pool.clear(); return set_err(ctx, CGMR_E_HIP, "hipEventCreate failed"); }
+  }
   return CGMR_OK;
 }
 

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/cgmr.h"
 #include "gn_device.h"
@@ -33,6 +34,10 @@ struct cgmr_ctx {
   bool profiling = false;
   double ksec[8] = {0};
   int64_t klaunch[8] = {0};
+  // profiling mode: one event pair per launch, recorded without synchronising (the stream stays busy, so a pair
+  // brackets the kernel and not an idle-to-busy launch latency); read back by profile_collect() after the final sync
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_cls;      // class of pair k (events 2k, 2k+1)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_a = nullptr, ev_b = nullptr;
 };
 

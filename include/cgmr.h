@@ -94,8 +94,10 @@ int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* f
  * measured with HIP events)  [4]=total wall.                                             */
 int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]);
 
-/* Per-kernel-class device time of GN runs made while profiling is on (HIP events around every
- * launch; slows the run down -- bench.py uses it only for the roofline figure).
+/* Per-kernel-class device time of GN runs made while profiling is on: a HIP event pair around every launch,
+ * recorded on the context's stream without synchronising (the stream stays busy, so a pair brackets the kernel,
+ * not an idle-to-busy launch latency) and read back after the call's final synchronisation.  At most 2048
+ * launches per call are timed.  bench.py uses it for the roofline figure.
  * classes: 0 linearize 1 assemble 2 chi2 3 front_factor 4 front_update 5 (unused: the forward solve rides
  * through front_factor) 6 solve_bwd 7 update
  * seconds_out[8], launches_out[8] are accumulated since profiling was switched on.       */
