@@ -241,12 +241,12 @@ def main():
     total_k = sum(v[0] for v in kt.values())
     dominant = max(kt.items(), key=lambda kv: kv[1][0])[0]
     # algorithmic HBM bytes of one factorisation pass of k_front_factor (DESIGN.md "roofline"):
-    #   read the H blocks (72 B each), write the factor panels (8 B per stored double; the column-major copy of
-    #   L11 is only written for the marginals, so 48*48 doubles per front are not counted), read each child's
-    #   update matrix once / write the fused ones (8 B * U_doubles)
+    #   read the H blocks (72 B each) and the leading slabs of the children's update matrices (the columns that fall
+    #   into the parent's own columns; the trailing blocks go to k_front_update), write the factor panels (8 B per
+    #   stored double; the column-major copy of L11 is only written for the marginals: 48*48 doubles per front less)
     nblk = info["free_poses"] + info["offdiag_blocks"]
     l_written = info["L_doubles"] - 48 * 48 * info["fronts"]
-    bytes_factor_iter = 72 * nblk + 8 * l_written + 8 * info["U_doubles"]
+    bytes_factor_iter = 72 * nblk + 8 * l_written + 8 * info["slab_doubles"]
     launches_per_iter = ff_n / (nprof * GN_ITERS)
     avg_launch_s = ff_s / max(ff_n, 1)
     bytes_per_launch = bytes_factor_iter / max(launches_per_iter, 1)

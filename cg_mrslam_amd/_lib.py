@@ -202,13 +202,13 @@ def gn_symbolic_info(nV, fixed, ef, et, want_perm=False):
     fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
     ef = np.ascontiguousarray(ef, dtype=np.int32)
     et = np.ascontiguousarray(et, dtype=np.int32)
-    out = np.zeros(12, dtype=np.int64)
+    out = np.zeros(13, dtype=np.int64)
     perm = np.zeros(nV, dtype=np.int32) if want_perm else None
     rc = lib.cgmr_gn_symbolic_info(C.c_int(nV), _ptr(fixed), C.c_int(len(ef)), _ptr(ef), _ptr(et), _ptr(out),
                                    _ptr(perm))
     if rc != 0:
         raise CgmrError(rc, "cgmr_gn_symbolic_info rejected the graph")
     keys = ["free_poses", "offdiag_blocks", "fronts", "levels", "L_doubles", "U_doubles", "max_border",
-            "factor_flops", "order_us", "structure_us", "max_children", "max_children_small_border"]
+            "factor_flops", "order_us", "structure_us", "max_children", "max_children_small_border", "slab_doubles"]
     info = dict(zip(keys, out.tolist()))
     return (info, perm) if want_perm else info

@@ -529,7 +529,7 @@ int cgmr_gn_optimize(cgmr_ctx* ctx, int nV, double* poses, const uint8_t* fixed,
 }
 
 int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx, const int32_t* to_idx,
-                          int64_t out[12], int32_t* perm_out) {
+                          int64_t out[13], int32_t* perm_out) {
   if (nV < 0 || nE < 0 || !out) return CGMR_E_INVALID;
   Symbolic S;
   int rc = analyze(nV, fixed, nE, from_idx, to_idx, S);
@@ -537,8 +537,9 @@ int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* f
   out[0] = S.nf; out[1] = S.nb; out[2] = (int64_t)S.fronts.size(); out[3] = (int64_t)S.level_ptr.size() - 1;
   out[4] = S.L_doubles; out[5] = S.U_doubles; out[6] = S.max_ns; out[7] = (int64_t)S.flops;
   out[8] = (int64_t)(1e6 * S.t_order); out[9] = (int64_t)(1e6 * S.t_struct);
-  out[10] = out[11] = 0;
+  out[10] = out[11] = out[12] = 0;
   for (const FrontDesc& F : S.fronts) {
+    if (F.parent >= 0) out[12] += (int64_t)3 * F.ns * ((3 * F.na + 1) & ~1);
     out[10] = std::max<int64_t>(out[10], F.nchild);
     if (F.ns >= 1 && F.ns <= 32) out[11] = std::max<int64_t>(out[11], F.nchild);
   }

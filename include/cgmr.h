@@ -85,9 +85,10 @@ int cgmr_gn_optimize_dev(cgmr_ctx* ctx, int nV, double* d_poses_xyt, const uint8
  * [4]=doubles in L   [5]=doubles in update matrices  [6]=max border (poses)
  * [7]=factor flops   [8]=ordering microseconds  [9]=structure microseconds
  * [10]=max children of a front  [11]=max children of a front with 1..32 border poses
+ * [12]=doubles of the update-matrix slabs the factor kernel reads (columns that fall into the parent's own columns)
  * perm_out (nullable, nV entries): permuted block column of each vertex or -1.          */
 int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx,
-                          const int32_t* to_idx, int64_t out[12], int32_t* perm_out);
+                          const int32_t* to_idx, int64_t out[13], int32_t* perm_out);
 
 /* Timing of the last cgmr_gn_optimize* call on this context, seconds:
  * out[0]=host ordering  [1]=host structure  [2]=upload+alloc  [3]=device GN iterations (stream time,
