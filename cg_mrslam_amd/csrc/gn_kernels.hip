@@ -193,6 +193,8 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record / whose maps are staged together
 constexpr int kRecInts = (int)(sizeof(WorkRec) / 4);
 constexpr int MAPW = 256;            // child rows per staged block of the row map (one per thread)
@@ -212,15 +214,13 @@ __device__ __forceinline__ size_t uidx(int gi, int gj, int r, int ra) {
 //   Ls   [W][LDW]  doubles   F11 (assembly), later the staging buffer of L11 for coalesced copies
 //   R    [ch_rows][LDW] doubles   chunk of F21 + the rhs row (assembly); ch_rows <= CH is the level's maximum
 //   maps: s_rmap[MAXC][MAPW] (child row -> position in my row list), s_cmap[MAXC][W] shorts; the work record
-//   Dinv [W], Pan[2][W][8] doubles: the published 8-column panel of L11 (double buffered), Ys[W]
+//   Dinv [W] doubles: reciprocals of the pivots
 constexpr int kOffLs = 0;
 constexpr int kOffRmap = kOffLs + W * LDW * 8;
 constexpr int kOffCmap = kOffRmap + 2 * MAXC * MAPW;
 constexpr int kOffRec = ((kOffCmap + 2 * MAXC * W + 15) / 16) * 16;
 constexpr int kOffDinv = ((kOffRec + 4 * kRecInts + 15) / 16) * 16;
-constexpr int kOffPan = kOffDinv + W * 8;
-constexpr int kOffYs = kOffPan + 2 * W * 8 * 8;
-constexpr int kOffR = ((kOffYs + W * 8 + 15) / 16) * 16;     // R comes last: a level whose fronts have few border rows is
+constexpr int kOffR = ((kOffDinv + W * 8 + 15) / 16) * 16;     // R comes last: a level whose fronts have few border rows is
                                                               // launched with less LDS, so that two workgroups share a CU
 constexpr int kRIdx = (kOffR - kOffLs) / 8;                  // R[0] as an index from Ls (slab_scatter uses one index space)
 constexpr int kSmemBytes = kOffR + CH * LDW * 8;
@@ -331,7 +331,7 @@ __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDes
 //   (3) the children's leading slabs, streamed front to back with 16-byte loads, two children in flight, and
 //       scattered into LDS through the maps.  Children are added in a fixed order with a barrier in between:
 //       no atomics, bit-reproducible.
-// Then the right-looking tall-panel factorisation (see below) and the stores.  The update matrix
+// Then the blocked factorisation of the panel in LDS (see below) and the stores.  The update matrix
 // U = ext_add - L21 L21^T of every front is formed by k_front_update, whose tiles spread over the idle CUs: forming
 // it here (tried for fronts of up to 96 border rows) made those fronts the slowest workgroup of their level.
 __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
@@ -351,8 +351,6 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   short* s_cmap = reinterpret_cast<short*>(smem + kOffCmap);
   int* s_rec = reinterpret_cast<int*>(smem + kOffRec);
   double* Dinv = reinterpret_cast<double*>(smem + kOffDinv);
-  double* Pan = reinterpret_cast<double*>(smem + kOffPan);
-  double* Ys = reinterpret_cast<double*>(smem + kOffYs);
   const int tid = threadIdx.x;
 #ifdef CGMR_PHASE_TIMING
   if (tid == 0 && work_begin + (int)blockIdx.x < 8192) g_wtime[2 * (work_begin + blockIdx.x)] = __builtin_amdgcn_s_memrealtime();
@@ -483,127 +481,160 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   }
   __syncthreads();
   PHASE(3);
-  // ---- B+C. right-looking tall-panel factorisation: every row of [F11; F21 chunk] lives in the registers of
-  // one lane (wave 0: the 48 rows of F11, waves 1-3: one border row per lane).  Per 8-column panel: wave 0
-  // factors the panel for the F11 rows (pivot broadcast with v_readlane, 1/sqrt by rsqrt + 2 Newton steps),
-  // publishes the panel columns L[k][c..c+7] and the reciprocals through LDS (double buffered: one barrier per
-  // panel); the border rows solve against the 8x8 diagonal block; then all rows apply the rank-8 update to
-  // their trailing columns with LDS broadcast reads.  A non-positive pivot records the GN iteration in *status
-  // (first failure wins); the pose update kernel then leaves the poses alone -- g2o's early return.
-  double x[W];
-  const bool isF11 = tid < 64;
-  {
-    const double* src = isF11 ? (Ls + min(tid, W - 1) * LDW) : (R + min(tid - 64, nr) * LDW);
-#pragma unroll
-    for (int k = 0; k < W; k++) x[k] = src[k];
-  }
-  double mydinv = 1.0;
+  // ---- B+C. blocked right-looking factorisation of the panel [F11; F21 chunk; rhs row] where it was assembled, in
+  // LDS, in three block columns of 16 (look-ahead of one block column):
+  //   factor_diag   wavefront 0 factors the 16x16 diagonal block in registers (lane i = row i, pivot broadcast with
+  //                 v_readlane, 1/sqrt by rsqrt + 2 Newton steps);
+  //   solve_rows    one thread per row below solves its 16 entries against the diagonal block;
+  //   update_tiles  the 16x16 tiles of a later block column subtract L[I][K] L[J][K]^T with
+  //                 v_mfma_f64_16x16x4_f64, operands straight from LDS (no per-FMA broadcast reads).
+  // The rhs row is the last row of the panel: what the solves leave there is y = L11^-1 (b + children), i.e. the
+  // forward solve.  A non-positive pivot records the GN iteration in *status (first failure wins); the pose update
+  // kernel then leaves the poses alone -- g2o's early return.
+  const int lane = tid & 63, wave = tid >> 6;
+  const int M = W + nr + 1;                                 // rows of the panel: F11, border rows of the chunk, rhs
+  const int NB = (M + 15) >> 4;
+  // row r of the panel: F11 rows in Ls, the others in R (kRIdx doubles behind Ls)
+#define PROW(r) (Ls + (r) * LDW + ((r) >= W ? kRIdx - W * LDW : 0))
   int fail = 0;
-  // wave 0: factor the 8-column panel starting at column c for the F11 rows and publish it
-#define FACTOR_PANEL(c)                                                                                      \
-  do {                                                                                                       \
-    double* pan_ = Pan + (((c) >> 3) & 1) * (W * 8);                                                         \
-    _Pragma("unroll") for (int jj = 0; jj < 8; jj++) {                                                       \
-      const int j = (c) + jj;                                                                                \
-      double d = readlane_f64(x[j], j);                                                                      \
-      if (!(d > 0.0)) { fail = 1; d = 1.0; }                                                                 \
-      double y = rsqrt_nr(d);                                                                                \
-      double lij = (tid == j) ? d * y : x[j] * y;                                                            \
-      x[j] = lij;                                                                                            \
-      if (tid == j) mydinv = y;                                                                              \
-      _Pragma("unroll") for (int q = jj + 1; q < 8; q++) x[(c) + q] = fma(-lij, readlane_f64(lij, (c) + q), x[(c) + q]); \
-    }                                                                                                        \
-    if (tid < W) {                                                                                           \
-      _Pragma("unroll") for (int q = 0; q < 8; q++) pan_[tid * 8 + q] = x[(c) + q];                          \
-      if (tid >= (c) && tid < (c) + 8) Dinv[tid] = mydinv;                                                   \
-    }                                                                                                        \
-  } while (0)
-  // rank-8 update of column k of my row with panel c
-#define TRAIL_COL(c, k)                                                                                      \
-  do {                                                                                                       \
-    const double2* lk_ = reinterpret_cast<const double2*>(Pan + (((c) >> 3) & 1) * (W * 8) + (k) * 8);       \
-    double acc_ = x[k];                                                                                      \
-    _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                          \
-      double2 l2_ = lk_[q];                                                                                  \
-      acc_ = fma(-x[(c) + 2 * q], l2_.x, acc_);                                                              \
-      acc_ = fma(-x[(c) + 2 * q + 1], l2_.y, acc_);                                                          \
-    }                                                                                                        \
-    x[k] = acc_;                                                                                             \
-  } while (0)
-  if (isF11) FACTOR_PANEL(0);
+  double mydinv = 1.0;
+  // C[I][Jt] -= L[I][Ks] L[Jt][Ks]^T for the row blocks I >= Jt, dealt round-robin to wavefronts wlo .. wlo+nw-1;
+  // two tiles per wavefront in flight (independent accumulator chains), B operand shared by all tiles
+  auto update_tiles = [&](int Jt, int Ks, int wlo, int nw) {
+    if (wave < wlo || wave >= wlo + nw) return;
+    const int ct = 16 * Jt, cs = 16 * Ks;
+    const double* brow = PROW(16 * Jt + (lane & 15)) + cs + (lane >> 4);
+    double bv[4];
 #pragma unroll
-  for (int c = 0; c < W; c += 8) {
-    if (c < w) {
-      const double* pan = Pan + ((c >> 3) & 1) * (W * 8);
-      __syncthreads();                                   // panel c is published
-      if (isF11) {
-        // look-ahead: bring the next panel's columns up to date, factor and publish it (into the other buffer)
-        // while the border rows are still busy with panel c, then finish my own trailing columns
-        if (c + 8 < w) {
+    for (int kk = 0; kk < 4; kk++) bv[kk] = brow[4 * kk];
+    for (int I = Jt + (wave - wlo); I < NB; I += 2 * nw) {
+      const int I2 = I + nw;
+      const bool has2 = I2 < NB;
+      const double* ar0 = PROW(min(16 * I + (lane & 15), M - 1)) + cs + (lane >> 4);
+      const double* ar1 = PROW(min(16 * I2 + (lane & 15), M - 1)) + cs + (lane >> 4);
+      double a0[4], a1[4];
+      double4_t acc0, acc1;
 #pragma unroll
-          for (int k = c + 8; k < c + 16 && k < W; k++) TRAIL_COL(c, k);
-          if (c + 8 < W) FACTOR_PANEL(c + 8 < W ? c + 8 : 0);
-        }
+      for (int kk = 0; kk < 4; kk++) { a0[kk] = -ar0[4 * kk]; a1[kk] = -ar1[4 * kk]; }
 #pragma unroll
-        for (int k = c + 16; k < W; k++)
-          if (k < w) TRAIL_COL(c, k);
-      } else {
+      for (int rg = 0; rg < 4; rg++) {
+        acc0[rg] = PROW(min(16 * I + (lane >> 4) + 4 * rg, M - 1))[ct + (lane & 15)];
+        acc1[rg] = PROW(min(16 * I2 + (lane >> 4) + 4 * rg, M - 1))[ct + (lane & 15)];
+      }
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-          double xj = x[c + jj];
+      for (int kk = 0; kk < 4; kk++) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], bv[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], bv[kk], acc1, 0, 0, 0);
+      }
 #pragma unroll
-          for (int q = 0; q < jj; q++) xj = fma(-x[c + q], pan[(c + jj) * 8 + q], xj);
-          x[c + jj] = xj * Dinv[c + jj];
-        }
-#pragma unroll
-        for (int k = c + 8; k < W; k++)
-          if (k < w) TRAIL_COL(c, k);
+      for (int rg = 0; rg < 4; rg++) {
+        const int row0 = 16 * I + (lane >> 4) + 4 * rg, row1 = 16 * I2 + (lane >> 4) + 4 * rg;
+        if (row0 < M) PROW(row0)[ct + (lane & 15)] = acc0[rg];
+        if (has2 && row1 < M) PROW(row1)[ct + (lane & 15)] = acc1[rg];
       }
     }
-  }
-#undef FACTOR_PANEL
-#undef TRAIL_COL
-  if (isF11 && fail && tid == 0) atomicCAS(status, 0, iter_tag);
-  PHASE(4);
-  double* P = Lbuf + L_off;
-  if (isF11) {
-    if (chunk == 0 && tid < W) {               // stage L11 in LDS (the F11 buffer is dead) for coalesced copies
+  };
+  // wavefront 0 factors the 16x16 diagonal block of block column J in registers (lane i = row i)
+  auto factor_diag = [&](int J) {
+    if (wave != 0) return;
+    const int c = 16 * J;
+    double x[16];
+    const int li = min(lane, 15);
 #pragma unroll
-      for (int k = 0; k < W; k++) Ls[tid * LDW + k] = (k <= tid) ? x[k] : 0.0;
-      P[kDinv + tid] = mydinv;
+    for (int q = 0; q < 16; q++) x[q] = Ls[(c + li) * LDW + c + q];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      double d = readlane_f64(x[j], j);
+      if (!(d > 0.0)) { fail = 1; d = 1.0; }
+      const double y = rsqrt_nr(d);
+      const double lij = (lane == j) ? d * y : x[j] * y;
+      x[j] = lij;
+      if (lane == j) mydinv = y;
+#pragma unroll
+      for (int q = j + 1; q < 16; q++) x[q] = fma(-lij, readlane_f64(lij, q), x[q]);
     }
-  } else if (tid - 64 < nr) {
-    double* dst = P + kL21 + (size_t)(r0 + tid - 64) * W;
+    if (lane < 16) {
 #pragma unroll
-    for (int k = 0; k < W; k += 2) *reinterpret_cast<double2*>(dst + k) = make_double2(x[k], x[k + 1]);
-  } else if (tid - 64 == nr) {
-    // the rhs row went through the same solve / trailing updates as a border row: it now holds y = L11^-1 t
-#pragma unroll
-    for (int k = 0; k < W; k++) Ys[k] = x[k];
-    if (chunk == 0) {
-#pragma unroll
-      for (int k = 0; k < W; k++)
-        if (k < w) yvec[3 * c0 + k] = x[k];
+      for (int q = 0; q < 16; q++) Ls[(c + lane) * LDW + c + q] = (q <= lane) ? x[q] : 0.0;
+      Dinv[c + lane] = mydinv;
     }
-  }
+  };
+  // one thread per row below the diagonal block of block column J solves its 16 entries against that block
+  // (two rows per thread, sharing the block's entries, measured slower)
+  auto solve_rows = [&](int J) {
+    const int c = 16 * J;
+    const int row = c + 16 + tid;
+    if (row >= M) return;
+    double* xr = PROW(row) + c;
+    double x[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) x[q] = xr[q];
+    // right-looking within the row: once x[q] is final it is pushed into all later entries (independent FMAs)
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const double xq = x[q] * Dinv[c + q];
+      x[q] = xq;
+      const double* lc = Ls + (c + q) * LDW + c + q;          // L[q][q]; L[j][q] is (j - q) rows below
+#pragma unroll
+      for (int j = q + 1; j < 16; j++) x[j] = fma(-xq, lc[(j - q) * LDW], x[j]);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) xr[q] = x[q];
+  };
+  const int nbc = min(W / 16, (w + 15) >> 4);                // block columns that hold real columns
+  // right-looking schedule with look-ahead: block column J+1 is brought up to date first, then wavefront 0 factors
+  // its diagonal block while wavefronts 1-3 push the same update into block column J+2
+  factor_diag(0);
   __syncthreads();
+  solve_rows(0);
+  __syncthreads();
+  if (nbc > 1) {
+    update_tiles(1, 0, 0, 4);
+    __syncthreads();
+    factor_diag(1);
+    if (nbc > 2) update_tiles(2, 0, 1, 3);
+    __syncthreads();
+    solve_rows(1);
+    __syncthreads();
+    if (nbc > 2) {
+      update_tiles(2, 1, 0, 4);
+      __syncthreads();
+      factor_diag(2);
+      __syncthreads();
+      solve_rows(2);
+      __syncthreads();
+    }
+  }
+  if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, iter_tag);
+  PHASE(4);
+  // ---- stores, all from LDS: L11 (lower triangle, zeros above), 1/diag, L21 rows of this chunk, y, u
+  double* P = Lbuf + L_off;
   if (chunk == 0) {
     for (int q = tid; q < W * W; q += 256) {
-      int i = q / W, k = q - i * W;
-      P[q] = Ls[i * LDW + k];                   // row-major copy (backward solve)
+      const int i = q / W, k = q - i * W;
+      P[q] = (k <= i) ? Ls[i * LDW + k] : 0.0;                 // row-major copy (backward solve)
     }
-    if (write_l11c)                             // column-major copy: only the multi-rhs forward solve of the marginals reads it
+    if (write_l11c)                                           // column-major copy: only the multi-rhs forward solve of the marginals reads it
       for (int q = tid; q < W * W; q += 256) {
-        int i = q / W, k = q - i * W;
-        P[kL11c + q] = Ls[k * LDW + i];
+        const int i = q / W, k = q - i * W;
+        P[kL11c + q] = (i <= k) ? Ls[k * LDW + i] : 0.0;       // element (row k, col i)
       }
+    if (tid < W) P[kDinv + tid] = (tid < w) ? Dinv[tid] : 1.0;
+    if (tid < w) yvec[3 * c0 + tid] = R[nr * LDW + tid];
   }
-  if (!isF11 && tid - 64 < nr) {                // border vector handed to the parent: u = ext_add(children) - L21 y
+  for (int q = tid; q < nr * W; q += 256) {
+    const int row = q / W, k = q - row * W;
+    P[kL21 + (size_t)(r0 + row) * W + k] = R[row * LDW + k];
+  }
+  if (tid < nr) {                                             // border vector handed to the parent: u = ext_add(children) - L21 y
+    const double* xr = R + tid * LDW;
+    const double* yr = R + nr * LDW;
     double dot = 0.0;
-#pragma unroll
-    for (int k = 0; k < W; k++) dot = fma(x[k], Ys[k], dot);
-    uvec[(size_t)3 * rows_off + r0 + tid - 64] = R[(tid - 64) * LDW + W] - dot;
+#pragma unroll 8
+    for (int k = 0; k < W; k++) dot = fma(xr[k], yr[k], dot);
+    uvec[(size_t)3 * rows_off + r0 + tid] = xr[W] - dot;
   }
+#undef PROW
   PHASE(5);
 #ifdef CGMR_PHASE_TIMING
   __syncthreads();

@@ -49,3 +49,15 @@ for l in range(lev.max() + 1):
     d = np.diff(ph[k, :6])
     f = front[k]
     print(l, d.tolist(), "| r", 3 * ns[f], "chunk", chunk[k], "kids", [3 * ns[c] for c in kids[f]], "dur %.1f us" % dur[k])
+
+try:
+    bc = np.zeros(4 * 8192, dtype=np.uint64)
+    lib.cgmr_debug_bc(C.c_void_p(bc.ctypes.data))
+    bc = bc.astype(np.int64).reshape(-1, 4)[:n]
+    print("B+C split of the slowest item per level [(a) mfma update, (b) diagonal block, (c) row solves] cycles (thread 0, incl. barriers):")
+    for l in range(lev.max() + 1):
+        items = [k for k in range(n) if lev[front[k]] == l]
+        k = max(items, key=lambda q: dur[q])
+        print(l, bc[k, :3].tolist(), "r", 3 * ns[front[k]])
+except AttributeError:
+    pass
