@@ -83,12 +83,21 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.h_tile_ptr.assign(D.nlevels + 1, 0);
   D.h_work_ptr.assign(D.nlevels + 1, 0);
   D.h_level_chrows.assign(D.nlevels, 1);
+  D.h_level_leaf.assign(D.nlevels, 1);
+  D.h_level_chunk.assign(D.nlevels, kChunkRows);
+  static const int leaf_chunk = getenv("CGMR_LEAF_CHUNK") ? atoi(getenv("CGMR_LEAF_CHUNK")) : kLeafChunkRows;
   for (int l = 0; l < D.nlevels; l++) {
+    for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++)
+      if (S.fronts[S.level_fronts[q]].nchild > 0) D.h_level_leaf[l] = 0;
+    // a level of leaves runs the register-light variant of the factor kernel: shorter chunks, so that the LDS of two
+    // workgroups fits a CU
+    const int chunk_rows = D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : kChunkRows;
+    D.h_level_chunk[l] = chunk_rows;
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
       int f = S.level_fronts[q];
       int r = 3 * S.fronts[f].ns;
-      int nchunk = std::max(1, (r + kChunkRows - 1) / kChunkRows);
-      D.h_level_chrows[l] = std::max(D.h_level_chrows[l], std::min(r, kChunkRows) + 1);
+      int nchunk = std::max(1, (r + chunk_rows - 1) / chunk_rows);
+      D.h_level_chrows[l] = std::max(D.h_level_chrows[l], std::min(r, chunk_rows) + 1);
       const int rec0 = (int)work.size();      // the front's first work record: the update tiles address the front through it
       for (int c = 0; c < nchunk; c++) {
         WorkRec wr;
@@ -598,6 +607,19 @@ int cgmr_gn_kernel_times(const cgmr_ctx* ctx, double seconds_out[8], int64_t lau
 
 }  // extern "C"
 
+// Debugging aid (host only): the front table of a graph's symbolic analysis, 6 ints per front: c0, nc, ns, parent, level, nchild.
+extern "C" int cgmr_debug_fronts(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int cap, int32_t* out) {
+  Symbolic S;
+  if (analyze(nV, fixed, nE, ef, et, S)) return -1;
+  int n = (int)S.fronts.size();
+  for (int f = 0; f < n && f < cap; f++) {
+    const FrontDesc& F = S.fronts[f];
+    int32_t* o = out + 6 * f;
+    o[0] = F.c0; o[1] = F.nc; o[2] = F.ns; o[3] = F.parent; o[4] = F.level; o[5] = F.nchild;
+  }
+  return n;
+}
+
 // Debugging aid: the (front, chunk) of every work item of the last analysed graph, and each front's parent / level.
 extern "C" int cgmr_debug_worklist(const cgmr_ctx* ctx, int32_t* front_out, int32_t* chunk_out, int cap, int32_t* parent_out,
                                    int32_t* level_out, int32_t* ns_out, int fcap) {
@@ -608,7 +630,8 @@ extern "C" int cgmr_debug_worklist(const cgmr_ctx* ctx, int32_t* front_out, int3
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
       int f = S.level_fronts[q];
       int r = 3 * S.fronts[f].ns;
-      int nchunk = std::max(1, (r + kChunkRows - 1) / kChunkRows);
+      const int chunk_rows = l < (int)ctx->gn.h_level_chunk.size() ? ctx->gn.h_level_chunk[l] : kChunkRows;
+      int nchunk = std::max(1, (r + chunk_rows - 1) / chunk_rows);
       for (int c = 0; c < nchunk; c++) { if (n < cap) { front_out[n] = f; chunk_out[n] = c; } n++; }
     }
   for (int f = 0; f < (int)S.fronts.size() && f < fcap; f++) { parent_out[f] = S.fronts[f].parent; level_out[f] = S.fronts[f].level; ns_out[f] = S.fronts[f].ns; }

@@ -172,10 +172,13 @@ constexpr int kL21 = 2 * W * W + W;
 __device__ unsigned long long g_phase[64 * 8];
 __device__ unsigned long long g_wphase[8 * 8192];          // per work item: cycle counter at PHASE(0..6)
 __device__ unsigned long long g_wtime[2 * 8192];          // per work item of k_front_factor: start / end (100 MHz)
+__device__ unsigned long long g_fphase[8 * 8192];         // per work item: cycle counter at the steps of the blocked factorisation
 __device__ unsigned long long g_utime[2 * 64];             // per level of k_front_update: min start / max end
 #define PHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_wphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0 && level_id < 64) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
+#define FPHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_fphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PHASE(i)
+#define FPHASE(i)
 #endif
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -184,13 +187,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) to double precision: hardware estimate + two Newton steps (no FP64 divide / sqrt
-// expansion on the pivot chain, which is the critical path of the whole factorisation).
+// 1/sqrt(d) to double precision: hardware estimate + one third-order correction, y (1 + e/2 + 3e^2/8) with
+// e = 1 - d y^2 (four dependent operations instead of the six of two Newton steps; no FP64 divide / sqrt expansion
+// on the pivot chain, which is the critical path of the whole factorisation).
 __device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-  y = y * (1.5 - 0.5 * d * y * y);
-  y = y * (1.5 - 0.5 * d * y * y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-(d * y), y, 1.0);
+  return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -225,6 +228,7 @@ constexpr int kOffR = ((kOffDinv + W * 8 + 15) / 16) * 16;     // R comes last: 
 constexpr int kRIdx = (kOffR - kOffLs) / 8;                  // R[0] as an index from Ls (slab_scatter uses one index space)
 constexpr int kSmemBytes = kOffR + CH * LDW * 8;
 static_assert(kSmemBytes <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
+static_assert(kOffR + (kLeafChunkRows + 1) * LDW * 8 <= 48 * 1024, "leaf variant: three workgroups per CU need <= 48 KiB each");
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ long long rfl64(long long v) {
@@ -334,17 +338,17 @@ __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDes
 // Then the blocked factorisation of the panel in LDS (see below) and the stores.  The update matrix
 // U = ext_add - L21 L21^T of every front is formed by k_front_update, whose tiles spread over the idle CUs: forming
 // it here (tried for fronts of up to 96 border rows) made those fronts the slowest workgroup of their level.
-__global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
-                                                         const FrontDesc* __restrict__ fronts,
-                                                         const int32_t* __restrict__ children,
-                                                         const int32_t* __restrict__ rel,
-                                                         const int32_t* __restrict__ apack,
-                                                         const double* __restrict__ Ablk, double* __restrict__ Lbuf,
-                                                         double* __restrict__ Ubuf, const double* __restrict__ bvec,
-                                                         double* __restrict__ yvec, double* __restrict__ uvec,
-                                                         int* __restrict__ status, int iter_tag, int level_id,
-                                                         int write_l11c, int ch_rows) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <bool LEAF>
+__device__ __forceinline__ void front_factor_body(unsigned char* smem, const WorkRec* __restrict__ work, int work_begin,
+                                                  const FrontDesc* __restrict__ fronts,
+                                                  const int32_t* __restrict__ children,
+                                                  const int32_t* __restrict__ rel,
+                                                  const int32_t* __restrict__ apack,
+                                                  const double* __restrict__ Ablk, double* __restrict__ Lbuf,
+                                                  double* __restrict__ Ubuf, const double* __restrict__ bvec,
+                                                  double* __restrict__ yvec, double* __restrict__ uvec,
+                                                  int* __restrict__ status, int iter_tag, int level_id,
+                                                  int write_l11c, int ch_rows, int chunk_rows) {
   double* Ls = reinterpret_cast<double*>(smem + kOffLs);
   double* R = reinterpret_cast<double*>(smem + kOffR);
   short* s_rmap = reinterpret_cast<short*>(smem + kOffRmap);
@@ -371,10 +375,10 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   const int a_off = rfl(WR->F.a_off), a_cnt = rfl(WR->F.a_cnt), chunk = rfl(WR->chunk);
   const long long L_off = rfl64(WR->F.L_off);
   const int w = 3 * nc, r = 3 * ns;
-  const int r0 = chunk * kChunkRows;
-  const int nr = max(0, min(kChunkRows, r - r0));   // border rows of this chunk; staging row nr carries the rhs
+  const int r0 = chunk * chunk_rows;
+  const int nr = max(0, min(chunk_rows, r - r0));   // border rows of this chunk; staging row nr carries the rhs
   // ---- round 2: rhs, H blocks, the children's row maps (first batch, first block) -- every load first ...
-  const int ncb0 = min(nchild, MAXC);
+  const int ncb0 = LEAF ? 0 : min(nchild, MAXC);
   const double bv = (tid < w) ? bvec[3 * c0 + tid] : 0.0;
   constexpr int AU = 4;
   const int na9 = a_cnt * 9;
@@ -388,11 +392,13 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
     av[u] = ok ? Ablk[(size_t)a_off * 9 + q] : 0.0;
   }
   int relv[MAXC];
+  if constexpr (!LEAF) {
 #pragma unroll
-  for (int c = 0; c < MAXC; c++) {
-    const int cs = min(c, max(ncb0 - 1, 0));             // surplus slots repeat a valid child and are ignored below
-    const int rg = 3 * WR->ch[cs].ns;
-    relv[c] = rel[WR->ch[cs].rel_off + min(tid, max(rg - 1, 0)) / 3];
+    for (int c = 0; c < MAXC; c++) {
+      const int cs = min(c, max(ncb0 - 1, 0));           // surplus slots repeat a valid child and are ignored below
+      const int rg = 3 * WR->ch[cs].ns;
+      relv[c] = rel[WR->ch[cs].rel_off + min(tid, max(rg - 1, 0)) / 3];
+    }
   }
   // ... then the LDS writes
   if (tid >= w && tid < W) Ls[tid * LDW + tid] = 1.0;        // identity padding of the unused columns
@@ -416,18 +422,21 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
       if (row >= 0 && row < nr) R[row * LDW + 3 * lc + el % 3] = v;
     }
   }
+  if constexpr (!LEAF) {
 #pragma unroll
-  for (int c = 0; c < MAXC; c++) {
-    if (c < ncb0) {
-      const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
-      const short pos = (short)(3 * relv[c] + tid % 3);
-      if (tid < rg) s_rmap[c * MAPW + tid] = pos;
-      if (tid < ra) s_cmap[c * W + tid] = pos;
+    for (int c = 0; c < MAXC; c++) {
+      if (c < ncb0) {
+        const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
+        const short pos = (short)(3 * relv[c] + tid % 3);
+        if (tid < rg) s_rmap[c * MAPW + tid] = pos;
+        if (tid < ra) s_cmap[c * W + tid] = pos;
+      }
     }
   }
   __syncthreads();
   PHASE(2);
   // ---- round 3: the children's leading slabs, two children in flight
+  if constexpr (!LEAF) {
   for (int cb = 0; cb < ncb0; cb += 2) {
     SlabLoads S0, S1;
     const bool two = cb + 1 < ncb0;
@@ -480,6 +489,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
     }
   }
   __syncthreads();
+  }
   PHASE(3);
   // ---- B+C. blocked right-looking factorisation of the panel [F11; F21 chunk; rhs row] where it was assembled, in
   // LDS, in three block columns of 16 (look-ahead of one block column):
@@ -491,7 +501,9 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   // The rhs row is the last row of the panel: what the solves leave there is y = L11^-1 (b + children), i.e. the
   // forward solve.  A non-positive pivot records the GN iteration in *status (first failure wins); the pose update
   // kernel then leaves the poses alone -- g2o's early return.
-  const int lane = tid & 63, wave = tid >> 6;
+  // logical wavefront number: wavefront 0 (the one that factors the diagonal blocks alone) sits on a different SIMD in
+  // consecutive rounds of workgroups, so that two workgroups sharing a CU do not serialise their diagonal blocks
+  const int lane = tid & 63, wave = ((tid >> 6) - (LEAF ? (int)(blockIdx.x >> 8) : 0)) & 3;
   const int M = W + nr + 1;                                 // rows of the panel: F11, border rows of the chunk, rhs
   const int NB = (M + 15) >> 4;
   // row r of the panel: F11 rows in Ls, the others in R (kRIdx doubles behind Ls)
@@ -534,7 +546,9 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
       }
     }
   };
-  // wavefront 0 factors the 16x16 diagonal block of block column J in registers (lane i = row i)
+  // wavefront 0 factors the 16x16 diagonal block of block column J in registers (lane i = row i), as L D L^T with the
+  // scaling by D^-1/2 deferred: the chain from one pivot to the next is readlane -> 1/d (estimate + cubic correction)
+  // -> one multiply -> fma on x[j+1]; the 16 reciprocal square roots are taken together afterwards, one per lane.
   auto factor_diag = [&](int J) {
     if (wave != 0) return;
     const int c = 16 * J;
@@ -542,17 +556,22 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
     const int li = min(lane, 15);
 #pragma unroll
     for (int q = 0; q < 16; q++) x[q] = Ls[(c + li) * LDW + c + q];
+    double dl = 1.0;                                          // my row's pivot
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      double d = readlane_f64(x[j], j);
-      if (!(d > 0.0)) { fail = 1; d = 1.0; }
-      const double y = rsqrt_nr(d);
-      const double lij = (lane == j) ? d * y : x[j] * y;
-      x[j] = lij;
-      if (lane == j) mydinv = y;
+      const double d = readlane_f64(x[j], j);
+      if (!(d > 0.0)) fail = 1;                               // off the chain: a failed front leaves NaN / Inf behind, nobody reads them
+      const double r0 = __builtin_amdgcn_rcp(d);
+      const double e = fma(-d, r0, 1.0);
+      const double sc = x[j] * fma(r0, fma(e, e, e), r0);     // a_ij / d
+      if (lane == j) dl = d;
 #pragma unroll
-      for (int q = j + 1; q < 16; q++) x[q] = fma(-lij, readlane_f64(lij, q), x[q]);
+      for (int q = j + 1; q < 16; q++) x[q] = fma(-sc, readlane_f64(x[j], q), x[q]);
     }
+    const double y = rsqrt_nr(dl);
+    mydinv = y;
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] *= readlane_f64(y, j);  // L[i][j] = a_ij d_j^-1/2 (j < i), L[i][i] = d_i d_i^-1/2
     if (lane < 16) {
 #pragma unroll
       for (int q = 0; q < 16; q++) Ls[(c + lane) * LDW + c + q] = (q <= lane) ? x[q] : 0.0;
@@ -584,23 +603,31 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   const int nbc = min(W / 16, (w + 15) >> 4);                // block columns that hold real columns
   // right-looking schedule with look-ahead: block column J+1 is brought up to date first, then wavefront 0 factors
   // its diagonal block while wavefronts 1-3 push the same update into block column J+2
+  FPHASE(0);
   factor_diag(0);
   __syncthreads();
+  FPHASE(1);
   solve_rows(0);
   __syncthreads();
+  FPHASE(2);
   if (nbc > 1) {
     update_tiles(1, 0, 0, 4);
     __syncthreads();
+    FPHASE(3);
     factor_diag(1);
     if (nbc > 2) update_tiles(2, 0, 1, 3);
     __syncthreads();
+    FPHASE(4);
     solve_rows(1);
     __syncthreads();
+    FPHASE(5);
     if (nbc > 2) {
       update_tiles(2, 1, 0, 4);
       __syncthreads();
+      FPHASE(6);
       factor_diag(2);
       __syncthreads();
+      FPHASE(7);
       solve_rows(2);
       __syncthreads();
     }
@@ -641,6 +668,38 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   if (tid == 0 && work_begin + (int)blockIdx.x < 8192) g_wtime[2 * (work_begin + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
   PHASE(6);
+}
+
+__global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
+                                                         const FrontDesc* __restrict__ fronts,
+                                                         const int32_t* __restrict__ children,
+                                                         const int32_t* __restrict__ rel,
+                                                         const int32_t* __restrict__ apack,
+                                                         const double* __restrict__ Ablk, double* __restrict__ Lbuf,
+                                                         double* __restrict__ Ubuf, const double* __restrict__ bvec,
+                                                         double* __restrict__ yvec, double* __restrict__ uvec,
+                                                         int* __restrict__ status, int iter_tag, int level_id,
+                                                         int write_l11c, int ch_rows, int chunk_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  front_factor_body<false>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec, status,
+                           iter_tag, level_id, write_l11c, ch_rows, chunk_rows);
+}
+
+// The leaves of the elimination tree (level 0: about half of all fronts) have no children: without the slab
+// streaming the kernel needs half the registers, so two workgroups share a CU and hide each other's round trips.
+__global__ __launch_bounds__(256, 2) void k_front_factor_leaf(const WorkRec* __restrict__ work, int work_begin,
+                                                                 const FrontDesc* __restrict__ fronts,
+                                                                 const int32_t* __restrict__ children,
+                                                                 const int32_t* __restrict__ rel,
+                                                                 const int32_t* __restrict__ apack,
+                                                                 const double* __restrict__ Ablk, double* __restrict__ Lbuf,
+                                                                 double* __restrict__ Ubuf, const double* __restrict__ bvec,
+                                                                 double* __restrict__ yvec, double* __restrict__ uvec,
+                                                                 int* __restrict__ status, int iter_tag, int level_id,
+                                                                 int write_l11c, int ch_rows, int chunk_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  front_factor_body<true>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec, status,
+                          iter_tag, level_id, write_l11c, ch_rows, chunk_rows);
 }
 
 // --------------------------------------------------------------------------- front update
@@ -869,19 +928,21 @@ void launch_assemble(hipStream_t st, const GnDevice& D) {
 }
 
 void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag, bool write_l11c) {
-  int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
-  (void)nfr;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kSmemBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor_leaf),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
     attr_set = true;
   }
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
   const int ch_rows = std::min(CH, D.h_level_chrows[l]);
-  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), kOffR + ch_rows * LDW * 8, st, D.work, D.h_work_ptr[l], D.fronts, D.children,
+  auto kern = D.h_level_leaf[l] ? k_front_factor_leaf : k_front_factor;
+  static const bool full_lds = getenv("CGMR_LEAF_FULL_LDS") != nullptr;
+  hipLaunchKernelGGL(kern, dim3(nw), dim3(256), (full_lds && D.h_level_leaf[l]) ? kSmemBytes : kOffR + ch_rows * LDW * 8, st, D.work, D.h_work_ptr[l], D.fronts, D.children,
                      D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, iter_tag, l,
-                     write_l11c ? 1 : 0, ch_rows);
+                     write_l11c ? 1 : 0, ch_rows, D.h_level_chunk[l]);
 }
 
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
@@ -907,6 +968,9 @@ void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
 #ifdef CGMR_PHASE_TIMING
 extern "C" int cgmr_debug_workphases(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_wphase), sizeof(unsigned long long) * 8 * 8192);
+}
+extern "C" int cgmr_debug_factorphases(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_fphase), sizeof(unsigned long long) * 8 * 8192);
 }
 extern "C" int cgmr_debug_worktimes(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_wtime), sizeof(unsigned long long) * 2 * 8192);

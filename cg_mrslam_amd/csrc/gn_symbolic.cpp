@@ -36,8 +36,20 @@ struct NDCtx {
   int max_par_depth = 0;              // recursion levels that fork a thread for one half
 };
 
-void emit_panels(NDCtx& C, int begin, int end) {
-  for (int p = begin; p < end; p += kPanelW) C.pstart[p] = 1;
+// What a parent separator needs to know about an ordered range: the size of its last panel (the one the separator,
+// placed right behind the range, could be merged with) and an estimate of the height of its elimination subtree in
+// panels.
+struct NDRange {
+  int last = 0;
+  int height = 0;
+};
+
+// cut [begin, end) into runs of kPanelW columns, the remainder last
+NDRange emit_panels(NDCtx& C, int begin, int end) {
+  NDRange r;
+  for (int p = begin; p < end; p += kPanelW) { C.pstart[p] = 1; r.height++; }
+  r.last = end > begin ? (end - begin - 1) % kPanelW + 1 : 0;
+  return r;
 }
 
 // BFS restricted to vertices with label == id; returns number reached, fills dist (by vertex)
@@ -61,10 +73,11 @@ int bfs(NDCtx& C, int32_t* q, int root, int id, int visited_id) {
   return qt;
 }
 
-void nd(NDCtx& C, int begin, int end, int depth) {
+// Orders [begin, end) and marks its panels.
+NDRange nd(NDCtx& C, int begin, int end, int depth) {
   int n = end - begin;
-  if (n <= 0) return;
-  if (n <= kPanelW) { emit_panels(C, begin, end); return; }
+  if (n <= 0) return NDRange();
+  if (n <= kPanelW) return emit_panels(C, begin, end);
   int32_t* Q = C.queue.data() + begin;                  // this call's slice of the BFS queue
   int id = C.next_label.fetch_add(3);
   for (int p = begin; p < end; p++) C.label[C.order[p]] = id;
@@ -77,19 +90,17 @@ void nd(NDCtx& C, int begin, int end, int depth) {
     for (int q = 0; q < reached; q++) C.tmp[k++] = Q[q];
     for (int p = begin; p < end; p++) if (C.label[C.order[p]] == id) C.tmp[k++] = C.order[p];
     std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
-    nd(C, begin, begin + reached, depth);
-    nd(C, begin + reached, end, depth);
-    return;
+    NDRange r1 = nd(C, begin, begin + reached, depth);
+    NDRange r2 = nd(C, begin + reached, end, depth);
+    r2.height = std::max(r1.height, r2.height);
+    return r2;
   }
   int far = Q[reached - 1];
   // second sweep from the far vertex gives the level structure
   int vis2 = id + 2;
   bfs(C, Q, far, vis1, vis2);
   int nlev = C.dist[Q[n - 1]] + 1;
-  if (nlev <= 2) {  // clique-like: nothing to dissect
-    emit_panels(C, begin, end);
-    return;
-  }
+  if (nlev <= 2) return emit_panels(C, begin, end);  // clique-like: nothing to dissect
   std::vector<int32_t> lvl_cnt(nlev + 1, 0);
   for (int q = 0; q < n; q++) lvl_cnt[C.dist[Q[q]]]++;
   // choose the separator level
@@ -128,16 +139,39 @@ void nd(NDCtx& C, int begin, int end, int depth) {
     else C.tmp[ps++] = v;
   }
   std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
-  emit_panels(C, begin + na + nb, end);
   // the two halves touch disjoint vertices and disjoint position ranges: fork one of them near the top
+  NDRange r1, r2;
   if (depth < C.max_par_depth && na > 512 && nb > 512) {
-    std::thread t([&C, begin, na, depth] { nd(C, begin, begin + na, depth + 1); });
-    nd(C, begin + na, begin + na + nb, depth + 1);
+    std::thread t([&C, &r1, begin, na, depth] { r1 = nd(C, begin, begin + na, depth + 1); });
+    r2 = nd(C, begin + na, begin + na + nb, depth + 1);
     t.join();
   } else {
-    nd(C, begin, begin + na, depth + 1);
-    nd(C, begin + na, begin + na + nb, depth + 1);
+    r1 = nd(C, begin, begin + na, depth + 1);
+    r2 = nd(C, begin + na, begin + na + nb, depth + 1);
   }
+  // Only the half right in front of the separator can share a panel with it (see the amalgamation in analyze()):
+  // that should be the taller one, so the two blocks trade places when the first turned out taller.
+  const int s0 = begin + na + nb;
+  if (r1.height > r2.height) {
+    std::rotate(C.order.begin() + begin, C.order.begin() + begin + na, C.order.begin() + s0);
+    std::rotate(C.pstart.begin() + begin, C.pstart.begin() + begin + na, C.pstart.begin() + s0);
+    std::swap(r1, r2);
+  }
+  // the separator in runs of kPanelW; when its remainder fits into the last panel of the half in front of it, the
+  // remainder goes first so that the amalgamation can merge the two (one level less on that path)
+  const int ssz = end - s0, rem = ssz % kPanelW;
+  NDRange out;
+  if (rem != 0 && r2.last + rem <= kPanelW) {
+    C.pstart[s0] = 1;
+    NDRange rest = emit_panels(C, s0 + rem, end);
+    out.last = ssz == rem ? r2.last + rem : rest.last;
+    out.height = std::max(r1.height + 1, r2.height) + rest.height;
+  } else {
+    NDRange all = emit_panels(C, s0, end);
+    out.last = all.last;
+    out.height = std::max(r1.height, r2.height) + all.height;
+  }
+  return out;
 }
 
 // run fn(lo, hi) over [0, n) on up to nthreads threads (static split)
@@ -306,6 +340,9 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   std::vector<std::vector<int32_t>> kids(nfr);
   S.rows.clear();
   std::vector<int32_t> list;
+  std::vector<uint8_t> dead(nfr, 0);
+  int ndead = 0;
+  static const bool amalgamate = !(getenv("CGMR_AMALGAMATE") && atoi(getenv("CGMR_AMALGAMATE")) == 0);
   for (int f = 0; f < nfr; f++) {
     FrontDesc& F = S.fronts[f];
     int last = F.c0 + F.nc - 1;
@@ -328,9 +365,54 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       int p = S.col_front[list[0]];
       F.parent = p;
       kids[p].push_back(f);
-      S.fronts[p].level = std::max(S.fronts[p].level, F.level + 1);
     }
     S.max_ns = std::max(S.max_ns, F.ns);
+    // Amalgamation: the front just before this one in the elimination order is absorbed when it is a child of this
+    // front and the two together still fit one panel.  Its border beyond my columns is part of my border already, so
+    // the row list stands; its columns merely carry explicit zeros in the rows it did not reach.  Every merge takes a
+    // level out of the paths through it -- the factorisation pays per level, not per flop.
+    while (amalgamate && f > 0) {
+      int g = f - 1;
+      while (g >= 0 && dead[g]) g--;
+      if (g < 0) break;
+      FrontDesc& G = S.fronts[g];
+      if (G.parent != f || G.c0 + G.nc != F.c0 || G.nc + F.nc > kPanelW) break;
+      std::vector<int32_t>& kf = kids[f];
+      auto it = std::find(kf.begin(), kf.end(), g);
+      const size_t at = it - kf.begin();
+      kf.erase(it);
+      kf.insert(kf.begin() + at, kids[g].begin(), kids[g].end());
+      for (int ch : kids[g]) S.fronts[ch].parent = f;
+      kids[g].clear();
+      F.c0 = G.c0;
+      F.nc += G.nc;
+      for (int c = G.c0; c < G.c0 + G.nc; c++) S.col_front[c] = f;
+      dead[g] = 1;
+      ndead++;
+    }
+  }
+  if (ndead > 0) {                    // compact the front table (ids stay monotone: children before parents)
+    std::vector<int32_t> newid(nfr, -1);
+    int k = 0;
+    for (int f = 0; f < nfr; f++) if (!dead[f]) newid[f] = k++;
+    for (int f = 0; f < nfr; f++) {
+      if (dead[f]) continue;
+      FrontDesc F = S.fronts[f];
+      if (F.parent >= 0) F.parent = newid[F.parent];
+      S.fronts[newid[f]] = F;
+      std::vector<int32_t> kf;
+      for (int ch : kids[f]) kf.push_back(newid[ch]);
+      kids[newid[f]] = std::move(kf);
+    }
+    nfr = k;
+    S.fronts.resize(nfr);
+    kids.resize(nfr);
+    for (int c = 0; c < nf; c++) S.col_front[c] = newid[S.col_front[c]];
+  }
+  for (int f = 0; f < nfr; f++) {     // levels: 0 = no children
+    int lv = 0;
+    for (int ch : kids[f]) lv = std::max(lv, S.fronts[ch].level + 1);
+    S.fronts[f].level = lv;
   }
   // children lists, rel / inv maps, A lists, offsets
   std::vector<int32_t> posmap(nf, -1);

@@ -21,6 +21,8 @@ constexpr int kFactorHeader = 2 * kFrontW * kFrontW + kFrontW;  // L11 row-major
 constexpr int kChunkRows = 191;      // border rows per k_front_factor workgroup: 3 wavefronts minus the lane that
                                      // carries the right-hand side through the factorisation
 
+constexpr int kLeafChunkRows = 62;   // the same for a level of leaves (k_front_factor_leaf: three workgroups per CU, 48 KB of LDS each)
+
 struct FrontDesc {                   // one per front, uploaded verbatim (all int32 / int64)
   int32_t c0;         // first block column (permuted order)
   int32_t nc;         // block columns owned by this front (<= kPanelW)
