@@ -250,9 +250,11 @@ void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double*
   hipStream_t st = ctx->stream;
   KTimer T{ctx};
   T.run(0, 1, [&] { launch_linearize(st, D, d_poses, D.ef, D.et, d_meas, d_info, chi_only ? 1 : 0); });
-  T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
-  if (chi_only || D.nf == 0) return;
-  T.run(1, 1, [&] { launch_assemble(st, D); });
+  if (chi_only || D.nf == 0) {
+    T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
+    return;
+  }
+  T.run(1, 1, [&] { launch_assemble(st, D, D.chi2 + it); });   // + the chi2 sum of this iteration
   static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;
   if (trace)
     fprintf(stderr, "[cgmr] arena %p .. %p; work %p rel %p apack %p Ablk %p bvec %p yvec %p uvec %p Lbuf %p Ubuf %p chi2 %p\n",

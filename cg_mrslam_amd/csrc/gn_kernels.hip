@@ -44,14 +44,18 @@ __device__ __forceinline__ double d_normalize_theta(double t) {
 // One thread per edge.  Writes the edge's quadratic-form terms component-major
 // (term[comp * nE + edge]) so that the stores of a wavefront are coalesced:
 //   comps  0.. 8  Hii = Ji^T O Ji      9..17  Hij = Ji^T O Jj     18..26  Hjj = Jj^T O Jj
-//         27..29  bi  = -Ji^T O e     30..32  bj  = -Jj^T O e         33   chi2 = e^T O e
+//         27..29  bi  = -Ji^T O e     30..32  bj  = -Jj^T O e
+// chi2 = e^T O e is summed per workgroup (fixed tree) into term[33 * nE + blockIdx.x]; block_chi2_sum() adds the
+// partial sums up, again in a fixed order: bit-reproducible.
 // Math: EdgeSE2::computeError / linearizeOplus / constructQuadraticForm.
 __global__ __launch_bounds__(256) void k_linearize(int nE, const double* __restrict__ poses,
                                                    const int32_t* __restrict__ ef, const int32_t* __restrict__ et,
                                                    const double* __restrict__ meas, const double* __restrict__ info,
                                                    double* __restrict__ term, int chi_only) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nE) return;
+  __shared__ double s_chi[4];
+  const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = k0 < nE;
+  const int k = live ? k0 : nE - 1;                      // idle lanes of the last workgroup shadow the last edge
   int i = ef[k], j = et[k];
   double xi0 = poses[3 * i], xi1 = poses[3 * i + 1], xi2 = poses[3 * i + 2];
   double xj0 = poses[3 * j], xj1 = poses[3 * j + 1], xj2 = poses[3 * j + 2];
@@ -69,8 +73,15 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, const double* __restr
 #pragma unroll
   for (int r = 0; r < 3; r++) Oe[r] = O[3 * r] * e[0] + O[3 * r + 1] * e[1] + O[3 * r + 2] * e[2];
   size_t E = (size_t)nE;
-  term[33 * E + k] = e[0] * Oe[0] + e[1] * Oe[1] + e[2] * Oe[2];
-  if (chi_only) return;
+  {
+    double ch = live ? e[0] * Oe[0] + e[1] * Oe[1] + e[2] * Oe[2] : 0.0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ch += __shfl_xor(ch, m, 64);
+    if ((threadIdx.x & 63) == 0) s_chi[threadIdx.x >> 6] = ch;
+    __syncthreads();
+    if (threadIdx.x == 0) term[33 * E + blockIdx.x] = (s_chi[0] + s_chi[1]) + (s_chi[2] + s_chi[3]);
+  }
+  if (chi_only || !live) return;
   double A[9] = {-c, -s, -s * dx + c * dy, s, -c, -c * dx - s * dy, 0, 0, -1};
   double B[9] = {c, s, 0, -s, c, 0, 0, 0, 1};
   double Ji[9], Jj[9];
@@ -111,11 +122,17 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, const double* __restr
 // One thread per scalar of a Hessian block (nf diagonal + nb lower off-diagonal blocks, 9
 // scalars each) followed by one thread per scalar of b.  Each thread walks its block's CSR
 // list of contributing edge terms in a fixed order (deterministic sums).
+// The last workgroup of the grid adds up the chi2 partial sums of the linearisation instead (saves a launch per iteration).
+__device__ __forceinline__ void block_chi2_sum(int nP, const double* __restrict__ part, double* __restrict__ out);
 __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const int32_t* __restrict__ asm_ptr,
                                                   const int32_t* __restrict__ asm_src,
                                                   const int32_t* __restrict__ blk_slot,
                                                   const double* __restrict__ term, double* __restrict__ Ablk,
-                                                  double* __restrict__ bvec) {
+                                                  double* __restrict__ bvec, double* __restrict__ chi_out) {
+  if (blockIdx.x == gridDim.x - 1) {
+    block_chi2_sum((nE + 255) / 256, term + (size_t)33 * nE, chi_out);
+    return;
+  }
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int nblk = nf + nb;
   size_t E = (size_t)nE;
@@ -145,18 +162,22 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
   }
 }
 
-// deterministic sum of the per-edge chi2 terms (one workgroup, fixed tree)
-__global__ __launch_bounds__(1024) void k_chi2_reduce(int nE, const double* __restrict__ chi, double* __restrict__ out) {
-  __shared__ double sh[1024];
+// deterministic sum of the per-workgroup chi2 partial sums of k_linearize (one workgroup of 256 threads, fixed tree)
+__device__ __forceinline__ void block_chi2_sum(int nP, const double* __restrict__ part, double* __restrict__ out) {
+  __shared__ double sh[256];
   double acc = 0;
-  for (int k = threadIdx.x; k < nE; k += 1024) acc += chi[k];
+  for (int k = threadIdx.x; k < nP; k += 256) acc += part[k];
   sh[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
+  for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
     __syncthreads();
   }
   if (threadIdx.x == 0) *out = sh[0];
+}
+
+__global__ __launch_bounds__(256) void k_chi2_reduce(int nP, const double* __restrict__ part, double* __restrict__ out) {
+  block_chi2_sum(nP, part, out);
 }
 
 // ------------------------------------------------------------------------- front factorise
@@ -918,13 +939,13 @@ void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, co
 }
 
 void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
-  hipLaunchKernelGGL(k_chi2_reduce, dim3(1), dim3(1024), 0, st, D.nE, D.term + (size_t)33 * D.nE, out);
+  hipLaunchKernelGGL(k_chi2_reduce, dim3(1), dim3(256), 0, st, (D.nE + 255) / 256, D.term + (size_t)33 * D.nE, out);
 }
 
-void launch_assemble(hipStream_t st, const GnDevice& D) {
+void launch_assemble(hipStream_t st, const GnDevice& D, double* chi_out) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
-  hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_slot, D.term, D.Ablk, D.bvec);
+  hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256 + 1), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
+                     D.asm_src, D.blk_slot, D.term, D.Ablk, D.bvec, chi_out);
 }
 
 void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag, bool write_l11c) {

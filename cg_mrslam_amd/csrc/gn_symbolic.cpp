@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -202,6 +203,9 @@ int host_threads() {
 
 int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S) {
   double t0 = now_s();
+  static const bool trace = getenv("CGMR_SYM_TRACE") != nullptr;
+  double tc = t0;
+  auto CK = [&](const char* what) { if (trace) { double t = now_s(); fprintf(stderr, "  sym %-28s %7.1f us\n", what, 1e6 * (t - tc)); tc = t; } };
   S = Symbolic();
   S.nV = nV;
   S.nE = nE;
@@ -244,6 +248,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     ap[nf] = w;
     ai.resize(w);
   }
+  CK("adjacency");
   // nested dissection
   const int NT = host_threads();
   std::vector<int32_t> order(nf), panel_start;
@@ -263,6 +268,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   for (int p = 0; p < nf; p++) iperm[order[p]] = p;
   S.perm.assign(nf, -1);
   for (int v = 0; v < nV; v++) if (S.hidx[v] >= 0) { S.vperm[v] = iperm[S.hidx[v]]; S.perm[S.vperm[v]] = v; }
+  CK("nested dissection + perm");
   S.t_order = now_s() - t0;
   double t1 = now_s();
 
@@ -276,6 +282,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       std::sort(ci.begin() + cp[c], ci.begin() + cp[c + 1]);
     }
   });
+  CK("permuted adjacency");
   // unique lower off-diagonal blocks: enumerate (c, r>c) column-major
   std::vector<int32_t> offbase(nf + 1, 0);
   for (int c = 0; c < nf; c++) {
@@ -296,6 +303,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     int pos = std::lower_bound(ci.begin() + first_gt, ci.begin() + hi, r) - ci.begin();
     return offbase[c] + (pos - first_gt);
   };
+  CK("off-diagonal blocks");
   // assembly CSR: block -> contributing edge terms
   S.asm_ptr.assign(nf + S.nb + 1, 0);
   std::vector<int32_t> e_off(nE, -1);
@@ -323,6 +331,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       // a > b: lower block (row a = i, col b = j) is Hij as is; else (row b = j, col a = i) = Hij^T
     }
   }
+  CK("assembly lists");
   // fronts
   int nfr = (int)panel_start.size();
   S.fronts.assign(nfr, FrontDesc());
@@ -414,6 +423,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     for (int ch : kids[f]) lv = std::max(lv, S.fronts[ch].level + 1);
     S.fronts[f].level = lv;
   }
+  CK("borders + amalgamation");
   // children lists, rel / inv maps, A lists, offsets
   std::vector<int32_t> posmap(nf, -1);
   int64_t Loff = 0, Uoff = 0;
@@ -458,6 +468,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     F.U_off = Uoff; Uoff += (r * r + r + 3) & ~int64_t(1);      // even offsets: the update matrices are read with 16-byte loads
     flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
   }
+  CK("maps + A lists");
   S.L_doubles = Loff;
   S.U_doubles = Uoff;
   S.flops = flops;

@@ -26,4 +26,4 @@ while True:
     f = max(kids[f], key=lambda q: lev[q])
 print("longest path, root first (front: c0 nc ns nchild level):")
 for f in path:
-    print("  %5d: c0 %5d nc %2d ns %3d nchild %2d level %2d  next-front-adjacent %s" % (f, F[f, 0], F[f, 1], F[f, 2], F[f, 5], F[f, 4], "yes" if (f + 1 < n and F[f, 3] == f + 1) else "no"))
+    print("  %5d: c0 %5d nc %2d ns %3d nchild %2d level %2d  next-front-adjacent %s" % (f, F[f, 0], F[f, 1], F[f, 2], F[f, 5], F[f, 4], "yes" if (f + 1 < n and F[f, 3] == f + 1) else "no"), " children (id:level:nc)", [(k, int(lev[k]), int(F[k, 1])) for k in kids[f]])
