@@ -268,28 +268,32 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 // Thread = (column pair cp, row lane rr): it owns columns 2cp, 2cp+1 of rows rr, rr + rpp, rr + 2 rpp, ... of the
 // block, so one column-map lookup and one row-map lookup per load.  Everything is issued by slab_issue() before
 // slab_scatter() touches any of it.
-struct SlabLoads {
-  double2 v[SU];
+template <int N>
+struct SlabLoadsT {
+  double2 v[N];
   double u;
 };
+typedef SlabLoadsT<SU> SlabLoads;
 struct SlabGeom {
   int cpw, rpp, rr, cp, rows;         // column pairs per row, rows per pass, my row lane / column pair, rows per block
 };
+template <int N = SU>
 __device__ __forceinline__ SlabGeom slab_geom(int tid, int ra) {
   SlabGeom g;
   g.cpw = max((ra + 1) >> 1, 1);
   g.rpp = 256 / g.cpw;
   g.rr = tid / g.cpw;
   g.cp = tid - g.rr * g.cpw;
-  g.rows = min(MAPW, g.rpp * SU);
+  g.rows = min(MAPW, g.rpp * N);
   return g;
 }
 
-__device__ __forceinline__ void slab_issue(SlabLoads& S, const SlabGeom& g, int tid, const double* __restrict__ U,
+template <int N>
+__device__ __forceinline__ void slab_issue(SlabLoadsT<N>& S, const SlabGeom& g, int tid, const double* __restrict__ U,
                                            const double* __restrict__ uc, int rg, int ra2, int row0) {
   const int rend = min(rg, row0 + g.rows);
 #pragma unroll
-  for (int u = 0; u < SU; u++) {
+  for (int u = 0; u < N; u++) {
     const int row = row0 + g.rr + g.rpp * u;
     const bool ok = g.rr < g.rpp && row < rend;
     S.v[u] = *reinterpret_cast<const double2*>(U + (ok ? (size_t)row * ra2 + 2 * g.cp : 0));   // idle lanes re-read element 0
@@ -301,27 +305,28 @@ __device__ __forceinline__ void slab_issue(SlabLoads& S, const SlabGeom& g, int 
 // lies kRIdx doubles behind Ls in LDS: one index space).  rmap[k] = position of child row row0 + k in my row list
 // (0..w-1 own columns, w.. border), cmap = the same map for rows 0..ra-1.  A child never sends two elements to the
 // same cell, so the adds of one call do not collide; calls for different children are separated by a barrier.
-__device__ __forceinline__ void slab_scatter(const SlabLoads& S, const SlabGeom& g, int tid, int rg, int ra, int row0,
+template <int N>
+__device__ __forceinline__ void slab_scatter(const SlabLoadsT<N>& S, const SlabGeom& g, int tid, int rg, int ra, int row0,
                                              const short* rmap, const short* cmap, int w, int r0, int nr, double* Ls) {
   const int rend = min(rg, row0 + g.rows);
   // every map lookup first ...
-  int prow[SU];
+  int prow[N];
 #pragma unroll
-  for (int u = 0; u < SU; u++) prow[u] = rmap[min(g.rr + g.rpp * u, g.rows - 1)];
+  for (int u = 0; u < N; u++) prow[u] = rmap[min(g.rr + g.rpp * u, g.rows - 1)];
   const int col0 = 2 * g.cp, col1 = 2 * g.cp + 1;
   const int pc0 = cmap[min(col0, max(ra - 1, 0))], pc1 = cmap[min(col1, max(ra - 1, 0))];
   const int prowu = rmap[min(tid, g.rows - 1)];
   // ... then the targets, then the adds
-  int dst[SU];
+  int dst[N];
 #pragma unroll
-  for (int u = 0; u < SU; u++) {
+  for (int u = 0; u < N; u++) {
     const int row = row0 + g.rr + g.rpp * u;
     const bool ok = g.rr < g.rpp && row < rend;
     const int pr = prow[u] - w - r0;
     dst[u] = !ok ? -1 : prow[u] < w ? prow[u] * LDW : (pr >= 0 && pr < nr) ? kRIdx + pr * LDW : -1;
   }
 #pragma unroll
-  for (int u = 0; u < SU; u++) {
+  for (int u = 0; u < N; u++) {
     const int row = row0 + g.rr + g.rpp * u;
     if (dst[u] < 0) continue;
     // rows of the leading block (row < ra) hold their lower triangle only
@@ -334,6 +339,8 @@ __device__ __forceinline__ void slab_scatter(const SlabLoads& S, const SlabGeom&
     else if (pr >= 0 && pr < nr) lds_add(Ls + kRIdx + pr * LDW + W, S.u);
   }
 }
+
+constexpr int SUS = kSmallSlabLoads;   // loads per thread that cover the whole leading slab of a "small" child (gn_symbolic.h)
 
 // child ci of the front: descriptor from the work record (first MAXC children) or from the front table
 __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDesc* __restrict__ fronts,
@@ -458,9 +465,12 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
   PHASE(2);
   // ---- round 3: the children's leading slabs, two children in flight
   if constexpr (!LEAF) {
-  for (int cb = 0; cb < ncb0; cb += 2) {
+  int nbig = 0;                                               // the big children come first
+  while (nbig < ncb0 && !slab_is_small(WR->ch[nbig].ns, WR->ch[nbig].na)) nbig++;
+  nbig = rfl(nbig);
+  for (int cb = 0; cb < nbig; cb += 2) {
     SlabLoads S0, S1;
-    const bool two = cb + 1 < ncb0;
+    const bool two = cb + 1 < nbig;
     const int cb1 = two ? cb + 1 : cb;
     const int rg0 = 3 * WR->ch[cb].ns, ra0 = 3 * WR->ch[cb].na;
     const int rg1 = 3 * WR->ch[cb1].ns, ra1 = 3 * WR->ch[cb1].na;
@@ -488,6 +498,28 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
         __syncthreads();
         slab_issue(S0, g, tid, Ubuf + WR->ch[cc].U_off, uvec + (size_t)3 * WR->ch[cc].rows_off, rg, even_up(ra), row0);
         slab_scatter(S0, g, tid, rg, ra, row0, s_rmap + cc * MAPW, s_cmap + cc * W, w, r0, nr, Ls);
+      }
+    }
+  }
+  // the small children: every load of every child first, then the adds child by child (fixed order, a barrier
+  // between two children: same sums as one child at a time, one memory round trip instead of one per pair)
+  if (nbig < ncb0) {
+    SlabLoadsT<SUS> T[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      if (c >= nbig && c < ncb0) {
+        const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
+        const SlabGeom g = slab_geom<SUS>(tid, ra);
+        slab_issue(T[c], g, tid, Ubuf + WR->ch[c].U_off, uvec + (size_t)3 * WR->ch[c].rows_off, rg, even_up(ra), 0);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      if (c >= nbig && c < ncb0) {
+        const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
+        const SlabGeom g = slab_geom<SUS>(tid, ra);
+        if (c > 0) __syncthreads();
+        slab_scatter(T[c], g, tid, rg, ra, 0, s_rmap + c * MAPW, s_cmap + c * W, w, r0, nr, Ls);
       }
     }
   }

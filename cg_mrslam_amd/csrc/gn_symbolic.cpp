@@ -430,6 +430,16 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   double flops = 0;
   for (int f = 0; f < nfr; f++) {
     FrontDesc& F = S.fronts[f];
+    // children: the big ones first (see slab_is_small), each group in id order
+    if (kids[f].size() > 1) {
+      const int cend = F.c0 + F.nc;
+      std::stable_partition(kids[f].begin(), kids[f].end(), [&](int ch) {
+        const FrontDesc& G = S.fronts[ch];
+        const int32_t* gr = S.rows.data() + G.rows_off;
+        const int na = (int)(std::lower_bound(gr, gr + G.ns, cend) - gr);
+        return !slab_is_small(G.ns, na);
+      });
+    }
     F.child_off = (int)S.children.size();
     F.nchild = (int)kids[f].size();
     S.children.insert(S.children.end(), kids[f].begin(), kids[f].end());

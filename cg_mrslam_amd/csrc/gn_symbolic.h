@@ -23,6 +23,16 @@ constexpr int kChunkRows = 191;      // border rows per k_front_factor workgroup
 
 constexpr int kLeafChunkRows = 62;   // the same for a level of leaves (k_front_factor_leaf: three workgroups per CU, 48 KB of LDS each)
 
+// A child is "small" when kSmallSlabLoads 16-byte loads per thread (256 threads, one column pair of one row each) cover
+// the whole leading slab of its update matrix: k_front_factor fetches all small children of a front in one round.
+// The children of a front are listed big ones first.
+constexpr int kSmallSlabLoads = 4;
+constexpr bool slab_is_small(int ns, int na) {
+  const int cpw = (3 * na + 1) / 2 > 1 ? (3 * na + 1) / 2 : 1;
+  const int rows = (256 / cpw) * kSmallSlabLoads < 256 ? (256 / cpw) * kSmallSlabLoads : 256;
+  return 3 * ns <= rows;
+}
+
 struct FrontDesc {                   // one per front, uploaded verbatim (all int32 / int64)
   int32_t c0;         // first block column (permuted order)
   int32_t nc;         // block columns owned by this front (<= kPanelW)
