@@ -70,8 +70,8 @@ struct BlobLayout {
 // Lay out and upload the structure arrays; point GnDevice into the arena.
 int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t* et, int iters) {
   // the factor kernels keep row positions (own columns + border rows) in 16-bit LDS maps
-  if (3 * (int64_t)S.max_ns + kFrontW > 32767)
-    return set_err(ctx, CGMR_E_INVALID, "a front has %d border poses; at most %d are supported", S.max_ns, (32767 - kFrontW) / 3);
+  if (3 * (int64_t)S.max_ns + kWideFrontW > 32767)
+    return set_err(ctx, CGMR_E_INVALID, "a front has %d border poses; at most %d are supported", S.max_ns, (32767 - kWideFrontW) / 3);
   GnDevice& D = ctx->gn;
   D.nV = S.nV; D.nE = S.nE; D.nf = S.nf; D.nb = S.nb;
   D.nfronts = (int)S.fronts.size();
@@ -85,13 +85,15 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.h_level_chrows.assign(D.nlevels, 1);
   D.h_level_leaf.assign(D.nlevels, 1);
   D.h_level_chunk.assign(D.nlevels, kChunkRows);
+  D.h_level_w = S.level_w;
   static const int leaf_chunk = getenv("CGMR_LEAF_CHUNK") ? atoi(getenv("CGMR_LEAF_CHUNK")) : kLeafChunkRows;
   for (int l = 0; l < D.nlevels; l++) {
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++)
       if (S.fronts[S.level_fronts[q]].nchild > 0) D.h_level_leaf[l] = 0;
     // a level of leaves runs the register-light variant of the factor kernel: shorter chunks, so that the LDS of two
     // workgroups fits a CU
-    const int chunk_rows = D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : kChunkRows;
+    const int chunk_rows = S.level_w[l] == kWideFrontW ? kWideChunkRows
+                           : (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : kChunkRows);
     D.h_level_chunk[l] = chunk_rows;
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
       int f = S.level_fronts[q];

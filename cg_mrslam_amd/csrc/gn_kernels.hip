@@ -26,10 +26,49 @@ namespace cgmr {
 
 namespace {
 
-constexpr int W = 3 * kPanelW;       // 48 scalar columns per front (zero / identity padded)
-constexpr int LDW = W + 1;           // LDS row stride (doubles), odd => conflict-free b64 column access
-constexpr int CH = kChunkRows + 1;   // rows of the LDS staging area: border rows of the chunk + the rhs row
 constexpr int TS = 32;               // tile edge of k_front_update
+constexpr int kRecIntsC = (int)(sizeof(WorkRec) / 4);
+constexpr int kMapW = 256;           // child rows per staged block of the row map (one per thread)
+
+// Every kernel that touches a factor panel is instantiated for the two panel widths, W = 48 scalar columns (fronts of
+// up to 16 poses) and W = 96 (the wide fronts near the top of the tree); all fronts of a level share the width.
+// Factor panel layout in Lbuf (doubles, all strides padded to W columns):
+//   [0, W*W)        L11 row-major   (lower triangle, zeros above)      -> backward solve
+//   [W*W, 2*W*W)    L11 column-major                                   -> forward solve of the marginals
+//   [2*W*W, +W)     1 / diag(L11)
+//   [2*W*W+W, ...)  L21, r rows of W
+// LDS plan of k_front_factor (bytes):
+//   Ls   [W][LDW]  doubles   F11 (assembly), factored in place
+//   maps: s_rmap[MAXC][kMapW] (child row -> position in my row list), s_cmap[MAXC][W] shorts; the work record
+//   Dinv [W] doubles: reciprocals of the pivots
+//   R    [ch_rows][LDW] doubles   chunk of F21 + the rhs row; ch_rows is the level's maximum.  R comes last: a level
+//        whose fronts have few border rows is launched with less LDS, so that several workgroups share a CU.
+#define CGMR_FRONT_CONSTS(WW)                                                                              \
+  [[maybe_unused]] constexpr int W = (WW);                                                                 \
+  [[maybe_unused]] constexpr int LDW = W + 1; /* LDS row stride (doubles), odd => conflict-free b64 column access */ \
+  [[maybe_unused]] constexpr int kL11c = W * W;                                                            \
+  [[maybe_unused]] constexpr int kDinv = 2 * W * W;                                                        \
+  [[maybe_unused]] constexpr int kL21 = 2 * W * W + W;                                                     \
+  [[maybe_unused]] constexpr int kOffLs = 0;                                                               \
+  [[maybe_unused]] constexpr int kOffRmap = kOffLs + W * LDW * 8;                                          \
+  [[maybe_unused]] constexpr int kOffCmap = kOffRmap + 2 * kWorkChildren * kMapW;                          \
+  [[maybe_unused]] constexpr int kOffRec = ((kOffCmap + 2 * kWorkChildren * W + 15) / 16) * 16;            \
+  [[maybe_unused]] constexpr int kOffDinv = ((kOffRec + 4 * kRecIntsC + 15) / 16) * 16;                    \
+  [[maybe_unused]] constexpr int kOffR = ((kOffDinv + W * 8 + 15) / 16) * 16;                              \
+  [[maybe_unused]] constexpr int kRIdx = (kOffR - kOffLs) / 8 /* R[0] as an index from Ls */
+
+// LDS bytes of a k_front_factor workgroup whose staging area holds `rows` rows (border rows of the chunk + the rhs row)
+constexpr int factor_smem_bytes(int w, int rows) {
+  const int ldw = w + 1;
+  const int off_cmap = w * ldw * 8 + 2 * kWorkChildren * kMapW;
+  const int off_rec = ((off_cmap + 2 * kWorkChildren * w + 15) / 16) * 16;
+  const int off_dinv = ((off_rec + 4 * kRecIntsC + 15) / 16) * 16;
+  const int off_r = ((off_dinv + w * 8 + 15) / 16) * 16;
+  return off_r + rows * ldw * 8;
+}
+static_assert(factor_smem_bytes(kFrontW, kChunkRows + 1) <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
+static_assert(factor_smem_bytes(kWideFrontW, kWideChunkRows + 1) <= 160 * 1024, "k_front_factor (wide) LDS plan exceeds 160 KiB");
+static_assert(factor_smem_bytes(kFrontW, kLeafChunkRows + 1) <= 48 * 1024, "leaf variant: three workgroups per CU need <= 48 KiB each");
 
 __device__ __forceinline__ double d_normalize_theta(double t) {
   const double pi = 3.14159265358979323846;
@@ -181,14 +220,6 @@ __global__ __launch_bounds__(256) void k_chi2_reduce(int nP, const double* __res
 }
 
 // ------------------------------------------------------------------------- front factorise
-// Factor panel layout in Lbuf (doubles, all strides padded to W = 48 columns):
-//   [0, W*W)        L11 row-major   (lower triangle, zeros above)      -> backward solve
-//   [W*W, 2*W*W)    L11 column-major                                   -> forward solve
-//   [2*W*W, +W)     1 / diag(L11)
-//   [2*W*W+W, ...)  L21, r rows of W
-constexpr int kL11c = W * W;
-constexpr int kDinv = 2 * W * W;
-constexpr int kL21 = 2 * W * W + W;
 #ifdef CGMR_PHASE_TIMING
 __device__ unsigned long long g_phase[64 * 8];
 __device__ unsigned long long g_wphase[8 * 8192];          // per work item: cycle counter at PHASE(0..6)
@@ -220,8 +251,8 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record / whose maps are staged together
-constexpr int kRecInts = (int)(sizeof(WorkRec) / 4);
-constexpr int MAPW = 256;            // child rows per staged block of the row map (one per thread)
+constexpr int kRecInts = kRecIntsC;
+constexpr int MAPW = kMapW;
 constexpr int SU = 24;               // double2 loads per thread and block: 256 rows x 48 columns of a child's leading slab
 // Update matrix of a front with r border rows, the first ra of which fall into its parent's own columns
 // (Ubuf + U_off, U_off even):
@@ -234,23 +265,6 @@ __device__ __forceinline__ size_t uidx(int gi, int gj, int r, int ra) {
   const int ra2 = even_up(ra);      // row stride of slab A: rows start on 16-byte boundaries
   return gj < ra ? (size_t)gi * ra2 + gj : (size_t)r * ra2 + (size_t)(gi - ra) * (r - ra) + (gj - ra);
 }
-// LDS plan of k_front_factor (bytes), one workgroup per CU:
-//   Ls   [W][LDW]  doubles   F11 (assembly), later the staging buffer of L11 for coalesced copies
-//   R    [ch_rows][LDW] doubles   chunk of F21 + the rhs row (assembly); ch_rows <= CH is the level's maximum
-//   maps: s_rmap[MAXC][MAPW] (child row -> position in my row list), s_cmap[MAXC][W] shorts; the work record
-//   Dinv [W] doubles: reciprocals of the pivots
-constexpr int kOffLs = 0;
-constexpr int kOffRmap = kOffLs + W * LDW * 8;
-constexpr int kOffCmap = kOffRmap + 2 * MAXC * MAPW;
-constexpr int kOffRec = ((kOffCmap + 2 * MAXC * W + 15) / 16) * 16;
-constexpr int kOffDinv = ((kOffRec + 4 * kRecInts + 15) / 16) * 16;
-constexpr int kOffR = ((kOffDinv + W * 8 + 15) / 16) * 16;     // R comes last: a level whose fronts have few border rows is
-                                                              // launched with less LDS, so that two workgroups share a CU
-constexpr int kRIdx = (kOffR - kOffLs) / 8;                  // R[0] as an index from Ls (slab_scatter uses one index space)
-constexpr int kSmemBytes = kOffR + CH * LDW * 8;
-static_assert(kSmemBytes <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
-static_assert(kOffR + (kLeafChunkRows + 1) * LDW * 8 <= 48 * 1024, "leaf variant: three workgroups per CU need <= 48 KiB each");
-
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ long long rfl64(long long v) {
   return ((long long)rfl((int)(v >> 32)) << 32) | (unsigned)rfl((int)v);
@@ -267,7 +281,7 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 // One block of a child's leading slab plus the matching piece of its border vector, as loaded by one thread.
 // Thread = (column pair cp, row lane rr): it owns columns 2cp, 2cp+1 of rows rr, rr + rpp, rr + 2 rpp, ... of the
 // block, so one column-map lookup and one row-map lookup per load.  Everything is issued by slab_issue() before
-// slab_scatter() touches any of it.
+// slab_scatter<WW>() touches any of it.
 template <int N>
 struct SlabLoadsT {
   double2 v[N];
@@ -305,9 +319,10 @@ __device__ __forceinline__ void slab_issue(SlabLoadsT<N>& S, const SlabGeom& g, 
 // lies kRIdx doubles behind Ls in LDS: one index space).  rmap[k] = position of child row row0 + k in my row list
 // (0..w-1 own columns, w.. border), cmap = the same map for rows 0..ra-1.  A child never sends two elements to the
 // same cell, so the adds of one call do not collide; calls for different children are separated by a barrier.
-template <int N>
+template <int WW, int N>
 __device__ __forceinline__ void slab_scatter(const SlabLoadsT<N>& S, const SlabGeom& g, int tid, int rg, int ra, int row0,
                                              const short* rmap, const short* cmap, int w, int r0, int nr, double* Ls) {
+  CGMR_FRONT_CONSTS(WW);
   const int rend = min(rg, row0 + g.rows);
   // every map lookup first ...
   int prow[N];
@@ -366,7 +381,7 @@ __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDes
 // Then the blocked factorisation of the panel in LDS (see below) and the stores.  The update matrix
 // U = ext_add - L21 L21^T of every front is formed by k_front_update, whose tiles spread over the idle CUs: forming
 // it here (tried for fronts of up to 96 border rows) made those fronts the slowest workgroup of their level.
-template <bool LEAF>
+template <bool LEAF, int WW>
 __device__ __forceinline__ void front_factor_body(unsigned char* smem, const WorkRec* __restrict__ work, int work_begin,
                                                   const FrontDesc* __restrict__ fronts,
                                                   const int32_t* __restrict__ children,
@@ -377,6 +392,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
                                                   double* __restrict__ yvec, double* __restrict__ uvec,
                                                   int* __restrict__ status, int iter_tag, int level_id,
                                                   int write_l11c, int ch_rows, int chunk_rows) {
+  CGMR_FRONT_CONSTS(WW);
   double* Ls = reinterpret_cast<double*>(smem + kOffLs);
   double* R = reinterpret_cast<double*>(smem + kOffR);
   short* s_rmap = reinterpret_cast<short*>(smem + kOffRmap);
@@ -482,10 +498,10 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
     slab_issue(S0, g0, tid, U0, uc0, rg0, even_up(ra0), 0);
     if (two) slab_issue(S1, g1, tid, U1, uc1, rg1, even_up(ra1), 0);
     if (cb > 0) __syncthreads();
-    slab_scatter(S0, g0, tid, rg0, ra0, 0, s_rmap + cb * MAPW, s_cmap + cb * W, w, r0, nr, Ls);
+    slab_scatter<WW>(S0, g0, tid, rg0, ra0, 0, s_rmap + cb * MAPW, s_cmap + cb * W, w, r0, nr, Ls);
     if (two) {
       __syncthreads();
-      slab_scatter(S1, g1, tid, rg1, ra1, 0, s_rmap + cb1 * MAPW, s_cmap + cb1 * W, w, r0, nr, Ls);
+      slab_scatter<WW>(S1, g1, tid, rg1, ra1, 0, s_rmap + cb1 * MAPW, s_cmap + cb1 * W, w, r0, nr, Ls);
     }
     // children with more border rows than one block: the remaining row blocks, maps staged per block
     for (int cc = cb; cc <= cb1; cc++) {
@@ -497,7 +513,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
           s_rmap[cc * MAPW + tid] = (short)(3 * rel[WR->ch[cc].rel_off + (row0 + tid) / 3] + (row0 + tid) % 3);
         __syncthreads();
         slab_issue(S0, g, tid, Ubuf + WR->ch[cc].U_off, uvec + (size_t)3 * WR->ch[cc].rows_off, rg, even_up(ra), row0);
-        slab_scatter(S0, g, tid, rg, ra, row0, s_rmap + cc * MAPW, s_cmap + cc * W, w, r0, nr, Ls);
+        slab_scatter<WW>(S0, g, tid, rg, ra, row0, s_rmap + cc * MAPW, s_cmap + cc * W, w, r0, nr, Ls);
       }
     }
   }
@@ -519,7 +535,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
         const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
         const SlabGeom g = slab_geom<SUS>(tid, ra);
         if (c > 0) __syncthreads();
-        slab_scatter(T[c], g, tid, rg, ra, 0, s_rmap + c * MAPW, s_cmap + c * W, w, r0, nr, Ls);
+        slab_scatter<WW>(T[c], g, tid, rg, ra, 0, s_rmap + c * MAPW, s_cmap + c * W, w, r0, nr, Ls);
       }
     }
   }
@@ -538,7 +554,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
       __syncthreads();
       SlabLoads S0;
       slab_issue(S0, g, tid, Ubuf + G.U_off, uvec + (size_t)3 * G.rows_off, rg, even_up(ra), row0);
-      slab_scatter(S0, g, tid, rg, ra, row0, s_rmap, s_cmap, w, r0, nr, Ls);
+      slab_scatter<WW>(S0, g, tid, rg, ra, row0, s_rmap, s_cmap, w, r0, nr, Ls);
     }
   }
   __syncthreads();
@@ -654,35 +670,24 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
     for (int q = 0; q < 16; q++) xr[q] = x[q];
   };
   const int nbc = min(W / 16, (w + 15) >> 4);                // block columns that hold real columns
-  // right-looking schedule with look-ahead: block column J+1 is brought up to date first, then wavefront 0 factors
-  // its diagonal block while wavefronts 1-3 push the same update into block column J+2
+  // right-looking schedule with look-ahead: block column K+1 is brought up to date first, then wavefront 0 factors
+  // its diagonal block while wavefronts 1-3 push the same update into the block columns after it
   FPHASE(0);
   factor_diag(0);
   __syncthreads();
   FPHASE(1);
-  solve_rows(0);
-  __syncthreads();
-  FPHASE(2);
-  if (nbc > 1) {
-    update_tiles(1, 0, 0, 4);
+  for (int K = 0; K < nbc; K++) {
+    solve_rows(K);
     __syncthreads();
-    FPHASE(3);
-    factor_diag(1);
-    if (nbc > 2) update_tiles(2, 0, 1, 3);
-    __syncthreads();
-    FPHASE(4);
-    solve_rows(1);
-    __syncthreads();
-    FPHASE(5);
-    if (nbc > 2) {
-      update_tiles(2, 1, 0, 4);
+    if (K == 0) FPHASE(2);
+    if (K + 1 < nbc) {
+      update_tiles(K + 1, K, 0, 4);
       __syncthreads();
-      FPHASE(6);
-      factor_diag(2);
+      if (K == 0) FPHASE(3);
+      factor_diag(K + 1);
+      for (int J = K + 2; J < nbc; J++) update_tiles(J, K, 1, 3);
       __syncthreads();
-      FPHASE(7);
-      solve_rows(2);
-      __syncthreads();
+      if (K == 0) FPHASE(4);
     }
   }
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, iter_tag);
@@ -723,6 +728,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
   PHASE(6);
 }
 
+template <int WW>
 __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
                                                          const FrontDesc* __restrict__ fronts,
                                                          const int32_t* __restrict__ children,
@@ -734,12 +740,13 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
                                                          int* __restrict__ status, int iter_tag, int level_id,
                                                          int write_l11c, int ch_rows, int chunk_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  front_factor_body<false>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec, status,
-                           iter_tag, level_id, write_l11c, ch_rows, chunk_rows);
+  front_factor_body<false, WW>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec,
+                               status, iter_tag, level_id, write_l11c, ch_rows, chunk_rows);
 }
 
 // The leaves of the elimination tree (level 0: about half of all fronts) have no children: without the slab
-// streaming the kernel needs half the registers, so two workgroups share a CU and hide each other's round trips.
+// streaming the kernel needs a quarter of the registers, and with short chunks three workgroups share a CU and
+// hide each other's round trips.
 __global__ __launch_bounds__(256, 2) void k_front_factor_leaf(const WorkRec* __restrict__ work, int work_begin,
                                                                  const FrontDesc* __restrict__ fronts,
                                                                  const int32_t* __restrict__ children,
@@ -751,8 +758,8 @@ __global__ __launch_bounds__(256, 2) void k_front_factor_leaf(const WorkRec* __r
                                                                  int* __restrict__ status, int iter_tag, int level_id,
                                                                  int write_l11c, int ch_rows, int chunk_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  front_factor_body<true>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec, status,
-                          iter_tag, level_id, write_l11c, ch_rows, chunk_rows);
+  front_factor_body<true, kFrontW>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec,
+                                   status, iter_tag, level_id, write_l11c, ch_rows, chunk_rows);
 }
 
 // --------------------------------------------------------------------------- front update
@@ -762,12 +769,14 @@ __global__ __launch_bounds__(256, 2) void k_front_factor_leaf(const WorkRec* __r
 // record (front + first MAXC children) -> the two 32-row slices of L21 and, for every child, the rows of its
 // trailing block that feed this tile (inv maps) -> the children's values; the product runs while they are in
 // flight.  Children are added in child order after the product: same sums as a sequential extend-add.
+template <int WW>
 __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict__ work,
                                                       const int32_t* __restrict__ tiles, int tile_begin,
                                                       const FrontDesc* __restrict__ fronts,
                                                       const int32_t* __restrict__ children,
                                                       const int32_t* __restrict__ inv,
                                                       const double* __restrict__ Lbuf, double* __restrict__ Ubuf) {
+  CGMR_FRONT_CONSTS(WW);
   __shared__ double Ai[TS * LDW];
   __shared__ double Aj[TS * LDW];
   __shared__ __attribute__((aligned(8))) int s_rec[kRecInts];
@@ -784,7 +793,7 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   const double* L21 = Lbuf + L_off + kL21;
   const int i0 = ti * TS, j0 = tj * TS;
   // ---- the two L21 slices and every child's row lookups: all loads first, then the LDS writes
-  constexpr int LQ = TS * W / 256;                            // 6 elements of each slice per thread
+  constexpr int LQ = TS * W / 256;                            // 6 (12) elements of each slice per thread
   double li[LQ], lj[LQ];
 #pragma unroll
   for (int u = 0; u < LQ; u++) {
@@ -880,70 +889,143 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
 }
 
 // ------------------------------------------------------------------------------ solves
-// Backward (L^T x = y), one workgroup per front, top-down by level.  The border part of x is staged in LDS
-// first (its gather chains two dependent global loads per row, which must not sit inside the reduction loop).
+// Backward (L^T x = y), one workgroup per front, top-down by level: x_own = L11^-T (y - L21^T x_border).
+// A chain of dependent round trips (descriptor -> border row indices -> x of the border -> ...), so everything that
+// does not depend on x is in flight before x arrives: the first pass over L21 (thread = column pair x row group,
+// 16-byte loads, NL rows per thread in flight) and L11 for the triangular solve of wavefront 0 (lane = column; the
+// 48-column instance keeps its column of L11 in registers, the 96-column one -- two columns per lane -- stages L11
+// in LDS and reads one row per step).
 constexpr int XB_CAP = 1536;         // border rows staged per pass
+constexpr int kBwdNL = 24;           // L21 rows per thread and pass
+constexpr int bwd_smem_bytes(int w) { return ((w > 64 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP) * 8; }
+template <int WW>
 __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__ fronts,
                                                    const int32_t* __restrict__ level_fronts, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
                                                    const double* __restrict__ yvec, double* __restrict__ xvec) {
-  constexpr int G5 = 5;
-  __shared__ double part[G5 * W];
-  __shared__ double xb[XB_CAP];
+  CGMR_FRONT_CONSTS(WW);
+  constexpr int HP = W / 2;            // column pairs per row
+  constexpr int G = 256 / HP;          // row groups of the border reduction (10 / 5)
+  constexpr int NL = kBwdNL;
+  constexpr int CPL = (W + 63) / 64;   // columns per lane in the triangular solve
+  constexpr bool LDS_L11 = W > 64;
+  constexpr int XQ = XB_CAP / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  double* Lt = reinterpret_cast<double*>(smem_b);            // [W][W] L11 row-major (96-column instance only)
+  double* dinv = Lt + (LDS_L11 ? W * W : 0);                 // [W]
+  double* part = dinv + W;                                   // [G][W]
+  double* xb = part + G * W;                                 // [XB_CAP]
   const int tid = threadIdx.x;
   const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
   const int w = 3 * F.nc, r = 3 * F.ns;
   const double* P = Lbuf + F.L_off;
   const double* L21 = P + kL21;
-  double Lcol[W];
-  double dv = 1.0;
-  if (tid < 64) {
-    const int lane = min(tid, W - 1);
+  // ---- L11: independent of x
+  constexpr int LT_Q = LDS_L11 ? W * W / 256 : 1;
+  double lt[LT_Q];
+  double Lcol[LDS_L11 ? 1 : W];
+  if constexpr (LDS_L11) {
 #pragma unroll
-    for (int k = 0; k < W; k++) Lcol[k] = P[k * W + lane];     // element (row k, col lane)
-    dv = P[kDinv + lane];
+    for (int u = 0; u < LT_Q; u++) lt[u] = P[tid + 256 * u];
+  } else {
+    if (tid < 64) {
+      const int lane = min(tid, W - 1);
+#pragma unroll
+      for (int k = 0; k < W; k++) Lcol[k] = P[k * W + lane];   // element (row k, col lane)
+    }
   }
-  const int j = tid % W, g = tid / W;
-  double acc = 0;
+  const double dvl = (tid < W) ? P[kDinv + tid] : 1.0;
+  // ---- border: acc[0..1] = sum over my rows of L21[p][2cp .. 2cp+1] x_border[p]
+  const int cp = tid % HP, g = tid / HP;
+  const bool active = tid < G * HP;
+  double acc0 = 0, acc1 = 0;
   for (int p0 = 0; p0 < r; p0 += XB_CAP) {
     const int np = min(XB_CAP, r - p0);
-    __syncthreads();
-    for (int p = tid; p < np; p += 256) xb[p] = xvec[3 * rows[F.rows_off + (p0 + p) / 3] + (p0 + p) % 3];
-    __syncthreads();
-    if (tid < G5 * W) {
-      for (int base = g; base < np; base += G5 * 8) {
-        double l[8];
+    int xi[XQ];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          int p = base + G5 * u;
-          l[u] = (p < np) ? L21[(size_t)(p0 + p) * W + j] : 0.0;
-        }
+    for (int u = 0; u < XQ; u++) {
+      const int p = tid + 256 * u;
+      xi[u] = (p < np) ? rows[F.rows_off + (p0 + p) / 3] : 0;
+    }
+    double2 l[NL];                                             // first pass over L21: in flight before x arrives
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          int p = base + G5 * u;
-          if (p < np) acc = fma(l[u], xb[p], acc);
-        }
+    for (int u = 0; u < NL; u++) {
+      const int p = g + G * u;
+      l[u] = (active && p < np) ? *reinterpret_cast<const double2*>(L21 + (size_t)(p0 + p) * W + 2 * cp) : make_double2(0.0, 0.0);
+    }
+    double xr[XQ];
+#pragma unroll
+    for (int u = 0; u < XQ; u++) {
+      const int p = tid + 256 * u;
+      xr[u] = (p < np) ? xvec[3 * xi[u] + (p0 + p) % 3] : 0.0;
+    }
+    if (p0 > 0) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < XQ; u++) {
+      const int p = tid + 256 * u;
+      if (p < np) xb[p] = xr[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      const int p = g + G * u;
+      if (p < np) { acc0 = fma(l[u].x, xb[p], acc0); acc1 = fma(l[u].y, xb[p], acc1); }
+    }
+    for (int base = G * NL; base < np; base += G * NL) {         // fronts with more than 240 (120) border rows
+#pragma unroll
+      for (int u = 0; u < NL; u++) {
+        const int p = base + g + G * u;
+        l[u] = (active && p < np) ? *reinterpret_cast<const double2*>(L21 + (size_t)(p0 + p) * W + 2 * cp) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < NL; u++) {
+        const int p = base + g + G * u;
+        if (p < np) { acc0 = fma(l[u].x, xb[p], acc0); acc1 = fma(l[u].y, xb[p], acc1); }
       }
     }
   }
-  if (tid < G5 * W) part[g * W + j] = acc;
+  if constexpr (LDS_L11) {
+#pragma unroll
+    for (int u = 0; u < LT_Q; u++) Lt[tid + 256 * u] = lt[u];
+  }
+  if (tid < W) dinv[tid] = dvl;
+  if (active) { part[g * W + 2 * cp] = acc0; part[g * W + 2 * cp + 1] = acc1; }
   __syncthreads();
   if (tid < 64) {
     const int lane = tid;
-    const int lj = min(lane, W - 1);
-    double v = (lane < w) ? yvec[3 * F.c0 + lane] : 0.0;
+    double v[CPL], xv[CPL];
 #pragma unroll
-    for (int gg = 0; gg < G5; gg++) v -= part[gg * W + lj];
-    double xv = 0.0;
+    for (int c = 0; c < CPL; c++) {
+      const int col = lane + 64 * c, cj = min(col, W - 1);
+      v[c] = (col < w) ? yvec[3 * F.c0 + col] : 0.0;
+#pragma unroll
+      for (int gg = 0; gg < G; gg++) v[c] -= part[gg * W + cj];
+      xv[c] = 0.0;
+    }
+    const double dv = dinv[min(lane, W - 1)];
 #pragma unroll
     for (int i = W - 1; i >= 0; i--) {
       if (i < w) {
-        double xi = readlane_f64(v, i) * readlane_f64(dv, i);
-        if (lane == i) xv = xi;
-        v -= Lcol[i] * xi;
+        if constexpr (LDS_L11) {
+          const double xi = readlane_f64(v[i / 64], i % 64) * dinv[i];
+#pragma unroll
+          for (int c = 0; c < CPL; c++) {
+            const int col = lane + 64 * c;
+            if (col == i) xv[c] = xi;
+            if (64 * c <= i) v[c] -= Lt[i * W + min(col, W - 1)] * xi;   // row i of L11 (zeros right of the diagonal)
+          }
+        } else {
+          const double xi = readlane_f64(v[0], i) * readlane_f64(dv, i);
+          if (lane == i) xv[0] = xi;
+          v[0] -= Lcol[i] * xi;
+        }
       }
     }
-    if (lane < w) xvec[3 * F.c0 + lane] = xv;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int col = lane + 64 * c;
+      if (col < w) xvec[3 * F.c0 + col] = xv[c];
+    }
   }
 }
 
@@ -983,31 +1065,42 @@ void launch_assemble(hipStream_t st, const GnDevice& D, double* chi_out) {
 void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag, bool write_l11c) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kSmemBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              factor_smem_bytes(kFrontW, kChunkRows + 1));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              factor_smem_bytes(kWideFrontW, kWideChunkRows + 1));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor_leaf),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, factor_smem_bytes(kFrontW, kChunkRows + 1));
     attr_set = true;
   }
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
-  const int ch_rows = std::min(CH, D.h_level_chrows[l]);
-  auto kern = D.h_level_leaf[l] ? k_front_factor_leaf : k_front_factor;
-  static const bool full_lds = getenv("CGMR_LEAF_FULL_LDS") != nullptr;
-  hipLaunchKernelGGL(kern, dim3(nw), dim3(256), (full_lds && D.h_level_leaf[l]) ? kSmemBytes : kOffR + ch_rows * LDW * 8, st, D.work, D.h_work_ptr[l], D.fronts, D.children,
-                     D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, iter_tag, l,
+  const int lw = D.h_level_w[l];
+  const int ch_rows = D.h_level_chrows[l];
+  auto kern = lw == kWideFrontW ? k_front_factor<kWideFrontW> : (D.h_level_leaf[l] ? k_front_factor_leaf : k_front_factor<kFrontW>);
+  hipLaunchKernelGGL(kern, dim3(nw), dim3(256), factor_smem_bytes(lw, ch_rows), st, D.work, D.h_work_ptr[l], D.fronts,
+                     D.children, D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, iter_tag, l,
                      write_l11c ? 1 : 0, ch_rows, D.h_level_chunk[l]);
 }
 
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
   int nt = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
-  if (nt > 0)
-    hipLaunchKernelGGL(k_front_update, dim3(nt), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children,
-                       D.inv, D.Lbuf, D.Ubuf);
+  if (nt <= 0) return;
+  auto kern = D.h_level_w[l] == kWideFrontW ? k_front_update<kWideFrontW> : k_front_update<kFrontW>;
+  hipLaunchKernelGGL(kern, dim3(nt), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children, D.inv, D.Lbuf,
+                     D.Ubuf);
 }
 
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_bwd<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              bwd_smem_bytes(kWideFrontW));
+    attr_set = true;
+  }
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
-  hipLaunchKernelGGL(k_solve_bwd, dim3(nfr), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l], D.rows,
+  const int lw = D.h_level_w[l];
+  auto kern = lw == kWideFrontW ? k_solve_bwd<kWideFrontW> : k_solve_bwd<kFrontW>;
+  hipLaunchKernelGGL(kern, dim3(nfr), dim3(256), bwd_smem_bytes(lw), st, D.fronts, D.level_fronts, D.h_level_ptr[l], D.rows,
                      D.Lbuf, D.yvec, D.xvec);
 }
 

@@ -18,6 +18,8 @@ double now_s() {
   return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
 }
 
+constexpr int kWideMinHeight = 0;     // default of CGMR_WIDE_MIN_HEIGHT (0 = no wide fronts: measured slower)
+
 // ------------------------------------------------------------------ nested dissection
 // Recursive bisection by breadth-first level structures: pick the level that splits the
 // subset most evenly among the thin ones, keep only its vertices that touch the next level
@@ -29,6 +31,8 @@ struct NDCtx {
   const std::vector<int32_t>& ai;
   std::vector<int32_t>& order;        // in/out working permutation
   std::vector<uint8_t>& pstart;       // pstart[pos] = 1 if a front begins at position pos
+  std::vector<uint8_t> wide;          // wide[pos] = 1: the position belongs to a separator cut into wide panels
+  int wide_min_height = 1 << 30;      // subtrees at least this tall get wide separators
   std::vector<int32_t> label;         // region id a vertex currently belongs to (indexed by vertex)
   std::vector<int32_t> dist;          // BFS depth (indexed by vertex)
   std::vector<int32_t> queue;         // BFS order, indexed by *position*: a call only touches [begin, end)
@@ -45,11 +49,12 @@ struct NDRange {
   int height = 0;
 };
 
-// cut [begin, end) into runs of kPanelW columns, the remainder last
-NDRange emit_panels(NDCtx& C, int begin, int end) {
+// cut [begin, end) into runs of `run` columns, the remainder last
+NDRange emit_panels(NDCtx& C, int begin, int end, int run = kPanelW) {
   NDRange r;
-  for (int p = begin; p < end; p += kPanelW) { C.pstart[p] = 1; r.height++; }
-  r.last = end > begin ? (end - begin - 1) % kPanelW + 1 : 0;
+  for (int p = begin; p < end; p += run) { C.pstart[p] = 1; r.height++; }
+  if (run > kPanelW) for (int p = begin; p < end; p++) C.wide[p] = 1;
+  r.last = end > begin ? (end - begin - 1) % run + 1 : 0;
   return r;
 }
 
@@ -156,19 +161,22 @@ NDRange nd(NDCtx& C, int begin, int end, int depth) {
   if (r1.height > r2.height) {
     std::rotate(C.order.begin() + begin, C.order.begin() + begin + na, C.order.begin() + s0);
     std::rotate(C.pstart.begin() + begin, C.pstart.begin() + begin + na, C.pstart.begin() + s0);
+    std::rotate(C.wide.begin() + begin, C.wide.begin() + begin + na, C.wide.begin() + s0);
     std::swap(r1, r2);
   }
   // the separator in runs of kPanelW; when its remainder fits into the last panel of the half in front of it, the
   // remainder goes first so that the amalgamation can merge the two (one level less on that path)
-  const int ssz = end - s0, rem = ssz % kPanelW;
+  const int run = std::max(r1.height, r2.height) >= C.wide_min_height ? kWidePanelW : kPanelW;
+  const int ssz = end - s0, rem = ssz % run;
   NDRange out;
-  if (rem != 0 && r2.last + rem <= kPanelW) {
+  if (rem != 0 && r2.last + rem <= run) {
     C.pstart[s0] = 1;
-    NDRange rest = emit_panels(C, s0 + rem, end);
+    if (run > kPanelW) for (int p = s0; p < s0 + rem; p++) C.wide[p] = 1;
+    NDRange rest = emit_panels(C, s0 + rem, end, run);
     out.last = ssz == rem ? r2.last + rem : rest.last;
     out.height = std::max(r1.height + 1, r2.height) + rest.height;
   } else {
-    NDRange all = emit_panels(C, s0, end);
+    NDRange all = emit_panels(C, s0, end, run);
     out.last = all.last;
     out.height = std::max(r1.height, r2.height) + all.height;
   }
@@ -252,6 +260,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   // nested dissection
   const int NT = host_threads();
   std::vector<int32_t> order(nf), panel_start;
+  std::vector<uint8_t> wide_pos;
   for (int v = 0; v < nf; v++) order[v] = v;
   {
     std::vector<uint8_t> pstart(nf, 0);
@@ -260,9 +269,15 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     C.dist.assign(nf, 0);
     C.queue.assign(nf, 0);
     C.tmp.assign(nf, 0);
+    C.wide.assign(nf, 0);
+    {
+      static const int wmh = getenv("CGMR_WIDE_MIN_HEIGHT") ? atoi(getenv("CGMR_WIDE_MIN_HEIGHT")) : kWideMinHeight;
+      C.wide_min_height = wmh > 0 ? wmh : (1 << 30);
+    }
     C.max_par_depth = NT >= 8 ? 3 : (NT >= 4 ? 2 : (NT >= 2 ? 1 : 0));
     nd(C, 0, nf, 0);
     for (int p = 0; p < nf; p++) if (pstart[p]) panel_start.push_back(p);
+    wide_pos.swap(C.wide);
   }
   std::vector<int32_t> iperm(nf);
   for (int p = 0; p < nf; p++) iperm[order[p]] = p;
@@ -385,7 +400,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       while (g >= 0 && dead[g]) g--;
       if (g < 0) break;
       FrontDesc& G = S.fronts[g];
-      if (G.parent != f || G.c0 + G.nc != F.c0 || G.nc + F.nc > kPanelW) break;
+      if (G.parent != f || G.c0 + G.nc != F.c0 || G.nc + F.nc > (wide_pos[F.c0 + F.nc - 1] ? kWidePanelW : kPanelW)) break;
       std::vector<int32_t>& kf = kids[f];
       auto it = std::find(kf.begin(), kf.end(), g);
       const size_t at = it - kf.begin();
@@ -418,11 +433,15 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     kids.resize(nfr);
     for (int c = 0; c < nf; c++) S.col_front[c] = newid[S.col_front[c]];
   }
+  int nlev = 0;
   for (int f = 0; f < nfr; f++) {     // levels: 0 = no children
     int lv = 0;
     for (int ch : kids[f]) lv = std::max(lv, S.fronts[ch].level + 1);
     S.fronts[f].level = lv;
+    nlev = std::max(nlev, lv + 1);
   }
+  S.level_w.assign(nlev, kFrontW);
+  for (const FrontDesc& F : S.fronts) if (F.nc > kPanelW) S.level_w[F.level] = kWideFrontW;
   CK("borders + amalgamation");
   // children lists, rel / inv maps, A lists, offsets
   std::vector<int32_t> posmap(nf, -1);
@@ -474,7 +493,8 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     }
     F.a_cnt = (int)S.alist.size() / 3 - F.a_off;
     int64_t w = 3 * (int64_t)F.nc, r = 3 * (int64_t)F.ns;
-    F.L_off = Loff; Loff += kFactorHeader + r * kFrontW;
+    const int64_t lw = S.level_w[F.level];
+    F.L_off = Loff; Loff += factor_header((int)lw) + r * lw;
     F.U_off = Uoff; Uoff += (r * r + r + 3) & ~int64_t(1);      // even offsets: the update matrices are read with 16-byte loads
     flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
   }
@@ -483,8 +503,6 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   S.U_doubles = Uoff;
   S.flops = flops;
   // levels
-  int nlev = 0;
-  for (const FrontDesc& F : S.fronts) nlev = std::max(nlev, F.level + 1);
   S.level_ptr.assign(nlev + 1, 0);
   for (const FrontDesc& F : S.fronts) S.level_ptr[F.level + 1]++;
   for (int l = 0; l < nlev; l++) S.level_ptr[l + 1] += S.level_ptr[l];

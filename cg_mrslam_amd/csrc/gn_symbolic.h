@@ -17,7 +17,13 @@ namespace cgmr {
 
 constexpr int kPanelW = 16;          // max poses (block columns) per front -> 48 scalar columns
 constexpr int kFrontW = 3 * kPanelW; // scalar columns per front (all panel strides are padded to this)
-constexpr int kFactorHeader = 2 * kFrontW * kFrontW + kFrontW;  // L11 row-major, L11 column-major, 1/diag
+// Near the top of the elimination tree, where a level holds a handful of fronts and costs the same ~45 us of dependent
+// memory round trips whatever its fronts hold, separators are cut into panels of up to 32 poses instead: a level that
+// holds such a front is run by the 96-column instances of the kernels (every front of that level is padded to 96).
+constexpr int kWidePanelW = 32;
+constexpr int kWideFrontW = 3 * kWidePanelW;
+constexpr int64_t factor_header(int w) { return 2 * (int64_t)w * w + w; }   // L11 row-major, L11 column-major, 1/diag
+constexpr int kWideChunkRows = 100;  // border rows per work item in a level of 96-column fronts (LDS: 96 x 97 F11 + the chunk)
 constexpr int kChunkRows = 191;      // border rows per k_front_factor workgroup: 3 wavefronts minus the lane that
                                      // carries the right-hand side through the factorisation
 
@@ -49,7 +55,7 @@ struct FrontDesc {                   // one per front, uploaded verbatim (all in
   int32_t a_off;      // offset into alist[] (triples) of the A blocks assembled by this front
   int32_t a_cnt;
   int32_t pad;
-  int64_t L_off;      // offset (doubles) of this front's factor panel: header (kFactorHeader) then L21 (r x kFrontW)
+  int64_t L_off;      // offset (doubles) of this front's factor panel: header (factor_header(W)) then L21 (r x W), W = its level's width
   int64_t U_off;      // offset (doubles) of this front's update matrix (r*r, row-major, lower part valid)
 };
 
@@ -86,6 +92,7 @@ struct Symbolic {
   std::vector<int32_t> alist;          // triples (block id [0..nf) diag / nf+k offdiag, local row block, local col block)
   std::vector<int32_t> level_ptr;      // nlevels+1, fronts sorted by level in level_fronts
   std::vector<int32_t> level_fronts;
+  std::vector<int32_t> level_w;        // per level: scalar columns of its fronts' panels (kFrontW, or kWideFrontW if any front is wide)
   std::vector<int32_t> col_front;      // permuted block column -> owning front
   int64_t L_doubles = 0, U_doubles = 0;
   int max_ns = 0;

@@ -20,10 +20,6 @@
 namespace cgmr {
 
 namespace {
-constexpr int W = kFrontW;
-constexpr int kL11c = W * W;
-constexpr int kDinv = 2 * W * W;
-constexpr int kL21 = 2 * W * W + W;
 constexpr int MB = 16;            // right-hand sides per workgroup in the multi-RHS forward solve
 
 __device__ __forceinline__ double d_norm_theta(double t) {
@@ -44,13 +40,15 @@ __global__ void k_marg_init_rhs(int nK, const int32_t* __restrict__ qcol, int m,
 }
 
 // Forward solve L Y = E for MB right-hand sides at a time: grid (fronts of the level, m / MB).
-// thread = (column c = tid % 16, row lane g = tid / 16)
+// thread = (column c = tid % 16, row lane g = tid / 16).  W = panel width of the level (gn_kernels.hip).
+template <int W>
 __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __restrict__ fronts,
                                                          const int32_t* __restrict__ level_fronts, int level_begin,
                                                          const int32_t* __restrict__ children,
                                                          const int32_t* __restrict__ rel, const int32_t* __restrict__ inv,
                                                          const double* __restrict__ Lbuf, int m,
                                                          double* __restrict__ Y, double* __restrict__ Uv) {
+  constexpr int kL11c = W * W, kDinv = 2 * W * W, kL21 = 2 * W * W + W;
   __shared__ double t1[W][MB + 1];
   const int tid = threadIdx.x;
   const int c = tid & 15, g = tid >> 4;
@@ -225,8 +223,9 @@ void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* 
   hipLaunchKernelGGL(k_marg_init_rhs, dim3((nK + 127) / 128), dim3(128), 0, st, nK, d_qcol, m, Y);
   for (int l = 0; l < D.nlevels; l++) {
     int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
-    hipLaunchKernelGGL(k_solve_fwd_multi, dim3(nfr, m / MB), dim3(256), 0, st, D.fronts, D.level_fronts,
-                       D.h_level_ptr[l], D.children, D.rel, D.inv, D.Lbuf, m, Y, Uv);
+    auto kern = D.h_level_w[l] == kWideFrontW ? k_solve_fwd_multi<kWideFrontW> : k_solve_fwd_multi<kFrontW>;
+    hipLaunchKernelGGL(kern, dim3(nfr, m / MB), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l], D.children,
+                       D.rel, D.inv, D.Lbuf, m, Y, Uv);
   }
   int T = m / 16;
   hipLaunchKernelGGL(k_gram_partial, dim3(T * T, nchunk), dim3(256), 0, st, 3 * D.nf, m, chunk, Y, part);
