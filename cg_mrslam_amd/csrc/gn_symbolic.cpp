@@ -80,16 +80,20 @@ int bfs(NDCtx& C, int32_t* q, int root, int id, int visited_id) {
 }
 
 // Orders [begin, end) and marks its panels.
-NDRange nd(NDCtx& C, int begin, int end, int depth) {
+// `start`: a vertex of the range known to lie at one end of it (the parent's sweep began or ended there), or -1.
+NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
   int n = end - begin;
   if (n <= 0) return NDRange();
   if (n <= kPanelW) return emit_panels(C, begin, end);
   int32_t* Q = C.queue.data() + begin;                  // this call's slice of the BFS queue
   int id = C.next_label.fetch_add(3);
   for (int p = begin; p < end; p++) C.label[C.order[p]] = id;
-  // first sweep: connectivity + a far vertex
-  int vis1 = id + 1;
-  int reached = bfs(C, Q, C.order[begin], id, vis1);
+  // first sweep: connectivity + a far vertex; skipped when the parent's sweep already left one (then the second
+  // sweep doubles as the connectivity check)
+  int vis1 = id + 1, vis2 = id + 2;
+  static const bool reuse_start = !(getenv("CGMR_ND_REUSE_START") && atoi(getenv("CGMR_ND_REUSE_START")) == 0);
+  const bool have_start = reuse_start && start >= 0;
+  int reached = have_start ? bfs(C, Q, start, id, vis2) : bfs(C, Q, C.order[begin], id, vis1);
   if (reached < n) {
     // disconnected: component first, then the rest (independent subtrees, no separator)
     int k = begin;
@@ -101,10 +105,12 @@ NDRange nd(NDCtx& C, int begin, int end, int depth) {
     r2.height = std::max(r1.height, r2.height);
     return r2;
   }
-  int far = Q[reached - 1];
-  // second sweep from the far vertex gives the level structure
-  int vis2 = id + 2;
-  bfs(C, Q, far, vis1, vis2);
+  if (!have_start) {
+    int far = Q[reached - 1];
+    // second sweep from the far vertex gives the level structure
+    bfs(C, Q, far, vis1, vis2);
+  }
+  const int start_a = Q[0], start_b = Q[n - 1];          // the two ends of this range: where the halves' sweeps start
   int nlev = C.dist[Q[n - 1]] + 1;
   if (nlev <= 2) return emit_panels(C, begin, end);  // clique-like: nothing to dissect
   std::vector<int32_t> lvl_cnt(nlev + 1, 0);
@@ -148,12 +154,12 @@ NDRange nd(NDCtx& C, int begin, int end, int depth) {
   // the two halves touch disjoint vertices and disjoint position ranges: fork one of them near the top
   NDRange r1, r2;
   if (depth < C.max_par_depth && na > 512 && nb > 512) {
-    std::thread t([&C, &r1, begin, na, depth] { r1 = nd(C, begin, begin + na, depth + 1); });
-    r2 = nd(C, begin + na, begin + na + nb, depth + 1);
+    std::thread t([&C, &r1, begin, na, depth, start_a] { r1 = nd(C, begin, begin + na, depth + 1, start_a); });
+    r2 = nd(C, begin + na, begin + na + nb, depth + 1, start_b);
     t.join();
   } else {
-    r1 = nd(C, begin, begin + na, depth + 1);
-    r2 = nd(C, begin + na, begin + na + nb, depth + 1);
+    r1 = nd(C, begin, begin + na, depth + 1, start_a);
+    r2 = nd(C, begin + na, begin + na + nb, depth + 1, start_b);
   }
   // Only the half right in front of the separator can share a panel with it (see the amalgamation in analyze()):
   // that should be the taller one, so the two blocks trade places when the first turned out taller.
