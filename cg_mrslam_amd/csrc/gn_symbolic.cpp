@@ -8,7 +8,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 
 namespace cgmr {
 namespace {
@@ -19,6 +23,82 @@ double now_s() {
 }
 
 constexpr int kWideMinHeight = 0;     // default of CGMR_WIDE_MIN_HEIGHT (0 = no wide fronts: measured slower)
+
+// A few persistent helper threads: the analysis forks a dozen short parallel sections per call, and creating a
+// thread for each costs more than most of them run.  Idle helpers spin briefly (the next section usually follows
+// within microseconds), then sleep.
+class HelperPool {
+ public:
+  struct Job {
+    std::function<void()> fn;
+    std::atomic<int> done{0};
+  };
+  explicit HelperPool(int nhelpers) : owner_(getpid()) {
+    for (int i = 0; i < nhelpers; i++) threads_.emplace_back([this] { loop(); });
+  }
+  ~HelperPool() {
+    if (getpid() != owner_) {                      // a forked child inherits the object but not the threads
+      for (auto& t : threads_) t.detach();
+      return;
+    }
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  int helpers() const { return (int)threads_.size(); }
+  // run `job` on a helper if one is idle, else right here; wait() returns when it is done
+  void run(Job& job) {
+    job.done.store(0, std::memory_order_relaxed);
+    bool queued = false;
+    if (getpid() == owner_) {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (busy_ + (int)queue_.size() < (int)threads_.size()) { queue_.push_back(&job); queued = true; }
+    }
+    if (!queued) { job.fn(); job.done.store(1, std::memory_order_release); return; }
+    pending_.fetch_add(1, std::memory_order_release);
+    cv_.notify_one();
+  }
+  static void wait(Job& job) {
+    while (!job.done.load(std::memory_order_acquire)) std::this_thread::yield();
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      Job* job = nullptr;
+      // spin for a while on the pending counter before sleeping on the condition variable
+      for (int spin = 0; spin < 100000 && !job; spin++) {
+        if (pending_.load(std::memory_order_acquire) > 0) {
+          std::lock_guard<std::mutex> lk(mu_);
+          if (!queue_.empty()) { job = queue_.front(); queue_.erase(queue_.begin()); busy_++; pending_.fetch_sub(1); }
+        }
+      }
+      if (!job) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
+        if (stop_) return;
+        job = queue_.front(); queue_.erase(queue_.begin()); busy_++; pending_.fetch_sub(1);
+      }
+      job->fn();
+      { std::lock_guard<std::mutex> lk(mu_); busy_--; }
+      job->done.store(1, std::memory_order_release);
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::vector<Job*> queue_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<int> pending_{0};
+  int busy_ = 0;
+  bool stop_ = false;
+  pid_t owner_;
+};
+
+int host_threads();
+HelperPool& pool() {
+  static HelperPool p(host_threads() - 1);
+  return p;
+}
 
 // ------------------------------------------------------------------ nested dissection
 // Recursive bisection by breadth-first level structures: pick the level that splits the
@@ -154,9 +234,11 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
   // the two halves touch disjoint vertices and disjoint position ranges: fork one of them near the top
   NDRange r1, r2;
   if (depth < C.max_par_depth && na > 512 && nb > 512) {
-    std::thread t([&C, &r1, begin, na, depth, start_a] { r1 = nd(C, begin, begin + na, depth + 1, start_a); });
+    HelperPool::Job job;
+    job.fn = [&C, &r1, begin, na, depth, start_a] { r1 = nd(C, begin, begin + na, depth + 1, start_a); };
+    pool().run(job);
     r2 = nd(C, begin + na, begin + na + nb, depth + 1, start_b);
-    t.join();
+    HelperPool::wait(job);
   } else {
     r1 = nd(C, begin, begin + na, depth + 1, start_a);
     r2 = nd(C, begin + na, begin + na + nb, depth + 1, start_b);
@@ -189,25 +271,37 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
   return out;
 }
 
+// adjacency rows are short (a pose has ~8 neighbours): insertion sort beats std::sort's dispatch there
+inline void sort_row(int32_t* b, int32_t* e) {
+  if (e - b > 24) { std::sort(b, e); return; }
+  for (int32_t* i = b + 1; i < e; i++) {
+    int32_t v = *i;
+    int32_t* j = i;
+    while (j > b && j[-1] > v) { *j = j[-1]; j--; }
+    *j = v;
+  }
+}
+
 // run fn(lo, hi) over [0, n) on up to nthreads threads (static split)
 template <typename Fn>
 void parallel_for(int n, int nthreads, Fn&& fn) {
   if (nthreads <= 1 || n < 4096) { fn(0, n); return; }
-  std::vector<std::thread> th;
+  std::vector<HelperPool::Job> jobs(nthreads - 1);
   int per = (n + nthreads - 1) / nthreads;
   for (int t = 1; t < nthreads; t++) {
     int lo = t * per, hi = std::min(n, lo + per);
-    if (lo < hi) th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+    jobs[t - 1].fn = [&fn, lo, hi] { if (lo < hi) fn(lo, hi); };
+    pool().run(jobs[t - 1]);
   }
   fn(0, std::min(n, per));
-  for (auto& x : th) x.join();
+  for (auto& j : jobs) HelperPool::wait(j);
 }
 
 int host_threads() {
   static int n = [] {
     const char* e = getenv("CGMR_HOST_THREADS");
     int v = e ? atoi(e) : 0;
-    if (v <= 0) { unsigned hc = std::thread::hardware_concurrency(); v = hc >= 8 ? 4 : (hc >= 4 ? 2 : 1); }
+    if (v <= 0) { unsigned hc = std::thread::hardware_concurrency(); v = hc >= 32 ? 8 : (hc >= 8 ? 4 : (hc >= 4 ? 2 : 1)); }
     return std::max(1, std::min(v, 16));
   }();
   return n;
@@ -250,14 +344,23 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       if (a < 0 || b < 0 || a == b) continue;
       ai[pos[a]++] = b; ai[pos[b]++] = a;
     }
-    // sort + dedupe each row, compact in place
+    // sort + dedupe each row (in parallel), then compact in place
+    std::vector<int32_t> len(nf);
+    parallel_for(nf, host_threads(), [&](int lo, int hi) {
+      for (int v = lo; v < hi; v++) {
+        int b = ap[v], e = ap[v + 1];
+        sort_row(ai.data() + b, ai.data() + e);
+        int w = b;
+        for (int p = b; p < e; p++) if (p == b || ai[p] != ai[p - 1]) ai[w++] = ai[p];
+        len[v] = w - b;
+      }
+    });
     int w = 0;
     for (int v = 0; v < nf; v++) {
-      int b = ap[v], e = ap[v + 1];
-      std::sort(ai.begin() + b, ai.begin() + e);
-      int start = w;
-      for (int p = b; p < e; p++) if (p == b || ai[p] != ai[p - 1]) ai[w++] = ai[p];
-      ap[v] = start;
+      int b = ap[v];
+      if (w != b) std::memmove(ai.data() + w, ai.data() + b, sizeof(int32_t) * len[v]);
+      ap[v] = w;
+      w += len[v];
     }
     ap[nf] = w;
     ai.resize(w);
@@ -300,57 +403,84 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     for (int c = lo; c < hi; c++) {
       int o = order[c], w = cp[c];
       for (int p = ap[o]; p < ap[o + 1]; p++) ci[w++] = iperm[ai[p]];
-      std::sort(ci.begin() + cp[c], ci.begin() + cp[c + 1]);
+      sort_row(ci.data() + cp[c], ci.data() + cp[c + 1]);
     }
   });
   CK("permuted adjacency");
   // unique lower off-diagonal blocks: enumerate (c, r>c) column-major
   std::vector<int32_t> offbase(nf + 1, 0);
-  for (int c = 0; c < nf; c++) {
-    int cnt = 0;
-    for (int p = cp[c]; p < cp[c + 1]; p++) if (ci[p] > c) cnt++;
-    offbase[c + 1] = offbase[c] + cnt;
-  }
+  parallel_for(nf, NT, [&](int lo, int hi) {
+    for (int c = lo; c < hi; c++) {
+      int cnt = 0;
+      for (int p = cp[c]; p < cp[c + 1]; p++) if (ci[p] > c) cnt++;
+      offbase[c + 1] = cnt;
+    }
+  });
+  for (int c = 0; c < nf; c++) offbase[c + 1] += offbase[c];
   S.nb = offbase[nf];
   S.off_row.resize(S.nb);
   S.off_col.resize(S.nb);
-  for (int c = 0; c < nf; c++) {
+  parallel_for(nf, NT, [&](int lo, int hi) {
+    for (int c = lo; c < hi; c++) {
+      int k = offbase[c];
+      for (int p = cp[c]; p < cp[c + 1]; p++) if (ci[p] > c) { S.off_row[k] = ci[p]; S.off_col[k] = c; k++; }
+    }
+  });
+  auto off_id = [&](int r, int c) {   // r > c: the blocks of column c are listed by ascending row, a handful of them
     int k = offbase[c];
-    for (int p = cp[c]; p < cp[c + 1]; p++) if (ci[p] > c) { S.off_row[k] = ci[p]; S.off_col[k] = c; k++; }
-  }
-  auto off_id = [&](int r, int c) {   // r > c
-    int lo = cp[c], hi = cp[c + 1];
-    int first_gt = std::upper_bound(ci.begin() + lo, ci.begin() + hi, c) - ci.begin();
-    int pos = std::lower_bound(ci.begin() + first_gt, ci.begin() + hi, r) - ci.begin();
-    return offbase[c] + (pos - first_gt);
+    while (S.off_row[k] != r) k++;
+    return k;
   };
   CK("off-diagonal blocks");
   // assembly CSR: block -> contributing edge terms
-  S.asm_ptr.assign(nf + S.nb + 1, 0);
-  std::vector<int32_t> e_off(nE, -1);
+  // (every thread walks all edges in order and keeps the blocks of its own key range: lists stay in edge order)
+  const int nkeys = nf + S.nb;
+  S.asm_ptr.assign(nkeys + 1, 0);
+  std::vector<int32_t> e_a(nE), e_b(nE), e_off(nE, -1);
   parallel_for(nE, NT, [&](int lo, int hi) {
     for (int k = lo; k < hi; k++) {
       int a = S.vperm[ef[k]], b = S.vperm[et[k]];
-      if (a >= 0 && b >= 0 && a != b) e_off[k] = a > b ? off_id(a, b) : off_id(b, a);
+      e_a[k] = a;
+      e_b[k] = (b >= 0 && a == b) ? -1 : b;              // self edge: one diagonal contribution only
+      if (a >= 0 && b >= 0 && a != b) e_off[k] = nf + (a > b ? off_id(a, b) : off_id(b, a));
     }
   });
-  for (int k = 0; k < nE; k++) {
-    int a = S.vperm[ef[k]], b = S.vperm[et[k]];
-    if (a >= 0) S.asm_ptr[a + 1]++;
-    if (b >= 0 && !(a == b && a >= 0)) S.asm_ptr[b + 1]++;
-    if (e_off[k] >= 0) S.asm_ptr[nf + e_off[k] + 1]++;
-  }
-  for (int q = 0; q < nf + S.nb; q++) S.asm_ptr[q + 1] += S.asm_ptr[q];
-  S.asm_src.resize(S.asm_ptr[nf + S.nb]);
+  CK("  asm: edge keys");
+  const int nkt = (nE >= 4096) ? NT : 1;
+  auto key_range = [&](int t, int& klo, int& khi) { klo = (int)((int64_t)nkeys * t / nkt); khi = (int)((int64_t)nkeys * (t + 1) / nkt); };
+  auto run_keyed = [&](auto&& body) {
+    std::vector<HelperPool::Job> jobs(nkt > 1 ? nkt - 1 : 0);
+    for (int t = 1; t < nkt; t++) { jobs[t - 1].fn = [&body, t] { body(t); }; pool().run(jobs[t - 1]); }
+    body(0);
+    for (auto& j : jobs) HelperPool::wait(j);
+  };
+  run_keyed([&](int t) {
+    int klo, khi;
+    key_range(t, klo, khi);
+    for (int k = 0; k < nE; k++) {
+      const int a = e_a[k], b = e_b[k], e = e_off[k];
+      if (a >= klo && a < khi) S.asm_ptr[a + 1]++;
+      if (b >= klo && b < khi) S.asm_ptr[b + 1]++;
+      if (e >= klo && e < khi) S.asm_ptr[e + 1]++;
+    }
+  });
+  CK("  asm: count");
+  for (int q = 0; q < nkeys; q++) S.asm_ptr[q + 1] += S.asm_ptr[q];
+  S.asm_src.resize(S.asm_ptr[nkeys]);
+  CK("  asm: prefix + resize");
   {
     std::vector<int32_t> pos(S.asm_ptr.begin(), S.asm_ptr.end() - 1);
-    for (int k = 0; k < nE; k++) {
-      int a = S.vperm[ef[k]], b = S.vperm[et[k]];
-      if (a >= 0) S.asm_src[pos[a]++] = 4 * k + 0;
-      if (b >= 0 && !(a == b && a >= 0)) S.asm_src[pos[b]++] = 4 * k + 1;
-      if (e_off[k] >= 0) S.asm_src[pos[nf + e_off[k]]++] = 4 * k + (a > b ? 2 : 3);
-      // a > b: lower block (row a = i, col b = j) is Hij as is; else (row b = j, col a = i) = Hij^T
-    }
+    run_keyed([&](int t) {
+      int klo, khi;
+      key_range(t, klo, khi);
+      for (int k = 0; k < nE; k++) {
+        const int a = e_a[k], b = e_b[k], e = e_off[k];
+        if (a >= klo && a < khi) S.asm_src[pos[a]++] = 4 * k + 0;
+        if (b >= klo && b < khi) S.asm_src[pos[b]++] = 4 * k + 1;
+        // a > b: lower block (row a = i, col b = j) is Hij as is; else (row b = j, col a = i) = Hij^T
+        if (e >= klo && e < khi) S.asm_src[pos[e]++] = 4 * k + (a > b ? 2 : 3);
+      }
+    });
   }
   CK("assembly lists");
   // fronts
