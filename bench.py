@@ -48,6 +48,15 @@ def pmc_traffic():
     return best
 
 
+def host_threads():
+    """Threads the library's symbolic analysis uses (gn_symbolic.cpp host_threads(): CGMR_HOST_THREADS or by core count)."""
+    e = int(os.environ.get("CGMR_HOST_THREADS", "0") or 0)
+    if e > 0:
+        return max(1, min(e, 16))
+    hc = os.cpu_count() or 1
+    return 8 if hc >= 32 else 4 if hc >= 8 else 2 if hc >= 4 else 1
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,7 +269,7 @@ def main():
         "avg_launch_us": round(1e6 * avg_launch_s, 2), "launches_per_gn_iter": round(launches_per_iter, 1),
         "algorithmic_bytes_per_launch": int(bytes_per_launch),
         "share_of_kernel_time": round(ff_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
-        "note": "latency-bound: 21 dependent tree levels of FP64 chains at one wave per SIMD; memory-side traffic "
+        "note": f"latency-bound: {info['levels']} dependent tree levels of FP64 chains at one wave per SIMD; memory-side traffic "
                 "(PMC) ~ algorithmic bytes, i.e. no wasted re-reads; see DESIGN.md 2.3",
     }
 
@@ -289,6 +298,7 @@ def main():
                    "gn_iterations_per_step": GN_ITERS, "graphs": world, "parallelism": f"1 robot sub-graph per GPU x{world}"},
         "chi2_final": float(chi[-1]), "chi2_initial": float(chi[0]),
         "host_symbolic_ms_per_step": round(1e3 * host_sym / args.steps, 3),
+        "host_threads": host_threads(),
         "device_ms_per_step": round(1e3 * dev_time / args.steps, 3),
         "symbolic": {k: info[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")},
         "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},

@@ -163,6 +163,8 @@ int bfs(NDCtx& C, int32_t* q, int root, int id, int visited_id) {
 // `start`: a vertex of the range known to lie at one end of it (the parent's sweep began or ended there), or -1.
 NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
   int n = end - begin;
+  static const bool nd_trace = getenv("CGMR_SYM_TRACE") != nullptr;
+  const double t_in = nd_trace ? now_s() : 0;
   if (n <= 0) return NDRange();
   if (n <= kPanelW) return emit_panels(C, begin, end);
   int32_t* Q = C.queue.data() + begin;                  // this call's slice of the BFS queue
@@ -231,6 +233,7 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
     else C.tmp[ps++] = v;
   }
   std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
+  if (nd_trace && depth <= 3) fprintf(stderr, "    nd depth %d n %5d own work %.1f us\n", depth, n, 1e6 * (now_s() - t_in));
   // the two halves touch disjoint vertices and disjoint position ranges: fork one of them near the top
   NDRange r1, r2;
   if (depth < C.max_par_depth && na > 512 && nb > 512) {

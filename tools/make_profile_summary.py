@@ -12,27 +12,31 @@ rows = list(csv.DictReader(open(f"{O}/bench_kernel_stats.csv")))
 with open(f"{P}/{rnd}_bench_kernel_stats.csv", "w") as f:
     f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
     for r in rows:
-        name = r["Name"].split("(")[0].replace("cgmr::", "")
+        name = r["Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
         if len(name) > 60: name = name[:57] + "..."
         f.write(f'{name},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.1f},{float(r["Percentage"]):.3f},{r["MinNs"]},{r["MaxNs"]}\n')
 # PMC summary: avg per launch per (kernel, counter)
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
 for path in glob.glob(f"{O}/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("cgmr::", "")
+        k = r["Kernel_Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
         if "rocclr" in k or "at::" in k: continue
         acc[(k, r["Counter_Name"])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 with open(f"{P}/{rnd}_pmc_summary.csv", "w") as f:
     f.write("kernel,counter,launches,avg_per_launch\n")
     for (k, c) in sorted(acc):
         f.write(f"{k},{c},{n[(k, c)]},{acc[(k, c)] / n[(k, c)]:.1f}\n")
-def avg(k, c): return acc[(k, c)] / max(n[(k, c)], 1)
+def avg(k, c):
+    # per-launch average over every instance of the kernel (k_front_factor<48>, k_front_factor_leaf, ...)
+    keys = [q for q in acc if q[1] == c and (q[0] == k or q[0].startswith(k + "<") or q[0].startswith(k + "_"))]
+    return sum(acc[q] for q in keys) / max(sum(n[q] for q in keys), 1), sum(n[q] for q in keys)
 traffic = {}
 for k in ("k_front_factor", "k_front_update", "k_solve_bwd", "k_assemble", "k_linearize", "k_match_close_batch"):
-    fe, wr = avg(k, "FETCH_SIZE") * 1024, avg(k, "WRITE_SIZE") * 1024      # rocprofv3 reports KB
+    (fe, nl), (wr, _) = avg(k, "FETCH_SIZE"), avg(k, "WRITE_SIZE")
+    fe, wr = fe * 1024, wr * 1024                                          # rocprofv3 reports KB
     traffic[k] = {"fetch_bytes_raw": round(fe), "write_bytes_raw": round(wr),
                   # MI355X_MICROARCH.md, HBM: FETCH_SIZE counts wide (16 B/lane) streaming reads at half their bytes
-                  "traffic_bytes_corrected": round(2 * fe + wr), "launches": n[(k, "FETCH_SIZE")]}
+                  "traffic_bytes_corrected": round(2 * fe + wr), "launches": nl}
 traffic["_note"] = ("per-launch averages from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh); "
                     "corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-count of wide streaming reads); matcher launch = 4096 pairs")
 json.dump(traffic, open(f"{P}/{rnd}_pmc_traffic.json", "w"), indent=1)
