@@ -695,9 +695,10 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
   // ---- stores, all from LDS: L11 (lower triangle, zeros above), 1/diag, L21 rows of this chunk, y, u
   double* P = Lbuf + L_off;
   if (chunk == 0) {
-    for (int q = tid; q < W * W; q += 256) {
-      const int i = q / W, k = q - i * W;
-      P[q] = (k <= i) ? Ls[i * LDW + k] : 0.0;                 // row-major copy (backward solve)
+    for (int q = tid; q < W * W / 2; q += 256) {               // row-major copy (backward solve), two columns per 16-byte store
+      const int i = q / (W / 2), k = 2 * (q - i * (W / 2));
+      const double a = (k <= i) ? Ls[i * LDW + k] : 0.0, b = (k + 1 <= i) ? Ls[i * LDW + k + 1] : 0.0;
+      *reinterpret_cast<double2*>(P + i * W + k) = make_double2(a, b);
     }
     if (write_l11c)                                           // column-major copy: only the multi-rhs forward solve of the marginals reads it
       for (int q = tid; q < W * W; q += 256) {
@@ -707,9 +708,9 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
     if (tid < W) P[kDinv + tid] = (tid < w) ? Dinv[tid] : 1.0;
     if (tid < w) yvec[3 * c0 + tid] = R[nr * LDW + tid];
   }
-  for (int q = tid; q < nr * W; q += 256) {
-    const int row = q / W, k = q - row * W;
-    P[kL21 + (size_t)(r0 + row) * W + k] = R[row * LDW + k];
+  for (int q = tid; q < nr * (W / 2); q += 256) {
+    const int row = q / (W / 2), k = 2 * (q - row * (W / 2));
+    *reinterpret_cast<double2*>(P + kL21 + (size_t)(r0 + row) * W + k) = make_double2(R[row * LDW + k], R[row * LDW + k + 1]);
   }
   if (tid < nr) {                                             // border vector handed to the parent: u = ext_add(children) - L21 y
     const double* xr = R + tid * LDW;
