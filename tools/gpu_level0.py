@@ -33,8 +33,7 @@ for L in (0, 1, 2):
     ts = np.arange(0, e.max(), 2.0)
     print("  running at t (2 us steps):", [int(((s <= t) & (e > t)).sum()) for t in ts])
     dp = np.diff(ph[items, :6], axis=1)
-    full = items[(fp[items, 7] > fp[items, 0])]
+    full = items[(fp[items, 4] > fp[items, 0])]
     if len(full):
-        seq = np.concatenate([fp[full, :], ph[full, 4:5]], axis=1)
-        print("  factorisation steps, fronts with 3 block columns (%d) [F0, S0, U10, F1|U20, S1, U21, F2, S2]:" % len(full), np.diff(seq, axis=1).mean(axis=0).round(0).tolist())
+        print("  first steps of the blocked factorisation, fronts with >= 2 block columns (%d) [F0, S0, U(1<-0), F1 | U(2..<-0)]:" % len(full), np.diff(fp[full, :5], axis=1).mean(axis=0).round(0).tolist())
     print("  mean phase cycles [rec+clear, round2, round3, factor, stores]:", dp.mean(axis=0).round(0).tolist(), " border rows mean", 3 * ns[front[items]].mean())
