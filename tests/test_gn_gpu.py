@@ -194,7 +194,8 @@ for (V, E, seed) in ((3000, 12000, 11), (6000, 20000, 12)):
     assert np.abs(synth.normalize_theta(p[:, 2] - p2[:, 2])).max() <= 1e-7
     q = np.arange(1, V, max(1, V // 40))[:32]
     cov = ctx.marginals(p, g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"], q)
-    cov2 = O.marginals(p, g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"], q)
+    st, cov2 = O.marginals(p, g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"], q)
+    assert st == 0
     assert np.abs(cov - cov2).max() <= 1e-6 * np.abs(cov2).max()
     print("levels", info["levels"], "fronts", info["fronts"])
 """
