@@ -287,8 +287,8 @@ inline void sort_row(int32_t* b, int32_t* e) {
 
 // run fn(lo, hi) over [0, n) on up to nthreads threads (static split)
 template <typename Fn>
-void parallel_for(int n, int nthreads, Fn&& fn) {
-  if (nthreads <= 1 || n < 4096) { fn(0, n); return; }
+void parallel_for(int n, int nthreads, Fn&& fn, int min_n = 4096) {
+  if (nthreads <= 1 || n < min_n) { fn(0, n); return; }
   std::vector<HelperPool::Job> jobs(nthreads - 1);
   int per = (n + nthreads - 1) / nthreads;
   for (int t = 1; t < nthreads; t++) {
@@ -582,61 +582,80 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   S.level_w.assign(nlev, kFrontW);
   for (const FrontDesc& F : S.fronts) if (F.nc > kPanelW) S.level_w[F.level] = kWideFrontW;
   CK("borders + amalgamation");
-  // children lists, rel / inv maps, A lists, offsets
-  std::vector<int32_t> posmap(nf, -1);
+  // children lists, rel / inv maps, A lists, offsets: the sizes first (serial, cheap), then the contents in parallel
   int64_t Loff = 0, Uoff = 0;
   double flops = 0;
-  for (int f = 0; f < nfr; f++) {
-    FrontDesc& F = S.fronts[f];
-    // children: the big ones first (see slab_is_small), each group in id order
-    if (kids[f].size() > 1) {
-      const int cend = F.c0 + F.nc;
-      std::stable_partition(kids[f].begin(), kids[f].end(), [&](int ch) {
-        const FrontDesc& G = S.fronts[ch];
-        const int32_t* gr = S.rows.data() + G.rows_off;
-        const int na = (int)(std::lower_bound(gr, gr + G.ns, cend) - gr);
-        return !slab_is_small(G.ns, na);
-      });
-    }
-    F.child_off = (int)S.children.size();
-    F.nchild = (int)kids[f].size();
-    S.children.insert(S.children.end(), kids[f].begin(), kids[f].end());
-    for (int q = 0; q < F.ns; q++) posmap[S.rows[F.rows_off + q]] = q;
-    // maps of each child into this front
-    for (int ch : kids[f]) {
-      FrontDesc& G = S.fronts[ch];
-      G.rel_off = (int)S.rel.size();
-      G.inv_off = (int)S.inv.size();
-      S.inv.resize(S.inv.size() + F.ns, -1);
-      int na = 0;
-      for (int q = 0; q < G.ns; q++) {
-        int r = S.rows[G.rows_off + q];
-        if (r < F.c0 + F.nc) { S.rel.push_back(r - F.c0); na++; }
-        else { int p = posmap[r]; S.rel.push_back(F.nc + p); S.inv[G.inv_off + p] = q; }
+  {
+    int64_t n_child = 0, n_rel = 0, n_inv = 0, n_a = 0;
+    for (int f = 0; f < nfr; f++) {
+      FrontDesc& F = S.fronts[f];
+      // children: the big ones first (see slab_is_small), each group in id order
+      if (kids[f].size() > 1) {
+        const int cend = F.c0 + F.nc;
+        std::stable_partition(kids[f].begin(), kids[f].end(), [&](int ch) {
+          const FrontDesc& G = S.fronts[ch];
+          const int32_t* gr = S.rows.data() + G.rows_off;
+          const int na = (int)(std::lower_bound(gr, gr + G.ns, cend) - gr);
+          return !slab_is_small(G.ns, na);
+        });
       }
-      G.na = na;
-    }
-    // A blocks of this front's columns
-    F.a_off = (int)S.alist.size() / 3;
-    for (int c = F.c0; c < F.c0 + F.nc; c++) {
-      int lc = c - F.c0;
-      S.alist.push_back(c); S.alist.push_back(lc); S.alist.push_back(lc);
-      int k = offbase[c];
-      for (int p = cp[c]; p < cp[c + 1]; p++) {
-        int r = ci[p];
-        if (r <= c) continue;
-        int lr = (r < F.c0 + F.nc) ? r - F.c0 : F.nc + posmap[r];
-        S.alist.push_back(nf + k); S.alist.push_back(lr); S.alist.push_back(lc);
-        k++;
+      F.child_off = (int)n_child;
+      F.nchild = (int)kids[f].size();
+      n_child += F.nchild;
+      for (int ch : kids[f]) {
+        FrontDesc& G = S.fronts[ch];
+        G.rel_off = (int)n_rel; n_rel += G.ns;
+        G.inv_off = (int)n_inv; n_inv += F.ns;
       }
+      F.a_off = (int)n_a;
+      F.a_cnt = F.nc + (offbase[F.c0 + F.nc] - offbase[F.c0]);
+      n_a += F.a_cnt;
+      int64_t w = 3 * (int64_t)F.nc, r = 3 * (int64_t)F.ns;
+      const int64_t lw = S.level_w[F.level];
+      F.L_off = Loff; Loff += factor_header((int)lw) + r * lw;
+      F.U_off = Uoff; Uoff += (r * r + r + 3) & ~int64_t(1);      // even offsets: the update matrices are read with 16-byte loads
+      flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
     }
-    F.a_cnt = (int)S.alist.size() / 3 - F.a_off;
-    int64_t w = 3 * (int64_t)F.nc, r = 3 * (int64_t)F.ns;
-    const int64_t lw = S.level_w[F.level];
-    F.L_off = Loff; Loff += factor_header((int)lw) + r * lw;
-    F.U_off = Uoff; Uoff += (r * r + r + 3) & ~int64_t(1);      // even offsets: the update matrices are read with 16-byte loads
-    flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
+    S.children.resize(n_child);
+    S.rel.resize(n_rel);
+    S.inv.assign(n_inv, -1);
+    S.alist.resize(3 * n_a);
   }
+  parallel_for(nfr, NT, [&](int flo, int fhi) {
+    std::vector<int32_t> posmap(nf, -1);                 // border row -> position in the current front's row list
+    for (int f = flo; f < fhi; f++) {
+      const FrontDesc& F = S.fronts[f];
+      std::copy(kids[f].begin(), kids[f].end(), S.children.begin() + F.child_off);
+      for (int q = 0; q < F.ns; q++) posmap[S.rows[F.rows_off + q]] = q;
+      // maps of each child into this front
+      for (int ch : kids[f]) {
+        FrontDesc& G = S.fronts[ch];
+        int32_t* rel = S.rel.data() + G.rel_off;
+        int32_t* inv = S.inv.data() + G.inv_off;
+        int na = 0;
+        for (int q = 0; q < G.ns; q++) {
+          int r = S.rows[G.rows_off + q];
+          if (r < F.c0 + F.nc) { rel[q] = r - F.c0; na++; }
+          else { int p = posmap[r]; rel[q] = F.nc + p; inv[p] = q; }
+        }
+        G.na = na;
+      }
+      // A blocks of this front's columns
+      int32_t* al = S.alist.data() + 3 * (size_t)F.a_off;
+      for (int c = F.c0; c < F.c0 + F.nc; c++) {
+        int lc = c - F.c0;
+        *al++ = c; *al++ = lc; *al++ = lc;
+        int k = offbase[c];
+        for (int p = cp[c]; p < cp[c + 1]; p++) {
+          int r = ci[p];
+          if (r <= c) continue;
+          int lr = (r < F.c0 + F.nc) ? r - F.c0 : F.nc + posmap[r];
+          *al++ = nf + k; *al++ = lr; *al++ = lc;
+          k++;
+        }
+      }
+    }
+  }, 256);
   CK("maps + A lists");
   S.L_doubles = Loff;
   S.U_doubles = Uoff;
