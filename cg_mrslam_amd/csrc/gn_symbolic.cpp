@@ -22,6 +22,7 @@ double now_s() {
   return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
 }
 
+constexpr int kRangeDepth = 2;        // ND depth whose halves become the parallel units of the border computation
 constexpr int kWideMinHeight = 0;     // default of CGMR_WIDE_MIN_HEIGHT (0 = no wide fronts: measured slower)
 
 // A few persistent helper threads: the analysis forks a dozen short parallel sections per call, and creating a
@@ -113,6 +114,9 @@ struct NDCtx {
   std::vector<uint8_t>& pstart;       // pstart[pos] = 1 if a front begins at position pos
   std::vector<uint8_t> wide;          // wide[pos] = 1: the position belongs to a separator cut into wide panels
   int wide_min_height = 1 << 30;      // subtrees at least this tall get wide separators
+  std::mutex range_mu;
+  std::vector<std::pair<int, int>> subtree_ranges;   // position ranges of the halves of the nodes at depth kRangeDepth:
+                                                     // complete subtrees, independent of each other
   std::vector<int32_t> label;         // region id a vertex currently belongs to (indexed by vertex)
   std::vector<int32_t> dist;          // BFS depth (indexed by vertex)
   std::vector<int32_t> queue;         // BFS order, indexed by *position*: a call only touches [begin, end)
@@ -249,11 +253,25 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
   // Only the half right in front of the separator can share a panel with it (see the amalgamation in analyze()):
   // that should be the taller one, so the two blocks trade places when the first turned out taller.
   const int s0 = begin + na + nb;
-  if (r1.height > r2.height) {
+  const bool swapped = r1.height > r2.height;
+  if (swapped) {
     std::rotate(C.order.begin() + begin, C.order.begin() + begin + na, C.order.begin() + s0);
     std::rotate(C.pstart.begin() + begin, C.pstart.begin() + begin + na, C.pstart.begin() + s0);
     std::rotate(C.wide.begin() + begin, C.wide.begin() + begin + na, C.wide.begin() + s0);
+    if (depth < kRangeDepth) {                           // subtree ranges recorded below move with their blocks
+      std::lock_guard<std::mutex> lk(C.range_mu);
+      for (auto& pr : C.subtree_ranges) {
+        if (pr.first >= begin && pr.second <= begin + na) { pr.first += nb; pr.second += nb; }
+        else if (pr.first >= begin + na && pr.second <= s0) { pr.first -= na; pr.second -= na; }
+      }
+    }
     std::swap(r1, r2);
+  }
+  if (depth == kRangeDepth && na > 0 && nb > 0) {
+    const int mid = begin + (swapped ? nb : na);
+    std::lock_guard<std::mutex> lk(C.range_mu);
+    C.subtree_ranges.emplace_back(begin, mid);
+    C.subtree_ranges.emplace_back(mid, s0);
   }
   // the separator in runs of kPanelW; when its remainder fits into the last panel of the half in front of it, the
   // remainder goes first so that the amalgamation can merge the two (one level less on that path)
@@ -373,6 +391,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   const int NT = host_threads();
   std::vector<int32_t> order(nf), panel_start;
   std::vector<uint8_t> wide_pos;
+  std::vector<std::pair<int, int>> pos_ranges;
   for (int v = 0; v < nf; v++) order[v] = v;
   {
     std::vector<uint8_t> pstart(nf, 0);
@@ -390,6 +409,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     nd(C, 0, nf, 0);
     for (int p = 0; p < nf; p++) if (pstart[p]) panel_start.push_back(p);
     wide_pos.swap(C.wide);
+    pos_ranges.swap(C.subtree_ranges);
   }
   std::vector<int32_t> iperm(nf);
   for (int p = 0; p < nf; p++) iperm[order[p]] = p;
@@ -498,46 +518,54 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     S.fronts[f].level = 0;
     for (int c = c0; c < c1; c++) S.col_front[c] = f;
   }
-  // border structure, bottom-up (children always have smaller ids than parents)
-  std::vector<int32_t> stamp(nf, -1);
+  // border structure, bottom-up (children always have smaller ids than parents).  The halves of the ND nodes at depth
+  // kRangeDepth are complete, mutually independent subtrees: their fronts are done in parallel (own row buffer, own
+  // stamps; a child whose parent lies outside the range is handed over afterwards), then the few fronts above them
+  // in order.  Same result as the one-pass loop.
   std::vector<std::vector<int32_t>> kids(nfr);
   S.rows.clear();
-  std::vector<int32_t> list;
   std::vector<uint8_t> dead(nfr, 0);
-  int ndead = 0;
   static const bool amalgamate = !(getenv("CGMR_AMALGAMATE") && atoi(getenv("CGMR_AMALGAMATE")) == 0);
-  for (int f = 0; f < nfr; f++) {
+  struct BorderCtx {
+    std::vector<int32_t> stamp, list;
+    std::vector<int32_t>* rows = nullptr;    // row lists of the fronts handled in this context
+    int flo = 0, fhi = 0;                   // front range of the context (parents outside are deferred)
+    int ndead = 0, max_ns = 0;
+  };
+  auto do_front = [&](int f, BorderCtx& X) {
     FrontDesc& F = S.fronts[f];
+    std::vector<int32_t>& rows = *X.rows;
     int last = F.c0 + F.nc - 1;
+    std::vector<int32_t>& list = X.list;
     list.clear();
     for (int c = F.c0; c <= last; c++)
       for (int p = cp[c + 1] - 1; p >= cp[c] && ci[p] > last; p--)
-        if (stamp[ci[p]] != f) { stamp[ci[p]] = f; list.push_back(ci[p]); }
+        if (X.stamp[ci[p]] != f) { X.stamp[ci[p]] = f; list.push_back(ci[p]); }
     for (int ch : kids[f]) {
       const FrontDesc& G = S.fronts[ch];
       for (int q = 0; q < G.ns; q++) {
-        int r = S.rows[G.rows_off + q];
-        if (r > last && stamp[r] != f) { stamp[r] = f; list.push_back(r); }
+        int r = rows[G.rows_off + q];
+        if (r > last && X.stamp[r] != f) { X.stamp[r] = f; list.push_back(r); }
       }
     }
     std::sort(list.begin(), list.end());
-    F.rows_off = (int)S.rows.size();
+    F.rows_off = (int)rows.size();
     F.ns = (int)list.size();
-    S.rows.insert(S.rows.end(), list.begin(), list.end());
+    rows.insert(rows.end(), list.begin(), list.end());
     if (F.ns > 0) {
       int p = S.col_front[list[0]];
       F.parent = p;
-      kids[p].push_back(f);
+      if (p < X.fhi) kids[p].push_back(f);          // (a parent outside the range gets its children afterwards)
     }
-    S.max_ns = std::max(S.max_ns, F.ns);
+    X.max_ns = std::max(X.max_ns, F.ns);
     // Amalgamation: the front just before this one in the elimination order is absorbed when it is a child of this
     // front and the two together still fit one panel.  Its border beyond my columns is part of my border already, so
     // the row list stands; its columns merely carry explicit zeros in the rows it did not reach.  Every merge takes a
     // level out of the paths through it -- the factorisation pays per level, not per flop.
-    while (amalgamate && f > 0) {
+    while (amalgamate && f > X.flo) {
       int g = f - 1;
-      while (g >= 0 && dead[g]) g--;
-      if (g < 0) break;
+      while (g >= X.flo && dead[g]) g--;
+      if (g < X.flo) break;
       FrontDesc& G = S.fronts[g];
       if (G.parent != f || G.c0 + G.nc != F.c0 || G.nc + F.nc > (wide_pos[F.c0 + F.nc - 1] ? kWidePanelW : kPanelW)) break;
       std::vector<int32_t>& kf = kids[f];
@@ -551,8 +579,64 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       F.nc += G.nc;
       for (int c = G.c0; c < G.c0 + G.nc; c++) S.col_front[c] = f;
       dead[g] = 1;
-      ndead++;
+      X.ndead++;
     }
+  };
+  // front ranges of the independent subtrees
+  std::sort(pos_ranges.begin(), pos_ranges.end());
+  std::vector<std::pair<int, int>> franges;
+  if (NT > 1 && nfr >= 256)
+    for (auto& pr : pos_ranges) {
+      int flo = (int)(std::lower_bound(panel_start.begin(), panel_start.end(), pr.first) - panel_start.begin());
+      int fhi = (int)(std::lower_bound(panel_start.begin(), panel_start.end(), pr.second) - panel_start.begin());
+      if (fhi > flo) franges.emplace_back(flo, fhi);
+    }
+  const int nrange = (int)franges.size();
+  std::vector<BorderCtx> rctx(nrange);
+  std::vector<std::vector<int32_t>> rrows(nrange);
+  std::vector<uint8_t> in_range(nfr, 0);
+  {
+    std::vector<HelperPool::Job> jobs(nrange);
+    for (int t = 0; t < nrange; t++) {
+      for (int f = franges[t].first; f < franges[t].second; f++) in_range[f] = 1;
+      jobs[t].fn = [&, t] {
+        BorderCtx& X = rctx[t];
+        X.stamp.assign(nf, -1);
+        X.rows = &rrows[t];
+        X.flo = franges[t].first;
+        X.fhi = franges[t].second;
+        for (int f = X.flo; f < X.fhi; f++) do_front(f, X);
+      };
+      if (t + 1 < nrange) pool().run(jobs[t]); else { jobs[t].fn(); jobs[t].done.store(1); }
+    }
+    for (int t = 0; t + 1 < nrange; t++) HelperPool::wait(jobs[t]);
+  }
+  int ndead = 0;
+  for (int t = 0; t < nrange; t++) {            // splice the row lists together, hand the subtree roots to their parents
+    const int base = (int)S.rows.size();
+    S.rows.insert(S.rows.end(), rrows[t].begin(), rrows[t].end());
+    for (int f = franges[t].first; f < franges[t].second; f++) {
+      if (dead[f]) continue;
+      FrontDesc& F = S.fronts[f];
+      F.rows_off += base;
+      if (F.ns > 0 && F.parent >= franges[t].second) kids[F.parent].push_back(f);
+    }
+    ndead += rctx[t].ndead;
+    S.max_ns = std::max(S.max_ns, rctx[t].max_ns);
+  }
+  {
+    BorderCtx X;                                 // the fronts above the subtrees, in order
+    X.stamp.assign(nf, -1);
+    X.rows = &S.rows;
+    X.flo = 0;
+    X.fhi = nfr;
+    for (int f = 0; f < nfr; f++) {
+      if (in_range[f]) continue;
+      std::sort(kids[f].begin(), kids[f].end());   // children in id order, as the one-pass loop lists them
+      do_front(f, X);
+    }
+    ndead += X.ndead;
+    S.max_ns = std::max(S.max_ns, X.max_ns);
   }
   if (ndead > 0) {                    // compact the front table (ids stay monotone: children before parents)
     std::vector<int32_t> newid(nfr, -1);

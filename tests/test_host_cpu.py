@@ -106,3 +106,42 @@ def test_g2o_robotlaser1_lines(tmp_path):
         np.testing.assert_allclose(back.lasers[k].odom_pose, pg.poses[k], atol=0)
     text = open(path).read().splitlines()
     assert text[0].startswith("VERTEX_SE2") and text[1].startswith("ROBOTLASER1") and text[2].startswith("FIX")
+
+
+_SYM_HASH = r"""
+import sys, ctypes as C, numpy as np, hashlib
+sys.path.insert(0, sys.argv[1])
+from cg_mrslam_amd import synth
+from cg_mrslam_amd._lib import load_library, gn_symbolic_info
+lib = load_library()
+h = hashlib.md5()
+for (V, E, seed) in ((10000, 40000, 12345), (3000, 9000, 7), (800, 2000, 3), (40, 60, 1)):
+    g = synth.make_pose_graph(V, E, seed=seed)
+    fx = np.ascontiguousarray(g["fixed"], dtype=np.uint8)
+    ef = np.ascontiguousarray(g["edge_from"], dtype=np.int32)
+    et = np.ascontiguousarray(g["edge_to"], dtype=np.int32)
+    out = np.zeros(20000 * 6, dtype=np.int32)
+    n = lib.cgmr_debug_fronts(C.c_int(V), C.c_void_p(fx.ctypes.data), C.c_int(len(ef)), C.c_void_p(ef.ctypes.data),
+                              C.c_void_p(et.ctypes.data), C.c_int(20000), C.c_void_p(out.ctypes.data))
+    info, perm = gn_symbolic_info(V, fx, ef, et, want_perm=True)
+    h.update(out[:6 * n].tobytes()); h.update(perm.tobytes())
+    h.update(str({k: v for k, v in info.items() if not k.endswith("_us")}).encode())
+print(h.hexdigest())
+"""
+
+
+def test_symbolic_analysis_independent_of_host_threads():
+    """The parallel sections of the host analysis (ND forks, border computation per subtree, keyed assembly lists)
+    must give the ordering, the front table and the sizes of the one-thread run: the thread count is read once per
+    process, hence subprocesses."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for nt in ("1", "3", "8"):
+        env = dict(os.environ, CGMR_HOST_THREADS=nt)
+        out = subprocess.run([sys.executable, "-c", _SYM_HASH, root], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        hashes.append(out.stdout.strip().splitlines()[-1])
+    assert hashes[0] == hashes[1] == hashes[2], hashes
