@@ -86,6 +86,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.h_level_leaf.assign(D.nlevels, 1);
   D.h_level_chunk.assign(D.nlevels, kChunkRows);
   D.h_level_w = S.level_w;
+  static const int mid_chunk = getenv("CGMR_CHUNK") ? std::min(kChunkRows, std::max(16, atoi(getenv("CGMR_CHUNK")))) : kMidChunkRows;
   static const int leaf_chunk = getenv("CGMR_LEAF_CHUNK") ? atoi(getenv("CGMR_LEAF_CHUNK")) : kLeafChunkRows;
   for (int l = 0; l < D.nlevels; l++) {
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++)
@@ -93,7 +94,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
     // a level of leaves runs the register-light variant of the factor kernel: shorter chunks, so that the LDS of two
     // workgroups fits a CU
     const int chunk_rows = S.level_w[l] == kWideFrontW ? kWideChunkRows
-                           : (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : kChunkRows);
+                           : (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
     D.h_level_chunk[l] = chunk_rows;
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
       int f = S.level_fronts[q];

@@ -304,12 +304,16 @@ __device__ __forceinline__ SlabGeom slab_geom(int tid, int ra) {
 
 template <int N>
 __device__ __forceinline__ void slab_issue(SlabLoadsT<N>& S, const SlabGeom& g, int tid, const double* __restrict__ U,
-                                           const double* __restrict__ uc, int rg, int ra2, int row0) {
+                                           const double* __restrict__ uc, int rg, int ra2, int row0,
+                                           const short* rmap, int w, int r0, int nr) {
   const int rend = min(rg, row0 + g.rows);
 #pragma unroll
   for (int u = 0; u < N; u++) {
     const int row = row0 + g.rr + g.rpp * u;
-    const bool ok = g.rr < g.rpp && row < rend;
+    // rows that land in another chunk's border rows are not fetched (a front cut into several work items streams each
+    // child once in total, not once per work item)
+    const int pr = rmap[min(g.rr + g.rpp * u, g.rows - 1)] - w - r0;
+    const bool ok = g.rr < g.rpp && row < rend && (pr < -r0 || (pr >= 0 && pr < nr));
     S.v[u] = *reinterpret_cast<const double2*>(U + (ok ? (size_t)row * ra2 + 2 * g.cp : 0));   // idle lanes re-read element 0
   }
   S.u = uc[min(row0 + tid, rg - 1)];
@@ -495,8 +499,8 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
     const double* U1 = Ubuf + WR->ch[cb1].U_off;
     const double* uc0 = uvec + (size_t)3 * WR->ch[cb].rows_off;
     const double* uc1 = uvec + (size_t)3 * WR->ch[cb1].rows_off;
-    slab_issue(S0, g0, tid, U0, uc0, rg0, even_up(ra0), 0);
-    if (two) slab_issue(S1, g1, tid, U1, uc1, rg1, even_up(ra1), 0);
+    slab_issue(S0, g0, tid, U0, uc0, rg0, even_up(ra0), 0, s_rmap + cb * MAPW, w, r0, nr);
+    if (two) slab_issue(S1, g1, tid, U1, uc1, rg1, even_up(ra1), 0, s_rmap + cb1 * MAPW, w, r0, nr);
     if (cb > 0) __syncthreads();
     slab_scatter<WW>(S0, g0, tid, rg0, ra0, 0, s_rmap + cb * MAPW, s_cmap + cb * W, w, r0, nr, Ls);
     if (two) {
@@ -512,7 +516,8 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
         if (tid < g.rows && row0 + tid < rg)
           s_rmap[cc * MAPW + tid] = (short)(3 * rel[WR->ch[cc].rel_off + (row0 + tid) / 3] + (row0 + tid) % 3);
         __syncthreads();
-        slab_issue(S0, g, tid, Ubuf + WR->ch[cc].U_off, uvec + (size_t)3 * WR->ch[cc].rows_off, rg, even_up(ra), row0);
+        slab_issue(S0, g, tid, Ubuf + WR->ch[cc].U_off, uvec + (size_t)3 * WR->ch[cc].rows_off, rg, even_up(ra), row0,
+                   s_rmap + cc * MAPW, w, r0, nr);
         slab_scatter<WW>(S0, g, tid, rg, ra, row0, s_rmap + cc * MAPW, s_cmap + cc * W, w, r0, nr, Ls);
       }
     }
@@ -526,7 +531,8 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
       if (c >= nbig && c < ncb0) {
         const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
         const SlabGeom g = slab_geom<SUS>(tid, ra);
-        slab_issue(T[c], g, tid, Ubuf + WR->ch[c].U_off, uvec + (size_t)3 * WR->ch[c].rows_off, rg, even_up(ra), 0);
+        slab_issue(T[c], g, tid, Ubuf + WR->ch[c].U_off, uvec + (size_t)3 * WR->ch[c].rows_off, rg, even_up(ra), 0,
+                   s_rmap + c * MAPW, w, r0, nr);
       }
     }
 #pragma unroll
@@ -553,7 +559,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
       }
       __syncthreads();
       SlabLoads S0;
-      slab_issue(S0, g, tid, Ubuf + G.U_off, uvec + (size_t)3 * G.rows_off, rg, even_up(ra), row0);
+      slab_issue(S0, g, tid, Ubuf + G.U_off, uvec + (size_t)3 * G.rows_off, rg, even_up(ra), row0, s_rmap, w, r0, nr);
       slab_scatter<WW>(S0, g, tid, rg, ra, row0, s_rmap, s_cmap, w, r0, nr, Ls);
     }
   }

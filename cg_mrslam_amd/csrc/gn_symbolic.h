@@ -24,8 +24,11 @@ constexpr int kWidePanelW = 32;
 constexpr int kWideFrontW = 3 * kWidePanelW;
 constexpr int64_t factor_header(int w) { return 2 * (int64_t)w * w + w; }   // L11 row-major, L11 column-major, 1/diag
 constexpr int kWideChunkRows = 100;  // border rows per work item in a level of 96-column fronts (LDS: 96 x 97 F11 + the chunk)
-constexpr int kChunkRows = 191;      // border rows per k_front_factor workgroup: 3 wavefronts minus the lane that
+constexpr int kChunkRows = 191;      // most border rows a k_front_factor workgroup can take: 3 wavefronts minus the lane that
                                      // carries the right-hand side through the factorisation
+constexpr int kMidChunkRows = 95;    // border rows per work item above the leaves: a front with a wide border is cut into
+                                     // several work items (each factors F11 again, fetches only the children's rows it owns):
+                                     // measured 191 / 127 / 95 / 63 / 47 rows -> 8.1 / 8.0 / 7.7 / 7.8 / 7.75 ms device on C2
 
 constexpr int kLeafChunkRows = 62;   // the same for a level of leaves (k_front_factor_leaf: three workgroups per CU, 48 KB of LDS each)
 
