@@ -39,7 +39,8 @@ constexpr int kMapW = 256;           // child rows per staged block of the row m
 //   [2*W*W+W, ...)  L21, r rows of W
 // LDS plan of k_front_factor (bytes):
 //   Ls   [W][LDW]  doubles   F11 (assembly), factored in place
-//   maps: s_rmap[MAXC][kMapW] (child row -> position in my row list), s_cmap[MAXC][W] shorts; the work record
+//   maps: s_rmap[MAXC][kMapW] (child row -> LDS offset of the panel row it is added into, map_dst()), s_cmap[MAXC][W]
+//        (child column -> my column) shorts; the work record
 //   Dinv [W] doubles: reciprocals of the pivots
 //   R    [ch_rows][LDW] doubles   chunk of F21 + the rhs row; ch_rows is the level's maximum.  R comes last: a level
 //        whose fronts have few border rows is launched with less LDS, so that several workgroups share a CU.
@@ -278,6 +279,15 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
   __builtin_amdgcn_ds_atomic_fadd_f64((lds_double*)p, v);
 }
 
+// Row map entry of a child row whose position in the parent's row list is `pos` (0..w-1 own columns, w.. border): the
+// LDS offset (doubles from Ls) of the panel row it is added into, or -1 if that row belongs to another work item.
+template <int WW>
+__device__ __forceinline__ short map_dst(int pos, int w, int r0, int nr) {
+  CGMR_FRONT_CONSTS(WW);
+  const int pr = pos - w - r0;
+  return (short)(pos < w ? pos * LDW : (pr >= 0 && pr < nr) ? kRIdx + pr * LDW : -1);
+}
+
 // One block of a child's leading slab plus the matching piece of its border vector, as loaded by one thread.
 // Thread = (column pair cp, row lane rr): it owns columns 2cp, 2cp+1 of rows rr, rr + rpp, rr + 2 rpp, ... of the
 // block, so one column-map lookup and one row-map lookup per load.  Everything is issued by slab_issue() before
@@ -305,57 +315,47 @@ __device__ __forceinline__ SlabGeom slab_geom(int tid, int ra) {
 template <int N>
 __device__ __forceinline__ void slab_issue(SlabLoadsT<N>& S, const SlabGeom& g, int tid, const double* __restrict__ U,
                                            const double* __restrict__ uc, int rg, int ra2, int row0,
-                                           const short* rmap, int w, int r0, int nr) {
+                                           const short* rmap) {
   const int rend = min(rg, row0 + g.rows);
 #pragma unroll
   for (int u = 0; u < N; u++) {
     const int row = row0 + g.rr + g.rpp * u;
-    // rows that land in another chunk's border rows are not fetched (a front cut into several work items streams each
-    // child once in total, not once per work item)
-    const int pr = rmap[min(g.rr + g.rpp * u, g.rows - 1)] - w - r0;
-    const bool ok = g.rr < g.rpp && row < rend && (pr < -r0 || (pr >= 0 && pr < nr));
+    // rows that land in another work item's border rows are not fetched (a front cut into several work items streams
+    // each child once in total, not once per work item)
+    const bool ok = g.rr < g.rpp && row < rend && rmap[min(g.rr + g.rpp * u, g.rows - 1)] >= 0;
     S.v[u] = *reinterpret_cast<const double2*>(U + (ok ? (size_t)row * ra2 + 2 * g.cp : 0));   // idle lanes re-read element 0
   }
   S.u = uc[min(row0 + tid, rg - 1)];
 }
 
 // Add the block into F11 (Ls), this chunk's F21 rows and rhs row / border-vector column (R, which directly
-// lies kRIdx doubles behind Ls in LDS: one index space).  rmap[k] = position of child row row0 + k in my row list
-// (0..w-1 own columns, w.. border), cmap = the same map for rows 0..ra-1.  A child never sends two elements to the
-// same cell, so the adds of one call do not collide; calls for different children are separated by a barrier.
+// lies kRIdx doubles behind Ls in LDS: one index space).  rmap[k] = map_dst() of child row row0 + k, cmap = my column
+// of child row / column 0..ra-1.  A child never sends two elements to the same cell, so the adds of one call do not
+// collide; calls for different children are separated by a barrier.
 template <int WW, int N>
 __device__ __forceinline__ void slab_scatter(const SlabLoadsT<N>& S, const SlabGeom& g, int tid, int rg, int ra, int row0,
                                              const short* rmap, const short* cmap, int w, int r0, int nr, double* Ls) {
   CGMR_FRONT_CONSTS(WW);
   const int rend = min(rg, row0 + g.rows);
   // every map lookup first ...
-  int prow[N];
-#pragma unroll
-  for (int u = 0; u < N; u++) prow[u] = rmap[min(g.rr + g.rpp * u, g.rows - 1)];
-  const int col0 = 2 * g.cp, col1 = 2 * g.cp + 1;
-  const int pc0 = cmap[min(col0, max(ra - 1, 0))], pc1 = cmap[min(col1, max(ra - 1, 0))];
-  const int prowu = rmap[min(tid, g.rows - 1)];
-  // ... then the targets, then the adds
   int dst[N];
 #pragma unroll
-  for (int u = 0; u < N; u++) {
-    const int row = row0 + g.rr + g.rpp * u;
-    const bool ok = g.rr < g.rpp && row < rend;
-    const int pr = prow[u] - w - r0;
-    dst[u] = !ok ? -1 : prow[u] < w ? prow[u] * LDW : (pr >= 0 && pr < nr) ? kRIdx + pr * LDW : -1;
-  }
+  for (int u = 0; u < N; u++) dst[u] = rmap[min(g.rr + g.rpp * u, g.rows - 1)];
+  const int col0 = 2 * g.cp, col1 = 2 * g.cp + 1;
+  const int pc0 = cmap[min(col0, max(ra - 1, 0))], pc1 = cmap[min(col1, max(ra - 1, 0))];
+  const int dstu = rmap[min(tid, g.rows - 1)];
+  // ... then the adds
 #pragma unroll
   for (int u = 0; u < N; u++) {
     const int row = row0 + g.rr + g.rpp * u;
-    if (dst[u] < 0) continue;
+    if (!(g.rr < g.rpp && row < rend) || dst[u] < 0) continue;
     // rows of the leading block (row < ra) hold their lower triangle only
     if (col0 < ra && (row >= ra || col0 <= row)) lds_add(Ls + dst[u] + pc0, S.v[u].x);
     if (col1 < ra && (row >= ra || col1 <= row)) lds_add(Ls + dst[u] + pc1, S.v[u].y);
   }
-  if (tid < g.rows && row0 + tid < rg) {                         // border vector of the child
-    const int pr = prowu - w - r0;
-    if (prowu < w) lds_add(Ls + kRIdx + nr * LDW + prowu, S.u);
-    else if (pr >= 0 && pr < nr) lds_add(Ls + kRIdx + pr * LDW + W, S.u);
+  if (tid < g.rows && row0 + tid < rg && dstu >= 0) {            // border vector of the child
+    if (dstu < kRIdx) lds_add(Ls + kRIdx + nr * LDW + dstu / LDW, S.u);   // an own column: the rhs row
+    else lds_add(Ls + dstu + W, S.u);                            // a border row of this work item: its column W
   }
 }
 
@@ -476,7 +476,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
       if (c < ncb0) {
         const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
         const short pos = (short)(3 * relv[c] + tid % 3);
-        if (tid < rg) s_rmap[c * MAPW + tid] = pos;
+        if (tid < rg) s_rmap[c * MAPW + tid] = map_dst<WW>(pos, w, r0, nr);
         if (tid < ra) s_cmap[c * W + tid] = pos;
       }
     }
@@ -499,8 +499,8 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
     const double* U1 = Ubuf + WR->ch[cb1].U_off;
     const double* uc0 = uvec + (size_t)3 * WR->ch[cb].rows_off;
     const double* uc1 = uvec + (size_t)3 * WR->ch[cb1].rows_off;
-    slab_issue(S0, g0, tid, U0, uc0, rg0, even_up(ra0), 0, s_rmap + cb * MAPW, w, r0, nr);
-    if (two) slab_issue(S1, g1, tid, U1, uc1, rg1, even_up(ra1), 0, s_rmap + cb1 * MAPW, w, r0, nr);
+    slab_issue(S0, g0, tid, U0, uc0, rg0, even_up(ra0), 0, s_rmap + cb * MAPW);
+    if (two) slab_issue(S1, g1, tid, U1, uc1, rg1, even_up(ra1), 0, s_rmap + cb1 * MAPW);
     if (cb > 0) __syncthreads();
     slab_scatter<WW>(S0, g0, tid, rg0, ra0, 0, s_rmap + cb * MAPW, s_cmap + cb * W, w, r0, nr, Ls);
     if (two) {
@@ -514,10 +514,10 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
       for (int row0 = g.rows; row0 < rg; row0 += g.rows) {
         __syncthreads();
         if (tid < g.rows && row0 + tid < rg)
-          s_rmap[cc * MAPW + tid] = (short)(3 * rel[WR->ch[cc].rel_off + (row0 + tid) / 3] + (row0 + tid) % 3);
+          s_rmap[cc * MAPW + tid] = map_dst<WW>(3 * rel[WR->ch[cc].rel_off + (row0 + tid) / 3] + (row0 + tid) % 3, w, r0, nr);
         __syncthreads();
         slab_issue(S0, g, tid, Ubuf + WR->ch[cc].U_off, uvec + (size_t)3 * WR->ch[cc].rows_off, rg, even_up(ra), row0,
-                   s_rmap + cc * MAPW, w, r0, nr);
+                   s_rmap + cc * MAPW);
         slab_scatter<WW>(S0, g, tid, rg, ra, row0, s_rmap + cc * MAPW, s_cmap + cc * W, w, r0, nr, Ls);
       }
     }
@@ -532,7 +532,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
         const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
         const SlabGeom g = slab_geom<SUS>(tid, ra);
         slab_issue(T[c], g, tid, Ubuf + WR->ch[c].U_off, uvec + (size_t)3 * WR->ch[c].rows_off, rg, even_up(ra), 0,
-                   s_rmap + c * MAPW, w, r0, nr);
+                   s_rmap + c * MAPW);
       }
     }
 #pragma unroll
@@ -554,12 +554,12 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
       __syncthreads();
       if (tid < g.rows && row0 + tid < rg) {
         const short pos = (short)(3 * rel[G.rel_off + (row0 + tid) / 3] + (row0 + tid) % 3);
-        s_rmap[tid] = pos;
+        s_rmap[tid] = map_dst<WW>(pos, w, r0, nr);
         if (row0 == 0 && tid < ra) s_cmap[tid] = pos;
       }
       __syncthreads();
       SlabLoads S0;
-      slab_issue(S0, g, tid, Ubuf + G.U_off, uvec + (size_t)3 * G.rows_off, rg, even_up(ra), row0, s_rmap, w, r0, nr);
+      slab_issue(S0, g, tid, Ubuf + G.U_off, uvec + (size_t)3 * G.rows_off, rg, even_up(ra), row0, s_rmap);
       slab_scatter<WW>(S0, g, tid, rg, ra, row0, s_rmap, s_cmap, w, r0, nr, Ls);
     }
   }
