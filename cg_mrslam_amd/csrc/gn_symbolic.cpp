@@ -196,7 +196,6 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
     // second sweep from the far vertex gives the level structure
     bfs(C, Q, far, vis1, vis2);
   }
-  const int start_a = Q[0], start_b = Q[n - 1];          // the two ends of this range: where the halves' sweeps start
   int nlev = C.dist[Q[n - 1]] + 1;
   if (nlev <= 2) return emit_panels(C, begin, end);  // clique-like: nothing to dissect
   std::vector<int32_t> lvl_cnt(nlev + 1, 0);
@@ -212,22 +211,73 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
     cum += lvl_cnt[j];
   }
   int js = best >= 0 ? best : fallback;
-  // partition queue order into A (levels < js, plus level-js vertices not touching js+1), B, S
+  // Separator: not all of level js, but a minimum vertex cover of the edges between level js and level js+1 (Koenig:
+  // from a maximum bipartite matching) -- every path from the near side to the far side crosses one of those edges.
+  // X = level-js vertices with a neighbour in level js+1, Y = those neighbours.  Covered vertices get dist = js,
+  // the other X move to the near side (dist js-1), the other Y stay on the far side.
+  {
+    int s_js = 0;
+    for (int j = 0; j < js; j++) s_js += lvl_cnt[j];
+    thread_local std::vector<int32_t> ylocal;             // vertex -> index in Y, -1 outside this block
+    if ((int)ylocal.size() < (int)C.label.size()) ylocal.assign(C.label.size(), -1);
+    std::vector<int32_t> X, Y, xptr(1, 0), xadj;
+    for (int q = s_js; q < s_js + lvl_cnt[js]; q++) {
+      int v = Q[q];
+      const size_t before = xadj.size();
+      for (int p = C.ap[v]; p < C.ap[v + 1]; p++) {
+        int w = C.ai[p];
+        if (C.label[w] != vis2 || C.dist[w] != js + 1) continue;
+        if (ylocal[w] < 0) { ylocal[w] = (int)Y.size(); Y.push_back(w); }
+        xadj.push_back(ylocal[w]);
+      }
+      if (xadj.size() == before) { C.dist[v] = js - 1; continue; }   // touches nothing beyond: near side
+      X.push_back(v);
+      xptr.push_back((int)xadj.size());
+    }
+    static const bool min_cover = !(getenv("CGMR_ND_MIN_COVER") && atoi(getenv("CGMR_ND_MIN_COVER")) == 0);
+    const int nx = (int)X.size(), ny = (int)Y.size();
+    if (min_cover && nx > 1 && ny > 0) {
+      std::vector<int32_t> mx(nx, -1), my(ny, -1), seen(ny, -1), stack;
+      // maximum matching by augmenting paths (the blocks are small: tens of vertices)
+      std::function<bool(int, int)> augment = [&](int x, int stamp) {
+        for (int p = xptr[x]; p < xptr[x + 1]; p++) {
+          int y = xadj[p];
+          if (seen[y] == stamp) continue;
+          seen[y] = stamp;
+          if (my[y] < 0 || augment(my[y], stamp)) { mx[x] = y; my[y] = x; return true; }
+        }
+        return false;
+      };
+      for (int x = 0; x < nx; x++) augment(x, x);
+      // Koenig: Z = reachable from the unmatched X by alternating paths; cover = (X \ Z) + (Y in Z)
+      std::vector<uint8_t> zx(nx, 0), zy(ny, 0);
+      for (int x = 0; x < nx; x++) if (mx[x] < 0) { zx[x] = 1; stack.push_back(x); }
+      while (!stack.empty()) {
+        int x = stack.back(); stack.pop_back();
+        for (int p = xptr[x]; p < xptr[x + 1]; p++) {
+          int y = xadj[p];
+          if (zy[y] || mx[x] == y) continue;
+          zy[y] = 1;
+          int x2 = my[y];
+          if (x2 >= 0 && !zx[x2]) { zx[x2] = 1; stack.push_back(x2); }
+        }
+      }
+      for (int x = 0; x < nx; x++) if (zx[x]) C.dist[X[x]] = js - 1;      // not in the cover: near side
+      for (int y = 0; y < ny; y++) if (zy[y]) C.dist[Y[y]] = js;          // in the cover: separator
+    }
+    for (int w : Y) ylocal[w] = -1;
+  }
   int na = 0, nb = 0;
   for (int q = 0; q < n; q++) {
-    int v = Q[q];
-    int d = C.dist[v];
+    int d = C.dist[Q[q]];
     if (d < js) na++;
     else if (d > js) nb++;
-    else {
-      bool touches = false;
-      for (int p = C.ap[v]; p < C.ap[v + 1] && !touches; p++) {
-        int w = C.ai[p];
-        if (C.label[w] == vis2 && C.dist[w] == js + 1) touches = true;
-      }
-      if (!touches) { na++; C.dist[v] = js - 1; }   // demote into A
-    }
   }
+  // the two ends of this range, where the halves' sweeps start: the root of the sweep and the farthest vertex that
+  // stayed on the far side (the cover may have claimed the last ones for the separator)
+  const int start_a = Q[0];
+  int start_b = -1;
+  for (int q = n - 1; q >= 0 && start_b < 0; q--) if (C.dist[Q[q]] > js) start_b = Q[q];
   int pa = begin, pb = begin + na, ps = begin + na + nb;
   for (int q = 0; q < n; q++) {
     int v = Q[q];

@@ -145,3 +145,75 @@ def test_symbolic_analysis_independent_of_host_threads():
         assert out.returncode == 0, out.stderr
         hashes.append(out.stdout.strip().splitlines()[-1])
     assert hashes[0] == hashes[1] == hashes[2], hashes
+
+
+def _front_table(V, fixed, ef, et):
+    import ctypes as C
+    from cg_mrslam_amd._lib import load_library, gn_symbolic_info
+    lib = load_library()
+    fx = np.ascontiguousarray(fixed, dtype=np.uint8)
+    ef = np.ascontiguousarray(ef, dtype=np.int32)
+    et = np.ascontiguousarray(et, dtype=np.int32)
+    out = np.zeros(60000 * 6, dtype=np.int32)
+    n = lib.cgmr_debug_fronts(C.c_int(V), C.c_void_p(fx.ctypes.data), C.c_int(len(ef)), C.c_void_p(ef.ctypes.data),
+                              C.c_void_p(et.ctypes.data), C.c_int(60000), C.c_void_p(out.ctypes.data))
+    assert 0 <= n <= 60000
+    info, perm = gn_symbolic_info(V, fx, ef, et, want_perm=True)
+    return out[:6 * n].reshape(n, 6), info, perm
+
+
+def _assert_valid_elimination_tree(V, fixed, ef, et):
+    """Front table = (c0, nc, ns, parent, level, nchild).  The fronts tile the permuted columns, hold <= 16 poses, parents
+    come later and sit on a higher level, and for every edge the front of the later column is an ancestor (or the
+    front itself) of the front of the earlier one -- the property the level-by-level factorisation relies on."""
+    F, info, perm = _front_table(V, fixed, ef, et)
+    nf = info["free_poses"]
+    n = len(F)
+    assert n == info["fronts"]
+    if n == 0:
+        return
+    assert F[0, 0] == 0 and np.all(F[1:, 0] == F[:-1, 0] + F[:-1, 1]) and F[-1, 0] + F[-1, 1] == nf
+    assert F[:, 1].min() >= 1 and F[:, 1].max() <= 16
+    col_front = np.repeat(np.arange(n), F[:, 1])
+    parent, level = F[:, 3], F[:, 4]
+    has_p = parent >= 0
+    assert np.all(parent[has_p] > np.nonzero(has_p)[0]) and np.all(level[parent[has_p]] > level[has_p])
+    assert level.max() + 1 == info["levels"]
+    assert sorted(perm[perm >= 0].tolist()) == list(range(nf))
+    for a, b in zip(ef, et):
+        ca, cb = perm[a], perm[b]
+        if ca < 0 or cb < 0 or ca == cb:
+            continue
+        f, g = col_front[min(ca, cb)], col_front[max(ca, cb)]
+        while f != g and 0 <= f < g:
+            f = parent[f]
+        assert f == g, (a, b)
+
+
+@pytest.mark.parametrize("V,E,seed", [(10000, 40000, 12345), (2500, 9000, 5), (500, 1500, 4), (60, 100, 2), (17, 16, 1)])
+def test_elimination_tree_valid_random_walks(V, E, seed):
+    g = synth.make_pose_graph(V, E, seed=seed)
+    _assert_valid_elimination_tree(V, g["fixed"], g["edge_from"], g["edge_to"])
+
+
+def test_elimination_tree_valid_special_shapes():
+    for g in (synth.make_hub_graph(40, 30, 3), synth.make_hub_graph(24, 40, 4), synth.make_lattice_graph(40)):
+        _assert_valid_elimination_tree(len(g["poses"]), g["fixed"], g["edge_from"], g["edge_to"])
+    # sub-graphs as the condensed-graph creator sees them: own edges only, gauge in the middle, foreign vertices inactive
+    for seed in (46, 49, 53):
+        R = synth.make_multi_robot(2, 1200, 4000, seed=seed)
+        for r in range(2):
+            gr = R[r]
+            V, n_own = len(gr["poses_all"]), gr["n_own"]
+            m = (gr["ef_all"] < n_own) & (gr["et_all"] < n_own)
+            for gauge in (0, n_own // 2):
+                fixed = np.zeros(V, dtype=np.uint8)
+                fixed[gauge] = 1
+                _assert_valid_elimination_tree(V, fixed, gr["ef_all"][m], gr["et_all"][m])
+    # two disconnected components, duplicate edges, several fixed vertices
+    g = synth.make_pose_graph(300, 700, seed=9)
+    ef = np.concatenate([g["edge_from"], g["edge_from"][:50], g["edge_from"] + 300])
+    et = np.concatenate([g["edge_to"], g["edge_to"][:50], g["edge_to"] + 300])
+    fixed = np.zeros(600, dtype=np.uint8)
+    fixed[[0, 17, 300, 455]] = 1
+    _assert_valid_elimination_tree(600, fixed, ef, et)
