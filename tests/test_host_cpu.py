@@ -217,3 +217,26 @@ def test_elimination_tree_valid_special_shapes():
     fixed = np.zeros(600, dtype=np.uint8)
     fixed[[0, 17, 300, 455]] = 1
     _assert_valid_elimination_tree(600, fixed, ef, et)
+
+
+def test_symbolic_analysis_survives_fork():
+    """The helper threads do not exist in a forked child: the analysis must fall back to the calling thread there
+    instead of queueing work for them (gloo / multiprocessing workers fork after the parent has used the library)."""
+    import os
+    import signal
+    from cg_mrslam_amd._lib import gn_symbolic_info
+    g = synth.make_pose_graph(6000, 20000, seed=21)
+    want = gn_symbolic_info(6000, g["fixed"], g["edge_from"], g["edge_to"])   # creates the pool in this process
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            signal.alarm(60)
+            got = gn_symbolic_info(6000, g["fixed"], g["edge_from"], g["edge_to"])
+            ok = all(got[k] == want[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border"))
+            os.write(w, b"1" if ok else b"0")
+        finally:
+            os._exit(0)
+    os.close(w)
+    _, status = os.waitpid(pid, 0)
+    assert os.read(r, 1) == b"1" and status == 0
