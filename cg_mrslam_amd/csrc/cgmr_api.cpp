@@ -134,6 +134,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   }
   BlobLayout B;
   size_t o_fronts = B.add<FrontDesc>(S.fronts.size());
+  size_t o_fronts_lv = B.add<FrontDesc>(S.fronts.size());   // the same descriptors in level order: the solves index them by workgroup
   size_t o_rows = B.add<int32_t>(S.rows.size());
   size_t o_children = B.add<int32_t>(S.children.size());
   size_t o_rel = B.add<int32_t>(S.rel.size());
@@ -170,6 +171,11 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   char* h = ctx->pinned;
   auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(h + off, src, bytes); };
   put(o_fronts, S.fronts.data(), S.fronts.size() * sizeof(FrontDesc));
+  {
+    std::vector<FrontDesc> lv(S.fronts.size());
+    for (size_t q = 0; q < S.level_fronts.size(); q++) lv[q] = S.fronts[S.level_fronts[q]];
+    put(o_fronts_lv, lv.data(), lv.size() * sizeof(FrontDesc));
+  }
   put(o_rows, S.rows.data(), S.rows.size() * 4);
   put(o_children, S.children.data(), S.children.size() * 4);
   put(o_rel, S.rel.data(), S.rel.size() * 4);
@@ -187,6 +193,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   char* d = ctx->gn_arena.ptr;
   HIP_TRY(ctx, hipMemcpyAsync(d, h, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
   D.fronts = (FrontDesc*)(d + o_fronts);
+  D.fronts_lv = (FrontDesc*)(d + o_fronts_lv);
   D.rows = (int32_t*)(d + o_rows);
   D.children = (int32_t*)(d + o_children);
   D.rel = (int32_t*)(d + o_rel);

@@ -14,6 +14,7 @@ struct GnDevice {
   int nV = 0, nE = 0, nf = 0, nb = 0, nlevels = 0, nfronts = 0;
   // structure (uploaded once per analyse)
   FrontDesc* fronts = nullptr;
+  FrontDesc* fronts_lv = nullptr;        // descriptors sorted by level (front q of the level order = fronts[level_fronts[q]])
   int32_t *rows = nullptr, *children = nullptr, *rel = nullptr, *inv = nullptr;
   WorkRec* work = nullptr;          // (front, chunk) work items of k_front_factor, level by level
   int32_t *level_fronts = nullptr, *tiles = nullptr, *apack = nullptr, *blk_slot = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;

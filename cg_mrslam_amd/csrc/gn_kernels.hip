@@ -907,8 +907,7 @@ constexpr int XB_CAP = 1536;         // border rows staged per pass
 constexpr int kBwdNL = 24;           // L21 rows per thread and pass
 constexpr int bwd_smem_bytes(int w) { return ((w > 64 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP) * 8; }
 template <int WW>
-__global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__ fronts,
-                                                   const int32_t* __restrict__ level_fronts, int level_begin,
+__global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
                                                    const double* __restrict__ yvec, double* __restrict__ xvec) {
   CGMR_FRONT_CONSTS(WW);
@@ -924,7 +923,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__
   double* part = dinv + W;                                   // [G][W]
   double* xb = part + G * W;                                 // [XB_CAP]
   const int tid = threadIdx.x;
-  const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
+  const FrontDesc F = fronts_lv[level_begin + blockIdx.x];    // descriptors in level order: no index hop
   const int w = 3 * F.nc, r = 3 * F.ns;
   const double* P = Lbuf + F.L_off;
   const double* L21 = P + kL21;
@@ -1108,8 +1107,8 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   const int lw = D.h_level_w[l];
   auto kern = lw == kWideFrontW ? k_solve_bwd<kWideFrontW> : k_solve_bwd<kFrontW>;
-  hipLaunchKernelGGL(kern, dim3(nfr), dim3(256), bwd_smem_bytes(lw), st, D.fronts, D.level_fronts, D.h_level_ptr[l], D.rows,
-                     D.Lbuf, D.yvec, D.xvec);
+  hipLaunchKernelGGL(kern, dim3(nfr), dim3(256), bwd_smem_bytes(lw), st, D.fronts_lv, D.h_level_ptr[l], D.rows, D.Lbuf,
+                     D.yvec, D.xvec);
 }
 
 void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
