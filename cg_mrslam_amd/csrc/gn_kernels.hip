@@ -12,8 +12,8 @@
 // Design ("GN kernels"): the factorisation is a supernodal multifrontal Cholesky.
 // The host (gn_symbolic.cpp) cuts the permuted matrix into dense fronts of <= 16 poses
 // (48 scalar columns) and sorts them into elimination-tree levels; one launch handles one
-// level, one workgroup handles one front (k_front_factor) or one 32x32 tile of a front's
-// update matrix (k_front_update).  Children hand their update matrices to the parent
+// level, one workgroup handles one front or, for a front with a wide border, one 95-row share of it
+// (k_front_factor), or one 32x32 tile of a front's update matrix (k_front_update).  Children hand their update matrices to the parent
 // through HBM/L2 ("extend-add", pulled by the parent in a fixed child order), so there are
 // no atomics anywhere and results are bit-reproducible run to run.  All arithmetic is FP64.
 #include <hip/hip_runtime.h>
@@ -372,19 +372,22 @@ __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDes
   return c;
 }
 
-// One workgroup per (front, chunk of CH border rows) of the current level.  A lone workgroup pulls cold data at
-// 10-25 bytes per clock and pays ~2500 clocks per dependent round trip (tools/ubench/cu_read_ubench.hip), so the
-// assembly is organised around few round trips and contiguous wide loads:
+// One workgroup per work item = (front, chunk of `chunk_rows` border rows) of the current level.  A lone workgroup
+// pulls cold data at 10-25 bytes per clock and pays ~2500 clocks per dependent round trip
+// (tools/ubench/cu_read_ubench.hip), so the assembly is organised around few round trips and contiguous wide loads:
 //   (1) the work record -- front descriptor plus the descriptors of its first MAXC children -- into LDS while
 //       LDS is being cleared;
 //   (2) everything addressed by the record: the rhs, this front's H blocks (stored contiguously in assembly
-//       order), the children's row maps (child row -> position in my row list);
-//   (3) the children's leading slabs, streamed front to back with 16-byte loads, two children in flight, and
-//       scattered into LDS through the maps.  Children are added in a fixed order with a barrier in between:
-//       no atomics, bit-reproducible.
-// Then the blocked factorisation of the panel in LDS (see below) and the stores.  The update matrix
-// U = ext_add - L21 L21^T of every front is formed by k_front_update, whose tiles spread over the idle CUs: forming
-// it here (tried for fronts of up to 96 border rows) made those fronts the slowest workgroup of their level.
+//       order), the children's row maps (child row -> LDS offset of the panel row it lands in, map_dst());
+//   (3) the children's leading slabs, streamed front to back with 16-byte loads -- the big children first, two in
+//       flight, then all small ones in one round -- and scattered into LDS through the maps; rows that belong to
+//       another work item of the front are not fetched.  Children are added in a fixed order with a barrier in
+//       between: no atomics, bit-reproducible.
+// Then the blocked factorisation of the panel in LDS (see below) and the stores.  Every work item of a front factors
+// F11 again (nobody waits for anybody) and owns its rows of L21.  The update matrix U = ext_add - L21 L21^T of every
+// front is formed by k_front_update, whose tiles spread over the idle CUs: forming it here (tried for fronts of up to
+// 96 border rows) made those fronts the slowest workgroup of their level.
+// LEAF: the level has no children at all -- rounds (2b) and (3) compile away, a quarter of the registers.
 template <bool LEAF, int WW>
 __device__ __forceinline__ void front_factor_body(unsigned char* smem, const WorkRec* __restrict__ work, int work_begin,
                                                   const FrontDesc* __restrict__ fronts,
