@@ -65,9 +65,9 @@ int cgmr_ctx_synchronize(cgmr_ctx* ctx);
  *   info_upper  [nE*6]         edge information matrices
  *   chi2_out    [iters+1]      (nullable) chi2 before each iteration and after the last
  * Host-pointer variant: copies in, runs on the GPU, copies poses and chi2 back.
- * Limit: a front of the elimination tree may have at most 10 906 border poses (16-bit row maps in LDS); a graph
+ * Limit: a front of the elimination tree may have at most 10 890 border poses (16-bit row maps in LDS); a graph
  * whose nested-dissection separators are wider is rejected with CGMR_E_INVALID (none of the BASELINE.json
- * configurations comes near: C2 has 118, a 100k-vertex / 300k-edge graph 818).              */
+ * configurations comes near: C2 has 74, a 100k-vertex / 300k-edge graph about 800).              */
 int cgmr_gn_optimize(cgmr_ctx* ctx, int nV, double* poses_xyt, const uint8_t* fixed, int nE,
                      const int32_t* from_idx, const int32_t* to_idx, const double* meas_xyt,
                      const double* info_upper, int iters, double* chi2_out);
