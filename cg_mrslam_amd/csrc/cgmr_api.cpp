@@ -264,7 +264,7 @@ void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double*
     T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
     return;
   }
-  T.run(1, 1, [&] { launch_assemble(st, D, D.chi2 + it); });   // + the chi2 sum of this iteration
+  T.run(1, 1, [&] { launch_assemble(st, D); });                // + the chi2 sum of this iteration (slot = iterations done)
   static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;
   if (trace)
     fprintf(stderr, "[cgmr] arena %p .. %p; work %p rel %p apack %p Ablk %p bvec %p yvec %p uvec %p Lbuf %p Ubuf %p chi2 %p\n",
@@ -288,7 +288,7 @@ void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double*
       fprintf(stderr, "[cgmr] level %d: %d fronts, %d work items, max r %d, max child rows %d\n", l,
               D.h_level_ptr[l + 1] - D.h_level_ptr[l], D.h_work_ptr[l + 1] - D.h_work_ptr[l], maxr, maxc);
     }
-    T.run(3, 1, [&] { launch_factor_level(st, D, l, it + 1, write_l11c); });
+    T.run(3, 1, [&] { launch_factor_level(st, D, l, write_l11c); });
     if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
   }
   if (!solve_and_update) return;
@@ -310,7 +310,23 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   GnDevice& D = ctx->gn;
   hipStream_t st = ctx->stream;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-  for (int it = 0; it <= iters; it++) gn_pass(ctx, d_poses, d_meas, d_info, it, it == iters, true);
+  // Every launch of a GN iteration is the same whatever the iteration's number (status[1] on the device supplies the
+  // chi2 slot and the failure tag): CGMR_GRAPH=1 captures one iteration into a hipGraph and replays it.
+  static const bool graph_mode = getenv("CGMR_GRAPH") && atoi(getenv("CGMR_GRAPH")) != 0;
+  static const bool trace_launches = getenv("CGMR_TRACE_LAUNCHES") != nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  if (graph_mode && !ctx->profiling && !trace_launches && iters >= 2 && st != nullptr && D.nf > 0) {
+    gn_init_kernels();
+    HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    gn_pass(ctx, d_poses, d_meas, d_info, 0, false, true);
+    HIP_TRY(ctx, hipStreamEndCapture(st, &graph));
+    HIP_TRY(ctx, hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+    for (int it = 0; it < iters; it++) HIP_TRY(ctx, hipGraphLaunch(graph_exec, st));
+    gn_pass(ctx, d_poses, d_meas, d_info, iters, true, true);
+  } else {
+    for (int it = 0; it <= iters; it++) gn_pass(ctx, d_poses, d_meas, d_info, it, it == iters, true);
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
   // read back chi2 + status
   std::vector<double> chi(iters + 1);
@@ -319,6 +335,8 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   HIP_TRY(ctx, hipMemcpyAsync(&status, D.status, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
+  if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+  if (graph) (void)hipGraphDestroy(graph);
   if (ctx->profiling) profile_collect(ctx);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);

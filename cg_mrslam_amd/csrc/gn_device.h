@@ -35,8 +35,9 @@ struct GnDevice {
 void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const int32_t* ef, const int32_t* et,
                       const double* meas, const double* info, int chi_only);
 void launch_chi2(hipStream_t st, const GnDevice& D, double* out);
-void launch_assemble(hipStream_t st, const GnDevice& D, double* chi_out);
-void launch_factor_level(hipStream_t st, const GnDevice& D, int level, int iter_tag, bool write_l11c);
+void launch_assemble(hipStream_t st, const GnDevice& D);
+void gn_init_kernels();
+void launch_factor_level(hipStream_t st, const GnDevice& D, int level, bool write_l11c);
 void launch_update_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);

@@ -168,9 +168,10 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
                                                   const int32_t* __restrict__ asm_src,
                                                   const int32_t* __restrict__ blk_slot,
                                                   const double* __restrict__ term, double* __restrict__ Ablk,
-                                                  double* __restrict__ bvec, double* __restrict__ chi_out) {
+                                                  double* __restrict__ bvec, double* __restrict__ chi_out,
+                                                  const int* __restrict__ status) {
   if (blockIdx.x == gridDim.x - 1) {
-    block_chi2_sum((nE + 255) / 256, term + (size_t)33 * nE, chi_out);
+    block_chi2_sum((nE + 255) / 256, term + (size_t)33 * nE, chi_out + status[1]);   // chi2 before iteration status[1]
     return;
   }
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -397,7 +398,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
                                                   const double* __restrict__ Ablk, double* __restrict__ Lbuf,
                                                   double* __restrict__ Ubuf, const double* __restrict__ bvec,
                                                   double* __restrict__ yvec, double* __restrict__ uvec,
-                                                  int* __restrict__ status, int iter_tag, int level_id,
+                                                  int* __restrict__ status, int level_id,
                                                   int write_l11c, int ch_rows, int chunk_rows) {
   CGMR_FRONT_CONSTS(WW);
   double* Ls = reinterpret_cast<double*>(smem + kOffLs);
@@ -700,7 +701,7 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
       if (K == 0) FPHASE(4);
     }
   }
-  if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, iter_tag);
+  if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);   // status[1]: GN iterations completed so far
   PHASE(4);
   // ---- stores, all from LDS: L11 (lower triangle, zeros above), 1/diag, L21 rows of this chunk, y, u
   double* P = Lbuf + L_off;
@@ -748,11 +749,11 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
                                                          const double* __restrict__ Ablk, double* __restrict__ Lbuf,
                                                          double* __restrict__ Ubuf, const double* __restrict__ bvec,
                                                          double* __restrict__ yvec, double* __restrict__ uvec,
-                                                         int* __restrict__ status, int iter_tag, int level_id,
+                                                         int* __restrict__ status, int level_id,
                                                          int write_l11c, int ch_rows, int chunk_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   front_factor_body<false, WW>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec,
-                               status, iter_tag, level_id, write_l11c, ch_rows, chunk_rows);
+                               status, level_id, write_l11c, ch_rows, chunk_rows);
 }
 
 // The leaves of the elimination tree (level 0: about half of all fronts) have no children: without the slab
@@ -766,11 +767,11 @@ __global__ __launch_bounds__(256, 2) void k_front_factor_leaf(const WorkRec* __r
                                                                  const double* __restrict__ Ablk, double* __restrict__ Lbuf,
                                                                  double* __restrict__ Ubuf, const double* __restrict__ bvec,
                                                                  double* __restrict__ yvec, double* __restrict__ uvec,
-                                                                 int* __restrict__ status, int iter_tag, int level_id,
+                                                                 int* __restrict__ status, int level_id,
                                                                  int write_l11c, int ch_rows, int chunk_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   front_factor_body<true, kFrontW>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec,
-                                   status, iter_tag, level_id, write_l11c, ch_rows, chunk_rows);
+                                   status, level_id, write_l11c, ch_rows, chunk_rows);
 }
 
 // --------------------------------------------------------------------------- front update
@@ -1042,10 +1043,14 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__
 // poses (+)= dx  (VertexSE2::oplusImpl: translation added in the global frame, angle wrapped)
 __global__ __launch_bounds__(256) void k_update_poses(int nV, const int32_t* __restrict__ vperm,
                                                       const double* __restrict__ xvec, double* __restrict__ poses,
-                                                      const int* __restrict__ status) {
+                                                      int* __restrict__ status) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nV) return;
-  if (*status != 0) return;
+  const int failed = status[0];
+  // status[1] counts the completed GN iterations: every launch of an iteration is the same whatever its number (the
+  // chi2 slot and the failure tag come from the counter), so one captured graph serves all of them
+  if (v == 0) status[1] = status[1] + 1;
+  if (failed != 0) return;
   int c = vperm[v];
   if (c < 0) return;
   poses[3 * v] += xvec[3 * c];
@@ -1066,29 +1071,35 @@ void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
   hipLaunchKernelGGL(k_chi2_reduce, dim3(1), dim3(256), 0, st, (D.nE + 255) / 256, D.term + (size_t)33 * D.nE, out);
 }
 
-void launch_assemble(hipStream_t st, const GnDevice& D, double* chi_out) {
+void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
   hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256 + 1), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_slot, D.term, D.Ablk, D.bvec, chi_out);
+                     D.asm_src, D.blk_slot, D.term, D.Ablk, D.bvec, D.chi2, D.status);
 }
 
-void launch_factor_level(hipStream_t st, const GnDevice& D, int l, int iter_tag, bool write_l11c) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              factor_smem_bytes(kFrontW, kChunkRows + 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              factor_smem_bytes(kWideFrontW, kWideChunkRows + 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor_leaf),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, factor_smem_bytes(kFrontW, kChunkRows + 1));
-    attr_set = true;
-  }
+// one-time kernel attributes (dynamic LDS above 64 KB); idempotent, never inside a stream capture
+void gn_init_kernels() {
+  static bool done = false;
+  if (done) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            factor_smem_bytes(kFrontW, kChunkRows + 1));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            factor_smem_bytes(kWideFrontW, kWideChunkRows + 1));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            factor_smem_bytes(kFrontW, kChunkRows + 1));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_bwd<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            bwd_smem_bytes(kWideFrontW));
+  done = true;
+}
+
+void launch_factor_level(hipStream_t st, const GnDevice& D, int l, bool write_l11c) {
+  gn_init_kernels();
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
   const int lw = D.h_level_w[l];
   const int ch_rows = D.h_level_chrows[l];
   auto kern = lw == kWideFrontW ? k_front_factor<kWideFrontW> : (D.h_level_leaf[l] ? k_front_factor_leaf : k_front_factor<kFrontW>);
   hipLaunchKernelGGL(kern, dim3(nw), dim3(256), factor_smem_bytes(lw, ch_rows), st, D.work, D.h_work_ptr[l], D.fronts,
-                     D.children, D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, iter_tag, l,
+                     D.children, D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, l,
                      write_l11c ? 1 : 0, ch_rows, D.h_level_chunk[l]);
 }
 
@@ -1101,12 +1112,7 @@ void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
 }
 
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_bwd<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              bwd_smem_bytes(kWideFrontW));
-    attr_set = true;
-  }
+  gn_init_kernels();
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   const int lw = D.h_level_w[l];
   auto kern = lw == kWideFrontW ? k_solve_bwd<kWideFrontW> : k_solve_bwd<kFrontW>;
