@@ -240,3 +240,33 @@ def test_symbolic_analysis_survives_fork():
     os.close(w)
     _, status = os.waitpid(pid, 0)
     assert os.read(r, 1) == b"1" and status == 0
+
+
+def test_symbolic_analysis_concurrent_callers():
+    """Several threads analysing different graphs at once (ctypes releases the GIL; the helper pool is shared): every
+    call must return what it returns alone."""
+    import threading
+    from cg_mrslam_amd._lib import gn_symbolic_info
+    graphs = [synth.make_pose_graph(V, E, seed=s) for (V, E, s) in ((6000, 20000, 31), (3000, 12000, 32), (9000, 30000, 33), (1500, 4000, 34))]
+    keys = ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")
+
+    def analyse(g):
+        info, perm = gn_symbolic_info(len(g["poses"]), g["fixed"], g["edge_from"], g["edge_to"], want_perm=True)
+        return tuple(info[k] for k in keys), perm.tobytes()
+
+    want = [analyse(g) for g in graphs]
+    got = [[None] * 4 for _ in graphs]
+
+    def worker(i):
+        for rep in range(4):
+            got[i][rep] = analyse(graphs[i])
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(graphs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    for i in range(len(graphs)):
+        for rep in range(4):
+            assert got[i][rep] == want[i]
