@@ -426,14 +426,14 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   GnDevice& D = ctx->gn;
   hipStream_t st = ctx->stream;
   if (D.nf == 0 || nq == 0) { HIP_TRY(ctx, hipStreamSynchronize(st)); return mode == 2 ? 0 : CGMR_OK; }
-  const int m = ((3 * nq + 15) / 16) * 16;
+  const int m = ((4 * nq + 15) / 16) * 16;          // 4 columns of Y per query (3 + 1 padding): a query never straddles a 16-column tile
   const int n = 3 * D.nf;
   const int chunk = 2048, nchunk = (n + chunk - 1) / chunk;
   // staging: poses | meas | info | qcol | qvert | Y | Uv | part | G | cov | est | info_out | flags
   struct L2 { size_t off = 0; size_t add(size_t b) { off = (off + 255) & ~size_t(255); size_t o = off; off += b; return o; } } L;
   size_t o_p = L.add(24 * (size_t)nV), o_m = L.add(24 * (size_t)nE), o_i = L.add(48 * (size_t)nE), o_qc = L.add(4 * (size_t)nq),
          o_qv = L.add(4 * (size_t)nq), o_Y = L.add(8 * (size_t)n * m), o_U = L.add(8 * ((size_t)3 * S.rows.size() + 3) * m),
-         o_part = L.add(8 * (size_t)nchunk * m * m), o_G = L.add(8 * (size_t)m * m), o_cov = L.add(72 * (size_t)nq),
+         o_part = L.add(8 * (size_t)nchunk * 16 * m), o_G = L.add(8 * (size_t)16 * m), o_cov = L.add(72 * (size_t)nq),
          o_est = L.add(24 * (size_t)nq), o_io = L.add(48 * (size_t)nq), o_fl = L.add(4 * (size_t)nq);
   rc = arena_reserve(ctx, ctx->io_arena, L.off + 256);
   if (rc) return rc;

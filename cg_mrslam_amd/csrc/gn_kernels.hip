@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "gn_symbolic.h"
 #include "gn_device.h"
 
@@ -1077,19 +1079,22 @@ void launch_assemble(hipStream_t st, const GnDevice& D) {
                      D.asm_src, D.blk_slot, D.term, D.Ablk, D.bvec, D.chi2, D.status);
 }
 
-// one-time kernel attributes (dynamic LDS above 64 KB); idempotent, never inside a stream capture
+// one-time kernel attributes (dynamic LDS above 64 KB): once per HIP device of the process (the attribute belongs to
+// the device's copy of the function), thread-safe, never inside a stream capture
 void gn_init_kernels() {
-  static bool done = false;
-  if (done) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            factor_smem_bytes(kFrontW, kChunkRows + 1));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            factor_smem_bytes(kWideFrontW, kWideChunkRows + 1));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            factor_smem_bytes(kFrontW, kChunkRows + 1));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_bwd<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            bwd_smem_bytes(kWideFrontW));
-  done = true;
+  static std::once_flag once[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::call_once(once[dev & 63], [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              factor_smem_bytes(kFrontW, kChunkRows + 1));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              factor_smem_bytes(kWideFrontW, kWideChunkRows + 1));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              factor_smem_bytes(kFrontW, kChunkRows + 1));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_bwd<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              bwd_smem_bytes(kWideFrontW));
+  });
 }
 
 void launch_factor_level(hipStream_t st, const GnDevice& D, int l, bool write_l11c) {

@@ -7,8 +7,11 @@
 // factor [g2o-recalled]; on the GPU the same blocks come out of
 //       Y = L^-1 E   (E = unit columns of the K query poses, multi right-hand-side forward solve
 //                     through the supernodal factor of gn_kernels.hip, level by level)
-//       Sigma = Y^T Y (dense contraction over the n = 3 * poses rows: the one GEMM-shaped piece of the
-//                     whole path; v_mfma_f64_16x16x4_f64, K split over workgroups, fixed-order reduction)
+//       Sigma_kk = Y_k^T Y_k for every query k: only the 3x3 diagonal blocks of Y^T Y are ever read
+//                     (graph_manipulator.cpp:134-142 asks for the (h,h) blocks), so each query gets 4 columns of Y
+//                     (3 + 1 padding) and only the diagonal 16x16 tiles (4 queries each) of the Gram matrix are
+//                     contracted over the n = 3 * poses rows: v_mfma_f64_16x16x4_f64, rows split over workgroups,
+//                     fixed-order reduction.  Work O(n m) instead of O(n m^2), scratch 8 * nchunk * 16 m bytes.
 // followed by one thread per condensed edge for the unscented transform (7 sigma points, alpha 1e-3,
 // beta 2, lambda = alpha^2 n) and the 3x3 inverse.
 #include <hip/hip_runtime.h>
@@ -29,14 +32,14 @@ __device__ __forceinline__ double d_norm_theta(double t) {
 }
 }  // namespace
 
-// E[3*vperm[q]+a][3k+a] = 1 for query k (others zero); Y is n x m row-major (m padded to 16)
+// E[3*vperm[q]+a][4k+a] = 1 for query k (others zero); Y is n x m row-major, 4 columns per query, m padded to 16
 __global__ void k_marg_init_rhs(int nK, const int32_t* __restrict__ qcol, int m, double* __restrict__ Y) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nK) return;
   int c = qcol[k];
   if (c < 0) return;
 #pragma unroll
-  for (int a = 0; a < 3; a++) Y[(size_t)(3 * c + a) * m + 3 * k + a] = 1.0;
+  for (int a = 0; a < 3; a++) Y[(size_t)(3 * c + a) * m + 4 * k + a] = 1.0;
 }
 
 // Forward solve L Y = E for MB right-hand sides at a time: grid (fronts of the level, m / MB).
@@ -89,55 +92,53 @@ __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __rest
   }
 }
 
-// Partial Gram matrices: workgroup (tile pair, K-chunk); each of the 4 wavefronts accumulates a 16x16 tile of
-// Y^T Y over its quarter of the chunk with v_mfma_f64_16x16x4_f64, then the four are summed in a fixed order.
-//   A operand (16 x 4): lane l holds A[i = l & 15][k = l >> 4] = Y[k0 + (l >> 4)][16 I + (l & 15)]
-//   B operand (4 x 16): lane l holds B[k = l >> 4][j = l & 15] = Y[k0 + (l >> 4)][16 J + (l & 15)]
+// Partial diagonal tiles of the Gram matrix: workgroup (tile I, row chunk); each of the 4 wavefronts accumulates the
+// 16x16 tile Y_I^T Y_I over its quarter of the chunk with v_mfma_f64_16x16x4_f64, then the four are summed in a fixed
+// order.  A and B operands are the same 4 x 16 slice of Y:
+//   lane l holds Y[k0 + (l >> 4)][16 I + (l & 15)]
 //   C/D: 4 doubles per lane, element (row = (l >> 4) + 4 * reg, col = l & 15)
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_gram_partial(int n, int m, int chunk, const double* __restrict__ Y,
-                                                      double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_gram_diag_partial(int n, int m, int chunk, const double* __restrict__ Y,
+                                                           double* __restrict__ part) {
   __shared__ double red[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = m / 16;
-  const int I = blockIdx.x / T, J = blockIdx.x - I * T;
+  const int I = blockIdx.x;
   const int k_begin = blockIdx.y * chunk, k_end = min(n, k_begin + chunk);
   const int per = (k_end - k_begin + 3) / 4;
   const int w0 = k_begin + wave * per, w1 = min(k_end, w0 + per);
   double4_t acc = {0, 0, 0, 0};
   const int kk = lane >> 4, ii = lane & 15;
   for (int k0 = w0; k0 < w1; k0 += 4) {
-    int k = k0 + kk;
-    double a = 0, b = 0;
-    if (k < w1) {
-      a = Y[(size_t)k * m + 16 * I + ii];
-      b = Y[(size_t)k * m + 16 * J + ii];
-    }
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    const int k = k0 + kk;
+    const double a = (k < w1) ? Y[(size_t)k * m + 16 * I + ii] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
   }
 #pragma unroll
   for (int rg = 0; rg < 4; rg++) red[wave][((lane >> 4) + 4 * rg) * 16 + (lane & 15)] = acc[rg];
   __syncthreads();
-  double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-  int row = tid >> 4, colj = tid & 15;
-  part[((size_t)blockIdx.y * m + 16 * I + row) * m + 16 * J + colj] = s;
+  const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  part[((size_t)blockIdx.y * T + I) * 256 + tid] = s;
 }
 
-__global__ void k_gram_reduce(int m, int nchunk, const double* __restrict__ part, double* __restrict__ G) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= m * m) return;
+// G[I][row][col] = sum over the row chunks, in chunk order
+__global__ void k_gram_diag_reduce(int T, int nchunk, const double* __restrict__ part, double* __restrict__ G) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)T * 256;
+  if (q >= total) return;
   double s = 0;
-  for (int c = 0; c < nchunk; c++) s += part[(size_t)c * m * m + q];
+  for (int c = 0; c < nchunk; c++) s += part[(size_t)c * total + q];
   G[q] = s;
 }
 
-// cov_out[k] = 3x3 diagonal block k of the Gram matrix
-__global__ void k_marg_extract(int nK, int m, const double* __restrict__ G, double* __restrict__ cov) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
+// cov_out[k] = the 3x3 block of query k inside its diagonal tile (4 queries per tile, 4 columns per query)
+__global__ void k_marg_extract(int nK, const double* __restrict__ G, double* __restrict__ cov) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nK * 9) return;
-  int k = q / 9, e = q - 9 * k;
-  cov[q] = G[(size_t)(3 * k + e / 3) * m + 3 * k + e % 3];
+  const int k = q / 9, e = q - 9 * k;
+  const int o = 4 * (k & 3);
+  cov[q] = G[(size_t)(k >> 2) * 256 + (o + e / 3) * 16 + o + e % 3];
 }
 
 // EdgeLabeler::labelEdge for star edges gauge -> v (SURVEY.md Appendix A [g2o-recalled]); one thread per edge.
@@ -227,10 +228,10 @@ void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* 
     hipLaunchKernelGGL(kern, dim3(nfr, m / MB), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_level_ptr[l], D.children,
                        D.rel, D.inv, D.Lbuf, m, Y, Uv);
   }
-  int T = m / 16;
-  hipLaunchKernelGGL(k_gram_partial, dim3(T * T, nchunk), dim3(256), 0, st, 3 * D.nf, m, chunk, Y, part);
-  hipLaunchKernelGGL(k_gram_reduce, dim3((m * m + 255) / 256), dim3(256), 0, st, m, nchunk, part, G);
-  hipLaunchKernelGGL(k_marg_extract, dim3((nK * 9 + 255) / 256), dim3(256), 0, st, nK, m, G, cov);
+  const int T = m / 16;
+  hipLaunchKernelGGL(k_gram_diag_partial, dim3(T, nchunk), dim3(256), 0, st, 3 * D.nf, m, chunk, Y, part);
+  hipLaunchKernelGGL(k_gram_diag_reduce, dim3((T * 256 + 255) / 256), dim3(256), 0, st, T, nchunk, part, G);
+  hipLaunchKernelGGL(k_marg_extract, dim3((nK * 9 + 255) / 256), dim3(256), 0, st, nK, G, cov);
 }
 
 void launch_label(hipStream_t st, int nK, const int32_t* d_qvert, int gauge, const double* poses, const double* cov,

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "matcher_device.h"
 #include "portable_sincos.h"
 
@@ -777,17 +779,21 @@ __global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const doubl
   }
 }
 
+// dynamic LDS above 64 KB: set once per HIP device of the process (thread-safe); one instantiation per kernel
+template <int KERNEL>
+static void set_lds_attr_once(const void* fn) {
+  static std::once_flag once[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::call_once(once[dev & 63], [fn] { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)); });
+}
+
 size_t match_smem_bytes() { return sizeof(Smem); }
 
 void launch_match_verify(hipStream_t st, const MatchParams& P, const double* pts2, const double* pts1, double nonmatched_score,
                          int lo_x, int lo_y, int hi_x, int hi_y, const uint8_t* kernel_lut, unsigned char* scratch,
                          double* score_out, int* nnm_out, int* err) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_verify), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sizeof(Smem));
-    attr_set = true;
-  }
+  set_lds_attr_once<0>(reinterpret_cast<const void*>(k_match_verify));
   hipLaunchKernelGGL(k_match_verify, dim3(1), dim3(256), sizeof(Smem), st, P, pts2, pts1, nonmatched_score, lo_x, lo_y, hi_x,
                      hi_y, kernel_lut, scratch, score_out, nnm_out, err);
 }
@@ -795,12 +801,7 @@ void launch_match_verify(hipStream_t st, const MatchParams& P, const double* pts
 void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const double* ref_pts, const double* qry_pts,
                          const RegionDesc* regions, const double* theta, const int32_t* items, const uint8_t* kernel_lut,
                          unsigned char* scratch, unsigned long long* bins, int* err) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_greedy), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sizeof(Smem));
-    attr_set = true;
-  }
+  set_lds_attr_once<0>(reinterpret_cast<const void*>(k_match_greedy));
   hipLaunchKernelGGL(k_match_greedy, dim3(nblocks), dim3(256), sizeof(Smem), st, P, ref_pts, qry_pts, regions, theta, items,
                      kernel_lut, scratch, bins, err);
 }
@@ -809,12 +810,7 @@ void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
                               double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_close_batch),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-    attr_set = true;
-  }
+  set_lds_attr_once<0>(reinterpret_cast<const void*>(k_match_close_batch));
   hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(CB_THREADS), sizeof(Smem), st, P, ranges_ref, ranges_qry, guess,
                      beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err);
 }

@@ -31,7 +31,8 @@ extern "C" int cgmr_occupancy_map(cgmr_ctx* ctx, const cgmr_occupancy_config* cf
                                   const float* ranges, const double* robot_poses_xyt, int32_t* hits_out,
                                   int32_t* misses_out, uint8_t* image_out, double* kernel_seconds_out) {
   if (!ctx) return CGMR_E_INVALID;
-  if (!cfg || n_scans < 0 || n_beams < 0 || cfg->rows <= 0 || cfg->cols <= 0 || !(cfg->resolution > 0) ||
+  // n_beams >= 1: the beam threads of a scan also carry its fillRobotPose cells (a scan without beams is not a scan)
+  if (!cfg || n_scans < 0 || n_beams < 1 || cfg->rows <= 0 || cfg->cols <= 0 || !(cfg->resolution > 0) ||
       (n_scans > 0 && n_beams > 0 && (!ranges || !robot_poses_xyt)) || cfg->square_size < 0)
     return set_err(ctx, CGMR_E_INVALID, "cgmr_occupancy_map: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -35,10 +35,11 @@ __global__ __launch_bounds__(256) void k_occ_integrate(OccParams P, const float*
   if (t >= (long long)P.n_scans * P.n_beams) return;
   const int s = (int)(t / P.n_beams), i = (int)(t - (long long)s * P.n_beams);
   const OccScan S = scans[s];
-  // fillRobotPose: the first 81 beams of a scan also mark the 9 x 9 cells around the robot
-  if (i < 81) {
+  // fillRobotPose (frequency_map.cpp:89-103): the beams of a scan share out the 9 x 9 cells around the robot
+  // (beam i marks cells i, i + n_beams, ...: all 81 whatever the beam count)
+  for (int c = i; c < 81; c += P.n_beams) {
     const int rgx = occ_w2m((float)S.rx, P.off_x, P.resolution), rgy = occ_w2m((float)S.ry, P.off_y, P.resolution);
-    const int cx = rgx + (i % 9) - 4, cy = rgy + (i / 9) - 4;
+    const int cx = rgx + (c % 9) - 4, cy = rgy + (c / 9) - 4;
     if (occ_inside(P, cx, cy)) atomicAdd(&misses[(size_t)cx * P.cols + cy], 1);
   }
   float r = ranges[(size_t)s * P.n_beams + i];

@@ -4,6 +4,17 @@
 // that decides a grid cell (matcher search angle, occupancy-map beam end points) must be bit-identical on host
 // and device, and libm and ocml are not.  Translation units that include this header must be compiled with
 // -ffp-contract=off (see Makefile).
+//  The polynomial kernels k_sin / k_cos and the three-stage pi/2 reduction below follow FreeBSD/Sun fdlibm
+// (__kernel_sin, __kernel_cos, __ieee754_rem_pio2: same coefficients, same evaluation order), whose licence asks
+// that this notice be preserved:
+// ====================================================
+// Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+// 
+// Developed at SunPro, a Sun Microsystems, Inc. business.
+// Permission to use, copy, modify, and distribute this
+// software is freely granted, provided that this notice
+// is preserved.
+// ====================================================
 #ifndef CGMR_PORTABLE_SINCOS_H
 #define CGMR_PORTABLE_SINCOS_H
 #include <hip/hip_runtime.h>

@@ -47,6 +47,18 @@
 
 /* ------------------------------------------------------------------ portable sin / cos */
 
+/* The polynomial kernels k_sin / k_cos and the three-stage pi/2 reduction below follow FreeBSD/Sun fdlibm
+ * (__kernel_sin, __kernel_cos, __ieee754_rem_pio2: same coefficients, same evaluation order), whose licence asks
+ * that this notice be preserved:
+ * ====================================================
+ * Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *
+ * Developed at SunPro, a Sun Microsystems, Inc. business.
+ * Permission to use, copy, modify, and distribute this
+ * software is freely granted, provided that this notice
+ * is preserved.
+ * ====================================================
+ */
 static double k_sin(double x, double y, int iy) {
   static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                       S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,

@@ -41,6 +41,19 @@ def test_map_matches_oracle(ctx, oracle, kw):
         assert (g.image == 100).sum() > 20
 
 
+def test_fewer_beams_than_robot_footprint_cells(ctx, oracle):
+    """fillRobotPose marks all 81 cells around the robot whatever the beam count (frequency_map.cpp:89-103): a
+    40-beam laser must still give the oracle's miss counts."""
+    tr = synth.make_trajectory(24, laps=0.1, n_beams=40)
+    g = Graph2occupancy(ctx, tr["truth"][::3], tr["scans"][::3], tr["angle_min"], tr["angle_inc"], tr["max_range"])
+    assert g.computeMap()
+    tposes, size, offset = g.geometry()
+    h, m, img = _oracle_map(oracle, g, tposes, size, offset)
+    np.testing.assert_array_equal(g.hits, h)
+    np.testing.assert_array_equal(g.misses, m)
+    np.testing.assert_array_equal(g.image, img)
+
+
 def test_full_trajectory_properties(ctx, oracle):
     """A whole lap (400 scans x 1081 beams): parity on a sample of scans is covered above; here size-independent
     properties at full size -- integrating the scans in two halves and adding equals integrating them at once
