@@ -180,6 +180,15 @@ class Context:
             self._check(rc)
         return to[:rc].copy(), est[:rc].copy(), iu[:rc].copy(), cov[:rc].copy()
 
+    def set_symbolic_cache(self, on: bool):
+        """Reuse of the ordering / symbolic analysis / structure upload across calls on the same edge list (default on)."""
+        self._check(self.lib.cgmr_set_symbolic_cache(self.h, C.c_int(1 if on else 0)))
+
+    def symbolic_cache_stats(self):
+        out = np.zeros(2, dtype=np.int64)
+        self._check(self.lib.cgmr_symbolic_cache_stats(self.h, _ptr(out)))
+        return {"hits": int(out[0]), "misses": int(out[1])}
+
     def gn_last_timing(self):
         out = np.zeros(5)
         self._check(self.lib.cgmr_gn_last_timing(self.h, _ptr(out)))

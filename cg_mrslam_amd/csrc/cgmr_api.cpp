@@ -54,6 +54,16 @@ int pinned_reserve(cgmr_ctx* ctx, size_t bytes) {
   return 0;
 }
 
+int pinned_mask_reserve(cgmr_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_mask_cap) return 0;
+  if (ctx->pinned_mask) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pinned_mask); ctx->pinned_mask = nullptr; ctx->pinned_mask_cap = 0; }
+  size_t want = bytes + bytes / 2 + 4096;
+  hipError_t e = hipHostMalloc((void**)&ctx->pinned_mask, want, hipHostMallocDefault);
+  if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+  ctx->pinned_mask_cap = want;
+  return 0;
+}
+
 namespace {
 
 struct BlobLayout {
@@ -149,6 +159,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_vperm = B.add<int32_t>(S.vperm.size());
   size_t o_ef = B.add<int32_t>(S.nE);
   size_t o_et = B.add<int32_t>(S.nE);
+  size_t o_orow = B.add<int32_t>(S.off_row.size());
+  size_t o_ocol = B.add<int32_t>(S.off_col.size());
   size_t blob_bytes = (B.off + 255) & ~size_t(255);
   // numeric work space
   BlobLayout N;
@@ -163,6 +175,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_U = N.add<double>((size_t)S.U_doubles + 1);
   size_t o_chi = N.add<double>((size_t)iters + 2);
   size_t o_status = N.add<int>(4);
+  size_t o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
   size_t total = N.off + 256;
   int rc = arena_reserve(ctx, ctx->gn_arena, total);
   if (rc) return rc;
@@ -190,6 +203,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   put(o_vperm, S.vperm.data(), S.vperm.size() * 4);
   put(o_ef, ef, (size_t)S.nE * 4);
   put(o_et, et, (size_t)S.nE * 4);
+  put(o_orow, S.off_row.data(), S.off_row.size() * 4);
+  put(o_ocol, S.off_col.data(), S.off_col.size() * 4);
   char* d = ctx->gn_arena.ptr;
   HIP_TRY(ctx, hipMemcpyAsync(d, h, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
   D.fronts = (FrontDesc*)(d + o_fronts);
@@ -208,6 +223,9 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.vperm = (int32_t*)(d + o_vperm);
   D.ef = (int32_t*)(d + o_ef);
   D.et = (int32_t*)(d + o_et);
+  D.off_row = (int32_t*)(d + o_orow);
+  D.off_col = (int32_t*)(d + o_ocol);
+  D.cmask = (uint8_t*)(d + o_cmask);
   D.term = (double*)(d + o_term);
   D.Ablk = (double*)(d + o_A);
   D.bvec = (double*)(d + o_b);
@@ -218,7 +236,59 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.Ubuf = (double*)(d + o_U);
   D.chi2 = (double*)(d + o_chi);
   D.status = (int*)(d + o_status);
+  return 0;
+}
+
+// Ordering + symbolic analysis + structure upload for the edge list (ef, et), or nothing at all when the context
+// still holds them for exactly this list (g2o redoes buildStructure + cs_schol on every optimize() call,
+// SURVEY.md 3.2; within one key frame -- optimize(1), covariance estimate, optimize(5), graph_slam.cpp:392-393,
+// 315-320 -- and within one multi-robot round the list does not change).  The analysis does not look at the fixed
+// flags (they are applied numerically, prepare_pass()), so a hit is bit-identical to a miss by construction.
+int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const int32_t* et, int iters) {
+  const bool hit = ctx->sym_cache_on && ctx->sym_valid && ctx->sym_nV == nV && (int)ctx->sym_ef.size() == nE &&
+                   iters <= ctx->sym_chi_cap &&
+                   (nE == 0 || (memcmp(ctx->sym_ef.data(), ef, sizeof(int32_t) * nE) == 0 &&
+                                memcmp(ctx->sym_et.data(), et, sizeof(int32_t) * nE) == 0));
+  if (hit) {
+    ctx->sym_hits++;
+    ctx->sym.t_order = ctx->sym.t_struct = 0;
+    return 0;
+  }
+  ctx->sym_misses++;
+  ctx->sym_valid = false;
+  int rc = analyze(nV, nullptr, nE, ef, et, ctx->sym);
+  if (rc) return set_err(ctx, CGMR_E_INVALID, "graph structure rejected (edge index out of range)");
+  const int chi_cap = std::max(iters, 30);
+  rc = gn_upload(ctx, ctx->sym, ef, et, chi_cap);
+  if (rc) return rc;
+  if (ctx->sym_cache_on) {
+    ctx->sym_nV = nV;
+    ctx->sym_ef.assign(ef, ef + nE);
+    ctx->sym_et.assign(et, et + nE);
+    ctx->sym_valid = true;
+  }
+  ctx->sym_chi_cap = chi_cap;
+  return 0;
+}
+
+// Per numeric pass: the column mask (fixed vertices; vertices whose edges are all switched off when only the
+// first n_active edges take part), the status words.  ctx->vmask keeps the per-vertex flags for the caller.
+int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int n_active) {
+  const Symbolic& S = ctx->sym;
+  GnDevice& D = ctx->gn;
+  ctx->vmask.assign(S.nV, 0);
+  if (fixed) for (int v = 0; v < S.nV; v++) ctx->vmask[v] = fixed[v] ? 1 : 0;
+  if (n_active < nE) {
+    std::vector<uint8_t> live(S.nV, 0);
+    for (int k = 0; k < n_active; k++) { live[ef[k]] = 1; live[et[k]] = 1; }
+    for (int v = 0; v < S.nV; v++) if (!live[v]) ctx->vmask[v] = 1;
+  }
   HIP_TRY(ctx, hipMemsetAsync(D.status, 0, 16, ctx->stream));
+  if (S.nf == 0) return 0;
+  int rc = pinned_mask_reserve(ctx, (size_t)S.nf);
+  if (rc) return rc;
+  for (int c = 0; c < S.nf; c++) ctx->pinned_mask[c] = (char)ctx->vmask[S.perm[c]];
+  HIP_TRY(ctx, hipMemcpyAsync(D.cmask, ctx->pinned_mask, (size_t)S.nf, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
 
@@ -254,12 +324,12 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
 };
 
 // one Gauss-Newton pass on the uploaded structure: linearise + chi2 [+ assemble + factor [+ solve + update]]
-void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double* d_info, int it, bool chi_only,
+void gn_pass(cgmr_ctx* ctx, double* d_poses, const GnEdges& Ed, int it, bool chi_only,
              bool solve_and_update, bool write_l11c = false) {
   GnDevice& D = ctx->gn;
   hipStream_t st = ctx->stream;
   KTimer T{ctx};
-  T.run(0, 1, [&] { launch_linearize(st, D, d_poses, D.ef, D.et, d_meas, d_info, chi_only ? 1 : 0); });
+  T.run(0, 1, [&] { launch_linearize(st, D, d_poses, Ed, chi_only ? 1 : 0); });
   if (chi_only || D.nf == 0) {
     T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
     return;
@@ -298,13 +368,13 @@ void gn_pass(cgmr_ctx* ctx, double* d_poses, const double* d_meas, const double*
 }
 
 int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE, const int32_t* ef,
-           const int32_t* et, const double* d_meas, const double* d_info, int iters, double* chi2_out) {
+           const int32_t* et, const GnEdges& Ed, int iters, double* chi2_out) {
   double t0 = wall_s();
   Symbolic& S = ctx->sym;
-  int rc = analyze(nV, fixed, nE, ef, et, S);
-  if (rc) return set_err(ctx, CGMR_E_INVALID, "graph structure rejected (edge index out of range or self edge)");
+  int rc = prepare_structure(ctx, nV, nE, ef, et, iters);
+  if (rc) return rc;
   double t1 = wall_s();
-  rc = gn_upload(ctx, S, ef, et, iters);
+  rc = prepare_pass(ctx, fixed, nE, ef, et, Ed.n_active);
   if (rc) return rc;
   double t2 = wall_s();
   GnDevice& D = ctx->gn;
@@ -319,13 +389,13 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   if (graph_mode && !ctx->profiling && !trace_launches && iters >= 2 && st != nullptr && D.nf > 0) {
     gn_init_kernels();
     HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    gn_pass(ctx, d_poses, d_meas, d_info, 0, false, true);
+    gn_pass(ctx, d_poses, Ed, 0, false, true);
     HIP_TRY(ctx, hipStreamEndCapture(st, &graph));
     HIP_TRY(ctx, hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
     for (int it = 0; it < iters; it++) HIP_TRY(ctx, hipGraphLaunch(graph_exec, st));
-    gn_pass(ctx, d_poses, d_meas, d_info, iters, true, true);
+    gn_pass(ctx, d_poses, Ed, iters, true, true);
   } else {
-    for (int it = 0; it <= iters; it++) gn_pass(ctx, d_poses, d_meas, d_info, it, it == iters, true);
+    for (int it = 0; it <= iters; it++) gn_pass(ctx, d_poses, Ed, it, it == iters, true);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
   // read back chi2 + status
@@ -419,9 +489,9 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   const int nq = (int)q.size();
   if (cov_out && mode != 2) memset(cov_out, 0, sizeof(double) * 9 * (size_t)nK);
   Symbolic& S = ctx->sym;
-  int rc = analyze(nV, fixed.data(), nE, ef, et, S);
-  if (rc) return set_err(ctx, CGMR_E_INVALID, "graph structure rejected");
-  rc = gn_upload(ctx, S, ef, et, 1);
+  int rc = prepare_structure(ctx, nV, nE, ef, et, 1);
+  if (rc) return rc;
+  rc = prepare_pass(ctx, fixed.data(), nE, ef, et, nE);
   if (rc) return rc;
   GnDevice& D = ctx->gn;
   hipStream_t st = ctx->stream;
@@ -439,7 +509,7 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   if (rc) return rc;
   char* d = ctx->io_arena.ptr;
   std::vector<int32_t> qcol(nq);
-  for (int k = 0; k < nq; k++) qcol[k] = S.vperm[q[k]];
+  for (int k = 0; k < nq; k++) qcol[k] = ctx->vmask[q[k]] ? -1 : S.vperm[q[k]];     // fixed / inactive: zeros
   HIP_TRY(ctx, hipMemcpyAsync(d + o_p, work.data(), 24 * (size_t)nV, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d + o_m, meas, 24 * (size_t)nE, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d + o_i, info, 48 * (size_t)nE, hipMemcpyHostToDevice, st));
@@ -448,7 +518,9 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   double* dp = (double*)(d + o_p);
   // the Hessian of this iteration (linearised at the initial guess) is what computeMarginals sees [g2o-recalled];
   // for the condensed graph the iteration is completed first: the factor stays valid, the poses move on
-  gn_pass(ctx, dp, (const double*)(d + o_m), (const double*)(d + o_i), 0, false, mode == 2, /*write_l11c=*/true);
+  GnEdges Ed;
+  Ed.meas_a = (const double*)(d + o_m); Ed.info_a = (const double*)(d + o_i); Ed.nA = nE; Ed.n_active = nE;
+  gn_pass(ctx, dp, Ed, 0, false, mode == 2, /*write_l11c=*/true);
   launch_marginals(st, D, nq, (const int32_t*)(d + o_qc), m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part),
                    (double*)(d + o_G), (double*)(d + o_cov), chunk, nchunk);
   if (mode == 2)
@@ -516,6 +588,7 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (ctx->io_arena.ptr) (void)hipFree(ctx->io_arena.ptr);
   if (ctx->mt_arena.ptr) (void)hipFree(ctx->mt_arena.ptr);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_mask) (void)hipHostFree(ctx->pinned_mask);
   for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_a, ctx->ev_b})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -539,7 +612,9 @@ int cgmr_gn_optimize_dev(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* 
       (nE > 0 && (!from_idx || !to_idx || !d_meas || !d_info)))
     return set_err(ctx, CGMR_E_INVALID, "cgmr_gn_optimize: null or negative argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return gn_run(ctx, nV, d_poses, fixed, nE, from_idx, to_idx, d_meas, d_info, iters, chi2_out);
+  GnEdges Ed;
+  Ed.meas_a = d_meas; Ed.info_a = d_info; Ed.nA = nE; Ed.n_active = nE;
+  return gn_run(ctx, nV, d_poses, fixed, nE, from_idx, to_idx, Ed, iters, chi2_out);
 }
 
 int cgmr_gn_optimize(cgmr_ctx* ctx, int nV, double* poses, const uint8_t* fixed, int nE, const int32_t* from_idx,
@@ -557,8 +632,9 @@ int cgmr_gn_optimize(cgmr_ctx* ctx, int nV, double* poses, const uint8_t* fixed,
   HIP_TRY(ctx, hipMemcpyAsync(d + op, poses, bp, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d + om, meas, bm, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d + oi, info, bi, hipMemcpyHostToDevice, ctx->stream));
-  rc = gn_run(ctx, nV, (double*)(d + op), fixed, nE, from_idx, to_idx, (const double*)(d + om),
-              (const double*)(d + oi), iters, chi2_out);
+  GnEdges Ed;
+  Ed.meas_a = (const double*)(d + om); Ed.info_a = (const double*)(d + oi); Ed.nA = nE; Ed.n_active = nE;
+  rc = gn_run(ctx, nV, (double*)(d + op), fixed, nE, from_idx, to_idx, Ed, iters, chi2_out);
   if (rc == CGMR_OK || rc <= CGMR_E_CHOLESKY_BASE) {
     hipError_t e = hipMemcpyAsync(poses, d + op, bp, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -571,7 +647,8 @@ int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* f
                           int64_t out[13], int32_t* perm_out) {
   if (nV < 0 || nE < 0 || !out) return CGMR_E_INVALID;
   Symbolic S;
-  int rc = analyze(nV, fixed, nE, from_idx, to_idx, S);
+  (void)fixed;          // the solver applies the fixed flags numerically: they are not part of the analysis
+  int rc = analyze(nV, nullptr, nE, from_idx, to_idx, S);
   if (rc) return CGMR_E_INVALID;
   out[0] = S.nf; out[1] = S.nb; out[2] = (int64_t)S.fronts.size(); out[3] = (int64_t)S.level_ptr.size() - 1;
   out[4] = S.L_doubles; out[5] = S.U_doubles; out[6] = S.max_ns; out[7] = (int64_t)S.flops;
@@ -607,6 +684,19 @@ int cgmr_condense(cgmr_ctx* ctx, int nV, const double* poses, int nE, const int3
   return marginal_driver(ctx, 2, nV, poses, nullptr, nE, ef, et, meas, info, gauge, nK, query, to_out, est_out, info_out, cov_out);
 }
 
+int cgmr_set_symbolic_cache(cgmr_ctx* ctx, int on) {
+  if (!ctx) return CGMR_E_INVALID;
+  ctx->sym_cache_on = on != 0;
+  ctx->sym_valid = false;
+  return CGMR_OK;
+}
+
+int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]) {
+  if (!ctx || !out) return CGMR_E_INVALID;
+  out[0] = ctx->sym_hits; out[1] = ctx->sym_misses;
+  return CGMR_OK;
+}
+
 int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]) {
   if (!ctx || !out) return CGMR_E_INVALID;
   memcpy(out, ctx->timing, sizeof(double) * 5);
@@ -640,7 +730,8 @@ int cgmr_gn_kernel_times(const cgmr_ctx* ctx, double seconds_out[8], int64_t lau
 // Debugging aid (host only): the front table of a graph's symbolic analysis, 6 ints per front: c0, nc, ns, parent, level, nchild.
 extern "C" int cgmr_debug_fronts(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int cap, int32_t* out) {
   Symbolic S;
-  if (analyze(nV, fixed, nE, ef, et, S)) return -1;
+  (void)fixed;
+  if (analyze(nV, nullptr, nE, ef, et, S)) return -1;
   int n = (int)S.fronts.size();
   for (int f = 0; f < n && f < cap; f++) {
     const FrontDesc& F = S.fronts[f];

@@ -27,6 +27,16 @@ struct cgmr_ctx {
   cgmr::Arena mt_arena;     // matcher work space
   char* pinned = nullptr;
   size_t pinned_cap = 0;
+  char* pinned_mask = nullptr;   // staging of the per-pass column mask (own buffer: the blob staging above is shared)
+  size_t pinned_mask_cap = 0;
+  // cache of the last symbolic analysis + uploaded structure, keyed by the edge list (exact compare)
+  bool sym_cache_on = true;
+  bool sym_valid = false;
+  int sym_nV = 0;
+  int sym_chi_cap = 0;
+  std::vector<int32_t> sym_ef, sym_et;
+  int64_t sym_hits = 0, sym_misses = 0;
+  std::vector<uint8_t> vmask;    // per vertex: masked in the current pass
   cgmr::Symbolic sym;
   cgmr::GnDevice gn;
   double timing[5] = {0, 0, 0, 0, 0};

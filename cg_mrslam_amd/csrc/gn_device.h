@@ -19,6 +19,9 @@ struct GnDevice {
   WorkRec* work = nullptr;          // (front, chunk) work items of k_front_factor, level by level
   int32_t *level_fronts = nullptr, *tiles = nullptr, *apack = nullptr, *blk_slot = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;
   int32_t *ef = nullptr, *et = nullptr;
+  int32_t *off_row = nullptr, *off_col = nullptr;   // permuted row / column of every off-diagonal H block
+  uint8_t* cmask = nullptr;              // per permuted column: 1 = taken out of the system for this pass (fixed vertex, or
+                                         // all of its edges switched off), written before every numeric pass
   // numeric work space
   double *term = nullptr, *Ablk = nullptr, *bvec = nullptr, *yvec = nullptr, *xvec = nullptr, *uvec = nullptr;
   double *Lbuf = nullptr, *Ubuf = nullptr;
@@ -32,8 +35,13 @@ struct GnDevice {
   std::vector<int32_t> h_level_chrows;   // per level: rows of the factor kernel's F21 staging area (max chunk rows + rhs row)
 };
 
-void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const int32_t* ef, const int32_t* et,
-                      const double* meas, const double* info, int chi_only);
+// Numeric edge data of one pass: edges [0, nA) from (meas_a, info_a), [nA, nE) from (meas_b, info_b); edges
+// [n_active, nE) are switched off.
+struct GnEdges {
+  const double *meas_a = nullptr, *info_a = nullptr, *meas_b = nullptr, *info_b = nullptr;
+  int nA = 0, n_active = 0;
+};
+void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const GnEdges& Ed, int chi_only);
 void launch_chi2(hipStream_t st, const GnDevice& D, double* out);
 void launch_assemble(hipStream_t st, const GnDevice& D);
 void gn_init_kernels();

@@ -90,18 +90,24 @@ __device__ __forceinline__ double d_normalize_theta(double t) {
 // chi2 = e^T O e is summed per workgroup (fixed tree) into term[33 * nE + blockIdx.x]; block_chi2_sum() adds the
 // partial sums up, again in a fixed order: bit-reproducible.
 // Math: EdgeSE2::computeError / linearizeOplus / constructQuadraticForm.
-__global__ __launch_bounds__(256) void k_linearize(int nE, const double* __restrict__ poses,
+// Edges [0, nA) take their measurement / information from (meas, info), edges [nA, nE) from (meas_b, info_b): the
+// device-resident robot graph keeps the edges received from other robots in a buffer of their own.  Edges
+// [n_active, nE) are switched off for this pass (the condensed graph is built on the robot's own edges only,
+// condensed_graph_buffer.cpp:347-366): they contribute exact zeros to H, b and chi2.
+__global__ __launch_bounds__(256) void k_linearize(int nE, int nA, int n_active, const double* __restrict__ poses,
                                                    const int32_t* __restrict__ ef, const int32_t* __restrict__ et,
                                                    const double* __restrict__ meas, const double* __restrict__ info,
+                                                   const double* __restrict__ meas_b, const double* __restrict__ info_b,
                                                    double* __restrict__ term, int chi_only) {
   __shared__ double s_chi[4];
   const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = k0 < nE;
-  const int k = live ? k0 : nE - 1;                      // idle lanes of the last workgroup shadow the last edge
+  const bool live = k0 < n_active;
+  const int k = k0 < nE ? k0 : nE - 1;                   // idle lanes of the last workgroup shadow the last edge
   int i = ef[k], j = et[k];
   double xi0 = poses[3 * i], xi1 = poses[3 * i + 1], xi2 = poses[3 * i + 2];
   double xj0 = poses[3 * j], xj1 = poses[3 * j + 1], xj2 = poses[3 * j + 2];
-  double z0 = meas[3 * k], z1 = meas[3 * k + 1], z2 = meas[3 * k + 2];
+  const double* zp = k < nA ? meas + 3 * (size_t)k : meas_b + 3 * (size_t)(k - nA);
+  double z0 = zp[0], z1 = zp[1], z2 = zp[2];
   double c = cos(xi2), s = sin(xi2);
   double dx = xj0 - xi0, dy = xj1 - xi1;
   double rx = c * dx + s * dy, ry = -s * dx + c * dy;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, const double* __restr
   double cz = cos(z2), sz = sin(z2);
   double tx = rx - z0, ty = ry - z1;
   double e[3] = {cz * tx + sz * ty, -sz * tx + cz * ty, d_normalize_theta(rth - z2)};
-  const double* u = info + 6 * (size_t)k;
+  const double* u = k < nA ? info + 6 * (size_t)k : info_b + 6 * (size_t)(k - nA);
   double O[9] = {u[0], u[1], u[2], u[1], u[3], u[4], u[2], u[4], u[5]};
   double Oe[3];
 #pragma unroll
@@ -123,7 +129,12 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, const double* __restr
     __syncthreads();
     if (threadIdx.x == 0) term[33 * E + blockIdx.x] = (s_chi[0] + s_chi[1]) + (s_chi[2] + s_chi[3]);
   }
-  if (chi_only || !live) return;
+  if (chi_only || k0 >= nE) return;
+  if (!live) {                                           // switched-off edge: exact zeros into the assembly
+#pragma unroll
+    for (int q = 0; q < 33; q++) term[(size_t)q * E + k] = 0.0;
+    return;
+  }
   double A[9] = {-c, -s, -s * dx + c * dy, s, -c, -c * dx - s * dy, 0, 0, -1};
   double B[9] = {c, s, 0, -s, c, 0, 0, 0, 1};
   double Ji[9], Jj[9];
@@ -166,9 +177,16 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, const double* __restr
 // list of contributing edge terms in a fixed order (deterministic sums).
 // The last workgroup of the grid adds up the chi2 partial sums of the linearisation instead (saves a launch per iteration).
 __device__ __forceinline__ void block_chi2_sum(int nP, const double* __restrict__ part, double* __restrict__ out);
+// Fixed vertices (g2o setFixed) are part of the *structure* -- the symbolic analysis depends on the edge list
+// only and is reused whatever is fixed -- and are taken out of the system numerically: cmask[c] != 0 turns row /
+// column c of H into the identity and its right-hand side into zero, so its dx is exactly zero and nothing
+// couples to it.  The same mask removes vertices all of whose edges are switched off for this pass.
 __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const int32_t* __restrict__ asm_ptr,
                                                   const int32_t* __restrict__ asm_src,
                                                   const int32_t* __restrict__ blk_slot,
+                                                  const uint8_t* __restrict__ cmask,
+                                                  const int32_t* __restrict__ off_row,
+                                                  const int32_t* __restrict__ off_col,
                                                   const double* __restrict__ term, double* __restrict__ Ablk,
                                                   double* __restrict__ bvec, double* __restrict__ chi_out,
                                                   const int* __restrict__ status) {
@@ -189,6 +207,8 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
       int comp = code == 0 ? el : code == 1 ? 18 + el : code == 2 ? 9 + el : 9 + elT;
       acc += term[(size_t)comp * E + edge];
     }
+    if (blk < nf) { if (cmask[blk]) acc = (el % 4 == 0) ? 1.0 : 0.0; }
+    else if (cmask[off_row[blk - nf]] | cmask[off_col[blk - nf]]) acc = 0.0;
     Ablk[(size_t)blk_slot[blk] * 9 + el] = acc;      // stored in the order the owning front assembles its blocks
     return;
   }
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
       int edge = src >> 2, code = src & 3;
       acc += term[(size_t)((code == 0 ? 27 : 30) + r) * E + edge];
     }
-    bvec[t] = acc;
+    bvec[t] = cmask[v] ? 0.0 : acc;
   }
 }
 
@@ -1044,6 +1064,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__
 
 // poses (+)= dx  (VertexSE2::oplusImpl: translation added in the global frame, angle wrapped)
 __global__ __launch_bounds__(256) void k_update_poses(int nV, const int32_t* __restrict__ vperm,
+                                                      const uint8_t* __restrict__ cmask,
                                                       const double* __restrict__ xvec, double* __restrict__ poses,
                                                       int* __restrict__ status) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1054,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_update_poses(int nV, const int32_t* __r
   if (v == 0) status[1] = status[1] + 1;
   if (failed != 0) return;
   int c = vperm[v];
-  if (c < 0) return;
+  if (c < 0 || cmask[c]) return;                       // not in the system / fixed: the estimate is not touched
   poses[3 * v] += xvec[3 * c];
   poses[3 * v + 1] += xvec[3 * c + 1];
   poses[3 * v + 2] = d_normalize_theta(poses[3 * v + 2] + xvec[3 * c + 2]);
@@ -1062,11 +1083,10 @@ __global__ __launch_bounds__(256) void k_update_poses(int nV, const int32_t* __r
 
 // ------------------------------------------------------------------------------ launchers
 
-void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const int32_t* ef, const int32_t* et,
-                      const double* meas, const double* info, int chi_only) {
+void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const GnEdges& Ed, int chi_only) {
   if (D.nE == 0) return;
-  hipLaunchKernelGGL(k_linearize, dim3((D.nE + 255) / 256), dim3(256), 0, st, D.nE, poses, ef, et, meas, info,
-                     D.term, chi_only);
+  hipLaunchKernelGGL(k_linearize, dim3((D.nE + 255) / 256), dim3(256), 0, st, D.nE, Ed.nA, Ed.n_active, poses, D.ef, D.et,
+                     Ed.meas_a, Ed.info_a, Ed.meas_b, Ed.info_b, D.term, chi_only);
 }
 
 void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
@@ -1076,7 +1096,7 @@ void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
 void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
   hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256 + 1), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_slot, D.term, D.Ablk, D.bvec, D.chi2, D.status);
+                     D.asm_src, D.blk_slot, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.bvec, D.chi2, D.status);
 }
 
 // one-time kernel attributes (dynamic LDS above 64 KB): once per HIP device of the process (the attribute belongs to
@@ -1126,7 +1146,7 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
 }
 
 void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
-  hipLaunchKernelGGL(k_update_poses, dim3((D.nV + 255) / 256), dim3(256), 0, st, D.nV, D.vperm, D.xvec, poses,
+  hipLaunchKernelGGL(k_update_poses, dim3((D.nV + 255) / 256), dim3(256), 0, st, D.nV, D.vperm, D.cmask, D.xvec, poses,
                      D.status);
 }
 

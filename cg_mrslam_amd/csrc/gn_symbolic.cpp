@@ -395,7 +395,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   for (int k = 0; k < nE; k++) { active[ef[k]] = 1; active[et[k]] = 1; }
   S.hidx.assign(nV, -1);
   int nf = 0;
-  for (int v = 0; v < nV; v++) if (active[v] && !fixed[v]) S.hidx[v] = nf++;
+  for (int v = 0; v < nV; v++) if (active[v] && !(fixed && fixed[v])) S.hidx[v] = nf++;
   S.nf = nf;
   S.vperm.assign(nV, -1);
   if (nf == 0) { S.level_ptr.assign(1, 0); return 0; }

@@ -104,6 +104,9 @@ struct Symbolic {
 };
 
 // Builds everything above.  Returns 0, or a negative error (-1 bad index).
+// `fixed` == nullptr: every vertex that has an edge gets a column (the solver's mode: fixed vertices are masked
+// numerically, so the analysis depends on the edge list only and is cached across calls with different fixed
+// sets); otherwise fixed vertices are eliminated structurally.
 int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S);
 
 }  // namespace cgmr

@@ -224,17 +224,17 @@ int cgmr_subsample(int n, const double* pts, double res, double* out) {
   return m;
 }
 
-int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts, int n_qry,
-                      const double* qry_pts, int n_regions, const float* regions, double step_x, double step_y,
-                      double theta_res, double max_score, double dx, double dy, double dth,
-                      cgmr_match_result* results_out, int cap, int* n_out) {
-  if (!ctx) return CGMR_E_INVALID;
-  if (!cfg || n_ref < 0 || n_qry < 0 || n_regions < 0 || cap < 0 || !n_out || (n_ref > 0 && !ref_pts) ||
-      (n_qry > 0 && !qry_pts) || (n_regions > 0 && !regions) || (cap > 0 && !results_out) || !(theta_res > 0) ||
+// CharGrid::greedySearch on a grid rasterised from ref_pts: every result of the <= 4 thread maps, ascending score
+static int greedy_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts, int n_qry,
+                       const double* qry_pts, int n_regions, const float* regions, double step_x, double step_y,
+                       double theta_res, double max_score, double dx, double dy, double dth,
+                       std::vector<cgmr_match_result>& res) {
+  res.clear();
+  if (!cfg || n_ref < 0 || n_qry < 0 || n_regions < 0 || (n_ref > 0 && !ref_pts) ||
+      (n_qry > 0 && !qry_pts) || (n_regions > 0 && !regions) || !(theta_res > 0) ||
       !(dx > 0) || !(dy > 0) || !(dth > 0))
-    return set_err(ctx, CGMR_E_INVALID, "cgmr_match_greedy: bad argument");
+    return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
   if (n_ref > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d reference points", kMatchMaxRef);
-  *n_out = 0;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MatchParams P;
   std::vector<uint8_t> kern;
@@ -333,7 +333,6 @@ int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, 
   if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", err);
   // decode: thread maps in thread order, each in (ix, iy, ith) order; then a stable sort on the score
   const unsigned long long* bins = (const unsigned long long*)h;
-  std::vector<cgmr_match_result> res;
   for (int th = 0; th < num_threads; th++)
     for (size_t q = 0; q < nbins; q++) {
       unsigned long long key = bins[(size_t)th * nbins + q];
@@ -357,6 +356,20 @@ int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, 
       res.push_back({(double)wx, (double)wy, theta[D.th_off + ti], (double)sc});
     }
   std::stable_sort(res.begin(), res.end(), [](const cgmr_match_result& a, const cgmr_match_result& b) { return a.score < b.score; });
+  return CGMR_OK;
+}
+
+int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts, int n_qry,
+                      const double* qry_pts, int n_regions, const float* regions, double step_x, double step_y,
+                      double theta_res, double max_score, double dx, double dy, double dth,
+                      cgmr_match_result* results_out, int cap, int* n_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (cap < 0 || !n_out || (cap > 0 && !results_out)) return set_err(ctx, CGMR_E_INVALID, "cgmr_match_greedy: bad argument");
+  *n_out = 0;
+  std::vector<cgmr_match_result> res;
+  int rc = greedy_core(ctx, cfg, n_ref, ref_pts, n_qry, qry_pts, n_regions, regions, step_x, step_y, theta_res, max_score,
+                       dx, dy, dth, res);
+  if (rc) return rc;
   *n_out = (int)res.size();
   for (int k = 0; k < (int)res.size() && k < cap; k++) results_out[k] = res[k];
   return CGMR_OK;
@@ -406,6 +419,243 @@ int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, con
   if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", err);
   *score_out = out.score;
   if (n_nonmatched_out) *n_nonmatched_out = out.nnm;
+  return CGMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The ScanMatcher member functions above the searches (src/matcher/scan_matcher.cpp:78-110, 112-189, 191-294, 358-505)
+// and CharGrid::hierarchicalSearch (src/matcher/chargrid.cpp:310-413): vertex sets arrive as flat scan sets, the
+// region / transform bookkeeping is host code with the reference's arithmetic (Vector3f regions: float; SE2
+// products: double with libm sin / cos), every search runs on the GPU.
+namespace {
+
+struct Se2 { double x, y, t; };
+inline double norm_theta(double t) {
+  const double pi = 3.14159265358979323846;
+  if (t >= -pi && t < pi) return t;
+  return t - 2 * pi * std::floor((t + pi) / (2 * pi));
+}
+inline Se2 se2_mul(const Se2& a, const Se2& b) {              // g2o SE2::operator* [g2o-recalled]
+  const double c = std::cos(a.t), s = std::sin(a.t);
+  return {a.x + (c * b.x - s * b.y), a.y + (s * b.x + c * b.y), norm_theta(a.t + b.t)};
+}
+inline Se2 se2_inv(const Se2& a) {
+  const double c = std::cos(a.t), s = std::sin(a.t);
+  return {-(c * a.x + s * a.y), -(-s * a.x + c * a.y), -a.t};
+}
+inline Se2 se2_of(const double* p) { return {p[0], p[1], p[2]}; }
+
+// ScanMatcher::applyTransfToScan (scan_matcher.cpp:78-87), appended to out
+void apply_transf(const Se2& T, const std::vector<double>& pts, std::vector<double>& out) {
+  const double c = std::cos(T.t), s = std::sin(T.t);
+  for (size_t i = 0; i + 1 < pts.size(); i += 2) {
+    out.push_back((c * pts[i] - s * pts[i + 1]) + T.x);
+    out.push_back((s * pts[i] + c * pts[i + 1]) + T.y);
+  }
+}
+
+std::vector<double> cartesian_of(const cgmr_matcher_config* cfg, const float* ranges) {
+  std::vector<double> v(2 * (size_t)cfg->n_beams);
+  int n = cgmr_scan_cartesian(cfg->n_beams, ranges, cfg->angle_min, cfg->angle_inc, cfg->max_range, cfg->min_range, v.data());
+  v.resize(2 * (size_t)std::max(n, 0));
+  return v;
+}
+
+bool scan_set_ok(const cgmr_scan_set* S) {
+  return S && S->n_scans >= 1 && S->ranges && S->poses_xyt && S->ref_index >= 0 && S->ref_index < S->n_scans;
+}
+
+// ScanMatcher::transformPointsFromVSet (scan_matcher.cpp:89-110): every scan of the set in the frame of the reference
+// vertex, `pre` applied on the left of every transform (verifyMatching moves set 2 by trel12 first)
+void points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* S, const Se2* pre, std::vector<double>& out) {
+  const Se2 lp = se2_of(cfg->laser_pose);
+  const Se2 ref = se2_of(S->poses_xyt + 3 * (size_t)S->ref_index);
+  for (int k = 0; k < S->n_scans; k++) {
+    std::vector<double> v = cartesian_of(cfg, S->ranges + (size_t)k * cfg->n_beams);
+    Se2 T = lp;
+    if (k != S->ref_index) T = se2_mul(se2_mul(se2_inv(ref), se2_of(S->poses_xyt + 3 * (size_t)k)), lp);
+    if (pre) T = (k == S->ref_index) ? se2_mul(*pre, lp)
+                                     : se2_mul(se2_mul(*pre, se2_mul(se2_inv(ref), se2_of(S->poses_xyt + 3 * (size_t)k))), lp);
+    apply_transf(T, v, out);
+  }
+}
+
+std::vector<double> subsample_of(const std::vector<double>& pts, double res) {
+  std::vector<double> out(pts.size());
+  int n = cgmr_subsample((int)(pts.size() / 2), pts.data(), res, out.data());
+  out.resize(2 * (size_t)std::max(n, 0));
+  return out;
+}
+
+// CharGrid::hierarchicalSearch (chargrid.cpp:310-344, 376-400): levels n-1 .. 0, step 2^i cells, theta step
+// max(2^i / 2, 1) * thetaRes, bins 2^i * (dx, dy, dth); every result of a level seeds a region of half a bin around
+// it for the next one; the last level only runs if the one before found something.
+int hierarchical_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref, int n_qry, const double* qry,
+                      int n_regions, const float* regions, double theta_res, double max_score, double dx, double dy,
+                      double dth, int n_levels, std::vector<cgmr_match_result>& out) {
+  out.clear();
+  std::vector<float> cur(regions, regions + 6 * (size_t)n_regions);
+  const float res_f = (float)cfg->resolution;
+  for (int lv = 0; lv < n_levels; lv++) {
+    const int i = n_levels - 1 - lv;
+    const int m = 1 << i;
+    const int mtheta = (m / 2 < 1) ? m : m / 2;
+    const bool last = lv == n_levels - 1;
+    if (last && out.empty()) break;
+    const float stepf = (float)m * res_f;
+    int rc = greedy_core(ctx, cfg, n_ref, ref, n_qry, qry, (int)(cur.size() / 6), cur.data(), (double)stepf, (double)stepf,
+                         mtheta * theta_res, max_score, dx * m, dy * m, dth * m, out);
+    if (rc) return rc;
+    if (last || out.empty()) break;
+    const double half[3] = {dx * m * .5, dy * m * .5, dth * m * .5};
+    cur.resize(6 * out.size());
+    for (size_t k = 0; k < out.size(); k++) {
+      const double c[3] = {out[k].x, out[k].y, out[k].theta};
+      for (int a = 0; a < 3; a++) {
+        cur[6 * k + a] = (float)(-half[a] + c[a]);
+        cur[6 * k + 3 + a] = (float)(half[a] + c[a]);
+      }
+    }
+  }
+  return CGMR_OK;
+}
+
+}  // namespace
+
+int cgmr_transform_points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* vset, double* pts_out, int cap) {
+  if (!cfg || !scan_set_ok(vset) || cap < 0 || (cap > 0 && !pts_out)) return CGMR_E_INVALID;
+  std::vector<double> pts;
+  points_from_vset(cfg, vset, nullptr, pts);
+  const int n = (int)(pts.size() / 2);
+  if (n > cap) return CGMR_E_INVALID;
+  if (n) memcpy(pts_out, pts.data(), sizeof(double) * pts.size());
+  return n;
+}
+
+int cgmr_match_hierarchical(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts, int n_qry,
+                            const double* qry_pts, int n_regions, const float* regions, double theta_res, double max_score,
+                            double dx, double dy, double dth, int n_levels, cgmr_match_result* results_out, int cap,
+                            int* n_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (n_levels < 1 || n_levels > 16 || cap < 0 || !n_out || (cap > 0 && !results_out) || n_regions < 0 || (n_regions > 0 && !regions))
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_match_hierarchical: bad argument");
+  *n_out = 0;
+  std::vector<cgmr_match_result> res;
+  int rc = hierarchical_core(ctx, cfg, n_ref, ref_pts, n_qry, qry_pts, n_regions, regions, theta_res, max_score, dx, dy, dth,
+                             n_levels, res);
+  if (rc) return rc;
+  *n_out = (int)res.size();
+  for (int k = 0; k < (int)res.size() && k < cap; k++) results_out[k] = res[k];
+  return CGMR_OK;
+}
+
+int cgmr_close_scan_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* vset,
+                             const float* cur_ranges, const double cur_pose_xyt[3], double max_score, double trel_out[3],
+                             int* found_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || !scan_set_ok(vset) || !cur_ranges || !cur_pose_xyt || !trel_out || !found_out)
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_close_scan_matching: bad argument");
+  *found_out = 0;
+  trel_out[0] = trel_out[1] = trel_out[2] = 0;
+  std::vector<double> ref;
+  points_from_vset(cfg, vset, nullptr, ref);                                       // scan_matcher.cpp:119-127
+  std::vector<double> qry;
+  apply_transf(se2_of(cfg->laser_pose), subsample_of(cartesian_of(cfg, cur_ranges), cfg->subsample_res), qry);   // :129-136
+  const Se2 g = se2_mul(se2_inv(se2_of(vset->poses_xyt + 3 * (size_t)vset->ref_index)), se2_of(cur_pose_xyt));
+  const float region[6] = {(float)(-cfg->win_x + g.x), (float)(-cfg->win_y + g.y), (float)(-cfg->win_theta + g.t),
+                           (float)(cfg->win_x + g.x),  (float)(cfg->win_y + g.y),  (float)(cfg->win_theta + g.t)};
+  const double step = (double)(float)cfg->resolution;
+  std::vector<cgmr_match_result> res;
+  int rc = greedy_core(ctx, cfg, (int)(ref.size() / 2), ref.data(), (int)(qry.size() / 2), qry.data(), 1, region, step, step,
+                       cfg->theta_res, max_score, cfg->bin_x, cfg->bin_y, cfg->bin_theta, res);
+  if (rc) return rc;
+  if (!res.empty()) { *found_out = 1; trel_out[0] = res[0].x; trel_out[1] = res[0].y; trel_out[2] = res[0].theta; }
+  return CGMR_OK;
+}
+
+int cgmr_scan_matching_lc(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
+                          const cgmr_scan_set* cur_set, double max_score, double* trel_out, int* n_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || !scan_set_ok(ref_set) || !scan_set_ok(cur_set) || !trel_out || !n_out)
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_scan_matching_lc: bad argument");
+  *n_out = 0;
+  std::vector<double> ref, cur;
+  points_from_vset(cfg, ref_set, nullptr, ref);
+  points_from_vset(cfg, cur_set, nullptr, cur);
+  std::vector<double> qry = subsample_of(cur, 0.1);                                // scan_matcher.cpp:216-217
+  const Se2 refp = se2_of(ref_set->poses_xyt + 3 * (size_t)ref_set->ref_index);
+  std::vector<float> regions, regionspi;                                           // :219-256
+  for (int k = 0; k < ref_set->n_scans; k++) {
+    Se2 rel = {0, 0, 0};
+    if (k != ref_set->ref_index) rel = se2_mul(se2_inv(refp), se2_of(ref_set->poses_xyt + 3 * (size_t)k));
+    const float lo[3] = {(float)(-.5 + rel.x), (float)(-1.5 + rel.y), (float)(-0.8 + rel.t)};
+    const float hi[3] = {(float)(.5 + rel.x), (float)(1.5 + rel.y), (float)(0.8 + rel.t)};
+    const float pi_f = (float)3.14159265358979323846;                              // Vector3f += M_PI: float arithmetic
+    regions.insert(regions.end(), {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]});
+    regionspi.insert(regionspi.end(), {lo[0], lo[1], lo[2] + pi_f, hi[0], hi[1], hi[2] + pi_f});
+  }
+  const double theta_res = 0.025, dx = 0.5, dy = 0.5, dth = 0.2;                   // :258-263
+  const double step = (double)(float)cfg->resolution;
+  struct Key { int a, b, c; bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); } };
+  std::vector<std::pair<Key, cgmr_match_result>> merged;                           // addToPrunedMap, chargrid.cpp:36-46
+  for (const std::vector<float>* regs : {&regions, &regionspi}) {
+    std::vector<cgmr_match_result> res;
+    int rc = greedy_core(ctx, cfg, (int)(ref.size() / 2), ref.data(), (int)(qry.size() / 2), qry.data(), (int)(regs->size() / 6),
+                         regs->data(), step, step, theta_res, max_score, dx, dy, dth, res);
+    if (rc) return rc;
+    if (res.empty()) continue;
+    cgmr_match_result best = res[0];
+    best.theta = norm_theta(best.theta);
+    const Key key = {(int)(best.x / dx), (int)(best.y / dy), (int)(best.theta / dth)};
+    bool seen = false;
+    for (auto& kv : merged)
+      if (!(kv.first < key) && !(key < kv.first)) { seen = true; if (kv.second.score > best.score) kv.second = best; }
+    if (!seen) merged.emplace_back(key, best);
+  }
+  std::sort(merged.begin(), merged.end(), [](const std::pair<Key, cgmr_match_result>& a, const std::pair<Key, cgmr_match_result>& b) { return a.first < b.first; });
+  for (size_t k = 0; k < merged.size(); k++) {
+    trel_out[3 * k] = merged[k].second.x; trel_out[3 * k + 1] = merged[k].second.y; trel_out[3 * k + 2] = merged[k].second.theta;
+  }
+  *n_out = (int)merged.size();
+  return CGMR_OK;
+}
+
+int cgmr_global_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
+                         const cgmr_scan_set* cur_set, double max_score, double trel_out[3], int* found_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || !scan_set_ok(ref_set) || !scan_set_ok(cur_set) || !trel_out || !found_out)
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_global_matching: bad argument");
+  *found_out = 0;
+  trel_out[0] = trel_out[1] = trel_out[2] = 0;
+  std::vector<double> ref, cur;
+  points_from_vset(cfg, ref_set, nullptr, ref);
+  points_from_vset(cfg, cur_set, nullptr, cur);
+  std::vector<double> qry = subsample_of(cur, 0.1);
+  const float pi_f = (float)3.14159265358979323846;
+  const float region[6] = {-10.f, -5.f, -pi_f, 10.f, 5.f, pi_f};                   // scan_matcher.cpp:383-391
+  std::vector<cgmr_match_result> res;
+  int rc = hierarchical_core(ctx, cfg, (int)(ref.size() / 2), ref.data(), (int)(qry.size() / 2), qry.data(), 1, region, 0.025,
+                             max_score, 0.5, 0.5, 0.2, 4, res);
+  if (rc) return rc;
+  if (!res.empty()) { *found_out = 1; trel_out[0] = res[0].x; trel_out[1] = res[0].y; trel_out[2] = res[0].theta; }
+  return CGMR_OK;
+}
+
+int cgmr_verify_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* set1, const cgmr_scan_set* set2,
+                         const double trel12[3], double* score_out, int* accepted_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || !scan_set_ok(set1) || !scan_set_ok(set2) || !trel12 || !score_out)
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_verify_matching: bad argument");
+  const Se2 t12 = se2_of(trel12);
+  std::vector<double> pts2, pts1;
+  points_from_vset(cfg, set2, &t12, pts2);                                         // scan_matcher.cpp:441-458
+  points_from_vset(cfg, set1, nullptr, pts1);
+  const float lower[2] = {(float)(-.3 + trel12[0]), (float)(-.3 + trel12[1])};     // :486-489
+  const float upper[2] = {(float)(.3 + trel12[0]), (float)(.3 + trel12[1])};
+  int rc = cgmr_match_verify(ctx, cfg, (int)(pts2.size() / 2), pts2.data(), (int)(pts1.size() / 2), pts1.data(), 0.3, lower,
+                             upper, score_out, nullptr);
+  if (rc) return rc;
+  if (accepted_out) *accepted_out = (*score_out <= 40.0) ? 1 : 0;                  // :497-504
   return CGMR_OK;
 }
 

@@ -80,8 +80,19 @@ int cgmr_gn_optimize_dev(cgmr_ctx* ctx, int nV, double* d_poses_xyt, const uint8
                          const int32_t* from_idx, const int32_t* to_idx, const double* d_meas_xyt,
                          const double* d_info_upper, int iters, double* chi2_out);
 
+/* The ordering + symbolic analysis + structure upload of the last analysed edge list stay on the context and are
+ * reused by every later call (cgmr_gn_optimize*, cgmr_marginals, cgmr_covariance_estimate, cgmr_condense*) whose
+ * (nV, from_idx, to_idx) are exactly the same -- the fixed flags are applied numerically and do not enter the
+ * analysis, so the pre-solve, the covariance estimate and the optimize(n) of one key frame
+ * (src/slam/graph_slam.cpp:392-393, 315-320; src/srslam.cpp:211) share one analysis.  Results are bit-identical
+ * with the cache on or off.  on = 0 switches the reuse off (every call analyses, as g2o does); default on.
+ * cgmr_symbolic_cache_stats: out[0] = calls served from the cache, out[1] = calls that analysed.        */
+int cgmr_set_symbolic_cache(cgmr_ctx* ctx, int on);
+int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]);
+
 /* Host-only: run the ordering / symbolic analysis and report its shape (no GPU needed).
- * out[0]=free poses  [1]=off-diagonal H blocks  [2]=fronts  [3]=tree levels
+ * out[0]=poses in the system (every vertex with an edge; `fixed` is ignored: fixed vertices are masked numerically)
+ * [1]=off-diagonal H blocks  [2]=fronts  [3]=tree levels
  * [4]=doubles in L   [5]=doubles in update matrices  [6]=max border (poses)
  * [7]=factor flops   [8]=ordering microseconds  [9]=structure microseconds
  * [10]=max children of a front  [11]=max children of a front with 1..32 border poses

@@ -212,3 +212,29 @@ def test_wide_fronts_match_oracle(height):
     out = subprocess.run([sys.executable, "-c", _WIDE_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "levels" in out.stdout
+
+
+def test_symbolic_cache_is_bit_identical_and_ignores_the_fixed_set(ctx, oracle):
+    """The analysis depends on the edge list only: optimize() with another fixed set, the covariance estimate and a
+    second optimize() on the same edges are served from the cache, and a cached call returns exactly the bits of an
+    analysing call."""
+    g = synth.make_pose_graph(1500, 5000, seed=21)
+    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+    ctx.set_symbolic_cache(False)
+    rc0, p0, chi0 = ctx.gn_optimize(*a, 4)
+    ctx.set_symbolic_cache(True)
+    s0 = ctx.symbolic_cache_stats()
+    rc1, p1, chi1 = ctx.gn_optimize(*a, 4)               # analyses (the switch dropped the cached structure)
+    rc2, p2, chi2 = ctx.gn_optimize(*a, 4)               # cached
+    fixed2 = np.zeros_like(g["fixed"]); fixed2[700] = 1
+    rc3, p3, chi3 = ctx.gn_optimize(g["poses"], fixed2, *a[2:], 4)   # other gauge, same edges: cached
+    cov = ctx.covariance_estimate(p2, *a[2:], 1499, np.array([3, 700, 1200], dtype=np.int32))
+    s1 = ctx.symbolic_cache_stats()
+    assert s1["misses"] - s0["misses"] == 1 and s1["hits"] - s0["hits"] == 3
+    assert rc0 == rc1 == rc2 == rc3 == 0
+    assert np.array_equal(p0, p1) and np.array_equal(p1, p2) and np.array_equal(chi0, chi2)
+    st, po, chio, _ = oracle.gn_optimize(g["poses"], fixed2, *a[2:], 4)
+    assert st == 0 and abs(chi3[-1] - chio[-1]) <= 1e-8 * chio[-1] and np.abs(p3 - po).max() < 1e-6
+    assert np.array_equal(p3[700], g["poses"][700])       # the fixed vertex is not touched
+    st, covo = oracle.covariance_estimate(p2, *a[2:], 1499, np.array([3, 700, 1200], dtype=np.int32))
+    assert st == 0 and np.abs(cov - covo).max() <= 1e-6 * np.abs(covo).max()
