@@ -1,28 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X (contract: see the task statement).
 
-Workload (BASELINE.json configs[1], "C2"): the synthetic 10k-vertex / 40k-edge SE2 pose graph of
-SURVEY.md section 8(d).  One *step* = one ``GraphSLAM::optimize(10)`` call (src/slam/graph_slam.cpp:561-575)
-from the odometry initial guess: host ordering + symbolic analysis (g2o redoes both on every optimize()
-call, so they are inside the timed region here as well), upload of the structure, 10 Gauss-Newton
-iterations on the GPU, chi2 read-back.  Numeric inputs (poses, measurements, information matrices) are
-resident in HBM before the timed region starts.  value = GN iterations / second over all ranks.
+Workload (BASELINE.json configs[1], "C2"): the synthetic 10k-vertex / 40k-edge SE2 pose graph of SURVEY.md section
+8(d).  One *step* = one ``GraphSLAM::optimize(10)`` call (src/slam/graph_slam.cpp:561-575) from the odometry initial
+guess: host ordering + symbolic analysis (g2o redoes both on every optimize() call, so in the headline they are inside
+the timed region here as well: the analysis cache is switched OFF for it), upload of the structure, 10 Gauss-Newton
+iterations on the GPU, chi2 read-back.  Numeric inputs (poses, measurements, information matrices) are resident in HBM
+before the timed region starts.  value = GN iterations / second over all ranks.  ``warm`` reports the same step with the
+analysis cache on (what a key frame's second and third solve on an unchanged graph cost).
 
-Multi-GPU (one process per GPU, torch.distributed / RCCL): every rank owns one robot's sub-graph (a C2
-graph with its own seed) -- the path shards by robot with no data-path collective inside optimize(); weak
-scaling.  For N > 1 one inter-robot round (condensed graphs for every peer + the RCCL all-gather of the
-44-byte/edge payload) is timed after the headline region and reported under ``exchange``.
-The second half of BASELINE.json's metric, scan-match pairs/s (config C3), is measured on rank 0 after the
-timed region and reported under ``matcher``.
+Multi-GPU (``--gpus N``: N ranks, one process per GPU; spawned here when the driver has not already done so): every rank
+owns one robot's sub-graph (a C2 graph with its own seed) -- the path shards by robot with no data-path collective
+inside optimize(); weak scaling.  For N > 1 the ``exchange`` leg then runs BASELINE.json's C5 protocol: N robots x 5000
+vertices grown 50 at a time, every round optimize(5) -> condensed graphs for every peer that asked -> ONE RCCL
+all-gather of the 44-byte/edge wire buffers on a side stream (overlapping the next round's solve) -> newest edge set per
+peer replaces the old one (cg_mrslam_amd/mrslam.py).
+The second half of BASELINE.json's metric, scan-match pairs/s (config C3: 10^6 distinct pairs resident in HBM), is
+measured on rank 0 after the timed region and reported under ``matcher``.
 
-Extra objects on the JSON line: ``roofline`` for the dominant kernel (k_front_factor, timed with HIP events
-on the context's stream) and ``cpu_baseline`` (the single-thread CPU oracle on rank 0, N=1 only).
+Extra objects on the JSON line: ``roofline`` for the dominant kernel (timed with HIP events on the context's stream) and
+``cpu_baseline`` (the CPU oracle on rank 0, N=1 only: one thread, and all host cores with the count stated).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -65,104 +70,252 @@ def parse():
     ap.add_argument("--vertices", type=int, default=10000)
     ap.add_argument("--edges", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--match-pairs", type=int, default=32768, help="scan pairs for the matcher leg (0 = skip)")
+    ap.add_argument("--match-pairs", type=int, default=1000000, help="distinct scan pairs of the matcher leg (0 = skip)")
+    ap.add_argument("--c5-vertices", type=int, default=5000, help="vertices per robot of the exchange leg (N > 1)")
+    ap.add_argument("--c5-edges", type=int, default=20000)
+    ap.add_argument("--c5-chunk", type=int, default=50, help="new vertices per round")
+    ap.add_argument("--c5-rounds", type=int, default=0, help="rounds to run (0 = all: vertices / chunk)")
     return ap.parse_args()
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_spawn(args):
+    """``--gpus N`` without a rank environment: start N ranks of this script (one per GPU) and wait for them."""
+    have_env = "RANK" in os.environ or "WORLD_SIZE" in os.environ
+    if have_env:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                             f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ...) or drop the environment")
+        return
+    if args.gpus <= 1:
+        return
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in alive:                      # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+# ----------------------------------------------------------------------------------------------- matcher leg (C3)
 def matcher_leg(ctx, dev, args, with_cpu):
-    """C3: batched closeScanMatching on synthetic 1081-beam scan pairs resident in HBM."""
+    """C3: batched closeScanMatching on synthetic 1081-beam scan pairs resident in HBM, all pairs distinct.  The first
+    4096 are the numpy recipe's pairs (tests/golden/match_close4096.npz pins their results), the rest come from the
+    same recipe evaluated on the GPU."""
     import torch
     from cg_mrslam_amd import synth
     from cg_mrslam_amd.matcher import ScanMatcher
-    base = min(4096, max(256, args.match_pairs))          # distinct synthetic pairs (tiled up to --match-pairs)
+    P = int(args.match_pairs)
+    base = min(4096, P)
     sp = synth.make_scan_pairs(base, seed=4242)
-    P = max(base, (args.match_pairs // base) * base)
-    rep = P // base
-    d_ref = torch.tensor(sp["ranges_ref"], device=dev).repeat(rep, 1).contiguous()
-    d_qry = torch.tensor(sp["ranges_qry"], device=dev).repeat(rep, 1).contiguous()
-    d_g = torch.tensor(sp["guess"], dtype=torch.float64, device=dev).repeat(rep, 1).contiguous()
+    d_ref = torch.empty((P, sp["n_beams"]), dtype=torch.float32, device=dev)
+    d_qry = torch.empty((P, sp["n_beams"]), dtype=torch.float32, device=dev)
+    d_g = torch.empty((P, 3), dtype=torch.float64, device=dev)
+    true_rel = torch.empty((P, 3), dtype=torch.float64, device=dev)
+    d_ref[:base] = torch.tensor(sp["ranges_ref"], device=dev)
+    d_qry[:base] = torch.tensor(sp["ranges_qry"], device=dev)
+    d_g[:base] = torch.tensor(sp["guess"], dtype=torch.float64, device=dev)
+    true_rel[:base] = torch.tensor(sp["true_rel"], dtype=torch.float64, device=dev)
+    if P > base:
+        gen = synth.make_scan_pairs_device(P - base, 990001, dev)
+        d_ref[base:], d_qry[base:], d_g[base:], true_rel[base:] = gen["ranges_ref"], gen["ranges_qry"], gen["guess"], gen["true_rel"]
+        del gen
     d_xyt = torch.zeros(P, 3, dtype=torch.float64, device=dev)
     d_score = torch.zeros(P, dtype=torch.float64, device=dev)
     d_found = torch.zeros(P, dtype=torch.uint8, device=dev)
     m = ScanMatcher(ctx, sp["n_beams"], sp["angle_min"], sp["angle_inc"], sp["max_range"])
     torch.cuda.synchronize()
     args_dev = (d_ref.data_ptr(), d_qry.data_ptr(), d_g.data_ptr(), P, d_xyt.data_ptr(), d_score.data_ptr(), d_found.data_ptr())
-    m.closeScanMatching_dev(*args_dev)                     # warm-up
+    nw = min(P, 65536)
+    m.closeScanMatching_dev(d_ref.data_ptr(), d_qry.data_ptr(), d_g.data_ptr(), nw, d_xyt.data_ptr(), d_score.data_ptr(),
+                            d_found.data_ptr())                                   # warm-up on a slice
     t0 = time.perf_counter()
     m.closeScanMatching_dev(*args_dev)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ksec = m.last_kernel_seconds()                         # HIP events on the context's stream
+    err = (d_xyt - true_rel).abs()
+    ok = (d_found != 0) & (err[:, 0] < 0.04) & (err[:, 1] < 0.04) & (err[:, 2] < 0.013)
     xyt = d_xyt[:base].cpu().numpy()
     found = d_found[:base].cpu().numpy().astype(bool)
-    err = np.abs(xyt - sp["true_rel"])
-    ok = found & (err[:, 0] < 0.04) & (err[:, 1] < 0.04) & (err[:, 2] < 0.013)
     pmc_m = pmc_traffic().get("k_match_close_batch")
+    # compute roof: the search adds 64 angles x 24 x 24 offsets x k kept points bytes per pair; the packed-byte (SWAR)
+    # adds do 4 of them per VALU lane-op, i.e. 256 per wave instruction; the chip issues 256 CUs x 4 SIMDs x clock wave
+    # instructions per second at most (one VALU instruction per SIMD and cycle)
+    kbar = 260.0
+    byte_adds = 64 * 24 * 24 * kbar
+    clk = 2.4e9
+    valu_issue_peak = 256 * 4 * clk                        # wave instructions / s
+    useful_rate = P * byte_adds / 256.0 / ksec             # wave instructions / s that do algorithmic adds
+    golden = None
+    gpath = os.path.join(ROOT, "tests", "golden", "match_close4096.npz")
+    if os.path.exists(gpath) and base == 4096:
+        G = np.load(gpath)
+        golden = bool(np.array_equal(G["xyt"], xyt) and np.array_equal(G["found"].astype(bool), found))
     out = {"metric": "scan-match pairs/sec (closeScanMatching, 1081 beams)", "value": round(P / wall, 1),
-           "unit": "pairs/s", "n_pairs": P, "distinct_pairs": base, "kernel_ms": round(1e3 * ksec, 3),
-           "wall_ms": round(1e3 * wall, 3), "recovered_truth_frac": round(float(ok.mean()), 4),
-           "roofline": {"kernel": "k_match_close_batch", "bound": "hbm", "achieved": round(P * 8.7e3 / ksec / 1e9, 3),
-                        "peak": 8000.0, "unit": "GB/s", "frac": round(P * 8.7e3 / ksec / 1e9 / 8000.0, 7),
-                        "traffic": (round(pmc_m["traffic_bytes_corrected"] / 4096 * P) if pmc_m else None),
-                        "note": "8.7 KB compulsory HBM bytes per pair; the binding resource is instruction issue "
-                                "(PMC: SIMD issue slots 93 % busy, 67 % VALU) on sparse-tile byte gathers, see DESIGN.md 3"}}
+           "unit": "pairs/s", "n_pairs": P, "distinct_pairs": P, "kernel_ms": round(1e3 * ksec, 3),
+           "wall_ms": round(1e3 * wall, 3), "recovered_truth_frac": round(float(ok.double().mean()), 4),
+           "first_4096_match_golden_fixture": golden,
+           "roofline": {"kernel": "k_match_close_batch", "bound": "valu-issue", "unit": "G wave-instr/s",
+                        "achieved": round(useful_rate / 1e9, 2), "peak": round(valu_issue_peak / 1e9, 1),
+                        "frac": round(useful_rate / valu_issue_peak, 4),
+                        "algorithmic_byte_adds_per_pair": int(byte_adds),
+                        "hbm": {"achieved_GBps": round(P * 8.7e3 / ksec / 1e9, 3), "peak_GBps": 8000.0,
+                                "frac": round(P * 8.7e3 / ksec / 1e9 / 8000.0, 7),
+                                "traffic_bytes_per_launch": (round(pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096) * P) if pmc_m else None)},
+                        "note": "useful = 64 x 24 x 24 x k(=260) byte adds per pair at 256 per packed-byte VALU wave instruction, "
+                                "against one VALU instruction per SIMD and clock (256 CUs x 4 SIMDs x 2.4 GHz); HBM carries "
+                                "8.7 KB per pair and is not the roof (DESIGN.md 3)"}}
     if with_cpu:
+        from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
         n = 64
+
+        def cpu_run(lo, hi):
+            return O.close_scan_match_batch(sp["ranges_ref"][lo:hi], sp["ranges_qry"][lo:hi], sp["angle_min"], sp["angle_inc"],
+                                            sp["max_range"], [0, 0, 0], sp["guess"][lo:hi])
         tc0 = time.perf_counter()
-        xo, so, fo = O.close_scan_match_batch(sp["ranges_ref"][:n], sp["ranges_qry"][:n], sp["angle_min"], sp["angle_inc"],
-                                              sp["max_range"], [0, 0, 0], sp["guess"][:n])
+        xo, so, fo = cpu_run(0, n)
         tc = time.perf_counter() - tc0
+        nproc = os.cpu_count() or 1
+        per = 16
+        tm0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nproc) as ex:
+            list(ex.map(lambda k: cpu_run(n + k * per, n + (k + 1) * per), range(nproc)))
+        tm = time.perf_counter() - tm0
         out["cpu_baseline"] = {"value": round(n / tc, 2), "unit": "pairs/s", "cores": 1, "kind": "port",
                                "sample": f"{n} pairs of the same workload, single thread",
+                               "all_cores": {"value": round(nproc * per / tm, 2), "cores": nproc,
+                                             "sample": f"{per} pairs on each of {nproc} threads (nproc = {nproc})"},
                                "bit_identical_to_gpu": bool(np.array_equal(xo, xyt[:n]) and np.array_equal(fo.astype(bool), found[:n]))}
     return out
 
 
-def exchange_round(ctx, rank, world, dev, args):
-    """One round of the multi-robot protocol on the C5-style world (every rank = one robot)."""
+# ----------------------------------------------------------------------------------------------- exchange leg (C5)
+def exchange_leg(ctx, rank, world, args, dry=False):
+    """BASELINE.json configs[4] (C5): ``world`` robots x ``--c5-vertices`` vertices, a round every ``--c5-chunk`` vertices."""
     import torch
     import torch.distributed as dist
     from cg_mrslam_amd import synth
-    from cg_mrslam_amd.condensed import CondensedGraphBuffer
-    from cg_mrslam_amd.graph import GraphSLAM, PoseGraph
-    R = synth.make_multi_robot(world, args.vertices // 2, args.edges // 2, seed=777)
-    gr = R[rank]
-    pg = PoseGraph(gr["ids"], gr["poses_all"], gr["fixed_all"], gr["ef_all"], gr["et_all"], gr["meas_all"], gr["info_all"])
-    buf = CondensedGraphBuffer(pg, rank, world, ctx=ctx)
-    for q, ids in gr["in_closures"].items():
-        buf.insertInClosure(q, ids)
-    slam = GraphSLAM(pg, ctx=ctx)
-    slam.optimize(5)
-    buf.exchange(device=dev if dev.type == "cuda" else None)   # round 0: requests travel
-    torch.cuda.synchronize(); dist.barrier()
-    t0 = time.perf_counter()
-    n_edges = 0
-    for q in range(world):
-        if q != rank and q in buf.out_closures:
-            n_edges += len(buf.computeCondensedGraph(q))
-    t1 = time.perf_counter()
-    nbytes = buf.exchange(device=dev if dev.type == "cuda" else None)
-    torch.cuda.synchronize(); dist.barrier()
-    t2 = time.perf_counter()
-    slam.optimize(5)
-    t = torch.tensor([t1 - t0, t2 - t1, float(n_edges), float((buf.in_edge_src >= 0).sum())], dtype=torch.float64, device=dev)
-    tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-    return {"robots": world, "vertices_per_robot": int(pg.n_vertices), "condense_ms_max": round(1e3 * float(tmax[0]), 3),
-            "allgather_ms_max": round(1e3 * float(tmax[1]), 3), "bytes_gathered_per_rank": int(nbytes),
-            "condensed_edges_sent_total": int(tsum[2]), "condensed_edges_received_total": int(tsum[3]),
-            "wire_bytes_per_edge": 44, "chi2_after": float(slam.last_chi2[-1]), "status": int(slam.last_status)}
+    from cg_mrslam_amd.condensed import Exchange, RobotGraph
+    from cg_mrslam_amd.mrslam import RobotRounds, RobotWorld
+    robots = synth.make_multi_robot(world, args.c5_vertices, args.c5_edges, seed=777)
+    w = RobotWorld(robots, rank, chunk=args.c5_chunk)
+    n_rounds = w.n_rounds if args.c5_rounds <= 0 else min(args.c5_rounds, w.n_rounds)
+    g = RobotGraph(None if dry else ctx, rank, world, cap_edges=128)
+    rr = RobotRounds(g, w, iterations=5)
+    ex = Exchange(g)
+    if dry:
+        # no device: the protocol with fake numerics (the books, the wire and the collective are real)
+        rr.optimize = lambda: 0
+        rr.last_chi2 = np.zeros(1)
+        def fake_condense():
+            built = 0
+            for p in range(world):
+                want = g.closures(p, "out") if p != rank else []
+                if len(want) >= 2:
+                    n = len(want) - 1
+                    g.set_condensed(p, want[0], want[1:], np.zeros((n, 3), dtype=np.float32),
+                                    np.tile(np.array([100, 0, 0, 100, 0, 1000], dtype=np.float32), (n, 1)))
+                    built += 1
+            return built
+        rr.condense = fake_condense
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    t_round, t_opt, t_cond, t_coll, n_in_total, built_total = [], [], [], [], 0, 0
+    sync(); dist.barrier()
+    t_all0 = time.perf_counter()
+    for t in range(n_rounds):
+        t0 = time.perf_counter()
+        rr.grow()
+        t1 = time.perf_counter()
+        rr.optimize()
+        t2 = time.perf_counter()
+        n_in = ex.finish()                      # previous round's all-gather, overlapped with grow + optimize above
+        t3 = time.perf_counter()
+        built_total += rr.condense()
+        t4 = time.perf_counter()
+        ex.start()
+        t5 = time.perf_counter()
+        if n_in is not None:
+            n_in_total += int(np.sum(n_in))
+        cs = ex.last_collective_seconds() if (t % 10 == 9) else None     # reading it waits for the collective: sample it
+        if cs is not None:
+            t_coll.append(cs)
+        t_round.append(t5 - t0); t_opt.append(t2 - t1); t_cond.append(t4 - t3)
+    ex.finish()
+    sync(); dist.barrier()
+    t_all = time.perf_counter() - t_all0
+    stat = torch.tensor([t_all, float(np.mean(t_round)), float(np.mean(t_opt)), float(np.mean(t_cond)), float(n_in_total),
+                         float(built_total), float(g.counts()["received_edges"])], dtype=torch.float64)
+    cdev = torch.device("cpu") if (dry or dist.get_backend() == "gloo") else torch.device("cuda", ctx.device)
+    smax = stat.clone().to(cdev); dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+    ssum = stat.clone().to(cdev); dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+    smax, ssum = smax.cpu(), ssum.cpu()
+    c = g.counts()
+    out = {"workload": f"C5: {world} robots x {args.c5_vertices} vertices / {args.c5_edges} edges, a round every {args.c5_chunk} vertices",
+           "robots": world, "rounds": n_rounds, "transport": ex.transport, "transport_fallback_reason": ex.fallback_reason,
+           "total_s_max": round(float(smax[0]), 4), "round_ms_mean_max": round(1e3 * float(smax[1]), 3),
+           "optimize5_ms_mean_max": round(1e3 * float(smax[2]), 3), "condense_ms_mean_max": round(1e3 * float(smax[3]), 3),
+           "allgather_device_ms_sampled": (round(1e3 * float(np.mean(t_coll)), 4) if t_coll else None),
+           "rounds_per_s_all_robots": round(world * n_rounds / float(smax[0]), 2),
+           "bytes_gathered_per_rank_per_round": int(world * g.wire_bytes()), "wire_bytes_per_edge": 44,
+           "condensed_graphs_built_total": int(ssum[5]), "condensed_edges_received_total": int(ssum[4]),
+           "received_edges_in_graphs_at_end": int(ssum[6]), "final_vertices_rank0": c["vertices"],
+           "chi2_after_rank0": (float(rr.last_chi2[-1]) if rr.last_chi2 is not None else None), "status_rank0": int(rr.last_status)}
+    ex.close()
+    return out
+
+
+def dry_main(args, rank, world):
+    """No GPU (CPU test of the launcher): rendezvous over gloo, the exchange leg on graphs without a device."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    args.c5_vertices, args.c5_edges = min(args.c5_vertices, 600), min(args.c5_edges, 2000)
+    exchange = exchange_leg(None, rank, world, args, dry=True)
+    if rank == 0:
+        print(json.dumps({"metric": "GN iterations/sec on 10k-vertex SE2 graph (final chi2 reported)", "value": None,
+                          "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "scaling": "weak", "exchange": exchange}))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
+    maybe_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CGMR_BENCH_DRY") == "1":
+        if world < 2:
+            raise SystemExit("CGMR_BENCH_DRY=1 tests the multi-rank plumbing: use --gpus N with N > 1")
+        return dry_main(args, rank, world)
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     # CGMR_BENCH_BACKEND=gloo + CGMR_BENCH_SINGLE_DEVICE=1 is a dry-run mode for 1-GPU boxes: all ranks share
@@ -201,6 +354,7 @@ def main():
         torch.cuda.current_stream().synchronize()
         _, chi = ctx.gn_optimize_dev(d_p.data_ptr(), V, fixed, ef, et, d_m.data_ptr(), d_i.data_ptr(), GN_ITERS)
 
+    ctx.set_symbolic_cache(False)             # headline = cold: ordering + symbolic analysis in every step, as g2o does
     for _ in range(args.warmup):
         step()
 
@@ -225,11 +379,27 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    p_cold = d_p.clone()
+    chi_cold = chi.copy()
 
-    # ---- one inter-robot round (N > 1): condensed graph for every peer that asked + all-gather (RCCL)
+    # ---- the same step with the analysis cache on (second and later solves of a key frame on an unchanged graph)
+    ctx.set_symbolic_cache(True)
+    step()
+    nwarm = max(3, min(10, args.steps))
+    torch.cuda.synchronize()
+    tw0 = time.perf_counter()
+    for _ in range(nwarm):
+        step()
+    torch.cuda.synchronize()
+    warm_ms = 1e3 * (time.perf_counter() - tw0) / nwarm
+    warm = {"ms_per_step": round(warm_ms, 4), "gn_iterations_per_s": round(GN_ITERS / (warm_ms * 1e-3), 2),
+            "bit_identical_to_cold": bool(torch.equal(p_cold, d_p) and np.array_equal(chi_cold, chi)),
+            "cache": ctx.symbolic_cache_stats()}
+
+    # ---- the C5 round protocol (N > 1): incremental sub-graphs, condensed graphs, one all-gather per round
     exchange = None
     if world > 1:
-        exchange = exchange_round(ctx, rank, world, cdev, args)
+        exchange = exchange_leg(ctx, rank, world, args)
 
     if rank != 0:
         if world > 1:
@@ -261,12 +431,14 @@ def main():
     bytes_per_launch = bytes_factor_iter / max(launches_per_iter, 1)
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     pmc = pmc_traffic()
+    per_level_us = {k: round(1e6 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if k in ("front_factor", "front_update", "solve_bwd")}
     roofline = {
         "kernel": "k_front_factor", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 6),
         "traffic": pmc.get("k_front_factor", {}).get("traffic_bytes_corrected"),
         "traffic_source": pmc.get("_source"),
         "avg_launch_us": round(1e6 * avg_launch_s, 2), "launches_per_gn_iter": round(launches_per_iter, 1),
+        "tree_levels": info["levels"], "per_level_us": per_level_us,
         "algorithmic_bytes_per_launch": int(bytes_per_launch),
         "share_of_kernel_time": round(ff_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
         "note": f"latency-bound: {info['levels']} dependent tree levels of FP64 chains at one wave per SIMD; memory-side traffic "
@@ -275,13 +447,22 @@ def main():
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
         tc0 = time.perf_counter()
         st, p_cpu, chi_cpu, tms = O.gn_optimize(g["poses"], fixed, ef, et, g["meas"], g["info"], GN_ITERS)
         tc = time.perf_counter() - tc0
+        nproc = os.cpu_count() or 1
+        nthr = min(nproc, 64)
+        tm0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nthr) as ex:        # robots are independent problems: one graph per core
+            list(ex.map(lambda k: O.gn_optimize(g["poses"], fixed, ef, et, g["meas"], g["info"], GN_ITERS), range(nthr)))
+        tm = time.perf_counter() - tm0
         cpu = {"value": round(GN_ITERS / tc, 3), "unit": "GN iterations/s", "cores": 1, "kind": "port",
                "sample": f"1 optimize({GN_ITERS}) call on the same {V}-vertex/{E}-edge graph, incl. ordering+symbolic",
                "seconds": round(tc, 4), "chi2_final": float(chi_cpu[-1]),
+               "all_cores": {"value": round(nthr * GN_ITERS / tm, 3), "cores": nthr, "nproc": nproc,
+                             "sample": f"{nthr} concurrent optimize({GN_ITERS}) calls, one per host thread (independent graphs)"},
                "chi2_rel_diff_vs_gpu": float(abs(chi_cpu[-1] - chi[-1]) / chi_cpu[-1]),
                "max_pose_diff_vs_gpu": float(np.abs(p_cpu - d_p.cpu().numpy()).max())}
 
@@ -294,12 +475,13 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"C2: synthetic {V}-vertex/{E}-edge SE2 pose graph per GPU, one step = "
-                               f"GraphSLAM::optimize({GN_ITERS}) incl. host ordering+symbolic analysis",
+                               f"GraphSLAM::optimize({GN_ITERS}) incl. host ordering+symbolic analysis (analysis cache off)",
                    "gn_iterations_per_step": GN_ITERS, "graphs": world, "parallelism": f"1 robot sub-graph per GPU x{world}"},
-        "chi2_final": float(chi[-1]), "chi2_initial": float(chi[0]),
+        "chi2_final": float(chi_cold[-1]), "chi2_initial": float(chi_cold[0]),
         "host_symbolic_ms_per_step": round(1e3 * host_sym / args.steps, 3),
         "host_threads": host_threads(),
         "device_ms_per_step": round(1e3 * dev_time / args.steps, 3),
+        "warm": warm,
         "symbolic": {k: info[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")},
         "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},
         "roofline": roofline, "cpu_baseline": cpu, "matcher": matcher, "exchange": exchange,

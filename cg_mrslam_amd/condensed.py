@@ -1,171 +1,309 @@
-"""Condensed-graph construction and inter-robot exchange for the multi-robot path.
+"""Multi-robot path: one robot's pose graph resident in HBM, its condensed graphs and the inter-robot exchange.
 
-Host-side mirror of the reference's
-  * ``CondensedGraphBuffer``  (src/mrslam/condensed_graph/condensed_graph_buffer.{h,cpp}): which of my
-    vertices each peer asked for (out-closures), which foreign vertices I ask for (in-closures), the edges
-    I built for / received from each peer, ``getMyEdges``, ``selectGaugeCentroid``,
-    ``computeCondensedGraph`` and ``insertEdgesFromRobot`` (replace-on-receive);
-  * the wire structs of ``msg_factory.h`` (``EdgeArrayMessage::ESE2Data``: int from, int to, 3 + 6 doubles
-    narrowed to float32 on the wire, src/mrslam/msg_factory.h:78-112,200-218): 44 bytes per edge;
-  * ``GraphComm``'s pairwise UDP send/receive (src/mrslam/graph_comm.cpp:103-193), replaced by ONE
-    all-gather per round of a fixed-capacity byte buffer per rank over RCCL/xGMI (``torch.distributed`` with
-    backend "nccl" on the GPUs, "gloo" in the CPU tests).
-
-The numeric work (``CondensedGraphCreator::compute``) runs on the GPU through ``Context.condense``.
+Thin host-side mirror of the reference's
+  * ``CondensedGraphBuffer``  (src/mrslam/condensed_graph/condensed_graph_buffer.{h,cpp}): in-/out-closures,
+    ``computeCondensedGraph``, ``insertEdgesFromRobot`` (replace-on-receive), ``getMyEdges``, ``selectGaugeCentroid``;
+  * ``MRGraphSLAM::addInterRobotData``  (src/mrslam/mr_graph_slam.cpp:331-395);
+  * the wire structs of ``msg_factory.h`` (44 bytes per edge, float32 on the wire, src/mrslam/msg_factory.h:78-112,200-218);
+  * ``GraphComm``'s pairwise UDP send / receive (src/mrslam/graph_comm.cpp:103-208), replaced by ONE all-gather per round
+    of a fixed-capacity buffer per rank over RCCL / xGMI
+over the C ABI (include/cgmr.h "robot graph" and "exchange"; csrc/mrslam_api.cpp, mrslam_kernels.hip, rccl_comm.cpp).
+Everything here is a ctypes call; there is no numeric or bookkeeping logic in Python and no CPU fallback for the numeric
+entry points (a graph created without a context only keeps the books, for CPU tests of the protocol).
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
-from .graph import PoseGraph
+from ._lib import CGMR_E_CHOLESKY_BASE, CgmrError, Context, load_library
 
-EDGE_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("est", "<f4", (3,)), ("info", "<f4", (6,))])
-assert EDGE_DTYPE.itemsize == 44            # CondensedGraphMessage: 44 bytes per edge
-
-
-def select_gauge_centroid(poses_xy: np.ndarray) -> int:
-    """``selectGaugeCentroid`` (condensed_graph_buffer.cpp:318-345): index of the vertex closest to the
-    centroid of the requested vertices' translations (first one wins ties)."""
-    c = poses_xy.sum(axis=0) / len(poses_xy)
-    d = np.sqrt(((poses_xy - c) ** 2).sum(axis=1))
-    return int(np.argmin(d))
+WIRE_EDGE_DTYPE = np.dtype([("from", "<i4"), ("to", "<i4"), ("est", "<f4", (3,)), ("info", "<f4", (6,))])
+assert WIRE_EDGE_DTYPE.itemsize == 44            # EdgeArrayMessage::ESE2Data on the wire
 
 
-class CondensedGraphBuffer:
-    def __init__(self, graph: PoseGraph, robot: int, n_robots: int, ctx=None, cap_edges: int = 128,
-                 base_id: int = 10000):
-        self.g = graph
-        self.robot = robot
-        self.n_robots = n_robots
-        self.ctx = ctx
-        self.cap = cap_edges
-        self.base_id = base_id
-        self.out_closures = {}      # peer -> sorted int array of MY vertex ids the peer asked for
-        self.in_closures = {}       # peer -> sorted int array of the peer's vertex ids I ask for
-        self.out_condensed = {}     # peer -> structured array EDGE_DTYPE (ids), level peer+1 in g2o terms
-        self.in_edge_src = np.full(graph.n_edges, -1, dtype=np.int32)   # peer that sent a level-0 edge, -1 = own
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
 
-    # ------------------------------------------------------------------ closures
-    def insertOutClosure(self, peer, vertex_ids):   # noqa: N802  (condensed_graph_buffer.cpp:152-170)
-        cur = self.out_closures.get(peer, np.zeros(0, dtype=np.int64))
-        self.out_closures[peer] = np.union1d(cur, np.asarray(vertex_ids, dtype=np.int64))
 
-    def insertInClosure(self, peer, vertex_ids):    # noqa: N802  (condensed_graph_buffer.cpp:131-150)
-        cur = self.in_closures.get(peer, np.zeros(0, dtype=np.int64))
-        self.in_closures[peer] = np.union1d(cur, np.asarray(vertex_ids, dtype=np.int64))
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
 
-    # ------------------------------------------------------------------ my edges
-    def my_edge_mask(self):
-        """``getMyEdges`` (condensed_graph_buffer.cpp:347-366): every edge except those received from other
-        robots; edges built *for* other robots live at level peer+1 and are not in the arrays at all."""
-        return (self.in_edge_src < 0) & (self.g.edge_level == 0)
 
-    def _index_of_ids(self, ids):
-        order = np.argsort(self.g.ids, kind="stable")
-        pos = np.searchsorted(self.g.ids[order], ids)
-        pos = np.minimum(pos, len(order) - 1)
-        ok = self.g.ids[order][pos] == ids
-        return np.where(ok, order[pos], -1)
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
 
-    # ------------------------------------------------------------------ build
-    def computeCondensedGraph(self, peer):   # noqa: N802  (condensed_graph_buffer.cpp:437-485)
-        """Star of condensed edges over the vertices ``peer`` asked for; stored (ids) in out_condensed[peer]."""
-        want = self.out_closures.get(peer)
-        if want is None or len(want) < 2:
-            self.out_condensed[peer] = np.zeros(0, dtype=EDGE_DTYPE)
-            return self.out_condensed[peer]
-        idx = self._index_of_ids(want)
-        idx = idx[idx >= 0]
-        if len(idx) < 2:
-            self.out_condensed[peer] = np.zeros(0, dtype=EDGE_DTYPE)
-            return self.out_condensed[peer]
-        gauge = int(idx[select_gauge_centroid(self.g.poses[idx, :2])])
-        m = self.my_edge_mask()
-        to, est, iu, _ = self.ctx.condense(self.g.poses, self.g.edge_from[m], self.g.edge_to[m], self.g.meas[m],
-                                           self.g.info[m], gauge, idx.astype(np.int32))
-        e = np.zeros(len(to), dtype=EDGE_DTYPE)
-        e["from"] = self.g.ids[gauge]
-        e["to"] = self.g.ids[to]
-        e["est"] = est.astype(np.float32)          # doubles are narrowed to float32 on the wire
-        e["info"] = iu.astype(np.float32)
-        self.out_condensed[peer] = e
-        return e
+
+class RobotGraph:
+    """``cgmr_graph``: the g2o optimiser of one robot plus its ``CondensedGraphBuffer``."""
+
+    def __init__(self, ctx: Context | None, robot: int, n_robots: int, base_id: int = 10000, cap_edges: int = 128):
+        self.lib = ctx.lib if ctx is not None else load_library()
+        self.lib.cgmr_graph_last_error.restype = C.c_char_p
+        self.lib.cgmr_graph_wire_bytes.restype = C.c_int64
+        self.lib.cgmr_graph_send_buffer.restype = C.c_void_p
+        self.lib.cgmr_graph_recv_buffer.restype = C.c_void_p
+        self.lib.cgmr_graph_destroy.restype = None
+        self.ctx, self.robot, self.n_robots, self.base_id, self.cap = ctx, robot, n_robots, base_id, cap_edges
+        h = C.c_void_p()
+        rc = self.lib.cgmr_graph_create(ctx.h if ctx is not None else C.c_void_p(0), C.c_int(robot), C.c_int(n_robots),
+                                        C.c_int(base_id), C.c_int(cap_edges), C.byref(h))
+        if rc != 0:
+            raise CgmrError(rc, "cgmr_graph_create failed")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cgmr_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow_cholesky=False):
+        if rc >= 0 or (allow_cholesky and rc <= CGMR_E_CHOLESKY_BASE):
+            return rc
+        raise CgmrError(rc, self.lib.cgmr_graph_last_error(self.h).decode() or
+                        (self.ctx.lib.cgmr_last_error(self.ctx.h).decode() if self.ctx is not None else ""))
+
+    # ------------------------------------------------------------------ graph
+    def add_vertices(self, ids, poses, fixed=None):
+        ids, poses = _i32(ids), _f64(poses).reshape(-1, 3)
+        fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.uint8)
+        self._check(self.lib.cgmr_graph_add_vertices(self.h, C.c_int(len(ids)), _p(ids), _p(poses), _p(fx) if fx is not None else C.c_void_p(0)))
+
+    def add_edges(self, from_ids, to_ids, meas, info):
+        f, t = _i32(from_ids), _i32(to_ids)
+        self._check(self.lib.cgmr_graph_add_edges(self.h, C.c_int(len(f)), _p(f), _p(t), _p(_f64(meas)), _p(_f64(info))))
+
+    def counts(self):
+        out = np.zeros(4, dtype=np.int32)
+        self._check(self.lib.cgmr_graph_counts(self.h, _p(out)))
+        return dict(zip(["vertices", "own_edges", "received_edges", "peers_with_requests"], out.tolist()))
+
+    def optimize(self, iters: int):
+        """``GraphSLAM::optimize(iters)``: returns (status, chi2[iters+1]); a Cholesky failure is a status, not an exception."""
+        chi = np.zeros(iters + 1)
+        rc = self.lib.cgmr_graph_optimize(self.h, C.c_int(iters), _p(chi))
+        self._check(rc, allow_cholesky=True)
+        return rc, chi
+
+    def poses(self, first=0, n=None):
+        n = self.counts()["vertices"] - first if n is None else n
+        out = np.zeros((n, 3))
+        self._check(self.lib.cgmr_graph_get_poses(self.h, C.c_int(first), C.c_int(n), _p(out)))
+        return out
+
+    def set_poses(self, first, poses):
+        poses = _f64(poses).reshape(-1, 3)
+        self._check(self.lib.cgmr_graph_set_poses(self.h, C.c_int(first), C.c_int(len(poses)), _p(poses)))
+
+    # ------------------------------------------------------------------ closures / condensed graphs
+    def insertInClosure(self, peer, ids):   # noqa: N802
+        ids = _i32(ids)
+        self._check(self.lib.cgmr_graph_insert_in_closure(self.h, C.c_int(peer), C.c_int(len(ids)), _p(ids)))
+
+    def insertOutClosure(self, peer, ids):   # noqa: N802
+        ids = _i32(ids)
+        self._check(self.lib.cgmr_graph_insert_out_closure(self.h, C.c_int(peer), C.c_int(len(ids)), _p(ids)))
+
+    def closures(self, peer, which="out"):
+        out = np.zeros(4096, dtype=np.int32)
+        n = self._check(self.lib.cgmr_graph_closures(self.h, C.c_int(peer), C.c_int(0 if which == "out" else 1), C.c_int(len(out)), _p(out)))
+        return out[:n].copy()
+
+    def computeCondensedGraph(self, peer: int = -1):   # noqa: N802
+        """``computeCondensedGraph`` for one peer or (``peer < 0``) for every peer that has asked; returns the number built."""
+        return self._check(self.lib.cgmr_graph_compute_condensed(self.h, C.c_int(peer)))
+
+    def condensed(self, peer):
+        """(gauge id, to ids[n], est[n,3], info_upper[n,6]) of the condensed graph built for ``peer``, double precision."""
+        cap = self.cap
+        gid = C.c_int32(-1)
+        to, est, iu = np.zeros(cap, dtype=np.int32), np.zeros((cap, 3)), np.zeros((cap, 6))
+        n = self._check(self.lib.cgmr_graph_get_condensed(self.h, C.c_int(peer), C.c_int(cap), C.byref(gid), _p(to), _p(est), _p(iu)))
+        return (int(gid.value) if n else None), to[:n].astype(np.int64), est[:n].copy(), iu[:n].copy()
+
+    def set_condensed(self, peer, from_id, to_ids, est, info):
+        to = _i32(to_ids)
+        e = np.ascontiguousarray(est, dtype=np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(info, dtype=np.float32).reshape(-1, 6)
+        self._check(self.lib.cgmr_graph_set_condensed(self.h, C.c_int(peer), C.c_int(len(to)), C.c_int32(int(from_id)), _p(to), _p(e), _p(i)))
 
     # ------------------------------------------------------------------ wire
-    def wire_bytes(self):
-        R, cap = self.n_robots, self.cap
-        return 4 * (2 + 2 * R) + R * cap * EDGE_DTYPE.itemsize + R * cap * 4
+    def wire_bytes(self) -> int:
+        return int(self.lib.cgmr_graph_wire_bytes(self.h))
 
-    def pack(self) -> np.ndarray:
-        """Fixed-capacity send buffer: header {robot, n_robots, n_edges[R], n_closures[R]} int32,
-        edges[R][cap] (44 B each, slice p = edges for peer p), closures[R][cap] int32 (ids I request from p)."""
-        R, cap = self.n_robots, self.cap
-        hdr = np.zeros(2 + 2 * R, dtype=np.int32)
-        hdr[0], hdr[1] = self.robot, R
-        edges = np.zeros((R, cap), dtype=EDGE_DTYPE)
-        clos = np.zeros((R, cap), dtype=np.int32)
-        for p in range(R):
-            e = self.out_condensed.get(p)
-            if e is not None and len(e):
-                n = min(len(e), cap)
-                edges[p, :n] = e[:n]
-                hdr[2 + p] = n
-            c = self.in_closures.get(p)
-            if c is not None and len(c):
-                n = min(len(c), cap)
-                clos[p, :n] = c[:n]
-                hdr[2 + R + p] = n
-        return np.concatenate([hdr.view(np.uint8), edges.reshape(-1).view(np.uint8), clos.reshape(-1).view(np.uint8)])
+    def send_buffer(self) -> int:
+        return int(self.lib.cgmr_graph_send_buffer(self.h) or 0)
 
-    def unpack(self, buf: np.ndarray):
-        """Inverse of ``pack`` for ONE sender's buffer: (sender, edges addressed to me, closures it requests from me)."""
-        R, cap = self.n_robots, self.cap
-        hdr = buf[:4 * (2 + 2 * R)].view(np.int32)
-        sender = int(hdr[0])
-        o = 4 * (2 + 2 * R)
-        edges = buf[o:o + R * cap * 44].view(EDGE_DTYPE).reshape(R, cap)
-        o += R * cap * 44
-        clos = buf[o:o + R * cap * 4].view(np.int32).reshape(R, cap)
-        me = self.robot
-        return sender, edges[me, :hdr[2 + me]].copy(), clos[me, :hdr[2 + R + me]].copy()
+    def recv_buffer(self) -> int:
+        return int(self.lib.cgmr_graph_recv_buffer(self.h) or 0)
 
-    # ------------------------------------------------------------------ receive
-    def insertEdgesFromRobot(self, peer, edges):   # noqa: N802  (condensed_graph_buffer.cpp:487-510)
-        """Replace the previous set received from ``peer`` by ``edges``; edges whose end points are not in my
-        graph are skipped (src/mrslam/mr_graph_slam.cpp:363)."""
-        g = self.g
-        keep = self.in_edge_src != peer
-        fi = self._index_of_ids(edges["from"].astype(np.int64)) if len(edges) else np.zeros(0, dtype=np.int64)
-        ti = self._index_of_ids(edges["to"].astype(np.int64)) if len(edges) else np.zeros(0, dtype=np.int64)
-        ok = (fi >= 0) & (ti >= 0)
-        n_new = int(ok.sum())
-        g.edge_from = np.concatenate([g.edge_from[keep], fi[ok].astype(np.int32)])
-        g.edge_to = np.concatenate([g.edge_to[keep], ti[ok].astype(np.int32)])
-        g.meas = np.concatenate([g.meas[keep], edges["est"][ok].astype(np.float64).reshape(-1, 3)])
-        g.info = np.concatenate([g.info[keep], edges["info"][ok].astype(np.float64).reshape(-1, 6)])
-        g.edge_level = np.concatenate([g.edge_level[keep], np.zeros(n_new, dtype=np.int32)])
-        self.in_edge_src = np.concatenate([self.in_edge_src[keep], np.full(n_new, peer, dtype=np.int32)])
-        return n_new
+    def pack(self, d_send: int = 0):
+        self._check(self.lib.cgmr_graph_pack(self.h, C.c_void_p(d_send)))
 
-    # ------------------------------------------------------------------ one exchange round
-    def exchange(self, group=None, device=None):
-        """All-gather every rank's send buffer and ingest what is addressed to me.  Returns bytes gathered.
-        With torch.distributed uninitialised (single robot) this is a no-op."""
+    def ingest(self, d_recv: int = 0):
+        n = np.zeros(self.n_robots, dtype=np.int32)
+        self._check(self.lib.cgmr_graph_ingest(self.h, C.c_void_p(d_recv), _p(n)))
+        return n
+
+    def pack_host(self) -> np.ndarray:
+        buf = np.zeros(self.wire_bytes(), dtype=np.uint8)
+        self._check(self.lib.cgmr_graph_pack_host(self.h, _p(buf)))
+        return buf
+
+    def ingest_host(self, recv) -> np.ndarray:
+        recv = np.ascontiguousarray(recv, dtype=np.uint8).reshape(-1)
+        if recv.size != self.n_robots * self.wire_bytes():
+            raise ValueError("receive buffer must hold n_robots wire buffers")
+        n = np.zeros(self.n_robots, dtype=np.int32)
+        self._check(self.lib.cgmr_graph_ingest_host(self.h, _p(recv), _p(n)))
+        return n
+
+    def received_edges(self, peer):
+        cap = self.cap
+        f, t, m, i = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32), np.zeros((cap, 3)), np.zeros((cap, 6))
+        n = self._check(self.lib.cgmr_graph_received_edges(self.h, C.c_int(peer), C.c_int(cap), _p(f), _p(t), _p(m), _p(i)))
+        return f[:n].astype(np.int64), t[:n].astype(np.int64), m[:n].copy(), i[:n].copy()
+
+    def last_seconds(self):
+        out = np.zeros(2)
+        self._check(self.lib.cgmr_graph_last_seconds(self.h, _p(out)))
+        return {"optimize": float(out[0]), "condense": float(out[1])}
+
+
+def unpack_wire(buf: np.ndarray, n_robots: int, cap: int):
+    """Decode one rank's wire buffer (tests, debugging): (robot, n_edges[R], n_closures[R], edges[R][cap], closures[R][cap])."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    hdr = buf[:4 * (2 + 2 * n_robots)].view(np.int32)
+    o = 4 * (2 + 2 * n_robots)
+    edges = buf[o:o + n_robots * cap * 44].view(WIRE_EDGE_DTYPE).reshape(n_robots, cap)
+    o += n_robots * cap * 44
+    clos = buf[o:o + n_robots * cap * 4].view(np.int32).reshape(n_robots, cap)
+    return int(hdr[0]), hdr[2:2 + n_robots].copy(), hdr[2 + n_robots:2 + 2 * n_robots].copy(), edges, clos
+
+
+class Exchange:
+    """One all-gather per round of every rank's wire buffer.
+
+    transport "rccl":  ``cgmr_allgather_condensed`` on device buffers, a native RCCL communicator on a side stream (the
+                       unique id travels through ``torch.distributed``); overlaps with whatever the context's stream does next
+    transport "torch": ``torch.distributed.all_gather_into_tensor`` on the same device buffers (backend nccl = RCCL)
+    transport "host":  host staging (backend gloo: CPU tests, single-GPU dry runs)
+    ``start()`` issues the collective, ``finish()`` ingests what arrived; in between the caller runs the next solve."""
+
+    def __init__(self, graph: RobotGraph, transport: str = "auto", group=None):
         import torch
         import torch.distributed as dist
-        if not dist.is_available() or not dist.is_initialized():
-            return 0
-        send = torch.from_numpy(self.pack())
-        if device is not None:
-            send = send.to(device)
-        world = dist.get_world_size(group)
-        recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
-        dist.all_gather_into_tensor(recv, send, group=group)
-        host = recv.cpu().numpy().reshape(world, -1)
-        for src in range(world):
-            sender, edges, closures = self.unpack(host[src])
-            if sender == self.robot:
-                continue
-            self.insertOutClosure(sender, closures)
-            self.insertEdgesFromRobot(sender, edges)
-        return int(recv.numel())
+        self.g, self.group, self.torch, self.dist = graph, group, torch, dist
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if self.world != graph.n_robots:
+            raise ValueError("one rank per robot: world size must equal n_robots")
+        self.wb = graph.wire_bytes()
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        if transport == "auto":
+            transport = "rccl" if (backend == "nccl" and graph.ctx is not None) else ("host" if backend in ("gloo", "none") else "torch")
+        self.comm = None
+        self.pending = None
+        self.fallback_reason = None
+        if transport == "rccl":
+            try:
+                self._init_rccl()
+            except Exception as e:          # noqa: BLE001 -- any failure: fall back to torch's own RCCL communicator
+                self.fallback_reason = f"{type(e).__name__}: {e}"
+                transport = "torch"
+            # all ranks must agree on the transport
+            flag = torch.tensor([1 if transport == "rccl" else 0], device=torch.device("cuda", graph.ctx.device))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0 and transport == "rccl":
+                self._destroy_comm()
+                transport = "torch"
+                self.fallback_reason = "a peer could not create the RCCL communicator"
+        self.transport = transport
+        if transport == "torch":
+            dev = torch.device("cuda", graph.ctx.device)
+            self.t_send = torch.zeros(self.wb, dtype=torch.uint8, device=dev)
+            self.t_recv = torch.zeros(self.world * self.wb, dtype=torch.uint8, device=dev)
+
+    def _init_rccl(self):
+        torch, dist, g = self.torch, self.dist, self.g
+        lib = g.lib
+        dev = torch.device("cuda", g.ctx.device)
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        ok = 0
+        if dist.get_rank(self.group) == 0:
+            h = np.zeros(128, dtype=np.uint8)
+            ok = lib.cgmr_comm_unique_id(_p(h))
+            uid = torch.from_numpy(h).to(dev)
+        st = torch.tensor([ok], device=dev)
+        dist.broadcast(st, src=0, group=self.group)
+        if int(st.item()) != 0:
+            raise CgmrError(int(st.item()), "cgmr_comm_unique_id failed on rank 0 (librccl not loadable)")
+        dist.broadcast(uid, src=0, group=self.group)
+        h = np.ascontiguousarray(uid.cpu().numpy())
+        comm = C.c_void_p()
+        rc = lib.cgmr_comm_create(g.ctx.h, C.c_int(self.world), C.c_int(dist.get_rank(self.group)), _p(h), C.byref(comm))
+        if rc != 0:
+            raise CgmrError(rc, g.ctx.lib.cgmr_last_error(g.ctx.h).decode())
+        self.comm = comm
+
+    def _destroy_comm(self):
+        if self.comm is not None:
+            self.g.lib.cgmr_comm_destroy.restype = None
+            self.g.lib.cgmr_comm_destroy(self.comm)
+            self.comm = None
+
+    def close(self):
+        self._destroy_comm()
+
+    def start(self):
+        """Serialise my message and issue the all-gather; returns immediately for the device transports."""
+        g = self.g
+        if self.world == 1:
+            self.pending = None
+            return
+        if self.transport == "rccl":
+            g.pack(0)
+            g.ctx._check(g.lib.cgmr_allgather_condensed(g.ctx.h, self.comm, C.c_void_p(g.send_buffer()), C.c_size_t(self.wb),
+                                                        C.c_void_p(g.recv_buffer())))
+            self.pending = "rccl"
+        elif self.transport == "torch":
+            g.pack(self.t_send.data_ptr())
+            g.ctx.synchronize()                       # the context's stream is not torch's: order by the host
+            self.pending = self.dist.all_gather_into_tensor(self.t_recv, self.t_send, group=self.group, async_op=True)
+        else:
+            send = self.torch.from_numpy(g.pack_host())
+            recv = self.torch.empty(self.world * self.wb, dtype=self.torch.uint8)
+            self.pending = (self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True), recv, send)
+
+    def finish(self):
+        """Wait for the all-gather issued by ``start()`` and ingest it.  Returns accepted edges per sender (or None)."""
+        g = self.g
+        if self.pending is None:
+            return None
+        if self.transport == "rccl":
+            g.ctx._check(g.lib.cgmr_comm_wait(g.ctx.h, self.comm))
+            n = g.ingest(0)
+        elif self.transport == "torch":
+            self.pending.wait()
+            self.torch.cuda.current_stream().synchronize()
+            n = g.ingest(self.t_recv.data_ptr())
+        else:
+            work, recv, _send = self.pending
+            work.wait()
+            n = g.ingest_host(recv.numpy())
+        self.pending = None
+        return n
+
+    def last_collective_seconds(self):
+        if self.transport != "rccl" or self.comm is None:
+            return None
+        s = C.c_double()
+        if self.g.lib.cgmr_comm_last_seconds(self.comm, C.byref(s)) != 0:
+            return None
+        return s.value

@@ -1,6 +1,7 @@
 // C ABI of libcgmr.so (include/cgmr.h): context management and the Gauss-Newton driver.
 // Compiled with hipcc; contains no kernels (those live in gn_kernels.hip / matcher_kernels.hip).
 #include "cgmr_ctx.h"
+#include "gn_host.h"
 
 #include <algorithm>
 #include <chrono>
@@ -63,8 +64,6 @@ int pinned_mask_reserve(cgmr_ctx* ctx, size_t bytes) {
   ctx->pinned_mask_cap = want;
   return 0;
 }
-
-namespace {
 
 struct BlobLayout {
   size_t off = 0;
@@ -273,7 +272,8 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
 
 // Per numeric pass: the column mask (fixed vertices; vertices whose edges are all switched off when only the
 // first n_active edges take part), the status words.  ctx->vmask keeps the per-vertex flags for the caller.
-int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int n_active) {
+int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int n_active, int slot,
+                 int nslots) {
   const Symbolic& S = ctx->sym;
   GnDevice& D = ctx->gn;
   ctx->vmask.assign(S.nV, 0);
@@ -285,10 +285,13 @@ int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef,
   }
   HIP_TRY(ctx, hipMemsetAsync(D.status, 0, 16, ctx->stream));
   if (S.nf == 0) return 0;
-  int rc = pinned_mask_reserve(ctx, (size_t)S.nf);
+  // several passes may be queued without a host synchronisation in between (one condensed graph per peer): each
+  // stages its mask in a slot of its own
+  int rc = pinned_mask_reserve(ctx, (size_t)S.nf * std::max(nslots, 1));
   if (rc) return rc;
-  for (int c = 0; c < S.nf; c++) ctx->pinned_mask[c] = (char)ctx->vmask[S.perm[c]];
-  HIP_TRY(ctx, hipMemcpyAsync(D.cmask, ctx->pinned_mask, (size_t)S.nf, hipMemcpyHostToDevice, ctx->stream));
+  char* pm = ctx->pinned_mask + (size_t)S.nf * slot;
+  for (int c = 0; c < S.nf; c++) pm[c] = (char)ctx->vmask[S.perm[c]];
+  HIP_TRY(ctx, hipMemcpyAsync(D.cmask, pm, (size_t)S.nf, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
 
@@ -325,7 +328,7 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
 
 // one Gauss-Newton pass on the uploaded structure: linearise + chi2 [+ assemble + factor [+ solve + update]]
 void gn_pass(cgmr_ctx* ctx, double* d_poses, const GnEdges& Ed, int it, bool chi_only,
-             bool solve_and_update, bool write_l11c = false) {
+             bool solve_and_update, bool write_l11c) {
   GnDevice& D = ctx->gn;
   hipStream_t st = ctx->stream;
   KTimer T{ctx};
@@ -374,7 +377,7 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   int rc = prepare_structure(ctx, nV, nE, ef, et, iters);
   if (rc) return rc;
   double t1 = wall_s();
-  rc = prepare_pass(ctx, fixed, nE, ef, et, Ed.n_active);
+  rc = prepare_pass(ctx, fixed, nE, ef, et, Ed.n_active, 0, 1);
   if (rc) return rc;
   double t2 = wall_s();
   GnDevice& D = ctx->gn;
@@ -389,13 +392,13 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   if (graph_mode && !ctx->profiling && !trace_launches && iters >= 2 && st != nullptr && D.nf > 0) {
     gn_init_kernels();
     HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    gn_pass(ctx, d_poses, Ed, 0, false, true);
+    gn_pass(ctx, d_poses, Ed, 0, false, true, false);
     HIP_TRY(ctx, hipStreamEndCapture(st, &graph));
     HIP_TRY(ctx, hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
     for (int it = 0; it < iters; it++) HIP_TRY(ctx, hipGraphLaunch(graph_exec, st));
-    gn_pass(ctx, d_poses, Ed, iters, true, true);
+    gn_pass(ctx, d_poses, Ed, iters, true, true, false);
   } else {
-    for (int it = 0; it <= iters; it++) gn_pass(ctx, d_poses, Ed, it, it == iters, true);
+    for (int it = 0; it <= iters; it++) gn_pass(ctx, d_poses, Ed, it, it == iters, true, false);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
   // read back chi2 + status
@@ -491,7 +494,7 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   Symbolic& S = ctx->sym;
   int rc = prepare_structure(ctx, nV, nE, ef, et, 1);
   if (rc) return rc;
-  rc = prepare_pass(ctx, fixed.data(), nE, ef, et, nE);
+  rc = prepare_pass(ctx, fixed.data(), nE, ef, et, nE, 0, 1);
   if (rc) return rc;
   GnDevice& D = ctx->gn;
   hipStream_t st = ctx->stream;
@@ -548,7 +551,6 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   return CGMR_OK;
 }
 
-}  // namespace
 }  // namespace cgmr
 
 using namespace cgmr;

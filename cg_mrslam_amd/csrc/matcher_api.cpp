@@ -427,6 +427,8 @@ int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, con
 // and CharGrid::hierarchicalSearch (src/matcher/chargrid.cpp:310-413): vertex sets arrive as flat scan sets, the
 // region / transform bookkeeping is host code with the reference's arithmetic (Vector3f regions: float; SE2
 // products: double with libm sin / cos), every search runs on the GPU.
+}  // extern "C"
+
 namespace {
 
 struct Se2 { double x, y, t; };
@@ -521,6 +523,8 @@ int hierarchical_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, 
 }
 
 }  // namespace
+
+extern "C" {
 
 int cgmr_transform_points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* vset, double* pts_out, int cap) {
   if (!cfg || !scan_set_ok(vset) || cap < 0 || (cap > 0 && !pts_out)) return CGMR_E_INVALID;

@@ -1,0 +1,699 @@
+// C ABI of the multi-robot path (include/cgmr.h, "robot graph"): one robot's pose graph resident in HBM, grown
+// incrementally, optimised in place, condensed for every peer that asked, exchanged as 44-byte wire edges.
+//
+// Reference behaviour being replaced:
+//   MRGraphSLAM::addInterRobotData            src/mrslam/mr_graph_slam.cpp:331-395  (closure requests in, edges in)
+//   CondensedGraphBuffer                      src/mrslam/condensed_graph/condensed_graph_buffer.cpp
+//     insertInClosure / insertOutClosure      :131-170      getMyEdges            :347-366
+//     selectGaugeCentroid                     :318-345      computeCondensedGraph :437-485
+//     insertEdgesFromRobot                    :487-510  (the newest set from a robot replaces the previous one)
+//   CondensedGraphCreator::compute            src/mrslam/condensed_graph/condensed_graph_creator.cpp:33-66
+//   wire structs                              src/mrslam/msg_factory.h:78-112,200-238
+// The graph *structure* (ids, edge end points, closure lists) lives on the host, as g2o's does; everything numeric
+// (poses, measurements, information matrices, received edges, the wire buffers) lives in HBM.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+#include <vector>
+
+#include "cgmr_ctx.h"
+#include "gn_host.h"
+#include "mrslam_device.h"
+
+using namespace cgmr;
+
+#define HIP_TRY(ctx, call)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) return set_err(ctx, CGMR_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+struct DevBuf {                       // growable device array; contents survive growth
+  char* ptr = nullptr;
+  size_t cap = 0;
+};
+
+struct PeerOut {                      // condensed graph built for one peer
+  int n = 0;                          // edges
+  int32_t gauge_id = -1;
+  std::vector<WireEdge> host;         // host copy (set by cgmr_graph_set_condensed or downloaded on demand)
+  bool host_valid = false;
+  std::vector<int32_t> to_idx;        // vertex index of every edge's far end
+};
+
+struct PeerIn {                       // edges received from one peer (the accepted, newest set)
+  std::vector<int32_t> slot, from_idx, to_idx;     // staging slot (peer * cap + k), end points (vertex indices)
+};
+
+}  // namespace
+
+struct cgmr_graph {
+  cgmr_ctx* ctx = nullptr;            // null: host-only bookkeeping (no numeric entry point works)
+  int robot = 0, n_robots = 1, base_id = 10000, cap = 128;
+  std::string err;
+  // vertices
+  std::vector<int32_t> ids;
+  std::unordered_map<int32_t, int32_t> index;
+  std::vector<uint8_t> fixed;
+  std::vector<double> h_poses;        // estimates as added / as of the last download
+  // own edges (segment A) and received edges (segment B, compact, peer order)
+  std::vector<int32_t> ef, et;
+  std::vector<double> h_meas, h_info;
+  std::vector<PeerIn> in;             // per peer
+  std::vector<PeerOut> out;           // per peer
+  std::vector<std::vector<int32_t>> out_closures, in_closures;   // sorted unique ids
+  std::vector<int32_t> all_ef, all_et;                           // A then B
+  int nB = 0;
+  // host staging of received numeric data (host-only mode and getters): slot-indexed like the device staging
+  std::vector<double> hs_meas, hs_info;
+  // device
+  DevBuf d_poses, d_meas_a, d_info_a, d_vids, d_work;
+  char* d_fixed_block = nullptr;      // one allocation for the fixed-size buffers below
+  double *d_stage_meas = nullptr, *d_stage_info = nullptr, *d_tmp_meas = nullptr, *d_tmp_info = nullptr;
+  double *d_meas_b = nullptr, *d_info_b = nullptr, *d_est64 = nullptr, *d_info64 = nullptr, *d_qposes = nullptr;
+  int32_t *d_ids_out = nullptr, *d_slot = nullptr, *d_qidx = nullptr, *d_status_all = nullptr;
+  unsigned char *d_send = nullptr, *d_recv = nullptr;
+  char* pinned = nullptr;             // header + closures staging, ids read-back, slot lists
+  size_t pinned_bytes = 0;
+  double last_condense_seconds = 0, last_optimize_seconds = 0;
+};
+
+namespace {
+
+int gerr(cgmr_graph* g, int code, const char* msg) {
+  g->err = msg;
+  if (g->ctx) set_err(g->ctx, code, "%s", msg);
+  return code;
+}
+
+int dev_grow(cgmr_graph* g, DevBuf& B, size_t used_bytes, size_t need_bytes) {
+  if (need_bytes <= B.cap) return 0;
+  cgmr_ctx* ctx = g->ctx;
+  size_t want = std::max(need_bytes + need_bytes / 2, (size_t)1 << 16);
+  char* p = nullptr;
+  hipError_t e = hipMalloc((void**)&p, want);
+  if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+  if (B.ptr) {
+    if (used_bytes) HIP_TRY(ctx, hipMemcpyAsync(p, B.ptr, used_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(B.ptr);
+  }
+  B.ptr = p;
+  B.cap = want;
+  return 0;
+}
+
+size_t round256(size_t v) { return (v + 255) & ~size_t(255); }
+
+int alloc_fixed(cgmr_graph* g) {
+  cgmr_ctx* ctx = g->ctx;
+  const size_t R = g->n_robots, cap = g->cap, slots = R * cap, wb = wire_bytes(g->n_robots, g->cap);
+  size_t off = 0;
+  auto add = [&](size_t bytes) { size_t o = off; off = round256(off + bytes); return o; };
+  const size_t o_sm = add(24 * slots), o_si = add(48 * slots), o_tm = add(24 * slots), o_ti = add(48 * slots),
+               o_mb = add(24 * slots), o_ib = add(48 * slots), o_e64 = add(24 * slots), o_i64 = add(48 * slots),
+               o_qp = add(24 * slots), o_ids = add(4 * R * (2 + 3 * cap)), o_slot = add(4 * slots), o_qi = add(4 * slots),
+               o_st = add(4 * R * 4), o_send = add(wb), o_recv = add(R * wb);
+  HIP_TRY(ctx, hipMalloc((void**)&g->d_fixed_block, off));
+  HIP_TRY(ctx, hipMemsetAsync(g->d_fixed_block, 0, off, ctx->stream));
+  char* d = g->d_fixed_block;
+  g->d_stage_meas = (double*)(d + o_sm); g->d_stage_info = (double*)(d + o_si);
+  g->d_tmp_meas = (double*)(d + o_tm); g->d_tmp_info = (double*)(d + o_ti);
+  g->d_meas_b = (double*)(d + o_mb); g->d_info_b = (double*)(d + o_ib);
+  g->d_est64 = (double*)(d + o_e64); g->d_info64 = (double*)(d + o_i64); g->d_qposes = (double*)(d + o_qp);
+  g->d_ids_out = (int32_t*)(d + o_ids); g->d_slot = (int32_t*)(d + o_slot); g->d_qidx = (int32_t*)(d + o_qi);
+  g->d_status_all = (int32_t*)(d + o_st);
+  g->d_send = (unsigned char*)(d + o_send); g->d_recv = (unsigned char*)(d + o_recv);
+  g->pinned_bytes = round256(wb) + round256(4 * R * (2 + 3 * cap)) + round256(4 * slots) + round256(24 * slots) + 4096;
+  HIP_TRY(ctx, hipHostMalloc((void**)&g->pinned, g->pinned_bytes, hipHostMallocDefault));
+  return 0;
+}
+
+void rebuild_all_edges(cgmr_graph* g) {
+  g->all_ef = g->ef;
+  g->all_et = g->et;
+  g->nB = 0;
+  for (int p = 0; p < g->n_robots; p++) {
+    g->all_ef.insert(g->all_ef.end(), g->in[p].from_idx.begin(), g->in[p].from_idx.end());
+    g->all_et.insert(g->all_et.end(), g->in[p].to_idx.begin(), g->in[p].to_idx.end());
+    g->nB += (int)g->in[p].slot.size();
+  }
+}
+
+void insert_sorted_unique(std::vector<int32_t>& v, const int32_t* ids, int n) {
+  v.insert(v.end(), ids, ids + n);
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
+// selectGaugeCentroid (condensed_graph_buffer.cpp:318-345): the vertex closest to the centroid of the requested
+// vertices' translations, first one (id order) wins ties
+int select_gauge_centroid(const std::vector<int32_t>& idx, const double* poses) {
+  double sx = 0, sy = 0;
+  for (int v : idx) { sx += poses[3 * (size_t)v]; sy += poses[3 * (size_t)v + 1]; }
+  const double cx = sx / (double)idx.size(), cy = sy / (double)idx.size();
+  int best = -1;
+  double bd = 1.79769313486231570815e308;
+  for (int v : idx) {
+    const double dx = poses[3 * (size_t)v] - cx, dy = poses[3 * (size_t)v + 1] - cy;
+    const double d = std::sqrt(dx * dx + dy * dy);
+    if (d < bd) { bd = d; best = v; }
+  }
+  return best;
+}
+
+// Shared tail of the two ingest paths.  per sender s: n_e / n_c and the ids as read from its buffer (ids layout of
+// k_wire_read).  Decides what is accepted (mr_graph_slam.cpp:331-395), refreshes the host structure and returns the
+// staging slots of the compact second edge segment.
+void ingest_decide(cgmr_graph* g, const int32_t* ids, std::vector<uint8_t>& accepted) {
+  const int R = g->n_robots, cap = g->cap;
+  accepted.assign(R, 0);
+  for (int s = 0; s < R; s++) {
+    if (s == g->robot) continue;
+    const int32_t* io = ids + (size_t)s * (2 + 3 * (size_t)cap);
+    const int n_e = io[0], n_c = io[1];
+    // closure requests: only vertices I have (mr_graph_slam.cpp:336-343); an empty set changes nothing (:345)
+    std::vector<int32_t> known;
+    for (int k = 0; k < n_c; k++) { const int32_t id = io[2 + 2 * cap + k]; if (g->index.count(id)) known.push_back(id); }
+    if (!known.empty()) insert_sorted_unique(g->out_closures[s], known.data(), (int)known.size());
+    // edges: both end points must exist (:360-363); the set replaces the previous one only if it is not empty (:393-394)
+    PeerIn nw;
+    for (int k = 0; k < n_e; k++) {
+      auto a = g->index.find(io[2 + 2 * k]), b = g->index.find(io[2 + 2 * k + 1]);
+      if (a == g->index.end() || b == g->index.end()) continue;
+      nw.slot.push_back(s * cap + k);
+      nw.from_idx.push_back(a->second);
+      nw.to_idx.push_back(b->second);
+    }
+    if (!nw.slot.empty()) { g->in[s] = std::move(nw); accepted[s] = 1; }
+  }
+  rebuild_all_edges(g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cgmr_graph_create(cgmr_ctx* ctx, int robot_id, int n_robots, int base_id, int cap_edges_per_peer, cgmr_graph** out) {
+  if (!out) return CGMR_E_INVALID;
+  *out = nullptr;
+  if (robot_id < 0 || n_robots < 1 || robot_id >= n_robots || n_robots > 64 || base_id < 1 || cap_edges_per_peer < 1 ||
+      cap_edges_per_peer > 2270)      // MAX_LENGTH_MSG = 100000 bytes holds about 2270 edges of 44 bytes (graph_comm.h)
+    return ctx ? set_err(ctx, CGMR_E_INVALID, "cgmr_graph_create: bad argument") : CGMR_E_INVALID;
+  cgmr_graph* g = new cgmr_graph();
+  g->ctx = ctx; g->robot = robot_id; g->n_robots = n_robots; g->base_id = base_id; g->cap = cap_edges_per_peer;
+  g->in.resize(n_robots); g->out.resize(n_robots);
+  g->out_closures.resize(n_robots); g->in_closures.resize(n_robots);
+  g->hs_meas.assign(3 * (size_t)n_robots * g->cap, 0.0);
+  g->hs_info.assign(6 * (size_t)n_robots * g->cap, 0.0);
+  if (ctx) {
+    if (hipSetDevice(ctx->device) != hipSuccess) { delete g; return CGMR_E_NO_DEVICE; }
+    int rc = alloc_fixed(g);
+    if (rc) { cgmr_graph_destroy(g); return rc; }
+  }
+  *out = g;
+  return CGMR_OK;
+}
+
+void cgmr_graph_destroy(cgmr_graph* g) {
+  if (!g) return;
+  if (g->ctx) {
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    for (DevBuf* b : {&g->d_poses, &g->d_meas_a, &g->d_info_a, &g->d_vids, &g->d_work})
+      if (b->ptr) (void)hipFree(b->ptr);
+    if (g->d_fixed_block) (void)hipFree(g->d_fixed_block);
+    if (g->pinned) (void)hipHostFree(g->pinned);
+  }
+  delete g;
+}
+
+const char* cgmr_graph_last_error(const cgmr_graph* g) { return g ? g->err.c_str() : "null graph"; }
+
+int cgmr_graph_add_vertices(cgmr_graph* g, int n, const int32_t* ids, const double* poses_xyt, const uint8_t* fixed) {
+  if (!g || n < 0 || (n > 0 && (!ids || !poses_xyt))) return CGMR_E_INVALID;
+  for (int k = 0; k < n; k++)
+    if (g->index.count(ids[k])) return gerr(g, CGMR_E_INVALID, "cgmr_graph_add_vertices: duplicate vertex id");
+  const size_t v0 = g->ids.size();
+  for (int k = 0; k < n; k++) {
+    g->index[ids[k]] = (int32_t)g->ids.size();
+    g->ids.push_back(ids[k]);
+    g->fixed.push_back(fixed ? fixed[k] : 0);
+  }
+  g->h_poses.insert(g->h_poses.end(), poses_xyt, poses_xyt + 3 * (size_t)n);
+  if (g->ctx && n > 0) {
+    cgmr_ctx* ctx = g->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = dev_grow(g, g->d_poses, 24 * v0, 24 * (v0 + n));
+    if (!rc) rc = dev_grow(g, g->d_vids, 4 * v0, 4 * (v0 + n));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_poses.ptr + 24 * v0, poses_xyt, 24 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_vids.ptr + 4 * v0, ids, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return CGMR_OK;
+}
+
+int cgmr_graph_add_edges(cgmr_graph* g, int n, const int32_t* from_ids, const int32_t* to_ids, const double* meas_xyt,
+                         const double* info_upper) {
+  if (!g || n < 0 || (n > 0 && (!from_ids || !to_ids || !meas_xyt || !info_upper))) return CGMR_E_INVALID;
+  const size_t e0 = g->ef.size();
+  for (int k = 0; k < n; k++) {
+    auto a = g->index.find(from_ids[k]), b = g->index.find(to_ids[k]);
+    if (a == g->index.end() || b == g->index.end()) {
+      g->ef.resize(e0); g->et.resize(e0);
+      return gerr(g, CGMR_E_INVALID, "cgmr_graph_add_edges: unknown vertex id");
+    }
+    g->ef.push_back(a->second);
+    g->et.push_back(b->second);
+  }
+  g->h_meas.insert(g->h_meas.end(), meas_xyt, meas_xyt + 3 * (size_t)n);
+  g->h_info.insert(g->h_info.end(), info_upper, info_upper + 6 * (size_t)n);
+  if (g->ctx && n > 0) {
+    cgmr_ctx* ctx = g->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = dev_grow(g, g->d_meas_a, 24 * e0, 24 * (e0 + n));
+    if (!rc) rc = dev_grow(g, g->d_info_a, 48 * e0, 48 * (e0 + n));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_meas_a.ptr + 24 * e0, meas_xyt, 24 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_info_a.ptr + 48 * e0, info_upper, 48 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  rebuild_all_edges(g);
+  return CGMR_OK;
+}
+
+int cgmr_graph_counts(const cgmr_graph* g, int32_t out[4]) {
+  if (!g || !out) return CGMR_E_INVALID;
+  out[0] = (int32_t)g->ids.size(); out[1] = (int32_t)g->ef.size(); out[2] = g->nB;
+  int np = 0;
+  for (int p = 0; p < g->n_robots; p++) np += g->out_closures[p].empty() ? 0 : 1;
+  out[3] = np;
+  return CGMR_OK;
+}
+
+// void GraphSLAM::optimize(int nrunnings) (src/slam/graph_slam.cpp:561-575) on the level-0 edges: own + received
+int cgmr_graph_optimize(cgmr_graph* g, int iters, double* chi2_out) {
+  if (!g || iters < 0) return CGMR_E_INVALID;
+  if (!g->ctx) return gerr(g, CGMR_E_NO_DEVICE, "cgmr_graph_optimize: the graph was created without a device context");
+  cgmr_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int nV = (int)g->ids.size(), nE = (int)g->all_ef.size();
+  if (nV == 0) return CGMR_OK;
+  GnEdges Ed;
+  Ed.meas_a = (const double*)g->d_meas_a.ptr; Ed.info_a = (const double*)g->d_info_a.ptr;
+  Ed.meas_b = g->d_meas_b; Ed.info_b = g->d_info_b;
+  Ed.nA = (int)g->ef.size(); Ed.n_active = nE;
+  const double t0 = wall_s();
+  int rc = gn_run(ctx, nV, (double*)g->d_poses.ptr, g->fixed.data(), nE, g->all_ef.data(), g->all_et.data(), Ed, iters, chi2_out);
+  g->last_optimize_seconds = wall_s() - t0;
+  return rc;
+}
+
+int cgmr_graph_get_poses(cgmr_graph* g, int first, int n, double* poses_out) {
+  if (!g || first < 0 || n < 0 || first + n > (int)g->ids.size() || (n > 0 && !poses_out)) return CGMR_E_INVALID;
+  if (g->ctx && n > 0) {
+    cgmr_ctx* ctx = g->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(g->h_poses.data() + 3 * (size_t)first, g->d_poses.ptr + 24 * (size_t)first, 24 * (size_t)n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (n) memcpy(poses_out, g->h_poses.data() + 3 * (size_t)first, 24 * (size_t)n);
+  return CGMR_OK;
+}
+
+int cgmr_graph_set_poses(cgmr_graph* g, int first, int n, const double* poses_xyt) {
+  if (!g || first < 0 || n < 0 || first + n > (int)g->ids.size() || (n > 0 && !poses_xyt)) return CGMR_E_INVALID;
+  if (n) memcpy(g->h_poses.data() + 3 * (size_t)first, poses_xyt, 24 * (size_t)n);
+  if (g->ctx && n > 0) {
+    cgmr_ctx* ctx = g->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_poses.ptr + 24 * (size_t)first, poses_xyt, 24 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CGMR_OK;
+}
+
+// CondensedGraphBuffer::insertInClosure (condensed_graph_buffer.cpp:131-150): ids of `peer`'s vertices I ask for
+int cgmr_graph_insert_in_closure(cgmr_graph* g, int peer, int n, const int32_t* vertex_ids) {
+  if (!g || peer < 0 || peer >= g->n_robots || n < 0 || (n > 0 && !vertex_ids)) return CGMR_E_INVALID;
+  insert_sorted_unique(g->in_closures[peer], vertex_ids, n);
+  return CGMR_OK;
+}
+
+// CondensedGraphBuffer::insertOutClosure (:152-170): ids of MY vertices `peer` asked for (unknown ids are dropped, as
+// MRGraphSLAM::addInterRobotData does before inserting, mr_graph_slam.cpp:336-343)
+int cgmr_graph_insert_out_closure(cgmr_graph* g, int peer, int n, const int32_t* vertex_ids) {
+  if (!g || peer < 0 || peer >= g->n_robots || n < 0 || (n > 0 && !vertex_ids)) return CGMR_E_INVALID;
+  std::vector<int32_t> known;
+  for (int k = 0; k < n; k++) if (g->index.count(vertex_ids[k])) known.push_back(vertex_ids[k]);
+  insert_sorted_unique(g->out_closures[peer], known.data(), (int)known.size());
+  return CGMR_OK;
+}
+
+int cgmr_graph_closures(const cgmr_graph* g, int peer, int which, int cap, int32_t* ids_out) {
+  if (!g || peer < 0 || peer >= g->n_robots || cap < 0 || (cap > 0 && !ids_out)) return CGMR_E_INVALID;
+  const std::vector<int32_t>& v = which ? g->in_closures[peer] : g->out_closures[peer];
+  for (int k = 0; k < (int)v.size() && k < cap; k++) ids_out[k] = v[k];
+  return (int)v.size();
+}
+
+// CondensedGraphBuffer::computeCondensedGraph(robot) (condensed_graph_buffer.cpp:437-485) for one peer or, with
+// peer < 0, for every peer that has asked for vertices: gauge = selectGaugeCentroid, edges = getMyEdges (own edges
+// only), CondensedGraphCreator::compute per peer.  One symbolic analysis (shared with cgmr_graph_optimize) serves all
+// peers: the gauge and the switched-off received edges are numeric masks.  The passes of all peers are queued on the
+// stream back to back; the labelled edges land in the send buffer as wire records.  Returns the number of peers built.
+int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
+  if (!g || peer >= g->n_robots) return CGMR_E_INVALID;
+  if (!g->ctx) return gerr(g, CGMR_E_NO_DEVICE, "cgmr_graph_compute_condensed: the graph was created without a device context");
+  cgmr_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const double t0 = wall_s();
+  const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), nE = (int)g->all_ef.size(), cap = g->cap;
+  struct Job { int peer; std::vector<int32_t> idx; int gauge; std::vector<int32_t> q; };
+  std::vector<Job> jobs;
+  for (int p = 0; p < g->n_robots; p++) {
+    if (p == g->robot || (peer >= 0 && p != peer)) continue;
+    Job J;
+    J.peer = p;
+    for (int32_t id : g->out_closures[p]) J.idx.push_back(g->index[id]);       // id order (VertexIDMap)
+    if (J.idx.size() < 2) { g->out[p].n = 0; g->out[p].host.clear(); g->out[p].host_valid = true; continue; }
+    if ((int)J.idx.size() - 1 > cap)
+      return gerr(g, CGMR_E_INVALID, "a peer asked for more vertices than the wire buffer holds (cap_edges_per_peer)");
+    jobs.push_back(std::move(J));
+  }
+  if (jobs.empty() || nA == 0) return 0;
+  // current estimates -> host (gauge selection, spanning-tree initial guess)
+  HIP_TRY(ctx, hipMemcpyAsync(g->h_poses.data(), g->d_poses.ptr, 24 * (size_t)nV, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  int rc = prepare_structure(ctx, nV, nE, g->all_ef.data(), g->all_et.data(), 1);
+  if (rc) return rc;
+  const Symbolic& S = ctx->sym;
+  GnDevice& D = ctx->gn;
+  const int nj = (int)jobs.size();
+  rc = dev_grow(g, g->d_work, 0, 24 * (size_t)nV * nj);
+  if (rc) return rc;
+  // marginals work space for the largest query set
+  int maxq = 0;
+  for (Job& J : jobs) maxq = std::max(maxq, (int)J.idx.size() - 1);
+  const int m_max = ((4 * maxq + 15) / 16) * 16, n = 3 * D.nf, chunk = 2048, nchunk = (n + chunk - 1) / chunk;
+  struct L2 { size_t off = 0; size_t add(size_t b) { off = (off + 255) & ~size_t(255); size_t o = off; off += b; return o; } } L;
+  const size_t o_qc = L.add(4 * (size_t)maxq * nj), o_Y = L.add(8 * (size_t)n * m_max),
+               o_U = L.add(8 * ((size_t)3 * S.rows.size() + 3) * m_max), o_part = L.add(8 * (size_t)nchunk * 16 * m_max),
+               o_G = L.add(8 * (size_t)16 * m_max), o_cov = L.add(72 * (size_t)maxq), o_fl = L.add(4 * (size_t)maxq);
+  rc = arena_reserve(ctx, ctx->io_arena, L.off + 256);
+  if (rc) return rc;
+  char* d = ctx->io_arena.ptr;
+  GnEdges Ed;
+  Ed.meas_a = (const double*)g->d_meas_a.ptr; Ed.info_a = (const double*)g->d_info_a.ptr;
+  Ed.meas_b = g->d_meas_b; Ed.info_b = g->d_info_b;
+  Ed.nA = nA; Ed.n_active = nA;                                  // getMyEdges: the received edges are switched off
+  std::vector<uint8_t> fixed(nV);
+  std::vector<double> work(3 * (size_t)nV);
+  std::vector<int32_t> qcol;
+  WireEdge* send_edges = reinterpret_cast<WireEdge*>(g->d_send + wire_edges_off(g->n_robots));
+  for (int i = 0; i < nj; i++) {
+    Job& J = jobs[i];
+    J.gauge = select_gauge_centroid(J.idx, g->h_poses.data());
+    for (int v : J.idx) if (v != J.gauge) J.q.push_back(v);
+    const int nq = (int)J.q.size();
+    // GraphManipulator::fixGauge + optimize(1) (graph_manipulator.cpp:62-124): only the gauge is fixed, spanning-tree
+    // initial guess over my own edges, one Gauss-Newton iteration; the marginals are those of that iteration's Hessian
+    std::fill(fixed.begin(), fixed.end(), 0);
+    fixed[J.gauge] = 1;
+    work = g->h_poses;
+    initial_guess_host(nV, work.data(), fixed.data(), nA, g->ef.data(), g->et.data(), g->h_meas.data());
+    double* d_work = (double*)(g->d_work.ptr + 24 * (size_t)nV * i);
+    HIP_TRY(ctx, hipMemcpyAsync(d_work, work.data(), 24 * (size_t)nV, hipMemcpyHostToDevice, st));
+    rc = prepare_pass(ctx, fixed.data(), nE, g->all_ef.data(), g->all_et.data(), nA, i, nj);
+    if (rc) return rc;
+    qcol.resize(nq);
+    for (int k = 0; k < nq; k++) qcol[k] = ctx->vmask[J.q[k]] ? -1 : S.vperm[J.q[k]];
+    int32_t* d_qc = (int32_t*)(d + o_qc) + (size_t)maxq * i;
+    int32_t* d_qv = g->d_qidx + (size_t)cap * i;
+    HIP_TRY(ctx, hipMemcpyAsync(d_qc, qcol.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_qv, J.q.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, st));
+    gn_pass(ctx, d_work, Ed, 0, false, true, /*write_l11c=*/true);
+    const int m = ((4 * nq + 15) / 16) * 16;
+    launch_marginals(st, D, nq, d_qc, m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part), (double*)(d + o_G),
+                     (double*)(d + o_cov), chunk, nchunk);
+    double* est64 = g->d_est64 + 3 * (size_t)cap * J.peer;
+    double* info64 = g->d_info64 + 6 * (size_t)cap * J.peer;
+    launch_label(st, nq, d_qv, J.gauge, d_work, (const double*)(d + o_cov), est64, info64, (int*)(d + o_fl));
+    launch_wire_write_edges(st, nq, g->ids[J.gauge], d_qv, (const int32_t*)g->d_vids.ptr, est64, info64,
+                            send_edges + (size_t)cap * J.peer);
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_status_all + i, D.status, 4, hipMemcpyDeviceToDevice, st));
+  }
+  std::vector<int32_t> status(nj, 0);
+  HIP_TRY(ctx, hipMemcpyAsync(status.data(), g->d_status_all, 4 * (size_t)nj, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipGetLastError());
+  for (int i = 0; i < nj; i++) {
+    PeerOut& O = g->out[jobs[i].peer];
+    if (status[i] != 0) { O.n = 0; O.host_valid = false; return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph"); }
+    O.n = (int)jobs[i].q.size();
+    O.gauge_id = g->ids[jobs[i].gauge];
+    O.to_idx = jobs[i].q;
+    O.host_valid = false;
+  }
+  g->last_condense_seconds = wall_s() - t0;
+  return nj;
+}
+
+// The condensed graph built for `peer`, in double precision (before the wire narrows it): returns the number of edges;
+// from_id_out = the gauge, to_ids_out [n], est_out [n*3], info_upper_out [n*6] (all nullable)
+int cgmr_graph_get_condensed(cgmr_graph* g, int peer, int cap, int32_t* from_id_out, int32_t* to_ids_out, double* est_out,
+                             double* info_upper_out) {
+  if (!g || peer < 0 || peer >= g->n_robots || cap < 0) return CGMR_E_INVALID;
+  PeerOut& O = g->out[peer];
+  const int n = std::min(O.n, cap);
+  if (from_id_out) *from_id_out = O.gauge_id;
+  if (O.host_valid) {               // set from the host (cgmr_graph_set_condensed): float32 is all there is
+    for (int k = 0; k < n; k++) {
+      if (to_ids_out) to_ids_out[k] = O.host[k].to;
+      if (est_out) for (int a = 0; a < 3; a++) est_out[3 * k + a] = O.host[k].est[a];
+      if (info_upper_out) for (int a = 0; a < 6; a++) info_upper_out[6 * k + a] = O.host[k].info[a];
+    }
+    return O.n;
+  }
+  if (!g->ctx) return O.n;
+  cgmr_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (to_ids_out) for (int k = 0; k < n; k++) to_ids_out[k] = g->ids[O.to_idx[k]];
+  if (est_out && n) HIP_TRY(ctx, hipMemcpyAsync(est_out, g->d_est64 + 3 * (size_t)g->cap * peer, 24 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (info_upper_out && n) HIP_TRY(ctx, hipMemcpyAsync(info_upper_out, g->d_info64 + 6 * (size_t)g->cap * peer, 48 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return O.n;
+}
+
+// Test / integration hook: install a condensed graph for `peer` from host data (what computeCondensedGraph would have
+// produced), in wire precision.
+int cgmr_graph_set_condensed(cgmr_graph* g, int peer, int n, int32_t from_id, const int32_t* to_ids, const float* est,
+                             const float* info_upper) {
+  if (!g || peer < 0 || peer >= g->n_robots || n < 0 || n > g->cap || (n > 0 && (!to_ids || !est || !info_upper))) return CGMR_E_INVALID;
+  PeerOut& O = g->out[peer];
+  O.n = n; O.gauge_id = from_id; O.host.resize(n); O.host_valid = true; O.to_idx.clear();
+  for (int k = 0; k < n; k++) {
+    O.host[k].from = from_id; O.host[k].to = to_ids[k];
+    memcpy(O.host[k].est, est + 3 * k, 12);
+    memcpy(O.host[k].info, info_upper + 6 * k, 24);
+  }
+  if (g->ctx && n > 0) {
+    cgmr_ctx* ctx = g->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    WireEdge* dst = reinterpret_cast<WireEdge*>(g->d_send + wire_edges_off(g->n_robots)) + (size_t)g->cap * peer;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, O.host.data(), sizeof(WireEdge) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CGMR_OK;
+}
+
+int64_t cgmr_graph_wire_bytes(const cgmr_graph* g) { return g ? (int64_t)wire_bytes(g->n_robots, g->cap) : -1; }
+
+namespace {
+// header + closure requests of this robot's wire buffer (host side)
+void fill_header(const cgmr_graph* g, unsigned char* buf) {
+  const int R = g->n_robots, cap = g->cap;
+  int32_t* hdr = reinterpret_cast<int32_t*>(buf);
+  hdr[0] = g->robot; hdr[1] = R;
+  int32_t* clos = reinterpret_cast<int32_t*>(buf + wire_clos_off(R, cap));
+  for (int p = 0; p < R; p++) {
+    hdr[2 + p] = g->out[p].n;
+    const std::vector<int32_t>& c = g->in_closures[p];
+    const int n = std::min((int)c.size(), cap);
+    hdr[2 + R + p] = n;
+    for (int k = 0; k < n; k++) clos[(size_t)p * cap + k] = c[k];
+  }
+}
+}  // namespace
+
+// Serialise this robot's round message (ComboMessage of condensed edges + closure requests, mr_graph_slam.cpp:527-562,
+// 607-670) into a device buffer of cgmr_graph_wire_bytes() bytes.  The edges are already in the graph's send buffer as
+// wire records (cgmr_graph_compute_condensed writes them there); the header and the request lists -- host bookkeeping --
+// are staged through pinned memory.  d_send_out may be NULL: the graph's own send buffer is then the message.
+int cgmr_graph_pack(cgmr_graph* g, void* d_send_out) {
+  if (!g) return CGMR_E_INVALID;
+  if (!g->ctx) return gerr(g, CGMR_E_NO_DEVICE, "cgmr_graph_pack: no device context (use cgmr_graph_pack_host)");
+  cgmr_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int R = g->n_robots, cap = g->cap;
+  for (int p = 0; p < R; p++)
+    if ((int)g->in_closures[p].size() > cap) return gerr(g, CGMR_E_INVALID, "more closure requests for a peer than the wire buffer holds (cap_edges_per_peer)");
+  const size_t wb = wire_bytes(R, cap);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));            // the pinned staging may still be in flight from the last round
+  memset(g->pinned, 0, wb);
+  fill_header(g, (unsigned char*)g->pinned);
+  HIP_TRY(ctx, hipMemcpyAsync(g->d_send, g->pinned, wire_edges_off(R), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(g->d_send + wire_clos_off(R, cap), g->pinned + wire_clos_off(R, cap), (size_t)R * cap * 4,
+                              hipMemcpyHostToDevice, ctx->stream));
+  if (d_send_out && d_send_out != (void*)g->d_send)
+    HIP_TRY(ctx, hipMemcpyAsync(d_send_out, g->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
+  return CGMR_OK;
+}
+
+void* cgmr_graph_send_buffer(cgmr_graph* g) { return g ? (void*)g->d_send : nullptr; }
+void* cgmr_graph_recv_buffer(cgmr_graph* g) { return g ? (void*)g->d_recv : nullptr; }
+
+// Host-memory variant (gloo / CPU tests): with a device context the device message is copied out, without one the
+// message is built from the host copies of the condensed graphs (cgmr_graph_set_condensed).
+int cgmr_graph_pack_host(cgmr_graph* g, void* send_out) {
+  if (!g || !send_out) return CGMR_E_INVALID;
+  const int R = g->n_robots, cap = g->cap;
+  const size_t wb = wire_bytes(R, cap);
+  if (g->ctx) {
+    int rc = cgmr_graph_pack(g, nullptr);
+    if (rc) return rc;
+    cgmr_ctx* ctx = g->ctx;
+    HIP_TRY(ctx, hipMemcpyAsync(send_out, g->d_send, wb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CGMR_OK;
+  }
+  for (int p = 0; p < R; p++) {
+    if ((int)g->in_closures[p].size() > cap) return gerr(g, CGMR_E_INVALID, "more closure requests for a peer than the wire buffer holds (cap_edges_per_peer)");
+    if (g->out[p].n > 0 && !g->out[p].host_valid) return gerr(g, CGMR_E_INVALID, "condensed graph not available on the host");
+  }
+  unsigned char* buf = (unsigned char*)send_out;
+  memset(buf, 0, wb);
+  fill_header(g, buf);
+  WireEdge* edges = reinterpret_cast<WireEdge*>(buf + wire_edges_off(R));
+  for (int p = 0; p < R; p++)
+    for (int k = 0; k < g->out[p].n; k++) edges[(size_t)p * cap + k] = g->out[p].host[k];
+  return CGMR_OK;
+}
+
+// MRGraphSLAM::addInterRobotData for the messages of all robots at once (mr_graph_slam.cpp:331-395): d_recv holds the
+// n_robots wire buffers in rank order (the all-gather's output).  Closure requests become out-closures; the edges
+// addressed to me whose end points I know replace the set previously received from that robot
+// (CondensedGraphBuffer::insertEdgesFromRobot, condensed_graph_buffer.cpp:487-510) -- an empty or fully unknown set
+// leaves the previous one in place (mr_graph_slam.cpp:393-394).  Numeric payload stays on the device (float32 ->
+// double, staging -> compact second edge segment); only ids and counts travel to the host.
+// n_edges_out (nullable) [n_robots]: accepted edges per sender this round (0 = nothing replaced).
+int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
+  if (!g) return CGMR_E_INVALID;
+  if (!g->ctx) return gerr(g, CGMR_E_NO_DEVICE, "cgmr_graph_ingest: no device context (use cgmr_graph_ingest_host)");
+  cgmr_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int R = g->n_robots, cap = g->cap;
+  const size_t wb = wire_bytes(R, cap), ids_bytes = 4 * (size_t)R * (2 + 3 * (size_t)cap);
+  const unsigned char* recv = d_recv ? (const unsigned char*)d_recv : g->d_recv;
+  launch_wire_read(st, R, cap, g->robot, wb, recv, g->d_tmp_meas, g->d_tmp_info, g->d_ids_out);
+  char* h_ids = g->pinned + round256(wb);
+  HIP_TRY(ctx, hipMemcpyAsync(h_ids, g->d_ids_out, ids_bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<uint8_t> accepted;
+  ingest_decide(g, (const int32_t*)h_ids, accepted);
+  for (int s = 0; s < R; s++) {
+    if (n_edges_out) n_edges_out[s] = accepted[s] ? (int32_t)g->in[s].slot.size() : 0;
+    if (!accepted[s]) continue;
+    const int n_e = ((const int32_t*)h_ids)[(size_t)s * (2 + 3 * (size_t)cap)];
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_stage_meas + 3 * (size_t)s * cap, g->d_tmp_meas + 3 * (size_t)s * cap, 24 * (size_t)n_e, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_stage_info + 6 * (size_t)s * cap, g->d_tmp_info + 6 * (size_t)s * cap, 48 * (size_t)n_e, hipMemcpyDeviceToDevice, st));
+  }
+  int32_t* h_slot = (int32_t*)(g->pinned + round256(wb) + round256(ids_bytes));
+  int j = 0;
+  for (int s = 0; s < R; s++) for (int32_t sl : g->in[s].slot) h_slot[j++] = sl;
+  if (j > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_slot, h_slot, 4 * (size_t)j, hipMemcpyHostToDevice, st));
+    launch_gather_edges(st, j, g->d_slot, g->d_stage_meas, g->d_stage_info, g->d_meas_b, g->d_info_b);
+  }
+  return CGMR_OK;
+}
+
+int cgmr_graph_ingest_host(cgmr_graph* g, const void* recv, int32_t* n_edges_out) {
+  if (!g || !recv) return CGMR_E_INVALID;
+  const int R = g->n_robots, cap = g->cap;
+  const size_t wb = wire_bytes(R, cap);
+  if (g->ctx) {
+    cgmr_ctx* ctx = g->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_recv, recv, (size_t)R * wb, hipMemcpyHostToDevice, ctx->stream));
+    return cgmr_graph_ingest(g, nullptr, n_edges_out);
+  }
+  // host-only mirror of k_wire_read + the staging copies
+  std::vector<int32_t> ids((size_t)R * (2 + 3 * (size_t)cap), 0);
+  std::vector<double> tm(3 * (size_t)R * cap), ti(6 * (size_t)R * cap);
+  for (int s = 0; s < R; s++) {
+    const unsigned char* buf = (const unsigned char*)recv + (size_t)s * wb;
+    const int32_t* hdr = (const int32_t*)buf;
+    int32_t* io = ids.data() + (size_t)s * (2 + 3 * (size_t)cap);
+    const bool ok = hdr[0] == s && s != g->robot;
+    const int n_e = std::min(std::max(hdr[2 + g->robot], 0), cap), n_c = std::min(std::max(hdr[2 + R + g->robot], 0), cap);
+    io[0] = ok ? n_e : 0; io[1] = ok ? n_c : 0;
+    const WireEdge* e = (const WireEdge*)(buf + wire_edges_off(R)) + (size_t)g->robot * cap;
+    const int32_t* c = (const int32_t*)(buf + wire_clos_off(R, cap)) + (size_t)g->robot * cap;
+    for (int k = 0; k < n_e; k++) {
+      io[2 + 2 * k] = e[k].from; io[2 + 2 * k + 1] = e[k].to;
+      for (int a = 0; a < 3; a++) tm[3 * ((size_t)s * cap + k) + a] = (double)e[k].est[a];
+      for (int a = 0; a < 6; a++) ti[6 * ((size_t)s * cap + k) + a] = (double)e[k].info[a];
+    }
+    for (int k = 0; k < n_c; k++) io[2 + 2 * cap + k] = c[k];
+  }
+  std::vector<uint8_t> accepted;
+  ingest_decide(g, ids.data(), accepted);
+  for (int s = 0; s < R; s++) {
+    if (n_edges_out) n_edges_out[s] = accepted[s] ? (int32_t)g->in[s].slot.size() : 0;
+    if (!accepted[s]) continue;
+    memcpy(g->hs_meas.data() + 3 * (size_t)s * cap, tm.data() + 3 * (size_t)s * cap, 24 * (size_t)cap);
+    memcpy(g->hs_info.data() + 6 * (size_t)s * cap, ti.data() + 6 * (size_t)s * cap, 48 * (size_t)cap);
+  }
+  return CGMR_OK;
+}
+
+// The edges currently held from `peer` (the second edge segment's slice): end point ids, measurement, information
+int cgmr_graph_received_edges(cgmr_graph* g, int peer, int cap, int32_t* from_ids_out, int32_t* to_ids_out, double* meas_out,
+                              double* info_upper_out) {
+  if (!g || peer < 0 || peer >= g->n_robots || cap < 0) return CGMR_E_INVALID;
+  const PeerIn& I = g->in[peer];
+  const int n = std::min((int)I.slot.size(), cap);
+  for (int k = 0; k < n; k++) {
+    if (from_ids_out) from_ids_out[k] = g->ids[I.from_idx[k]];
+    if (to_ids_out) to_ids_out[k] = g->ids[I.to_idx[k]];
+  }
+  if ((meas_out || info_upper_out) && n > 0) {
+    if (g->ctx) {
+      cgmr_ctx* ctx = g->ctx;
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      HIP_TRY(ctx, hipMemcpyAsync(g->hs_meas.data(), g->d_stage_meas, 24 * (size_t)g->n_robots * g->cap, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(g->hs_info.data(), g->d_stage_info, 48 * (size_t)g->n_robots * g->cap, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    for (int k = 0; k < n; k++) {
+      if (meas_out) memcpy(meas_out + 3 * k, g->hs_meas.data() + 3 * (size_t)I.slot[k], 24);
+      if (info_upper_out) memcpy(info_upper_out + 6 * k, g->hs_info.data() + 6 * (size_t)I.slot[k], 48);
+    }
+  }
+  return (int)I.slot.size();
+}
+
+int cgmr_graph_last_seconds(const cgmr_graph* g, double out[2]) {
+  if (!g || !out) return CGMR_E_INVALID;
+  out[0] = g->last_optimize_seconds; out[1] = g->last_condense_seconds;
+  return CGMR_OK;
+}
+
+}  // extern "C"

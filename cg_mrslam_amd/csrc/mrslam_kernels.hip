@@ -1,0 +1,110 @@
+// HIP kernels (gfx950) for the device-resident robot graph of the multi-robot path: wire (de)serialisation of the
+// condensed-graph exchange and the small gathers around it.
+//
+// Reference behaviour being replaced:
+//   msg_factory.h:78-112,200-218   EdgeArrayMessage::ESE2Data -- {int from, int to, estimate[3], information[6]},
+//                                  doubles narrowed to float32 on the wire: 44 bytes per edge
+//   mr_graph_slam.cpp:352-394      addInterRobotData: received edges become EdgeSE2 (float32 widened to double)
+//   condensed_graph_buffer.cpp:487-510  insertEdgesFromRobot: the newest set from a robot replaces the previous one
+// All of it is HBM-bound byte shuffling on a few KB per round: one thread per edge, coalesced 44-byte records.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mrslam_device.h"
+
+namespace cgmr {
+
+// condensed edges of one peer, labelled in FP64 (k_label_edges) -> 44-byte wire records in the send buffer
+__global__ void k_wire_write_edges(int n, int from_id, const int32_t* __restrict__ to_vertex,
+                                   const int32_t* __restrict__ vertex_ids, const double* __restrict__ est,
+                                   const double* __restrict__ info, WireEdge* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  WireEdge w;
+  w.from = from_id;
+  w.to = vertex_ids[to_vertex[k]];
+#pragma unroll
+  for (int a = 0; a < 3; a++) w.est[a] = (float)est[3 * k + a];          // msg_factory.h:97-112: double -> float
+#pragma unroll
+  for (int a = 0; a < 6; a++) w.info[a] = (float)info[6 * k + a];
+  out[k] = w;
+}
+
+// Received wire buffers of all ranks -> FP64 staging of the slices addressed to `me`, plus the (from, to) ids and the
+// closure requests of every sender in a compact array the host reads back (structure lives on the host).
+//   recv      [n_ranks][wire_bytes]
+//   stage_*   [n_ranks * cap] slots: sender s at s * cap
+//   ids_out   [n_ranks][2 + 3 * cap] int32: n_edges, n_closures, (from, to) * cap, closures * cap
+__global__ void k_wire_read(int n_ranks, int cap, int me, size_t wire_bytes, const unsigned char* __restrict__ recv,
+                            double* __restrict__ stage_meas, double* __restrict__ stage_info, int32_t* __restrict__ ids_out) {
+  const int s = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned char* buf = recv + (size_t)s * wire_bytes;
+  const int32_t* hdr = reinterpret_cast<const int32_t*>(buf);
+  const size_t o_edges = 4 * (size_t)(2 + 2 * n_ranks);
+  const size_t o_clos = o_edges + (size_t)n_ranks * cap * sizeof(WireEdge);
+  const int n_e = min(max(hdr[2 + me], 0), cap), n_c = min(max(hdr[2 + n_ranks + me], 0), cap);
+  int32_t* io = ids_out + (size_t)s * (2 + 3 * (size_t)cap);
+  if (k == 0) { io[0] = (hdr[0] == s && s != me) ? n_e : 0; io[1] = (hdr[0] == s && s != me) ? n_c : 0; }
+  if (k >= cap) return;
+  if (k < n_e) {
+    const WireEdge w = reinterpret_cast<const WireEdge*>(buf + o_edges)[(size_t)me * cap + k];
+    io[2 + 2 * k] = w.from;
+    io[2 + 2 * k + 1] = w.to;
+    double* m = stage_meas + 3 * ((size_t)s * cap + k);
+    double* f = stage_info + 6 * ((size_t)s * cap + k);
+#pragma unroll
+    for (int a = 0; a < 3; a++) m[a] = (double)w.est[a];
+#pragma unroll
+    for (int a = 0; a < 6; a++) f[a] = (double)w.info[a];
+  }
+  if (k < n_c) io[2 + 2 * cap + k] = reinterpret_cast<const int32_t*>(buf + o_clos)[(size_t)me * cap + k];
+}
+
+// dst[j] = src[slot[j]] for 3- and 6-double records (accepted received edges -> the compact second edge segment)
+__global__ void k_gather_edges(int n, const int32_t* __restrict__ slot, const double* __restrict__ src_meas,
+                               const double* __restrict__ src_info, double* __restrict__ dst_meas,
+                               double* __restrict__ dst_info) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int s = slot[j];
+#pragma unroll
+  for (int a = 0; a < 3; a++) dst_meas[3 * (size_t)j + a] = src_meas[3 * (size_t)s + a];
+#pragma unroll
+  for (int a = 0; a < 6; a++) dst_info[6 * (size_t)j + a] = src_info[6 * (size_t)s + a];
+}
+
+// out[k] = poses[idx[k]] (query vertices of all peers: the host picks the gauges from them)
+__global__ void k_gather_poses(int n, const int32_t* __restrict__ idx, const double* __restrict__ poses,
+                               double* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int v = idx[k];
+#pragma unroll
+  for (int a = 0; a < 3; a++) out[3 * (size_t)k + a] = poses[3 * (size_t)v + a];
+}
+
+void launch_wire_write_edges(hipStream_t st, int n, int from_id, const int32_t* to_vertex, const int32_t* vertex_ids,
+                             const double* est, const double* info, WireEdge* out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_wire_write_edges, dim3((n + 127) / 128), dim3(128), 0, st, n, from_id, to_vertex, vertex_ids, est, info, out);
+}
+
+void launch_wire_read(hipStream_t st, int n_ranks, int cap, int me, size_t wire_bytes, const unsigned char* recv,
+                      double* stage_meas, double* stage_info, int32_t* ids_out) {
+  hipLaunchKernelGGL(k_wire_read, dim3((cap + 127) / 128, n_ranks), dim3(128), 0, st, n_ranks, cap, me, wire_bytes, recv,
+                     stage_meas, stage_info, ids_out);
+}
+
+void launch_gather_edges(hipStream_t st, int n, const int32_t* slot, const double* src_meas, const double* src_info,
+                         double* dst_meas, double* dst_info) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_edges, dim3((n + 127) / 128), dim3(128), 0, st, n, slot, src_meas, src_info, dst_meas, dst_info);
+}
+
+void launch_gather_poses(hipStream_t st, int n, const int32_t* idx, const double* poses, double* out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_poses, dim3((n + 127) / 128), dim3(128), 0, st, n, idx, poses, out);
+}
+
+}  // namespace cgmr

@@ -51,9 +51,23 @@ def normalize_theta(t):
     return t - 2 * math.pi * math.floor((t + math.pi) / (2 * math.pi))
 
 
+class ScanSet(C.Structure):
+    """``cgmr_scan_set`` (include/cgmr.h): the flat form of a g2o VertexSet with RobotLaser data + its reference vertex."""
+    _fields_ = [("n_scans", C.c_int), ("ranges", C.c_void_p), ("poses_xyt", C.c_void_p), ("ref_index", C.c_int)]
+
+
+def _scan_set(scans, ref_index):
+    """scans: list of (ranges, pose).  Returns (ScanSet, keep-alive arrays)."""
+    ranges = np.ascontiguousarray(np.stack([np.asarray(r, dtype=np.float32) for r, _ in scans]), dtype=np.float32)
+    poses = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for _, p in scans]), dtype=np.float64)
+    s = ScanSet(len(scans), C.c_void_p(ranges.ctypes.data), C.c_void_p(poses.ctypes.data), int(ref_index))
+    return s, (ranges, poses)
+
+
 class _GenericSearch:
-    """Searches every ScanMatcher can run (grid/kernel taken from ``self.cfg``).  Scans are passed as
-    ``(ranges, vertex_pose)`` pairs, the flat-array form of a g2o VertexSet with RobotLaser user data."""
+    """The ScanMatcher member functions every matcher can run (grid / kernel / laser taken from ``self.cfg``), thin
+    callers of the C ABI (csrc/matcher_api.cpp does the region / transform bookkeeping, the GPU the searches).  Scans
+    are passed as ``(ranges, vertex_pose)`` pairs, the flat-array form of a g2o VertexSet with RobotLaser user data."""
 
     # ---- host helpers with the reference's arithmetic (libcgmr.so, no GPU) -----------------------------------
     def cartesian(self, ranges):
@@ -80,17 +94,13 @@ class _GenericSearch:
 
     def transformPointsFromVSet(self, scans, ref_index):   # noqa: N802  (scan_matcher.cpp:89-110)
         """scans: list of (ranges, pose) in the caller's (id-ordered) iteration order; ref_index: the reference vertex."""
-        lp = np.array([self.cfg.laser_pose[k] for k in range(3)])
-        ref_pose = np.asarray(scans[ref_index][1], dtype=np.float64)
-        out = []
-        for k, (ranges, pose) in enumerate(scans):
-            v = self.cartesian(ranges)
-            if k == ref_index:
-                out.append(self.applyTransfToScan(lp, v))
-            else:
-                trel = _se2_mul(_se2_inv(ref_pose), np.asarray(pose, dtype=np.float64))
-                out.append(self.applyTransfToScan(_se2_mul(trel, lp), v))
-        return np.concatenate(out) if out else np.zeros((0, 2))
+        s, keep = _scan_set(scans, ref_index)
+        cap = len(scans) * int(self.cfg.n_beams)
+        out = np.zeros((max(cap, 1), 2))
+        n = self.ctx.lib.cgmr_transform_points_from_vset(C.byref(self.cfg), C.byref(s), C.c_void_p(out.ctypes.data), C.c_int(cap))
+        if n < 0:
+            raise CgmrError(n, "cgmr_transform_points_from_vset: bad scan set")
+        return out[:n].copy()
 
     # ---- CharGrid::greedySearch / hierarchicalSearch on the GPU ---------------------------------------------
     def greedySearch(self, ref_pts, qry_pts, regions, thetaRes, maxScore, dx, dy, dth, step=None, cap=65536):   # noqa: N802,N803
@@ -109,106 +119,72 @@ class _GenericSearch:
         m = min(n.value, cap)
         return np.array([[buf[k].x, buf[k].y, buf[k].theta, buf[k].score] for k in range(m)]).reshape(-1, 4)
 
-    def hierarchicalSearch(self, ref_pts, qry_pts, regions, thetaRes, maxScore, dx, dy, dth, nLevels):   # noqa: N802,N803
-        """chargrid.cpp:310-344 + 376-400: coarse-to-fine, every surviving result seeds a region of the next level."""
-        res_f = float(np.float32(self.cfg.resolution))
-        cur = np.ascontiguousarray(regions, dtype=np.float32).reshape(-1, 6)
-        out = np.zeros((0, 4))
-        for lv in range(nLevels):
-            i = nLevels - 1 - lv
-            m = 2 ** i
-            mtheta = m if m // 2 < 1 else m // 2
-            last = lv == nLevels - 1
-            if last and len(out) == 0:
-                break                                   # the last level only runs if the previous one found something
-            out = self.greedySearch(ref_pts, qry_pts, cur, mtheta * thetaRes, maxScore, dx * m, dy * m, dth * m,
-                                    step=float(np.float32(m) * np.float32(res_f)))
-            if last or len(out) == 0:
-                break
-            half = np.array([dx * m, dy * m, dth * m]) * .5
-            cur = np.concatenate([(-half + out[:, :3]).astype(np.float32), (half + out[:, :3]).astype(np.float32)], axis=1)
-        return out
+    def hierarchicalSearch(self, ref_pts, qry_pts, regions, thetaRes, maxScore, dx, dy, dth, nLevels, cap=65536):   # noqa: N802,N803
+        """CharGrid::hierarchicalSearch (chargrid.cpp:310-344, 376-400) through ``cgmr_match_hierarchical``."""
+        ref = np.ascontiguousarray(ref_pts, dtype=np.float64).reshape(-1, 2)
+        qry = np.ascontiguousarray(qry_pts, dtype=np.float64).reshape(-1, 2)
+        reg = np.ascontiguousarray(regions, dtype=np.float32).reshape(-1, 6)
+        buf = (MatchResult * cap)()
+        n = C.c_int(0)
+        rc = self.ctx.lib.cgmr_match_hierarchical(self.ctx.h, C.byref(self.cfg), C.c_int(len(ref)), C.c_void_p(ref.ctypes.data),
+                                                  C.c_int(len(qry)), C.c_void_p(qry.ctypes.data), C.c_int(len(reg)),
+                                                  C.c_void_p(reg.ctypes.data), C.c_double(thetaRes), C.c_double(maxScore),
+                                                  C.c_double(dx), C.c_double(dy), C.c_double(dth), C.c_int(nLevels), buf,
+                                                  C.c_int(cap), C.byref(n))
+        self.ctx._check(rc)
+        m = min(n.value, cap)
+        return np.array([[buf[k].x, buf[k].y, buf[k].theta, buf[k].score] for k in range(m)]).reshape(-1, 4)
 
     # ---- ScanMatcher::scanMatchingLC (scan_matcher.cpp:201-294) ---------------------------------------------
     def scanMatchingLC(self, ref_scans, ref_index, cur_scans, cur_index, maxScore):   # noqa: N802,N803
         """Returns the list of SE2 (x, y, theta) the reference pushes into ``trel`` (0-2 entries)."""
-        ref_pts = self.transformPointsFromVSet(ref_scans, ref_index)
-        qry = self.subsample(self.transformPointsFromVSet(cur_scans, cur_index), 0.1)
-        ref_pose = np.asarray(ref_scans[ref_index][1], dtype=np.float64)
-        regions, regionspi = [], []
-        for k, (_, pose) in enumerate(ref_scans):
-            rel = np.zeros(3) if k == ref_index else _se2_mul(_se2_inv(ref_pose), np.asarray(pose, dtype=np.float64))
-            lower = np.array([-.5 + rel[0], -1.5 + rel[1], -0.8 + rel[2]], dtype=np.float32)
-            upper = np.array([.5 + rel[0], 1.5 + rel[1], 0.8 + rel[2]], dtype=np.float32)
-            regions.append(np.concatenate([lower, upper]))
-            lower2, upper2 = lower.copy(), upper.copy()
-            lower2[2] += np.float32(np.pi)           # Vector3f += M_PI: float arithmetic
-            upper2[2] += np.float32(np.pi)
-            regionspi.append(np.concatenate([lower2, upper2]))
-        theta_res, dx, dy, dth = 0.025, 0.5, 0.5, 0.2
-        merged = {}
-        for regs in (regions, regionspi):
-            res = self.greedySearch(ref_pts, qry, np.array(regs), theta_res, maxScore, dx, dy, dth)
-            if len(res):
-                best = res[0].copy()
-                best[2] = normalize_theta(best[2])
-                key = (int(best[0] / dx), int(best[1] / dy), int(best[2] / dth))
-                if key not in merged or merged[key][3] > best[3]:     # addToPrunedMap
-                    merged[key] = best
-        return [merged[k][:3].copy() for k in sorted(merged)]
+        a, ka = _scan_set(ref_scans, ref_index)
+        b, kb = _scan_set(cur_scans, cur_index)
+        out = np.zeros((2, 3))
+        n = C.c_int(0)
+        rc = self.ctx.lib.cgmr_scan_matching_lc(self.ctx.h, C.byref(self.cfg), C.byref(a), C.byref(b), C.c_double(maxScore),
+                                                C.c_void_p(out.ctypes.data), C.byref(n))
+        self.ctx._check(rc)
+        return [out[k].copy() for k in range(n.value)]
 
     # ---- ScanMatcher::globalMatching (scan_matcher.cpp:366-428) ---------------------------------------------
     def globalMatching(self, ref_scans, ref_index, cur_scans, cur_index, maxScore):   # noqa: N802,N803
-        ref_pts = self.transformPointsFromVSet(ref_scans, ref_index)
-        qry = self.subsample(self.transformPointsFromVSet(cur_scans, cur_index), 0.1)
-        region = np.array([[-10, -5, np.float32(-np.pi), 10, 5, np.float32(np.pi)]], dtype=np.float32)
-        res = self.hierarchicalSearch(ref_pts, qry, region, 0.025, maxScore, 0.5, 0.5, 0.2, 4)
-        if len(res):
-            return True, res[0, :3].copy()
-        return False, None
-
-
+        a, ka = _scan_set(ref_scans, ref_index)
+        b, kb = _scan_set(cur_scans, cur_index)
+        out = np.zeros(3)
+        found = C.c_int(0)
+        rc = self.ctx.lib.cgmr_global_matching(self.ctx.h, C.byref(self.cfg), C.byref(a), C.byref(b), C.c_double(maxScore),
+                                               C.c_void_p(out.ctypes.data), C.byref(found))
+        self.ctx._check(rc)
+        return (True, out.copy()) if found.value else (False, None)
 
     # ---- ScanMatcher::closeScanMatching with a multi-scan reference set (scan_matcher.cpp:112-189) ---------------
     def closeScanMatchingVSet(self, ref_scans, origin_index, cur_ranges, cur_pose, maxScore=0.15):   # noqa: N802,N803
         """The reference's call shape: up to 6 reference scans (graph_slam.cpp:230-241) rasterised in the frame of the
         origin vertex, the current scan subsampled, window around origin^-1 * current.  Returns (found, trel)."""
-        ref_pts = self.transformPointsFromVSet(ref_scans, origin_index)
-        lp = np.array([self.cfg.laser_pose[k] for k in range(3)])
-        qry = self.applyTransfToScan(lp, self.subsample(self.cartesian(cur_ranges), 0.1))
-        g = _se2_mul(_se2_inv(np.asarray(ref_scans[origin_index][1], dtype=np.float64)), np.asarray(cur_pose, dtype=np.float64))
-        region = np.array([[-.3 + g[0], -.3 + g[1], -0.2 + g[2], .3 + g[0], .3 + g[1], 0.2 + g[2]]], dtype=np.float32)
-        res = self.greedySearch(ref_pts, qry, region, 0.0125 * .5, maxScore, 0.5, 0.5, 0.2)
-        if len(res):
-            return True, res[0, :3].copy()
-        return False, None
+        a, ka = _scan_set(ref_scans, origin_index)
+        cur = np.ascontiguousarray(cur_ranges, dtype=np.float32)
+        pose = np.ascontiguousarray(cur_pose, dtype=np.float64)
+        out = np.zeros(3)
+        found = C.c_int(0)
+        rc = self.ctx.lib.cgmr_close_scan_matching(self.ctx.h, C.byref(self.cfg), C.byref(a), C.c_void_p(cur.ctypes.data),
+                                                   C.c_void_p(pose.ctypes.data), C.c_double(maxScore),
+                                                   C.c_void_p(out.ctypes.data), C.byref(found))
+        self.ctx._check(rc)
+        return (True, out.copy()) if found.value else (False, None)
 
     # ---- ScanMatcher::verifyMatching (scan_matcher.cpp:430-505) --------------------------------------------------
-    def verifyMatching(self, scans1, ref1_index, scans2, ref2_index, trel12, threshold=40.0):   # noqa: N802
+    def verifyMatching(self, scans1, ref1_index, scans2, ref2_index, trel12):   # noqa: N802
         """Returns (accepted, score).  ``trel12``: pose of reference vertex 2 in the frame of reference vertex 1."""
-        lp = np.array([self.cfg.laser_pose[k] for k in range(3)])
-        trel12 = np.asarray(trel12, dtype=np.float64)
-        ref2_pose = np.asarray(scans2[ref2_index][1], dtype=np.float64)
-        pts2 = []
-        for k, (ranges, pose) in enumerate(scans2):
-            v = self.cartesian(ranges)
-            if k == ref2_index:
-                pts2.append(self.applyTransfToScan(_se2_mul(trel12, lp), v))
-            else:
-                t = _se2_mul(_se2_mul(trel12, _se2_mul(_se2_inv(ref2_pose), np.asarray(pose, dtype=np.float64))), lp)
-                pts2.append(self.applyTransfToScan(t, v))
-        pts2 = np.ascontiguousarray(np.concatenate(pts2))
-        pts1 = np.ascontiguousarray(self.transformPointsFromVSet(scans1, ref1_index))
-        lower = np.array([-.3 + trel12[0], -.3 + trel12[1]], dtype=np.float32)
-        upper = np.array([.3 + trel12[0], .3 + trel12[1]], dtype=np.float32)
+        a, ka = _scan_set(scans1, ref1_index)
+        b, kb = _scan_set(scans2, ref2_index)
+        t = np.ascontiguousarray(trel12, dtype=np.float64)
         score = C.c_double()
-        nnm = C.c_int()
-        rc = self.ctx.lib.cgmr_match_verify(self.ctx.h, C.byref(self.cfg), C.c_int(len(pts2)), C.c_void_p(pts2.ctypes.data),
-                                            C.c_int(len(pts1)), C.c_void_p(pts1.ctypes.data), C.c_double(0.3),
-                                            C.c_void_p(lower.ctypes.data), C.c_void_p(upper.ctypes.data), C.byref(score),
-                                            C.byref(nnm))
+        acc = C.c_int()
+        rc = self.ctx.lib.cgmr_verify_matching(self.ctx.h, C.byref(self.cfg), C.byref(a), C.byref(b), C.c_void_p(t.ctypes.data),
+                                               C.byref(score), C.byref(acc))
         self.ctx._check(rc)
-        return score.value <= threshold, score.value
+        return bool(acc.value), score.value
 
 
 class ScanMatcher(_GenericSearch):

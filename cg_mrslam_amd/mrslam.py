@@ -1,0 +1,168 @@
+"""Round driver of the multi-robot path on synthetic worlds (BASELINE.json configs C4 / C5).
+
+The reference's ``cg_mrslam`` node (src/cg_mrslam.cpp:206-259) adds a key frame, looks for constraints, optimises and
+-- from its communication threads (src/mrslam/graph_comm.cpp:126-208) -- sends every robot in range a ComboMessage
+with the condensed graph built for it and the list of vertices it wants condensed in return
+(src/mrslam/mr_graph_slam.cpp:527-562, 607-670); incoming messages are digested by
+``MRGraphSLAM::addInterRobotData`` (src/mrslam/mr_graph_slam.cpp:331-395).  Here the same protocol runs in rounds, one
+round every ``chunk`` new vertices (C5: 50), one rank = one robot = one GPU:
+
+    grow           the robot's own sub-graph gains ``chunk`` vertices, their odometry / loop-closure edges and the
+                   inter-robot closures that became possible (both end points exist): a foreign vertex + an edge
+                   own -> foreign, information diag(100, 100, 1000) (mr_graph_slam.cpp:234-236), a closure request
+    optimize(5)    local solve on own + received level-0 edges
+    ingest         what the previous round's all-gather delivered (one round of latency, like a UDP message that
+                   arrives while the robot is busy): requests -> out-closures, newest edge set per peer replaces the old
+    condense       one star of condensed edges per peer that has asked (own edges only)
+    exchange       one all-gather of the 44-byte/edge wire buffers, issued on a side stream: it overlaps with the
+                   next round's grow + optimize
+
+``RobotRounds`` drives one robot through any object with the ``RobotGraph`` interface (the product:
+``cg_mrslam_amd.condensed.RobotGraph``; the tests also run ``tests/ref_condensed.RefRobotGraph`` on the CPU oracle
+through the very same rounds and compare edge by edge).  All numerics are behind that interface.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import synth
+
+INTER_ROBOT_INFO = np.array([100.0, 0, 0, 100.0, 0, 1000.0])     # mr_graph_slam.cpp:234-236, 310-312
+
+
+class RobotWorld:
+    """Robot ``r``'s share of a ``synth.make_multi_robot`` world, served in increments of ``chunk`` vertices."""
+
+    def __init__(self, robots, r, chunk=50, base_id=10000):
+        g = robots[r]
+        self.r, self.chunk, self.base_id = r, chunk, base_id
+        self.n_own = int(g["n_own"])
+        self.n_rounds = (self.n_own + chunk - 1) // chunk
+        self.ids = g["ids"][:self.n_own].astype(np.int64)
+        self.truth0 = g["truth"][0].copy()
+        n_e = len(g["edge_from"])
+        self.ef, self.et = g["edge_from"].astype(np.int64), g["edge_to"].astype(np.int64)
+        self.meas, self.info = g["meas"], g["info"]
+        # own edge k becomes available in the round that adds its later end point
+        self.e_round = np.maximum(self.ef, self.et) // chunk
+        self.e_order = np.argsort(self.e_round, kind="stable")
+        self.e_ptr = np.searchsorted(self.e_round[self.e_order], np.arange(self.n_rounds + 1))
+        # inter-robot closures: own vertex i -> copy of peer p's vertex j; possible once both exist
+        ci = g["ef_all"][n_e:].astype(np.int64)
+        fid = g["ids"][g["et_all"][n_e:]].astype(np.int64)
+        self.c_own, self.c_fid = ci, fid
+        self.c_meas, self.c_info = g["meas_all"][n_e:], g["info_all"][n_e:]
+        self.c_round = np.maximum(ci, fid % base_id) // chunk
+        self.c_order = np.argsort(self.c_round, kind="stable")
+        self.c_ptr = np.searchsorted(self.c_round[self.c_order], np.arange(self.n_rounds + 1))
+
+    def increment(self, t):
+        """Round ``t`` (0-based): (first new own vertex, one past the last, own-edge indices, closure indices)."""
+        v0, v1 = t * self.chunk, min(self.n_own, (t + 1) * self.chunk)
+        return v0, v1, self.e_order[self.e_ptr[t]:self.e_ptr[t + 1]], self.c_order[self.c_ptr[t]:self.c_ptr[t + 1]]
+
+
+class RobotRounds:
+    """One robot of the round protocol above on ``graph`` (``RobotGraph`` interface)."""
+
+    def __init__(self, graph, world: RobotWorld, iterations: int = 5):
+        self.g, self.w, self.iterations = graph, world, iterations
+        self.t = 0
+        self.foreign = {}             # foreign vertex id -> True once it is in the graph
+        self.n_vertices = 0
+        self.last_status, self.last_chi2 = 0, None
+
+    def grow(self):
+        """Add round ``t``'s increment.  New own vertices are dead-reckoned from the newest vertex' current estimate,
+        new foreign vertices from the current estimate of the own vertex that saw them (closure measurement)."""
+        g, w, t = self.g, self.w, self.t
+        v0, v1, e_idx, c_idx = w.increment(t)
+        if v0 == 0:
+            prev = w.truth0.copy()
+            new = [prev]
+            first = 1
+        else:
+            prev = g.poses(self._own_slot[v0 - 1], 1)[0]
+            new, first = [], v0
+        for k in range(first, v1):
+            prev = synth.se2_compose(prev[None], w.meas[k - 1][None])[0]       # odometry edge k-1: (k-1) -> k
+            new.append(prev)
+        fixed = np.zeros(v1 - v0, dtype=np.uint8)
+        if v0 == 0:
+            fixed[0] = 1                                                        # the robot's first vertex is its gauge
+            self._own_slot = {}
+        g.add_vertices(w.ids[v0:v1], np.array(new).reshape(-1, 3), fixed)
+        for k in range(v0, v1):
+            self._own_slot[k] = self.n_vertices + (k - v0)
+        self.n_vertices += v1 - v0
+        if len(e_idx):
+            g.add_edges(w.ids[w.ef[e_idx]], w.ids[w.et[e_idx]], w.meas[e_idx], w.info[e_idx])
+        # inter-robot closures that became possible
+        if len(c_idx):
+            new_f_ids, new_f_pose, req = [], [], {}
+            for c in c_idx:
+                fid = int(w.c_fid[c])
+                if fid not in self.foreign:
+                    self.foreign[fid] = True
+                    own_pose = g.poses(self._own_slot[int(w.c_own[c])], 1)[0]
+                    new_f_ids.append(fid)
+                    new_f_pose.append(synth.se2_compose(own_pose[None], w.c_meas[c][None])[0])
+                    req.setdefault(fid // w.base_id, []).append(fid)
+            if new_f_ids:
+                g.add_vertices(np.array(new_f_ids), np.array(new_f_pose).reshape(-1, 3), None)
+                self.n_vertices += len(new_f_ids)
+            g.add_edges(w.ids[w.c_own[c_idx]], w.c_fid[c_idx], w.c_meas[c_idx], w.c_info[c_idx])
+            for p, ids in req.items():
+                g.insertInClosure(p, np.array(ids))                            # ask p for condensed edges among them
+        self.t += 1
+
+    def optimize(self):
+        self.last_status, self.last_chi2 = self.g.optimize(self.iterations)
+        return self.last_status
+
+    def condense(self):
+        return self.g.computeCondensedGraph(-1)
+
+    def round(self, exchange):
+        """One full round against an ``Exchange``-like object (``start()`` / ``finish()``)."""
+        self.grow()
+        self.optimize()
+        n_in = exchange.finish()            # previous round's all-gather: it ran while this round grew and solved
+        built = self.condense()
+        exchange.start()
+        return n_in, built
+
+
+class LoopbackExchange:
+    """All robots in one process (tests, single-GPU dry runs): the 'all-gather' is a concatenation of host buffers."""
+
+    def __init__(self, graphs):
+        self.graphs = graphs
+        self.wire = None
+
+    def start_all(self):
+        self.wire = np.concatenate([g.pack_host() for g in self.graphs])
+
+    def finish_all(self):
+        if self.wire is None:
+            return None
+        out = [g.ingest_host(self.wire) for g in self.graphs]
+        self.wire = None
+        return out
+
+
+def run_rounds_loopback(rounds, n_rounds):
+    """Drive several ``RobotRounds`` (one per robot, same process) through ``n_rounds`` rounds with a loopback exchange,
+    in the order a real run has: everybody grows and solves, then ingests the previous round, condenses, exchanges."""
+    ex = LoopbackExchange([r.g for r in rounds])
+    log = []
+    for _ in range(n_rounds):
+        for r in rounds:
+            r.grow()
+            r.optimize()
+        n_in = ex.finish_all()
+        built = [r.condense() for r in rounds]
+        ex.start_all()
+        log.append((n_in, built, [float(r.last_chi2[-1]) for r in rounds]))
+    ex.finish_all()
+    return log

@@ -453,3 +453,87 @@ def make_lattice_graph(n: int = 60, seed: int = 5, spacing: float = 1.0):
     fixed = np.zeros(V, dtype=np.uint8)
     fixed[0] = 1
     return dict(truth=truth, poses=poses, fixed=fixed, edge_from=e_from, edge_to=e_to, meas=meas, info=info)
+
+
+def make_scan_pairs_device(n_pairs: int, seed: int, device, n_beams: int = LASER_BEAMS, range_noise: float = 0.01,
+                           chunk: int = 16384):
+    """The C3 recipe of ``make_scan_pairs`` evaluated on the GPU with torch (workload generator of the benchmark: 10^6
+    *distinct* pairs would take a quarter of an hour in numpy).  Same room / box / pose / guess distributions, torch's
+    own generator instead of the counter-based one, so the pairs are not those of ``make_scan_pairs``.
+    Returns device tensors: ranges_ref, ranges_qry (P, n_beams) float32; guess, true_rel (P, 3) float64."""
+    import torch
+    P = int(n_pairs)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    ref = torch.empty((P, n_beams), dtype=torch.float32, device=device)
+    qry = torch.empty((P, n_beams), dtype=torch.float32, device=device)
+    guess = torch.empty((P, 3), dtype=torch.float64, device=device)
+    true_rel = torch.empty((P, 3), dtype=torch.float64, device=device)
+    ang0 = LASER_ANGLE_MIN + LASER_ANGLE_INC * torch.arange(n_beams, dtype=torch.float64, device=device)
+
+    def compose(a, b):
+        c, s = torch.cos(a[:, 2]), torch.sin(a[:, 2])
+        t = a[:, 2] + b[:, 2]
+        t = t - 2 * np.pi * torch.floor((t + np.pi) / (2 * np.pi))
+        return torch.stack([a[:, 0] + c * b[:, 0] - s * b[:, 1], a[:, 1] + s * b[:, 0] + c * b[:, 1], t], dim=1)
+
+    def raycast(pose, boxes, valid):
+        """pose (n,3); boxes (n,5,4) x0 y0 x1 y1; valid (n,5) bool -> (n, n_beams) distance to the nearest wall."""
+        a = pose[:, 2:3] + ang0[None, :]
+        dx, dy = torch.cos(a), torch.sin(a)
+        px, py = pose[:, 0:1], pose[:, 1:2]
+        best = torch.full_like(a, LASER_MAX_RANGE * 2.0)
+        for b in range(boxes.shape[1]):
+            x0, y0, x1, y1 = (boxes[:, b, k:k + 1] for k in range(4))
+            vb = valid[:, b:b + 1]
+            for xw in (x0, x1):
+                t = (xw - px) / dx
+                yy = py + t * dy
+                ok = vb & (t > 1e-9) & (yy >= y0) & (yy <= y1) & (t < best)
+                best = torch.where(ok, t, best)
+            for yw in (y0, y1):
+                t = (yw - py) / dy
+                xx = px + t * dx
+                ok = vb & (t > 1e-9) & (xx >= x0) & (xx <= x1) & (t < best)
+                best = torch.where(ok, t, best)
+        return best
+
+    for p0 in range(0, P, chunk):
+        n = min(chunk, P - p0)
+        u = torch.rand((n, 32), dtype=torch.float64, device=device, generator=gen)
+        w, h = 6.0 + 14.0 * u[:, 0], 6.0 + 14.0 * u[:, 1]
+        nb = (u[:, 2] * 5).to(torch.int64)
+        boxes = torch.zeros((n, 5, 4), dtype=torch.float64, device=device)
+        valid = torch.zeros((n, 5), dtype=torch.bool, device=device)
+        boxes[:, 0] = torch.stack([-w / 2, -h / 2, w / 2, h / 2], dim=1)
+        valid[:, 0] = True
+        for b in range(4):
+            bw, bh = 0.5 + 1.5 * u[:, 3 + 4 * b], 0.5 + 1.5 * u[:, 4 + 4 * b]
+            cx, cy = (u[:, 5 + 4 * b] - 0.5) * (w - bw - 1.0), (u[:, 6 + 4 * b] - 0.5) * (h - bh - 1.0)
+            boxes[:, 1 + b] = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], dim=1)
+            valid[:, 1 + b] = nb > b
+        # first pose in the middle third of the room, pushed out of the interior boxes (up to 8 attempts)
+        p1 = torch.zeros((n, 3), dtype=torch.float64, device=device)
+        done = torch.zeros(n, dtype=torch.bool, device=device)
+        for attempt in range(8):
+            ax = torch.remainder(u[:, 23] - 0.5 + 0.11 * attempt, 1.0) - 0.5
+            ay = torch.remainder(u[:, 24] - 0.5 + 0.07 * attempt, 1.0) - 0.5
+            cand = torch.stack([ax * w / 3, ay * h / 3, (u[:, 25] - 0.5) * 2 * np.pi], dim=1)
+            inside = torch.zeros(n, dtype=torch.bool, device=device)
+            for b in range(1, 5):
+                inside |= valid[:, b] & (boxes[:, b, 0] - 0.6 < cand[:, 0]) & (cand[:, 0] < boxes[:, b, 2] + 0.6) & \
+                          (boxes[:, b, 1] - 0.6 < cand[:, 1]) & (cand[:, 1] < boxes[:, b, 3] + 0.6)
+            take = ~done & (~inside | (attempt == 7))
+            p1 = torch.where(take[:, None], cand, p1)
+            done |= take
+        d = torch.stack([(u[:, 26] - 0.5) * 0.5, (u[:, 27] - 0.5) * 0.5, (u[:, 28] - 0.5) * 0.3], dim=1)
+        p2 = compose(p1, d)
+        g = compose(d, torch.stack([(u[:, 29] - 0.5) * 0.1, (u[:, 30] - 0.5) * 0.1, (u[:, 31] - 0.5) * 0.04], dim=1))
+        for pose, out in ((p1, ref), (p2, qry)):
+            r = raycast(pose, boxes, valid)
+            r = r + range_noise * torch.randn(r.shape, dtype=torch.float64, device=device, generator=gen)
+            out[p0:p0 + n] = torch.clamp(r, 0.05, LASER_MAX_RANGE * 2).to(torch.float32)
+        guess[p0:p0 + n] = g
+        true_rel[p0:p0 + n] = d
+    return dict(ranges_ref=ref, ranges_qry=qry, guess=guess, true_rel=true_rel, angle_min=LASER_ANGLE_MIN,
+                angle_inc=LASER_ANGLE_INC, max_range=LASER_MAX_RANGE, n_beams=n_beams)

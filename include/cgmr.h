@@ -25,6 +25,7 @@
 #ifndef CGMR_H
 #define CGMR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -217,6 +218,53 @@ int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, 
                       double theta_res, double max_score, double dx, double dy, double dth,
                       cgmr_match_result* results_out, int cap, int* n_out);
 
+/* ------------------------------------------------------------------------------------------
+ * The ScanMatcher member functions (src/matcher/scan_matcher.h:45-78) on flat scan sets.
+ *
+ * A cgmr_scan_set is the flat form of the (OptimizableGraph::VertexSet&, OptimizableGraph::Vertex* reference)
+ * argument pairs of the reference: the RobotLaser ranges and the VertexSE2 estimates of the set's vertices, in
+ * the order the caller iterates its set (the reference iterates a std::set<Vertex*>, i.e. in address order; the
+ * rasterised grid and the searches do not depend on that order, the concatenated point list does), and which of
+ * them is the reference vertex.  The laser description and laserParams().laserPose come from the config.
+ * All of these run the region / transform bookkeeping on the host with the reference's arithmetic (Vector3f
+ * regions in float, SE2 products in double with libm) and every search on the GPU.
+ *
+ *   cgmr_close_scan_matching   bool closeScanMatching(vset, originVertex, currentVertex, SE2* trel, maxScore)
+ *                              scan_matcher.cpp:112-189 with the reference's real call shape: the last vertex and up
+ *                              to 5 predecessors (src/slam/graph_slam.cpp:230-244); window / steps / bins from cfg
+ *   cgmr_scan_matching_lc      bool scanMatchingLC(vset, ref, currvset, current, vector<SE2>& trel, maxScore)
+ *                              scan_matcher.cpp:191-294 (the single-vertex overload :191-199 is a set of one):
+ *                              trel_out [2*3], *n_out = 0..2 results; the bool is *n_out > 0
+ *   cgmr_global_matching       bool globalMatching(vset, ref, currvset, current, SE2* trel, maxScore)
+ *                              scan_matcher.cpp:358-428 (+ the single-vertex overload): 4-level hierarchical search
+ *                              over +/-(10 m, 5 m, pi)
+ *   cgmr_verify_matching       bool verifyMatching(vset1, ref1, vset2, ref2, SE2 trel12, double* score)
+ *                              scan_matcher.cpp:430-505; *accepted_out = score <= 40
+ *   cgmr_match_hierarchical    CharGrid::hierarchicalSearch(mresvec, points, regions, params, nLevels)
+ *                              chargrid.cpp:310-413 on explicit point lists (see cgmr_match_greedy for the arguments)
+ *   cgmr_transform_points_from_vset  ScanMatcher::transformPointsFromVSet, scan_matcher.cpp:89-110 (host only);
+ *                              returns the number of points written to pts_out [cap*2], or < 0          */
+typedef struct cgmr_scan_set {
+  int n_scans;
+  const float* ranges;          /* [n_scans * cfg->n_beams] */
+  const double* poses_xyt;      /* [n_scans * 3] vertex estimates */
+  int ref_index;                /* the reference (origin) vertex of the set */
+} cgmr_scan_set;
+int cgmr_close_scan_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* vset,
+                             const float* cur_ranges, const double cur_pose_xyt[3], double max_score, double trel_out[3],
+                             int* found_out);
+int cgmr_scan_matching_lc(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
+                          const cgmr_scan_set* cur_set, double max_score, double* trel_out, int* n_out);
+int cgmr_global_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
+                         const cgmr_scan_set* cur_set, double max_score, double trel_out[3], int* found_out);
+int cgmr_verify_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* set1, const cgmr_scan_set* set2,
+                         const double trel12[3], double* score_out, int* accepted_out);
+int cgmr_match_hierarchical(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts_xy, int n_qry,
+                            const double* qry_pts_xy, int n_regions, const float* regions, double theta_res, double max_score,
+                            double dx, double dy, double dth, int n_levels, cgmr_match_result* results_out, int cap,
+                            int* n_out);
+int cgmr_transform_points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* vset, double* pts_out, int cap);
+
 /* Host helpers with the reference's exact arithmetic (no GPU): RawLaser::cartesian [g2o-recalled] and
  * CharGrid::subsample (src/matcher/chargrid.cpp:61-122).  Both return the number of points written. */
 int cgmr_scan_cartesian(int n_beams, const float* ranges, double angle_min, double angle_inc, double max_range,
@@ -232,6 +280,90 @@ int cgmr_subsample(int n, const double* pts_xy, double res, double* pts_out);
 int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, const double* pts2_xy, int n1,
                       const double* pts1_xy, double nonmatched_score, const float lower_xy[2], const float upper_xy[2],
                       double* score_out, int* n_nonmatched_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Robot graph: one robot's pose graph resident in HBM -- the multi-robot path.
+ *
+ * Replaces, for one robot (= one rank = one GPU), the part of MRGraphSLAM that touches numbers:
+ *   the g2o SparseOptimizer the robot grows key frame by key frame         src/slam/graph_slam.cpp:87-122,197-267
+ *   GraphSLAM::optimize                                                    src/slam/graph_slam.cpp:561-575
+ *   CondensedGraphBuffer::{insertInClosure, insertOutClosure, getMyEdges, selectGaugeCentroid, computeCondensedGraph,
+ *     insertEdgesFromRobot}          src/mrslam/condensed_graph/condensed_graph_buffer.cpp:131-170,318-366,437-510
+ *   CondensedGraphCreator::compute                  src/mrslam/condensed_graph/condensed_graph_creator.cpp:33-66
+ *   MRGraphSLAM::addInterRobotData (messages in)                           src/mrslam/mr_graph_slam.cpp:331-395
+ *   the wire structs (44 B / edge, float32)                                src/mrslam/msg_factory.h:78-112,200-238
+ * Vertices and edges are addressed by g2o *id* here (robot * baseId + k, graph_slam.cpp:95,155): messages carry ids.
+ * The structure (ids, end points, closure lists) is host state; poses, measurements, information matrices, received
+ * edges and the wire buffers are device state.  A graph created with ctx == NULL does the bookkeeping only (CPU
+ * tests, no numeric entry point works).  Calls on one graph must be serialised by the caller (graphMutex).
+ *
+ * Round protocol (C5: every 50 new vertices):
+ *   cgmr_graph_optimize(g, 5)                      local solve on own + received level-0 edges
+ *   cgmr_graph_compute_condensed(g, -1)            one star of condensed edges per peer that asked (own edges only)
+ *   cgmr_graph_pack(g, send)                       my message: edges for every peer + my closure requests
+ *   cgmr_allgather_condensed(ctx, comm, ...)       one RCCL all-gather on a side stream (overlaps the next solve)
+ *   cgmr_comm_wait + cgmr_graph_ingest(g, recv)    requests -> out-closures; newest edge set per peer replaces the old
+ *
+ * Wire buffer of one rank, cgmr_graph_wire_bytes() bytes:
+ *   int32 robot, n_robots, n_edges[R], n_closures[R];  {int32 from, to; float est[3]; float info[6]} edges[R][cap];
+ *   int32 closures[R][cap]          (slice p = what is addressed to robot p)                                   */
+typedef struct cgmr_graph cgmr_graph;
+typedef struct cgmr_comm cgmr_comm;
+
+int cgmr_graph_create(cgmr_ctx* ctx, int robot_id, int n_robots, int base_id, int cap_edges_per_peer, cgmr_graph** out);
+void cgmr_graph_destroy(cgmr_graph* g);
+const char* cgmr_graph_last_error(const cgmr_graph* g);
+/* ids must be new; fixed nullable (all free).  Edges: both end points must exist; these are the robot's OWN level-0
+ * edges (odometry, scan matching, inter-robot closures it found itself). */
+int cgmr_graph_add_vertices(cgmr_graph* g, int n, const int32_t* ids, const double* poses_xyt, const uint8_t* fixed);
+int cgmr_graph_add_edges(cgmr_graph* g, int n, const int32_t* from_ids, const int32_t* to_ids, const double* meas_xyt,
+                         const double* info_upper);
+/* out[0] = vertices, [1] = own edges, [2] = received edges currently in the graph, [3] = peers with out-closures */
+int cgmr_graph_counts(const cgmr_graph* g, int32_t out[4]);
+/* GraphSLAM::optimize(iters); chi2_out nullable [iters+1]; returns like cgmr_gn_optimize */
+int cgmr_graph_optimize(cgmr_graph* g, int iters, double* chi2_out);
+/* estimates of vertices first .. first+n-1 in insertion order */
+int cgmr_graph_get_poses(cgmr_graph* g, int first, int n, double* poses_out);
+int cgmr_graph_set_poses(cgmr_graph* g, int first, int n, const double* poses_xyt);
+int cgmr_graph_insert_in_closure(cgmr_graph* g, int peer, int n, const int32_t* vertex_ids);
+int cgmr_graph_insert_out_closure(cgmr_graph* g, int peer, int n, const int32_t* vertex_ids);
+/* which = 0: out-closures (my ids `peer` asked for), 1: in-closures (ids I ask `peer` for); returns the count */
+int cgmr_graph_closures(const cgmr_graph* g, int peer, int which, int cap, int32_t* ids_out);
+/* computeCondensedGraph for `peer`, or for every peer with out-closures when peer < 0; returns the number built */
+int cgmr_graph_compute_condensed(cgmr_graph* g, int peer);
+/* the condensed graph built for `peer` in double precision: returns its edge count; outputs nullable */
+int cgmr_graph_get_condensed(cgmr_graph* g, int peer, int cap, int32_t* from_id_out, int32_t* to_ids_out, double* est_out,
+                             double* info_upper_out);
+/* install a condensed graph from host data in wire precision (tests, or a caller that labels edges itself) */
+int cgmr_graph_set_condensed(cgmr_graph* g, int peer, int n, int32_t from_id, const int32_t* to_ids, const float* est,
+                             const float* info_upper);
+int64_t cgmr_graph_wire_bytes(const cgmr_graph* g);
+/* device buffers owned by the graph: wire_bytes / n_robots * wire_bytes */
+void* cgmr_graph_send_buffer(cgmr_graph* g);
+void* cgmr_graph_recv_buffer(cgmr_graph* g);
+/* d_send_out NULL = the graph's own send buffer; d_recv NULL = the graph's own receive buffer */
+int cgmr_graph_pack(cgmr_graph* g, void* d_send_out);
+int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out);
+/* the same through host memory (gloo; CPU tests on a graph without a device) */
+int cgmr_graph_pack_host(cgmr_graph* g, void* send_out);
+int cgmr_graph_ingest_host(cgmr_graph* g, const void* recv, int32_t* n_edges_out);
+/* the edges currently held from `peer`: returns their count; outputs nullable */
+int cgmr_graph_received_edges(cgmr_graph* g, int peer, int cap, int32_t* from_ids_out, int32_t* to_ids_out, double* meas_out,
+                              double* info_upper_out);
+/* wall seconds of the last cgmr_graph_optimize / cgmr_graph_compute_condensed */
+int cgmr_graph_last_seconds(const cgmr_graph* g, double out[2]);
+
+/* Exchange (replaces GraphComm's pairwise UDP, src/mrslam/graph_comm.cpp:103-208, by one collective per round).
+ * A communicator wraps an RCCL communicator over the ranks' GPUs (xGMI inside a node) and a side stream:
+ *   rank 0: cgmr_comm_unique_id(id) -> distribute the 128 bytes out of band -> every rank: cgmr_comm_create.
+ * cgmr_allgather_condensed queues ncclAllGather(d_send, d_recv, bytes_per_rank) on the side stream behind everything
+ * already queued on the context's stream and returns; cgmr_comm_wait makes the context's stream wait for it. */
+int cgmr_comm_unique_id(void* id_out_128);
+int cgmr_comm_create(cgmr_ctx* ctx, int n_ranks, int rank, const void* unique_id_128, cgmr_comm** out);
+void cgmr_comm_destroy(cgmr_comm* comm);
+int cgmr_allgather_condensed(cgmr_ctx* ctx, cgmr_comm* comm, const void* d_send, size_t bytes_per_rank, void* d_recv);
+int cgmr_comm_wait(cgmr_ctx* ctx, cgmr_comm* comm);
+int cgmr_comm_last_seconds(cgmr_comm* comm, double* seconds);
 
 /* ------------------------------------------------------------------ occupancy map
  * cgmr_occupancy_map replaces, for all scans of a graph at once, FrequencyMap::integrateScan + fillRobotPose

@@ -5,7 +5,7 @@ import types
 
 import numpy as np
 
-from cg_mrslam_amd.matcher import _GenericSearch
+from ref_scan_matcher import RefScanMatcherLogic
 from oracle import oracle as O
 
 
@@ -14,15 +14,20 @@ class OracleContext:
         st, p, chi, _ = O.gn_optimize(poses, fixed, ef, et, meas, info, iters)
         return st, p, chi
 
+    def condense(self, poses, ef, et, meas, info, gauge, query):
+        n, to, est, iu, cov = O.condense(poses, ef, et, meas, info, gauge, query)
+        assert n >= 0
+        return to, est, iu, cov
+
     def covariance_estimate(self, poses, ef, et, meas, info, gauge, query):
         st, cov = O.covariance_estimate(poses, ef, et, meas, info, gauge, query)
         assert st == 0
         return cov
 
 
-class OracleMatcher(_GenericSearch):
-    """The generic searches of ``_GenericSearch`` (region bookkeeping shared with the product mirror) on the
-    oracle's cartesian / subsample / greedy_search."""
+class OracleMatcher(RefScanMatcherLogic):
+    """The plain-Python restatement of the ScanMatcher bookkeeping (tests/ref_scan_matcher.py) on the oracle's
+    cartesian / subsample / greedy_search / verify: nothing of the product is involved."""
 
     def __init__(self, angle_min, angle_inc, max_range, ll, ur, resolution, kernel_range, laser_pose=(0.0, 0.0, 0.0)):
         self.cfg = types.SimpleNamespace(angle_min=angle_min, angle_inc=angle_inc, max_range=max_range, min_range=0.0,
@@ -40,6 +45,11 @@ class OracleMatcher(_GenericSearch):
         n, res = O.greedy_search(self.ll, self.ur, self.cfg.resolution, self.cfg.resolution, self.cfg.kernel_range,
                                  ref_pts, qry_pts, regions, step, thetaRes, maxScore, dx, dy, dth, cap=cap)
         return np.asarray(res, dtype=np.float64).reshape(-1, 4)[:n]
+
+    def verify(self, pts2, pts1, lower, upper, nonmatched_score):
+        _, score = O.verify(self.ll, self.ur, self.cfg.resolution, self.cfg.resolution, self.cfg.kernel_range, pts2, pts1,
+                            lower, upper, nonmatched_score)
+        return score
 
 
 def close_matcher(la):

@@ -1,67 +1,133 @@
-"""CPU tests of the condensed-graph bookkeeping and the inter-robot exchange (gloo, world_size 2)."""
+"""CPU tests of the multi-robot bookkeeping behind the C ABI (cgmr_graph_* on a graph without a device: closures, wire
+format, replace-on-receive) against the plain-numpy restatement (tests/ref_condensed.py), and of the inter-robot
+exchange over gloo with world_size 2."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 from cg_mrslam_amd import synth
-from cg_mrslam_amd.condensed import EDGE_DTYPE, CondensedGraphBuffer, select_gauge_centroid
-from cg_mrslam_amd.graph import PoseGraph
+from cg_mrslam_amd.condensed import WIRE_EDGE_DTYPE, RobotGraph, unpack_wire
+from ref_condensed import EDGE_DTYPE, CondensedGraphBuffer, RefRobotGraph, select_gauge_centroid
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _robot_graph(g):
-    return PoseGraph(g["ids"], g["poses_all"], g["fixed_all"], g["ef_all"], g["et_all"], g["meas_all"], g["info_all"])
+def _fill(graph, g):
+    """Whole robot graph of synth.make_multi_robot into a RobotGraph-like object."""
+    graph.add_vertices(g["ids"], g["poses_all"], g["fixed_all"])
+    graph.add_edges(g["ids"][g["ef_all"]], g["ids"][g["et_all"]], g["meas_all"], g["info_all"])
+    for q, ids in g["in_closures"].items():
+        graph.insertInClosure(q, ids)
 
 
-def _fake_edges(ids_from, ids_to, seed):
+def _fake(n, seed):
     rng = np.random.default_rng(seed)
-    e = np.zeros(len(ids_to), dtype=EDGE_DTYPE)
-    e["from"] = ids_from
-    e["to"] = ids_to
-    e["est"] = rng.normal(size=(len(ids_to), 3)).astype(np.float32)
-    e["info"] = np.tile(np.array([100, 0, 0, 100, 0, 1000], dtype=np.float32), (len(ids_to), 1))
-    return e
+    return rng.normal(size=(n, 3)).astype(np.float32), np.tile(np.array([100, 0, 0, 100, 0, 1000], dtype=np.float32), (n, 1))
 
 
-def test_wire_format_is_44_bytes_and_round_trips():
+def test_wire_edge_is_44_bytes():
+    assert WIRE_EDGE_DTYPE.itemsize == 44 == EDGE_DTYPE.itemsize
+
+
+def test_wire_format_matches_numpy_restatement_and_round_trips():
     R = synth.make_multi_robot(3, 300, 800, seed=5)
-    b = [CondensedGraphBuffer(_robot_graph(R[r]), r, 3, cap_edges=64) for r in range(3)]
-    for q, ids in R[0]["in_closures"].items():
-        b[0].insertInClosure(q, ids)
-    b[0].out_condensed[1] = _fake_edges(5, np.arange(6, 16), 1)
-    b[0].out_condensed[2] = _fake_edges(7, np.arange(20, 23), 2)
-    buf = b[0].pack()
-    assert buf.dtype == np.uint8 and len(buf) == b[0].wire_bytes()
-    sender, edges, clos = b[1].unpack(buf)
-    assert sender == 0 and len(edges) == 10
-    assert np.array_equal(edges, b[0].out_condensed[1])
-    assert np.array_equal(clos, R[0]["in_closures"][1][:64])
-    sender, edges, _ = b[2].unpack(buf)
-    assert len(edges) == 3 and np.array_equal(edges["to"], [20, 21, 22])
+    c = [RobotGraph(None, r, 3, cap_edges=64) for r in range(3)]
+    ref = [RefRobotGraph(None, r, 3, cap_edges=64) for r in range(3)]
+    for r in range(3):
+        _fill(c[r], R[r]); _fill(ref[r], R[r])
+    own = R[0]["ids"][:300]
+    e1, i1 = _fake(10, 1)
+    e2, i2 = _fake(3, 2)
+    c[0].set_condensed(1, own[5], own[6:16], e1, i1)
+    c[0].set_condensed(2, own[7], own[20:23], e2, i2)
+    for peer, frm, to, e, i in ((1, own[5], own[6:16], e1, i1), (2, own[7], own[20:23], e2, i2)):
+        w = np.zeros(len(to), dtype=EDGE_DTYPE)
+        w["from"], w["to"], w["est"], w["info"] = frm, to, e, i
+        ref[0].buf.out_condensed[peer] = w
+    buf = c[0].pack_host()
+    assert buf.dtype == np.uint8 and len(buf) == c[0].wire_bytes() == ref[0].buf.wire_bytes()
+    assert np.array_equal(buf, ref[0].pack_host())                       # byte-identical to the restatement
+    robot, n_e, n_c, edges, clos = unpack_wire(buf, 3, 64)
+    assert robot == 0 and list(n_e) == [0, 10, 3]
+    assert np.array_equal(edges[1, :10]["to"], own[6:16]) and np.array_equal(edges[1, :10]["est"], e1)
+    assert np.array_equal(clos[1, :n_c[1]], np.sort(R[0]["in_closures"][1]))
 
 
-def test_insert_edges_replaces_previous_set_and_skips_unknown_vertices():
+def test_ingest_replaces_previous_set_skips_unknown_and_keeps_on_empty():
     R = synth.make_multi_robot(2, 300, 800, seed=6)
-    g = _robot_graph(R[0])
-    buf = CondensedGraphBuffer(g, 0, 2)
-    n0 = g.n_edges
-    foreign = R[0]["in_closures"][1]
+    a, b = RobotGraph(None, 0, 2), RobotGraph(None, 1, 2)
+    ra, rb = RefRobotGraph(None, 0, 2), RefRobotGraph(None, 1, 2)
+    for g, src in ((a, R[0]), (b, R[1]), (ra, R[0]), (rb, R[1])):
+        _fill(g, src)
+    n0 = a.counts()["own_edges"]
+    foreign = np.sort(R[0]["in_closures"][1])           # robot 1's vertices robot 0 knows
     assert len(foreign) >= 3
-    e1 = _fake_edges(foreign[0], foreign[1:3], 3)
-    e1 = np.concatenate([e1, _fake_edges(foreign[0], np.array([19999]), 4)])     # unknown end point: skipped
-    assert buf.insertEdgesFromRobot(1, e1) == 2
-    assert g.n_edges == n0 + 2 and (buf.in_edge_src >= 0).sum() == 2
-    assert buf.my_edge_mask().sum() == n0                                         # getMyEdges excludes received edges
-    e2 = _fake_edges(foreign[1], foreign[2:3], 5)
-    assert buf.insertEdgesFromRobot(1, e2) == 1                                   # replaces, does not accumulate
-    assert g.n_edges == n0 + 1
-    assert g.meas.dtype == np.float64 and np.allclose(g.meas[-1], e2["est"][0])
+
+    def send(frm, to, seed):
+        e, i = _fake(len(to), seed)
+        b.set_condensed(0, frm, to, e, i)
+        w = np.zeros(len(to), dtype=EDGE_DTYPE)
+        w["from"], w["to"], w["est"], w["info"] = frm, to, e, i
+        rb.buf.out_condensed[0] = w
+        wire = np.concatenate([a.pack_host(), b.pack_host()])
+        assert np.array_equal(wire, np.concatenate([ra.pack_host(), rb.pack_host()]))
+        return a.ingest_host(wire), ra.ingest_host(wire), e
+
+    # 3 edges, one with an end point robot 0 has never seen: skipped (mr_graph_slam.cpp:360-363)
+    n, n_ref, e = send(foreign[0], np.array([foreign[1], foreign[2], 19999]), 3)
+    assert list(n) == [0, 2] == list(n_ref)
+    assert a.counts() == {"vertices": a.counts()["vertices"], "own_edges": n0, "received_edges": 2, "peers_with_requests": 1}
+    f, t, m, i = a.received_edges(1)
+    fr, tr, mr, ir = ra.received_edges(1)
+    assert np.array_equal(f, fr) and np.array_equal(t, tr) and np.array_equal(m, mr) and np.array_equal(i, ir)
+    assert m.dtype == np.float64 and np.array_equal(m, e[:2].astype(np.float64))      # float32 widened to double
+    # the newest set replaces the previous one (condensed_graph_buffer.cpp:487-510)
+    n, n_ref, e = send(foreign[1], foreign[2:3], 5)
+    assert list(n) == [0, 1] == list(n_ref) and a.counts()["received_edges"] == 1
+    # a message whose edges are all unknown to me (or that has none) leaves the previous set in place (:393-394)
+    n, n_ref, _ = send(foreign[1], np.array([19998]), 6)
+    assert list(n) == [0, 0] == list(n_ref) and a.counts()["received_edges"] == 1
+    n, n_ref, _ = send(foreign[1], np.zeros(0, dtype=np.int64), 7)
+    assert list(n) == [0, 0] == list(n_ref) and a.counts()["received_edges"] == 1
+    assert np.array_equal(a.received_edges(1)[2], ra.received_edges(1)[2])
+    # the closure requests of robot 1 became out-closures of robot 0: exactly the ids robot 1 asks for
+    assert np.array_equal(a.closures(1, "out"), np.sort(R[1]["in_closures"][0]))
+    assert np.array_equal(a.closures(1, "out"), np.sort(ra.buf.out_closures[1]))
+
+
+def test_capacity_overflow_is_an_error_not_a_truncation():
+    g = RobotGraph(None, 0, 2, cap_edges=4)
+    g.add_vertices(np.arange(10), np.zeros((10, 3)))
+    from cg_mrslam_amd._lib import CgmrError
+    with pytest.raises(CgmrError):
+        g.set_condensed(1, 0, np.arange(1, 7), *_fake(6, 1))             # 6 edges > cap 4
+    g.insertInClosure(1, 10000 + np.arange(5))                           # 5 requests > cap 4
+    with pytest.raises(CgmrError):
+        g.pack_host()
+    r = RefRobotGraph(None, 0, 2, cap_edges=4)
+    r.insertInClosure(1, 10000 + np.arange(5))
+    with pytest.raises(ValueError):
+        r.pack_host()
 
 
 def test_select_gauge_centroid():
     xy = np.array([[0.0, 0], [10, 0], [4, 1], [5, 5]])
     assert select_gauge_centroid(xy) == 2
+
+
+def test_numeric_entry_points_need_a_device():
+    from cg_mrslam_amd._lib import CgmrError
+    g = RobotGraph(None, 0, 2)
+    g.add_vertices([0, 1], np.zeros((2, 3)), [1, 0])
+    g.add_edges([0], [1], [[1.0, 0, 0]], [[100, 0, 0, 100, 0, 1000]])
+    with pytest.raises(CgmrError):
+        g.optimize(1)
+    with pytest.raises(CgmrError):
+        g.computeCondensedGraph(-1)
 
 
 def _free_port():
@@ -74,25 +140,28 @@ def _free_port():
 
 def _worker(rank, world, port, out):
     import torch.distributed as dist
+    from cg_mrslam_amd.condensed import Exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     R = synth.make_multi_robot(world, 300, 800, seed=7)
-    g = _robot_graph(R[rank])
-    buf = CondensedGraphBuffer(g, rank, world, cap_edges=64)
-    for q, ids in R[rank]["in_closures"].items():
-        buf.insertInClosure(q, ids)
-    n0 = g.n_edges
+    g = RobotGraph(None, rank, world, cap_edges=64)
+    _fill(g, R[rank])
+    ex = Exchange(g)
+    assert ex.transport == "host"
+    n0 = g.counts()["own_edges"]
     # round 1: only requests travel (nobody knows yet what the peers want)
-    buf.exchange()
+    ex.start(); ex.finish()
     peer = 1 - rank
-    want = buf.out_closures[peer]                       # what the peer asked me for: ids of MY vertices
-    assert np.array_equal(want, R[peer]["in_closures"][rank])
-    # build a (fake, CPU) condensed star over the requested vertices and send it in round 2
-    buf.out_condensed[peer] = _fake_edges(want[0], want[1:], 10 + rank)
-    buf.exchange()
-    got = (buf.in_edge_src == peer).sum()
-    out.put((rank, int(n0), int(g.n_edges), int(got), len(R[rank]["in_closures"][peer])))
+    want = g.closures(peer, "out")                      # what the peer asked me for: ids of MY vertices
+    assert np.array_equal(want, np.sort(R[peer]["in_closures"][rank]))
+    # a (fake, CPU) condensed star over the requested vertices travels in round 2
+    e, i = _fake(len(want) - 1, 10 + rank)
+    g.set_condensed(peer, want[0], want[1:], e, i)
+    ex.start()
+    n = ex.finish()
+    c = g.counts()
+    out.put((rank, int(n0), c["own_edges"], c["received_edges"], int(n[peer]), len(R[rank]["in_closures"][peer])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -109,6 +178,28 @@ def test_gloo_two_rank_exchange():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, n0, n1, got, n_in in res:
+    for rank, n0, own, recv, got, n_in in res:
         # I receive a star over the vertices *I* asked for: n_in - 1 edges, all end points known to me
-        assert got == n_in - 1 and n1 == n0 + got
+        assert got == recv == n_in - 1 and own == n0
+
+
+def test_bench_gpus_2_spawns_two_ranks_dry_run():
+    """``bench.py --gpus 2`` without RANK in the environment must start two ranks itself.  Without a GPU the ranks run the
+    protocol dry (CGMR_BENCH_DRY=1: rendezvous over gloo, the C5 round protocol on graphs without a device with fake
+    condensed edges) -- the launcher, the rank plumbing and the exchange leg are what is tested here."""
+    env = dict(os.environ, CGMR_BENCH_DRY="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    import json
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["dry_run"] is True
+    ex = out["exchange"]
+    assert ex is not None and ex["robots"] == 2 and ex["rounds"] >= 2 and ex["condensed_edges_received_total"] > 0
+    # a rank count that disagrees with the environment is refused, not ignored
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
+    assert p2.returncode != 0 and "WORLD_SIZE" in (p2.stderr + p2.stdout)

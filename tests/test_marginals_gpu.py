@@ -5,8 +5,7 @@ import numpy as np
 import pytest
 
 from cg_mrslam_amd import synth
-from cg_mrslam_amd.condensed import CondensedGraphBuffer
-from cg_mrslam_amd.graph import GraphSLAM, PoseGraph
+from cg_mrslam_amd.condensed import RobotGraph
 
 pytestmark = pytest.mark.gpu
 
@@ -66,46 +65,46 @@ def test_condense_matches_oracle_and_chain_closed_form(ctx, oracle):
 
 
 def test_two_robot_round_reduces_error(ctx):
-    """One full multi-robot round on one GPU (robots run one after the other, the 'wire' is pack/unpack):
-    optimise, build the condensed graph each peer asked for, exchange, re-optimise.  The received condensed
-    edges must tie the foreign vertices together consistently: chi2 stays ~dof and the foreign poses move
-    towards their truth."""
+    """One full multi-robot round on one GPU with the whole graphs loaded at once (robots run one after the other, the
+    'wire' is pack_host / ingest_host): optimise, build the condensed graph each peer asked for, exchange, re-optimise.
+    The received condensed edges must tie the foreign vertices together consistently: chi2 stays ~dof and the foreign
+    poses move towards their truth.  (The oracle-compared multi-round version is tests/test_multirobot_gpu.py.)"""
     for seed in range(46, 80):                            # first seed whose two walks actually meet
         R = synth.make_multi_robot(2, 1200, 4000, seed=seed)
         if all(len(R[r]["in_closures"].get(1 - r, [])) >= 8 for r in range(2)):
             break
-    bufs, slams = [], []
+    graphs = []
     for r in range(2):
         gr = R[r]
-        pg = PoseGraph(gr["ids"], gr["poses_all"], gr["fixed_all"], gr["ef_all"], gr["et_all"], gr["meas_all"], gr["info_all"])
-        b = CondensedGraphBuffer(pg, r, 2, ctx=ctx)
+        g = RobotGraph(ctx, r, 2)
+        g.add_vertices(gr["ids"], gr["poses_all"], gr["fixed_all"])
+        g.add_edges(gr["ids"][gr["ef_all"]], gr["ids"][gr["et_all"]], gr["meas_all"], gr["info_all"])
         for q, ids in gr["in_closures"].items():
-            b.insertInClosure(q, ids)
-        bufs.append(b)
-        slams.append(GraphSLAM(pg, ctx=ctx))
-    for s in slams:
-        s.optimize(6)
-    wire = [b.pack() for b in bufs]                       # round 1: requests only
-    for r in range(2):
-        sender, edges, clos = bufs[r].unpack(wire[1 - r])
-        bufs[r].insertOutClosure(sender, clos)
-    for r in range(2):
-        e = bufs[r].computeCondensedGraph(1 - r)
-        assert len(e) == len(bufs[r].out_closures[1 - r]) - 1 > 3
-        assert np.all(np.isfinite(e["est"])) and np.all(np.isfinite(e["info"]))
-    wire = [b.pack() for b in bufs]                       # round 2: condensed edges travel
+            g.insertInClosure(q, ids)
+        graphs.append(g)
+    for g in graphs:
+        assert g.optimize(6)[0] == 0
+    wire = np.concatenate([g.pack_host() for g in graphs])          # round 1: requests only
+    for g in graphs:
+        assert list(g.ingest_host(wire)) == [0, 0]
+    for r, g in enumerate(graphs):
+        assert g.computeCondensedGraph(1 - r) == 1
+        gid, to, est, iu = g.condensed(1 - r)
+        assert len(to) == len(g.closures(1 - r, "out")) - 1 > 3
+        assert np.all(np.isfinite(est)) and np.all(np.isfinite(iu))
+    wire = np.concatenate([g.pack_host() for g in graphs])          # round 2: condensed edges travel
     before = []
-    for r in range(2):
+    for r, g in enumerate(graphs):
         n_own = R[r]["n_own"]
-        before.append(np.abs(slams[r].graph.poses[n_own:, :2] - R[r]["truth_all"][n_own:, :2]).mean())
-        sender, edges, clos = bufs[r].unpack(wire[1 - r])
-        assert bufs[r].insertEdgesFromRobot(sender, edges) == len(edges)
-    for r in range(2):
-        slams[r].optimize(6)
-        assert slams[r].last_status == 0
-        g = slams[r].graph
-        dof = 3 * g.n_edges - 3 * (g.n_vertices - 1)
-        assert slams[r].last_chi2[-1] < 1.5 * dof
+        before.append(np.abs(g.poses()[n_own:, :2] - R[r]["truth_all"][n_own:, :2]).mean())
+        n = g.ingest_host(wire)
+        assert n[1 - r] == len(graphs[1 - r].condensed(r)[1])
+    for r, g in enumerate(graphs):
+        rc, chi = g.optimize(6)
+        assert rc == 0
+        c = g.counts()
+        dof = 3 * (c["own_edges"] + c["received_edges"]) - 3 * (c["vertices"] - 1)
+        assert chi[-1] < 1.5 * dof
         n_own = R[r]["n_own"]
-        after = np.abs(g.poses[n_own:, :2] - R[r]["truth_all"][n_own:, :2]).mean()
+        after = np.abs(g.poses()[n_own:, :2] - R[r]["truth_all"][n_own:, :2]).mean()
         assert after < before[r] * 1.05                  # never worse; usually clearly better

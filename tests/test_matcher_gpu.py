@@ -266,3 +266,44 @@ def test_close_matching_with_multi_scan_reference_set(ctx, oracle):
     f1, t1 = m.closeScanMatchingVSet([scans[3]], 0, cur_r, cur_true + [0.05, 0.04, -0.02], 0.15)
     fb, tb, sb = m.closeScanMatching(scans[3][0], cur_r, g)
     assert f1 and fb[0] and np.array_equal(t1, tb[0])
+
+
+def test_c_abi_scan_matcher_members_match_python_restatement_on_oracle(ctx, oracle):
+    """Every ScanMatcher member function of the C ABI (csrc/matcher_api.cpp: transformPointsFromVSet,
+    closeScanMatching with a 6-scan set, scanMatchingLC, globalMatching, verifyMatching) against the plain-Python
+    restatement of the same bookkeeping (tests/ref_scan_matcher.py) running on the CPU oracle: bit-identical."""
+    import oracle_backend as ob
+    from cg_mrslam_amd.matcher import LCScanMatcher, ScanMatcher
+    ang = synth.LASER_ANGLE_MIN + synth.LASER_ANGLE_INC * np.arange(1081)
+    boxes = [(-6.0, -4.5, 6.0, 4.5), (1.0, 1.0, 2.2, 2.0), (-3.0, -2.5, -2.2, -1.0)]
+    poses = [np.array([0.12 * k, -0.06 * k + 0.01 * k * k, 0.04 * k]) for k in range(6)]
+    scans = [(synth._raycast_boxes(p[0], p[1], p[2] + ang, boxes, 30.0).astype(np.float32), p) for p in poses]
+    cur_true = np.array([0.85, -0.25, 0.22])
+    cur_r = synth._raycast_boxes(cur_true[0], cur_true[1], cur_true[2] + ang, boxes, 30.0).astype(np.float32)
+    cur_est = cur_true + [0.06, -0.05, 0.03]
+    la = (1081, synth.LASER_ANGLE_MIN, synth.LASER_ANGLE_INC, 30.0)
+    lp = (0.1, -0.02, 0.03)                                    # a laser that is not at the robot centre
+    mc, mo = ScanMatcher(ctx, *la, laser_pose=lp), ob.OracleMatcher(la[1], la[2], la[3], (-15.0, -15.0), (15.0, 15.0), 0.025, 0.2, lp)
+    lc, lo = LCScanMatcher(ctx, *la, laser_pose=lp), ob.OracleMatcher(la[1], la[2], la[3], (-35.0, -35.0), (35.0, 35.0), 0.1, 0.5, lp)
+    assert np.array_equal(mc.transformPointsFromVSet(scans, 5), mo.transformPointsFromVSet(scans, 5))
+    # closeScanMatching: the reference's call shape (last vertex + 5 predecessors, graph_slam.cpp:230-244)
+    f_c, t_c = mc.closeScanMatchingVSet(scans, 5, cur_r, cur_est, 0.15)
+    f_o, t_o = mo.closeScanMatchingVSet(scans, 5, cur_r, cur_est, 0.15)
+    assert f_c and f_o and np.array_equal(t_c, t_o)
+    rel_true = synth.se2_compose(synth.se2_inverse(poses[5]), cur_true)
+    assert np.abs(t_c[:2] - rel_true[:2]).max() < 0.03 and abs(t_c[2] - rel_true[2]) < 0.0126
+    # scanMatchingLC, 3-scan reference set and 2-scan current set
+    est2 = synth.se2_compose(cur_est, synth.se2_compose(synth.se2_inverse(cur_true), poses[5]))   # consistent with cur_est
+    cur_set = [(cur_r, cur_est), (scans[5][0], est2)]
+    r_c = lc.scanMatchingLC(scans[:3], 1, cur_set, 0, 0.3)
+    r_o = lo.scanMatchingLC(scans[:3], 1, cur_set, 0, 0.3)
+    assert len(r_c) == len(r_o) >= 1 and all(np.array_equal(a, b) for a, b in zip(r_c, r_o))
+    # globalMatching
+    g_c = lc.globalMatching(scans[:2], 0, [(cur_r, cur_est)], 0, 0.2)
+    g_o = lo.globalMatching(scans[:2], 0, [(cur_r, cur_est)], 0, 0.2)
+    assert g_c[0] == g_o[0] and g_c[0] and np.array_equal(g_c[1], g_o[1])
+    # verifyMatching with two-scan sets and a transform that is off by 0.4 m (unexplained points -> low window mean)
+    for t12 in (synth.se2_compose(synth.se2_inverse(poses[0]), cur_true), np.array([0.4, 0.3, 0.1])):
+        v_c = lc.verifyMatching(scans[:2], 0, cur_set, 0, t12)
+        v_o = lo.verifyMatching(scans[:2], 0, cur_set, 0, t12)
+        assert v_c[0] == v_o[0] and v_c[1] == v_o[1]

@@ -1,0 +1,148 @@
+"""GPU parity tests of the multi-robot path (rows a7, a8, e of SURVEY.md section 8): the device-resident robot graph,
+its condensed graphs and the exchange, through the C ABI, against the CPU oracle driven through the same rounds by the
+plain-numpy restatement of the bookkeeping (tests/ref_condensed.py).
+Tolerances: condensed measurement <= 1e-6 (m, rad), information <= 1e-4 relative (it is the inverse of a 3x3 covariance
+whose entries agree to ~1e-9; the inversion amplifies by its condition number), poses <= 1e-6; the wire is float32."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cg_mrslam_amd import synth
+from cg_mrslam_amd.condensed import RobotGraph, unpack_wire
+from cg_mrslam_amd.mrslam import RobotRounds, RobotWorld, run_rounds_loopback
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rounds(graph_factory, robots, chunk, n_robots):
+    return [RobotRounds(graph_factory(r), RobotWorld(robots, r, chunk=chunk)) for r in range(n_robots)]
+
+
+def _meeting_world(n_robots, n_v, n_e, min_shared=8):
+    for seed in range(46, 120):                            # first seed whose walks actually meet
+        R = synth.make_multi_robot(n_robots, n_v, n_e, seed=seed)
+        if all(len(R[r]["in_closures"].get(q, [])) >= min_shared for r in range(n_robots) for q in range(n_robots) if q != r):
+            return R
+    raise AssertionError("no seed makes the robots meet")
+
+
+def test_two_robot_rounds_match_oracle_backend_edge_by_edge(ctx, oracle):
+    """Two robots, 8 rounds of 150 vertices each on one GPU (loopback exchange), the same rounds on the oracle backend:
+    every condensed edge of every round's final graphs, every received edge and the final poses agree; the received
+    condensed edges pull the foreign vertices towards their truth."""
+    import oracle_backend as ob
+    from ref_condensed import RefRobotGraph
+    R = _meeting_world(2, 1200, 4000)
+    n_rounds, chunk = 8, 150
+    gpu = _rounds(lambda r: RobotGraph(ctx, r, 2), R, chunk, 2)
+    ref = _rounds(lambda r: RefRobotGraph(ob.OracleContext(), r, 2), R, chunk, 2)
+    log_g = run_rounds_loopback(gpu, n_rounds)
+    log_o = run_rounds_loopback(ref, n_rounds)
+    exchanged = 0
+    for t in range(n_rounds):
+        (n_in_g, built_g, chi_g), (n_in_o, built_o, chi_o) = log_g[t], log_o[t]
+        assert built_g == built_o
+        if n_in_g is not None:
+            assert [list(a) for a in n_in_g] == [list(a) for a in n_in_o]
+            exchanged += int(np.sum(n_in_g))
+        assert np.allclose(chi_g, chi_o, rtol=1e-6)
+    assert exchanged > 20                                   # condensed edges really travelled, in several rounds
+    for r in range(2):
+        a, b = gpu[r].g, ref[r].g
+        assert a.counts() == b.counts()
+        gid_a, to_a, est_a, iu_a = a.condensed(1 - r)
+        gid_b, to_b, est_b, iu_b = b.condensed(1 - r)
+        assert gid_a == gid_b and len(to_a) >= 7 and np.array_equal(to_a, to_b)
+        assert np.abs(est_a - est_b).max() < 1e-6
+        assert np.abs(iu_a - iu_b).max() <= 1e-4 * np.abs(iu_b).max()
+        fa, ta, ma, ia = a.received_edges(1 - r)
+        fb, tb, mb, ib = b.received_edges(1 - r)
+        assert len(fa) >= 7 and np.array_equal(fa, fb) and np.array_equal(ta, tb)
+        assert np.abs(ma - mb).max() < 1e-5 and np.abs(ia - ib).max() <= 2e-4 * np.abs(ib).max()    # float32 wire
+        pa, pb = a.poses(), b.poses()
+        assert np.abs(pa[:, :2] - pb[:, :2]).max() < 1e-6 and np.abs(synth.normalize_theta(pa[:, 2] - pb[:, 2])).max() < 1e-6
+        # the wire message is what the restatement would send (ids exactly, float32 payload to rounding)
+        robot, n_e, n_c, edges, clos = unpack_wire(a.pack_host(), 2, a.cap)
+        robot_b, n_e_b, n_c_b, edges_b, clos_b = unpack_wire(b.pack_host(), 2, b.cap)
+        assert robot == robot_b == r and np.array_equal(n_e, n_e_b) and np.array_equal(n_c, n_c_b) and np.array_equal(clos, clos_b)
+        k = n_e[1 - r]
+        assert np.array_equal(edges[1 - r, :k]["to"], edges_b[1 - r, :k]["to"]) and np.array_equal(edges[1 - r, :k]["from"], edges_b[1 - r, :k]["from"])
+        assert np.abs(edges[1 - r, :k]["est"] - edges_b[1 - r, :k]["est"]).max() < 1e-5
+
+
+def test_condense_on_c5_sized_subgraph_with_100_requested_vertices(ctx, oracle):
+    """Row a7 at C5 size: a 5000-vertex / 20000-edge sub-graph, ~100 requested vertices (K ~ 100), against the oracle;
+    and the same through the flat-array entry point cgmr_condense."""
+    g = synth.make_pose_graph(5000, 20000, seed=321, id_base=30000)
+    rg = RobotGraph(ctx, 3, 4)
+    rg.add_vertices(g["ids"], g["poses"], g["fixed"])
+    rg.add_edges(g["ids"][g["edge_from"]], g["ids"][g["edge_to"]], g["meas"], g["info"])
+    rc, chi = rg.optimize(5)
+    assert rc == 0
+    want = g["ids"][np.sort(np.random.default_rng(5).choice(5000, size=101, replace=False))]
+    rg.insertOutClosure(1, want)
+    assert rg.computeCondensedGraph(1) == 1
+    gid, to, est, iu = rg.condensed(1)
+    p = rg.poses()
+    idx = (want - 30000).astype(np.int32)
+    c = p[idx, :2].mean(axis=0)
+    gauge = int(idx[np.argmin(np.sqrt(((p[idx, :2] - c) ** 2).sum(axis=1)))])
+    assert gid == 30000 + gauge and len(to) == 100
+    n, to_o, est_o, iu_o, _ = oracle.condense(p, g["edge_from"], g["edge_to"], g["meas"], g["info"], gauge, idx)
+    assert n == 100 and np.array_equal(to - 30000, to_o)
+    assert np.abs(est - est_o).max() < 1e-6 and np.abs(iu - iu_o).max() <= 1e-4 * np.abs(iu_o).max()
+    to_f, est_f, iu_f, _ = ctx.condense(p, g["edge_from"], g["edge_to"], g["meas"], g["info"], gauge, idx)
+    assert np.array_equal(to_f, to_o) and np.abs(est_f - est).max() < 1e-9 and np.abs(iu_f - iu).max() <= 1e-7 * np.abs(iu).max()
+    s = rg.last_seconds()
+    print(f"C5-sized condense, K = 100: {1e3 * s['condense']:.2f} ms; optimize(5) {1e3 * s['optimize']:.2f} ms")
+
+
+def test_native_rccl_allgather_single_rank(ctx):
+    """cgmr_comm_* / cgmr_allgather_condensed with a one-rank RCCL communicator: librccl resolves, the collective runs
+    on the side stream behind the context's stream, cgmr_comm_wait orders the ingest after it."""
+    lib = ctx.lib
+    uid = np.zeros(128, dtype=np.uint8)
+    assert lib.cgmr_comm_unique_id(C.c_void_p(uid.ctypes.data)) == 0
+    comm = C.c_void_p()
+    assert lib.cgmr_comm_create(ctx.h, C.c_int(1), C.c_int(0), C.c_void_p(uid.ctypes.data), C.byref(comm)) == 0, \
+        lib.cgmr_last_error(ctx.h)
+    g = RobotGraph(ctx, 0, 1)
+    g.add_vertices([0, 1, 2], np.zeros((3, 3)), [1, 0, 0])
+    g.insertInClosure(0, [1, 2])
+    g.pack(0)
+    rc = lib.cgmr_allgather_condensed(ctx.h, comm, C.c_void_p(g.send_buffer()), C.c_size_t(g.wire_bytes()), C.c_void_p(g.recv_buffer()))
+    assert rc == 0, lib.cgmr_last_error(ctx.h)
+    assert lib.cgmr_comm_wait(ctx.h, comm) == 0
+    n = g.ingest(0)
+    assert list(n) == [0]
+    ctx.synchronize()
+    sent = g.pack_host()
+    s = C.c_double()
+    assert lib.cgmr_comm_last_seconds(comm, C.byref(s)) == 0 and s.value >= 0
+    robot, n_e, n_c, edges, clos = unpack_wire(sent, 1, g.cap)
+    assert robot == 0 and list(n_c) == [2] and list(clos[0, :2]) == [1, 2]
+    lib.cgmr_comm_destroy.restype = None
+    lib.cgmr_comm_destroy(comm)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """``bench.py --gpus 2`` spawns its two ranks itself; on this one-GPU box they share cuda:0 and the collectives run
+    over gloo (CGMR_BENCH_SINGLE_DEVICE / CGMR_BENCH_BACKEND).  The C5 exchange leg must really exchange."""
+    env = dict(os.environ, CGMR_BENCH_SINGLE_DEVICE="1", CGMR_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--vertices", "2000",
+           "--edges", "7000", "--match-pairs", "0", "--c5-vertices", "800", "--c5-edges", "2800", "--c5-chunk", "100"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["warm"]["bit_identical_to_cold"]
+    ex = out["exchange"]
+    assert ex["robots"] == 2 and ex["rounds"] == 8 and ex["transport"] == "host"
+    assert ex["condensed_graphs_built_total"] > 0 and ex["condensed_edges_received_total"] > 0 and ex["status_rank0"] == 0
