@@ -41,6 +41,7 @@ struct cgmr_ctx {
   cgmr::GnDevice gn;
   double timing[5] = {0, 0, 0, 0, 0};
   double match_seconds = 0;
+  int64_t match_pairs = 0, match_slow_pairs = 0;   // last batched close-matching launch: pairs, pairs off the LDS fast path
   bool profiling = false;
   double ksec[8] = {0};
   int64_t klaunch[8] = {0};

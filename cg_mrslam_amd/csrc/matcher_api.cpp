@@ -65,10 +65,11 @@ int setup_geometry(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, MatchParams& P
   return CGMR_OK;
 }
 
-int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const float* d_ref, const float* d_qry,
-              const double* d_guess, double max_score, double* d_xyt, double* d_score, uint8_t* d_found,
-              int32_t* d_nres) {
-  if (!cfg || n_pairs < 0) return set_err(ctx, CGMR_E_INVALID, "cgmr_match_close_batch: bad argument");
+int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_ref_scans, const float* d_ref,
+              const double* d_xform, const float* d_qry, const double* d_guess, double max_score, double* d_xyt,
+              double* d_score, uint8_t* d_found, int32_t* d_nres) {
+  if (!cfg || n_pairs < 0 || n_ref_scans < 1 || n_ref_scans > kMatchMaxRefScans)
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_match_close_batch: bad argument (1..%d reference scans per pair)", kMatchMaxRefScans);
   if (cfg->n_beams <= 0 || cfg->n_beams > kMatchMaxPoints)
     return set_err(ctx, CGMR_E_INVALID, "n_beams %d outside (0, %d]", cfg->n_beams, kMatchMaxPoints);
   MatchParams P;
@@ -76,6 +77,7 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const 
   { int rc0 = setup_geometry(ctx, cfg, P, kern); if (rc0) return rc0; }
   P.n_pairs = n_pairs;
   P.n_beams = cfg->n_beams;
+  P.n_ref_scans = n_ref_scans;
   P.max_range = cfg->max_range; P.min_range = cfg->min_range;
   P.lp_c = std::cos(cfg->laser_pose[2]); P.lp_s = std::sin(cfg->laser_pose[2]);
   P.lp_x = cfg->laser_pose[0]; P.lp_y = cfg->laser_pose[1];
@@ -85,7 +87,8 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const 
   P.sub_res = cfg->subsample_res;
   if ((2 * cfg->win_theta) / cfg->theta_res + 2 > kMatchMaxTheta)
     return set_err(ctx, CGMR_E_INVALID, "more than %d search angles", kMatchMaxTheta);
-  P.scratch_stride = ((size_t)4 * kMatchMaxPoints * sizeof(double) + (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
+  P.scratch_stride = ((size_t)4 * kMatchMaxPoints * sizeof(double) + (size_t)4 * kMatchMaxRefScans * kMatchMaxPoints +
+                      (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
   if (n_pairs == 0) return CGMR_OK;
   hipDeviceProp_t prop;
   HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -113,19 +116,37 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const 
   char* d = ctx->mt_arena.ptr;
   HIP_TRY(ctx, hipMemcpyAsync(d, ctx->pinned, hbytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  launch_match_close_batch(ctx->stream, nblocks, P, d_ref, d_qry, d_guess, (const double*)(d + o_cos),
+  launch_match_close_batch(ctx->stream, nblocks, P, d_ref, d_xform, d_qry, d_guess, (const double*)(d + o_cos),
                            (const double*)(d + o_sin), (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch),
                            d_xyt, d_score, d_found, d_nres, (int*)(d + o_err));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  int err = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  int errv[4] = {0, 0, 0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, sizeof errv, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->match_seconds = 1e-3 * ms;
-  if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel rejected the search (code %d: window/bins too large)", err);
+  ctx->match_pairs = n_pairs;
+  ctx->match_slow_pairs = errv[2];
+  if (errv[0] != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel rejected the search (code %d: window/bins too large)", errv[0]);
   return CGMR_OK;
+}
+
+// (cos, sin, tx, ty) of rel * laserPose per reference scan: what transformPointsFromVSet hands applyTransfToScan
+void scan_transforms(const cgmr_matcher_config* cfg, size_t n, const double* rel_xyt, double* out4) {
+  const double lx = cfg->laser_pose[0], ly = cfg->laser_pose[1], lt = cfg->laser_pose[2];
+  const double pi = 3.14159265358979323846;
+  for (size_t k = 0; k < n; k++) {
+    const double* a = rel_xyt + 3 * k;
+    const double c = std::cos(a[2]), s = std::sin(a[2]);
+    double t = a[2] + lt;
+    if (!(t >= -pi && t < pi)) t = t - 2 * pi * std::floor((t + pi) / (2 * pi));
+    out4[4 * k] = std::cos(t);
+    out4[4 * k + 1] = std::sin(t);
+    out4[4 * k + 2] = a[0] + (c * lx - s * ly);
+    out4[4 * k + 3] = a[1] + (s * lx + c * ly);
+  }
 }
 
 }  // namespace
@@ -150,7 +171,63 @@ int cgmr_match_close_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
                                double* d_score, uint8_t* d_found, int32_t* d_nres) {
   if (!ctx) return CGMR_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return match_run(ctx, cfg, n_pairs, d_ref, d_qry, d_guess, max_score, d_xyt, d_score, d_found, d_nres);
+  return match_run(ctx, cfg, n_pairs, 1, d_ref, nullptr, d_qry, d_guess, max_score, d_xyt, d_score, d_found, d_nres);
+}
+
+int cgmr_scan_transforms(const cgmr_matcher_config* cfg, int n, const double* rel_xyt, double* xform_out) {
+  if (!cfg || n < 0 || (n > 0 && (!rel_xyt || !xform_out))) return CGMR_E_INVALID;
+  scan_transforms(cfg, (size_t)n, rel_xyt, xform_out);
+  return CGMR_OK;
+}
+
+int cgmr_match_close_vset_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_ref_scans,
+                                    const float* d_ranges_ref, const double* d_ref_xform, const float* d_ranges_qry,
+                                    const double* d_guess_xyt, double max_score, double* d_out_xyt, double* d_out_score,
+                                    uint8_t* d_out_found, int32_t* d_out_nresults) {
+  if (!ctx) return CGMR_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return match_run(ctx, cfg, n_pairs, n_ref_scans, d_ranges_ref, d_ref_xform, d_ranges_qry, d_guess_xyt, max_score, d_out_xyt,
+                   d_out_score, d_out_found, d_out_nresults);
+}
+
+int cgmr_match_close_vset_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_ref_scans,
+                                const float* ranges_ref, const double* ref_rel_xyt, const float* ranges_qry,
+                                const double* guess, double max_score, double* out_xyt, double* out_score,
+                                uint8_t* out_found, int32_t* out_nres) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || n_pairs < 0 || n_ref_scans < 1 || n_ref_scans > kMatchMaxRefScans ||
+      (n_pairs > 0 && (!ranges_ref || !ref_rel_xyt || !ranges_qry || !guess || !out_xyt || !out_score || !out_found)))
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_match_close_vset_batch: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n_pairs == 0) return CGMR_OK;
+  const size_t ns = (size_t)n_pairs * n_ref_scans, nbq = (size_t)n_pairs * cfg->n_beams, nbr = ns * cfg->n_beams;
+  std::vector<double> xf(4 * ns);
+  scan_transforms(cfg, ns, ref_rel_xyt, xf.data());
+  Layout L;
+  size_t o_ref = L.add(nbr * 4), o_xf = L.add(ns * 32), o_qry = L.add(nbq * 4), o_g = L.add((size_t)n_pairs * 24),
+         o_x = L.add((size_t)n_pairs * 24), o_s = L.add((size_t)n_pairs * 8), o_f = L.add(n_pairs), o_n = L.add((size_t)n_pairs * 4);
+  int rc = arena_reserve(ctx, ctx->io_arena, L.off + 256);
+  if (rc) return rc;
+  char* d = ctx->io_arena.ptr;
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_ref, ranges_ref, nbr * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_xf, xf.data(), ns * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_qry, ranges_qry, nbq * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_g, guess, (size_t)n_pairs * 24, hipMemcpyHostToDevice, ctx->stream));
+  rc = match_run(ctx, cfg, n_pairs, n_ref_scans, (const float*)(d + o_ref), (const double*)(d + o_xf), (const float*)(d + o_qry),
+                 (const double*)(d + o_g), max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), (int32_t*)(d + o_n));
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out_xyt, d + o_x, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out_score, d + o_s, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out_found, d + o_f, n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_nres) HIP_TRY(ctx, hipMemcpyAsync(out_nres, d + o_n, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CGMR_OK;
+}
+
+int cgmr_match_last_stats(const cgmr_ctx* ctx, int64_t out[2]) {
+  if (!ctx || !out) return CGMR_E_INVALID;
+  out[0] = ctx->match_pairs; out[1] = ctx->match_slow_pairs;
+  return CGMR_OK;
 }
 
 int cgmr_match_close_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const float* ranges_ref,
@@ -171,7 +248,7 @@ int cgmr_match_close_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_
   HIP_TRY(ctx, hipMemcpyAsync(d + o_ref, ranges_ref, nb * 4, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d + o_qry, ranges_qry, nb * 4, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d + o_g, guess, (size_t)n_pairs * 24, hipMemcpyHostToDevice, ctx->stream));
-  rc = match_run(ctx, cfg, n_pairs, (const float*)(d + o_ref), (const float*)(d + o_qry), (const double*)(d + o_g),
+  rc = match_run(ctx, cfg, n_pairs, 1, (const float*)(d + o_ref), nullptr, (const float*)(d + o_qry), (const double*)(d + o_g),
                  max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), (int32_t*)(d + o_n));
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(out_xyt, d + o_x, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -561,11 +638,30 @@ int cgmr_close_scan_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
     return set_err(ctx, CGMR_E_INVALID, "cgmr_close_scan_matching: bad argument");
   *found_out = 0;
   trel_out[0] = trel_out[1] = trel_out[2] = 0;
+  const Se2 org = se2_of(vset->poses_xyt + 3 * (size_t)vset->ref_index);
+  if (vset->n_scans <= kMatchMaxRefScans && cfg->n_beams <= kMatchMaxPoints) {
+    // the reference's call shape (last vertex + up to 5 predecessors): one pair of the batched kernel
+    std::vector<double> rel(3 * (size_t)vset->n_scans, 0.0);
+    for (int k = 0; k < vset->n_scans; k++) {
+      if (k == vset->ref_index) continue;                                          // origin: the laser pose alone (scan_matcher.cpp:102-103)
+      const Se2 r = se2_mul(se2_inv(org), se2_of(vset->poses_xyt + 3 * (size_t)k));
+      rel[3 * k] = r.x; rel[3 * k + 1] = r.y; rel[3 * k + 2] = r.t;
+    }
+    const Se2 g = se2_mul(se2_inv(org), se2_of(cur_pose_xyt));
+    const double guess[3] = {g.x, g.y, g.t};
+    double score = 0;
+    uint8_t found = 0;
+    int rc = cgmr_match_close_vset_batch(ctx, cfg, 1, vset->n_scans, vset->ranges, rel.data(), cur_ranges, guess, max_score,
+                                         trel_out, &score, &found, nullptr);
+    if (rc) return rc;
+    *found_out = found;
+    return CGMR_OK;
+  }
   std::vector<double> ref;
   points_from_vset(cfg, vset, nullptr, ref);                                       // scan_matcher.cpp:119-127
   std::vector<double> qry;
   apply_transf(se2_of(cfg->laser_pose), subsample_of(cartesian_of(cfg, cur_ranges), cfg->subsample_res), qry);   // :129-136
-  const Se2 g = se2_mul(se2_inv(se2_of(vset->poses_xyt + 3 * (size_t)vset->ref_index)), se2_of(cur_pose_xyt));
+  const Se2 g = se2_mul(se2_inv(org), se2_of(cur_pose_xyt));
   const float region[6] = {(float)(-cfg->win_x + g.x), (float)(-cfg->win_y + g.y), (float)(-cfg->win_theta + g.t),
                            (float)(cfg->win_x + g.x),  (float)(cfg->win_y + g.y),  (float)(cfg->win_theta + g.t)};
   const double step = (double)(float)cfg->resolution;

@@ -11,9 +11,11 @@ constexpr int kMatchDirGuardY = 7;           // directory guard band along y: 3 
 constexpr int kMatchMaxDir = 152 * 157;      // 8x8-cell tiles of the largest grid (1200 x 1200 cells) + guard band
 constexpr int kMatchTilesLds = 1408;         // tiles resident in LDS; the rest spills to HBM
 constexpr int kMatchMaxTheta = 80;           // search angles per region
+constexpr int kMatchMaxRefScans = 6;         // scans of a close-matching reference set (graph_slam.cpp:230-244: last vertex + 5)
 
 struct MatchParams {
   int n_pairs, n_beams;
+  int n_ref_scans;                           // scans per reference set of the batched close matcher (1..kMatchMaxRefScans)
   // grid (ScanMatcher::initializeGrid, src/matcher/scan_matcher.cpp:63-66; gridmap.h:196-214)
   float ll_x, ll_y, res, inv_res;
   int nx, ny;
@@ -49,7 +51,7 @@ void launch_match_verify(hipStream_t st, const MatchParams& P, const double* pts
 void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const double* ref_pts, const double* qry_pts,
                          const RegionDesc* regions, const double* theta, const int32_t* items, const uint8_t* kernel_lut,
                          unsigned char* scratch, unsigned long long* bins, int* err);
-void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref,
+void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
                               double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err);

@@ -131,7 +131,7 @@ __device__ __forceinline__ void stamp_word(uint32_t* wp, uint32_t kv) {
 
 // resetGrid + addAndConvolvePoints for n packed reference cells: directory marking, tile slot assignment (block
 // scan), tile initialisation, compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
-__device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
+__device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
                            int* err) {
   const int tid = threadIdx.x;
   const int NTHR = blockDim.x;
@@ -192,6 +192,7 @@ __device__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell,
     if (p >= n) continue;
     uint32_t packed = rcell[p];
     if (packed == 0x80008000u) continue;
+    if (p > 0 && rcell[p - 1] == packed) continue;       // neighbouring beams in one cell: the min is idempotent
     int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
     int x = rx + ki - ctr;
     if (x < 0 || x >= P.nx) continue;
@@ -235,7 +236,12 @@ __device__ __forceinline__ int grid_cell(const Smem& S, const MatchParams& P, co
 }  // namespace
 
 // One workgroup per scan pair (persistent stride over the batch).
+// Reference set: P.n_ref_scans scans per pair (1..kMatchMaxRefScans: the reference passes the last vertex and up to 5
+// predecessors, src/slam/graph_slam.cpp:230-244), ranges_ref [pair][scan][beam]; ref_xform [pair][scan][4] =
+// (cos, sin, tx, ty) of (origin^-1 * v_scan) * laserPose, computed on the host with libm exactly as
+// transformPointsFromVSet / applyTransfToScan do (scan_matcher.cpp:78-110); null = every scan at the laser pose.
 __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P, const float* __restrict__ ranges_ref,
+                                                           const double* __restrict__ ref_xform,
                                                            const float* __restrict__ ranges_qry,
                                                            const double* __restrict__ guess,
                                                            const double* __restrict__ beam_cos,
@@ -254,7 +260,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
   unsigned char* my = scratch + (size_t)blockIdx.x * P.scratch_stride;
   double* qraw = reinterpret_cast<double*>(my);                           // 2 * MAXPTS
   double* qpts = qraw + 2 * MAXPTS;                                       // 2 * MAXPTS
-  uint32_t* gtiles = reinterpret_cast<uint32_t*>(qpts + 2 * MAXPTS);      // overflow tiles
+  uint32_t* rcell_g = reinterpret_cast<uint32_t*>(qpts + 2 * MAXPTS);     // packed reference cells of a multi-scan set
+  uint32_t* gtiles = rcell_g + kMatchMaxRefScans * MAXPTS;                // overflow tiles
   const int nty = (P.ny + 7) >> 3;
   // directory with a guard band (1 tile row left/right, 3 tile columns below and 4 above) so that the fast search
   // path can look up cells outside the grid without a bounds test: guard entries point at the all-zero tile
@@ -340,20 +347,27 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     __syncthreads();
     MPHASE(2);
     // ---------------- reference scan -> cells -----------------------------------------------------------------
-    uint32_t* rcell = S.plist[0];           // int16 x | int16 y << 16, 0x80008000 = invalid
-    for (int i = tid; i < B; i += CB_THREADS) {
+    // a single scan's cells fit the (still idle) point lists in LDS; a multi-scan set goes through the HBM scratch
+    const int NS = P.n_ref_scans;
+    uint32_t* rcell_l = S.plist[0];         // int16 x | int16 y << 16, 0x80008000 = invalid
+    for (int i = tid; i < NS * B; i += CB_THREADS) {
+      const int sc = i / B, bm = i - sc * B;
       uint32_t packed = 0x80008000u;
-      double r = (double)ranges_ref[(size_t)pair * B + i];
+      double r = (double)ranges_ref[((size_t)pair * NS + sc) * B + bm];
       if (r < P.max_range && r > P.min_range) {
-        double x = beam_cos[i] * r, y = beam_sin[i] * r;
-        double wx = (P.lp_c * x - P.lp_s * y) + P.lp_x, wy = (P.lp_s * x + P.lp_c * y) + P.lp_y;
+        double x = beam_cos[bm] * r, y = beam_sin[bm] * r;
+        double tc = P.lp_c, ts = P.lp_s, tx = P.lp_x, ty = P.lp_y;
+        if (ref_xform) { const double* T = ref_xform + 4 * ((size_t)pair * NS + sc); tc = T[0]; ts = T[1]; tx = T[2]; ty = T[3]; }
+        double wx = (tc * x - ts * y) + tx, wy = (ts * x + tc * y) + ty;
         packed = world_to_packed_cell(P, wx, wy);
       }
-      rcell[i] = packed;
+      if (NS == 1) rcell_l[i] = packed; else rcell_g[i] = packed;
     }
     __syncthreads();
-    build_grid(S, P, rcell, B, gtiles, /*allow_fast=*/true, err);
+    if (NS == 1) build_grid(S, P, rcell_l, B, gtiles, /*allow_fast=*/true, err);
+    else build_grid(S, P, rcell_g, NS * B, gtiles, /*allow_fast=*/true, err);
     const bool fast = S.misc[12] != 0;
+    if (!fast && tid == 0) atomicAdd(err + 2, 1);          // pairs whose tiles did not fit LDS (generic search path)
     MPHASE(5);
     // ---------------- search window, angle table, bins -----------------------------------------------------
     if (tid == 0) {
@@ -806,12 +820,12 @@ void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, cons
                      kernel_lut, scratch, bins, err);
 }
 
-void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref,
+void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
                               double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err) {
   set_lds_attr_once<0>(reinterpret_cast<const void*>(k_match_close_batch));
-  hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(CB_THREADS), sizeof(Smem), st, P, ranges_ref, ranges_qry, guess,
+  hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(CB_THREADS), sizeof(Smem), st, P, ranges_ref, ref_xform, ranges_qry, guess,
                      beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err);
 }
 

@@ -237,6 +237,28 @@ class ScanMatcher(_GenericSearch):
             return found.astype(bool), xyt, score, nres
         return found.astype(bool), xyt, score
 
+    def closeScanMatchingVSetBatch(self, ranges_ref, ref_rel, ranges_cur, guess, maxScore=0.15):   # noqa: N802,N803
+        """Batched ``closeScanMatching`` with the reference's call shape: ``ranges_ref`` (P, S, n_beams) -- S <= 6 scans per
+        reference set (last vertex + predecessors, graph_slam.cpp:230-244), ``ref_rel`` (P, S, 3) = origin^-1 * v_k (zeros
+        for the origin), ``ranges_cur`` (P, n_beams), ``guess`` (P, 3).  Returns (found[P], trel[P,3], score[P])."""
+        rr = np.ascontiguousarray(ranges_ref, dtype=np.float32)
+        P, S, B = rr.shape
+        rq = np.ascontiguousarray(ranges_cur, dtype=np.float32).reshape(P, B)
+        rel = np.ascontiguousarray(ref_rel, dtype=np.float64).reshape(P, S, 3)
+        g = np.ascontiguousarray(guess, dtype=np.float64).reshape(P, 3)
+        xyt, score, found = np.zeros((P, 3)), np.zeros(P), np.zeros(P, dtype=np.uint8)
+        rc = self.ctx.lib.cgmr_match_close_vset_batch(self.ctx.h, C.byref(self.cfg), C.c_int(P), C.c_int(S), C.c_void_p(rr.ctypes.data),
+                                                      C.c_void_p(rel.ctypes.data), C.c_void_p(rq.ctypes.data),
+                                                      C.c_void_p(g.ctypes.data), C.c_double(maxScore), C.c_void_p(xyt.ctypes.data),
+                                                      C.c_void_p(score.ctypes.data), C.c_void_p(found.ctypes.data), C.c_void_p(0))
+        self.ctx._check(rc)
+        return found.astype(bool), xyt, score
+
+    def last_stats(self):
+        out = np.zeros(2, dtype=np.int64)
+        self.ctx._check(self.ctx.lib.cgmr_match_last_stats(self.ctx.h, C.c_void_p(out.ctypes.data)))
+        return {"pairs": int(out[0]), "slow_pairs": int(out[1])}
+
     def closeScanMatching_dev(self, d_ranges_ref, d_ranges_cur, d_guess, n_pairs, d_xyt, d_score, d_found,   # noqa: N802
                               maxScore=0.15, d_nres=0):   # noqa: N803
         """Device-pointer variant (ints from ``tensor.data_ptr()``)."""

@@ -165,6 +165,26 @@ int cgmr_match_close_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
                                const float* d_ranges_ref, const float* d_ranges_qry, const double* d_guess_xyt,
                                double max_score, double* d_out_xyt, double* d_out_score, uint8_t* d_out_found,
                                int32_t* d_out_nresults);
+/* The same with the reference's real call shape: GraphSLAM::addDataSM / findConstraints always pass the last vertex
+ * and up to 5 predecessors as the reference set (src/slam/graph_slam.cpp:230-244; scan_matcher.cpp:119-127 rasterises
+ * all of them into one grid).  Every pair has n_ref_scans (1..6) reference scans; a set with fewer is padded with
+ * all-zero scans (no valid beam).
+ *   ranges_ref   [n_pairs * n_ref_scans * n_beams]
+ *   ref_rel_xyt  [n_pairs * n_ref_scans * 3]   origin^-1 * v_k of every scan (zeros for the origin vertex itself)
+ * The _dev variant takes, instead of ref_rel_xyt, d_ref_xform [n_pairs * n_ref_scans * 4] = (cos, sin, tx, ty) of
+ * (origin^-1 * v_k) * laserPose as cgmr_scan_transforms() (host, libm -- what applyTransfToScan uses) computes them. */
+int cgmr_match_close_vset_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_ref_scans,
+                                const float* ranges_ref, const double* ref_rel_xyt, const float* ranges_qry,
+                                const double* guess_xyt, double max_score, double* out_xyt, double* out_score,
+                                uint8_t* out_found, int32_t* out_nresults);
+int cgmr_match_close_vset_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_ref_scans,
+                                    const float* d_ranges_ref, const double* d_ref_xform, const float* d_ranges_qry,
+                                    const double* d_guess_xyt, double max_score, double* d_out_xyt, double* d_out_score,
+                                    uint8_t* d_out_found, int32_t* d_out_nresults);
+int cgmr_scan_transforms(const cgmr_matcher_config* cfg, int n, const double* rel_xyt, double* xform_out);
+/* out[0] = pairs of the last batched close-matching launch, out[1] = those whose grid tiles did not fit the LDS pool
+ * (they take the slower generic search path; same results) */
+int cgmr_match_last_stats(const cgmr_ctx* ctx, int64_t out[2]);
 /* Device time (HIP events on the context's stream) of the last matcher launch, seconds. */
 int cgmr_match_last_kernel_seconds(const cgmr_ctx* ctx, double* seconds);
 

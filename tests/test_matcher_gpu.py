@@ -307,3 +307,63 @@ def test_c_abi_scan_matcher_members_match_python_restatement_on_oracle(ctx, orac
         v_c = lc.verifyMatching(scans[:2], 0, cur_set, 0, t12)
         v_o = lo.verifyMatching(scans[:2], 0, cur_set, 0, t12)
         assert v_c[0] == v_o[0] and v_c[1] == v_o[1]
+
+
+def _keyframe_sets(n_sets, n_scans=6, seed=77):
+    """Reference sets the way GraphSLAM::addDataSM builds them: the last vertex + its predecessors along a trajectory
+    (graph_slam.cpp:230-244), the next key frame as the current scan, odometry estimates as vertex poses."""
+    tr = synth.make_trajectory(40 + 3 * n_sets, seed=seed, laps=0.35)
+    ref, rel, cur, guess, sets = [], [], [], [], []
+    for k in range(n_sets):
+        last = 8 + 3 * k
+        idx = [last - 2 * j for j in range(n_scans)][::-1]          # origin (the last vertex) is the final scan of the set
+        scans = [(tr["scans"][i], tr["odom"][i]) for i in idx]
+        org = tr["odom"][last]
+        ref.append(np.stack([tr["scans"][i] for i in idx]))
+        rel.append(np.stack([np.zeros(3) if i == last else synth.se2_compose(synth.se2_inverse(org), tr["odom"][i]) for i in idx]))
+        cur.append(tr["scans"][last + 2])
+        guess.append(synth.se2_compose(synth.se2_inverse(org), tr["odom"][last + 2]))
+        sets.append((scans, n_scans - 1, tr["scans"][last + 2], tr["odom"][last + 2]))
+    return np.stack(ref), np.stack(rel), np.stack(cur), np.stack(guess), sets, tr
+
+
+def test_close_matching_batch_with_six_scan_reference_sets(ctx, oracle):
+    """The batched close matcher with the reference's real call shape (6-scan reference sets): bit-identical to the
+    per-set C entry point, to the generic search path, and to the Python restatement on the oracle; the sets stay on
+    the LDS fast path."""
+    import oracle_backend as ob
+    from cg_mrslam_amd.matcher import ScanMatcher
+    ref, rel, cur, guess, sets, tr = _keyframe_sets(24)
+    la = (1081, synth.LASER_ANGLE_MIN, synth.LASER_ANGLE_INC, 30.0)
+    m = ScanMatcher(ctx, *la)
+    found, trel, score = m.closeScanMatchingVSetBatch(ref, rel, cur, guess, 0.15)
+    st = m.last_stats()
+    assert st["pairs"] == 24 and st["slow_pairs"] == 0
+    assert found.sum() >= 22
+    mo = ob.OracleMatcher(la[1], la[2], la[3], (-15.0, -15.0), (15.0, 15.0), 0.025, 0.2)
+    for k in (0, 5, 11, 23):
+        scans, oi, cr, cp = sets[k]
+        f1, t1 = m.closeScanMatchingVSet(scans, oi, cr, cp, 0.15)                 # per-set C entry point
+        fo, to = mo.closeScanMatchingVSet(scans, oi, cr, cp, 0.15)               # restatement on the CPU oracle
+        assert f1 == fo == bool(found[k])
+        if fo:
+            assert np.array_equal(t1, to) and np.array_equal(trel[k], to)
+        # the generic search path on the same points
+        ref_pts = m.transformPointsFromVSet(scans, oi)
+        qry = m.subsample(m.cartesian(cr), 0.1)
+        g = guess[k]
+        region = np.array([[-.3 + g[0], -.3 + g[1], -0.2 + g[2], .3 + g[0], .3 + g[1], 0.2 + g[2]]], dtype=np.float32)
+        res = m.greedySearch(ref_pts, qry, region, 0.0125 * .5, 0.15, 0.5, 0.5, 0.2)
+        assert (len(res) > 0) == fo and (not fo or (np.array_equal(res[0, :3], to) and res[0, 3] == score[k]))
+    # the matched increments follow the true motion
+    for k in range(24):
+        if found[k]:
+            last = 8 + 3 * k
+            true_rel = synth.se2_compose(synth.se2_inverse(tr["truth"][last]), tr["truth"][last + 2])
+            # the estimate is relative to the odometry frame of the set; compare the increment's length
+            assert abs(np.hypot(*trel[k][:2]) - np.hypot(*true_rel[:2])) < 0.06
+    # fewer scans than the set holds: padded with all-zero scans (no valid beam) == the shorter set
+    pad = ref[:4].copy(); pad[:, :3] = 0.0
+    f_p, t_p, _ = m.closeScanMatchingVSetBatch(pad, rel[:4], cur[:4], guess[:4], 0.15)
+    f_s, t_s, _ = m.closeScanMatchingVSetBatch(ref[:4, 3:], rel[:4, 3:], cur[:4], guess[:4], 0.15)
+    assert np.array_equal(f_p, f_s) and np.array_equal(t_p, t_s)
