@@ -301,107 +301,147 @@ int cgmr_subsample(int n, const double* pts, double res, double* out) {
   return m;
 }
 
-// CharGrid::greedySearch on a grid rasterised from ref_pts: every result of the <= 4 thread maps, ascending score
-static int greedy_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts, int n_qry,
-                       const double* qry_pts, int n_regions, const float* regions, double step_x, double step_y,
-                       double theta_res, double max_score, double dx, double dy, double dth,
-                       std::vector<cgmr_match_result>& res) {
-  res.clear();
-  if (!cfg || n_ref < 0 || n_qry < 0 || n_regions < 0 || (n_ref > 0 && !ref_pts) ||
-      (n_qry > 0 && !qry_pts) || (n_regions > 0 && !regions) || !(theta_res > 0) ||
-      !(dx > 0) || !(dy > 0) || !(dth > 0))
-    return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
-  if (n_ref > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d reference points", kMatchMaxRef);
+// One search of a batch: CharGrid::greedySearch(mresvec, points, regions, params) on a grid rasterised from its own
+// reference points.
+struct SearchJob {
+  const double* ref = nullptr; int n_ref = 0;
+  const double* qry = nullptr; int n_qry = 0;
+  const float* regions = nullptr; int n_regions = 0;
+};
+
+// CharGrid::greedySearch for every job of the batch in ONE launch; per job every result of its <= 4 thread maps,
+// ascending score (ties: result-map order).  All jobs share the grid geometry, the steps and the discretisation.
+static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const std::vector<SearchJob>& jobs, double step_x,
+                             double step_y, double theta_res, double max_score, double dx, double dy, double dth,
+                             std::vector<std::vector<cgmr_match_result>>& out) {
+  const int nj = (int)jobs.size();
+  out.assign(nj, {});
+  if (!cfg || !(theta_res > 0) || !(dx > 0) || !(dy > 0) || !(dth > 0)) return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
+  for (const SearchJob& J : jobs) {
+    if (J.n_ref < 0 || J.n_qry < 0 || J.n_regions < 0 || (J.n_ref > 0 && !J.ref) || (J.n_qry > 0 && !J.qry) || (J.n_regions > 0 && !J.regions))
+      return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
+    if (J.n_ref > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d reference points", kMatchMaxRef);
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MatchParams P;
   std::vector<uint8_t> kern;
   int rc = setup_geometry(ctx, cfg, P, kern);
   if (rc) return rc;
   P.max_score = max_score; P.dx = dx; P.dy = dy; P.dth = dth; P.theta_res = theta_res;
-  P.n_ref = n_ref; P.n_qry = n_qry; P.n_regions = n_regions;
   // chargrid.cpp:214-221
   int xs = (int)(step_x / P.res), ys = (int)(step_y / P.res);
   if (xs <= 0) xs = 1;
   if (ys <= 0) ys = 1;
   P.x_steps = xs; P.y_steps = ys;
-  if (n_regions == 0) return CGMR_OK;
-  // regions -> descriptors, exactly like the reference walks them (chargrid.cpp:223-239)
-  const int num_threads = std::min(n_regions, 4);
-  const int chunk = n_regions / num_threads;
-  std::vector<RegionDesc> R(n_regions);
+  // regions -> descriptors, exactly like the reference walks them (chargrid.cpp:223-239), job by job
+  std::vector<RegionDesc> R;
   std::vector<double> theta;
-  std::vector<int32_t> items;
-  std::vector<uint32_t> next_order(num_threads, 0);
-  bool any = false;
-  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
+  std::vector<int32_t> items, block_job;
+  std::vector<GreedyJob> G(nj);
+  std::vector<int> first_region(nj, 0), nthreads(nj, 0);
+  size_t n_refs = 0, n_qrys = 0, total_bins = 0;
+  int max_ref = 1, nblocks = 0, live = 0;
   auto w2g = [&](float w, float ll) { return (int)std::lrint((w - ll) * P.inv_res); };
-  for (int r = 0; r < n_regions; r++) {
-    const float* g = regions + 6 * r;
-    RegionDesc& D = R[r];
-    D.lo_x = w2g(g[0], P.ll_x); D.lo_y = w2g(g[1], P.ll_y);
-    int hi_x = w2g(g[3], P.ll_x), hi_y = w2g(g[4], P.ll_y);
-    D.ni = hi_x > D.lo_x ? (hi_x - D.lo_x + xs - 1) / xs : 0;
-    D.nj = hi_y > D.lo_y ? (hi_y - D.lo_y + ys - 1) / ys : 0;
-    D.th_off = (int)theta.size();
-    for (double t = g[2]; t < g[5]; t += theta_res) {
-      theta.push_back(t);
-      if (theta.size() - D.th_off > 100000) return set_err(ctx, CGMR_E_INVALID, "too many search angles in a region");
+  for (const SearchJob& J : jobs) live += J.n_regions > 0 ? 1 : 0;
+  const int blocks_cap = std::max(1, std::min(128, 1024 / std::max(live, 1)));     // few jobs: several workgroups each
+  for (int j = 0; j < nj; j++) {
+    const SearchJob& J = jobs[j];
+    GreedyJob& D0 = G[j];
+    memset(&D0, 0, sizeof D0);
+    D0.ref_off = (int32_t)n_refs; D0.n_ref = J.n_ref; n_refs += (size_t)J.n_ref;
+    D0.qry_off = (int32_t)n_qrys; D0.n_qry = J.n_qry; n_qrys += (size_t)J.n_qry;
+    D0.item_off = (int32_t)(items.size() / 2);
+    D0.block0 = nblocks;
+    first_region[j] = (int)R.size();
+    max_ref = std::max(max_ref, J.n_ref);
+    if (J.n_regions == 0) continue;
+    const int num_threads = std::min(J.n_regions, 4);
+    const int chunk = J.n_regions / num_threads;
+    nthreads[j] = num_threads;
+    std::vector<uint32_t> next_order(num_threads, 0);
+    bool any = false;
+    int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
+    for (int r = 0; r < J.n_regions; r++) {
+      const float* g = J.regions + 6 * r;
+      RegionDesc D;
+      D.lo_x = w2g(g[0], P.ll_x); D.lo_y = w2g(g[1], P.ll_y);
+      int hi_x = w2g(g[3], P.ll_x), hi_y = w2g(g[4], P.ll_y);
+      D.ni = hi_x > D.lo_x ? (hi_x - D.lo_x + xs - 1) / xs : 0;
+      D.nj = hi_y > D.lo_y ? (hi_y - D.lo_y + ys - 1) / ys : 0;
+      D.th_off = (int)theta.size();
+      for (double t = g[2]; t < g[5]; t += theta_res) {
+        theta.push_back(t);
+        if (theta.size() - D.th_off > 100000) return set_err(ctx, CGMR_E_INVALID, "too many search angles in a region");
+      }
+      D.nth = (int)theta.size() - D.th_off;
+      D.thread = std::min(r / chunk, num_threads - 1);
+      D.order_base = next_order[D.thread];
+      unsigned long long cnt = (unsigned long long)D.nth * D.ni * D.nj;
+      if (next_order[D.thread] + cnt > 0xffffffffULL) return set_err(ctx, CGMR_E_INVALID, "search space exceeds 2^32 candidates per result map");
+      next_order[D.thread] += (uint32_t)cnt;
+      const int rid = (int)R.size();
+      R.push_back(D);
+      if (cnt == 0) continue;
+      for (int ti = 0; ti < D.nth; ti++) { items.push_back(rid); items.push_back(ti); }
+      float xa = P.ll_x + (P.res * (float)D.lo_x), xb = P.ll_x + (P.res * (float)(D.lo_x + (D.ni - 1) * xs));
+      float ya = P.ll_y + (P.res * (float)D.lo_y), yb = P.ll_y + (P.res * (float)(D.lo_y + (D.nj - 1) * ys));
+      int a0 = (int)((double)xa / dx), a1 = (int)((double)xb / dx), c0 = (int)((double)ya / dy), c1 = (int)((double)yb / dy);
+      int e0 = (int)(theta[D.th_off] / dth), e1 = (int)(theta[D.th_off + D.nth - 1] / dth);
+      if (!any) { bx0 = a0; bx1 = a1; by0 = c0; by1 = c1; bt0 = e0; bt1 = e1; any = true; }
+      else { bx0 = std::min(bx0, a0); bx1 = std::max(bx1, a1); by0 = std::min(by0, c0); by1 = std::max(by1, c1);
+             bt0 = std::min(bt0, e0); bt1 = std::max(bt1, e1); }
     }
-    D.nth = (int)theta.size() - D.th_off;
-    D.thread = std::min(r / chunk, num_threads - 1);
-    D.order_base = next_order[D.thread];
-    unsigned long long cnt = (unsigned long long)D.nth * D.ni * D.nj;
-    if (next_order[D.thread] + cnt > 0xffffffffULL) return set_err(ctx, CGMR_E_INVALID, "search space exceeds 2^32 candidates per result map");
-    next_order[D.thread] += (uint32_t)cnt;
-    if (cnt == 0) continue;
-    for (int ti = 0; ti < D.nth; ti++) { items.push_back(r); items.push_back(ti); }
-    float xa = P.ll_x + (P.res * (float)D.lo_x), xb = P.ll_x + (P.res * (float)(D.lo_x + (D.ni - 1) * xs));
-    float ya = P.ll_y + (P.res * (float)D.lo_y), yb = P.ll_y + (P.res * (float)(D.lo_y + (D.nj - 1) * ys));
-    int a0 = (int)((double)xa / dx), a1 = (int)((double)xb / dx), c0 = (int)((double)ya / dy), c1 = (int)((double)yb / dy);
-    int e0 = (int)(theta[D.th_off] / dth), e1 = (int)(theta[D.th_off + D.nth - 1] / dth);
-    if (!any) { bx0 = a0; bx1 = a1; by0 = c0; by1 = c1; bt0 = e0; bt1 = e1; any = true; }
-    else { bx0 = std::min(bx0, a0); bx1 = std::max(bx1, a1); by0 = std::min(by0, c0); by1 = std::max(by1, c1);
-           bt0 = std::min(bt0, e0); bt1 = std::max(bt1, e1); }
+    D0.n_items = (int32_t)(items.size() / 2) - D0.item_off;
+    if (!any || D0.n_items == 0) { D0.n_items = 0; continue; }
+    D0.bx0 = bx0; D0.by0 = by0; D0.bt0 = bt0; D0.nbx = bx1 - bx0 + 1; D0.nby = by1 - by0 + 1; D0.nbt = bt1 - bt0 + 1;
+    const size_t nbins = (size_t)D0.nbx * D0.nby * D0.nbt;
+    if (nbins * num_threads > (size_t)1 << 26) return set_err(ctx, CGMR_E_INVALID, "result discretisation too fine for the search volume");
+    D0.bins_off = (int64_t)total_bins;
+    total_bins += nbins * num_threads;
+    D0.n_blocks = std::max(1, std::min(blocks_cap, D0.n_items / 8));
+    for (int b = 0; b < D0.n_blocks; b++) block_job.push_back(j);
+    nblocks += D0.n_blocks;
   }
-  if (!any) return CGMR_OK;
-  P.bx0 = bx0; P.by0 = by0; P.bt0 = bt0; P.nbx = bx1 - bx0 + 1; P.nby = by1 - by0 + 1; P.nbt = bt1 - bt0 + 1;
-  const size_t nbins = (size_t)P.nbx * P.nby * P.nbt;
-  if (nbins * num_threads > (size_t)1 << 26) return set_err(ctx, CGMR_E_INVALID, "result discretisation too fine for the search volume");
-  P.n_items = (int)items.size() / 2;
-  int nblocks = std::max(1, std::min(128, P.n_items / 8));
-  P.ref_cap = (std::max(n_ref, 1) + 63) & ~63;
+  if (nblocks == 0) return CGMR_OK;
+  if (total_bins > (size_t)1 << 28) return set_err(ctx, CGMR_E_INVALID, "result maps of the batch exceed 2 GB");
+  P.ref_cap = (max_ref + 63) & ~63;
   P.scratch_stride = ((size_t)4 * P.ref_cap + (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
   Layout L;
-  size_t o_ref = L.add(16 * (size_t)std::max(n_ref, 1)), o_q = L.add(16 * (size_t)std::max(n_qry, 1)),
-         o_reg = L.add(sizeof(RegionDesc) * R.size()), o_th = L.add(8 * theta.size()), o_it = L.add(4 * items.size()),
-         o_kern = L.add(kern.size()), o_err = L.add(16);
+  size_t o_ref = L.add(16 * std::max<size_t>(n_refs, 1)), o_q = L.add(16 * std::max<size_t>(n_qrys, 1)),
+         o_reg = L.add(sizeof(RegionDesc) * std::max<size_t>(R.size(), 1)), o_th = L.add(8 * std::max<size_t>(theta.size(), 1)),
+         o_it = L.add(4 * std::max<size_t>(items.size(), 1)), o_job = L.add(sizeof(GreedyJob) * (size_t)nj),
+         o_bj = L.add(4 * block_job.size()), o_kern = L.add(kern.size()), o_err = L.add(16);
   size_t hbytes = L.off;
-  size_t o_bins = L.add(8 * nbins * num_threads), o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
+  size_t o_bins = L.add(8 * total_bins), o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
   rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
   if (rc) return rc;
-  rc = pinned_reserve(ctx, std::max(hbytes, 8 * nbins * num_threads));
+  rc = pinned_reserve(ctx, std::max(hbytes, 8 * total_bins));
   if (rc) return rc;
   char* h = ctx->pinned;
-  if (n_ref) memcpy(h + o_ref, ref_pts, 16 * (size_t)n_ref);
-  if (n_qry) memcpy(h + o_q, qry_pts, 16 * (size_t)n_qry);
-  memcpy(h + o_reg, R.data(), sizeof(RegionDesc) * R.size());
-  memcpy(h + o_th, theta.data(), 8 * theta.size());
-  memcpy(h + o_it, items.data(), 4 * items.size());
+  for (int j = 0; j < nj; j++) {
+    if (jobs[j].n_ref) memcpy(h + o_ref + 16 * (size_t)G[j].ref_off, jobs[j].ref, 16 * (size_t)jobs[j].n_ref);
+    if (jobs[j].n_qry) memcpy(h + o_q + 16 * (size_t)G[j].qry_off, jobs[j].qry, 16 * (size_t)jobs[j].n_qry);
+  }
+  if (!R.empty()) memcpy(h + o_reg, R.data(), sizeof(RegionDesc) * R.size());
+  if (!theta.empty()) memcpy(h + o_th, theta.data(), 8 * theta.size());
+  if (!items.empty()) memcpy(h + o_it, items.data(), 4 * items.size());
+  memcpy(h + o_job, G.data(), sizeof(GreedyJob) * (size_t)nj);
+  memcpy(h + o_bj, block_job.data(), 4 * block_job.size());
   memcpy(h + o_kern, kern.data(), kern.size());
   memset(h + o_err, 0, 16);
   char* d = ctx->mt_arena.ptr;
   HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(d + o_bins, 0xff, 8 * nbins * num_threads, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d + o_bins, 0xff, 8 * total_bins, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  launch_match_greedy(ctx->stream, nblocks, P, (const double*)(d + o_ref), (const double*)(d + o_q),
-                      (const RegionDesc*)(d + o_reg), (const double*)(d + o_th), (const int32_t*)(d + o_it),
-                      (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch), (unsigned long long*)(d + o_bins),
-                      (int*)(d + o_err));
+  launch_match_greedy(ctx->stream, nblocks, P, (const GreedyJob*)(d + o_job), (const int32_t*)(d + o_bj), (const double*)(d + o_ref),
+                      (const double*)(d + o_q), (const RegionDesc*)(d + o_reg), (const double*)(d + o_th),
+                      (const int32_t*)(d + o_it), (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch),
+                      (unsigned long long*)(d + o_bins), (int*)(d + o_err));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   int err = 0;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer is reused for the read-back below
   HIP_TRY(ctx, hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(h, d + o_bins, 8 * nbins * num_threads, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h, d + o_bins, 8 * total_bins, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   float ms = 0;
@@ -409,30 +449,53 @@ static int greedy_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref,
   ctx->match_seconds = 1e-3 * ms;
   if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", err);
   // decode: thread maps in thread order, each in (ix, iy, ith) order; then a stable sort on the score
-  const unsigned long long* bins = (const unsigned long long*)h;
-  for (int th = 0; th < num_threads; th++)
-    for (size_t q = 0; q < nbins; q++) {
-      unsigned long long key = bins[(size_t)th * nbins + q];
-      if (key == ~0ULL) continue;
-      uint32_t ord = (uint32_t)(key & 0xffffffffu);
-      int reg = -1;
-      for (int r = 0; r < n_regions; r++)
-        if (R[r].thread == th && (unsigned long long)R[r].nth * R[r].ni * R[r].nj > 0 && ord >= R[r].order_base &&
-            ord - R[r].order_base < (unsigned long long)R[r].nth * R[r].ni * R[r].nj) { reg = r; break; }
-      if (reg < 0) return set_err(ctx, CGMR_E_INVALID, "corrupt result key");
-      const RegionDesc& D = R[reg];
-      uint32_t local = ord - D.order_base;
-      int ncand = D.ni * D.nj;
-      int ti = (int)(local / ncand), cidx = (int)(local % ncand);
-      int a = cidx / D.nj, b = cidx % D.nj;
-      float wx = P.ll_x + (P.res * (float)(D.lo_x + a * xs));
-      float wy = P.ll_y + (P.res * (float)(D.lo_y + b * ys));
-      uint32_t sb = (uint32_t)(key >> 32);
-      float sc;
-      memcpy(&sc, &sb, 4);
-      res.push_back({(double)wx, (double)wy, theta[D.th_off + ti], (double)sc});
-    }
-  std::stable_sort(res.begin(), res.end(), [](const cgmr_match_result& a, const cgmr_match_result& b) { return a.score < b.score; });
+  for (int j = 0; j < nj; j++) {
+    const GreedyJob& D0 = G[j];
+    if (D0.n_items == 0) continue;
+    const size_t nbins = (size_t)D0.nbx * D0.nby * D0.nbt;
+    const unsigned long long* bins = (const unsigned long long*)h + D0.bins_off;
+    std::vector<cgmr_match_result>& res = out[j];
+    for (int th = 0; th < nthreads[j]; th++)
+      for (size_t q = 0; q < nbins; q++) {
+        unsigned long long key = bins[(size_t)th * nbins + q];
+        if (key == ~0ULL) continue;
+        uint32_t ord = (uint32_t)(key & 0xffffffffu);
+        int reg = -1;
+        for (int r = first_region[j]; r < first_region[j] + jobs[j].n_regions; r++) {
+          const unsigned long long cnt = (unsigned long long)R[r].nth * R[r].ni * R[r].nj;
+          if (R[r].thread == th && cnt > 0 && ord >= R[r].order_base && ord - R[r].order_base < cnt) { reg = r; break; }
+        }
+        if (reg < 0) return set_err(ctx, CGMR_E_INVALID, "corrupt result key");
+        const RegionDesc& D = R[reg];
+        uint32_t local = ord - D.order_base;
+        int ncand = D.ni * D.nj;
+        int ti = (int)(local / ncand), cidx = (int)(local % ncand);
+        int a = cidx / D.nj, b = cidx % D.nj;
+        float wx = P.ll_x + (P.res * (float)(D.lo_x + a * xs));
+        float wy = P.ll_y + (P.res * (float)(D.lo_y + b * ys));
+        uint32_t sb = (uint32_t)(key >> 32);
+        float sc;
+        memcpy(&sc, &sb, 4);
+        res.push_back({(double)wx, (double)wy, theta[D.th_off + ti], (double)sc});
+      }
+    std::stable_sort(res.begin(), res.end(), [](const cgmr_match_result& a, const cgmr_match_result& b) { return a.score < b.score; });
+  }
+  return CGMR_OK;
+}
+
+// single search
+static int greedy_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts, int n_qry,
+                       const double* qry_pts, int n_regions, const float* regions, double step_x, double step_y,
+                       double theta_res, double max_score, double dx, double dy, double dth,
+                       std::vector<cgmr_match_result>& res) {
+  res.clear();
+  std::vector<SearchJob> jobs(1);
+  jobs[0].ref = ref_pts; jobs[0].n_ref = n_ref; jobs[0].qry = qry_pts; jobs[0].n_qry = n_qry;
+  jobs[0].regions = regions; jobs[0].n_regions = n_regions;
+  std::vector<std::vector<cgmr_match_result>> out;
+  int rc = greedy_batch_core(ctx, cfg, jobs, step_x, step_y, theta_res, max_score, dx, dy, dth, out);
+  if (rc) return rc;
+  res.swap(out[0]);
   return CGMR_OK;
 }
 
@@ -452,50 +515,91 @@ int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, 
   return CGMR_OK;
 }
 
+struct VerifyIn {
+  const double* pts2 = nullptr; int n2 = 0;
+  const double* pts1 = nullptr; int n1 = 0;
+  float lower[2] = {0, 0}, upper[2] = {0, 0};
+};
+
+// numeric core of verifyMatching for a batch of candidate transforms, one workgroup each, one launch
+static int verify_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const std::vector<VerifyIn>& in, double nonmatched_score,
+                             std::vector<double>& score, std::vector<int>& nnm) {
+  const int nj = (int)in.size();
+  score.assign(nj, 0.0);
+  nnm.assign(nj, 0);
+  if (nj == 0) return CGMR_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MatchParams P;
+  std::vector<uint8_t> kern;
+  int rc = setup_geometry(ctx, cfg, P, kern);
+  if (rc) return rc;
+  auto w2g = [&](float w, float ll) { return (int)std::lrint((w - ll) * P.inv_res); };
+  std::vector<VerifyJob> J(nj);
+  size_t n2s = 0, n1s = 0;
+  int maxn = 1;
+  for (int j = 0; j < nj; j++) {
+    if (in[j].n1 < 0 || in[j].n2 < 0 || (in[j].n1 > 0 && !in[j].pts1) || (in[j].n2 > 0 && !in[j].pts2)) return set_err(ctx, CGMR_E_INVALID, "verify: bad argument");
+    if (in[j].n1 > kMatchMaxRef || in[j].n2 > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d points", kMatchMaxRef);
+    J[j].p2_off = (int32_t)n2s; J[j].n2 = in[j].n2; n2s += (size_t)in[j].n2;
+    J[j].p1_off = (int32_t)n1s; J[j].n1 = in[j].n1; n1s += (size_t)in[j].n1;
+    J[j].lo_x = w2g(in[j].lower[0], P.ll_x); J[j].lo_y = w2g(in[j].lower[1], P.ll_y);
+    J[j].hi_x = w2g(in[j].upper[0], P.ll_x); J[j].hi_y = w2g(in[j].upper[1], P.ll_y);
+    maxn = std::max(maxn, std::max(in[j].n1, in[j].n2));
+  }
+  P.ref_cap = (maxn + 63) & ~63;
+  P.scratch_stride = ((size_t)8 * P.ref_cap + (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
+  Layout L;
+  size_t o2 = L.add(16 * std::max<size_t>(n2s, 1)), o1 = L.add(16 * std::max<size_t>(n1s, 1)), o_job = L.add(sizeof(VerifyJob) * (size_t)nj),
+         o_kern = L.add(kern.size()), o_err = L.add(16);
+  size_t hbytes = L.off;
+  size_t o_sc = L.add(8 * (size_t)nj), o_nn = L.add(4 * (size_t)nj), o_scratch = L.add(P.scratch_stride * (size_t)nj);
+  rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
+  if (rc) return rc;
+  rc = pinned_reserve(ctx, hbytes);
+  if (rc) return rc;
+  char* h = ctx->pinned;
+  for (int j = 0; j < nj; j++) {
+    if (in[j].n2) memcpy(h + o2 + 16 * (size_t)J[j].p2_off, in[j].pts2, 16 * (size_t)in[j].n2);
+    if (in[j].n1) memcpy(h + o1 + 16 * (size_t)J[j].p1_off, in[j].pts1, 16 * (size_t)in[j].n1);
+  }
+  memcpy(h + o_job, J.data(), sizeof(VerifyJob) * (size_t)nj);
+  memcpy(h + o_kern, kern.data(), kern.size());
+  memset(h + o_err, 0, 16);
+  char* d = ctx->mt_arena.ptr;
+  HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  launch_match_verify(ctx->stream, nj, P, (const VerifyJob*)(d + o_job), (const double*)(d + o2), (const double*)(d + o1),
+                      nonmatched_score, (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch), (double*)(d + o_sc),
+                      (int*)(d + o_nn), (int*)(d + o_err));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  int err = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(score.data(), d + o_sc, 8 * (size_t)nj, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(nnm.data(), d + o_nn, 4 * (size_t)nj, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->match_seconds = 1e-3 * ms;
+  if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", err);
+  return CGMR_OK;
+}
+
 int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, const double* pts2, int n1, const double* pts1,
                       double nonmatched_score, const float lower_xy[2], const float upper_xy[2], double* score_out,
                       int* n_nonmatched_out) {
   if (!ctx) return CGMR_E_INVALID;
   if (!cfg || n1 < 0 || n2 < 0 || (n1 > 0 && !pts1) || (n2 > 0 && !pts2) || !lower_xy || !upper_xy || !score_out)
     return set_err(ctx, CGMR_E_INVALID, "cgmr_match_verify: bad argument");
-  if (n1 > kMatchMaxRef || n2 > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d points", kMatchMaxRef);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  MatchParams P;
-  std::vector<uint8_t> kern;
-  int rc = setup_geometry(ctx, cfg, P, kern);
+  std::vector<VerifyIn> in(1);
+  in[0].pts2 = pts2; in[0].n2 = n2; in[0].pts1 = pts1; in[0].n1 = n1;
+  in[0].lower[0] = lower_xy[0]; in[0].lower[1] = lower_xy[1]; in[0].upper[0] = upper_xy[0]; in[0].upper[1] = upper_xy[1];
+  std::vector<double> score;
+  std::vector<int> nnm;
+  int rc = verify_batch_core(ctx, cfg, in, nonmatched_score, score, nnm);
   if (rc) return rc;
-  P.n_ref = n2; P.n_qry = n1;
-  P.ref_cap = (std::max(std::max(n1, n2), 1) + 63) & ~63;
-  auto w2g = [&](float w, float ll) { return (int)std::lrint((w - ll) * P.inv_res); };
-  int lo_x = w2g(lower_xy[0], P.ll_x), lo_y = w2g(lower_xy[1], P.ll_y), hi_x = w2g(upper_xy[0], P.ll_x), hi_y = w2g(upper_xy[1], P.ll_y);
-  Layout L;
-  size_t o2 = L.add(16 * (size_t)std::max(n2, 1)), o1 = L.add(16 * (size_t)std::max(n1, 1)), o_kern = L.add(kern.size()),
-         o_err = L.add(16);
-  size_t hbytes = L.off;
-  size_t o_out = L.add(16), o_scratch = L.add((size_t)8 * P.ref_cap + (size_t)P.overflow_tiles * 64 + 256);
-  rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
-  if (rc) return rc;
-  rc = pinned_reserve(ctx, hbytes);
-  if (rc) return rc;
-  char* h = ctx->pinned;
-  if (n2) memcpy(h + o2, pts2, 16 * (size_t)n2);
-  if (n1) memcpy(h + o1, pts1, 16 * (size_t)n1);
-  memcpy(h + o_kern, kern.data(), kern.size());
-  memset(h + o_err, 0, 16);
-  char* d = ctx->mt_arena.ptr;
-  HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
-  launch_match_verify(ctx->stream, P, (const double*)(d + o2), (const double*)(d + o1), nonmatched_score, lo_x, lo_y, hi_x, hi_y,
-                      (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch), (double*)(d + o_out), (int*)(d + o_out + 8),
-                      (int*)(d + o_err));
-  struct { double score; int nnm; int pad; } out;
-  int err = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&out, d + o_out, 16, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipGetLastError());
-  if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", err);
-  *score_out = out.score;
-  if (n_nonmatched_out) *n_nonmatched_out = out.nnm;
+  *score_out = score[0];
+  if (n_nonmatched_out) *n_nonmatched_out = nnm[0];
   return CGMR_OK;
 }
 
@@ -566,36 +670,67 @@ std::vector<double> subsample_of(const std::vector<double>& pts, double res) {
   return out;
 }
 
-// CharGrid::hierarchicalSearch (chargrid.cpp:310-344, 376-400): levels n-1 .. 0, step 2^i cells, theta step
-// max(2^i / 2, 1) * thetaRes, bins 2^i * (dx, dy, dth); every result of a level seeds a region of half a bin around
-// it for the next one; the last level only runs if the one before found something.
-int hierarchical_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref, int n_qry, const double* qry,
-                      int n_regions, const float* regions, double theta_res, double max_score, double dx, double dy,
-                      double dth, int n_levels, std::vector<cgmr_match_result>& out) {
-  out.clear();
-  std::vector<float> cur(regions, regions + 6 * (size_t)n_regions);
+// CharGrid::hierarchicalSearch (chargrid.cpp:310-344, 376-400) for a batch of searches: levels n-1 .. 0, step 2^i
+// cells, theta step max(2^i / 2, 1) * thetaRes, bins 2^i * (dx, dy, dth); every result of a level seeds a region of
+// half a bin around it for the next one; the last level only runs if the one before found something.  One launch per
+// level serves every search that is still alive.
+int hierarchical_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const std::vector<SearchJob>& jobs0, double theta_res,
+                            double max_score, double dx, double dy, double dth, int n_levels,
+                            std::vector<std::vector<cgmr_match_result>>& out) {
+  const int nj = (int)jobs0.size();
+  out.assign(nj, {});
+  std::vector<std::vector<float>> cur(nj);
+  std::vector<uint8_t> alive(nj, 1);
+  for (int j = 0; j < nj; j++) cur[j].assign(jobs0[j].regions, jobs0[j].regions + 6 * (size_t)jobs0[j].n_regions);
   const float res_f = (float)cfg->resolution;
   for (int lv = 0; lv < n_levels; lv++) {
     const int i = n_levels - 1 - lv;
     const int m = 1 << i;
     const int mtheta = (m / 2 < 1) ? m : m / 2;
     const bool last = lv == n_levels - 1;
-    if (last && out.empty()) break;
+    std::vector<SearchJob> jobs;
+    std::vector<int> who;
+    for (int j = 0; j < nj; j++) {
+      if (!alive[j]) continue;
+      if (last && out[j].empty()) { alive[j] = 0; continue; }
+      SearchJob J = jobs0[j];
+      J.regions = cur[j].data();
+      J.n_regions = (int)(cur[j].size() / 6);
+      jobs.push_back(J);
+      who.push_back(j);
+    }
+    if (jobs.empty()) break;
     const float stepf = (float)m * res_f;
-    int rc = greedy_core(ctx, cfg, n_ref, ref, n_qry, qry, (int)(cur.size() / 6), cur.data(), (double)stepf, (double)stepf,
-                         mtheta * theta_res, max_score, dx * m, dy * m, dth * m, out);
+    std::vector<std::vector<cgmr_match_result>> res;
+    int rc = greedy_batch_core(ctx, cfg, jobs, (double)stepf, (double)stepf, mtheta * theta_res, max_score, dx * m, dy * m, dth * m, res);
     if (rc) return rc;
-    if (last || out.empty()) break;
     const double half[3] = {dx * m * .5, dy * m * .5, dth * m * .5};
-    cur.resize(6 * out.size());
-    for (size_t k = 0; k < out.size(); k++) {
-      const double c[3] = {out[k].x, out[k].y, out[k].theta};
-      for (int a = 0; a < 3; a++) {
-        cur[6 * k + a] = (float)(-half[a] + c[a]);
-        cur[6 * k + 3 + a] = (float)(half[a] + c[a]);
+    for (size_t q = 0; q < who.size(); q++) {
+      const int j = who[q];
+      out[j].swap(res[q]);
+      if (last || out[j].empty()) { alive[j] = 0; continue; }
+      cur[j].resize(6 * out[j].size());
+      for (size_t k = 0; k < out[j].size(); k++) {
+        const double c[3] = {out[j][k].x, out[j][k].y, out[j][k].theta};
+        for (int a = 0; a < 3; a++) {
+          cur[j][6 * k + a] = (float)(-half[a] + c[a]);
+          cur[j][6 * k + 3 + a] = (float)(half[a] + c[a]);
+        }
       }
     }
   }
+  return CGMR_OK;
+}
+
+int hierarchical_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref, int n_qry, const double* qry,
+                      int n_regions, const float* regions, double theta_res, double max_score, double dx, double dy,
+                      double dth, int n_levels, std::vector<cgmr_match_result>& out) {
+  std::vector<SearchJob> jobs(1);
+  jobs[0].ref = ref; jobs[0].n_ref = n_ref; jobs[0].qry = qry; jobs[0].n_qry = n_qry; jobs[0].regions = regions; jobs[0].n_regions = n_regions;
+  std::vector<std::vector<cgmr_match_result>> res;
+  int rc = hierarchical_batch_core(ctx, cfg, jobs, theta_res, max_score, dx, dy, dth, n_levels, res);
+  if (rc) return rc;
+  out.swap(res[0]);
   return CGMR_OK;
 }
 
@@ -673,90 +808,153 @@ int cgmr_close_scan_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
   return CGMR_OK;
 }
 
-int cgmr_scan_matching_lc(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
-                          const cgmr_scan_set* cur_set, double max_score, double* trel_out, int* n_out) {
+int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* ref_sets,
+                                const cgmr_scan_set* cur_sets, double max_score, double* trel_out, int* n_out) {
   if (!ctx) return CGMR_E_INVALID;
-  if (!cfg || !scan_set_ok(ref_set) || !scan_set_ok(cur_set) || !trel_out || !n_out)
+  if (!cfg || n_jobs < 0 || (n_jobs > 0 && (!ref_sets || !cur_sets || !trel_out || !n_out)))
     return set_err(ctx, CGMR_E_INVALID, "cgmr_scan_matching_lc: bad argument");
-  *n_out = 0;
-  std::vector<double> ref, cur;
-  points_from_vset(cfg, ref_set, nullptr, ref);
-  points_from_vset(cfg, cur_set, nullptr, cur);
-  std::vector<double> qry = subsample_of(cur, 0.1);                                // scan_matcher.cpp:216-217
-  const Se2 refp = se2_of(ref_set->poses_xyt + 3 * (size_t)ref_set->ref_index);
-  std::vector<float> regions, regionspi;                                           // :219-256
-  for (int k = 0; k < ref_set->n_scans; k++) {
-    Se2 rel = {0, 0, 0};
-    if (k != ref_set->ref_index) rel = se2_mul(se2_inv(refp), se2_of(ref_set->poses_xyt + 3 * (size_t)k));
-    const float lo[3] = {(float)(-.5 + rel.x), (float)(-1.5 + rel.y), (float)(-0.8 + rel.t)};
-    const float hi[3] = {(float)(.5 + rel.x), (float)(1.5 + rel.y), (float)(0.8 + rel.t)};
-    const float pi_f = (float)3.14159265358979323846;                              // Vector3f += M_PI: float arithmetic
-    regions.insert(regions.end(), {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]});
-    regionspi.insert(regionspi.end(), {lo[0], lo[1], lo[2] + pi_f, hi[0], hi[1], hi[2] + pi_f});
+  for (int j = 0; j < n_jobs; j++)
+    if (!scan_set_ok(ref_sets + j) || !scan_set_ok(cur_sets + j)) return set_err(ctx, CGMR_E_INVALID, "cgmr_scan_matching_lc: bad scan set");
+  struct Key { int a, b, c; bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); } };
+  std::vector<std::vector<double>> ref(n_jobs), qry(n_jobs);
+  std::vector<std::vector<float>> regions(n_jobs), regionspi(n_jobs);
+  for (int j = 0; j < n_jobs; j++) {
+    std::vector<double> cur;
+    points_from_vset(cfg, ref_sets + j, nullptr, ref[j]);
+    points_from_vset(cfg, cur_sets + j, nullptr, cur);
+    qry[j] = subsample_of(cur, 0.1);                                               // scan_matcher.cpp:216-217
+    const cgmr_scan_set* S = ref_sets + j;
+    const Se2 refp = se2_of(S->poses_xyt + 3 * (size_t)S->ref_index);
+    for (int k = 0; k < S->n_scans; k++) {                                         // :219-256
+      Se2 rel = {0, 0, 0};
+      if (k != S->ref_index) rel = se2_mul(se2_inv(refp), se2_of(S->poses_xyt + 3 * (size_t)k));
+      const float lo[3] = {(float)(-.5 + rel.x), (float)(-1.5 + rel.y), (float)(-0.8 + rel.t)};
+      const float hi[3] = {(float)(.5 + rel.x), (float)(1.5 + rel.y), (float)(0.8 + rel.t)};
+      const float pi_f = (float)3.14159265358979323846;                            // Vector3f += M_PI: float arithmetic
+      regions[j].insert(regions[j].end(), {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]});
+      regionspi[j].insert(regionspi[j].end(), {lo[0], lo[1], lo[2] + pi_f, hi[0], hi[1], hi[2] + pi_f});
+    }
   }
   const double theta_res = 0.025, dx = 0.5, dy = 0.5, dth = 0.2;                   // :258-263
   const double step = (double)(float)cfg->resolution;
-  struct Key { int a, b, c; bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); } };
-  std::vector<std::pair<Key, cgmr_match_result>> merged;                           // addToPrunedMap, chargrid.cpp:36-46
-  for (const std::vector<float>* regs : {&regions, &regionspi}) {
-    std::vector<cgmr_match_result> res;
-    int rc = greedy_core(ctx, cfg, (int)(ref.size() / 2), ref.data(), (int)(qry.size() / 2), qry.data(), (int)(regs->size() / 6),
-                         regs->data(), step, step, theta_res, max_score, dx, dy, dth, res);
+  std::vector<std::vector<std::pair<Key, cgmr_match_result>>> merged(n_jobs);      // addToPrunedMap, chargrid.cpp:36-46
+  for (int pass = 0; pass < 2; pass++) {
+    std::vector<SearchJob> jobs(n_jobs);
+    for (int j = 0; j < n_jobs; j++) {
+      const std::vector<float>& rg = pass ? regionspi[j] : regions[j];
+      jobs[j].ref = ref[j].data(); jobs[j].n_ref = (int)(ref[j].size() / 2);
+      jobs[j].qry = qry[j].data(); jobs[j].n_qry = (int)(qry[j].size() / 2);
+      jobs[j].regions = rg.data(); jobs[j].n_regions = (int)(rg.size() / 6);
+    }
+    std::vector<std::vector<cgmr_match_result>> res;
+    int rc = greedy_batch_core(ctx, cfg, jobs, step, step, theta_res, max_score, dx, dy, dth, res);
     if (rc) return rc;
-    if (res.empty()) continue;
-    cgmr_match_result best = res[0];
-    best.theta = norm_theta(best.theta);
-    const Key key = {(int)(best.x / dx), (int)(best.y / dy), (int)(best.theta / dth)};
-    bool seen = false;
-    for (auto& kv : merged)
-      if (!(kv.first < key) && !(key < kv.first)) { seen = true; if (kv.second.score > best.score) kv.second = best; }
-    if (!seen) merged.emplace_back(key, best);
+    for (int j = 0; j < n_jobs; j++) {
+      if (res[j].empty()) continue;
+      cgmr_match_result best = res[j][0];
+      best.theta = norm_theta(best.theta);
+      const Key key = {(int)(best.x / dx), (int)(best.y / dy), (int)(best.theta / dth)};
+      bool seen = false;
+      for (auto& kv : merged[j])
+        if (!(kv.first < key) && !(key < kv.first)) { seen = true; if (kv.second.score > best.score) kv.second = best; }
+      if (!seen) merged[j].emplace_back(key, best);
+    }
   }
-  std::sort(merged.begin(), merged.end(), [](const std::pair<Key, cgmr_match_result>& a, const std::pair<Key, cgmr_match_result>& b) { return a.first < b.first; });
-  for (size_t k = 0; k < merged.size(); k++) {
-    trel_out[3 * k] = merged[k].second.x; trel_out[3 * k + 1] = merged[k].second.y; trel_out[3 * k + 2] = merged[k].second.theta;
+  for (int j = 0; j < n_jobs; j++) {
+    auto& mj = merged[j];
+    std::sort(mj.begin(), mj.end(), [](const std::pair<Key, cgmr_match_result>& a, const std::pair<Key, cgmr_match_result>& b) { return a.first < b.first; });
+    for (size_t k = 0; k < mj.size(); k++) {
+      double* t = trel_out + 6 * (size_t)j + 3 * k;
+      t[0] = mj[k].second.x; t[1] = mj[k].second.y; t[2] = mj[k].second.theta;
+    }
+    n_out[j] = (int)mj.size();
   }
-  *n_out = (int)merged.size();
+  return CGMR_OK;
+}
+
+int cgmr_scan_matching_lc(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
+                          const cgmr_scan_set* cur_set, double max_score, double* trel_out, int* n_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!ref_set || !cur_set || !trel_out || !n_out) return set_err(ctx, CGMR_E_INVALID, "cgmr_scan_matching_lc: bad argument");
+  *n_out = 0;
+  return cgmr_scan_matching_lc_batch(ctx, cfg, 1, ref_set, cur_set, max_score, trel_out, n_out);
+}
+
+int cgmr_global_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* ref_sets,
+                               const cgmr_scan_set* cur_sets, double max_score, double* trel_out, int* found_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || n_jobs < 0 || (n_jobs > 0 && (!ref_sets || !cur_sets || !trel_out || !found_out)))
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_global_matching: bad argument");
+  for (int j = 0; j < n_jobs; j++)
+    if (!scan_set_ok(ref_sets + j) || !scan_set_ok(cur_sets + j)) return set_err(ctx, CGMR_E_INVALID, "cgmr_global_matching: bad scan set");
+  std::vector<std::vector<double>> ref(n_jobs), qry(n_jobs);
+  const float pi_f = (float)3.14159265358979323846;
+  const float region[6] = {-10.f, -5.f, -pi_f, 10.f, 5.f, pi_f};                   // scan_matcher.cpp:383-391
+  std::vector<SearchJob> jobs(n_jobs);
+  for (int j = 0; j < n_jobs; j++) {
+    std::vector<double> cur;
+    points_from_vset(cfg, ref_sets + j, nullptr, ref[j]);
+    points_from_vset(cfg, cur_sets + j, nullptr, cur);
+    qry[j] = subsample_of(cur, 0.1);
+    jobs[j].ref = ref[j].data(); jobs[j].n_ref = (int)(ref[j].size() / 2);
+    jobs[j].qry = qry[j].data(); jobs[j].n_qry = (int)(qry[j].size() / 2);
+    jobs[j].regions = region; jobs[j].n_regions = 1;
+  }
+  std::vector<std::vector<cgmr_match_result>> res;
+  int rc = hierarchical_batch_core(ctx, cfg, jobs, 0.025, max_score, 0.5, 0.5, 0.2, 4, res);
+  if (rc) return rc;
+  for (int j = 0; j < n_jobs; j++) {
+    double* t = trel_out + 3 * (size_t)j;
+    t[0] = t[1] = t[2] = 0;
+    found_out[j] = res[j].empty() ? 0 : 1;
+    if (!res[j].empty()) { t[0] = res[j][0].x; t[1] = res[j][0].y; t[2] = res[j][0].theta; }
+  }
   return CGMR_OK;
 }
 
 int cgmr_global_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
                          const cgmr_scan_set* cur_set, double max_score, double trel_out[3], int* found_out) {
   if (!ctx) return CGMR_E_INVALID;
-  if (!cfg || !scan_set_ok(ref_set) || !scan_set_ok(cur_set) || !trel_out || !found_out)
-    return set_err(ctx, CGMR_E_INVALID, "cgmr_global_matching: bad argument");
+  if (!ref_set || !cur_set || !trel_out || !found_out) return set_err(ctx, CGMR_E_INVALID, "cgmr_global_matching: bad argument");
   *found_out = 0;
-  trel_out[0] = trel_out[1] = trel_out[2] = 0;
-  std::vector<double> ref, cur;
-  points_from_vset(cfg, ref_set, nullptr, ref);
-  points_from_vset(cfg, cur_set, nullptr, cur);
-  std::vector<double> qry = subsample_of(cur, 0.1);
-  const float pi_f = (float)3.14159265358979323846;
-  const float region[6] = {-10.f, -5.f, -pi_f, 10.f, 5.f, pi_f};                   // scan_matcher.cpp:383-391
-  std::vector<cgmr_match_result> res;
-  int rc = hierarchical_core(ctx, cfg, (int)(ref.size() / 2), ref.data(), (int)(qry.size() / 2), qry.data(), 1, region, 0.025,
-                             max_score, 0.5, 0.5, 0.2, 4, res);
+  return cgmr_global_matching_batch(ctx, cfg, 1, ref_set, cur_set, max_score, trel_out, found_out);
+}
+
+int cgmr_verify_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* sets1,
+                               const cgmr_scan_set* sets2, const double* trel12, double* score_out, int* accepted_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || n_jobs < 0 || (n_jobs > 0 && (!sets1 || !sets2 || !trel12 || !score_out)))
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_verify_matching: bad argument");
+  for (int j = 0; j < n_jobs; j++)
+    if (!scan_set_ok(sets1 + j) || !scan_set_ok(sets2 + j)) return set_err(ctx, CGMR_E_INVALID, "cgmr_verify_matching: bad scan set");
+  std::vector<std::vector<double>> p2(n_jobs), p1(n_jobs);
+  std::vector<VerifyIn> in(n_jobs);
+  for (int j = 0; j < n_jobs; j++) {
+    const double* t = trel12 + 3 * (size_t)j;
+    const Se2 t12 = se2_of(t);
+    points_from_vset(cfg, sets2 + j, &t12, p2[j]);                                 // scan_matcher.cpp:441-458
+    points_from_vset(cfg, sets1 + j, nullptr, p1[j]);
+    in[j].pts2 = p2[j].data(); in[j].n2 = (int)(p2[j].size() / 2);
+    in[j].pts1 = p1[j].data(); in[j].n1 = (int)(p1[j].size() / 2);
+    in[j].lower[0] = (float)(-.3 + t[0]); in[j].lower[1] = (float)(-.3 + t[1]);    // :486-489
+    in[j].upper[0] = (float)(.3 + t[0]); in[j].upper[1] = (float)(.3 + t[1]);
+  }
+  std::vector<double> score;
+  std::vector<int> nnm;
+  int rc = verify_batch_core(ctx, cfg, in, 0.3, score, nnm);
   if (rc) return rc;
-  if (!res.empty()) { *found_out = 1; trel_out[0] = res[0].x; trel_out[1] = res[0].y; trel_out[2] = res[0].theta; }
+  for (int j = 0; j < n_jobs; j++) {
+    score_out[j] = score[j];
+    if (accepted_out) accepted_out[j] = (score[j] <= 40.0) ? 1 : 0;                // :497-504
+  }
   return CGMR_OK;
 }
 
 int cgmr_verify_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* set1, const cgmr_scan_set* set2,
                          const double trel12[3], double* score_out, int* accepted_out) {
   if (!ctx) return CGMR_E_INVALID;
-  if (!cfg || !scan_set_ok(set1) || !scan_set_ok(set2) || !trel12 || !score_out)
-    return set_err(ctx, CGMR_E_INVALID, "cgmr_verify_matching: bad argument");
-  const Se2 t12 = se2_of(trel12);
-  std::vector<double> pts2, pts1;
-  points_from_vset(cfg, set2, &t12, pts2);                                         // scan_matcher.cpp:441-458
-  points_from_vset(cfg, set1, nullptr, pts1);
-  const float lower[2] = {(float)(-.3 + trel12[0]), (float)(-.3 + trel12[1])};     // :486-489
-  const float upper[2] = {(float)(.3 + trel12[0]), (float)(.3 + trel12[1])};
-  int rc = cgmr_match_verify(ctx, cfg, (int)(pts2.size() / 2), pts2.data(), (int)(pts1.size() / 2), pts1.data(), 0.3, lower,
-                             upper, score_out, nullptr);
-  if (rc) return rc;
-  if (accepted_out) *accepted_out = (*score_out <= 40.0) ? 1 : 0;                  // :497-504
-  return CGMR_OK;
+  if (!set1 || !set2 || !trel12 || !score_out) return set_err(ctx, CGMR_E_INVALID, "cgmr_verify_matching: bad argument");
+  return cgmr_verify_matching_batch(ctx, cfg, 1, set1, set2, trel12, score_out, accepted_out);
 }
 
 int cgmr_match_last_kernel_seconds(const cgmr_ctx* ctx, double* seconds) {

@@ -44,13 +44,30 @@ struct RegionDesc {                          // one search region, precomputed o
   uint32_t order_base;                       // visit order of its first candidate inside that map
 };
 
+// One search of a batched k_match_greedy launch (own reference / query points, regions, result maps)
+struct GreedyJob {
+  int32_t ref_off, n_ref;                    // points into the launch's reference / query point arrays
+  int32_t qry_off, n_qry;
+  int32_t item_off, n_items;                 // its (region, angle) work items
+  int32_t bx0, by0, bt0, nbx, nby, nbt;      // bounding box of its result bins
+  int32_t block0, n_blocks;                  // workgroups [block0, block0 + n_blocks) serve it
+  int64_t bins_off;                          // first key of its result maps (num_threads * nbins keys)
+};
+
+// One verifyMatching of a batched k_match_verify launch
+struct VerifyJob {
+  int32_t p2_off, n2, p1_off, n1;            // points into the launch's pts2 / pts1 arrays
+  int32_t lo_x, lo_y, hi_x, hi_y;            // countPoints window in cells
+};
+
 size_t match_smem_bytes();
-void launch_match_verify(hipStream_t st, const MatchParams& P, const double* pts2, const double* pts1, double nonmatched_score,
-                         int lo_x, int lo_y, int hi_x, int hi_y, const uint8_t* kernel_lut, unsigned char* scratch,
-                         double* score_out, int* nnm_out, int* err);
-void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const double* ref_pts, const double* qry_pts,
-                         const RegionDesc* regions, const double* theta, const int32_t* items, const uint8_t* kernel_lut,
-                         unsigned char* scratch, unsigned long long* bins, int* err);
+void launch_match_verify(hipStream_t st, int n_jobs, const MatchParams& P, const VerifyJob* jobs, const double* pts2, const double* pts1,
+                         double nonmatched_score, const uint8_t* kernel_lut, unsigned char* scratch, double* score_out,
+                         int* nnm_out, int* err);
+void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const GreedyJob* jobs, const int32_t* block_job,
+                         const double* ref_pts, const double* qry_pts, const RegionDesc* regions, const double* theta,
+                         const int32_t* items, const uint8_t* kernel_lut, unsigned char* scratch, unsigned long long* bins,
+                         int* err);
 void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,

@@ -626,40 +626,50 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 
 
 // Generic CharGrid::greedySearch over a set of regions (chargrid.cpp:208-308) on a grid rasterised from the given
-// reference points: used by the loop-closure and hierarchical/global matchers (scanMatchingLC, globalMatching,
-// scan_matcher.cpp:201-294,366-428).  Every workgroup rasterises the grid, then takes (region, angle) work items
-// round-robin, one per wavefront; the pruned result maps are one global table of 64-bit keys updated with
+// reference points: the loop-closure and hierarchical / global matchers (scanMatchingLC, globalMatching,
+// scan_matcher.cpp:201-294,366-428).  Batched: a launch serves many independent searches ("jobs": own reference points,
+// query points, regions, result maps) -- the inter-robot matcher tries every candidate vertex of every peer
+// (mr_graph_slam.cpp:287-295), the loop-closure matcher every candidate set of a key frame (graph_slam.cpp:444).
+// Workgroups [block0, block0 + n_blocks) belong to a job: each rasterises the job's grid, then takes (region, angle)
+// work items round-robin, one per wavefront; the pruned result maps are global tables of 64-bit keys updated with
 // atomicMin (score bits << 32 | visit order inside the reference's per-thread map), decoded on the host.
 // Any grid size / step; cell reads go through the bounds-checked directory lookup.
-__global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const double* __restrict__ ref_pts,
-                                                      const double* __restrict__ qry_pts,
+__global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const GreedyJob* __restrict__ jobs,
+                                                      const int32_t* __restrict__ block_job,
+                                                      const double* __restrict__ ref_pts_all,
+                                                      const double* __restrict__ qry_pts_all,
                                                       const RegionDesc* __restrict__ regions,
                                                       const double* __restrict__ theta,
                                                       const int32_t* __restrict__ items,
                                                       const uint8_t* __restrict__ kernel_lut,
                                                       unsigned char* __restrict__ scratch,
-                                                      unsigned long long* __restrict__ bins, int* __restrict__ err) {
+                                                      unsigned long long* __restrict__ bins_all, int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const GreedyJob J = jobs[block_job[blockIdx.x]];
+  const int jb = blockIdx.x - J.block0;                      // my index among the job's workgroups
+  const double* ref_pts = ref_pts_all + 2 * (size_t)J.ref_off;
+  const double* qry_pts = qry_pts_all + 2 * (size_t)J.qry_off;
+  unsigned long long* bins = bins_all + J.bins_off;
   unsigned char* my = scratch + (size_t)blockIdx.x * P.scratch_stride;
   uint32_t* rcell = reinterpret_cast<uint32_t*>(my);                               // P.ref_cap packed cells
   uint32_t* gtiles = rcell + P.ref_cap;
   const int nty = (P.ny + 7) >> 3;
   const int DW = nty + kMatchDirGuardY;
   for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
-  for (int i = tid; i < P.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
+  for (int i = tid; i < J.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
   __syncthreads();
-  build_grid(S, P, rcell, P.n_ref, gtiles, /*allow_fast=*/false, err);
+  build_grid(S, P, rcell, J.n_ref, gtiles, /*allow_fast=*/false, err);
   const float ikscale = (float)(1. / (float)P.kscale);
-  const int nbins = P.nbx * P.nby * P.nbt;
+  const int nbins = J.nbx * J.nby * J.nbt;
   uint32_t* const pl = &S.plist[0][0] + wave * (2 * LISTCAP);     // 4 wavefronts: two lists each
-  for (int it0 = blockIdx.x * GR_WAVES; it0 < P.n_items; it0 += gridDim.x * GR_WAVES) {
+  for (int it0 = jb * GR_WAVES; it0 < J.n_items; it0 += J.n_blocks * GR_WAVES) {
     const int it = it0 + wave;
-    if (it >= P.n_items) continue;
-    const RegionDesc R = regions[items[2 * it]];
-    const int ti = items[2 * it + 1];
+    if (it >= J.n_items) continue;
+    const RegionDesc R = regions[items[2 * (size_t)(J.item_off + it)]];
+    const int ti = items[2 * (size_t)(J.item_off + it) + 1];
     const double t = theta[R.th_off + ti];
     double sn, cs;
     portable_sincos(t, &sn, &cs);
@@ -678,8 +688,8 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
       int k = 0;
       uint32_t prev = 0;
       bool have_prev = false;
-      for (int c0 = 0; c0 < P.n_qry; c0 += MAXPTS - 64) {
-        const int c1 = min(P.n_qry, c0 + MAXPTS - 64);
+      for (int c0 = 0; c0 < J.n_qry; c0 += MAXPTS - 64) {
+        const int c1 = min(J.n_qry, c0 + MAXPTS - 64);
         int kc = 0;
         for (int base = c0; base < c1; base += 64) {
           int q = base + lane;
@@ -723,12 +733,12 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
         if ((double)dsum < P.max_score) {
           float wx = P.ll_x + (P.res * (float)ci[u]);
           float wyy = P.ll_y + (P.res * (float)cj[u]);
-          int bx = (int)((double)wx / P.dx) - P.bx0, by = (int)((double)wyy / P.dy) - P.by0;
-          int bt = (int)(t / P.dth) - P.bt0;
-          if (bx < 0 || bx >= P.nbx || by < 0 || by >= P.nby || bt < 0 || bt >= P.nbt) { atomicExch(err, 4); continue; }
+          int bx = (int)((double)wx / P.dx) - J.bx0, by = (int)((double)wyy / P.dy) - J.by0;
+          int bt = (int)(t / P.dth) - J.bt0;
+          if (bx < 0 || bx >= J.nbx || by < 0 || by >= J.nby || bt < 0 || bt >= J.nbt) { atomicExch(err, 4); continue; }
           unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
                                    (unsigned long long)(R.order_base + (unsigned)(ti * ncand + cidx));
-          atomicMin(&bins[(size_t)R.thread * nbins + (bx * P.nby + by) * P.nbt + bt], key);
+          atomicMin(&bins[(size_t)R.thread * nbins + (bx * J.nby + by) * J.nbt + bt], key);
         }
       }
     }
@@ -736,33 +746,37 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const doubl
 }
 
 
-// Numeric core of ScanMatcher::verifyMatching (scan_matcher.cpp:430-505) in one workgroup: grid from pts2, the
+// Numeric core of ScanMatcher::verifyMatching (scan_matcher.cpp:430-505), one workgroup per job: grid from pts2, the
 // points of pts1 the grid does not explain, a second grid from those, mean cell value over a window.
-__global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const double* __restrict__ pts2,
-                                                      const double* __restrict__ pts1, double nonmatched_score,
-                                                      int lo_x, int lo_y, int hi_x, int hi_y,
+__global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const VerifyJob* __restrict__ jobs,
+                                                      const double* __restrict__ pts2_all,
+                                                      const double* __restrict__ pts1_all, double nonmatched_score,
                                                       const uint8_t* __restrict__ kernel_lut,
-                                                      unsigned char* __restrict__ scratch, double* __restrict__ score_out,
+                                                      unsigned char* __restrict__ scratch_all, double* __restrict__ score_out,
                                                       int* __restrict__ nnm_out, int* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
+  const VerifyJob J = jobs[blockIdx.x];
+  const double* pts2 = pts2_all + 2 * (size_t)J.p2_off;
+  const double* pts1 = pts1_all + 2 * (size_t)J.p1_off;
+  unsigned char* scratch = scratch_all + (size_t)blockIdx.x * P.scratch_stride;
   uint32_t* rcell = reinterpret_cast<uint32_t*>(scratch);            // P.ref_cap packed cells
   uint32_t* rcell2 = rcell + P.ref_cap;                              // cells of the unexplained points
   uint32_t* gtiles = rcell2 + P.ref_cap;
   const int DW = ((P.ny + 7) >> 3) + kMatchDirGuardY;
   for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
-  for (int i = tid; i < P.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, pts2[2 * i], pts2[2 * i + 1]);
+  for (int i = tid; i < J.n2; i += 256) rcell[i] = world_to_packed_cell(P, pts2[2 * i], pts2[2 * i + 1]);
   __syncthreads();
-  build_grid(S, P, rcell, P.n_ref, gtiles, /*allow_fast=*/false, err);
+  build_grid(S, P, rcell, J.n2, gtiles, /*allow_fast=*/false, err);
   const float ikscale = (float)(1. / (float)P.kscale);
   // unexplained points: ordered compaction (the stamp is order independent, the count is reported)
   int base = 0;
-  for (int i0 = 0; i0 < P.n_qry; i0 += 256) {
+  for (int i0 = 0; i0 < J.n1; i0 += 256) {
     int i = i0 + tid;
     uint32_t packed = 0x80008000u;
     int keep = 0;
-    if (i < P.n_qry) {
+    if (i < J.n1) {
       packed = world_to_packed_cell(P, pts1[2 * i], pts1[2 * i + 1]);
       int gx = (int16_t)(packed & 0xffff), gy = (int16_t)(packed >> 16);
       if ((unsigned)gx < (unsigned)P.nx && (unsigned)gy < (unsigned)P.ny) {
@@ -779,17 +793,17 @@ __global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const doubl
   const int nnm = base;
   build_grid(S, P, rcell2, nnm, gtiles, /*allow_fast=*/false, err);
   int isum = 0;
-  const int ni = max(0, hi_x - lo_x), nj = max(0, hi_y - lo_y);
+  const int ni = max(0, J.hi_x - J.lo_x), nj = max(0, J.hi_y - J.lo_y);
   for (int q = tid; q < ni * nj; q += 256) {
     int a = q / nj, b = q - a * nj;
-    isum += grid_cell(S, P, gtiles, DW, lo_x + a, lo_y + b);
+    isum += grid_cell(S, P, gtiles, DW, J.lo_x + a, J.lo_y + b);
   }
   int total;
   block_scan_excl(isum, scan_scratch(S), &total);
   if (tid == 0) {
-    int visited = (hi_x - lo_x) * (hi_y - lo_y);
-    *score_out = (double)((float)total / (float)visited);
-    *nnm_out = nnm;
+    int visited = (J.hi_x - J.lo_x) * (J.hi_y - J.lo_y);
+    score_out[blockIdx.x] = (double)((float)total / (float)visited);
+    nnm_out[blockIdx.x] = nnm;
   }
 }
 
@@ -804,27 +818,28 @@ static void set_lds_attr_once(const void* fn) {
 
 size_t match_smem_bytes() { return sizeof(Smem); }
 
-void launch_match_verify(hipStream_t st, const MatchParams& P, const double* pts2, const double* pts1, double nonmatched_score,
-                         int lo_x, int lo_y, int hi_x, int hi_y, const uint8_t* kernel_lut, unsigned char* scratch,
-                         double* score_out, int* nnm_out, int* err) {
+void launch_match_verify(hipStream_t st, int n_jobs, const MatchParams& P, const VerifyJob* jobs, const double* pts2, const double* pts1,
+                         double nonmatched_score, const uint8_t* kernel_lut, unsigned char* scratch, double* score_out,
+                         int* nnm_out, int* err) {
   set_lds_attr_once<0>(reinterpret_cast<const void*>(k_match_verify));
-  hipLaunchKernelGGL(k_match_verify, dim3(1), dim3(256), sizeof(Smem), st, P, pts2, pts1, nonmatched_score, lo_x, lo_y, hi_x,
-                     hi_y, kernel_lut, scratch, score_out, nnm_out, err);
+  hipLaunchKernelGGL(k_match_verify, dim3(n_jobs), dim3(256), sizeof(Smem), st, P, jobs, pts2, pts1, nonmatched_score, kernel_lut,
+                     scratch, score_out, nnm_out, err);
 }
 
-void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const double* ref_pts, const double* qry_pts,
-                         const RegionDesc* regions, const double* theta, const int32_t* items, const uint8_t* kernel_lut,
-                         unsigned char* scratch, unsigned long long* bins, int* err) {
-  set_lds_attr_once<0>(reinterpret_cast<const void*>(k_match_greedy));
-  hipLaunchKernelGGL(k_match_greedy, dim3(nblocks), dim3(256), sizeof(Smem), st, P, ref_pts, qry_pts, regions, theta, items,
-                     kernel_lut, scratch, bins, err);
+void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const GreedyJob* jobs, const int32_t* block_job,
+                         const double* ref_pts, const double* qry_pts, const RegionDesc* regions, const double* theta,
+                         const int32_t* items, const uint8_t* kernel_lut, unsigned char* scratch, unsigned long long* bins,
+                         int* err) {
+  set_lds_attr_once<1>(reinterpret_cast<const void*>(k_match_greedy));
+  hipLaunchKernelGGL(k_match_greedy, dim3(nblocks), dim3(256), sizeof(Smem), st, P, jobs, block_job, ref_pts, qry_pts, regions,
+                     theta, items, kernel_lut, scratch, bins, err);
 }
 
 void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
                               double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err) {
-  set_lds_attr_once<0>(reinterpret_cast<const void*>(k_match_close_batch));
+  set_lds_attr_once<2>(reinterpret_cast<const void*>(k_match_close_batch));
   hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(CB_THREADS), sizeof(Smem), st, P, ranges_ref, ref_xform, ranges_qry, guess,
                      beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err);
 }

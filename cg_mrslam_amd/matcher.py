@@ -187,7 +187,52 @@ class _GenericSearch:
         return bool(acc.value), score.value
 
 
-class ScanMatcher(_GenericSearch):
+def _scan_set_array(sets):
+    """list of (scans, ref_index) -> (ctypes array of ScanSet, keep-alive list)."""
+    arr = (ScanSet * len(sets))()
+    keep = []
+    for k, (scans, ri) in enumerate(sets):
+        s, ka = _scan_set(scans, ri)
+        arr[k] = s
+        keep.append(ka)
+    return arr, keep
+
+
+class _BatchedSearch:
+    """Batched forms of the ScanMatcher member functions: many independent calls, one kernel launch
+    per search level.  ``jobs``: list of (ref_scans, ref_index, cur_scans, cur_index)."""
+
+    def scanMatchingLCBatch(self, jobs, maxScore):   # noqa: N802,N803
+        a, ka = _scan_set_array([(j[0], j[1]) for j in jobs])
+        b, kb = _scan_set_array([(j[2], j[3]) for j in jobs])
+        out, n = np.zeros((len(jobs), 2, 3)), np.zeros(len(jobs), dtype=np.int32)
+        self.ctx._check(self.ctx.lib.cgmr_scan_matching_lc_batch(self.ctx.h, C.byref(self.cfg), C.c_int(len(jobs)), a, b,
+                                                                 C.c_double(maxScore), C.c_void_p(out.ctypes.data),
+                                                                 C.c_void_p(n.ctypes.data)))
+        return [[out[j, k].copy() for k in range(n[j])] for j in range(len(jobs))]
+
+    def globalMatchingBatch(self, jobs, maxScore):   # noqa: N802,N803
+        a, ka = _scan_set_array([(j[0], j[1]) for j in jobs])
+        b, kb = _scan_set_array([(j[2], j[3]) for j in jobs])
+        out, f = np.zeros((len(jobs), 3)), np.zeros(len(jobs), dtype=np.int32)
+        self.ctx._check(self.ctx.lib.cgmr_global_matching_batch(self.ctx.h, C.byref(self.cfg), C.c_int(len(jobs)), a, b,
+                                                                C.c_double(maxScore), C.c_void_p(out.ctypes.data),
+                                                                C.c_void_p(f.ctypes.data)))
+        return [(True, out[j].copy()) if f[j] else (False, None) for j in range(len(jobs))]
+
+    def verifyMatchingBatch(self, jobs, trel12):   # noqa: N802
+        """jobs: list of (scans1, ref1_index, scans2, ref2_index); trel12 (n, 3).  Returns [(accepted, score)]."""
+        a, ka = _scan_set_array([(j[0], j[1]) for j in jobs])
+        b, kb = _scan_set_array([(j[2], j[3]) for j in jobs])
+        t = np.ascontiguousarray(trel12, dtype=np.float64).reshape(len(jobs), 3)
+        sc, acc = np.zeros(len(jobs)), np.zeros(len(jobs), dtype=np.int32)
+        self.ctx._check(self.ctx.lib.cgmr_verify_matching_batch(self.ctx.h, C.byref(self.cfg), C.c_int(len(jobs)), a, b,
+                                                                C.c_void_p(t.ctypes.data), C.c_void_p(sc.ctypes.data),
+                                                                C.c_void_p(acc.ctypes.data)))
+        return [(bool(acc[j]), float(sc[j])) for j in range(len(jobs))]
+
+
+class ScanMatcher(_GenericSearch, _BatchedSearch):
     """The close-range matcher the reference builds in GraphSLAM::init (src/slam/graph_slam.cpp:58-59):
     ``initializeKernel(resolution, kernelRadius)`` + ``initializeGrid((-15,-15),(15,15), resolution)``."""
 

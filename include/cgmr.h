@@ -284,6 +284,18 @@ int cgmr_match_hierarchical(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n
                             double dx, double dy, double dth, int n_levels, cgmr_match_result* results_out, int cap,
                             int* n_out);
 int cgmr_transform_points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* vset, double* pts_out, int cap);
+/* Batched forms: n_jobs independent calls in one go -- the loop-closure matcher tries every
+ * candidate set of a key frame (graph_slam.cpp:388-485), the inter-robot matcher every candidate vertex of every peer
+ * (mr_graph_slam.cpp:213-220, 287-295).  All jobs of a call share cfg; every search level is ONE kernel launch that
+ * serves all jobs (each job's grid is rasterised by the workgroups assigned to it), results are those of the single
+ * calls.  trel_out: [n_jobs*6] (LC: up to 2 results each) / [n_jobs*3]; n_out / found_out / score_out / accepted_out
+ * [n_jobs]; trel12 [n_jobs*3]. */
+int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* ref_sets,
+                                const cgmr_scan_set* cur_sets, double max_score, double* trel_out, int* n_out);
+int cgmr_global_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* ref_sets,
+                               const cgmr_scan_set* cur_sets, double max_score, double* trel_out, int* found_out);
+int cgmr_verify_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* sets1,
+                               const cgmr_scan_set* sets2, const double* trel12, double* score_out, int* accepted_out);
 
 /* Host helpers with the reference's exact arithmetic (no GPU): RawLaser::cartesian [g2o-recalled] and
  * CharGrid::subsample (src/matcher/chargrid.cpp:61-122).  Both return the number of points written. */

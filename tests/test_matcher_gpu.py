@@ -367,3 +367,39 @@ def test_close_matching_batch_with_six_scan_reference_sets(ctx, oracle):
     f_p, t_p, _ = m.closeScanMatchingVSetBatch(pad, rel[:4], cur[:4], guess[:4], 0.15)
     f_s, t_s, _ = m.closeScanMatchingVSetBatch(ref[:4, 3:], rel[:4, 3:], cur[:4], guess[:4], 0.15)
     assert np.array_equal(f_p, f_s) and np.array_equal(t_p, t_s)
+
+
+def test_batched_lc_global_verify_equal_single_calls(ctx, oracle):
+    """a batch of loop-closure / global / verify jobs (one launch per search level for all of them)
+    returns exactly what the single calls return -- which the tests above pin against the oracle."""
+    import time
+    from cg_mrslam_amd.matcher import LCScanMatcher
+    ref, rel, cur, guess, sets, tr = _keyframe_sets(12, n_scans=3, seed=78)
+    la = (1081, synth.LASER_ANGLE_MIN, synth.LASER_ANGLE_INC, 30.0)
+    lc = LCScanMatcher(ctx, *la)
+    jobs = []
+    for k, (scans, oi, cr, cp) in enumerate(sets):
+        off = np.array([0.3 * np.cos(k), 0.4 * np.sin(2 * k), 0.2 * np.sin(k)])     # a poor prior for the current vertex
+        jobs.append((scans, oi, [(cr, cp + off)], 0))
+    t0 = time.perf_counter()
+    single_lc = [lc.scanMatchingLC(j[0], j[1], j[2], j[3], 0.3) for j in jobs]
+    t1 = time.perf_counter()
+    batch_lc = lc.scanMatchingLCBatch(jobs, 0.3)
+    t2 = time.perf_counter()
+    assert sum(len(r) for r in single_lc) >= 10
+    for a, b in zip(single_lc, batch_lc):
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+    single_g = [lc.globalMatching(j[0], j[1], j[2], j[3], 0.25) for j in jobs[:6]]
+    t3 = time.perf_counter()
+    batch_g = lc.globalMatchingBatch(jobs[:6], 0.25)
+    t4 = time.perf_counter()
+    assert sum(1 for f, _ in single_g if f) >= 4
+    for (fa, ta), (fb, tb) in zip(single_g, batch_g):
+        assert fa == fb and (not fa or np.array_equal(ta, tb))
+    vjobs = [(j[0], j[1], j[2], j[3]) for j in jobs]
+    t12 = np.array([r[0] if len(r) else np.array([0.4, 0.2, 0.1]) for r in single_lc])
+    single_v = [lc.verifyMatching(j[0], j[1], j[2], j[3], t12[k]) for k, j in enumerate(vjobs)]
+    batch_v = lc.verifyMatchingBatch(vjobs, t12)
+    assert single_v == batch_v
+    print(f"12 LC jobs: {1e3 * (t1 - t0):.1f} ms one by one, {1e3 * (t2 - t1):.1f} ms batched; "
+          f"6 global jobs: {1e3 * (t3 - t2):.1f} ms one by one, {1e3 * (t4 - t3):.1f} ms batched")
