@@ -403,3 +403,39 @@ def test_batched_lc_global_verify_equal_single_calls(ctx, oracle):
     assert single_v == batch_v
     print(f"12 LC jobs: {1e3 * (t1 - t0):.1f} ms one by one, {1e3 * (t2 - t1):.1f} ms batched; "
           f"6 global jobs: {1e3 * (t3 - t2):.1f} ms one by one, {1e3 * (t4 - t3):.1f} ms batched")
+
+
+def test_hand_derived_three_point_scan_on_gpu(ctx):
+    """The hand-derived known answers of tests/known_answers.py (worked out from chargrid.cpp / gridmap.h, no
+    implementation involved) through the C ABI."""
+    import known_answers as K
+    from cg_mrslam_amd.matcher import ScanMatcher
+    m = ScanMatcher(ctx, 1081, synth.LASER_ANGLE_MIN, synth.LASER_ANGLE_INC, 30.0)
+    res = m.greedySearch(K.REF, K.REF, K.REGION, 0.00625, 0.5, 0.5, 0.5, 0.2)
+    assert len(res) == 1 and tuple(res[0]) == K.EXPECTED_SAME
+    res = m.greedySearch(K.REF, K.REF + [0.025, 0.0], K.REGION, 0.00625, 0.5, 0.5, 0.5, 0.2)
+    assert len(res) == 1 and tuple(res[0]) == K.EXPECTED_SHIFTED
+    res = m.greedySearch(K.REF, K.REF, K.REGION, 0.00625, 0.5, 0.0125, 0.0125, 0.2)
+    got = {(round((r[0] + 15) * 40), round((r[1] + 15) * 40)): r[3] for r in res}
+    assert len(res) == 16
+    for i in range(598, 602):
+        for j in range(598, 602):
+            assert got[(i, j)] == K.expected_score(i, j, K.QUERY_CELLS), (i, j)
+
+
+def test_committed_4096_pair_subset_of_c3(ctx):
+    """parity on a committed 4096-pair subset of the C3 workload (tests/golden/match_close4096.npz:
+    the CPU oracle's results for synth.make_scan_pairs(4096, seed=4242), inputs pinned by their SHA-256): bit-exact."""
+    import hashlib
+    import os
+    from cg_mrslam_amd.matcher import ScanMatcher
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "match_close4096.npz"))
+    sp = synth.make_scan_pairs(int(G["n_pairs"]), seed=int(G["seed"]))
+    h = hashlib.sha256()
+    for k in ("ranges_ref", "ranges_qry", "guess"):
+        h.update(np.ascontiguousarray(sp[k]).tobytes())
+    assert h.hexdigest() == str(G["inputs_sha256"]), "the regenerated inputs differ from those the fixture was made from"
+    m = ScanMatcher(ctx, sp["n_beams"], sp["angle_min"], sp["angle_inc"], sp["max_range"])
+    found, xyt, score = m.closeScanMatching(sp["ranges_ref"], sp["ranges_qry"], sp["guess"])
+    assert np.array_equal(found, G["found"].astype(bool)) and np.array_equal(xyt, G["xyt"]) and np.array_equal(score, G["score"])
+    assert m.last_stats()["slow_pairs"] == 0

@@ -154,3 +154,32 @@ def test_golden_close_match(oracle):
     xyt, score, found = oracle.close_scan_match_batch(d["ranges_ref"][:4], d["ranges_qry"][:4], float(d["angle_min"]),
                                                       float(d["angle_inc"]), float(d["max_range"]), [0, 0, 0], d["guess"][:4])
     assert np.array_equal(xyt, d["xyt"][:4]) and np.array_equal(score, d["score"][:4]) and np.array_equal(found, d["found"][:4])
+
+
+def test_hand_derived_three_point_scan(oracle):
+    """Known answers worked out by hand from chargrid.cpp / gridmap.h / scan_matcher.cpp (tests/known_answers.py): the
+    stamped grid, the candidate scores and the single pruned result, incl. the float rounding of grid2world."""
+    import known_answers as K
+    grid = oracle.rasterize(K.GRID["ll"], K.GRID["ur"], K.GRID["res"], K.GRID["res"], K.GRID["kernel_range"], K.REF)
+    assert grid.shape == (1200, 1200)
+    for (cx, cy) in K.CELLS:
+        assert grid[cx, cy] == 0
+    for x, y in [(641, 620), (640, 622), (640, 626), (648, 620), (649, 620), (688, 568), (672, 552), (100, 100), (660, 600)]:
+        assert grid[x, y] == K.expected_grid_value(x, y), (x, y)
+    assert (grid != 25).sum() == sum(1 for x in range(600, 700) for y in range(540, 640) if K.expected_grid_value(x, y) != 25)
+    # every candidate below the threshold, one at a time (a tight maxScore isolates single offsets): scores by hand
+    n, res = oracle.greedy_search(K.GRID["ll"], K.GRID["ur"], K.GRID["res"], K.GRID["res"], K.GRID["kernel_range"], K.REF, K.REF,
+                                  K.REGION, 0.025, 0.00625, 0.5, 0.5, 0.5, 0.2)
+    assert n == 1 and tuple(res[0]) == K.EXPECTED_SAME
+    shifted = K.REF + [0.025, 0.0]
+    n, res = oracle.greedy_search(K.GRID["ll"], K.GRID["ur"], K.GRID["res"], K.GRID["res"], K.GRID["kernel_range"], K.REF, shifted,
+                                  K.REGION, 0.025, 0.00625, 0.5, 0.5, 0.5, 0.2)
+    assert n == 1 and tuple(res[0]) == K.EXPECTED_SHIFTED
+    # finer result bins (0.025 m: one bin per offset) expose every candidate's score
+    n, res = oracle.greedy_search(K.GRID["ll"], K.GRID["ur"], K.GRID["res"], K.GRID["res"], K.GRID["kernel_range"], K.REF, K.REF,
+                                  K.REGION, 0.025, 0.00625, 0.5, 0.0125, 0.0125, 0.2)
+    got = {(round((r[0] + 15) * 40), round((r[1] + 15) * 40)): r[3] for r in res[:n]}
+    for i in range(598, 602):
+        for j in range(598, 602):
+            assert got[(i, j)] == K.expected_score(i, j, K.QUERY_CELLS), (i, j)
+    assert n == 16 and got[(600, 600)] == 0.0 and got[(601, 600)] == 0.0234375 and got[(600, 602 - 1)] == K.expected_score(600, 601, K.QUERY_CELLS)
