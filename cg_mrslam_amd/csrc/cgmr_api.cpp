@@ -238,6 +238,44 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   return 0;
 }
 
+// `n` extra copies of the numeric work space of the uploaded structure (the structure arrays are shared): independent
+// numeric passes on the same graph -- one condensed graph per peer -- run concurrently on streams of their own.
+int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
+  const Symbolic& S = ctx->sym;
+  const GnDevice& D0 = ctx->gn;
+  BlobLayout N;
+  size_t o_term = N.add<double>((size_t)34 * S.nE), o_A = N.add<double>((size_t)9 * (S.nf + S.nb)), o_b = N.add<double>((size_t)3 * S.nf),
+         o_y = N.add<double>((size_t)3 * S.nf), o_x = N.add<double>((size_t)3 * S.nf), o_u = N.add<double>((size_t)3 * S.rows.size() + 3),
+         o_L = N.add<double>((size_t)S.L_doubles + 1), o_U = N.add<double>((size_t)S.U_doubles + 1), o_chi = N.add<double>(8),
+         o_status = N.add<int>(4), o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
+  const size_t per = (N.off + 255) & ~size_t(255);
+  int rc = arena_reserve(ctx, ctx->rep_arena, per * (size_t)std::max(n, 1) + 256);
+  if (rc) return rc;
+  out.assign(n, D0);
+  for (int i = 0; i < n; i++) {
+    char* d = ctx->rep_arena.ptr + per * (size_t)i;
+    GnDevice& D = out[i];
+    D.term = (double*)(d + o_term); D.Ablk = (double*)(d + o_A); D.bvec = (double*)(d + o_b); D.yvec = (double*)(d + o_y);
+    D.xvec = (double*)(d + o_x); D.uvec = (double*)(d + o_u); D.Lbuf = (double*)(d + o_L); D.Ubuf = (double*)(d + o_U);
+    D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.cmask = (uint8_t*)(d + o_cmask);
+  }
+  return 0;
+}
+
+// side streams for concurrent passes, created on first use
+int aux_streams(cgmr_ctx* ctx, int n) {
+  while ((int)ctx->aux.size() < n) {
+    hipStream_t s = nullptr;
+    hipEvent_t e = nullptr;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->aux.push_back(s);
+    ctx->aux_done.push_back(e);
+  }
+  if (!ctx->aux_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+  return 0;
+}
+
 // Ordering + symbolic analysis + structure upload for the edge list (ef, et), or nothing at all when the context
 // still holds them for exactly this list (g2o redoes buildStructure + cs_schol on every optimize() call,
 // SURVEY.md 3.2; within one key frame -- optimize(1), covariance estimate, optimize(5), graph_slam.cpp:392-393,
@@ -274,8 +312,12 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
 // first n_active edges take part), the status words.  ctx->vmask keeps the per-vertex flags for the caller.
 int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int n_active, int slot,
                  int nslots) {
+  return prepare_pass_on(ctx, ctx->gn, ctx->stream, fixed, nE, ef, et, n_active, slot, nslots);
+}
+
+int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et,
+                    int n_active, int slot, int nslots) {
   const Symbolic& S = ctx->sym;
-  GnDevice& D = ctx->gn;
   ctx->vmask.assign(S.nV, 0);
   if (fixed) for (int v = 0; v < S.nV; v++) ctx->vmask[v] = fixed[v] ? 1 : 0;
   if (n_active < nE) {
@@ -283,7 +325,7 @@ int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef,
     for (int k = 0; k < n_active; k++) { live[ef[k]] = 1; live[et[k]] = 1; }
     for (int v = 0; v < S.nV; v++) if (!live[v]) ctx->vmask[v] = 1;
   }
-  HIP_TRY(ctx, hipMemsetAsync(D.status, 0, 16, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(D.status, 0, 16, st));
   if (S.nf == 0) return 0;
   // several passes may be queued without a host synchronisation in between (one condensed graph per peer): each
   // stages its mask in a slot of its own
@@ -291,7 +333,7 @@ int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef,
   if (rc) return rc;
   char* pm = ctx->pinned_mask + (size_t)S.nf * slot;
   for (int c = 0; c < S.nf; c++) pm[c] = (char)ctx->vmask[S.perm[c]];
-  HIP_TRY(ctx, hipMemcpyAsync(D.cmask, pm, (size_t)S.nf, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(D.cmask, pm, (size_t)S.nf, hipMemcpyHostToDevice, st));
   return 0;
 }
 
@@ -306,17 +348,18 @@ void profile_collect(cgmr_ctx* ctx) {
 
 struct KTimer {   // optional per-launch-class timing (profiling mode only)
   cgmr_ctx* ctx;
+  hipStream_t st;
   template <typename Fn>
   void run(int cls, int nlaunch, Fn&& fn) {
     static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;      // debugging aid: name every launch, sync after it
     if (trace) {
       fprintf(stderr, "[cgmr] launch class %d (0 lin 1 asm 2 chi2 3 factor 4 update 6 bwd 7 poses)\n", cls);
       fn();
-      hipError_t e = hipStreamSynchronize(ctx->stream);
+      hipError_t e = hipStreamSynchronize(st);
       fprintf(stderr, "[cgmr]   done: %s\n", hipGetErrorString(e));
       return;
     }
-    if (!ctx->profiling || 2 * (ctx->ev_cls.size() + 1) > ctx->ev_pool.size()) { fn(); return; }
+    if (!ctx->profiling || st != ctx->stream || 2 * (ctx->ev_cls.size() + 1) > ctx->ev_pool.size()) { fn(); return; }
     const size_t k = ctx->ev_cls.size();
     (void)hipEventRecord(ctx->ev_pool[2 * k], ctx->stream);
     fn();
@@ -329,9 +372,13 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
 // one Gauss-Newton pass on the uploaded structure: linearise + chi2 [+ assemble + factor [+ solve + update]]
 void gn_pass(cgmr_ctx* ctx, double* d_poses, const GnEdges& Ed, int it, bool chi_only,
              bool solve_and_update, bool write_l11c) {
-  GnDevice& D = ctx->gn;
-  hipStream_t st = ctx->stream;
-  KTimer T{ctx};
+  gn_pass_on(ctx, ctx->gn, ctx->stream, d_poses, Ed, it, chi_only, solve_and_update, write_l11c);
+}
+
+// the same on an explicit device view (the context's, or a replica with its own numeric work space) and stream
+void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, const GnEdges& Ed, int it, bool chi_only,
+                bool solve_and_update, bool write_l11c) {
+  KTimer T{ctx, st};
   T.run(0, 1, [&] { launch_linearize(st, D, d_poses, Ed, chi_only ? 1 : 0); });
   if (chi_only || D.nf == 0) {
     T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
@@ -589,6 +636,11 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (ctx->gn_arena.ptr) (void)hipFree(ctx->gn_arena.ptr);
   if (ctx->io_arena.ptr) (void)hipFree(ctx->io_arena.ptr);
   if (ctx->mt_arena.ptr) (void)hipFree(ctx->mt_arena.ptr);
+  if (ctx->rep_arena.ptr) (void)hipFree(ctx->rep_arena.ptr);
+  if (ctx->mg_arena.ptr) (void)hipFree(ctx->mg_arena.ptr);
+  for (hipStream_t a : ctx->aux) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+  for (hipEvent_t e : ctx->aux_done) (void)hipEventDestroy(e);
+  if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_mask) (void)hipHostFree(ctx->pinned_mask);
   for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_a, ctx->ev_b})

@@ -25,6 +25,11 @@ struct cgmr_ctx {
   cgmr::Arena gn_arena;     // structure + numeric work space of the last analysed graph
   cgmr::Arena io_arena;     // staging for the host-pointer entry points
   cgmr::Arena mt_arena;     // matcher work space
+  cgmr::Arena rep_arena;    // replicas of the GN numeric work space (concurrent passes on one structure)
+  cgmr::Arena mg_arena;     // marginals work space of the concurrent passes
+  std::vector<hipStream_t> aux;          // side streams of the concurrent passes
+  std::vector<hipEvent_t> aux_done;
+  hipEvent_t aux_fork = nullptr;
   char* pinned = nullptr;
   size_t pinned_cap = 0;
   char* pinned_mask = nullptr;   // staging of the per-pass column mask (own buffer: the blob staging above is shared)

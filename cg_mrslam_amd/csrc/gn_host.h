@@ -11,6 +11,13 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
 // ctx->vmask keeps the per-vertex flags.  slot / nslots: staging slot of the mask when passes are queued back to back
 int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int n_active, int slot,
                  int nslots);
+int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et,
+                    int n_active, int slot, int nslots);
+// n extra copies of the numeric work space of the uploaded structure; side streams for concurrent passes
+int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out);
+int aux_streams(cgmr_ctx* ctx, int n);
+void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, const GnEdges& Ed, int it, bool chi_only,
+                bool solve_and_update, bool write_l11c);
 // one Gauss-Newton pass on the uploaded structure: linearise + chi2 [+ assemble + factor [+ solve + update]]
 void gn_pass(cgmr_ctx* ctx, double* d_poses, const GnEdges& Ed, int it, bool chi_only, bool solve_and_update, bool write_l11c);
 int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et,

@@ -393,21 +393,29 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
   int rc = prepare_structure(ctx, nV, nE, g->all_ef.data(), g->all_et.data(), 1);
   if (rc) return rc;
   const Symbolic& S = ctx->sym;
-  GnDevice& D = ctx->gn;
   const int nj = (int)jobs.size();
+  // every peer's pass gets a copy of the numeric work space and a stream of its own: one pass keeps a handful of
+  // workgroups busy per tree level, so the passes of all peers overlap almost perfectly
+  const int nstreams = std::min(nj, 8);
+  rc = aux_streams(ctx, nstreams);
+  if (rc) return rc;
+  std::vector<GnDevice> reps;
+  rc = gn_replicas(ctx, nj, reps);
+  if (rc) return rc;
   rc = dev_grow(g, g->d_work, 0, 24 * (size_t)nV * nj);
   if (rc) return rc;
-  // marginals work space for the largest query set
+  // marginals work space per pass, sized for the largest query set
   int maxq = 0;
   for (Job& J : jobs) maxq = std::max(maxq, (int)J.idx.size() - 1);
-  const int m_max = ((4 * maxq + 15) / 16) * 16, n = 3 * D.nf, chunk = 2048, nchunk = (n + chunk - 1) / chunk;
+  const int nf = ctx->gn.nf;
+  const int m_max = ((4 * maxq + 15) / 16) * 16, n = 3 * nf, chunk = 2048, nchunk = (n + chunk - 1) / chunk;
   struct L2 { size_t off = 0; size_t add(size_t b) { off = (off + 255) & ~size_t(255); size_t o = off; off += b; return o; } } L;
-  const size_t o_qc = L.add(4 * (size_t)maxq * nj), o_Y = L.add(8 * (size_t)n * m_max),
+  const size_t o_qc = L.add(4 * (size_t)maxq), o_Y = L.add(8 * (size_t)n * m_max),
                o_U = L.add(8 * ((size_t)3 * S.rows.size() + 3) * m_max), o_part = L.add(8 * (size_t)nchunk * 16 * m_max),
                o_G = L.add(8 * (size_t)16 * m_max), o_cov = L.add(72 * (size_t)maxq), o_fl = L.add(4 * (size_t)maxq);
-  rc = arena_reserve(ctx, ctx->io_arena, L.off + 256);
+  const size_t per_job = (L.off + 255) & ~size_t(255);
+  rc = arena_reserve(ctx, ctx->mg_arena, per_job * (size_t)nj + 256);
   if (rc) return rc;
-  char* d = ctx->io_arena.ptr;
   GnEdges Ed;
   Ed.meas_a = (const double*)g->d_meas_a.ptr; Ed.info_a = (const double*)g->d_info_a.ptr;
   Ed.meas_b = g->d_meas_b; Ed.info_b = g->d_info_b;
@@ -416,8 +424,13 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
   std::vector<double> work(3 * (size_t)nV);
   std::vector<int32_t> qcol;
   WireEdge* send_edges = reinterpret_cast<WireEdge*>(g->d_send + wire_edges_off(g->n_robots));
+  HIP_TRY(ctx, hipEventRecord(ctx->aux_fork, st));
+  for (int k = 0; k < nstreams; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->aux_fork, 0));
   for (int i = 0; i < nj; i++) {
     Job& J = jobs[i];
+    hipStream_t sj = ctx->aux[i % nstreams];
+    GnDevice& D = reps[i];
+    char* d = ctx->mg_arena.ptr + per_job * (size_t)i;
     J.gauge = select_gauge_centroid(J.idx, g->h_poses.data());
     for (int v : J.idx) if (v != J.gauge) J.q.push_back(v);
     const int nq = (int)J.q.size();
@@ -428,25 +441,29 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
     work = g->h_poses;
     initial_guess_host(nV, work.data(), fixed.data(), nA, g->ef.data(), g->et.data(), g->h_meas.data());
     double* d_work = (double*)(g->d_work.ptr + 24 * (size_t)nV * i);
-    HIP_TRY(ctx, hipMemcpyAsync(d_work, work.data(), 24 * (size_t)nV, hipMemcpyHostToDevice, st));
-    rc = prepare_pass(ctx, fixed.data(), nE, g->all_ef.data(), g->all_et.data(), nA, i, nj);
+    HIP_TRY(ctx, hipMemcpyAsync(d_work, work.data(), 24 * (size_t)nV, hipMemcpyHostToDevice, sj));
+    rc = prepare_pass_on(ctx, D, sj, fixed.data(), nE, g->all_ef.data(), g->all_et.data(), nA, i, nj);
     if (rc) return rc;
     qcol.resize(nq);
     for (int k = 0; k < nq; k++) qcol[k] = ctx->vmask[J.q[k]] ? -1 : S.vperm[J.q[k]];
-    int32_t* d_qc = (int32_t*)(d + o_qc) + (size_t)maxq * i;
+    int32_t* d_qc = (int32_t*)(d + o_qc);
     int32_t* d_qv = g->d_qidx + (size_t)cap * i;
-    HIP_TRY(ctx, hipMemcpyAsync(d_qc, qcol.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(d_qv, J.q.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, st));
-    gn_pass(ctx, d_work, Ed, 0, false, true, /*write_l11c=*/true);
+    HIP_TRY(ctx, hipMemcpyAsync(d_qc, qcol.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, sj));
+    HIP_TRY(ctx, hipMemcpyAsync(d_qv, J.q.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, sj));
+    gn_pass_on(ctx, D, sj, d_work, Ed, 0, false, true, /*write_l11c=*/true);
     const int m = ((4 * nq + 15) / 16) * 16;
-    launch_marginals(st, D, nq, d_qc, m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part), (double*)(d + o_G),
+    launch_marginals(sj, D, nq, d_qc, m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part), (double*)(d + o_G),
                      (double*)(d + o_cov), chunk, nchunk);
     double* est64 = g->d_est64 + 3 * (size_t)cap * J.peer;
     double* info64 = g->d_info64 + 6 * (size_t)cap * J.peer;
-    launch_label(st, nq, d_qv, J.gauge, d_work, (const double*)(d + o_cov), est64, info64, (int*)(d + o_fl));
-    launch_wire_write_edges(st, nq, g->ids[J.gauge], d_qv, (const int32_t*)g->d_vids.ptr, est64, info64,
+    launch_label(sj, nq, d_qv, J.gauge, d_work, (const double*)(d + o_cov), est64, info64, (int*)(d + o_fl));
+    launch_wire_write_edges(sj, nq, g->ids[J.gauge], d_qv, (const int32_t*)g->d_vids.ptr, est64, info64,
                             send_edges + (size_t)cap * J.peer);
-    HIP_TRY(ctx, hipMemcpyAsync(g->d_status_all + i, D.status, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(g->d_status_all + i, D.status, 4, hipMemcpyDeviceToDevice, sj));
+  }
+  for (int k = 0; k < nstreams; k++) {
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_done[k], ctx->aux[k]));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->aux_done[k], 0));
   }
   std::vector<int32_t> status(nj, 0);
   HIP_TRY(ctx, hipMemcpyAsync(status.data(), g->d_status_all, 4 * (size_t)nj, hipMemcpyDeviceToHost, st));
