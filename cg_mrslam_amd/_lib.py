@@ -201,8 +201,8 @@ class Context:
         sec = np.zeros(8)
         n = np.zeros(8, dtype=np.int64)
         self._check(self.lib.cgmr_gn_kernel_times(self.h, _ptr(sec), _ptr(n)))
-        names = ["linearize", "assemble", "chi2", "front_factor", "front_update", "unused", "solve_bwd", "update"]
-        return {k: (float(s), int(c)) for k, s, c in zip(names, sec, n) if k != "unused"}
+        names = ["linearize", "assemble", "chi2", "front_factor", "front_update", "top_block", "solve_bwd", "update"]
+        return {k: (float(s), int(c)) for k, s, c in zip(names, sec, n)}
 
 
 def gn_symbolic_info(nV, fixed, ef, et, want_perm=False):
@@ -211,13 +211,14 @@ def gn_symbolic_info(nV, fixed, ef, et, want_perm=False):
     fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
     ef = np.ascontiguousarray(ef, dtype=np.int32)
     et = np.ascontiguousarray(et, dtype=np.int32)
-    out = np.zeros(13, dtype=np.int64)
+    out = np.zeros(16, dtype=np.int64)
     perm = np.zeros(nV, dtype=np.int32) if want_perm else None
     rc = lib.cgmr_gn_symbolic_info(C.c_int(nV), _ptr(fixed), C.c_int(len(ef)), _ptr(ef), _ptr(et), _ptr(out),
                                    _ptr(perm))
     if rc != 0:
         raise CgmrError(rc, "cgmr_gn_symbolic_info rejected the graph")
     keys = ["free_poses", "offdiag_blocks", "fronts", "levels", "L_doubles", "U_doubles", "max_border",
-            "factor_flops", "order_us", "structure_us", "max_children", "max_children_small_border", "slab_doubles"]
+            "factor_flops", "order_us", "structure_us", "max_children", "max_children_small_border", "slab_doubles",
+            "launch_levels", "top_block_fronts", "top_block_cols"]
     info = dict(zip(keys, out.tolist()))
     return (info, perm) if want_perm else info

@@ -84,8 +84,11 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   GnDevice& D = ctx->gn;
   D.nV = S.nV; D.nE = S.nE; D.nf = S.nf; D.nb = S.nb;
   D.nfronts = (int)S.fronts.size();
-  D.nlevels = (int)S.level_ptr.size() - 1;
-  D.h_level_ptr = S.level_ptr;
+  D.nlevels = (int)S.gn_level_ptr.size() - 1;           // Gauss-Newton levels: without the top block
+  D.h_level_ptr = S.gn_level_ptr;
+  D.nlevels_full = (int)S.level_ptr.size() - 1;
+  D.h_flevel_ptr = S.level_ptr;
+  const std::vector<int32_t>& LF = S.gn_level_fronts;
   // update tiles per level
   std::vector<int32_t> tiles;
   std::vector<WorkRec> work;
@@ -98,15 +101,15 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   static const int mid_chunk = getenv("CGMR_CHUNK") ? std::min(kChunkRows, std::max(16, atoi(getenv("CGMR_CHUNK")))) : kMidChunkRows;
   static const int leaf_chunk = getenv("CGMR_LEAF_CHUNK") ? atoi(getenv("CGMR_LEAF_CHUNK")) : kLeafChunkRows;
   for (int l = 0; l < D.nlevels; l++) {
-    for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++)
-      if (S.fronts[S.level_fronts[q]].nchild > 0) D.h_level_leaf[l] = 0;
+    for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++)
+      if (S.fronts[LF[q]].nchild > 0) D.h_level_leaf[l] = 0;
     // a level of leaves runs the register-light variant of the factor kernel: shorter chunks, so that the LDS of two
     // workgroups fits a CU
     const int chunk_rows = S.level_w[l] == kWideFrontW ? kWideChunkRows
                            : (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
     D.h_level_chunk[l] = chunk_rows;
-    for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
-      int f = S.level_fronts[q];
+    for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++) {
+      int f = LF[q];
       int r = 3 * S.fronts[f].ns;
       int nchunk = std::max(1, (r + chunk_rows - 1) / chunk_rows);
       D.h_level_chrows[l] = std::max(D.h_level_chrows[l], std::min(r, chunk_rows) + 1);
@@ -160,6 +163,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_et = B.add<int32_t>(S.nE);
   size_t o_orow = B.add<int32_t>(S.off_row.size());
   size_t o_ocol = B.add<int32_t>(S.off_col.size());
+  size_t o_tf = B.add<int32_t>(S.top_fronts.size()), o_tc = B.add<int32_t>(S.top_children.size()), o_tb = B.add<int32_t>(S.top_blocks.size());
   size_t blob_bytes = (B.off + 255) & ~size_t(255);
   // numeric work space
   BlobLayout N;
@@ -184,8 +188,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(h + off, src, bytes); };
   put(o_fronts, S.fronts.data(), S.fronts.size() * sizeof(FrontDesc));
   {
-    std::vector<FrontDesc> lv(S.fronts.size());
-    for (size_t q = 0; q < S.level_fronts.size(); q++) lv[q] = S.fronts[S.level_fronts[q]];
+    std::vector<FrontDesc> lv(S.fronts.size());                  // Gauss-Newton level order (the backward solve's index)
+    for (size_t q = 0; q < LF.size(); q++) lv[q] = S.fronts[LF[q]];
     put(o_fronts_lv, lv.data(), lv.size() * sizeof(FrontDesc));
   }
   put(o_rows, S.rows.data(), S.rows.size() * 4);
@@ -204,6 +208,9 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   put(o_et, et, (size_t)S.nE * 4);
   put(o_orow, S.off_row.data(), S.off_row.size() * 4);
   put(o_ocol, S.off_col.data(), S.off_col.size() * 4);
+  put(o_tf, S.top_fronts.data(), S.top_fronts.size() * 4);
+  put(o_tc, S.top_children.data(), S.top_children.size() * 4);
+  put(o_tb, S.top_blocks.data(), S.top_blocks.size() * 4);
   char* d = ctx->gn_arena.ptr;
   HIP_TRY(ctx, hipMemcpyAsync(d, h, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
   D.fronts = (FrontDesc*)(d + o_fronts);
@@ -225,6 +232,9 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.off_row = (int32_t*)(d + o_orow);
   D.off_col = (int32_t*)(d + o_ocol);
   D.cmask = (uint8_t*)(d + o_cmask);
+  D.top_fronts = (int32_t*)(d + o_tf); D.top_children = (int32_t*)(d + o_tc); D.top_blocks = (int32_t*)(d + o_tb);
+  D.top_nfronts = (int)S.top_fronts.size(); D.top_c0 = S.top_c0; D.top_ncols = 3 * S.top_nposes;
+  D.top_nchild = (int)S.top_children.size(); D.top_nblk = (int)S.top_blocks.size() / 3;
   D.term = (double*)(d + o_term);
   D.Ablk = (double*)(d + o_A);
   D.bvec = (double*)(d + o_b);
@@ -394,13 +404,13 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
     if (trace) {
       int maxr = 0, maxc = 0;
       for (int q = D.h_level_ptr[l]; q < D.h_level_ptr[l + 1]; q++) {
-        const FrontDesc& F = ctx->sym.fronts[ctx->sym.level_fronts[q]];
+        const FrontDesc& F = ctx->sym.fronts[ctx->sym.gn_level_fronts[q]];
         maxr = std::max(maxr, 3 * F.ns);
         for (int k = 0; k < F.nchild; k++) maxc = std::max(maxc, 3 * ctx->sym.fronts[ctx->sym.children[F.child_off + k]].ns);
       }
       if (D.h_level_ptr[l + 1] - D.h_level_ptr[l] <= 2)
         for (int q = D.h_level_ptr[l]; q < D.h_level_ptr[l + 1]; q++) {
-          const FrontDesc& F = ctx->sym.fronts[ctx->sym.level_fronts[q]];
+          const FrontDesc& F = ctx->sym.fronts[ctx->sym.gn_level_fronts[q]];
           fprintf(stderr, "[cgmr]   front nc %d ns %d na %d nchild %d a_cnt %d L_off %lld U_off %lld:", F.nc, F.ns, F.na, F.nchild, F.a_cnt, (long long)F.L_off, (long long)F.U_off);
           for (int k = 0; k < F.nchild; k++) { const FrontDesc& G = ctx->sym.fronts[ctx->sym.children[F.child_off + k]]; fprintf(stderr, " child(ns %d na %d U_off %lld)", G.ns, G.na, (long long)G.U_off); }
           fprintf(stderr, "\n");
@@ -411,6 +421,8 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
     T.run(3, 1, [&] { launch_factor_level(st, D, l, write_l11c); });
     if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
   }
+  // the top of the tree in one launch: assembly, factorisation, forward and backward solve of the block's columns
+  if (D.top_nfronts > 0) T.run(5, 1, [&] { launch_top_block(st, D, /*store_l=*/write_l11c, write_l11c); });
   if (!solve_and_update) return;
   // (the forward solve L y = b rides through k_front_factor as an extra row of every front)
   for (int l = D.nlevels - 1; l >= 0; l--) T.run(6, 1, [&] { launch_bwd_level(st, D, l); });
@@ -698,7 +710,7 @@ int cgmr_gn_optimize(cgmr_ctx* ctx, int nV, double* poses, const uint8_t* fixed,
 }
 
 int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx, const int32_t* to_idx,
-                          int64_t out[13], int32_t* perm_out) {
+                          int64_t out[16], int32_t* perm_out) {
   if (nV < 0 || nE < 0 || !out) return CGMR_E_INVALID;
   Symbolic S;
   (void)fixed;          // the solver applies the fixed flags numerically: they are not part of the analysis
@@ -708,6 +720,7 @@ int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* f
   out[4] = S.L_doubles; out[5] = S.U_doubles; out[6] = S.max_ns; out[7] = (int64_t)S.flops;
   out[8] = (int64_t)(1e6 * S.t_order); out[9] = (int64_t)(1e6 * S.t_struct);
   out[10] = out[11] = out[12] = 0;
+  out[13] = (int64_t)S.gn_level_ptr.size() - 1; out[14] = (int64_t)S.top_fronts.size(); out[15] = 3 * (int64_t)S.top_nposes;
   for (const FrontDesc& F : S.fronts) {
     if (F.parent >= 0) out[12] += (int64_t)3 * F.ns * ((3 * F.na + 1) & ~1);
     out[10] = std::max<int64_t>(out[10], F.nchild);

@@ -27,8 +27,13 @@ struct GnDevice {
   double *Lbuf = nullptr, *Ubuf = nullptr;
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
+  // top block (k_top_block): the last fronts of the root's chain, handled by one workgroup in LDS
+  int top_nfronts = 0, top_c0 = 0, top_ncols = 0, top_nchild = 0, top_nblk = 0;
+  int32_t *top_fronts = nullptr, *top_children = nullptr, *top_blocks = nullptr;
   // host copies
-  std::vector<int32_t> h_level_ptr, h_tile_ptr, h_work_ptr;
+  int nlevels_full = 0;                  // tree levels including the top block's (the marginals walk every front)
+  std::vector<int32_t> h_flevel_ptr;     // full level lists (level_fronts on the device is the full list as well)
+  std::vector<int32_t> h_level_ptr, h_tile_ptr, h_work_ptr;   // Gauss-Newton levels (without the top block)
   std::vector<uint8_t> h_level_leaf;     // per level: 1 if no front of the level has children (leaf variant of the factor kernel)
   std::vector<int32_t> h_level_w;        // per level: panel width of its fronts (kFrontW / kWideFrontW)
   std::vector<int32_t> h_level_chunk;    // per level: border rows per work item (kChunkRows, fewer for a level of leaves)
@@ -49,6 +54,7 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int level, bool writ
 void launch_update_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);
+void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c);
 // marginals_kernels.hip
 void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* d_qcol, int m, double* Y, double* Uv,
                       double* part, double* G, double* cov, int chunk, int nchunk);

@@ -395,6 +395,131 @@ __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDes
   return c;
 }
 
+// (The same blocked factorisation as inside front_factor_body, as a function: k_top_block uses it.  The panel kernel
+// keeps its own inlined copy -- routing it through this function costs 5 % of the device time, measured.)
+// Blocked right-looking Cholesky of a panel held in LDS, in block columns of 16 with one block column of look-ahead
+// (256 threads).  prow(r) = row r of the panel (M rows: the columns' own rows first, then border rows, the
+// right-hand side last), drow(r) = the same for rows of the first 16 * nbc (always the leading region, row stride LDD
+// doubles -- a compile-time constant: the row solves address the diagonal block with immediate offsets):
+//   factor_diag   wavefront 0 factors the 16x16 diagonal block in registers (lane i = row i), as L D L^T with the
+//                 scaling by D^-1/2 deferred: the chain from one pivot to the next is readlane -> 1/d (estimate + cubic
+//                 correction) -> one multiply -> fma; the 16 reciprocal square roots are taken together afterwards;
+//   solve_rows    one thread per row below solves its 16 entries against the diagonal block;
+//   update_tiles  the 16x16 tiles of a later block column subtract L[I][K] L[J][K]^T with v_mfma_f64_16x16x4_f64,
+//                 operands straight from LDS (no per-FMA broadcast reads).
+// The right-hand side is the last row of the panel: what the solves leave there is y = L^-1 b, i.e. the forward
+// solve.  Returns (on wavefront 0) whether a pivot was not positive.  Dinv[c] receives 1 / L[c][c].
+template <int LDD, typename RowFn, typename DiagRowFn>
+__device__ __forceinline__ int blocked_cholesky(RowFn prow, DiagRowFn drow, int M, int nbc, double* Dinv, int tid, int lane, int wave) {
+  const int NB = (M + 15) >> 4;
+  int fail = 0;
+  double mydinv = 1.0;
+  // C[I][Jt] -= L[I][Ks] L[Jt][Ks]^T for the row blocks I >= Jt, dealt round-robin to wavefronts wlo .. wlo+nw-1;
+  // two tiles per wavefront in flight (independent accumulator chains), B operand shared by all tiles
+  auto update_tiles = [&](int Jt, int Ks, int wlo, int nw) {
+    if (wave < wlo || wave >= wlo + nw) return;
+    const int ct = 16 * Jt, cs = 16 * Ks;
+    const double* brow = prow(min(16 * Jt + (lane & 15), M - 1)) + cs + (lane >> 4);
+    double bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) bv[kk] = brow[4 * kk];
+    for (int I = Jt + (wave - wlo); I < NB; I += 2 * nw) {
+      const int I2 = I + nw;
+      const bool has2 = I2 < NB;
+      const double* ar0 = prow(min(16 * I + (lane & 15), M - 1)) + cs + (lane >> 4);
+      const double* ar1 = prow(min(16 * I2 + (lane & 15), M - 1)) + cs + (lane >> 4);
+      double a0[4], a1[4];
+      double4_t acc0, acc1;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) { a0[kk] = -ar0[4 * kk]; a1[kk] = -ar1[4 * kk]; }
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        acc0[rg] = prow(min(16 * I + (lane >> 4) + 4 * rg, M - 1))[ct + (lane & 15)];
+        acc1[rg] = prow(min(16 * I2 + (lane >> 4) + 4 * rg, M - 1))[ct + (lane & 15)];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], bv[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], bv[kk], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int row0 = 16 * I + (lane >> 4) + 4 * rg, row1 = 16 * I2 + (lane >> 4) + 4 * rg;
+        if (row0 < M) prow(row0)[ct + (lane & 15)] = acc0[rg];
+        if (has2 && row1 < M) prow(row1)[ct + (lane & 15)] = acc1[rg];
+      }
+    }
+  };
+  auto factor_diag = [&](int J) {
+    if (wave != 0) return;
+    const int c = 16 * J;
+    double x[16];
+    const int li = min(lane, 15);
+#pragma unroll
+    for (int q = 0; q < 16; q++) x[q] = drow(c + li)[c + q];
+    double dl = 1.0;                                          // my row's pivot
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const double d = readlane_f64(x[j], j);
+      if (!(d > 0.0)) fail = 1;                               // off the chain: a failed front leaves NaN / Inf behind, nobody reads them
+      const double r0 = __builtin_amdgcn_rcp(d);
+      const double e = fma(-d, r0, 1.0);
+      const double sc = x[j] * fma(r0, fma(e, e, e), r0);     // a_ij / d
+      if (lane == j) dl = d;
+#pragma unroll
+      for (int q = j + 1; q < 16; q++) x[q] = fma(-sc, readlane_f64(x[j], q), x[q]);
+    }
+    const double y = rsqrt_nr(dl);
+    mydinv = y;
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] *= readlane_f64(y, j);  // L[i][j] = a_ij d_j^-1/2 (j < i), L[i][i] = d_i d_i^-1/2
+    if (lane < 16) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) drow(c + lane)[c + q] = (q <= lane) ? x[q] : 0.0;
+      Dinv[c + lane] = mydinv;
+    }
+  };
+  // one thread per row below the diagonal block of block column J solves its 16 entries against that block
+  // (two rows per thread, sharing the block's entries, measured slower)
+  auto solve_rows = [&](int J) {
+    const int c = 16 * J;
+    const int row = c + 16 + tid;
+    if (row >= M) return;
+    double* xr = prow(row) + c;
+    double x[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) x[q] = xr[q];
+    // right-looking within the row: once x[q] is final it is pushed into all later entries (independent FMAs)
+    const double* l0 = drow(c) + c;                           // L[c][c]
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const double xq = x[q] * Dinv[c + q];
+      x[q] = xq;
+      const double* lc = l0 + q * LDD + q;                    // L[q][q]; L[j][q] is (j - q) rows below
+#pragma unroll
+      for (int j = q + 1; j < 16; j++) x[j] = fma(-xq, lc[(j - q) * LDD], x[j]);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) xr[q] = x[q];
+  };
+  // right-looking schedule with look-ahead: block column K+1 is brought up to date first, then wavefront 0 factors
+  // its diagonal block while wavefronts 1-3 push the same update into the block columns after it
+  factor_diag(0);
+  __syncthreads();
+  for (int K = 0; K < nbc; K++) {
+    solve_rows(K);
+    __syncthreads();
+    if (K + 1 < nbc) {
+      update_tiles(K + 1, K, 0, 4);
+      __syncthreads();
+      factor_diag(K + 1);
+      for (int J = K + 2; J < nbc; J++) update_tiles(J, K, 1, 3);
+      __syncthreads();
+    }
+  }
+  return fail;
+}
+
 // One workgroup per work item = (front, chunk of `chunk_rows` border rows) of the current level.  A lone workgroup
 // pulls cold data at 10-25 bytes per clock and pays ~2500 clocks per dependent round trip
 // (tools/ubench/cu_read_ubench.hip), so the assembly is organised around few round trips and contiguous wide loads:
@@ -922,6 +1047,126 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
       if (gi[a] < r && gj[b] <= gi[a]) Uo[uidx(gi[a], gj[b], r, my_ra)] = acc[2 * a + b];
 }
 
+// ------------------------------------------------------------------------------ top block
+// The last fronts of the root's chain (gn_symbolic.h: top_fronts; together at most kTopMaxCols columns, no border
+// beyond them) as ONE dense matrix in the LDS of one workgroup: assembly from the H blocks and from the update matrices
+// of every child that hangs below the block, blocked Cholesky with the right-hand side riding along, backward solve
+// of the block's columns -- one launch instead of three (factor, update, backward solve) per front and tree level, on
+// the part of the tree where a level holds a single front and the chip idles.  Children are added in a fixed order
+// (ascending front id) with a barrier in between: bit-reproducible.
+//   P    [16 nbc + 1][LD]   rows / columns 0 .. ncols-1 the block, identity padding up to 16 nbc, last row the rhs
+// With store_l the factor is also written in the per-front panel layout (the marginals' forward solve reads it).
+constexpr int kTopLD = kTopMaxCols + 1;                      // row stride of the block in LDS (doubles), whatever its size
+constexpr int top_smem_bytes(int ncols) {
+  const int n16 = (ncols + 15) / 16 * 16;
+  return ((n16 + 1) * kTopLD + n16) * 8 + 2 * 1024;
+}
+static_assert(kTopMaxCols % 16 == 0 && top_smem_bytes(kTopMaxCols) <= 160 * 1024, "top block exceeds the LDS");
+
+__global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfronts, const int32_t* __restrict__ top_fronts,
+                                                    int nchild, const int32_t* __restrict__ top_children, int nblk,
+                                                    const int32_t* __restrict__ top_blocks,
+                                                    const FrontDesc* __restrict__ fronts, const int32_t* __restrict__ rows,
+                                                    const double* __restrict__ Ablk, const double* __restrict__ bvec,
+                                                    const double* __restrict__ Ubuf, const double* __restrict__ uvec,
+                                                    double* __restrict__ Lbuf, double* __restrict__ yvec,
+                                                    double* __restrict__ xvec, int* __restrict__ status, int store_l,
+                                                    int write_l11c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LD = kTopLD;
+  const int n16 = (ncols + 15) / 16 * 16, M = n16 + 1, nbc = n16 / 16;
+  double* P = reinterpret_cast<double*>(smem);
+  double* Dinv = P + (size_t)M * LD;
+  short* cmap = reinterpret_cast<short*>(Dinv + n16);        // row of the block a child's border row lands in (<= 1024 rows)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int q = tid; q < M * LD; q += 256) P[q] = 0.0;
+  __syncthreads();
+  // ---- right-hand side, identity padding, H blocks
+  for (int j = tid; j < ncols; j += 256) P[(size_t)n16 * LD + j] = bvec[3 * (size_t)c0 + j];
+  for (int j = ncols + tid; j < n16; j += 256) P[(size_t)j * LD + j] = 1.0;
+  for (int q = tid; q < 9 * nblk; q += 256) {
+    const int b = q / 9, el = q - 9 * b;
+    const int slot = top_blocks[3 * b], rb = top_blocks[3 * b + 1], cb = top_blocks[3 * b + 2];
+    P[(size_t)(3 * rb + el / 3) * LD + 3 * cb + el % 3] = Ablk[9 * (size_t)slot + el];
+  }
+  __syncthreads();
+  // ---- the children below the block: the whole update matrix (lower triangle) and the border vector of each
+  for (int ci = 0; ci < nchild; ci++) {
+    const FrontDesc G = fronts[top_children[ci]];
+    const int r = 3 * G.ns, ra = 3 * G.na;
+    for (int k = tid; k < r; k += 256) cmap[k] = (short)(3 * (rows[G.rows_off + k / 3] - c0) + k % 3);
+    __syncthreads();
+    const double* U = Ubuf + G.U_off;
+    const float rinv = 1.0f / (float)r;
+    constexpr int TU = 8;                                     // loads in flight per thread: every load first, then the adds
+    for (int q0 = 0; q0 < r * r; q0 += 256 * TU) {
+      double val[TU];
+      int dst[TU];
+#pragma unroll
+      for (int u = 0; u < TU; u++) {
+        const int q = q0 + tid + 256 * u;
+        int i = (int)((float)q * rinv);                       // q / r for q < 2^14 (exact after one correction step)
+        if ((i + 1) * r <= q) i++;
+        if (i * r > q) i--;
+        const int j = q - i * r;
+        const bool ok = q < r * r && j <= i;
+        val[u] = U[ok ? uidx(i, j, r, ra) : 0];
+        dst[u] = ok ? cmap[i] * LD + cmap[j] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < TU; u++) if (dst[u] >= 0) lds_add(P + dst[u], val[u]);
+    }
+    for (int k = tid; k < r; k += 256) lds_add(P + (size_t)n16 * LD + cmap[k], uvec[3 * (size_t)G.rows_off + k]);
+    __syncthreads();
+  }
+  // ---- factorisation (the rhs row becomes y = L^-1 b)
+  auto prow = [=](int r) -> double* { return P + (size_t)r * LD; };
+  const int fail = blocked_cholesky<LD>(prow, prow, M, nbc, Dinv, tid, lane, wave);
+  if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);
+  __syncthreads();
+  // ---- backward solve L^T x = y of the block's columns (nothing above them): wavefront 0, lane = columns lane, lane + 64
+  if (wave == 0) {
+    double v[2], xv[2] = {0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 2; c++) v[c] = (lane + 64 * c < ncols) ? P[(size_t)n16 * LD + lane + 64 * c] : 0.0;
+    for (int i = ncols - 1; i >= 0; i--) {
+      const double xi = readlane_f64(i < 64 ? v[0] : v[1], i & 63) * Dinv[i];
+      const double* Li = P + (size_t)i * LD;                  // row i of L: entries left of the diagonal
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int col = lane + 64 * c;
+        if (col == i) xv[c] = xi;
+        if (col < i) v[c] = fma(-Li[col], xi, v[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int col = lane + 64 * c;
+      if (col < ncols) { xvec[3 * (size_t)c0 + col] = xv[c]; yvec[3 * (size_t)c0 + col] = P[(size_t)n16 * LD + col]; }
+    }
+  }
+  if (!store_l) return;
+  // ---- the factor in the per-front panel layout (W = 48): L11 row-major, L11 column-major, 1 / diag, L21
+  constexpr int W = kFrontW, kL11c = W * W, kDinv = 2 * W * W, kL21 = 2 * W * W + W;
+  for (int fi = 0; fi < nfronts; fi++) {
+    const FrontDesc F = fronts[top_fronts[fi]];
+    const int a = 3 * (F.c0 - c0), w = 3 * F.nc, r = 3 * F.ns;
+    double* Pn = Lbuf + F.L_off;
+    for (int q = tid; q < W * W; q += 256) {
+      const int i = q / W, k = q - i * W;
+      const double lv = (i < w && k <= i) ? P[(size_t)(a + i) * LD + a + k] : ((i >= w && i == k) ? 1.0 : 0.0);
+      Pn[q] = lv;                                             // element (row i, column k)
+      if (write_l11c) Pn[kL11c + k * W + i] = lv;             // column-major copy: element (row i, column k) at k * W + i
+    }
+    for (int k = tid; k < W; k += 256) Pn[kDinv + k] = (k < w) ? Dinv[a + k] : 1.0;
+    for (int q = tid; q < r * W; q += 256) {
+      const int p = q / W, k = q - p * W;
+      const int row = 3 * (rows[F.rows_off + p / 3] - c0) + p % 3;
+      Pn[kL21 + q] = (k < w) ? P[(size_t)row * LD + a + k] : 0.0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ solves
 // Backward (L^T x = y), one workgroup per front, top-down by level: x_own = L11^-T (y - L21^T x_border).
 // A chain of dependent round trips (descriptor -> border row indices -> x of the border -> ...), so everything that
@@ -1114,6 +1359,8 @@ void gn_init_kernels() {
                               factor_smem_bytes(kFrontW, kChunkRows + 1));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_bwd<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               bwd_smem_bytes(kWideFrontW));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_block), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              top_smem_bytes(kTopMaxCols));
   });
 }
 
@@ -1143,6 +1390,14 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   auto kern = lw == kWideFrontW ? k_solve_bwd<kWideFrontW> : k_solve_bwd<kFrontW>;
   hipLaunchKernelGGL(kern, dim3(nfr), dim3(256), bwd_smem_bytes(lw), st, D.fronts_lv, D.h_level_ptr[l], D.rows, D.Lbuf,
                      D.yvec, D.xvec);
+}
+
+void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c) {
+  gn_init_kernels();
+  if (D.top_nfronts <= 0) return;
+  hipLaunchKernelGGL(k_top_block, dim3(1), dim3(256), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols, D.top_nfronts,
+                     D.top_fronts, D.top_nchild, D.top_children, D.top_nblk, D.top_blocks, D.fronts, D.rows, D.Ablk, D.bvec, D.Ubuf,
+                     D.uvec, D.Lbuf, D.yvec, D.xvec, D.status, store_l ? 1 : 0, write_l11c ? 1 : 0);
 }
 
 void launch_update(hipStream_t st, const GnDevice& D, double* poses) {

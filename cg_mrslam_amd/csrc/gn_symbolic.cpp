@@ -803,6 +803,62 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     std::vector<int32_t> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
     for (int f = 0; f < nfr; f++) S.level_fronts[pos[S.fronts[f].level]++] = f;
   }
+  // ---- top block: walk down the root's chain while the columns stay consecutive and fit
+  S.gn_level_ptr = S.level_ptr;
+  S.gn_level_fronts = S.level_fronts;
+  static const bool top_on = !(getenv("CGMR_TOP_BLOCK") && atoi(getenv("CGMR_TOP_BLOCK")) == 0);
+  if (top_on && nfr > 0) {
+    int root = nfr - 1;                                    // the last front of the elimination order
+    const FrontDesc& Rt = S.fronts[root];
+    if (Rt.parent < 0 && Rt.ns == 0 && Rt.level == nlev - 1 && S.level_ptr[nlev] - S.level_ptr[nlev - 1] == 1 &&
+        3 * Rt.nc <= kTopMaxCols && S.level_w[Rt.level] == kFrontW) {
+      std::vector<int32_t> chain(1, root);
+      int cols = 3 * Rt.nc;
+      for (;;) {
+        const FrontDesc& B = S.fronts[chain.back()];
+        int next = -1;
+        for (int k = 0; k < B.nchild; k++) {
+          const int c = S.children[B.child_off + k];
+          const FrontDesc& C = S.fronts[c];
+          if (C.c0 + C.nc == B.c0 && C.level == B.level - 1) { next = c; break; }
+        }
+        if (next < 0) break;
+        const FrontDesc& C = S.fronts[next];
+        // every border row of the candidate must lie inside the block (it does when the chain ends in a border-less
+        // root and the columns are consecutive), its level must use the narrow panels
+        if (cols + 3 * C.nc > kTopMaxCols || S.level_w[C.level] != kFrontW) break;
+        chain.push_back(next);
+        cols += 3 * C.nc;
+      }
+      std::reverse(chain.begin(), chain.end());            // bottom-up
+      S.top_fronts = chain;
+      S.top_c0 = S.fronts[chain[0]].c0;
+      S.top_nposes = cols / 3;
+      std::vector<uint8_t> in_top(nfr, 0);
+      for (int f : chain) in_top[f] = 1;
+      for (int f = 0; f < nfr; f++)
+        if (!in_top[f] && S.fronts[f].parent >= 0 && in_top[S.fronts[f].parent]) S.top_children.push_back(f);
+      for (int f : chain) {
+        const FrontDesc& F = S.fronts[f];
+        for (int k = 0; k < F.a_cnt; k++) {
+          const int lr = S.alist[3 * (size_t)(F.a_off + k) + 1], lc = S.alist[3 * (size_t)(F.a_off + k) + 2];
+          const int grow = lr < F.nc ? F.c0 + lr : S.rows[F.rows_off + lr - F.nc];
+          S.top_blocks.push_back(F.a_off + k);
+          S.top_blocks.push_back(grow - S.top_c0);
+          S.top_blocks.push_back(F.c0 + lc - S.top_c0);
+        }
+      }
+      // Gauss-Newton level lists without the block
+      S.gn_level_fronts.clear();
+      S.gn_level_ptr.assign(1, 0);
+      for (int l = 0; l < nlev; l++) {
+        for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++)
+          if (!in_top[S.level_fronts[q]]) S.gn_level_fronts.push_back(S.level_fronts[q]);
+        if ((int)S.gn_level_fronts.size() > S.gn_level_ptr.back()) S.gn_level_ptr.push_back((int)S.gn_level_fronts.size());
+        else if (l < nlev - (int)chain.size()) S.gn_level_ptr.push_back((int)S.gn_level_fronts.size());   // (cannot happen: every lower level has a front)
+      }
+    }
+  }
   S.t_struct = now_s() - t1;
   return 0;
 }

@@ -35,6 +35,8 @@ constexpr int kLeafChunkRows = 62;   // the same for a level of leaves (k_front_
 // A child is "small" when kSmallSlabLoads 16-byte loads per thread (256 threads, one column pair of one row each) cover
 // the whole leading slab of its update matrix: k_front_factor fetches all small children of a front in one round.
 // The children of a front are listed big ones first.
+constexpr int kTopMaxCols = 128;     // scalar columns of the top block, a multiple of 16: (128 + 1) x 129 doubles = 130 KB of LDS
+
 constexpr int kSmallSlabLoads = 4;
 constexpr bool slab_is_small(int ns, int na) {
   const int cpw = (3 * na + 1) / 2 > 1 ? (3 * na + 1) / 2 : 1;
@@ -97,6 +99,15 @@ struct Symbolic {
   std::vector<int32_t> level_fronts;
   std::vector<int32_t> level_w;        // per level: scalar columns of its fronts' panels (kFrontW, or kWideFrontW if any front is wide)
   std::vector<int32_t> col_front;      // permuted block column -> owning front
+  // Top block: the last fronts of the root's chain (each the parent of the one before, consecutive columns, the root
+  // has no border) whose columns together fit one workgroup's LDS as a dense matrix.  One launch assembles, factors
+  // and back-solves them (k_top_block) instead of three launches per front; they are left out of the Gauss-Newton level
+  // lists below (gn_*), the full lists above still hold them (the marginals' forward solve walks every front).
+  std::vector<int32_t> top_fronts;     // bottom-up; empty: no top block
+  int32_t top_c0 = 0, top_nposes = 0;  // first block column / block columns of the top block
+  std::vector<int32_t> top_children;   // fronts outside the block whose parent is inside, ascending id
+  std::vector<int32_t> top_blocks;     // triples (slot in Ablk, local block row, local block column) of the block's H blocks
+  std::vector<int32_t> gn_level_ptr, gn_level_fronts;   // levels without the top block
   int64_t L_doubles = 0, U_doubles = 0;
   int max_ns = 0;
   double flops = 0;                    // factorisation flops (dense fronts)

@@ -98,9 +98,11 @@ int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]);
  * [7]=factor flops   [8]=ordering microseconds  [9]=structure microseconds
  * [10]=max children of a front  [11]=max children of a front with 1..32 border poses
  * [12]=doubles of the update-matrix slabs the factor kernel reads (columns that fall into the parent's own columns)
+ * [13]=tree levels that are launched one by one: the last fronts of the root's chain are handled together by one extra
+ *   launch, the "top block"  [14]=fronts of the top block  [15]=its scalar columns
  * perm_out (nullable, nV entries): permuted block column of each vertex or -1.          */
 int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx,
-                          const int32_t* to_idx, int64_t out[13], int32_t* perm_out);
+                          const int32_t* to_idx, int64_t out[16], int32_t* perm_out);
 
 /* Timing of the last cgmr_gn_optimize* call on this context, seconds:
  * out[0]=host ordering  [1]=host structure  [2]=upload+alloc  [3]=device GN iterations (stream time,
@@ -111,7 +113,7 @@ int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]);
  * recorded on the context's stream without synchronising (the stream stays busy, so a pair brackets the kernel,
  * not an idle-to-busy launch latency) and read back after the call's final synchronisation.  At most 2048
  * launches per call are timed.  bench.py uses it for the roofline figure.
- * classes: 0 linearize 1 assemble 2 chi2 3 front_factor 4 front_update 5 (unused: the forward solve rides
+ * classes: 0 linearize 1 assemble 2 chi2 3 front_factor 4 front_update 5 top_block (the forward solve rides
  * through front_factor) 6 solve_bwd 7 update
  * seconds_out[8], launches_out[8] are accumulated since profiling was switched on.       */
 int cgmr_set_profiling(cgmr_ctx* ctx, int on);
