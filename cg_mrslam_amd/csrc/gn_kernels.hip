@@ -83,8 +83,10 @@ __device__ __forceinline__ double d_normalize_theta(double t) {
 }  // namespace
 
 // ------------------------------------------------------------------------------ linearise
-// One thread per edge.  Writes the edge's quadratic-form terms component-major
-// (term[comp * nE + edge]) so that the stores of a wavefront are coalesced:
+// One thread per edge.  Writes the edge's quadratic-form terms as one 264-byte record per edge (term[edge * 33 + comp]):
+// the assembly gathers whole 3x3 blocks (9 adjacent threads read 72 contiguous bytes), and the three blocks an edge
+// feeds sit in the same few cache lines -- with the component-major layout of round 1 every gathered scalar touched a
+// line of its own (memory-side traffic 2.9x the algorithmic bytes):
 //   comps  0.. 8  Hii = Ji^T O Ji      9..17  Hij = Ji^T O Jj     18..26  Hjj = Jj^T O Jj
 //         27..29  bi  = -Ji^T O e     30..32  bj  = -Jj^T O e
 // chi2 = e^T O e is summed per workgroup (fixed tree) into term[33 * nE + blockIdx.x]; block_chi2_sum() adds the
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, int nA, int n_active,
   if (chi_only || k0 >= nE) return;
   if (!live) {                                           // switched-off edge: exact zeros into the assembly
 #pragma unroll
-    for (int q = 0; q < 33; q++) term[(size_t)q * E + k] = 0.0;
+    for (int q = 0; q < 33; q++) term[(size_t)k * 33 + q] = 0.0;
     return;
   }
   double A[9] = {-c, -s, -s * dx + c * dy, s, -c, -c * dx - s * dy, 0, 0, -1};
@@ -162,12 +164,12 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, int nA, int n_active,
       double hii = JiO[3 * r] * Ji[q] + JiO[3 * r + 1] * Ji[3 + q] + JiO[3 * r + 2] * Ji[6 + q];
       double hij = JiO[3 * r] * Jj[q] + JiO[3 * r + 1] * Jj[3 + q] + JiO[3 * r + 2] * Jj[6 + q];
       double hjj = JjO[3 * r] * Jj[q] + JjO[3 * r + 1] * Jj[3 + q] + JjO[3 * r + 2] * Jj[6 + q];
-      term[(size_t)(3 * r + q) * E + k] = hii;
-      term[(size_t)(9 + 3 * r + q) * E + k] = hij;
-      term[(size_t)(18 + 3 * r + q) * E + k] = hjj;
+      term[(size_t)k * 33 + 3 * r + q] = hii;
+      term[(size_t)k * 33 + 9 + 3 * r + q] = hij;
+      term[(size_t)k * 33 + 18 + 3 * r + q] = hjj;
     }
-    term[(size_t)(27 + r) * E + k] = -(JiO[3 * r] * e[0] + JiO[3 * r + 1] * e[1] + JiO[3 * r + 2] * e[2]);
-    term[(size_t)(30 + r) * E + k] = -(JjO[3 * r] * e[0] + JjO[3 * r + 1] * e[1] + JjO[3 * r + 2] * e[2]);
+    term[(size_t)k * 33 + 27 + r] = -(JiO[3 * r] * e[0] + JiO[3 * r + 1] * e[1] + JiO[3 * r + 2] * e[2]);
+    term[(size_t)k * 33 + 30 + r] = -(JjO[3 * r] * e[0] + JjO[3 * r + 1] * e[1] + JjO[3 * r + 2] * e[2]);
   }
 }
 
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
       int src = asm_src[p];
       int edge = src >> 2, code = src & 3;
       int comp = code == 0 ? el : code == 1 ? 18 + el : code == 2 ? 9 + el : 9 + elT;
-      acc += term[(size_t)comp * E + edge];
+      acc += term[(size_t)edge * 33 + comp];
     }
     if (blk < nf) { if (cmask[blk]) acc = (el % 4 == 0) ? 1.0 : 0.0; }
     else if (cmask[off_row[blk - nf]] | cmask[off_col[blk - nf]]) acc = 0.0;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
     for (int p = asm_ptr[v]; p < asm_ptr[v + 1]; p++) {
       int src = asm_src[p];
       int edge = src >> 2, code = src & 3;
-      acc += term[(size_t)((code == 0 ? 27 : 30) + r) * E + edge];
+      acc += term[(size_t)edge * 33 + (code == 0 ? 27 : 30) + r];
     }
     bvec[t] = cmask[v] ? 0.0 : acc;
   }
