@@ -131,12 +131,17 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, int nA, int n_active,
     __syncthreads();
     if (threadIdx.x == 0) term[33 * E + blockIdx.x] = (s_chi[0] + s_chi[1]) + (s_chi[2] + s_chi[3]);
   }
-  if (chi_only || k0 >= nE) return;
-  if (!live) {                                           // switched-off edge: exact zeros into the assembly
+  if (chi_only) return;
+  // the 33 doubles of an edge go through LDS so that the workgroup writes its 256 records as one contiguous stream
+  // (a thread writing its own 264-byte record produced 1.5x the bytes at the memory side in partial lines)
+  extern __shared__ __attribute__((aligned(16))) double s_t[];        // [256][33]
+  double* mine = s_t + threadIdx.x * 33;
+  const bool compute = live && k0 < nE;
+  if (!compute) {                                        // switched-off edge (or past the end): exact zeros into the assembly
 #pragma unroll
-    for (int q = 0; q < 33; q++) term[(size_t)k * 33 + q] = 0.0;
-    return;
+    for (int q = 0; q < 33; q++) mine[q] = 0.0;
   }
+  if (compute) {
   double A[9] = {-c, -s, -s * dx + c * dy, s, -c, -c * dx - s * dy, 0, 0, -1};
   double B[9] = {c, s, 0, -s, c, 0, 0, 0, 1};
   double Ji[9], Jj[9];
@@ -164,13 +169,18 @@ __global__ __launch_bounds__(256) void k_linearize(int nE, int nA, int n_active,
       double hii = JiO[3 * r] * Ji[q] + JiO[3 * r + 1] * Ji[3 + q] + JiO[3 * r + 2] * Ji[6 + q];
       double hij = JiO[3 * r] * Jj[q] + JiO[3 * r + 1] * Jj[3 + q] + JiO[3 * r + 2] * Jj[6 + q];
       double hjj = JjO[3 * r] * Jj[q] + JjO[3 * r + 1] * Jj[3 + q] + JjO[3 * r + 2] * Jj[6 + q];
-      term[(size_t)k * 33 + 3 * r + q] = hii;
-      term[(size_t)k * 33 + 9 + 3 * r + q] = hij;
-      term[(size_t)k * 33 + 18 + 3 * r + q] = hjj;
+      mine[3 * r + q] = hii;
+      mine[9 + 3 * r + q] = hij;
+      mine[18 + 3 * r + q] = hjj;
     }
-    term[(size_t)k * 33 + 27 + r] = -(JiO[3 * r] * e[0] + JiO[3 * r + 1] * e[1] + JiO[3 * r + 2] * e[2]);
-    term[(size_t)k * 33 + 30 + r] = -(JjO[3 * r] * e[0] + JjO[3 * r + 1] * e[1] + JjO[3 * r + 2] * e[2]);
+    mine[27 + r] = -(JiO[3 * r] * e[0] + JiO[3 * r + 1] * e[1] + JiO[3 * r + 2] * e[2]);
+    mine[30 + r] = -(JjO[3 * r] * e[0] + JjO[3 * r + 1] * e[1] + JjO[3 * r + 2] * e[2]);
   }
+  }
+  __syncthreads();
+  const int e0 = blockIdx.x * 256, ne = min(256, nE - e0);
+  double* out = term + (size_t)e0 * 33;
+  for (int q = threadIdx.x; q < ne * 33; q += 256) out[q] = s_t[q];
 }
 
 // --------------------------------------------------------------------------------- assemble
@@ -1332,7 +1342,8 @@ __global__ __launch_bounds__(256) void k_update_poses(int nV, const int32_t* __r
 
 void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const GnEdges& Ed, int chi_only) {
   if (D.nE == 0) return;
-  hipLaunchKernelGGL(k_linearize, dim3((D.nE + 255) / 256), dim3(256), 0, st, D.nE, Ed.nA, Ed.n_active, poses, D.ef, D.et,
+  gn_init_kernels();
+  hipLaunchKernelGGL(k_linearize, dim3((D.nE + 255) / 256), dim3(256), chi_only ? 0 : 256 * 33 * sizeof(double), st, D.nE, Ed.nA, Ed.n_active, poses, D.ef, D.et,
                      Ed.meas_a, Ed.info_a, Ed.meas_b, Ed.info_b, D.term, chi_only);
 }
 
@@ -1361,6 +1372,8 @@ void gn_init_kernels() {
                               factor_smem_bytes(kFrontW, kChunkRows + 1));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_bwd<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               bwd_smem_bytes(kWideFrontW));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              256 * 33 * (int)sizeof(double));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_block), hipFuncAttributeMaxDynamicSharedMemorySize,
                               top_smem_bytes(kTopMaxCols));
   });
