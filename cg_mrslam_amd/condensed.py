@@ -116,6 +116,10 @@ class RobotGraph:
         n = self._check(self.lib.cgmr_graph_closures(self.h, C.c_int(peer), C.c_int(0 if which == "out" else 1), C.c_int(len(out)), _p(out)))
         return out[:n].copy()
 
+    def set_optimal_gauge(self, optimal: bool):
+        """``computeCondensedGraph(robot, optimal)``: selectOptimalGauge instead of selectGaugeCentroid (reference default: off)."""
+        self._check(self.lib.cgmr_graph_set_optimal_gauge(self.h, C.c_int(1 if optimal else 0)))
+
     def computeCondensedGraph(self, peer: int = -1):   # noqa: N802
         """``computeCondensedGraph`` for one peer or (``peer < 0``) for every peer that has asked; returns the number built."""
         return self._check(self.lib.cgmr_graph_compute_condensed(self.h, C.c_int(peer)))

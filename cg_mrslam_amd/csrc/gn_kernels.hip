@@ -208,7 +208,6 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
   }
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int nblk = nf + nb;
-  size_t E = (size_t)nE;
   if (t < nblk * 9) {
     int blk = t / 9, el = t - 9 * blk;
     int elT = (el % 3) * 3 + el / 3;

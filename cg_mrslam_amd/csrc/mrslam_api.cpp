@@ -43,6 +43,7 @@ struct PeerOut {                      // condensed graph built for one peer
   std::vector<WireEdge> host;         // host copy (set by cgmr_graph_set_condensed or downloaded on demand)
   bool host_valid = false;
   std::vector<int32_t> to_idx;        // vertex index of every edge's far end
+  double uncertainty = 0;             // selectOptimalGauge: overall uncertainty of the chosen star
 };
 
 struct PeerIn {                       // edges received from one peer (the accepted, newest set)
@@ -80,6 +81,7 @@ struct cgmr_graph {
   char* pinned = nullptr;             // header + closures staging, ids read-back, slot lists
   size_t pinned_bytes = 0;
   double last_condense_seconds = 0, last_optimize_seconds = 0;
+  bool optimal_gauge = false;         // computeCondensedGraph(robot, optimal)
 };
 
 namespace {
@@ -361,41 +363,31 @@ int cgmr_graph_closures(const cgmr_graph* g, int peer, int which, int cap, int32
   return (int)v.size();
 }
 
-// CondensedGraphBuffer::computeCondensedGraph(robot) (condensed_graph_buffer.cpp:437-485) for one peer or, with
-// peer < 0, for every peer that has asked for vertices: gauge = selectGaugeCentroid, edges = getMyEdges (own edges
-// only), CondensedGraphCreator::compute per peer.  One symbolic analysis (shared with cgmr_graph_optimize) serves all
-// peers: the gauge and the switched-off received edges are numeric masks.  The passes of all peers are queued on the
-// stream back to back; the labelled edges land in the send buffer as wire records.  Returns the number of peers built.
-int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
-  if (!g || peer >= g->n_robots) return CGMR_E_INVALID;
-  if (!g->ctx) return gerr(g, CGMR_E_NO_DEVICE, "cgmr_graph_compute_condensed: the graph was created without a device context");
+}  // extern "C"
+
+namespace {
+
+struct CondJob {
+  int peer = 0;
+  int gauge = 0;                      // vertex index
+  std::vector<int32_t> q;             // the other requested vertices (vertex indices, id order)
+};
+
+// CondensedGraphCreator::compute (condensed_graph_creator.cpp:33-66) for a batch of (gauge, vertex set) jobs on the
+// robot's own edges.  One symbolic analysis (shared with cgmr_graph_optimize: same edge list) serves all jobs -- the
+// gauge and the switched-off received edges are numeric masks.  Every job gets a copy of the numeric work space and
+// a side stream: one pass keeps a handful of workgroups busy per tree level, so the passes overlap almost perfectly.
+// to_wire: the labelled edges go to the peer's slots (double-precision copy + 44-byte wire records in the send
+// buffer); otherwise only the information matrices come back (info_out[i], 6 doubles per edge: gauge search).
+int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::vector<std::vector<double>>* info_out) {
   cgmr_ctx* ctx = g->ctx;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const double t0 = wall_s();
   const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), nE = (int)g->all_ef.size(), cap = g->cap;
-  struct Job { int peer; std::vector<int32_t> idx; int gauge; std::vector<int32_t> q; };
-  std::vector<Job> jobs;
-  for (int p = 0; p < g->n_robots; p++) {
-    if (p == g->robot || (peer >= 0 && p != peer)) continue;
-    Job J;
-    J.peer = p;
-    for (int32_t id : g->out_closures[p]) J.idx.push_back(g->index[id]);       // id order (VertexIDMap)
-    if (J.idx.size() < 2) { g->out[p].n = 0; g->out[p].host.clear(); g->out[p].host_valid = true; continue; }
-    if ((int)J.idx.size() - 1 > cap)
-      return gerr(g, CGMR_E_INVALID, "a peer asked for more vertices than the wire buffer holds (cap_edges_per_peer)");
-    jobs.push_back(std::move(J));
-  }
-  if (jobs.empty() || nA == 0) return 0;
-  // current estimates -> host (gauge selection, spanning-tree initial guess)
-  HIP_TRY(ctx, hipMemcpyAsync(g->h_poses.data(), g->d_poses.ptr, 24 * (size_t)nV, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  const int nj = (int)jobs.size();
+  if (nj == 0) return 0;
   int rc = prepare_structure(ctx, nV, nE, g->all_ef.data(), g->all_et.data(), 1);
   if (rc) return rc;
   const Symbolic& S = ctx->sym;
-  const int nj = (int)jobs.size();
-  // every peer's pass gets a copy of the numeric work space and a stream of its own: one pass keeps a handful of
-  // workgroups busy per tree level, so the passes of all peers overlap almost perfectly
   const int nstreams = std::min(nj, 8);
   rc = aux_streams(ctx, nstreams);
   if (rc) return rc;
@@ -405,14 +397,15 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
   rc = dev_grow(g, g->d_work, 0, 24 * (size_t)nV * nj);
   if (rc) return rc;
   // marginals work space per pass, sized for the largest query set
-  int maxq = 0;
-  for (Job& J : jobs) maxq = std::max(maxq, (int)J.idx.size() - 1);
+  int maxq = 1;
+  for (CondJob& J : jobs) maxq = std::max(maxq, (int)J.q.size());
   const int nf = ctx->gn.nf;
   const int m_max = ((4 * maxq + 15) / 16) * 16, n = 3 * nf, chunk = 2048, nchunk = (n + chunk - 1) / chunk;
   struct L2 { size_t off = 0; size_t add(size_t b) { off = (off + 255) & ~size_t(255); size_t o = off; off += b; return o; } } L;
-  const size_t o_qc = L.add(4 * (size_t)maxq), o_Y = L.add(8 * (size_t)n * m_max),
+  const size_t o_qc = L.add(4 * (size_t)maxq), o_qv = L.add(4 * (size_t)maxq), o_Y = L.add(8 * (size_t)n * m_max),
                o_U = L.add(8 * ((size_t)3 * S.rows.size() + 3) * m_max), o_part = L.add(8 * (size_t)nchunk * 16 * m_max),
-               o_G = L.add(8 * (size_t)16 * m_max), o_cov = L.add(72 * (size_t)maxq), o_fl = L.add(4 * (size_t)maxq);
+               o_G = L.add(8 * (size_t)16 * m_max), o_cov = L.add(72 * (size_t)maxq), o_fl = L.add(4 * (size_t)maxq),
+               o_e64 = L.add(24 * (size_t)maxq), o_i64 = L.add(48 * (size_t)maxq), o_st = L.add(16);
   const size_t per_job = (L.off + 255) & ~size_t(255);
   rc = arena_reserve(ctx, ctx->mg_arena, per_job * (size_t)nj + 256);
   if (rc) return rc;
@@ -427,12 +420,10 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
   HIP_TRY(ctx, hipEventRecord(ctx->aux_fork, st));
   for (int k = 0; k < nstreams; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->aux_fork, 0));
   for (int i = 0; i < nj; i++) {
-    Job& J = jobs[i];
+    CondJob& J = jobs[i];
     hipStream_t sj = ctx->aux[i % nstreams];
     GnDevice& D = reps[i];
     char* d = ctx->mg_arena.ptr + per_job * (size_t)i;
-    J.gauge = select_gauge_centroid(J.idx, g->h_poses.data());
-    for (int v : J.idx) if (v != J.gauge) J.q.push_back(v);
     const int nq = (int)J.q.size();
     // GraphManipulator::fixGauge + optimize(1) (graph_manipulator.cpp:62-124): only the gauge is fixed, spanning-tree
     // initial guess over my own edges, one Gauss-Newton iteration; the marginals are those of that iteration's Hessian
@@ -447,38 +438,136 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
     qcol.resize(nq);
     for (int k = 0; k < nq; k++) qcol[k] = ctx->vmask[J.q[k]] ? -1 : S.vperm[J.q[k]];
     int32_t* d_qc = (int32_t*)(d + o_qc);
-    int32_t* d_qv = g->d_qidx + (size_t)cap * i;
+    int32_t* d_qv = (int32_t*)(d + o_qv);
     HIP_TRY(ctx, hipMemcpyAsync(d_qc, qcol.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, sj));
     HIP_TRY(ctx, hipMemcpyAsync(d_qv, J.q.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, sj));
     gn_pass_on(ctx, D, sj, d_work, Ed, 0, false, true, /*write_l11c=*/true);
     const int m = ((4 * nq + 15) / 16) * 16;
     launch_marginals(sj, D, nq, d_qc, m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part), (double*)(d + o_G),
                      (double*)(d + o_cov), chunk, nchunk);
-    double* est64 = g->d_est64 + 3 * (size_t)cap * J.peer;
-    double* info64 = g->d_info64 + 6 * (size_t)cap * J.peer;
+    double* est64 = to_wire ? g->d_est64 + 3 * (size_t)cap * J.peer : (double*)(d + o_e64);
+    double* info64 = to_wire ? g->d_info64 + 6 * (size_t)cap * J.peer : (double*)(d + o_i64);
     launch_label(sj, nq, d_qv, J.gauge, d_work, (const double*)(d + o_cov), est64, info64, (int*)(d + o_fl));
-    launch_wire_write_edges(sj, nq, g->ids[J.gauge], d_qv, (const int32_t*)g->d_vids.ptr, est64, info64,
-                            send_edges + (size_t)cap * J.peer);
-    HIP_TRY(ctx, hipMemcpyAsync(g->d_status_all + i, D.status, 4, hipMemcpyDeviceToDevice, sj));
+    if (to_wire)
+      launch_wire_write_edges(sj, nq, g->ids[J.gauge], d_qv, (const int32_t*)g->d_vids.ptr, est64, info64,
+                              send_edges + (size_t)cap * J.peer);
+    HIP_TRY(ctx, hipMemcpyAsync(d + o_st, D.status, 4, hipMemcpyDeviceToDevice, sj));
   }
   for (int k = 0; k < nstreams; k++) {
     HIP_TRY(ctx, hipEventRecord(ctx->aux_done[k], ctx->aux[k]));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->aux_done[k], 0));
   }
   std::vector<int32_t> status(nj, 0);
-  HIP_TRY(ctx, hipMemcpyAsync(status.data(), g->d_status_all, 4 * (size_t)nj, hipMemcpyDeviceToHost, st));
+  if (info_out) info_out->assign(nj, {});
+  for (int i = 0; i < nj; i++) {
+    char* d = ctx->mg_arena.ptr + per_job * (size_t)i;
+    HIP_TRY(ctx, hipMemcpyAsync(&status[i], d + o_st, 4, hipMemcpyDeviceToHost, st));
+    if (info_out && !to_wire) {
+      (*info_out)[i].resize(6 * jobs[i].q.size());
+      HIP_TRY(ctx, hipMemcpyAsync((*info_out)[i].data(), d + o_i64, 48 * jobs[i].q.size(), hipMemcpyDeviceToHost, st));
+    }
+  }
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
-  for (int i = 0; i < nj; i++) {
-    PeerOut& O = g->out[jobs[i].peer];
-    if (status[i] != 0) { O.n = 0; O.host_valid = false; return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph"); }
-    O.n = (int)jobs[i].q.size();
-    O.gauge_id = g->ids[jobs[i].gauge];
-    O.to_idx = jobs[i].q;
+  for (int i = 0; i < nj; i++)
+    if (status[i] != 0) return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
+  return 0;
+}
+
+// computeOverallUncertainty (condensed_graph_buffer.cpp:172-180): sum over the star's edges of det(information^-1)
+double overall_uncertainty(const std::vector<double>& info_upper) {
+  double total = 0;
+  for (size_t k = 0; k + 5 < info_upper.size(); k += 6) {
+    const double* u = &info_upper[k];
+    const double a = u[0], b = u[1], c = u[2], d = u[3], e = u[4], f = u[5];
+    const double det = a * (d * f - e * e) - b * (b * f - e * c) + c * (b * e - d * c);
+    total += 1.0 / det;                                          // det(A^-1) = 1 / det(A)
+  }
+  return total;
+}
+
+}  // namespace
+
+extern "C" {
+
+// CondensedGraphBuffer::computeCondensedGraph(robot, optimal) (condensed_graph_buffer.cpp:437-485) for one peer or, with
+// peer < 0, for every peer that has asked for vertices: gauge = selectGaugeCentroid (:318-345) -- or, after
+// cgmr_graph_set_optimal_gauge(g, 1), selectOptimalGauge (:252-288: the candidate whose star has the smallest overall
+// uncertainty, every candidate's condensed graph being built for that) --, edges = getMyEdges (own edges only),
+// CondensedGraphCreator::compute per peer.  The passes of all peers (and of the gauge candidates) are queued on side
+// streams back to back; the labelled edges land in the send buffer as wire records.  Returns the number of peers built.
+int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
+  if (!g || peer >= g->n_robots) return CGMR_E_INVALID;
+  if (!g->ctx) return gerr(g, CGMR_E_NO_DEVICE, "cgmr_graph_compute_condensed: the graph was created without a device context");
+  cgmr_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const double t0 = wall_s();
+  const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), cap = g->cap;
+  struct Want { int peer; std::vector<int32_t> idx; };
+  std::vector<Want> wants;
+  for (int p = 0; p < g->n_robots; p++) {
+    if (p == g->robot || (peer >= 0 && p != peer)) continue;
+    Want W;
+    W.peer = p;
+    for (int32_t id : g->out_closures[p]) W.idx.push_back(g->index[id]);       // id order (VertexIDMap)
+    if (W.idx.size() < 2) { g->out[p].n = 0; g->out[p].host.clear(); g->out[p].host_valid = true; continue; }
+    if ((int)W.idx.size() - 1 > cap)
+      return gerr(g, CGMR_E_INVALID, "a peer asked for more vertices than the wire buffer holds (cap_edges_per_peer)");
+    wants.push_back(std::move(W));
+  }
+  if (wants.empty() || nA == 0) return 0;
+  // current estimates -> host (gauge selection, spanning-tree initial guess)
+  HIP_TRY(ctx, hipMemcpyAsync(g->h_poses.data(), g->d_poses.ptr, 24 * (size_t)nV, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<CondJob> jobs;
+  for (Want& W : wants) {
+    CondJob J;
+    J.peer = W.peer;
+    J.gauge = select_gauge_centroid(W.idx, g->h_poses.data());
+    if (g->optimal_gauge) {
+      // selectOptimalGauge: every requested vertex in turn as the gauge, eight candidates' passes in flight
+      double best = 1.79769313486231570815e308;
+      for (size_t c0 = 0; c0 < W.idx.size(); c0 += 8) {
+        std::vector<CondJob> cand;
+        for (size_t c = c0; c < std::min(W.idx.size(), c0 + 8); c++) {
+          CondJob C;
+          C.peer = W.peer; C.gauge = W.idx[c];
+          for (int v : W.idx) if (v != C.gauge) C.q.push_back(v);
+          cand.push_back(std::move(C));
+        }
+        std::vector<std::vector<double>> info;
+        int rc = run_cond_jobs(g, cand, /*to_wire=*/false, &info);
+        if (rc) return rc;
+        for (size_t c = 0; c < cand.size(); c++) {
+          const double u = overall_uncertainty(info[c]);
+          if (u < best) { best = u; J.gauge = cand[c].gauge; }
+        }
+      }
+      g->out[W.peer].uncertainty = best;
+    }
+    for (int v : W.idx) if (v != J.gauge) J.q.push_back(v);
+    jobs.push_back(std::move(J));
+  }
+  int rc = run_cond_jobs(g, jobs, /*to_wire=*/true, nullptr);
+  if (rc) { for (CondJob& J : jobs) { g->out[J.peer].n = 0; g->out[J.peer].host_valid = false; } return rc; }
+  for (CondJob& J : jobs) {
+    PeerOut& O = g->out[J.peer];
+    O.n = (int)J.q.size();
+    O.gauge_id = g->ids[J.gauge];
+    O.to_idx = J.q;
     O.host_valid = false;
   }
   g->last_condense_seconds = wall_s() - t0;
-  return nj;
+  return (int)jobs.size();
+}
+
+// optimal = 1: computeCondensedGraph picks the gauge with selectOptimalGauge instead of selectGaugeCentroid (the
+// reference's default is the centroid: condensed_graph_buffer.h:55, mr_graph_slam.cpp:347)
+int cgmr_graph_set_optimal_gauge(cgmr_graph* g, int optimal) {
+  if (!g) return CGMR_E_INVALID;
+  g->optimal_gauge = optimal != 0;
+  return CGMR_OK;
 }
 
 // The condensed graph built for `peer`, in double precision (before the wire narrows it): returns the number of edges;

@@ -365,6 +365,9 @@ int cgmr_graph_insert_out_closure(cgmr_graph* g, int peer, int n, const int32_t*
 int cgmr_graph_closures(const cgmr_graph* g, int peer, int which, int cap, int32_t* ids_out);
 /* computeCondensedGraph for `peer`, or for every peer with out-closures when peer < 0; returns the number built */
 int cgmr_graph_compute_condensed(cgmr_graph* g, int peer);
+/* optimal = 1: pick the gauge with selectOptimalGauge (condensed_graph_buffer.cpp:252-288: every requested vertex in turn,
+ * smallest sum of det(information^-1) over the star wins) instead of selectGaugeCentroid; the reference's default is 0 */
+int cgmr_graph_set_optimal_gauge(cgmr_graph* g, int optimal);
 /* the condensed graph built for `peer` in double precision: returns its edge count; outputs nullable */
 int cgmr_graph_get_condensed(cgmr_graph* g, int peer, int cap, int32_t* from_id_out, int32_t* to_ids_out, double* est_out,
                              double* info_upper_out);

@@ -259,6 +259,18 @@ class RefRobotGraph:
             return self.gauge[peer][1], None
         gauge = int(idx[select_gauge_centroid(g.poses[idx, :2])])
         m = b.my_edge_mask()
+        if getattr(self, "optimal_gauge", False):
+            # selectOptimalGauge (condensed_graph_buffer.cpp:252-288) with computeOverallUncertainty (:172-180)
+            best = np.inf
+            self.uncertainties = {}
+            for cand in idx:
+                _, _, iu_c, _ = self.ctx.condense(g.poses, g.edge_from[m], g.edge_to[m], g.meas[m], g.info[m], int(cand), idx.astype(np.int32))
+                u = 0.0
+                for a, bb, c, d, e, f in iu_c:
+                    u += 1.0 / (a * (d * f - e * e) - bb * (bb * f - e * c) + c * (bb * e - d * c))
+                self.uncertainties[int(g.ids[cand])] = u
+                if u < best:
+                    best, gauge = u, int(cand)
         to, est, iu, _ = self.ctx.condense(g.poses, g.edge_from[m], g.edge_to[m], g.meas[m], g.info[m], gauge, idx.astype(np.int32))
         e = np.zeros(len(to), dtype=EDGE_DTYPE)
         e["from"] = g.ids[gauge]; e["to"] = g.ids[to]

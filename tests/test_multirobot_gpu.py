@@ -146,3 +146,32 @@ def test_bench_two_ranks_on_one_gpu():
     ex = out["exchange"]
     assert ex["robots"] == 2 and ex["rounds"] == 8 and ex["transport"] == "host"
     assert ex["condensed_graphs_built_total"] > 0 and ex["condensed_edges_received_total"] > 0 and ex["status_rank0"] == 0
+
+
+def test_select_optimal_gauge_matches_oracle_backend(ctx, oracle):
+    """computeCondensedGraph(robot, optimal = true): selectOptimalGauge (condensed_graph_buffer.cpp:252-288) -- every
+    requested vertex in turn as the gauge, the star with the smallest sum of det(information^-1) wins -- against the same
+    search on the oracle backend: same gauge (the runner-up is clearly worse), same edges."""
+    import oracle_backend as ob
+    from ref_condensed import RefRobotGraph
+    g = synth.make_pose_graph(1500, 5000, seed=77, id_base=20000)
+    want = g["ids"][np.sort(np.random.default_rng(9).choice(1500, size=12, replace=False))]
+    graphs = [RobotGraph(ctx, 2, 4), RefRobotGraph(ob.OracleContext(), 2, 4)]
+    for rg in graphs:
+        rg.add_vertices(g["ids"], g["poses"], g["fixed"])
+        rg.add_edges(g["ids"][g["edge_from"]], g["ids"][g["edge_to"]], g["meas"], g["info"])
+        assert rg.optimize(6)[0] == 0
+        rg.insertOutClosure(0, want)
+    graphs[0].set_optimal_gauge(True)
+    graphs[1].optimal_gauge = True
+    assert graphs[0].computeCondensedGraph(0) == 1 and graphs[1].computeCondensedGraph(0) == 1
+    gid_a, to_a, est_a, iu_a = graphs[0].condensed(0)
+    gid_b, to_b, est_b, iu_b = graphs[1].condensed(0)
+    u = sorted(graphs[1].uncertainties.values())
+    assert u[1] > u[0] * (1 + 1e-6)                          # the choice is not a coin flip
+    assert gid_a == gid_b and np.array_equal(to_a, to_b) and len(to_a) == 11
+    assert np.abs(est_a - est_b).max() < 1e-6 and np.abs(iu_a - iu_b).max() <= 1e-4 * np.abs(iu_b).max()
+    # and it differs from the centroid choice on this graph, i.e. the search did something
+    graphs[0].set_optimal_gauge(False)
+    graphs[0].computeCondensedGraph(0)
+    assert graphs[0].condensed(0)[0] != gid_a or len(set(graphs[1].uncertainties.values())) == 1
