@@ -438,11 +438,12 @@ def main():
         "traffic": pmc.get("k_front_factor", {}).get("traffic_bytes_corrected"),
         "traffic_source": pmc.get("_source"),
         "avg_launch_us": round(1e6 * avg_launch_s, 2), "launches_per_gn_iter": round(launches_per_iter, 1),
-        "tree_levels": info["levels"], "per_level_us": per_level_us,
+        "tree_levels": info["levels"], "launched_levels": info["launch_levels"], "top_block_columns": info["top_block_cols"],
+        "per_level_us": per_level_us,
         "algorithmic_bytes_per_launch": int(bytes_per_launch),
         "share_of_kernel_time": round(ff_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
-        "note": f"latency-bound: {info['levels']} dependent tree levels of FP64 chains at one wave per SIMD; memory-side traffic "
-                "(PMC) ~ algorithmic bytes, i.e. no wasted re-reads; see DESIGN.md 2.3",
+        "note": f"latency-bound: {info['launch_levels']} dependent tree levels (+ the top block) of FP64 pivot chains at one wave per SIMD; "
+                "memory-side traffic (PMC) ~ algorithmic bytes, i.e. no wasted re-reads; see DESIGN.md 2.3",
     }
 
     cpu = None
