@@ -169,6 +169,25 @@ class RobotGraph:
         self._check(self.lib.cgmr_graph_ingest_host(self.h, _p(recv), _p(n)))
         return n
 
+    def message_for(self, peer):
+        """``constructCondensedGraphMessage(peer)``: a ``messages.CondensedGraphMessage`` or None (nothing to send)."""
+        from .messages import EDGE_DTYPE, CondensedGraphMessage
+        cap = self.cap
+        edges, clos = np.zeros(cap, dtype=EDGE_DTYPE), np.zeros(cap, dtype=np.int32)
+        ne, nc = C.c_int32(0), C.c_int32(0)
+        rc = self._check(self.lib.cgmr_graph_message_for(self.h, C.c_int(peer), C.c_int(cap), _p(edges), C.byref(ne), C.c_int(cap),
+                                                         _p(clos), C.byref(nc)))
+        return CondensedGraphMessage(self.robot, edges[:ne.value].copy(), clos[:nc.value].copy()) if rc == 1 else None
+
+    def message_from(self, msg) -> int:
+        """``addInterRobotData(CondensedGraphMessage*)``: returns the number of edges now held from the sender because of
+        this message (0 = the previous set stays)."""
+        e = np.ascontiguousarray(msg.edges)
+        c = _i32(msg.closures)
+        n = C.c_int32(0)
+        self._check(self.lib.cgmr_graph_message_from(self.h, C.c_int(msg.robotId), C.c_int(len(e)), _p(e), C.c_int(len(c)), _p(c), C.byref(n)))
+        return int(n.value)
+
     def received_edges(self, peer):
         cap = self.cap
         f, t, m, i = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32), np.zeros((cap, 3)), np.zeros((cap, 6))

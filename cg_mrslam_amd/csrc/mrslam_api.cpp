@@ -770,6 +770,67 @@ int cgmr_graph_ingest_host(cgmr_graph* g, const void* recv, int32_t* n_edges_out
   return CGMR_OK;
 }
 
+// MRGraphSLAM::constructCondensedGraphMessage(idRobotTo) (mr_graph_slam.cpp:607-670): the part of this robot's round
+// message that is addressed to ONE peer, as the reference's CondensedGraphMessage carries it -- the condensed edges built
+// for `peer` in wire precision (44 bytes each) and the ids of `peer`'s vertices this robot wants condensed in return.
+// Returns 1 if there is a message (a closure list for the peer exists or there are edges, :664-667), 0 if not.
+int cgmr_graph_message_for(cgmr_graph* g, int peer, int cap_edges, void* edges44_out, int32_t* n_edges_out, int cap_closures,
+                           int32_t* closure_ids_out, int32_t* n_closures_out) {
+  if (!g || peer < 0 || peer >= g->n_robots || cap_edges < 0 || cap_closures < 0 || !n_edges_out || !n_closures_out)
+    return CGMR_E_INVALID;
+  const int R = g->n_robots, cap = g->cap;
+  const size_t wb = wire_bytes(R, cap);
+  std::vector<unsigned char> buf(wb);
+  int rc = cgmr_graph_pack_host(g, buf.data());
+  if (rc) return rc;
+  const int32_t* hdr = reinterpret_cast<const int32_t*>(buf.data());
+  const int n_e = hdr[2 + peer], n_c = hdr[2 + R + peer];
+  if (n_e > cap_edges || n_c > cap_closures) return gerr(g, CGMR_E_INVALID, "cgmr_graph_message_for: output capacity too small");
+  if (n_e > 0 && !edges44_out) return CGMR_E_INVALID;
+  if (n_c > 0 && !closure_ids_out) return CGMR_E_INVALID;
+  if (n_e > 0) memcpy(edges44_out, buf.data() + wire_edges_off(R) + (size_t)peer * cap * sizeof(WireEdge), (size_t)n_e * sizeof(WireEdge));
+  if (n_c > 0) memcpy(closure_ids_out, buf.data() + wire_clos_off(R, cap) + (size_t)peer * cap * 4, (size_t)n_c * 4);
+  *n_edges_out = n_e;
+  *n_closures_out = n_c;
+  return (n_e > 0 || !g->in_closures[peer].empty()) ? 1 : 0;
+}
+
+// MRGraphSLAM::addInterRobotData(CondensedGraphMessage*) (mr_graph_slam.cpp:331-395) for ONE message: the closure requests
+// for vertices this robot has become out-closures and the condensed graph for `sender` is rebuilt at once (:345-348); the
+// edges whose end points exist replace the set previously received from `sender`, unless none survives (:393-394).
+// n_accepted_out (nullable): edges now held from `sender` because of this message (0 = previous set kept).
+int cgmr_graph_message_from(cgmr_graph* g, int sender, int n_edges, const void* edges44, int n_closures,
+                            const int32_t* closure_ids, int32_t* n_accepted_out) {
+  if (!g || sender < 0 || sender >= g->n_robots || sender == g->robot || n_edges < 0 || n_closures < 0 ||
+      (n_edges > 0 && !edges44) || (n_closures > 0 && !closure_ids))
+    return CGMR_E_INVALID;
+  const int R = g->n_robots, cap = g->cap;
+  if (n_edges > cap || n_closures > cap) return gerr(g, CGMR_E_INVALID, "cgmr_graph_message_from: message exceeds cap_edges_per_peer");
+  const size_t wb = wire_bytes(R, cap);
+  std::vector<unsigned char> buf((size_t)R * wb, 0);
+  for (int s = 0; s < R; s++) {                                 // every block needs its sender id; only one carries data
+    int32_t* h = reinterpret_cast<int32_t*>(buf.data() + (size_t)s * wb);
+    h[0] = s; h[1] = R;
+  }
+  unsigned char* blk = buf.data() + (size_t)sender * wb;
+  int32_t* hdr = reinterpret_cast<int32_t*>(blk);
+  hdr[2 + g->robot] = n_edges;
+  hdr[2 + R + g->robot] = n_closures;
+  if (n_edges) memcpy(blk + wire_edges_off(R) + (size_t)g->robot * cap * sizeof(WireEdge), edges44, (size_t)n_edges * sizeof(WireEdge));
+  if (n_closures) memcpy(blk + wire_clos_off(R, cap) + (size_t)g->robot * cap * 4, closure_ids, (size_t)n_closures * 4);
+  bool any_known = false;
+  for (int k = 0; k < n_closures; k++) any_known = any_known || g->index.count(closure_ids[k]);
+  std::vector<int32_t> acc(R, 0);
+  int rc = cgmr_graph_ingest_host(g, buf.data(), acc.data());
+  if (rc) return rc;
+  if (n_accepted_out) *n_accepted_out = acc[sender];
+  if (any_known && g->ctx) {
+    rc = cgmr_graph_compute_condensed(g, sender);
+    if (rc < 0) return rc;
+  }
+  return CGMR_OK;
+}
+
 // The edges currently held from `peer` (the second edge segment's slice): end point ids, measurement, information
 int cgmr_graph_received_edges(cgmr_graph* g, int peer, int cap, int32_t* from_ids_out, int32_t* to_ids_out, double* meas_out,
                               double* info_upper_out) {

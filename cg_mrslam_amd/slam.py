@@ -121,10 +121,19 @@ class ClosureBuffer:
         self.edges = []          # list of dict(from,to,meas,id)
         self.vertices = []       # list of [vertex, time]
 
+    def addEdge(self, e):   # noqa: N802
+        if not any(e is q for q in self.edges):
+            self.edges.append(e)
+
+    def removeEdge(self, e):   # noqa: N802
+        self.edges = [q for q in self.edges if q is not e]
+
     def addEdgeSet(self, eset):   # noqa: N802
         for e in eset:
-            if not any(e is q for q in self.edges):
-                self.edges.append(e)
+            self.addEdge(e)
+
+    def findVertex(self, v):   # noqa: N802
+        return any(q[0] == v for q in self.vertices)
 
     def addVertex(self, v):   # noqa: N802
         self.vertices.append([v, 0])
@@ -185,7 +194,7 @@ class LoopClosureChecker:
         for q in self.edges:
             a = moved.get(q["from"], self.poses[q["from"]])
             b = moved.get(q["to"], self.poses[q["to"]])
-            chi.append(_edge_chi2(a, b, q["meas"], SM_INFO))
+            chi.append(_edge_chi2(a, b, q["meas"], q.get("info", SM_INFO)))
         return chi
 
     def inliers(self):

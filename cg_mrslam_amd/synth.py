@@ -383,7 +383,7 @@ def make_scan_pairs(n_pairs: int, seed: int = 4242, n_beams: int = LASER_BEAMS,
 
 
 def make_trajectory(n_steps: int = 400, seed: int = 31, n_beams: int = LASER_BEAMS, range_noise: float = 0.01,
-                    odom_noise=(0.004, 0.004, 0.002), laps: float = 1.25):
+                    odom_noise=(0.004, 0.004, 0.002), laps: float = 1.25, start: float = 0.0, moving_boxes=None):
     """A robot driving ``laps`` rounds of a rectangular corridor loop inside a room with pillars: true poses,
     drifting odometry (what ``rh.getOdom()`` would return, srslam.cpp:195) and one 1081-beam scan per step.
     Revisiting the start after one lap gives the front end loop-closure candidates."""
@@ -396,7 +396,7 @@ def make_trajectory(n_steps: int = 400, seed: int = 31, n_beams: int = LASER_BEA
     # centre line of the corridor: rectangle through the middle of the ring, traversed counter-clockwise
     cx0, cy0, cx1, cy1 = -7.25, -4.25, 7.25, 4.25
     per = 2 * ((cx1 - cx0) + (cy1 - cy0))
-    s = np.linspace(0.0, laps * per, T) % per
+    s = (start + np.linspace(0.0, laps * per, T)) % per           # start: metres along the centre line
     truth = np.empty((T, 3))
     for k, sk in enumerate(s):
         if sk < (cx1 - cx0):
@@ -422,11 +422,28 @@ def make_trajectory(n_steps: int = 400, seed: int = 31, n_beams: int = LASER_BEA
     ang0 = LASER_ANGLE_MIN + LASER_ANGLE_INC * np.arange(n_beams)
     scans = np.empty((T, n_beams), dtype=np.float32)
     for k in range(T):
-        r = _raycast_boxes(truth[k, 0], truth[k, 1], truth[k, 2] + ang0, boxes, LASER_MAX_RANGE)
+        bk = boxes if moving_boxes is None else boxes + [tuple(b) for b in moving_boxes[k]]   # (T, M, 4): obstacles per step
+        r = _raycast_boxes(truth[k, 0], truth[k, 1], truth[k, 2] + ang0, bk, LASER_MAX_RANGE)
         r = r + range_noise * normal(seed + 1, k, n_beams)
         scans[k] = np.clip(r, 0.05, LASER_MAX_RANGE * 2).astype(np.float32)
     return dict(truth=truth, odom=odom, scans=scans, angle_min=LASER_ANGLE_MIN, angle_inc=LASER_ANGLE_INC,
                 max_range=LASER_MAX_RANGE, n_beams=n_beams)
+
+
+def make_robot_team(n_robots: int = 2, n_steps: int = 120, laps: float = 0.3, gap: float = 3.0, seed: int = 31,
+                    body: float = 0.0, **kw):
+    """``n_robots`` robots in the world of ``make_trajectory`` driving the same corridor loop ``gap`` metres apart
+    (robot r starts r * gap metres ahead of robot 0), each with its own odometry drift and range noise: neighbours stay
+    within the simulated communication range (5 m, graph_comm.h:47) and see overlapping parts of the room, robots two
+    or more places apart do not talk once ``gap`` > 2.5 m (BASELINE config C4: cg_mrslam, sim modality)."""
+    team = [make_trajectory(n_steps, seed=seed + 101 * r, laps=laps, start=gap * r, **kw) for r in range(n_robots)]
+    if body > 0:          # the robots see each other: a square of side ``body`` at every other robot's true position
+        h = body / 2
+        for r in range(n_robots):
+            others = np.stack([np.stack([team[q]["truth"][:, 0] - h, team[q]["truth"][:, 1] - h, team[q]["truth"][:, 0] + h,
+                                         team[q]["truth"][:, 1] + h], axis=1) for q in range(n_robots) if q != r], axis=1)
+            team[r] = make_trajectory(n_steps, seed=seed + 101 * r, laps=laps, start=gap * r, moving_boxes=others, **kw)
+    return team
 
 
 def make_lattice_graph(n: int = 60, seed: int = 5, spacing: float = 1.0):

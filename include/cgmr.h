@@ -384,6 +384,15 @@ int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out);
 /* the same through host memory (gloo; CPU tests on a graph without a device) */
 int cgmr_graph_pack_host(cgmr_graph* g, void* send_out);
 int cgmr_graph_ingest_host(cgmr_graph* g, const void* recv, int32_t* n_edges_out);
+/* One peer's share of the round message as the reference's CondensedGraphMessage carries it
+ * (MRGraphSLAM::constructCondensedGraphMessage, src/mrslam/mr_graph_slam.cpp:607-670): edges44_out receives
+ * {int32 from, to; float est[3]; float info[6]} records.  Returns 1 = there is a message, 0 = nothing to send, < 0 error. */
+int cgmr_graph_message_for(cgmr_graph* g, int peer, int cap_edges, void* edges44_out, int32_t* n_edges_out, int cap_closures,
+                           int32_t* closure_ids_out, int32_t* n_closures_out);
+/* MRGraphSLAM::addInterRobotData(CondensedGraphMessage*) (src/mrslam/mr_graph_slam.cpp:331-395) for one message from
+ * `sender`: requests -> out-closures + the condensed graph for `sender` rebuilt; edges replace the previous set. */
+int cgmr_graph_message_from(cgmr_graph* g, int sender, int n_edges, const void* edges44, int n_closures,
+                            const int32_t* closure_ids, int32_t* n_accepted_out);
 /* the edges currently held from `peer`: returns their count; outputs nullable */
 int cgmr_graph_received_edges(cgmr_graph* g, int peer, int cap, int32_t* from_ids_out, int32_t* to_ids_out, double* meas_out,
                               double* info_upper_out);

@@ -296,6 +296,30 @@ class RefRobotGraph:
             n[s] = self.buf.ingest_from(s, edges, clos)
         return n
 
+    def closures(self, peer, which="out"):
+        d = self.buf.out_closures if which == "out" else self.buf.in_closures
+        return np.asarray(d.get(peer, np.zeros(0, dtype=np.int64)), dtype=np.int32)
+
+    def message_for(self, peer):
+        """constructCondensedGraphMessage (mr_graph_slam.cpp:607-670)."""
+        from cg_mrslam_amd.messages import CondensedGraphMessage
+        b = self.buf
+        e = b.out_condensed.get(peer, np.zeros(0, dtype=EDGE_DTYPE))
+        c = b.in_closures.get(peer)
+        if not len(e) and (c is None or not len(c)):
+            return None
+        return CondensedGraphMessage(self.robot, e.copy(), np.zeros(0, dtype=np.int32) if c is None else c.astype(np.int32))
+
+    def message_from(self, msg):
+        """addInterRobotData(CondensedGraphMessage*) (mr_graph_slam.cpp:331-395)."""
+        b = self.buf
+        clos = np.asarray(msg.closures, dtype=np.int64)
+        known = (b._index_of_ids(clos) >= 0).any() if len(clos) else False
+        n = b.ingest_from(msg.robotId, np.asarray(msg.edges, dtype=EDGE_DTYPE), clos)
+        if known:
+            self.computeCondensedGraph(msg.robotId)
+        return n
+
     def received_edges(self, peer):
         g, b = self.pg, self.buf
         m = b.in_edge_src == peer
