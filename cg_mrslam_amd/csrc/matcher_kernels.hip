@@ -48,14 +48,16 @@ constexpr int MAXBINS = 128;                  // close matching: 0.6 m / 0.5 m b
 constexpr int MAXTHETA = kMatchMaxTheta;
 
 struct Smem {
+  // the directory comes first: its byte addresses then fit the 16-bit field of the fast search path's list entries
+  uint16_t dir[kMatchMaxDir];                // tile directory: 0xFFFF = untouched (all cells = fill)
   uint32_t tiles[NT_LDS * 16];               // 64-byte tiles, cell (x&7, y&7) at byte (x&7)*8 + (y&7)   (16-B aligned)
-  uint32_t plist[NTH][LISTCAP];              // per-angle point lists: int16 x | int16 y << 16           (16-B aligned)
+  uint32_t plist[NTH][LISTCAP];              // per-angle point lists (16-B aligned)
   unsigned long long bins[MAXBINS];          // (score bits << 32 | visit order), min = best, first seen
   double theta[MAXTHETA];
   uint8_t kernel[1024];
   int misc[16];
-  uint16_t dir[kMatchMaxDir];                // tile directory: 0xFFFF = untouched (all cells = fill)
 };
+static_assert((sizeof(uint16_t) * kMatchMaxDir) % 16 == 0, "tile pool must stay 16-byte aligned behind the directory");
 // block_scan_excl scratch (one int per thread + total): the last point list, idle whenever a scan runs
 __device__ __forceinline__ int* scan_scratch(Smem& S) { return reinterpret_cast<int*>(S.plist[NTH - 1]); }
 static_assert(LISTCAP >= 516, "scan scratch needs 516 ints");
@@ -86,6 +88,63 @@ __device__ __forceinline__ int clamp_med3(int x, int hi) {     // min(max(x, LO)
   const int lo = LO;
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
   return r;
+}
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2 lds_cu2;
+
+// Fast search path, one class of a per-angle point list (entries whose first search cell sits in the lower / upper half
+// of its 8-cell tile row: HI = 0 / 1).  Entry = px8 << 18 | sh << 16 | dir_addr:
+//   px8       x cell of the rotated point + first x offset of the window + 8 (guard band), 14 bits signed
+//   sh        (first y cell) & 3: byte shift inside the first 32-bit word
+//   dir_addr  LDS byte address of the directory entry of tile row 0, tile column (first y cell) >> 3
+// Everything that depends on the point's y only is resolved when the list is built (it is the same for every lane: the
+// 24 y offsets of a lane start at the window's first one); per lane remain the x clamp, the tile row, the four
+// directory / tile-row loads and six packed-byte adds.
+template <bool HI>
+__device__ __forceinline__ void gather_class(const uint32_t* list, int n, int half, int a18, int hi_clamp, uint32_t dw2,
+                                             uint32_t tiles_base, uint32_t (&part)[6], int (&acc)[24], int& npart,
+                                             int flush_iters) {
+  for (int q = 4 * half; q < n; q += 2 * PT) {
+    const uint4 pk4 = *reinterpret_cast<const uint4*>(&list[q]);
+    const uint32_t pk[PT] = {pk4.x, pk4.y, pk4.z, pk4.w};
+    uint32_t d[PT][4], rowoff[PT];
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+      int t = (int)pk[u] + a18;                                  // (px8 + a) << 18, the low 18 bits ride along
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(t), "s"(hi_clamp));       // x clamp into the guard band
+      const uint32_t tx1 = (uint32_t)t >> 21;                    // tile row + 1
+      rowoff[u] = (((uint32_t)t >> 18) & 7u) * 8u + tiles_base;  // row of the cell inside its tile
+      const uint32_t da = __umul24(tx1, dw2) + (pk[u] & 0xffffu);
+      const lds_vu16* dp = (const lds_vu16*)(size_t)da;
+      d[u][0] = dp[0]; d[u][1] = dp[1]; d[u][2] = dp[2]; d[u][3] = dp[3];
+    }
+    uint32_t D[PT][8];
+#pragma unroll
+    for (int u = 0; u < PT; u++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const u32x2 w = *(lds_cu2*)(size_t)(d[u][t] * 64u + rowoff[u]);
+        D[u][2 * t] = w.x;
+        D[u][2 * t + 1] = w.y;
+      }
+#pragma unroll
+    for (int u = 0; u < PT; u++) {
+      const uint32_t sh = (pk[u] >> 16) & 3u;
+#pragma unroll
+      for (int t = 0; t < 6; t++)
+        part[t] += __builtin_amdgcn_alignbyte(D[u][t + 1 + (HI ? 1 : 0)], D[u][t + (HI ? 1 : 0)], sh);
+    }
+    if (++npart == flush_iters) {
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[4 * t + c] += (part[t] >> (8 * c)) & 0xff;
+        part[t] = 0;
+      }
+      npart = 0;
+    }
+  }
 }
 
 // block-wide exclusive scan of one int per thread (any power-of-two block size <= 512); returns the exclusive prefix, total in *total
@@ -402,19 +461,25 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
     // a scan with more subsampled points than one list holds: half the wavefronts search, with two lists each
-    const bool wide = nq > LISTCAP - 2 * PT;
+    const bool wide = nq > LISTCAP - 4 * PT;
     const int nsearch = wide ? NTH / 2 : NTH;
     uint32_t* const pl = &S.plist[0][0] + (wide ? 2 * wave : wave) * LISTCAP;
+    const int lcap = wide ? 2 * LISTCAP : LISTCAP;
+    // list entries of the fast path carry LDS addresses of the directory in 16 bits (gather_class)
+    const uint32_t lds_dir = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.dir);
+    const uint32_t lds_tiles = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.tiles);
+    const bool v2 = fast && nj <= 24 && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u;
     MPHASE(6);
     // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
     for (int tb = 0; tb < nth; tb += nsearch) {
       const int ti = (wave < nsearch) ? tb + wave : nth;
-      int k = 0;
+      int k = 0, k0p = 0, k1p = 0;
       if (ti < nth) {
         double c, s;
         portable_sincos(S.theta[ti], &s, &c);
         uint32_t prev = 0x7fff7fffu;       // (-10000,-10000) can never match: use an impossible packed value
         bool have_prev = false;
+        int k0 = 0, k1 = 0;
         for (int base = 0; base < nq; base += 64) {
           int q = base + lane;
           uint32_t packed = 0;
@@ -428,15 +493,39 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
           uint32_t left = __shfl_up(packed, 1, 64);
           if (lane == 0) left = prev;
           bool keep = valid && (!(lane == 0 && !have_prev) ? (packed != left) : true);
-          unsigned long long mask = __ballot(keep);
-          int pos = k + __popcll(mask & ((1ULL << lane) - 1ULL));
-          if (keep) pl[pos] = packed;
-          k += __popcll(mask);
+          const unsigned long long below = (1ULL << lane) - 1ULL;
+          if (v2) {
+            // resolve what depends on the point's y alone (all lanes search the same 24 y offsets) and split the list by
+            // the half of the 8-cell tile row the first cell falls into: class 0 grows from the front, class 1 from the back
+            const int cy0 = clamp_med3<-24>((int)(int16_t)(packed >> 16) + lo_y, P.ny);
+            const int o = cy0 & 7;
+            const int px8 = min(max((int)(int16_t)(packed & 0xffff) + lo_x + 8, -8000), 8000);
+            const uint32_t entry = ((uint32_t)px8 << 18) | ((uint32_t)(o & 3) << 16) | (lds_dir + 2u * (uint32_t)((cy0 >> 3) + 3));
+            const bool c1 = keep && o >= 4, c0 = keep && o < 4;
+            const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+            if (c0) pl[k0 + __popcll(m0 & below)] = entry;
+            if (c1) pl[lcap - 1 - (k1 + __popcll(m1 & below))] = entry;
+            k0 += __popcll(m0);
+            k1 += __popcll(m1);
+          } else {
+            unsigned long long mask = __ballot(keep);
+            int pos = k + __popcll(mask & below);
+            if (keep) pl[pos] = packed;
+            k += __popcll(mask);
+          }
           int lastv = min(63, nq - base - 1);
           prev = __shfl(packed, lastv, 64);
           have_prev = true;
         }
-        if (lane < 2 * PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
+        if (v2) {
+          // pad both classes to whole iterations (8 entries) with a point far to the left: clamped into the guard band
+          const uint32_t null_entry = ((uint32_t)(-8000) << 18) | (lds_dir + 6u);
+          k0p = (k0 + 2 * PT - 1) & ~(2 * PT - 1);
+          k1p = (k1 + 2 * PT - 1) & ~(2 * PT - 1);
+          if (lane < k0p - k0) pl[k0 + lane] = null_entry;
+          if (lane < k1p - k1) pl[lcap - 1 - (k1 + lane)] = null_entry;
+          k = k0 + k1;
+        } else if (lane < 2 * PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
       }
       __builtin_amdgcn_wave_barrier();
       if (ti < nth && fast) {
@@ -463,6 +552,11 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 #pragma unroll
           for (int c = 0; c < 24; c++) acc[c] = 0;
           int npart = 0;
+          if (v2) {
+            // a = job (one segment): the lane's x offset rides in the list entries' px8 field
+            gather_class<false>(pl, k0p, half, a << 18, ((P.nx + 15) << 18) | 0x3ffff, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
+            gather_class<true>(pl + lcap - k1p, k1p, half, a << 18, ((P.nx + 15) << 18) | 0x3ffff, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
+          } else
           for (int q = 4 * half; q < k; q += 2 * PT) {
             const uint4 pk4 = *reinterpret_cast<const uint4*>(&pl[q]);
             const uint32_t pk[PT] = {pk4.x, pk4.y, pk4.z, pk4.w};
