@@ -338,34 +338,69 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     // sort keys live in the (not yet used) tile pool: 2048 x u64
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(S.tiles);
     const double ires = 1. / P.sub_res;
-    for (int i = tid; i < 2048; i += CB_THREADS) {
-      unsigned long long key = ~0ULL;
+    // bitonic sort of 2048 keys in registers: lane l of wavefront w holds keys 256 w + 64 u + l (u = 0..3).  Exchanges at
+    // distance 64 / 128 pair two registers of a lane, smaller distances go through the cross-lane network, and only the
+    // six exchanges at distance 256 / 512 / 1024 cross wavefronts (through LDS, with workgroup barriers).
+    static_assert(CB_THREADS == 512, "the sort's ownership map assumes 8 wavefronts x 256 keys");
+    unsigned long long key[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = wave * 256 + u * 64 + lane;
+      key[u] = ~0ULL;
       if (i < B) {
         double r = (double)ranges_qry[(size_t)pair * B + i];
         if (r < P.max_range && r > P.min_range) {
           double x = beam_cos[i] * r, y = beam_sin[i] * r;
           qraw[2 * i] = x; qraw[2 * i + 1] = y;
           int kx = (int)(ires * x), ky = (int)(ires * y);
-          key = ((unsigned long long)(unsigned)(kx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(ky + (1 << 20)) << 21) |
-                (unsigned long long)i;
+          key[u] = ((unsigned long long)(unsigned)(kx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(ky + (1 << 20)) << 21) |
+                   (unsigned long long)i;
         }
       }
-      keys[i] = key;
     }
-    __syncthreads();
     for (int k = 2; k <= 2048; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < 2048; i += CB_THREADS) {
-          int l = i ^ j;
-          if (l > i) {
-            unsigned long long a = keys[i], b = keys[l];
-            bool up = ((i & k) == 0);
-            if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+        if (j >= 256) {
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 4; u++) keys[wave * 256 + u * 64 + lane] = key[u];
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = wave * 256 + u * 64 + lane;
+            const unsigned long long other = keys[i ^ j];
+            const bool keep_min = ((i & j) == 0) == ((i & k) == 0);      // the lower index keeps the minimum in an ascending run
+            key[u] = keep_min ? (other < key[u] ? other : key[u]) : (other > key[u] ? other : key[u]);
+          }
+        } else if (j >= 64) {
+          const int du = j >> 6;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int v = u ^ du;
+            if (v > u) {
+              const int i = wave * 256 + u * 64 + lane;
+              const unsigned long long a = key[u], b = key[v];
+              const bool up = (i & k) == 0;
+              const bool swap = (a > b) == up;
+              key[u] = swap ? b : a;
+              key[v] = swap ? a : b;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = wave * 256 + u * 64 + lane;
+            const unsigned long long other = __shfl_xor(key[u], j, 64);
+            const bool keep_min = ((lane & j) == 0) == ((i & k) == 0);
+            key[u] = keep_min ? (other < key[u] ? other : key[u]) : (other > key[u] ? other : key[u]);
           }
         }
-        __syncthreads();
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) keys[wave * 256 + u * 64 + lane] = key[u];
+    __syncthreads();
     MPHASE(1);
     // bucket leaders: sorted position i starts a bucket if its (kx,ky) differs from position i-1
     int nlead = 0;
