@@ -99,49 +99,66 @@ typedef __attribute__((address_space(3))) const u32x2 lds_cu2;
 //   sh        (first y cell) & 3: byte shift inside the first 32-bit word
 //   dir_addr  LDS byte address of the directory entry of tile row 0, tile column (first y cell) >> 3
 // Everything that depends on the point's y only is resolved when the list is built (it is the same for every lane: the
-// 24 y offsets of a lane start at the window's first one); per lane remain the x clamp, the tile row, the four
-// directory / tile-row loads and six packed-byte adds.
+// 24 y offsets of a lane start at the window's first one).  A lane owns two x rows of the window (offsets a, a + 1) and
+// one fifth of the points: 12 lanes cover the 24 rows for one point, 60 of the 64 lanes work (the earlier layout -- one
+// row per lane, two point subsets -- kept 48 busy).  Per point and row remain the x clamp, the tile row, four directory
+// and four tile-row loads and six packed-byte adds.
+constexpr int GRP = 5;                         // point subsets per wavefront
+constexpr int RPL = 2;                         // x rows per lane
+constexpr int PPI = 2;                         // points per lane and iteration
 template <bool HI>
-__device__ __forceinline__ void gather_class(const uint32_t* list, int n, int half, int a18, int hi_clamp, uint32_t dw2,
-                                             uint32_t tiles_base, uint32_t (&part)[6], int (&acc)[24], int& npart,
+__device__ __forceinline__ void gather_rows2(const uint32_t* list, int n, int grp, int a18, int hi_clamp, uint32_t dw2,
+                                             uint32_t tiles_base, uint32_t (&part)[RPL][6], int (&acc)[RPL][24], int& npart,
                                              int flush_iters) {
-  for (int q = 4 * half; q < n; q += 2 * PT) {
-    const uint4 pk4 = *reinterpret_cast<const uint4*>(&list[q]);
-    const uint32_t pk[PT] = {pk4.x, pk4.y, pk4.z, pk4.w};
-    uint32_t d[PT][4], rowoff[PT];
+  for (int q = PPI * grp; q < n; q += PPI * GRP) {
+    const uint2 pk2 = *reinterpret_cast<const uint2*>(&list[q]);
+    const uint32_t pk[PPI] = {pk2.x, pk2.y};
+    uint32_t d[PPI][RPL][4], rowoff[PPI][RPL];
 #pragma unroll
-    for (int u = 0; u < PT; u++) {
-      int t = (int)pk[u] + a18;                                  // (px8 + a) << 18, the low 18 bits ride along
-      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(t), "s"(hi_clamp));       // x clamp into the guard band
-      const uint32_t tx1 = (uint32_t)t >> 21;                    // tile row + 1
-      rowoff[u] = (((uint32_t)t >> 18) & 7u) * 8u + tiles_base;  // row of the cell inside its tile
-      const uint32_t da = __umul24(tx1, dw2) + (pk[u] & 0xffffu);
-      const lds_vu16* dp = (const lds_vu16*)(size_t)da;
-      d[u][0] = dp[0]; d[u][1] = dp[1]; d[u][2] = dp[2]; d[u][3] = dp[3];
-    }
-    uint32_t D[PT][8];
+    for (int u = 0; u < PPI; u++) {
+      const uint32_t da0 = pk[u] & 0xffffu;
 #pragma unroll
-    for (int u = 0; u < PT; u++)
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const u32x2 w = *(lds_cu2*)(size_t)(d[u][t] * 64u + rowoff[u]);
-        D[u][2 * t] = w.x;
-        D[u][2 * t + 1] = w.y;
+      for (int w = 0; w < RPL; w++) {
+        int t = (int)pk[u] + a18 + (w << 18);                      // (px8 + a + w) << 18, the low 18 bits ride along
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(t), "s"(hi_clamp));       // x clamp into the guard band
+        const uint32_t tx1 = (uint32_t)t >> 21;                    // tile row + 1
+        uint32_t r8;
+        asm("v_bfe_u32 %0, %1, 18, 3" : "=v"(r8) : "v"(t));        // (cx8 & 7): row of the cell inside its tile
+        rowoff[u][w] = r8 * 8u + tiles_base;
+        const uint32_t da = __umul24(tx1, dw2) + da0;
+        const lds_vu16* dp = (const lds_vu16*)(size_t)da;
+        d[u][w][0] = dp[0]; d[u][w][1] = dp[1]; d[u][w][2] = dp[2]; d[u][w][3] = dp[3];
       }
+    }
+    uint32_t D[PPI][RPL][8];
 #pragma unroll
-    for (int u = 0; u < PT; u++) {
+    for (int u = 0; u < PPI; u++)
+#pragma unroll
+      for (int w = 0; w < RPL; w++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const u32x2 v = *(lds_cu2*)(size_t)(d[u][w][t] * 64u + rowoff[u][w]);
+          D[u][w][2 * t] = v.x;
+          D[u][w][2 * t + 1] = v.y;
+        }
+#pragma unroll
+    for (int u = 0; u < PPI; u++) {
       const uint32_t sh = (pk[u] >> 16) & 3u;
 #pragma unroll
-      for (int t = 0; t < 6; t++)
-        part[t] += __builtin_amdgcn_alignbyte(D[u][t + 1 + (HI ? 1 : 0)], D[u][t + (HI ? 1 : 0)], sh);
+      for (int w = 0; w < RPL; w++)
+#pragma unroll
+        for (int t = 0; t < 6; t++)
+          part[w][t] += __builtin_amdgcn_alignbyte(D[u][w][t + 1 + (HI ? 1 : 0)], D[u][w][t + (HI ? 1 : 0)], sh);
     }
     if (++npart == flush_iters) {
 #pragma unroll
-      for (int t = 0; t < 6; t++) {
+      for (int w = 0; w < RPL; w++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc[4 * t + c] += (part[t] >> (8 * c)) & 0xff;
-        part[t] = 0;
-      }
+        for (int t = 0; t < 6; t++) {
+#pragma unroll
+          for (int c = 0; c < 4; c++) acc[w][4 * t + c] += (part[w][t] >> (8 * c)) & 0xff;
+          part[w][t] = 0;
+        }
       npart = 0;
     }
   }
@@ -496,14 +513,14 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
     // a scan with more subsampled points than one list holds: half the wavefronts search, with two lists each
-    const bool wide = nq > LISTCAP - 4 * PT;
+    const bool wide = nq > LISTCAP - 2 * PPI * GRP;
     const int nsearch = wide ? NTH / 2 : NTH;
     uint32_t* const pl = &S.plist[0][0] + (wide ? 2 * wave : wave) * LISTCAP;
     const int lcap = wide ? 2 * LISTCAP : LISTCAP;
     // list entries of the fast path carry LDS addresses of the directory in 16 bits (gather_class)
     const uint32_t lds_dir = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.dir);
     const uint32_t lds_tiles = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.tiles);
-    const bool v2 = fast && nj <= 24 && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u;
+    const bool v2 = fast && nj <= 24 && ni <= 12 * RPL && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u && K2 * PPI <= 255;
     MPHASE(6);
     // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
     for (int tb = 0; tb < nth; tb += nsearch) {
@@ -553,18 +570,75 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
           have_prev = true;
         }
         if (v2) {
-          // pad both classes to whole iterations (8 entries) with a point far to the left: clamped into the guard band
+          // pad both classes to whole iterations (10 entries) with a point far to the left: clamped into the guard band
           const uint32_t null_entry = ((uint32_t)(-8000) << 18) | (lds_dir + 6u);
-          k0p = (k0 + 2 * PT - 1) & ~(2 * PT - 1);
-          k1p = (k1 + 2 * PT - 1) & ~(2 * PT - 1);
+          k0p = (k0 + PPI * GRP - 1) / (PPI * GRP) * (PPI * GRP);
+          k1p = (k1 + PPI * GRP - 1) / (PPI * GRP) * (PPI * GRP);
           if (lane < k0p - k0) pl[k0 + lane] = null_entry;
           if (lane < k1p - k1) pl[lcap - 1 - (k1 + lane)] = null_entry;
           k = k0 + k1;
         } else if (lane < 2 * PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
       }
       __builtin_amdgcn_wave_barrier();
-      if (ti < nth && fast) {
-        // ---- fast path: lane = (half h of the wavefront, x-row a, segment of 24 consecutive y offsets).
+      if (ti < nth && v2) {
+        // ---- fast path, window of at most 24 x 24 offsets: lane = (point subset g of 5, x rows 2r and 2r + 1), see gather_rows2
+        const int grp = lane / 12, r = lane - 12 * grp;
+        const bool act = lane < 12 * GRP;
+        uint32_t part[RPL][6];
+        int acc[RPL][24];
+#pragma unroll
+        for (int w = 0; w < RPL; w++) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) part[w][c] = 0;
+#pragma unroll
+          for (int c = 0; c < 24; c++) acc[w][c] = 0;
+        }
+        int npart = 0;
+        const int flush_iters = max(1, (255 / K2) / PPI);    // packed-byte partial sums cannot overflow before this
+        const int hi_clamp = ((P.nx + 15) << 18) | 0x3ffff;
+        gather_rows2<false>(pl, act ? k0p : 0, grp, (RPL * r) << 18, hi_clamp, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
+        gather_rows2<true>(pl + lcap - k1p, act ? k1p : 0, grp, (RPL * r) << 18, hi_clamp, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
+#pragma unroll
+        for (int w = 0; w < RPL; w++)
+#pragma unroll
+          for (int t = 0; t < 6; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[w][4 * t + c] += (part[w][t] >> (8 * c)) & 0xff;
+        // the five subsets' sums meet in LDS: the wavefront's list is not needed any more, its first 576 words take the
+        // totals of the 24 x 24 offsets (row-major, 24 per row)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int* totals = reinterpret_cast<int*>(pl);
+        for (int q = lane; q < 24 * 24; q += 64) totals[q] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+#pragma unroll
+          for (int w = 0; w < RPL; w++)
+#pragma unroll
+            for (int c = 0; c < 24; c++) atomicAdd(&totals[(RPL * r + w) * 24 + c], acc[w][c]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < CAND_U; u++) {
+          const int cidx = u * 64 + lane;
+          if (cidx >= ncand) continue;
+          const int a = cidx / nj, b = cidx - a * nj;
+          float dsum = (float)totals[a * 24 + b] * ikscale;
+          dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
+          if ((double)dsum < P.max_score) {
+            float wx = P.ll_x + (P.res * (float)(lo_x + a));
+            float wyy = P.ll_y + (P.res * (float)(lo_y + b));
+            int bx = (int)((double)wx / P.dx) - bx0, by = (int)((double)wyy / P.dy) - by0;
+            int bt = (int)(S.theta[ti] / P.dth) - bt0;
+            unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
+                                     (unsigned long long)(unsigned)(ti * ncand + cidx);
+            atomicMin(&S.bins[(bx * nby + by) * nbt + bt], key);
+          }
+        }
+      } else if (ti < nth && fast) {
+        // ---- fast path, any window: lane = (half h of the wavefront, x-row a, segment of 24 consecutive y offsets).
         // Both halves work on the same 32 (row, segment) jobs; half h takes points 8i+4h .. 8i+4h+3 of the list,
         // the two partial sums are added at the end.  Per point a lane fetches the 4 tile rows that hold its
         // 24 (+7 alignment) cells and adds them as packed bytes.
@@ -587,11 +661,6 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 #pragma unroll
           for (int c = 0; c < 24; c++) acc[c] = 0;
           int npart = 0;
-          if (v2) {
-            // a = job (one segment): the lane's x offset rides in the list entries' px8 field
-            gather_class<false>(pl, k0p, half, a << 18, ((P.nx + 15) << 18) | 0x3ffff, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
-            gather_class<true>(pl + lcap - k1p, k1p, half, a << 18, ((P.nx + 15) << 18) | 0x3ffff, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
-          } else
           for (int q = 4 * half; q < k; q += 2 * PT) {
             const uint4 pk4 = *reinterpret_cast<const uint4*>(&pl[q]);
             const uint32_t pk[PT] = {pk4.x, pk4.y, pk4.z, pk4.w};
