@@ -46,6 +46,7 @@ constexpr int PT = 4;                        // points gathered per inner iterat
 constexpr int CAND_U = 9;                    // candidates per lane per block (64*9 = 576 = 24x24)
 constexpr int MAXBINS = 128;                  // close matching: 0.6 m / 0.5 m bins x 0.4 rad / 0.2 rad -> at most 27
 constexpr int MAXTHETA = kMatchMaxTheta;
+constexpr int kKcolOff = 320;                // Smem::kernel: the kdim x kdim table at 0 (<= 289 bytes), 17 padded columns behind it
 
 struct Smem {
   // the directory comes first: its byte addresses then fit the 16-bit field of the fast search path's list entries
@@ -218,6 +219,14 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
   const int ctr = (P.kdim - 1) / 2;
   for (int q = tid; q < (ndir + 1) / 2; q += NTHR) reinterpret_cast<uint32_t*>(S.dir)[q] = 0;
+  // kernel columns for the stamping below: column ki as 32 bytes = 4 x 0xff, the kdim values along y, 0xff padding, so
+  // that the 32-bit word that covers four consecutive cells of a stamp is two aligned words and a byte alignment
+  const bool kcols = P.kdim <= 17;
+  if (kcols)
+    for (int q = tid; q < P.kdim * 32; q += NTHR) {
+      const int ki = q >> 5, b = q & 31, dy = b - 4;
+      S.kernel[kKcolOff + q] = (dy >= 0 && dy < P.kdim) ? S.kernel[dy * P.kdim + ki] : (uint8_t)0xff;
+    }
   __syncthreads();
   for (int i = tid; i < n; i += NTHR) {
     uint32_t packed = rcell[i];
@@ -242,11 +251,12 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     // point at the all-fill tile, cells outside the grid are redirected to the all-zero tile.
     const bool fastp = allow_fast && (ntile + 2 <= NT_LDS) && ((P.nx & 7) == 0) && ((P.ny & 7) == 0) &&
                        P.x_steps == 1 && P.y_steps == 1 && K2 * PT <= 255;
+    int row = b0 / DW, col = b0 - row * DW;
     for (int q = b0; q < b1; q++) {
-      const int row = q / DW, col = q - row * DW;
       const bool guard = row == 0 || row == ntx + 1 || col < 3 || col >= nty + 3;
       if (S.dir[q]) S.dir[q] = (uint16_t)base++;
       else S.dir[q] = fastp ? (uint16_t)(guard ? ntile + 1 : ntile) : (uint16_t)0xFFFF;
+      if (++col == DW) { col = 0; row++; }
     }
     if (tid == 0) { S.misc[0] = ntile; S.misc[12] = fastp ? 1 : 0; }
     if (ntile > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
@@ -262,9 +272,18 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   // stamp: work item = (reference point, kernel row); byte-min through compare-and-swap on 32-bit words.
   // Neighbouring beams stamp overlapping cells; spread concurrently processed items over far-apart points
   // (stride 67 modulo an odd count) so that the compare-and-swap rarely has to retry.
-  const int np = n | 1;
-  for (int wi = tid; wi < np * P.kdim; wi += NTHR) {
-    int ki = wi / np, p = (int)(((long long)(wi - ki * np) * 67) % np);
+  int np = n | 1;
+  while (np % 67 == 0) np += 2;                                  // the stride must be coprime to the count
+  const float inv_np = 1.0f / (float)np;
+  const int step_k = NTHR / np, step_r = NTHR - step_k * np;
+  int ki = tid / np, rem = tid - ki * np;                        // work item wi = ki * np + rem, advanced without divisions
+  for (int wi = tid; wi < np * P.kdim; wi += NTHR, ki += step_k, rem += step_r) {
+    if (rem >= np) { rem -= np; ki++; }
+    // p = (rem * 67) % np: the product stays below 2^24, so a float quotient is off by at most one
+    const int x67 = rem * 67;
+    int p = x67 - (int)((float)x67 * inv_np) * np;
+    if (p < 0) p += np;
+    if (p >= np) p -= np;
     if (p >= n) continue;
     uint32_t packed = rcell[p];
     if (packed == 0x80008000u) continue;
@@ -274,6 +293,30 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     if (x < 0 || x >= P.nx) continue;
     int y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
     if (y0 > y1) continue;
+    if (kcols && ry - ctr >= 0 && ry + ctr < P.ny) {
+      // the whole column lies inside the grid: its words come from the padded kernel column
+      const uint32_t* kc = reinterpret_cast<const uint32_t*>(&S.kernel[kKcolOff + ki * 32]);
+      const uint4 ka = *reinterpret_cast<const uint4*>(kc), kb = *reinterpret_cast<const uint4*>(kc + 4);
+      const uint32_t W[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+      const int phi = y0 & 3, wy0 = y0 & ~3;
+      const int nw = ((y1 - wy0) >> 2) + 1;                       // at most 5 for a 17-cell column
+      const uint32_t sft = (uint32_t)(4 - phi) & 3u;
+      const bool whole = phi == 0;                                // byte offset 4: the next word as it is
+      const int drow = ((x >> 3) + 1) * DW + 3, wx = (x & 7) * 2;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        if (k >= nw) break;
+        const uint32_t lo = whole ? W[k + 1] : W[k], hi = whole ? W[min(k + 2, 7)] : W[k + 1];
+        const uint32_t kv = __builtin_amdgcn_alignbyte(hi, lo, sft);
+        if (kv == 0xffffffffu) continue;
+        const int wy = wy0 + 4 * k;
+        const int d = S.dir[drow + (wy >> 3)];
+        const int woff = wx + ((wy & 7) >> 2);
+        if (d < NT_LDS) stamp_word(&S.tiles[d * 16 + woff], kv);
+        else stamp_word(&gtiles[(size_t)(d - NT_LDS) * 16 + woff], kv);
+      }
+      continue;
+    }
     for (int wy = y0 & ~3; wy <= y1; wy += 4) {        // aligned 4-cell words along y
       uint32_t kv = 0;
 #pragma unroll
@@ -620,12 +663,27 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the acceptance test dsum(total) < maxScore is monotone in the integer total: find the smallest total that
+        // fails it once per angle (lanes try the totals around maxScore * k * kscale) and compare integers per candidate
+        int tfail;
+        {
+          const int guess = (int)(P.max_score * (double)k * (double)P.kscale);
+          const int tt = max(0, guess - 31 + lane);
+          float ds = (float)tt * ikscale;
+          ds = k ? (float)((double)ds / (double)k) : (float)(P.max_score + 1);
+          const unsigned long long fails = __ballot(!((double)ds < P.max_score));
+          // lanes are in ascending order of total: the first failing lane marks the threshold; none failing (or all)
+          // means the guess was off by more than the probed range -- then every candidate takes the exact test
+          tfail = (fails != 0 && (fails & 1ULL) == 0) ? max(0, guess - 31) + (__ffsll((long long)fails) - 1) : -1;
+        }
 #pragma unroll
         for (int u = 0; u < CAND_U; u++) {
           const int cidx = u * 64 + lane;
           if (cidx >= ncand) continue;
           const int a = cidx / nj, b = cidx - a * nj;
-          float dsum = (float)totals[a * 24 + b] * ikscale;
+          const int total = totals[a * 24 + b];
+          if (tfail >= 0 && total >= tfail) continue;
+          float dsum = (float)total * ikscale;
           dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
           if ((double)dsum < P.max_score) {
             float wx = P.ll_x + (P.res * (float)(lo_x + a));
