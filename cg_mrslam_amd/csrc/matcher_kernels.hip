@@ -418,6 +418,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         }
       }
     }
+    MPHASE(9);
     for (int k = 2; k <= 2048; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
         if (j >= 256) {

@@ -15,3 +15,4 @@ names = ["qry cartesian+sort", "subsample means", "ref cells+dir", "dir scan+til
 for i, n in enumerate(names):
     print(f"{n:22s} {o[i+1]-o[i]:>10d}")
 print("total", o[8]-o[0])
+print("  of the first phase: load + keys", o[9]-o[0], " sort", o[1]-o[9])
