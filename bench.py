@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--vertices", type=int, default=10000)
     ap.add_argument("--edges", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-team", action="store_true", help="skip the C4 leg (four robots of the cg_mrslam node on this GPU)")
     ap.add_argument("--match-pairs", type=int, default=1000000, help="distinct scan pairs of the matcher leg (0 = skip)")
     ap.add_argument("--c5-vertices", type=int, default=5000, help="vertices per robot of the exchange leg (N > 1)")
     ap.add_argument("--c5-edges", type=int, default=20000)
@@ -120,6 +121,42 @@ def maybe_spawn(args):
 
 
 # ----------------------------------------------------------------------------------------------- matcher leg (C3)
+def team_leg(ctx, n_robots=4, n_steps=90):
+    """C4: the cg_mrslam node in sim modality, four robots in one process on this GPU (each a device-resident robot
+    graph + the GPU matchers; inter-robot closures through batched global / verify matching, condensed graphs exchanged
+    as the reference's own messages).  Reported, not part of `value`."""
+    from cg_mrslam_amd import synth
+    from cg_mrslam_amd.condensed import RobotGraph
+    from cg_mrslam_amd.matcher import LCScanMatcher, ScanMatcher
+    from cg_mrslam_amd.mr_graph_slam import GraphCommSim, MRGraphSLAMDriver, run_cg_mrslam
+    team = synth.make_robot_team(n_robots, n_steps=n_steps, laps=0.21, gap=3.0, body=0.5)
+    la = (team[0]["n_beams"], team[0]["angle_min"], team[0]["angle_inc"], team[0]["max_range"])
+    slams = []
+    for r in range(n_robots):
+        s = MRGraphSLAMDriver(ctx, ScanMatcher(ctx, *la), LCScanMatcher(ctx, *la), RobotGraph(ctx, r, n_robots), r, n_robots,
+                              windowLoopClosure=5, minInliers=4)
+        s.setInterRobotClosureParams(0.15, 3, 5)
+        s.setDetectRobotInRange(True)
+        slams.append(s)
+    comm = GraphCommSim(slams)
+    t0 = time.perf_counter()
+    loops = run_cg_mrslam(slams, team, comm=comm, linearUpdate=0.5)
+    dt = time.perf_counter() - t0
+    kf = sum(lp.key_frames for lp in loops)
+    err = 0.0
+    for s, tr in zip(slams, team):
+        own = [q for q in range(s.g.n_vertices) if s.isMyVertex(q)]
+        tp = tr["truth"]
+        err = max(err, max(float(np.min(np.hypot(tp[:, 0] - p[0], tp[:, 1] - p[1]))) for p in s.g.poses[own]))
+    return {"workload": f"C4: cg_mrslam sim modality, {n_robots} robots x {n_steps} ticks in one process on one GPU (synthetic corridor world, "
+                        "robots 3 m apart, 5 m communication range, detectRobotInRange)",
+            "key_frames": kf, "seconds": round(dt, 3), "key_frames_per_s": round(kf / dt, 1),
+            "messages_delivered": comm.delivered, "bytes_sent": int(sum(x.bytes_sent for x in comm.senders)),
+            "inter_robot_edges": int(sum(s.edge_kind.count("mr") for s in slams)),
+            "condensed_edges_held": int(sum(s.edge_kind.count("cond") for s in slams)),
+            "max_distance_to_true_path_m": round(err, 4)}
+
+
 def matcher_leg(ctx, dev, args, with_cpu):
     """C3: batched closeScanMatching on synthetic 1081-beam scan pairs resident in HBM, all pairs distinct.  The first
     4096 are the numpy recipe's pairs (tests/golden/match_close4096.npz pins their results), the rest come from the
@@ -495,6 +532,7 @@ def main():
         "symbolic": {k: info[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")},
         "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},
         "roofline": roofline, "cpu_baseline": cpu, "matcher": matcher, "exchange": exchange,
+        "team": (team_leg(ctx) if world == 1 and not args.no_team else None),
     }
     if cpu:
         out["speedup_vs_cpu_1thread"] = round(out["value"] / cpu["value"], 2)

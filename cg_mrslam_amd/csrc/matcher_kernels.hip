@@ -100,7 +100,7 @@ typedef __attribute__((address_space(3))) const u32x2 lds_cu2;
 //   sh        (first y cell) & 3: byte shift inside the first 32-bit word
 //   dir_addr  LDS byte address of the directory entry of tile row 0, tile column (first y cell) >> 3
 // Everything that depends on the point's y only is resolved when the list is built (it is the same for every lane: the
-// 24 y offsets of a lane start at the window's first one).  A lane owns two x rows of the window (offsets a, a + 1) and
+// 24 y offsets of a lane start at the window's first one).  A lane owns two x rows of the window (offsets r, r + 12) and
 // one fifth of the points: 12 lanes cover the 24 rows for one point, 60 of the 64 lanes work (the earlier layout -- one
 // row per lane, two point subsets -- kept 48 busy).  Per point and row remain the x clamp, the tile row, four directory
 // and four tile-row loads and six packed-byte adds.
@@ -120,7 +120,7 @@ __device__ __forceinline__ void gather_rows2(const uint32_t* list, int n, int gr
       const uint32_t da0 = pk[u] & 0xffffu;
 #pragma unroll
       for (int w = 0; w < RPL; w++) {
-        int t = (int)pk[u] + a18 + (w << 18);                      // (px8 + a + w) << 18, the low 18 bits ride along
+        int t = (int)pk[u] + a18 + ((12 * w) << 18);               // (px8 + r + 12 w) << 18, the low 18 bits ride along
         asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(t), "s"(hi_clamp));       // x clamp into the guard band
         const uint32_t tx1 = (uint32_t)t >> 21;                    // tile row + 1
         uint32_t r8;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       }
       __builtin_amdgcn_wave_barrier();
       if (ti < nth && v2) {
-        // ---- fast path, window of at most 24 x 24 offsets: lane = (point subset g of 5, x rows 2r and 2r + 1), see gather_rows2
+        // ---- fast path, window of at most 24 x 24 offsets: lane = (point subset g of 5, x rows r and r + 12), see gather_rows2
         const int grp = lane / 12, r = lane - 12 * grp;
         const bool act = lane < 12 * GRP;
         uint32_t part[RPL][6];
@@ -640,8 +640,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         int npart = 0;
         const int flush_iters = max(1, (255 / K2) / PPI);    // packed-byte partial sums cannot overflow before this
         const int hi_clamp = ((P.nx + 15) << 18) | 0x3ffff;
-        gather_rows2<false>(pl, act ? k0p : 0, grp, (RPL * r) << 18, hi_clamp, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
-        gather_rows2<true>(pl + lcap - k1p, act ? k1p : 0, grp, (RPL * r) << 18, hi_clamp, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
+        gather_rows2<false>(pl, act ? k0p : 0, grp, r << 18, hi_clamp, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
+        gather_rows2<true>(pl + lcap - k1p, act ? k1p : 0, grp, r << 18, hi_clamp, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
 #pragma unroll
         for (int w = 0; w < RPL; w++)
 #pragma unroll
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 #pragma unroll
           for (int w = 0; w < RPL; w++)
 #pragma unroll
-            for (int c = 0; c < 24; c++) atomicAdd(&totals[(RPL * r + w) * 24 + c], acc[w][c]);
+            for (int c = 0; c < 24; c++) atomicAdd(&totals[(r + 12 * w) * 24 + c], acc[w][c]);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -7,7 +7,7 @@ O=$R/gpurun_out/prof_round
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/bench --output-format csv -- python $R/bench.py > $O/bench.log 2>&1
-tail -1 $O/bench.log > $O/bench_line.json
+grep "^{\"metric\"" $O/bench.log | tail -1 > $O/bench_line.json
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/gn_$n --output-format csv -- python $R/tools/gn_profile_run.py > $O/gn_$n.log 2>&1
