@@ -376,6 +376,23 @@ void parallel_for(int n, int nthreads, Fn&& fn, int min_n = 4096) {
   for (auto& j : jobs) HelperPool::wait(j);
 }
 
+}  // namespace
+
+// run task(0) .. task(n - 1) on the helper pool (the caller takes the last one); for the callers of analyze() that have
+// a few independent host-side jobs of their own
+void host_run_tasks(int n, const std::function<void(int)>& task) {
+  if (n <= 0) return;
+  std::vector<HelperPool::Job> jobs(n - 1);
+  for (int t = 0; t + 1 < n; t++) {
+    jobs[t].fn = [&task, t] { task(t); };
+    pool().run(jobs[t]);
+  }
+  task(n - 1);
+  for (auto& j : jobs) HelperPool::wait(j);
+}
+
+namespace {
+
 int host_threads() {
   static int n = [] {
     const char* e = getenv("CGMR_HOST_THREADS");

@@ -10,6 +10,7 @@
 // groups columns into dense "fronts" of at most CGMR_PANEL_W poses, and emits flat index
 // arrays that the HIP kernels consume without any pointer chasing.
 #pragma once
+#include <functional>
 #include <cstdint>
 #include <vector>
 
@@ -112,12 +113,16 @@ struct Symbolic {
   int max_ns = 0;
   double flops = 0;                    // factorisation flops (dense fronts)
   double t_order = 0, t_struct = 0;    // seconds spent in ordering / structure
+  double t_upload = 0;                 // ... and in staging + enqueueing the structure blob (set by the caller)
 };
 
 // Builds everything above.  Returns 0, or a negative error (-1 bad index).
 // `fixed` == nullptr: every vertex that has an edge gets a column (the solver's mode: fixed vertices are masked
 // numerically, so the analysis depends on the edge list only and is cached across calls with different fixed
 // sets); otherwise fixed vertices are eliminated structurally.
+// task(0) .. task(n - 1) on the analysis' helper threads (blocking)
+void host_run_tasks(int n, const std::function<void(int)>& task);
+
 int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S);
 
 }  // namespace cgmr
