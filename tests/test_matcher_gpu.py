@@ -83,6 +83,17 @@ def test_small_scans_and_single_pair(ctx, oracle):
     assert np.array_equal(got1[1][0], got[1][0])
 
 
+def test_beam_counts_divisible_by_the_stamping_stride(ctx, oracle):
+    """The rasteriser visits the reference beams with stride 67 modulo an odd count so that concurrent stamps rarely
+    overlap; a count that is a multiple of 67 (1005 beams = 15 x 67, and 1004 -> 1005) must not lose beams: the
+    permutation has to stay a bijection."""
+    for nb in (1005, 1004, 469):
+        sp = synth.make_scan_pairs(6, seed=300 + nb, n_beams=nb)
+        m = _matcher(ctx, sp)
+        got = m.closeScanMatching(sp["ranges_ref"], sp["ranges_qry"], sp["guess"])
+        _assert_same(got, _oracle(oracle, sp, sp["ranges_ref"], sp["ranges_qry"], sp["guess"]))
+
+
 def test_scattered_scans_take_the_overflow_paths(ctx, oracle):
     """Scans whose points do not lie on walls: (a) a reference scan that touches more tiles than the LDS pool holds
     (tiles spill to HBM, the pair takes the bounds-checked search), (b) a query scan with more subsampled points
