@@ -99,6 +99,43 @@ def test_ingest_replaces_previous_set_skips_unknown_and_keeps_on_empty():
     assert np.array_equal(a.closures(1, "out"), np.sort(ra.buf.out_closures[1]))
 
 
+def test_one_peer_messages_equal_the_all_gather_path():
+    """``cgmr_graph_message_for`` / ``cgmr_graph_message_from`` (constructCondensedGraphMessage / addInterRobotData for
+    ONE CondensedGraphMessage, mr_graph_slam.cpp:607-670, 331-395) move exactly what the round buffer moves, as the
+    reference's own byte string."""
+    from cg_mrslam_amd.messages import CondensedGraphMessage, from_bytes
+    R = synth.make_multi_robot(2, 300, 800, seed=6)
+    a, b = RobotGraph(None, 0, 2), RobotGraph(None, 1, 2)
+    ra, rb = RefRobotGraph(None, 0, 2), RefRobotGraph(None, 1, 2)
+    for g, src in ((a, R[0]), (b, R[1]), (ra, R[0]), (rb, R[1])):
+        _fill(g, src)
+    foreign = np.sort(R[0]["in_closures"][1])
+    e, i = _fake(2, 11)
+    b.set_condensed(0, foreign[0], foreign[1:3], e, i)
+    w = np.zeros(2, dtype=EDGE_DTYPE)
+    w["from"], w["to"], w["est"], w["info"] = foreign[0], foreign[1:3], e, i
+    rb.buf.out_condensed[0] = w
+    msg, msg_ref = b.message_for(0), rb.message_for(0)
+    assert isinstance(msg, CondensedGraphMessage) and msg.robotId == 1
+    assert msg.to_bytes() == msg_ref.to_bytes()                  # edges for robot 0 + the ids robot 1 asks robot 0 for
+    assert np.array_equal(msg.closures, np.sort(R[1]["in_closures"][0]))
+    got = a.message_from(from_bytes(msg.to_bytes()))
+    want = ra.buf.ingest_from(1, msg_ref.edges, msg_ref.closures)      # (the restatement's compute step needs a solver)
+    assert got == want == 2
+    f, t, m, ii = a.received_edges(1)
+    fr, tr, mr, ir = ra.received_edges(1)
+    assert np.array_equal(f, fr) and np.array_equal(t, tr) and np.array_equal(m, mr) and np.array_equal(ii, ir)
+    assert np.array_equal(a.closures(1, "out"), np.sort(ra.buf.out_closures[1]))
+    # nothing for a robot that neither asked nor is asked
+    c = RobotGraph(None, 0, 3)
+    c.add_vertices([0, 1], np.zeros((2, 3)), [1, 0])
+    assert c.message_for(2) is None
+    # a message over the capacity, from oneself or from an unknown robot is refused
+    for bad in (CondensedGraphMessage(0), CondensedGraphMessage(5), CondensedGraphMessage(1, np.zeros(200, dtype=EDGE_DTYPE))):
+        with pytest.raises(Exception):
+            a.message_from(bad)
+
+
 def test_capacity_overflow_is_an_error_not_a_truncation():
     g = RobotGraph(None, 0, 2, cap_edges=4)
     g.add_vertices(np.arange(10), np.zeros((10, 3)))
