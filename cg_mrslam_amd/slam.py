@@ -223,6 +223,7 @@ class GraphSLAMDriver(GraphSLAM):
         self.windowLoopClosure, self.maxScore = windowLoopClosure, maxScore
         self.inlierThreshold, self.minInliers = inlierThreshold, minInliers
         self.lasers = {}            # vertex index -> float32 ranges
+        self._id_index = {}         # vertex id -> index (g2o's VertexIDMap lookup)
         self._running_vertex_id = 0
         self._running_edge_id = 0
         self.edge_ids = []
@@ -236,8 +237,7 @@ class GraphSLAMDriver(GraphSLAM):
 
     # ------------------------------------------------------------------ graph bookkeeping
     def _index_of_id(self, vid):
-        hit = np.flatnonzero(self.g.ids == vid)
-        return int(hit[0]) if len(hit) else None
+        return self._id_index.get(int(vid))
 
     def _add_vertex(self, vid, pose, fixed, ranges):
         g = self.g
@@ -245,6 +245,7 @@ class GraphSLAMDriver(GraphSLAM):
         g.poses = np.vstack([g.poses, np.asarray(pose, dtype=np.float64).reshape(1, 3)])
         g.fixed = np.append(g.fixed, np.uint8(1 if fixed else 0))
         idx = g.n_vertices - 1
+        self._id_index[int(vid)] = idx
         self.lasers[idx] = np.ascontiguousarray(ranges, dtype=np.float32)
         return idx
 
