@@ -194,6 +194,36 @@ def test_three_robots_only_neighbours_talk(oracle):
     assert any(l[0] == "combo" and l[1] == 1 for l in slams[0].log) and any(l[0] == "combo" and l[1] == 2 for l in slams[1].log)
 
 
+def test_robots_drifting_out_of_range_stop_talking_and_windows_expire(oracle):
+    """Robot 1 starts 1 m ahead of robot 0 and drives 2.4 times as fast: while they are within SIM_COMM_RANGE every new
+    vertex travels as a ComboMessage, afterwards nothing does (graph_comm.cpp:126-155); vertices that never matched age
+    out of the unmatched-vertex window (mr_closure_buffer.cpp:93-118) and their scans are dropped."""
+    n = 120
+    team = [synth.make_trajectory(n, seed=31, laps=0.15, start=0.0), synth.make_trajectory(n, seed=132, laps=0.36, start=1.0)]
+    la = (team[0]["n_beams"], team[0]["angle_min"], team[0]["angle_inc"], team[0]["max_range"])
+    slams = [_oracle_slam(r, 2, la) for r in range(2)]
+    comm = GraphCommSim(slams)
+    gaps = [float(np.hypot(*(team[0]["truth"][k][:2] - team[1]["truth"][k][:2]))) for k in range(n)]
+    last_in_range = max(k for k in range(n) if gaps[k] < 5.0)
+    assert 10 < last_in_range < n - 30                      # the scenario really separates the robots well before the end
+    delivered = []
+    from cg_mrslam_amd.mr_graph_slam import RobotLoop
+    loops = [RobotLoop(s, tr["odom"], tr["scans"], tr["truth"][0], 0.5) for s, tr in zip(slams, team)]
+    for k in range(1, n):
+        for lp in loops:
+            lp.tick(k)
+        comm.cycle([tr["truth"][k] for tr in team])
+        delivered.append(comm.delivered)
+    assert delivered[last_in_range - 1] > 5                  # they talked ...
+    assert delivered[-1] == delivered[last_in_range]         # ... and not a single message after the last tick in range
+    for s in slams:
+        # ten key frames after the separation every unmatched vertex has left its window, and with it its scan
+        assert s.interRobotVertices.size() == 0
+        assert all(s._index_of_id(v) is not None or s._buffered(v) for v in s.peer)
+        # what was accepted before stays in the graph and keeps being optimised
+        assert s.last_status == 0 and np.isfinite(s.g.poses).all()
+
+
 # ------------------------------------------------------------------------------------------------ one rank per robot
 def _free_port():
     s = socket.socket()
