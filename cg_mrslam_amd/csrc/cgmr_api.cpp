@@ -107,14 +107,15 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
     const int chunk_rows = S.level_w[l] == kWideFrontW ? kWideChunkRows
                            : (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
     D.h_level_chunk[l] = chunk_rows;
-    int nwork = 0, ntile = 0;
+    int nwork = 0;
+    int xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};                     // update tiles per XCD (see the tile list below)
     for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++) {
       const int r = 3 * S.fronts[LF[q]].ns;
       nwork += std::max(1, (r + chunk_rows - 1) / chunk_rows);
       D.h_level_chrows[l] = std::max(D.h_level_chrows[l], std::min(r, chunk_rows) + 1);
-      if (r > 0) { const int T = (r + 31) / 32; ntile += T * (T + 1) / 2; }
+      if (r > 0) { const int T = (r + 31) / 32; *std::min_element(xload, xload + 8) += T * (T + 1) / 2; }
     }
-    D.h_tile_ptr[l + 1] = D.h_tile_ptr[l] + ntile;
+    D.h_tile_ptr[l + 1] = D.h_tile_ptr[l] + 8 * *std::max_element(xload, xload + 8);
     D.h_work_ptr[l + 1] = D.h_work_ptr[l] + nwork;
   }
   const size_t n_tiles = (size_t)D.h_tile_ptr[D.nlevels], n_work = (size_t)D.h_work_ptr[D.nlevels];
@@ -169,10 +170,16 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
       case 0: {                                                  // work records + update tiles, level by level
         WorkRec* work = reinterpret_cast<WorkRec*>(h + o_work);
         int32_t* tiles = reinterpret_cast<int32_t*>(h + o_tiles);
+        // Update tiles of one front sit 8 apart in the launch: workgroup b runs on XCD b % 8 (observed; speed only), so
+        // the tiles that share the front's L21 rows share one L2 instead of fetching them into up to eight.  A front goes
+        // to the XCD with the fewest tiles so far; the shorter queues are padded with empty entries (rec = -1).
         for (int l = 0; l < D.nlevels; l++) {
           const int chunk_rows = D.h_level_chunk[l];
           int w = D.h_work_ptr[l];
-          size_t t3 = 3 * (size_t)D.h_tile_ptr[l];
+          int32_t* tl = tiles + 3 * (size_t)D.h_tile_ptr[l];
+          const int slots = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
+          for (int k = 0; k < slots; k++) { tl[3 * k] = -1; tl[3 * k + 1] = 0; tl[3 * k + 2] = 0; }
+          int xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++) {
             const int f = LF[q];
             const int r = 3 * S.fronts[f].ns;
@@ -193,8 +200,12 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
             }
             if (r == 0) continue;                // a root: no update matrix
             const int T = (r + 31) / 32;
+            const int x = (int)(std::min_element(xload, xload + 8) - xload);
             for (int ti = 0; ti < T; ti++)
-              for (int tj = 0; tj <= ti; tj++) { tiles[t3++] = rec0; tiles[t3++] = ti; tiles[t3++] = tj; }
+              for (int tj = 0; tj <= ti; tj++) {
+                int32_t* e = tl + 3 * (size_t)(8 * xload[x]++ + x);
+                e[0] = rec0; e[1] = ti; e[2] = tj;
+              }
           }
         }
         break;

@@ -954,6 +954,7 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   const int tid = threadIdx.x;
   const int32_t* tl = tiles + 3 * (size_t)(tile_begin + blockIdx.x);
   const int rec = tl[0], ti = tl[1], tj = tl[2];
+  if (rec < 0) return;                                        // padding of the XCD-interleaved tile list
   if (tid < kRecInts) s_rec[tid] = reinterpret_cast<const int*>(work + rec)[tid];
   __syncthreads();
   const WorkRec* WR = reinterpret_cast<const WorkRec*>(s_rec);
