@@ -513,7 +513,17 @@ def main():
                "chi2_rel_diff_vs_gpu": float(abs(chi_cpu[-1] - chi[-1]) / chi_cpu[-1]),
                "max_pose_diff_vs_gpu": float(np.abs(p_cpu - d_p.cpu().numpy()).max())}
 
-    matcher = matcher_leg(ctx, dev, args, with_cpu=(world == 1 and not args.no_cpu_baseline)) if args.match_pairs > 0 else None
+    def guarded(name, fn):
+        # a secondary leg that fails must not take the headline line with it: the error is reported in its place
+        try:
+            return fn()
+        except Exception as e:                                   # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            return {"error": f"{name}: {type(e).__name__}: {e}"}
+
+    matcher = (guarded("matcher", lambda: matcher_leg(ctx, dev, args, with_cpu=(world == 1 and not args.no_cpu_baseline)))
+               if args.match_pairs > 0 else None)
 
     total_iters = GN_ITERS * args.steps * world
     out = {
@@ -532,7 +542,7 @@ def main():
         "symbolic": {k: info[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")},
         "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},
         "roofline": roofline, "cpu_baseline": cpu, "matcher": matcher, "exchange": exchange,
-        "team": (team_leg(ctx) if world == 1 and not args.no_team else None),
+        "team": (guarded("team", lambda: team_leg(ctx)) if world == 1 and not args.no_team else None),
     }
     if cpu:
         out["speedup_vs_cpu_1thread"] = round(out["value"] / cpu["value"], 2)
