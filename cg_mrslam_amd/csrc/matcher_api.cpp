@@ -398,7 +398,7 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
     if (nbins * num_threads > (size_t)1 << 26) return set_err(ctx, CGMR_E_INVALID, "result discretisation too fine for the search volume");
     D0.bins_off = (int64_t)total_bins;
     total_bins += nbins * num_threads;
-    D0.n_blocks = std::max(1, std::min(blocks_cap, D0.n_items / 8));
+    D0.n_blocks = std::max(1, std::min(blocks_cap, (D0.n_items + 3) / 4));      // one (region, angle) item per wavefront and round
     for (int b = 0; b < D0.n_blocks; b++) block_job.push_back(j);
     nblocks += D0.n_blocks;
   }
