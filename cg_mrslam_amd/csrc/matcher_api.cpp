@@ -663,6 +663,50 @@ void points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* S, co
   }
 }
 
+// Reference points of a multi-scan set hit the same walls once per scan; the rasteriser's byte-min is idempotent, so only
+// the first point of every distinct grid cell has to be stamped.  Cells exactly as the kernel computes them
+// (world_to_packed_cell: double -> float, world2grid in float, round to nearest even).
+void keep_first_point_per_cell(const cgmr_matcher_config* cfg, std::vector<double>& pts) {
+  const size_t n = pts.size() / 2;
+  if (n < 2048) return;
+  const float ll_x = (float)cfg->grid_ll_x, ll_y = (float)cfg->grid_ll_y;
+  const float inv_res = (float)(1. / (float)cfg->resolution);
+  size_t cap = 1;
+  while (cap < 2 * n) cap <<= 1;
+  std::vector<uint32_t> table(cap, 0xffffffffu);            // open addressing; 0xffffffff cannot be a packed cell (clamped coordinates)
+  size_t w = 0;
+  for (size_t i = 0; i < n; i++) {
+    float gx = ((float)pts[2 * i] - ll_x) * inv_res, gy = ((float)pts[2 * i + 1] - ll_y) * inv_res;
+    gx = std::fmin(std::fmax(gx, -30000.f), 30000.f);
+    gy = std::fmin(std::fmax(gy, -30000.f), 30000.f);
+    const int rx = (int)std::lrintf(gx), ry = (int)std::lrintf(gy);
+    const uint32_t key = ((uint32_t)(uint16_t)(int16_t)rx) | ((uint32_t)(uint16_t)(int16_t)ry << 16);
+    size_t h = (key * 2654435761u) & (cap - 1);
+    bool seen = false;
+    while (table[h] != 0xffffffffu) {
+      if (table[h] == key) { seen = true; break; }
+      h = (h + 1) & (cap - 1);
+    }
+    if (seen) continue;
+    table[h] = key;
+    pts[2 * w] = pts[2 * i]; pts[2 * w + 1] = pts[2 * i + 1];
+    w++;
+  }
+  pts.resize(2 * w);
+}
+
+// the reference points of job j's scan set; jobs that pass the very same set (same arrays) share one computation
+const std::vector<double>& reference_points(const cgmr_matcher_config* cfg, const cgmr_scan_set* sets, int j,
+                                            std::vector<std::vector<double>>& store, std::vector<int>& alias) {
+  for (int k = 0; k < j; k++)
+    if (sets[k].ranges == sets[j].ranges && sets[k].poses_xyt == sets[j].poses_xyt && sets[k].n_scans == sets[j].n_scans &&
+        sets[k].ref_index == sets[j].ref_index) { alias[j] = alias[k]; return store[alias[j]]; }
+  alias[j] = j;
+  points_from_vset(cfg, sets + j, nullptr, store[j]);
+  keep_first_point_per_cell(cfg, store[j]);
+  return store[j];
+}
+
 std::vector<double> subsample_of(const std::vector<double>& pts, double res) {
   std::vector<double> out(pts.size());
   int n = cgmr_subsample((int)(pts.size() / 2), pts.data(), res, out.data());
@@ -818,9 +862,10 @@ int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
   struct Key { int a, b, c; bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); } };
   std::vector<std::vector<double>> ref(n_jobs), qry(n_jobs);
   std::vector<std::vector<float>> regions(n_jobs), regionspi(n_jobs);
+  std::vector<int> ref_alias(n_jobs, 0);
   for (int j = 0; j < n_jobs; j++) {
     std::vector<double> cur;
-    points_from_vset(cfg, ref_sets + j, nullptr, ref[j]);
+    (void)reference_points(cfg, ref_sets, j, ref, ref_alias);
     points_from_vset(cfg, cur_sets + j, nullptr, cur);
     qry[j] = subsample_of(cur, 0.1);                                               // scan_matcher.cpp:216-217
     const cgmr_scan_set* S = ref_sets + j;
@@ -842,7 +887,8 @@ int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
     std::vector<SearchJob> jobs(n_jobs);
     for (int j = 0; j < n_jobs; j++) {
       const std::vector<float>& rg = pass ? regionspi[j] : regions[j];
-      jobs[j].ref = ref[j].data(); jobs[j].n_ref = (int)(ref[j].size() / 2);
+      const std::vector<double>& rj = ref[ref_alias[j]];
+      jobs[j].ref = rj.data(); jobs[j].n_ref = (int)(rj.size() / 2);
       jobs[j].qry = qry[j].data(); jobs[j].n_qry = (int)(qry[j].size() / 2);
       jobs[j].regions = rg.data(); jobs[j].n_regions = (int)(rg.size() / 6);
     }
@@ -891,12 +937,13 @@ int cgmr_global_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
   const float pi_f = (float)3.14159265358979323846;
   const float region[6] = {-10.f, -5.f, -pi_f, 10.f, 5.f, pi_f};                   // scan_matcher.cpp:383-391
   std::vector<SearchJob> jobs(n_jobs);
+  std::vector<int> ref_alias(n_jobs, 0);
   for (int j = 0; j < n_jobs; j++) {
     std::vector<double> cur;
-    points_from_vset(cfg, ref_sets + j, nullptr, ref[j]);
+    const std::vector<double>& rj = reference_points(cfg, ref_sets, j, ref, ref_alias);
     points_from_vset(cfg, cur_sets + j, nullptr, cur);
     qry[j] = subsample_of(cur, 0.1);
-    jobs[j].ref = ref[j].data(); jobs[j].n_ref = (int)(ref[j].size() / 2);
+    jobs[j].ref = rj.data(); jobs[j].n_ref = (int)(rj.size() / 2);
     jobs[j].qry = qry[j].data(); jobs[j].n_qry = (int)(qry[j].size() / 2);
     jobs[j].regions = region; jobs[j].n_regions = 1;
   }
