@@ -83,7 +83,7 @@ def main(argv=None):
     n = a.nRobots
     team = synth.make_robot_team(n, n_steps=a.steps, laps=a.laps, gap=a.gap, seed=a.seed, body=a.body)
     la = (team[0]["n_beams"], team[0]["angle_min"], team[0]["angle_inc"], team[0]["max_range"])
-    ranks = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    ranks = "RANK" in os.environ and "WORLD_SIZE" in os.environ          # launched by torch.distributed.run: one rank per robot
     t0 = time.time()
     if ranks:
         import torch

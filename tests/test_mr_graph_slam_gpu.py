@@ -138,3 +138,18 @@ def test_cg_mrslam_cli_one_rank_per_robot_equals_one_process(tmp_path):
         assert a["vertices"] == b["vertices"] and a["edges"] == b["edges"] and a["chi2"] == b["chi2"]
     for r in range(2):
         assert (tmp_path / f"robot-{r}-one.g2o").read_text() == (tmp_path / f"robot-{r}-ranks.g2o").read_text()
+
+
+def test_cg_mrslam_cli_rank_mode_over_rccl_single_rank(tmp_path):
+    """The rank mode with the default backend (nccl = RCCL): outboxes live in HBM, the all-gather is an RCCL collective.
+    One GPU here, so one rank = one robot; the multi-rank path is the gloo test above."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", "-m", "cg_mrslam_amd.cg_mrslam", "-nRobots", "1", "-steps", "60", "-laps", "0.14",
+           "-linearUpdate", "0.5", "-o", str(tmp_path / "solo.g2o")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rep = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["robots"]
+    assert len(rep) == 1 and rep[0]["transport"] == "all-gather/nccl" and rep[0]["own_vertices"] >= 8
+    assert rep[0]["max_distance_to_true_path_m"] < 0.2 and (tmp_path / "robot-0-solo.g2o").exists()
