@@ -23,6 +23,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
 def _make(ctx, r, n_robots, la, gpu):
     if gpu:
         s = MRGraphSLAMDriver(ctx, ScanMatcher(ctx, *la), LCScanMatcher(ctx, *la), RobotGraph(ctx, r, n_robots), r, n_robots,
@@ -129,7 +138,7 @@ def test_cg_mrslam_cli_one_rank_per_robot_equals_one_process(tmp_path):
     one = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["robots"]
     assert all(r["edges"].get("mr", 0) >= 1 and r["edges"].get("cond", 0) >= 1 for r in one), one
     launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-              "--master-port", "29631", "-m", "cg_mrslam_amd.cg_mrslam"]
+              "--master-port", _free_port(), "-m", "cg_mrslam_amd.cg_mrslam"]
     p = subprocess.run(launch + base[3:] + ["-o", str(tmp_path / "ranks.g2o"), "-device", "0", "-backend", "gloo"], env=env,
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -146,7 +155,7 @@ def test_cg_mrslam_cli_rank_mode_over_rccl_single_rank(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29633", "-m", "cg_mrslam_amd.cg_mrslam", "-nRobots", "1", "-steps", "60", "-laps", "0.14",
+           "--master-port", _free_port(), "-m", "cg_mrslam_amd.cg_mrslam", "-nRobots", "1", "-steps", "60", "-laps", "0.14",
            "-linearUpdate", "0.5", "-o", str(tmp_path / "solo.g2o")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
