@@ -89,6 +89,14 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
     return set_err(ctx, CGMR_E_INVALID, "more than %d search angles", kMatchMaxTheta);
   P.scratch_stride = ((size_t)4 * kMatchMaxPoints * sizeof(double) + (size_t)4 * kMatchMaxRefScans * kMatchMaxPoints +
                       (size_t)P.overflow_tiles * 64 + 255) & ~size_t(255);
+  // reference sets of several scans see the same walls once per scan: a bitmap of the grid's cells (per workgroup, in its
+  // scratch) lets the rasteriser stamp every cell once
+  size_t cellmap_bytes = 0;
+  if (n_ref_scans > 1) {
+    cellmap_bytes = ((((size_t)P.nx * P.ny + 31) / 32) * 4 + 255) & ~size_t(255);
+    P.cellmap_off = P.scratch_stride;
+    P.scratch_stride += cellmap_bytes;
+  }
   if (n_pairs == 0) return CGMR_OK;
   hipDeviceProp_t prop;
   HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -115,6 +123,8 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   ((int*)(ctx->pinned + o_err))[1] = nblocks;     // work counter: the first nblocks pairs are taken by blockIdx
   char* d = ctx->mt_arena.ptr;
   HIP_TRY(ctx, hipMemcpyAsync(d, ctx->pinned, hbytes, hipMemcpyHostToDevice, ctx->stream));
+  if (cellmap_bytes)      // the arena is shared with the other matcher launches: the bitmaps start every launch cleared
+    HIP_TRY(ctx, hipMemset2DAsync(d + o_scratch + P.cellmap_off, P.scratch_stride, 0, cellmap_bytes, (size_t)nblocks, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   launch_match_close_batch(ctx->stream, nblocks, P, d_ref, d_xform, d_qry, d_guess, (const double*)(d + o_cos),
                            (const double*)(d + o_sin), (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch),

@@ -28,6 +28,8 @@ struct MatchParams {
   int x_steps, y_steps;
   int overflow_tiles;
   size_t scratch_stride;
+  size_t cellmap_off;                        // multi-scan reference sets: byte offset of the workgroup's cell bitmap (nx * ny bits,
+                                             // all zero between pairs) inside its scratch; 0 = none
   // generic multi-region search (k_match_greedy)
   int n_ref, n_qry, n_regions, n_items;
   int ref_cap;                               // packed-cell slots per point list in the HBM scratch (>= n_ref, n_qry)

@@ -519,8 +519,56 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       if (NS == 1) rcell_l[i] = packed; else rcell_g[i] = packed;
     }
     __syncthreads();
+    uint32_t* const cellmap = P.cellmap_off ? reinterpret_cast<uint32_t*>(my + P.cellmap_off) : nullptr;
     if (NS == 1) build_grid(S, P, rcell_l, B, gtiles, /*allow_fast=*/true, err);
-    else build_grid(S, P, rcell_g, NS * B, gtiles, /*allow_fast=*/true, err);
+    else if (!cellmap) build_grid(S, P, rcell_g, NS * B, gtiles, /*allow_fast=*/true, err);
+    else {
+      // A cell is rasterised for the first point that claims it (byte-min stamps are idempotent): the other scans' copies
+      // of the same wall are dropped, the survivors are compacted into the idle point lists in LDS (all but the last
+      // one, which the block scans use) and the rasteriser runs on that list.
+      constexpr int LCAP = (NTH - 1) * LISTCAP;
+      uint32_t* const clist = &S.plist[0][0];
+      if (tid == 0) S.misc[14] = 0;
+      __syncthreads();
+      for (int i = tid; i < NS * B; i += CB_THREADS) {
+        const uint32_t packed = rcell_g[i];
+        if (packed == 0x80008000u) continue;
+        const int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+        bool keep = true;
+        if ((unsigned)rx < (unsigned)P.nx && (unsigned)ry < (unsigned)P.ny) {                 // (off the grid: kept as it is)
+          const unsigned bit = (unsigned)rx * (unsigned)P.ny + (unsigned)ry;
+          keep = !(atomicOr(&cellmap[bit >> 5], 1u << (bit & 31)) & (1u << (bit & 31)));
+        }
+        if (keep) {
+          const int slot = atomicAdd(&S.misc[14], 1);
+          if (slot < LCAP) clist[slot] = packed;
+          else rcell_g[i] = packed;                               // (stays in the scratch list: see the overflow path)
+        } else rcell_g[i] = 0x80008000u;
+      }
+      __syncthreads();
+      const int nkept = S.misc[14];
+      __syncthreads();
+      if (nkept <= LCAP) build_grid(S, P, clist, nkept, gtiles, /*allow_fast=*/true, err);
+      else build_grid(S, P, rcell_g, NS * B, gtiles, /*allow_fast=*/true, err);               // more distinct cells than the lists hold
+      // every surviving point clears its word: the bitmap is all zero again for the next pair
+      if (nkept <= LCAP) {
+        for (int i = tid; i < nkept; i += CB_THREADS) {
+          const uint32_t packed = clist[i];
+          const int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+          if ((unsigned)rx < (unsigned)P.nx && (unsigned)ry < (unsigned)P.ny)
+            cellmap[((unsigned)rx * (unsigned)P.ny + (unsigned)ry) >> 5] = 0u;
+        }
+      } else {
+        for (int i = tid; i < NS * B; i += CB_THREADS) {
+          const uint32_t packed = rcell_g[i];
+          if (packed == 0x80008000u) continue;
+          const int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+          if ((unsigned)rx < (unsigned)P.nx && (unsigned)ry < (unsigned)P.ny)
+            cellmap[((unsigned)rx * (unsigned)P.ny + (unsigned)ry) >> 5] = 0u;
+        }
+      }
+      __syncthreads();
+    }
     const bool fast = S.misc[12] != 0;
     if (!fast && tid == 0) atomicAdd(err + 2, 1);          // pairs whose tiles did not fit LDS (generic search path)
     MPHASE(5);
