@@ -520,7 +520,23 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     }
     __syncthreads();
     uint32_t* const cellmap = P.cellmap_off ? reinterpret_cast<uint32_t*>(my + P.cellmap_off) : nullptr;
-    if (NS == 1) build_grid(S, P, rcell_l, B, gtiles, /*allow_fast=*/true, err);
+    if (NS == 1) {
+      // valid beams whose cell differs from the previous beam's, compacted behind the raw list (the rasteriser's work
+      // items are (point, kernel row): a quarter of the raw list's items would be skipped one by one)
+      uint32_t* const cl1 = &S.plist[2][0];
+      static_assert(2 * LISTCAP >= MAXPTS && NTH >= 5, "compacted single-scan list");
+      if (tid == 0) S.misc[14] = 0;
+      __syncthreads();
+      for (int i = tid; i < B; i += CB_THREADS) {
+        const uint32_t packed = rcell_l[i];
+        if (packed == 0x80008000u || (i > 0 && rcell_l[i - 1] == packed)) continue;
+        cl1[atomicAdd(&S.misc[14], 1)] = packed;
+      }
+      __syncthreads();
+      const int nkept1 = S.misc[14];
+      __syncthreads();
+      build_grid(S, P, cl1, nkept1, gtiles, /*allow_fast=*/true, err);
+    }
     else if (!cellmap) build_grid(S, P, rcell_g, NS * B, gtiles, /*allow_fast=*/true, err);
     else {
       // A cell is rasterised for the first point that claims it (byte-min stamps are idempotent): the other scans' copies
