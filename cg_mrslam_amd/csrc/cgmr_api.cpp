@@ -79,8 +79,8 @@ struct BlobLayout {
 // Lay out and upload the structure arrays; point GnDevice into the arena.
 int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t* et, int iters) {
   // the factor kernels keep row positions (own columns + border rows) in 16-bit LDS maps
-  if (3 * (int64_t)S.max_ns + kWideFrontW > 32767)
-    return set_err(ctx, CGMR_E_INVALID, "a front has %d border poses; at most %d are supported", S.max_ns, (32767 - kWideFrontW) / 3);
+  if (3 * (int64_t)S.max_ns + kFrontW > 32767)
+    return set_err(ctx, CGMR_E_INVALID, "a front has %d border poses; at most %d are supported", S.max_ns, (32767 - kFrontW) / 3);
   GnDevice& D = ctx->gn;
   D.nV = S.nV; D.nE = S.nE; D.nf = S.nf; D.nb = S.nb;
   D.nfronts = (int)S.fronts.size();
@@ -98,14 +98,12 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.h_level_chrows.assign(D.nlevels, 1);
   D.h_level_leaf.assign(D.nlevels, 1);
   D.h_level_chunk.assign(D.nlevels, kChunkRows);
-  D.h_level_w = S.level_w;
   for (int l = 0; l < D.nlevels; l++) {
     for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++)
       if (S.fronts[LF[q]].nchild > 0) D.h_level_leaf[l] = 0;
     // a level of leaves runs the register-light variant of the factor kernel: shorter chunks, so that the LDS of two
     // workgroups fits a CU
-    const int chunk_rows = S.level_w[l] == kWideFrontW ? kWideChunkRows
-                           : (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
+    const int chunk_rows = (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
     D.h_level_chunk[l] = chunk_rows;
     int nwork = 0;
     int xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};                     // update tiles per XCD (see the tile list below)

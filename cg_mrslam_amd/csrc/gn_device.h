@@ -35,7 +35,6 @@ struct GnDevice {
   std::vector<int32_t> h_flevel_ptr;     // full level lists (level_fronts on the device is the full list as well)
   std::vector<int32_t> h_level_ptr, h_tile_ptr, h_work_ptr;   // Gauss-Newton levels (without the top block)
   std::vector<uint8_t> h_level_leaf;     // per level: 1 if no front of the level has children (leaf variant of the factor kernel)
-  std::vector<int32_t> h_level_w;        // per level: panel width of its fronts (kFrontW / kWideFrontW)
   std::vector<int32_t> h_level_chunk;    // per level: border rows per work item (kChunkRows, fewer for a level of leaves)
   std::vector<int32_t> h_level_chrows;   // per level: rows of the factor kernel's F21 staging area (max chunk rows + rhs row)
 };

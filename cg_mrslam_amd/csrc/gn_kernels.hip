@@ -23,6 +23,7 @@
 
 #include "gn_symbolic.h"
 #include "gn_device.h"
+#include "panel_cholesky.h"
 
 namespace cgmr {
 
@@ -67,11 +68,11 @@ constexpr int factor_smem_bytes(int w, int rows) {
   const int off_rec = ((off_cmap + 2 * kWorkChildren * w + 15) / 16) * 16;
   const int off_dinv = ((off_rec + 4 * kRecIntsC + 15) / 16) * 16;
   const int off_r = ((off_dinv + w * 8 + 15) / 16) * 16;
-  return off_r + rows * ldw * 8;
+  return off_r + ((w + rows + 15) / 16 * 16 - w) * ldw * 8;    // panel rows padded to a multiple of 16 (panel_cholesky.h)
 }
 static_assert(factor_smem_bytes(kFrontW, kChunkRows + 1) <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
-static_assert(factor_smem_bytes(kWideFrontW, kWideChunkRows + 1) <= 160 * 1024, "k_front_factor (wide) LDS plan exceeds 160 KiB");
-static_assert(factor_smem_bytes(kFrontW, kLeafChunkRows + 1) <= 48 * 1024, "leaf variant: three workgroups per CU need <= 48 KiB each");
+static_assert(3 * factor_smem_bytes(kFrontW, kLeafChunkRows + 1) <= 160 * 1024, "leaf variant: three workgroups per CU");
+static_assert(kFrontW + kChunkRows + 1 <= 208, "panel_cholesky: at most 4 x 48 rows below a diagonal block");
 
 __device__ __forceinline__ double d_normalize_theta(double t) {
   const double pi = 3.14159265358979323846;
@@ -268,23 +269,6 @@ __device__ unsigned long long g_utime[2 * 64];             // per level of k_fro
 #define FPHASE(i)
 #endif
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(d) to double precision: hardware estimate + one third-order correction, y (1 + e/2 + 3e^2/8) with
-// e = 1 - d y^2 (four dependent operations instead of the six of two Newton steps; no FP64 divide / sqrt expansion
-// on the pivot chain, which is the critical path of the whole factorisation).
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  const double y = __builtin_amdgcn_rsq(d);
-  const double e = fma(-(d * y), y, 1.0);
-  return fma(y * e, fma(0.375, e, 0.5), y);
-}
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
 constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record / whose maps are staged together
 constexpr int kRecInts = kRecIntsC;
 constexpr int MAPW = kMapW;
@@ -404,131 +388,6 @@ __device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDes
   c.U_off = G.U_off; c.ns = G.ns; c.na = G.na; c.rel_off = G.rel_off; c.inv_off = G.inv_off; c.rows_off = G.rows_off;
   c.pad = 0;
   return c;
-}
-
-// (The same blocked factorisation as inside front_factor_body, as a function: k_top_block uses it.  The panel kernel
-// keeps its own inlined copy -- routing it through this function costs 5 % of the device time, measured.)
-// Blocked right-looking Cholesky of a panel held in LDS, in block columns of 16 with one block column of look-ahead
-// (256 threads).  prow(r) = row r of the panel (M rows: the columns' own rows first, then border rows, the
-// right-hand side last), drow(r) = the same for rows of the first 16 * nbc (always the leading region, row stride LDD
-// doubles -- a compile-time constant: the row solves address the diagonal block with immediate offsets):
-//   factor_diag   wavefront 0 factors the 16x16 diagonal block in registers (lane i = row i), as L D L^T with the
-//                 scaling by D^-1/2 deferred: the chain from one pivot to the next is readlane -> 1/d (estimate + cubic
-//                 correction) -> one multiply -> fma; the 16 reciprocal square roots are taken together afterwards;
-//   solve_rows    one thread per row below solves its 16 entries against the diagonal block;
-//   update_tiles  the 16x16 tiles of a later block column subtract L[I][K] L[J][K]^T with v_mfma_f64_16x16x4_f64,
-//                 operands straight from LDS (no per-FMA broadcast reads).
-// The right-hand side is the last row of the panel: what the solves leave there is y = L^-1 b, i.e. the forward
-// solve.  Returns (on wavefront 0) whether a pivot was not positive.  Dinv[c] receives 1 / L[c][c].
-template <int LDD, typename RowFn, typename DiagRowFn>
-__device__ __forceinline__ int blocked_cholesky(RowFn prow, DiagRowFn drow, int M, int nbc, double* Dinv, int tid, int lane, int wave) {
-  const int NB = (M + 15) >> 4;
-  int fail = 0;
-  double mydinv = 1.0;
-  // C[I][Jt] -= L[I][Ks] L[Jt][Ks]^T for the row blocks I >= Jt, dealt round-robin to wavefronts wlo .. wlo+nw-1;
-  // two tiles per wavefront in flight (independent accumulator chains), B operand shared by all tiles
-  auto update_tiles = [&](int Jt, int Ks, int wlo, int nw) {
-    if (wave < wlo || wave >= wlo + nw) return;
-    const int ct = 16 * Jt, cs = 16 * Ks;
-    const double* brow = prow(min(16 * Jt + (lane & 15), M - 1)) + cs + (lane >> 4);
-    double bv[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) bv[kk] = brow[4 * kk];
-    for (int I = Jt + (wave - wlo); I < NB; I += 2 * nw) {
-      const int I2 = I + nw;
-      const bool has2 = I2 < NB;
-      const double* ar0 = prow(min(16 * I + (lane & 15), M - 1)) + cs + (lane >> 4);
-      const double* ar1 = prow(min(16 * I2 + (lane & 15), M - 1)) + cs + (lane >> 4);
-      double a0[4], a1[4];
-      double4_t acc0, acc1;
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) { a0[kk] = -ar0[4 * kk]; a1[kk] = -ar1[4 * kk]; }
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        acc0[rg] = prow(min(16 * I + (lane >> 4) + 4 * rg, M - 1))[ct + (lane & 15)];
-        acc1[rg] = prow(min(16 * I2 + (lane >> 4) + 4 * rg, M - 1))[ct + (lane & 15)];
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], bv[kk], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], bv[kk], acc1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int row0 = 16 * I + (lane >> 4) + 4 * rg, row1 = 16 * I2 + (lane >> 4) + 4 * rg;
-        if (row0 < M) prow(row0)[ct + (lane & 15)] = acc0[rg];
-        if (has2 && row1 < M) prow(row1)[ct + (lane & 15)] = acc1[rg];
-      }
-    }
-  };
-  auto factor_diag = [&](int J) {
-    if (wave != 0) return;
-    const int c = 16 * J;
-    double x[16];
-    const int li = min(lane, 15);
-#pragma unroll
-    for (int q = 0; q < 16; q++) x[q] = drow(c + li)[c + q];
-    double dl = 1.0;                                          // my row's pivot
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const double d = readlane_f64(x[j], j);
-      if (!(d > 0.0)) fail = 1;                               // off the chain: a failed front leaves NaN / Inf behind, nobody reads them
-      const double r0 = __builtin_amdgcn_rcp(d);
-      const double e = fma(-d, r0, 1.0);
-      const double sc = x[j] * fma(r0, fma(e, e, e), r0);     // a_ij / d
-      if (lane == j) dl = d;
-#pragma unroll
-      for (int q = j + 1; q < 16; q++) x[q] = fma(-sc, readlane_f64(x[j], q), x[q]);
-    }
-    const double y = rsqrt_nr(dl);
-    mydinv = y;
-#pragma unroll
-    for (int j = 0; j < 16; j++) x[j] *= readlane_f64(y, j);  // L[i][j] = a_ij d_j^-1/2 (j < i), L[i][i] = d_i d_i^-1/2
-    if (lane < 16) {
-#pragma unroll
-      for (int q = 0; q < 16; q++) drow(c + lane)[c + q] = (q <= lane) ? x[q] : 0.0;
-      Dinv[c + lane] = mydinv;
-    }
-  };
-  // one thread per row below the diagonal block of block column J solves its 16 entries against that block
-  // (two rows per thread, sharing the block's entries, measured slower)
-  auto solve_rows = [&](int J) {
-    const int c = 16 * J;
-    const int row = c + 16 + tid;
-    if (row >= M) return;
-    double* xr = prow(row) + c;
-    double x[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) x[q] = xr[q];
-    // right-looking within the row: once x[q] is final it is pushed into all later entries (independent FMAs)
-    const double* l0 = drow(c) + c;                           // L[c][c]
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const double xq = x[q] * Dinv[c + q];
-      x[q] = xq;
-      const double* lc = l0 + q * LDD + q;                    // L[q][q]; L[j][q] is (j - q) rows below
-#pragma unroll
-      for (int j = q + 1; j < 16; j++) x[j] = fma(-xq, lc[(j - q) * LDD], x[j]);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; q++) xr[q] = x[q];
-  };
-  // right-looking schedule with look-ahead: block column K+1 is brought up to date first, then wavefront 0 factors
-  // its diagonal block while wavefronts 1-3 push the same update into the block columns after it
-  factor_diag(0);
-  __syncthreads();
-  for (int K = 0; K < nbc; K++) {
-    solve_rows(K);
-    __syncthreads();
-    if (K + 1 < nbc) {
-      update_tiles(K + 1, K, 0, 4);
-      __syncthreads();
-      factor_diag(K + 1);
-      for (int J = K + 2; J < nbc; J++) update_tiles(J, K, 1, 3);
-      __syncthreads();
-    }
-  }
-  return fail;
 }
 
 // One workgroup per work item = (front, chunk of `chunk_rows` border rows) of the current level.  A lone workgroup
@@ -728,137 +587,20 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
   __syncthreads();
   }
   PHASE(3);
-  // ---- B+C. blocked right-looking factorisation of the panel [F11; F21 chunk; rhs row] where it was assembled, in
-  // LDS, in three block columns of 16 (look-ahead of one block column):
-  //   factor_diag   wavefront 0 factors the 16x16 diagonal block in registers (lane i = row i, pivot broadcast with
-  //                 v_readlane, 1/sqrt by rsqrt + 2 Newton steps);
-  //   solve_rows    one thread per row below solves its 16 entries against the diagonal block;
-  //   update_tiles  the 16x16 tiles of a later block column subtract L[I][K] L[J][K]^T with
-  //                 v_mfma_f64_16x16x4_f64, operands straight from LDS (no per-FMA broadcast reads).
-  // The rhs row is the last row of the panel: what the solves leave there is y = L11^-1 (b + children), i.e. the
-  // forward solve.  A non-positive pivot records the GN iteration in *status (first failure wins); the pose update
-  // kernel then leaves the poses alone -- g2o's early return.
-  // logical wavefront number: the wavefront that factors the diagonal blocks alone sits on a different SIMD in
-  // consecutive rounds of workgroups, so that the three leaf workgroups sharing a CU do not queue their diagonal
-  // blocks (issue-bound) on one SIMD: 7.96 -> 7.57 ms device on C2
-  const int lane = tid & 63, wave = ((tid >> 6) - (LEAF ? (int)(blockIdx.x >> 8) : 0)) & 3;
+  // ---- blocked factorisation of the panel [F11; F21 chunk; rhs row] where it was assembled, in LDS (panel_cholesky.h):
+  // per block column of 16 one elimination pass -- every wavefront factors the diagonal block in lanes 48..63 and
+  // solves 48 rows below it in lanes 0..47 -- and the trailing update on v_mfma_f64_16x16x4_f64.  The rhs row is the
+  // last row of the panel: what the eliminations leave there is y = L11^-1 (b + children), i.e. the forward solve.
+  // A non-positive pivot records the GN iteration in *status (first failure wins); the pose update kernel then leaves
+  // the poses alone -- g2o's early return.
+  const int lane = tid & 63, wave = tid >> 6;
   const int M = W + nr + 1;                                 // rows of the panel: F11, border rows of the chunk, rhs
-  const int NB = (M + 15) >> 4;
   // row r of the panel: F11 rows in Ls, the others in R (kRIdx doubles behind Ls)
-#define PROW(r) (Ls + (r) * LDW + ((r) >= W ? kRIdx - W * LDW : 0))
-  int fail = 0;
-  double mydinv = 1.0;
-  // C[I][Jt] -= L[I][Ks] L[Jt][Ks]^T for the row blocks I >= Jt, dealt round-robin to wavefronts wlo .. wlo+nw-1;
-  // two tiles per wavefront in flight (independent accumulator chains), B operand shared by all tiles
-  auto update_tiles = [&](int Jt, int Ks, int wlo, int nw) {
-    if (wave < wlo || wave >= wlo + nw) return;
-    const int ct = 16 * Jt, cs = 16 * Ks;
-    const double* brow = PROW(16 * Jt + (lane & 15)) + cs + (lane >> 4);
-    double bv[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) bv[kk] = brow[4 * kk];
-    for (int I = Jt + (wave - wlo); I < NB; I += 2 * nw) {
-      const int I2 = I + nw;
-      const bool has2 = I2 < NB;
-      const double* ar0 = PROW(min(16 * I + (lane & 15), M - 1)) + cs + (lane >> 4);
-      const double* ar1 = PROW(min(16 * I2 + (lane & 15), M - 1)) + cs + (lane >> 4);
-      double a0[4], a1[4];
-      double4_t acc0, acc1;
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) { a0[kk] = -ar0[4 * kk]; a1[kk] = -ar1[4 * kk]; }
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        acc0[rg] = PROW(min(16 * I + (lane >> 4) + 4 * rg, M - 1))[ct + (lane & 15)];
-        acc1[rg] = PROW(min(16 * I2 + (lane >> 4) + 4 * rg, M - 1))[ct + (lane & 15)];
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], bv[kk], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], bv[kk], acc1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int row0 = 16 * I + (lane >> 4) + 4 * rg, row1 = 16 * I2 + (lane >> 4) + 4 * rg;
-        if (row0 < M) PROW(row0)[ct + (lane & 15)] = acc0[rg];
-        if (has2 && row1 < M) PROW(row1)[ct + (lane & 15)] = acc1[rg];
-      }
-    }
-  };
-  // wavefront 0 factors the 16x16 diagonal block of block column J in registers (lane i = row i), as L D L^T with the
-  // scaling by D^-1/2 deferred: the chain from one pivot to the next is readlane -> 1/d (estimate + cubic correction)
-  // -> one multiply -> fma on x[j+1]; the 16 reciprocal square roots are taken together afterwards, one per lane.
-  auto factor_diag = [&](int J) {
-    if (wave != 0) return;
-    const int c = 16 * J;
-    double x[16];
-    const int li = min(lane, 15);
-#pragma unroll
-    for (int q = 0; q < 16; q++) x[q] = Ls[(c + li) * LDW + c + q];
-    double dl = 1.0;                                          // my row's pivot
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const double d = readlane_f64(x[j], j);
-      if (!(d > 0.0)) fail = 1;                               // off the chain: a failed front leaves NaN / Inf behind, nobody reads them
-      const double r0 = __builtin_amdgcn_rcp(d);
-      const double e = fma(-d, r0, 1.0);
-      const double sc = x[j] * fma(r0, fma(e, e, e), r0);     // a_ij / d
-      if (lane == j) dl = d;
-#pragma unroll
-      for (int q = j + 1; q < 16; q++) x[q] = fma(-sc, readlane_f64(x[j], q), x[q]);
-    }
-    const double y = rsqrt_nr(dl);
-    mydinv = y;
-#pragma unroll
-    for (int j = 0; j < 16; j++) x[j] *= readlane_f64(y, j);  // L[i][j] = a_ij d_j^-1/2 (j < i), L[i][i] = d_i d_i^-1/2
-    if (lane < 16) {
-#pragma unroll
-      for (int q = 0; q < 16; q++) Ls[(c + lane) * LDW + c + q] = (q <= lane) ? x[q] : 0.0;
-      Dinv[c + lane] = mydinv;
-    }
-  };
-  // one thread per row below the diagonal block of block column J solves its 16 entries against that block
-  // (two rows per thread, sharing the block's entries, measured slower)
-  auto solve_rows = [&](int J) {
-    const int c = 16 * J;
-    const int row = c + 16 + tid;
-    if (row >= M) return;
-    double* xr = PROW(row) + c;
-    double x[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) x[q] = xr[q];
-    // right-looking within the row: once x[q] is final it is pushed into all later entries (independent FMAs)
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const double xq = x[q] * Dinv[c + q];
-      x[q] = xq;
-      const double* lc = Ls + (c + q) * LDW + c + q;          // L[q][q]; L[j][q] is (j - q) rows below
-#pragma unroll
-      for (int j = q + 1; j < 16; j++) x[j] = fma(-xq, lc[(j - q) * LDW], x[j]);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; q++) xr[q] = x[q];
-  };
+  auto roff = [](int r) -> int { return r * LDW + (r >= W ? kRIdx - W * LDW : 0); };
   const int nbc = min(W / 16, (w + 15) >> 4);                // block columns that hold real columns
-  // right-looking schedule with look-ahead: block column K+1 is brought up to date first, then wavefront 0 factors
-  // its diagonal block while wavefronts 1-3 push the same update into the block columns after it
   FPHASE(0);
-  factor_diag(0);
-  __syncthreads();
+  const int fail = panel_cholesky(Ls, roff, M, nbc, Dinv, lane, wave);
   FPHASE(1);
-  for (int K = 0; K < nbc; K++) {
-    solve_rows(K);
-    __syncthreads();
-    if (K == 0) FPHASE(2);
-    if (K + 1 < nbc) {
-      update_tiles(K + 1, K, 0, 4);
-      __syncthreads();
-      if (K == 0) FPHASE(3);
-      factor_diag(K + 1);
-      for (int J = K + 2; J < nbc; J++) update_tiles(J, K, 1, 3);
-      __syncthreads();
-      if (K == 0) FPHASE(4);
-    }
-  }
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);   // status[1]: GN iterations completed so far
   PHASE(4);
   // ---- stores, all from LDS: L11 (lower triangle, zeros above), 1/diag, L21 rows of this chunk, y, u
@@ -889,7 +631,6 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
     for (int k = 0; k < W; k++) dot = fma(xr[k], yr[k], dot);
     uvec[(size_t)3 * rows_off + r0 + tid] = xr[W] - dot;
   }
-#undef PROW
   PHASE(5);
 #ifdef CGMR_PHASE_TIMING
   __syncthreads();
@@ -1071,7 +812,7 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
 constexpr int kTopLD = kTopMaxCols + 1;                      // row stride of the block in LDS (doubles), whatever its size
 constexpr int top_smem_bytes(int ncols) {
   const int n16 = (ncols + 15) / 16 * 16;
-  return ((n16 + 1) * kTopLD + n16) * 8 + 2 * 1024;
+  return ((n16 + 16) * kTopLD + n16) * 8 + 2 * 1024;         // rows padded to a multiple of 16 (panel_cholesky.h)
 }
 static_assert(kTopMaxCols % 16 == 0 && top_smem_bytes(kTopMaxCols) <= 160 * 1024, "top block exceeds the LDS");
 
@@ -1088,7 +829,7 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
   constexpr int LD = kTopLD;
   const int n16 = (ncols + 15) / 16 * 16, M = n16 + 1, nbc = n16 / 16;
   double* P = reinterpret_cast<double*>(smem);
-  double* Dinv = P + (size_t)M * LD;
+  double* Dinv = P + (size_t)(n16 + 16) * LD;
   short* cmap = reinterpret_cast<short*>(Dinv + n16);        // row of the block a child's border row lands in (<= 1024 rows)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int q = tid; q < M * LD; q += 256) P[q] = 0.0;
@@ -1132,8 +873,8 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
     __syncthreads();
   }
   // ---- factorisation (the rhs row becomes y = L^-1 b)
-  auto prow = [=](int r) -> double* { return P + (size_t)r * LD; };
-  const int fail = blocked_cholesky<LD>(prow, prow, M, nbc, Dinv, tid, lane, wave);
+  auto roff = [](int r) -> int { return r * LD; };
+  const int fail = panel_cholesky(P, roff, M, nbc, Dinv, lane, wave);
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);
   __syncthreads();
   // ---- backward solve L^T x = y of the block's columns (nothing above them): wavefront 0, lane = columns lane, lane + 64
@@ -1366,12 +1107,8 @@ void gn_init_kernels() {
   std::call_once(once[dev & 63], [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               factor_smem_bytes(kFrontW, kChunkRows + 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              factor_smem_bytes(kWideFrontW, kWideChunkRows + 1));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
                               factor_smem_bytes(kFrontW, kChunkRows + 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_bwd<kWideFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              bwd_smem_bytes(kWideFrontW));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize), hipFuncAttributeMaxDynamicSharedMemorySize,
                               256 * 33 * (int)sizeof(double));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_block), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1382,9 +1119,9 @@ void gn_init_kernels() {
 void launch_factor_level(hipStream_t st, const GnDevice& D, int l, bool write_l11c) {
   gn_init_kernels();
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
-  const int lw = D.h_level_w[l];
+  const int lw = kFrontW;
   const int ch_rows = D.h_level_chrows[l];
-  auto kern = lw == kWideFrontW ? k_front_factor<kWideFrontW> : (D.h_level_leaf[l] ? k_front_factor_leaf : k_front_factor<kFrontW>);
+  auto kern = D.h_level_leaf[l] ? k_front_factor_leaf : k_front_factor<kFrontW>;
   hipLaunchKernelGGL(kern, dim3(nw), dim3(256), factor_smem_bytes(lw, ch_rows), st, D.work, D.h_work_ptr[l], D.fronts,
                      D.children, D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, l,
                      write_l11c ? 1 : 0, ch_rows, D.h_level_chunk[l]);
@@ -1393,7 +1130,7 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int l, bool write_l1
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
   int nt = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
   if (nt <= 0) return;
-  auto kern = D.h_level_w[l] == kWideFrontW ? k_front_update<kWideFrontW> : k_front_update<kFrontW>;
+  auto kern = k_front_update<kFrontW>;
   hipLaunchKernelGGL(kern, dim3(nt), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children, D.inv, D.Lbuf,
                      D.Ubuf);
 }
@@ -1401,8 +1138,8 @@ void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   gn_init_kernels();
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
-  const int lw = D.h_level_w[l];
-  auto kern = lw == kWideFrontW ? k_solve_bwd<kWideFrontW> : k_solve_bwd<kFrontW>;
+  const int lw = kFrontW;
+  auto kern = k_solve_bwd<kFrontW>;
   hipLaunchKernelGGL(kern, dim3(nfr), dim3(256), bwd_smem_bytes(lw), st, D.fronts_lv, D.h_level_ptr[l], D.rows, D.Lbuf,
                      D.yvec, D.xvec);
 }

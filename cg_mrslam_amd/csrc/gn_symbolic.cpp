@@ -23,7 +23,6 @@ double now_s() {
 }
 
 constexpr int kRangeDepth = 2;        // ND depth whose halves become the parallel units of the border computation
-constexpr int kWideMinHeight = 0;     // default of CGMR_WIDE_MIN_HEIGHT (0 = no wide fronts: measured slower)
 
 // A few persistent helper threads: the analysis forks a dozen short parallel sections per call, and creating a
 // thread for each costs more than most of them run.  Idle helpers spin briefly (the next section usually follows
@@ -112,8 +111,6 @@ struct NDCtx {
   const std::vector<int32_t>& ai;
   std::vector<int32_t>& order;        // in/out working permutation
   std::vector<uint8_t>& pstart;       // pstart[pos] = 1 if a front begins at position pos
-  std::vector<uint8_t> wide;          // wide[pos] = 1: the position belongs to a separator cut into wide panels
-  int wide_min_height = 1 << 30;      // subtrees at least this tall get wide separators
   std::mutex range_mu;
   std::vector<std::pair<int, int>> subtree_ranges;   // position ranges of the halves of the nodes at depth kRangeDepth:
                                                      // complete subtrees, independent of each other
@@ -137,7 +134,6 @@ struct NDRange {
 NDRange emit_panels(NDCtx& C, int begin, int end, int run = kPanelW) {
   NDRange r;
   for (int p = begin; p < end; p += run) { C.pstart[p] = 1; r.height++; }
-  if (run > kPanelW) for (int p = begin; p < end; p++) C.wide[p] = 1;
   r.last = end > begin ? (end - begin - 1) % run + 1 : 0;
   return r;
 }
@@ -315,7 +311,6 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
   if (swapped) {
     std::rotate(C.order.begin() + begin, C.order.begin() + begin + na, C.order.begin() + s0);
     std::rotate(C.pstart.begin() + begin, C.pstart.begin() + begin + na, C.pstart.begin() + s0);
-    std::rotate(C.wide.begin() + begin, C.wide.begin() + begin + na, C.wide.begin() + s0);
     if (depth < kRangeDepth) {                           // subtree ranges recorded below move with their blocks
       std::lock_guard<std::mutex> lk(C.range_mu);
       for (auto& pr : C.subtree_ranges) {
@@ -333,12 +328,11 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
   }
   // the separator in runs of kPanelW; when its remainder fits into the last panel of the half in front of it, the
   // remainder goes first so that the amalgamation can merge the two (one level less on that path)
-  const int run = std::max(r1.height, r2.height) >= C.wide_min_height ? kWidePanelW : kPanelW;
+  const int run = kPanelW;
   const int ssz = end - s0, rem = ssz % run;
   NDRange out;
   if (rem != 0 && r2.last + rem <= run) {
     C.pstart[s0] = 1;
-    if (run > kPanelW) for (int p = s0; p < s0 + rem; p++) C.wide[p] = 1;
     NDRange rest = emit_panels(C, s0 + rem, end, run);
     out.last = ssz == rem ? r2.last + rem : rest.last;
     out.height = std::max(r1.height + 1, r2.height) + rest.height;
@@ -465,7 +459,6 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   // nested dissection
   const int NT = host_threads();
   std::vector<int32_t> order(nf), panel_start;
-  std::vector<uint8_t> wide_pos;
   std::vector<std::pair<int, int>> pos_ranges;
   for (int v = 0; v < nf; v++) order[v] = v;
   {
@@ -474,15 +467,9 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     C.vs.assign(nf, NDCtx::VState{0, 0});
     C.queue.assign(nf, 0);
     C.tmp.assign(nf, 0);
-    C.wide.assign(nf, 0);
-    {
-      static const int wmh = getenv("CGMR_WIDE_MIN_HEIGHT") ? atoi(getenv("CGMR_WIDE_MIN_HEIGHT")) : kWideMinHeight;
-      C.wide_min_height = wmh > 0 ? wmh : (1 << 30);
-    }
     C.max_par_depth = NT >= 8 ? 3 : (NT >= 4 ? 2 : (NT >= 2 ? 1 : 0));
     nd(C, 0, nf, 0);
     for (int p = 0; p < nf; p++) if (pstart[p]) panel_start.push_back(p);
-    wide_pos.swap(C.wide);
     pos_ranges.swap(C.subtree_ranges);
   }
   std::vector<int32_t> iperm(nf);
@@ -641,7 +628,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       while (g >= X.flo && dead[g]) g--;
       if (g < X.flo) break;
       FrontDesc& G = S.fronts[g];
-      if (G.parent != f || G.c0 + G.nc != F.c0 || G.nc + F.nc > (wide_pos[F.c0 + F.nc - 1] ? kWidePanelW : kPanelW)) break;
+      if (G.parent != f || G.c0 + G.nc != F.c0 || G.nc + F.nc > kPanelW) break;
       std::vector<int32_t>& kf = kids[f];
       auto it = std::find(kf.begin(), kf.end(), g);
       const size_t at = it - kf.begin();
@@ -737,8 +724,6 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     S.fronts[f].level = lv;
     nlev = std::max(nlev, lv + 1);
   }
-  S.level_w.assign(nlev, kFrontW);
-  for (const FrontDesc& F : S.fronts) if (F.nc > kPanelW) S.level_w[F.level] = kWideFrontW;
   CK("borders + amalgamation");
   // children lists, rel / inv maps, A lists, offsets: the sizes first (serial, cheap), then the contents in parallel
   int64_t Loff = 0, Uoff = 0;
@@ -769,7 +754,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       F.a_cnt = F.nc + (offbase[F.c0 + F.nc] - offbase[F.c0]);
       n_a += F.a_cnt;
       int64_t w = 3 * (int64_t)F.nc, r = 3 * (int64_t)F.ns;
-      const int64_t lw = S.level_w[F.level];
+      const int64_t lw = kFrontW;
       F.L_off = Loff; Loff += factor_header((int)lw) + r * lw;
       F.U_off = Uoff; Uoff += (r * r + r + 3) & ~int64_t(1);      // even offsets: the update matrices are read with 16-byte loads
       flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
@@ -835,7 +820,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     int root = nfr - 1;                                    // the last front of the elimination order
     const FrontDesc& Rt = S.fronts[root];
     if (Rt.parent < 0 && Rt.ns == 0 && Rt.level == nlev - 1 && S.level_ptr[nlev] - S.level_ptr[nlev - 1] == 1 &&
-        3 * Rt.nc <= kTopMaxCols && S.level_w[Rt.level] == kFrontW) {
+        3 * Rt.nc <= kTopMaxCols) {
       std::vector<int32_t> chain(1, root);
       int cols = 3 * Rt.nc;
       for (;;) {
@@ -850,7 +835,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
         const FrontDesc& C = S.fronts[next];
         // every border row of the candidate must lie inside the block (it does when the chain ends in a border-less
         // root and the columns are consecutive), its level must use the narrow panels
-        if (cols + 3 * C.nc > kTopMaxCols || S.level_w[C.level] != kFrontW) break;
+        if (cols + 3 * C.nc > kTopMaxCols) break;
         chain.push_back(next);
         cols += 3 * C.nc;
       }

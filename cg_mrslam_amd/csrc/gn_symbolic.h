@@ -18,20 +18,14 @@ namespace cgmr {
 
 constexpr int kPanelW = 16;          // max poses (block columns) per front -> 48 scalar columns
 constexpr int kFrontW = 3 * kPanelW; // scalar columns per front (all panel strides are padded to this)
-// Near the top of the elimination tree, where a level holds a handful of fronts and costs the same ~45 us of dependent
-// memory round trips whatever its fronts hold, separators are cut into panels of up to 32 poses instead: a level that
-// holds such a front is run by the 96-column instances of the kernels (every front of that level is padded to 96).
-constexpr int kWidePanelW = 32;
-constexpr int kWideFrontW = 3 * kWidePanelW;
 constexpr int64_t factor_header(int w) { return 2 * (int64_t)w * w + w; }   // L11 row-major, L11 column-major, 1/diag
-constexpr int kWideChunkRows = 100;  // border rows per work item in a level of 96-column fronts (LDS: 96 x 97 F11 + the chunk)
-constexpr int kChunkRows = 191;      // most border rows a k_front_factor workgroup can take: 3 wavefronts minus the lane that
-                                     // carries the right-hand side through the factorisation
+constexpr int kChunkRows = 159;      // most border rows a k_front_factor workgroup can take: the elimination passes of the
+                                     // panel factorisation hold 4 x 48 rows below a diagonal block (panel_cholesky.h)
 constexpr int kMidChunkRows = 95;    // border rows per work item above the leaves: a front with a wide border is cut into
                                      // several work items (each factors F11 again, fetches only the children's rows it owns):
                                      // measured 191 / 127 / 95 / 63 / 47 rows -> 8.1 / 8.0 / 7.7 / 7.8 / 7.75 ms device on C2
 
-constexpr int kLeafChunkRows = 62;   // the same for a level of leaves (k_front_factor_leaf: three workgroups per CU, 48 KB of LDS each)
+constexpr int kLeafChunkRows = 63;   // the same for a level of leaves (k_front_factor_leaf: three workgroups per CU, 48 KB of LDS each)
 
 // A child is "small" when kSmallSlabLoads 16-byte loads per thread (256 threads, one column pair of one row each) cover
 // the whole leading slab of its update matrix: k_front_factor fetches all small children of a front in one round.
@@ -98,7 +92,6 @@ struct Symbolic {
   std::vector<int32_t> alist;          // triples (block id [0..nf) diag / nf+k offdiag, local row block, local col block)
   std::vector<int32_t> level_ptr;      // nlevels+1, fronts sorted by level in level_fronts
   std::vector<int32_t> level_fronts;
-  std::vector<int32_t> level_w;        // per level: scalar columns of its fronts' panels (kFrontW, or kWideFrontW if any front is wide)
   std::vector<int32_t> col_front;      // permuted block column -> owning front
   // Top block: the last fronts of the root's chain (each the parent of the one before, consecutive columns, the root
   // has no border) whose columns together fit one workgroup's LDS as a dense matrix.  One launch assembles, factors

@@ -175,45 +175,6 @@ def test_graphslam_mirror_and_g2o_io(ctx, oracle, tmp_path):
     assert abs(gs2.chi2() - chi2[-1]) / chi2[-1] < 1e-2        # default .g2o precision is lossy
 
 
-_WIDE_CHILD = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-from cg_mrslam_amd import synth, Context
-from cg_mrslam_amd._lib import gn_symbolic_info
-from oracle import oracle as O
-ctx = Context(0)
-for (V, E, seed) in ((3000, 12000, 11), (6000, 20000, 12)):
-    g = synth.make_pose_graph(V, E, seed=seed)
-    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
-    info = gn_symbolic_info(V, g["fixed"], g["edge_from"], g["edge_to"])
-    rc, p, chi = ctx.gn_optimize(*a, 8)
-    st, p2, chi2, _ = O.gn_optimize(*a, 8)
-    assert rc == 0 and st == 0
-    assert abs(chi[-1] - chi2[-1]) <= 1e-8 * chi2[-1], (chi[-1], chi2[-1])
-    assert np.abs(p[:, :2] - p2[:, :2]).max() <= 1e-6
-    assert np.abs(synth.normalize_theta(p[:, 2] - p2[:, 2])).max() <= 1e-7
-    q = np.arange(1, V, max(1, V // 40))[:32]
-    cov = ctx.marginals(p, g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"], q)
-    st, cov2 = O.marginals(p, g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"], q)
-    assert st == 0
-    assert np.abs(cov - cov2).max() <= 1e-6 * np.abs(cov2).max()
-    print("levels", info["levels"], "fronts", info["fronts"])
-"""
-
-
-@pytest.mark.parametrize("height", [3, 5])
-def test_wide_fronts_match_oracle(height):
-    """The 96-column instances of the panel kernels (off by default: CGMR_WIDE_MIN_HEIGHT is read once per process,
-    hence the subprocess): GN and marginals against the oracle on graphs whose upper tree levels become wide."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CGMR_WIDE_MIN_HEIGHT=str(height))
-    out = subprocess.run([sys.executable, "-c", _WIDE_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert "levels" in out.stdout
-
-
 def test_symbolic_cache_is_bit_identical_and_ignores_the_fixed_set(ctx, oracle):
     """The analysis depends on the edge list only: optimize() with another fixed set, the covariance estimate and a
     second optimize() on the same edges are served from the cache, and a cached call returns exactly the bits of an
