@@ -98,28 +98,36 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.h_level_chrows.assign(D.nlevels, 1);
   D.h_level_leaf.assign(D.nlevels, 1);
   D.h_level_chunk.assign(D.nlevels, kChunkRows);
+  // update tiles run in the launch the schedule gave their front (sched_t: its own level or, with slack, a later one)
+  std::vector<std::vector<int32_t>> sched(D.nlevels);
+  for (int q = 0; q < (int)LF.size(); q++) {
+    const FrontDesc& F = S.fronts[LF[q]];
+    if (F.ns > 0) sched[std::min(F.sched_t, D.nlevels - 1)].push_back(LF[q]);
+  }
+  for (auto& v : sched) std::sort(v.begin(), v.end());
+  std::vector<int32_t> rec0_of(S.fronts.size(), -1);        // a front's first work record: the update tiles address the front through it
   for (int l = 0; l < D.nlevels; l++) {
     for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++)
       if (S.fronts[LF[q]].nchild > 0) D.h_level_leaf[l] = 0;
-    // a level of leaves runs the register-light variant of the factor kernel: shorter chunks, so that the LDS of two
-    // workgroups fits a CU
+    // a level of leaves gets shorter chunks, so that the LDS of three workgroups fits a CU
     const int chunk_rows = (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
     D.h_level_chunk[l] = chunk_rows;
     int nwork = 0;
-    int xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};                     // update tiles per XCD (see the tile list below)
     for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++) {
       const int r = 3 * S.fronts[LF[q]].ns;
+      rec0_of[LF[q]] = D.h_work_ptr[l] + nwork;
       nwork += std::max(1, (r + chunk_rows - 1) / chunk_rows);
       D.h_level_chrows[l] = std::max(D.h_level_chrows[l], std::min(r, chunk_rows) + 1);
-      if (r > 0) { const int T = (r + 31) / 32; *std::min_element(xload, xload + 8) += T * (T + 1) / 2; }
+    }
+    int xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};                     // update tiles per XCD (see the tile list below)
+    for (int f : sched[l]) {
+      const int T = (3 * S.fronts[f].ns + 31) / 32;
+      *std::min_element(xload, xload + 8) += T * (T + 1) / 2;
     }
     D.h_tile_ptr[l + 1] = D.h_tile_ptr[l] + 8 * *std::max_element(xload, xload + 8);
     D.h_work_ptr[l + 1] = D.h_work_ptr[l] + nwork;
   }
   const size_t n_tiles = (size_t)D.h_tile_ptr[D.nlevels], n_work = (size_t)D.h_work_ptr[D.nlevels];
-  // H blocks are stored in the order their fronts assemble them (alist order): k_assemble writes block b to
-  // slot blk_slot[b]; apack[slot] = local row block | local column block << 16
-  const size_t nblk = S.alist.size() / 3;
   BlobLayout B;
   size_t o_fronts = B.add<FrontDesc>(S.fronts.size());
   size_t o_fronts_lv = B.add<FrontDesc>(S.fronts.size());   // the same descriptors in level order: the solves index them by workgroup
@@ -127,8 +135,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_children = B.add<int32_t>(S.children.size());
   size_t o_rel = B.add<int32_t>(S.rel.size());
   size_t o_inv = B.add<int32_t>(S.inv.size());
-  size_t o_apack = B.add<int32_t>(nblk);
-  size_t o_slot = B.add<int32_t>(nblk);
+  size_t o_bdst = B.add<int32_t>(S.blk_dst.size());
+  size_t o_rdst = B.add<int32_t>(S.b_dst.size());
   size_t o_lf = B.add<int32_t>(S.level_fronts.size());
   size_t o_tiles = B.add<int32_t>(3 * n_tiles);
   size_t o_work = B.add<WorkRec>(n_work);
@@ -152,6 +160,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_u = N.add<double>((size_t)3 * S.rows.size() + 3);
   size_t o_L = N.add<double>((size_t)S.L_doubles + 1);
   size_t o_U = N.add<double>((size_t)S.U_doubles + 1);
+  size_t o_pan = N.add<double>((size_t)S.pan_doubles + 2);
   size_t o_chi = N.add<double>((size_t)iters + 2);
   size_t o_status = N.add<int>(4);
   size_t o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
@@ -174,15 +183,10 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
         for (int l = 0; l < D.nlevels; l++) {
           const int chunk_rows = D.h_level_chunk[l];
           int w = D.h_work_ptr[l];
-          int32_t* tl = tiles + 3 * (size_t)D.h_tile_ptr[l];
-          const int slots = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
-          for (int k = 0; k < slots; k++) { tl[3 * k] = -1; tl[3 * k + 1] = 0; tl[3 * k + 2] = 0; }
-          int xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++) {
             const int f = LF[q];
             const int r = 3 * S.fronts[f].ns;
             const int nchunk = std::max(1, (r + chunk_rows - 1) / chunk_rows);
-            const int rec0 = w;                  // the front's first work record: the update tiles address the front through it
             for (int c = 0; c < nchunk; c++) {
               WorkRec& wr = work[w++];
               memset(&wr, 0, sizeof wr);
@@ -196,27 +200,27 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
                 wc.rel_off = G.rel_off; wc.inv_off = G.inv_off; wc.rows_off = G.rows_off;
               }
             }
-            if (r == 0) continue;                // a root: no update matrix
-            const int T = (r + 31) / 32;
+          }
+          int32_t* tl = tiles + 3 * (size_t)D.h_tile_ptr[l];
+          const int slots = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
+          for (int k = 0; k < slots; k++) { tl[3 * k] = -1; tl[3 * k + 1] = 0; tl[3 * k + 2] = 0; }
+          int xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int f : sched[l]) {
+            const int T = (3 * S.fronts[f].ns + 31) / 32;
             const int x = (int)(std::min_element(xload, xload + 8) - xload);
             for (int ti = 0; ti < T; ti++)
               for (int tj = 0; tj <= ti; tj++) {
                 int32_t* e = tl + 3 * (size_t)(8 * xload[x]++ + x);
-                e[0] = rec0; e[1] = ti; e[2] = tj;
+                e[0] = rec0_of[f]; e[1] = ti; e[2] = tj;
               }
           }
         }
         break;
       }
-      case 1: {
-        int32_t* apack = reinterpret_cast<int32_t*>(h + o_apack);
-        int32_t* blk_slot = reinterpret_cast<int32_t*>(h + o_slot);
-        for (size_t q = 0; q < nblk; q++) {
-          apack[q] = S.alist[3 * q + 1] | (S.alist[3 * q + 2] << 16);
-          blk_slot[S.alist[3 * q]] = (int32_t)q;
-        }
+      case 1:
+        put(o_bdst, S.blk_dst.data(), S.blk_dst.size() * 4);
+        put(o_rdst, S.b_dst.data(), S.b_dst.size() * 4);
         break;
-      }
       case 2: {
         put(o_fronts, S.fronts.data(), S.fronts.size() * sizeof(FrontDesc));
         FrontDesc* lv = reinterpret_cast<FrontDesc*>(h + o_fronts_lv);       // Gauss-Newton level order (the backward solve's index)
@@ -257,8 +261,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.children = (int32_t*)(d + o_children);
   D.rel = (int32_t*)(d + o_rel);
   D.inv = (int32_t*)(d + o_inv);
-  D.apack = (int32_t*)(d + o_apack);
-  D.blk_slot = (int32_t*)(d + o_slot);
+  D.blk_dst = (int32_t*)(d + o_bdst);
+  D.b_dst = (int32_t*)(d + o_rdst);
   D.level_fronts = (int32_t*)(d + o_lf);
   D.tiles = (int32_t*)(d + o_tiles);
   D.work = (WorkRec*)(d + o_work);
@@ -281,6 +285,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.uvec = (double*)(d + o_u);
   D.Lbuf = (double*)(d + o_L);
   D.Ubuf = (double*)(d + o_U);
+  D.Pan = (double*)(d + o_pan);
+  D.pan_doubles = S.pan_doubles;
   D.chi2 = (double*)(d + o_chi);
   D.status = (int*)(d + o_status);
   return 0;
@@ -294,7 +300,8 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
   BlobLayout N;
   size_t o_term = N.add<double>((size_t)34 * S.nE), o_A = N.add<double>((size_t)9 * (S.nf + S.nb)), o_b = N.add<double>((size_t)3 * S.nf),
          o_y = N.add<double>((size_t)3 * S.nf), o_x = N.add<double>((size_t)3 * S.nf), o_u = N.add<double>((size_t)3 * S.rows.size() + 3),
-         o_L = N.add<double>((size_t)S.L_doubles + 1), o_U = N.add<double>((size_t)S.U_doubles + 1), o_chi = N.add<double>(8),
+         o_L = N.add<double>((size_t)S.L_doubles + 1), o_U = N.add<double>((size_t)S.U_doubles + 1),
+         o_pan = N.add<double>((size_t)S.pan_doubles + 2), o_chi = N.add<double>(8),
          o_status = N.add<int>(4), o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
   const size_t per = (N.off + 255) & ~size_t(255);
   int rc = arena_reserve(ctx, ctx->rep_arena, per * (size_t)std::max(n, 1) + 256);
@@ -304,7 +311,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
     char* d = ctx->rep_arena.ptr + per * (size_t)i;
     GnDevice& D = out[i];
     D.term = (double*)(d + o_term); D.Ablk = (double*)(d + o_A); D.bvec = (double*)(d + o_b); D.yvec = (double*)(d + o_y);
-    D.xvec = (double*)(d + o_x); D.uvec = (double*)(d + o_u); D.Lbuf = (double*)(d + o_L); D.Ubuf = (double*)(d + o_U);
+    D.xvec = (double*)(d + o_x); D.uvec = (double*)(d + o_u); D.Lbuf = (double*)(d + o_L); D.Ubuf = (double*)(d + o_U); D.Pan = (double*)(d + o_pan);
     D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.cmask = (uint8_t*)(d + o_cmask);
   }
   return 0;
@@ -434,11 +441,13 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
     T.run(2, 1, [&] { launch_chi2(st, D, D.chi2 + it); });
     return;
   }
+  // the assembled panels start from zero: H blocks and b (k_assemble), then the children's contributions level by level
+  if (D.pan_doubles > 0) (void)hipMemsetAsync(D.Pan, 0, sizeof(double) * (size_t)D.pan_doubles, st);
   T.run(1, 1, [&] { launch_assemble(st, D); });                // + the chi2 sum of this iteration (slot = iterations done)
   static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;
   if (trace)
-    fprintf(stderr, "[cgmr] arena %p .. %p; work %p rel %p apack %p Ablk %p bvec %p yvec %p uvec %p Lbuf %p Ubuf %p chi2 %p\n",
-            (void*)ctx->gn_arena.ptr, (void*)(ctx->gn_arena.ptr + ctx->gn_arena.cap), (void*)D.work, (void*)D.rel, (void*)D.apack,
+    fprintf(stderr, "[cgmr] arena %p .. %p; work %p rel %p Pan %p Ablk %p bvec %p yvec %p uvec %p Lbuf %p Ubuf %p chi2 %p\n",
+            (void*)ctx->gn_arena.ptr, (void*)(ctx->gn_arena.ptr + ctx->gn_arena.cap), (void*)D.work, (void*)D.rel, (void*)D.Pan,
             (void*)D.Ablk, (void*)D.bvec, (void*)D.yvec, (void*)D.uvec, (void*)D.Lbuf, (void*)D.Ubuf, (void*)D.chi2);
   for (int l = 0; l < D.nlevels; l++) {
     if (trace) {

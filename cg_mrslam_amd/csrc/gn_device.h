@@ -17,7 +17,7 @@ struct GnDevice {
   FrontDesc* fronts_lv = nullptr;        // descriptors sorted by level (front q of the level order = fronts[level_fronts[q]])
   int32_t *rows = nullptr, *children = nullptr, *rel = nullptr, *inv = nullptr;
   WorkRec* work = nullptr;          // (front, chunk) work items of k_front_factor, level by level
-  int32_t *level_fronts = nullptr, *tiles = nullptr, *apack = nullptr, *blk_slot = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;
+  int32_t *level_fronts = nullptr, *tiles = nullptr, *blk_dst = nullptr, *b_dst = nullptr, *asm_ptr = nullptr, *asm_src = nullptr, *vperm = nullptr;
   int32_t *ef = nullptr, *et = nullptr;
   int32_t *off_row = nullptr, *off_col = nullptr;   // permuted row / column of every off-diagonal H block
   uint8_t* cmask = nullptr;              // per permuted column: 1 = taken out of the system for this pass (fixed vertex, or
@@ -25,6 +25,8 @@ struct GnDevice {
   // numeric work space
   double *term = nullptr, *Ablk = nullptr, *bvec = nullptr, *yvec = nullptr, *xvec = nullptr, *uvec = nullptr;
   double *Lbuf = nullptr, *Ubuf = nullptr;
+  double* Pan = nullptr;                 // assembled panels of all fronts (gn_symbolic.h: FrontDesc::pan_off), zeroed before every assembly
+  int64_t pan_doubles = 0;
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
   // top block (k_top_block): the last fronts of the root's chain, handled by one workgroup in LDS

@@ -31,47 +31,29 @@ namespace {
 
 constexpr int TS = 32;               // tile edge of k_front_update
 constexpr int kRecIntsC = (int)(sizeof(WorkRec) / 4);
-constexpr int kMapW = 256;           // child rows per staged block of the row map (one per thread)
 
-// Every kernel that touches a factor panel is instantiated for the two panel widths, W = 48 scalar columns (fronts of
-// up to 16 poses) and W = 96 (the wide fronts near the top of the tree); all fronts of a level share the width.
-// Factor panel layout in Lbuf (doubles, all strides padded to W columns):
+// Factor panel layout in Lbuf (doubles, all strides padded to W = 48 columns; the kernels that touch it keep the width
+// as a template parameter):
 //   [0, W*W)        L11 row-major   (lower triangle, zeros above)      -> backward solve
 //   [W*W, 2*W*W)    L11 column-major                                   -> forward solve of the marginals
 //   [2*W*W, +W)     1 / diag(L11)
 //   [2*W*W+W, ...)  L21, r rows of W
-// LDS plan of k_front_factor (bytes):
-//   Ls   [W][LDW]  doubles   F11 (assembly), factored in place
-//   maps: s_rmap[MAXC][kMapW] (child row -> LDS offset of the panel row it is added into, map_dst()), s_cmap[MAXC][W]
-//        (child column -> my column) shorts; the work record
-//   Dinv [W] doubles: reciprocals of the pivots
-//   R    [ch_rows][LDW] doubles   chunk of F21 + the rhs row; ch_rows is the level's maximum.  R comes last: a level
-//        whose fronts have few border rows is launched with less LDS, so that several workgroups share a CU.
 #define CGMR_FRONT_CONSTS(WW)                                                                              \
   [[maybe_unused]] constexpr int W = (WW);                                                                 \
   [[maybe_unused]] constexpr int LDW = W + 1; /* LDS row stride (doubles), odd => conflict-free b64 column access */ \
   [[maybe_unused]] constexpr int kL11c = W * W;                                                            \
   [[maybe_unused]] constexpr int kDinv = 2 * W * W;                                                        \
-  [[maybe_unused]] constexpr int kL21 = 2 * W * W + W;                                                     \
-  [[maybe_unused]] constexpr int kOffLs = 0;                                                               \
-  [[maybe_unused]] constexpr int kOffRmap = kOffLs + W * LDW * 8;                                          \
-  [[maybe_unused]] constexpr int kOffCmap = kOffRmap + 2 * kWorkChildren * kMapW;                          \
-  [[maybe_unused]] constexpr int kOffRec = ((kOffCmap + 2 * kWorkChildren * W + 15) / 16) * 16;            \
-  [[maybe_unused]] constexpr int kOffDinv = ((kOffRec + 4 * kRecIntsC + 15) / 16) * 16;                    \
-  [[maybe_unused]] constexpr int kOffR = ((kOffDinv + W * 8 + 15) / 16) * 16;                              \
-  [[maybe_unused]] constexpr int kRIdx = (kOffR - kOffLs) / 8 /* R[0] as an index from Ls */
+  [[maybe_unused]] constexpr int kL21 = 2 * W * W + W
 
-// LDS bytes of a k_front_factor workgroup whose staging area holds `rows` rows (border rows of the chunk + the rhs row)
-constexpr int factor_smem_bytes(int w, int rows) {
-  const int ldw = w + 1;
-  const int off_cmap = w * ldw * 8 + 2 * kWorkChildren * kMapW;
-  const int off_rec = ((off_cmap + 2 * kWorkChildren * w + 15) / 16) * 16;
-  const int off_dinv = ((off_rec + 4 * kRecIntsC + 15) / 16) * 16;
-  const int off_r = ((off_dinv + w * 8 + 15) / 16) * 16;
-  return off_r + ((w + rows + 15) / 16 * 16 - w) * ldw * 8;    // panel rows padded to a multiple of 16 (panel_cholesky.h)
-}
-static_assert(factor_smem_bytes(kFrontW, kChunkRows + 1) <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
-static_assert(3 * factor_smem_bytes(kFrontW, kLeafChunkRows + 1) <= 160 * 1024, "leaf variant: three workgroups per CU");
+// LDS plan of k_front_factor: the panel [F11 (48 rows); border rows of the chunk; rhs row], rows padded to a multiple of 16
+// (panel_cholesky.h), row stride 49 doubles (48 columns + the border-vector column), then the 48 pivot reciprocals.
+// `rows` = rows below F11 (the level's largest chunk + 1): a level with short borders is launched with less LDS, so
+// that several workgroups share a CU.
+constexpr int factor_panel_rows(int rows) { return (kFrontW + rows + 15) / 16 * 16; }
+constexpr int factor_smem_bytes(int rows) { return (factor_panel_rows(rows) * (kFrontW + 1) + kFrontW) * 8; }
+static_assert(factor_smem_bytes(kChunkRows + 1) <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
+static_assert(3 * factor_smem_bytes(kLeafChunkRows + 1) <= 160 * 1024, "a level of leaves: three workgroups per CU");
+static_assert(2 * factor_smem_bytes(kMidChunkRows + 1) <= 160 * 1024, "above the leaves: two workgroups per CU");
 static_assert(kFrontW + kChunkRows + 1 <= 208, "panel_cholesky: at most 4 x 48 rows below a diagonal block");
 
 __device__ __forceinline__ double d_normalize_theta(double t) {
@@ -196,11 +178,13 @@ __device__ __forceinline__ void block_chi2_sum(int nP, const double* __restrict_
 // couples to it.  The same mask removes vertices all of whose edges are switched off for this pass.
 __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const int32_t* __restrict__ asm_ptr,
                                                   const int32_t* __restrict__ asm_src,
-                                                  const int32_t* __restrict__ blk_slot,
+                                                  const int32_t* __restrict__ blk_dst,
+                                                  const int32_t* __restrict__ b_dst,
                                                   const uint8_t* __restrict__ cmask,
                                                   const int32_t* __restrict__ off_row,
                                                   const int32_t* __restrict__ off_col,
                                                   const double* __restrict__ term, double* __restrict__ Ablk,
+                                                  double* __restrict__ Pan,
                                                   double* __restrict__ bvec, double* __restrict__ chi_out,
                                                   const int* __restrict__ status) {
   if (blockIdx.x == gridDim.x - 1) {
@@ -221,7 +205,11 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
     }
     if (blk < nf) { if (cmask[blk]) acc = (el % 4 == 0) ? 1.0 : 0.0; }
     else if (cmask[off_row[blk - nf]] | cmask[off_col[blk - nf]]) acc = 0.0;
-    Ablk[(size_t)blk_slot[blk] * 9 + el] = acc;      // stored in the order the owning front assembles its blocks
+    // straight into the owning front's assembled panel (element (i, j) of the block: i rows of kPanStride down, j
+    // columns right); the blocks of the top block's fronts stay in Ablk, in the order k_top_block assembles them
+    const int dst = blk_dst[blk];
+    if (dst >= 0) Pan[(size_t)dst + (el / 3) * kPanStride + el % 3] = acc;
+    else Ablk[(size_t)(-dst - 1) * 9 + el] = acc;
     return;
   }
   t -= nblk * 9;
@@ -233,7 +221,10 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
       int edge = src >> 2, code = src & 3;
       acc += term[(size_t)edge * 33 + (code == 0 ? 27 : 30) + r];
     }
-    bvec[t] = cmask[v] ? 0.0 : acc;
+    acc = cmask[v] ? 0.0 : acc;
+    bvec[t] = acc;
+    const int dst = b_dst[v];
+    if (dst >= 0) Pan[(size_t)dst + r] = acc;                  // right-hand-side row of the owning front's panel
   }
 }
 
@@ -269,16 +260,15 @@ __device__ unsigned long long g_utime[2 * 64];             // per level of k_fro
 #define FPHASE(i)
 #endif
 
-constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record / whose maps are staged together
+constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record
 constexpr int kRecInts = kRecIntsC;
-constexpr int MAPW = kMapW;
-constexpr int SU = 24;               // double2 loads per thread and block: 256 rows x 48 columns of a child's leading slab
 // Update matrix of a front with r border rows, the first ra of which fall into its parent's own columns
 // (Ubuf + U_off, U_off even):
 //   slab A  [r][ra2]       columns 0..ra-1 of every row (rows < ra: lower triangle valid),
-//                          row stride ra2 = ra rounded up to even                           -> parent's F11 / F21
-//   slab B  [r-ra][r-ra]   the trailing block, lower triangle valid                          -> parent's update matrix
-// Both are read front to back by the parent: contiguous 16-byte loads instead of a gather.
+//                          row stride ra2 = ra rounded up to even      -> parent's F11 / F21: since round 3 these cells are
+//                          added straight into the parent's assembled panel (Pan) by the update tiles and exist in Ubuf
+//                          only for the children of the top block
+//   slab B  [r-ra][r-ra]   the trailing block, lower triangle valid    -> parent's update matrix
 __device__ __forceinline__ int even_up(int v) { return (v + 1) & ~1; }
 __device__ __forceinline__ size_t uidx(int gi, int gj, int r, int ra) {
   const int ra2 = even_up(ra);      // row stride of slab A: rows start on 16-byte boundaries
@@ -289,339 +279,133 @@ __device__ __forceinline__ long long rfl64(long long v) {
   return ((long long)rfl((int)(v >> 32)) << 32) | (unsigned)rfl((int)v);
 }
 
-// LDS += without a return value: one ds_add_f64, nothing to wait for.  The cells written by one call site never
-// collide (see slab_scatter), so this is not used for atomicity but because plain read-modify-writes through
-// possibly aliasing pointers are serialised by the compiler (one LDS round trip per element).
+// LDS += without a return value: one ds_add_f64, nothing to wait for (k_top_block's extend-add).
 typedef __attribute__((address_space(3))) double lds_double;
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __builtin_amdgcn_ds_atomic_fadd_f64((lds_double*)p, v);
 }
 
-// Row map entry of a child row whose position in the parent's row list is `pos` (0..w-1 own columns, w.. border): the
-// LDS offset (doubles from Ls) of the panel row it is added into, or -1 if that row belongs to another work item.
-template <int WW>
-__device__ __forceinline__ short map_dst(int pos, int w, int r0, int nr) {
-  CGMR_FRONT_CONSTS(WW);
-  const int pr = pos - w - r0;
-  return (short)(pos < w ? pos * LDW : (pr >= 0 && pr < nr) ? kRIdx + pr * LDW : -1);
-}
-
-// One block of a child's leading slab plus the matching piece of its border vector, as loaded by one thread.
-// Thread = (column pair cp, row lane rr): it owns columns 2cp, 2cp+1 of rows rr, rr + rpp, rr + 2 rpp, ... of the
-// block, so one column-map lookup and one row-map lookup per load.  Everything is issued by slab_issue() before
-// slab_scatter<WW>() touches any of it.
-template <int N>
-struct SlabLoadsT {
-  double2 v[N];
-  double u;
-};
-typedef SlabLoadsT<SU> SlabLoads;
-struct SlabGeom {
-  int cpw, rpp, rr, cp, rows;         // column pairs per row, rows per pass, my row lane / column pair, rows per block
-};
-template <int N = SU>
-__device__ __forceinline__ SlabGeom slab_geom(int tid, int ra) {
-  SlabGeom g;
-  g.cpw = max((ra + 1) >> 1, 1);
-  g.rpp = 256 / g.cpw;
-  g.rr = tid / g.cpw;
-  g.cp = tid - g.rr * g.cpw;
-  g.rows = min(MAPW, g.rpp * N);
-  return g;
-}
-
-template <int N>
-__device__ __forceinline__ void slab_issue(SlabLoadsT<N>& S, const SlabGeom& g, int tid, const double* __restrict__ U,
-                                           const double* __restrict__ uc, int rg, int ra2, int row0,
-                                           const short* rmap) {
-  const int rend = min(rg, row0 + g.rows);
-#pragma unroll
-  for (int u = 0; u < N; u++) {
-    const int row = row0 + g.rr + g.rpp * u;
-    // rows that land in another work item's border rows are not fetched (a front cut into several work items streams
-    // each child once in total, not once per work item)
-    const bool ok = g.rr < g.rpp && row < rend && rmap[min(g.rr + g.rpp * u, g.rows - 1)] >= 0;
-    S.v[u] = *reinterpret_cast<const double2*>(U + (ok ? (size_t)row * ra2 + 2 * g.cp : 0));   // idle lanes re-read element 0
-  }
-  S.u = uc[min(row0 + tid, rg - 1)];
-}
-
-// Add the block into F11 (Ls), this chunk's F21 rows and rhs row / border-vector column (R, which directly
-// lies kRIdx doubles behind Ls in LDS: one index space).  rmap[k] = map_dst() of child row row0 + k, cmap = my column
-// of child row / column 0..ra-1.  A child never sends two elements to the same cell, so the adds of one call do not
-// collide; calls for different children are separated by a barrier.
-template <int WW, int N>
-__device__ __forceinline__ void slab_scatter(const SlabLoadsT<N>& S, const SlabGeom& g, int tid, int rg, int ra, int row0,
-                                             const short* rmap, const short* cmap, int w, int r0, int nr, double* Ls) {
-  CGMR_FRONT_CONSTS(WW);
-  const int rend = min(rg, row0 + g.rows);
-  // every map lookup first ...
-  int dst[N];
-#pragma unroll
-  for (int u = 0; u < N; u++) dst[u] = rmap[min(g.rr + g.rpp * u, g.rows - 1)];
-  const int col0 = 2 * g.cp, col1 = 2 * g.cp + 1;
-  const int pc0 = cmap[min(col0, max(ra - 1, 0))], pc1 = cmap[min(col1, max(ra - 1, 0))];
-  const int dstu = rmap[min(tid, g.rows - 1)];
-  // ... then the adds
-#pragma unroll
-  for (int u = 0; u < N; u++) {
-    const int row = row0 + g.rr + g.rpp * u;
-    if (!(g.rr < g.rpp && row < rend) || dst[u] < 0) continue;
-    // rows of the leading block (row < ra) hold their lower triangle only
-    if (col0 < ra && (row >= ra || col0 <= row)) lds_add(Ls + dst[u] + pc0, S.v[u].x);
-    if (col1 < ra && (row >= ra || col1 <= row)) lds_add(Ls + dst[u] + pc1, S.v[u].y);
-  }
-  if (tid < g.rows && row0 + tid < rg && dstu >= 0) {            // border vector of the child
-    if (dstu < kRIdx) lds_add(Ls + kRIdx + nr * LDW + dstu / LDW, S.u);   // an own column: the rhs row
-    else lds_add(Ls + dstu + W, S.u);                            // a border row of this work item: its column W
-  }
-}
-
-constexpr int SUS = kSmallSlabLoads;   // loads per thread that cover the whole leading slab of a "small" child (gn_symbolic.h)
-
-// child ci of the front: descriptor from the work record (first MAXC children) or from the front table
-__device__ __forceinline__ WorkChild get_child(const WorkRec* WR, const FrontDesc* __restrict__ fronts,
-                                               const int32_t* __restrict__ children, int child_off, int ci) {
-  if (ci < MAXC) return WR->ch[ci];
-  const FrontDesc G = fronts[children[child_off + ci]];
-  WorkChild c;
-  c.U_off = G.U_off; c.ns = G.ns; c.na = G.na; c.rel_off = G.rel_off; c.inv_off = G.inv_off; c.rows_off = G.rows_off;
-  c.pad = 0;
-  return c;
-}
-
 // One workgroup per work item = (front, chunk of `chunk_rows` border rows) of the current level.  A lone workgroup
-// pulls cold data at 10-25 bytes per clock and pays ~2500 clocks per dependent round trip
-// (tools/ubench/cu_read_ubench.hip), so the assembly is organised around few round trips and contiguous wide loads:
-//   (1) the work record -- front descriptor plus the descriptors of its first MAXC children -- into LDS while
-//       LDS is being cleared;
-//   (2) everything addressed by the record: the rhs, this front's H blocks (stored contiguously in assembly
-//       order), the children's row maps (child row -> LDS offset of the panel row it lands in, map_dst());
-//   (3) the children's leading slabs, streamed front to back with 16-byte loads -- the big children first, two in
-//       flight, then all small ones in one round -- and scattered into LDS through the maps; rows that belong to
-//       another work item of the front are not fetched.  Children are added in a fixed order with a barrier in
-//       between: no atomics, bit-reproducible.
-// Then the blocked factorisation of the panel in LDS (see below) and the stores.  Every work item of a front factors
-// F11 again (nobody waits for anybody) and owns its rows of L21.  The update matrix U = ext_add - L21 L21^T of every
-// front is formed by k_front_update, whose tiles spread over the idle CUs: forming it here (tried for fronts of up to
-// 96 border rows) made those fronts the slowest workgroup of their level.
-// LEAF: the level has no children at all -- rounds (2b) and (3) compile away, a quarter of the registers.
-template <bool LEAF, int WW>
-__device__ __forceinline__ void front_factor_body(unsigned char* smem, const WorkRec* __restrict__ work, int work_begin,
-                                                  const FrontDesc* __restrict__ fronts,
-                                                  const int32_t* __restrict__ children,
-                                                  const int32_t* __restrict__ rel,
-                                                  const int32_t* __restrict__ apack,
-                                                  const double* __restrict__ Ablk, double* __restrict__ Lbuf,
-                                                  double* __restrict__ Ubuf, const double* __restrict__ bvec,
-                                                  double* __restrict__ yvec, double* __restrict__ uvec,
-                                                  int* __restrict__ status, int level_id,
-                                                  int write_l11c, int ch_rows, int chunk_rows) {
-  CGMR_FRONT_CONSTS(WW);
-  double* Ls = reinterpret_cast<double*>(smem + kOffLs);
-  double* R = reinterpret_cast<double*>(smem + kOffR);
-  short* s_rmap = reinterpret_cast<short*>(smem + kOffRmap);
-  short* s_cmap = reinterpret_cast<short*>(smem + kOffCmap);
-  int* s_rec = reinterpret_cast<int*>(smem + kOffRec);
-  double* Dinv = reinterpret_cast<double*>(smem + kOffDinv);
+// pays ~2500 clocks per dependent round trip to memory and pulls cold data at 10-25 bytes per clock
+// (tools/ubench/cu_read_ubench.hip), so the kernel is two round trips and no more:
+//   (1) the work record (scalar loads: front, chunk, where the panel lies);
+//   (2) the front's ASSEMBLED panel -- F11, this chunk's border rows, the right-hand-side row: three contiguous pieces
+//       of Pan, every 16-byte load of the workgroup in flight at once.  H blocks and b were put there by k_assemble,
+//       the leading slab and the border vector of every child by that child's update tiles (k_front_update) in an
+//       earlier launch; a front whose children shared a launch has up to kMaxPanSlots copies, summed here in a fixed
+//       order.  (Round 2 streamed the children's slabs into LDS here, through row / column maps and ds_add_f64: 17-24k of
+//       a work item's 65k cycles, and 3.6k for the maps, the H blocks and the rhs before that.)
+// Then the blocked factorisation of the panel in LDS (panel_cholesky.h) and the stores.  Every work item of a front
+// factors F11 again (nobody waits for anybody) and owns its rows of L21.  The update matrix U = ext_add - L21 L21^T of
+// every front is formed by k_front_update, whose tiles spread over the idle CUs.
+constexpr int kPanLoads = 15;        // 16-byte loads per thread and round: 3840 double2 = a 95-row chunk's panel in one round
+__global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
+                                                      const double* __restrict__ Pan, double* __restrict__ Lbuf,
+                                                      double* __restrict__ yvec, double* __restrict__ uvec,
+                                                      int* __restrict__ status, int level_id, int write_l11c, int chunk_rows) {
+  CGMR_FRONT_CONSTS(kFrontW);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* P = reinterpret_cast<double*>(smem);
   const int tid = threadIdx.x;
 #ifdef CGMR_PHASE_TIMING
   if (tid == 0 && work_begin + (int)blockIdx.x < 8192) g_wtime[2 * (work_begin + blockIdx.x)] = __builtin_amdgcn_s_memrealtime();
 #endif
   PHASE(0);
-  // ---- round 1: the work record; LDS is cleared while it is in flight
-  {
-    const int* g = reinterpret_cast<const int*>(work + work_begin + blockIdx.x);
-    if (tid < kRecInts) s_rec[tid] = g[tid];
-  }
-  for (int q = tid; q < W * LDW; q += 256) Ls[q] = 0.0;
-  for (int q = tid; q < ch_rows * LDW; q += 256) R[q] = 0.0;
-  __syncthreads();
-  PHASE(1);
-  const WorkRec* WR = reinterpret_cast<const WorkRec*>(s_rec);
-  const int c0 = rfl(WR->F.c0), nc = rfl(WR->F.nc), ns = rfl(WR->F.ns), rows_off = rfl(WR->F.rows_off);
-  const int child_off = rfl(WR->F.child_off), nchild = rfl(WR->F.nchild);
-  const int a_off = rfl(WR->F.a_off), a_cnt = rfl(WR->F.a_cnt), chunk = rfl(WR->chunk);
-  const long long L_off = rfl64(WR->F.L_off);
+  // ---- round 1: the work record
+  const WorkRec* WR = work + work_begin + blockIdx.x;
+  const int c0 = WR->F.c0, nc = WR->F.nc, ns = WR->F.ns, rows_off = WR->F.rows_off, chunk = WR->chunk, slots = WR->F.pan_slots;
+  const long long L_off = WR->F.L_off, pan_off = WR->F.pan_off;
   const int w = 3 * nc, r = 3 * ns;
   const int r0 = chunk * chunk_rows;
-  const int nr = max(0, min(chunk_rows, r - r0));   // border rows of this chunk; staging row nr carries the rhs
-  // ---- round 2: rhs, H blocks, the children's row maps (first batch, first block) -- every load first ...
-  const int ncb0 = LEAF ? 0 : min(nchild, MAXC);
-  const double bv = (tid < w) ? bvec[3 * c0 + tid] : 0.0;
-  constexpr int AU = 4;
-  const int na9 = a_cnt * 9;
-  double av[AU];
-  int apk[AU];
+  const int nr = max(0, min(chunk_rows, r - r0));   // border rows of this chunk; panel row W + nr carries the rhs
+  const int M = W + nr + 1;                          // rows of the panel
+  double* Dinv = P + factor_panel_rows(nr + 1) * LDW;
+  PHASE(1);
+  // ---- round 2: the panel, as double2 (25 per row: columns 0..47, the border-vector column, one of padding)
+  {
+    constexpr int H2 = kPanStride / 2;
+    const int nA = W * H2, nB = nr * H2, nq = nA + nB + H2;
+    const double2* src = reinterpret_cast<const double2*>(Pan + pan_off);
+    const size_t slot2 = (size_t)pan_size(ns) / 2;
+    for (int base = 0; base < nq; base += 256 * kPanLoads) {
+      double2 v[kPanLoads], v1[kPanLoads];
+      int so[kPanLoads];
 #pragma unroll
-  for (int u = 0; u < AU; u++) {
-    const int q = tid + 256 * u;
-    const bool ok = q < na9;
-    apk[u] = ok ? apack[a_off + q / 9] : -1;
-    av[u] = ok ? Ablk[(size_t)a_off * 9 + q] : 0.0;
-  }
-  int relv[MAXC];
-  if constexpr (!LEAF) {
+      for (int u = 0; u < kPanLoads; u++) {
+        const int q = base + tid + 256 * u;
+        so[u] = q < nA ? q : (q < nA + nB ? (W + r0) * H2 + (q - nA) : (W + r) * H2 + (q - nA - nB));
+        v[u] = q < nq ? src[so[u]] : make_double2(0.0, 0.0);
+      }
+      if (slots > 1) {
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-      const int cs = min(c, max(ncb0 - 1, 0));           // surplus slots repeat a valid child and are ignored below
-      const int rg = 3 * WR->ch[cs].ns;
-      relv[c] = rel[WR->ch[cs].rel_off + min(tid, max(rg - 1, 0)) / 3];
-    }
-  }
-  // ... then the LDS writes
-  if (tid >= w && tid < W) Ls[tid * LDW + tid] = 1.0;        // identity padding of the unused columns
-  if (tid < w) R[nr * LDW + tid] = bv;                        // rhs row: b of my columns (+ children below)
+        for (int u = 0; u < kPanLoads; u++) {
+          const int q = base + tid + 256 * u;
+          v1[u] = q < nq ? src[slot2 + so[u]] : make_double2(0.0, 0.0);
+        }
 #pragma unroll
-  for (int u = 0; u < AU; u++) {
-    if (apk[u] < 0) continue;
-    const int el = (tid + 256 * u) % 9, lr = apk[u] & 0xffff, lc = apk[u] >> 16;
-    if (lr < nc) Ls[(3 * lr + el / 3) * LDW + 3 * lc + el % 3] = av[u];
-    else {
-      int row = 3 * (lr - nc) + el / 3 - r0;
-      if (row >= 0 && row < nr) R[row * LDW + 3 * lc + el % 3] = av[u];
-    }
-  }
-  for (int q = tid + 256 * AU; q < na9; q += 256) {           // fronts with more than 113 H blocks
-    const int pk = apack[a_off + q / 9], el = q % 9, lr = pk & 0xffff, lc = pk >> 16;
-    const double v = Ablk[(size_t)a_off * 9 + q];
-    if (lr < nc) Ls[(3 * lr + el / 3) * LDW + 3 * lc + el % 3] = v;
-    else {
-      int row = 3 * (lr - nc) + el / 3 - r0;
-      if (row >= 0 && row < nr) R[row * LDW + 3 * lc + el % 3] = v;
-    }
-  }
-  if constexpr (!LEAF) {
+        for (int u = 0; u < kPanLoads; u++) { v[u].x += v1[u].x; v[u].y += v1[u].y; }
+        for (int sl = 2; sl < slots; sl++) {
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-      if (c < ncb0) {
-        const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
-        const short pos = (short)(3 * relv[c] + tid % 3);
-        if (tid < rg) s_rmap[c * MAPW + tid] = map_dst<WW>(pos, w, r0, nr);
-        if (tid < ra) s_cmap[c * W + tid] = pos;
+          for (int u = 0; u < kPanLoads; u++) {
+            const int q = base + tid + 256 * u;
+            v1[u] = q < nq ? src[sl * slot2 + so[u]] : make_double2(0.0, 0.0);
+          }
+#pragma unroll
+          for (int u = 0; u < kPanLoads; u++) { v[u].x += v1[u].x; v[u].y += v1[u].y; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kPanLoads; u++) {
+        const int q = base + tid + 256 * u;
+        if (q >= nq) continue;
+        const int row = (q * 5243) >> 17;                    // q / 25 for q < 2^15
+        const int c2 = 2 * (q - H2 * row);
+        double vx = v[u].x, vy = v[u].y;
+        if (row >= w && row < W) {                           // identity padding of the unused columns
+          if (c2 == row) vx = 1.0;
+          if (c2 + 1 == row) vy = 1.0;
+        }
+        P[row * LDW + c2] = vx;
+        if (c2 + 1 < LDW) P[row * LDW + c2 + 1] = vy;
       }
     }
   }
   __syncthreads();
   PHASE(2);
-  // ---- round 3: the children's leading slabs, two children in flight
-  if constexpr (!LEAF) {
-  int nbig = 0;                                               // the big children come first
-  while (nbig < ncb0 && !slab_is_small(WR->ch[nbig].ns, WR->ch[nbig].na)) nbig++;
-  nbig = rfl(nbig);
-  for (int cb = 0; cb < nbig; cb += 2) {
-    SlabLoads S0, S1;
-    const bool two = cb + 1 < nbig;
-    const int cb1 = two ? cb + 1 : cb;
-    const int rg0 = 3 * WR->ch[cb].ns, ra0 = 3 * WR->ch[cb].na;
-    const int rg1 = 3 * WR->ch[cb1].ns, ra1 = 3 * WR->ch[cb1].na;
-    const SlabGeom g0 = slab_geom(tid, ra0), g1 = slab_geom(tid, ra1);
-    const double* U0 = Ubuf + WR->ch[cb].U_off;
-    const double* U1 = Ubuf + WR->ch[cb1].U_off;
-    const double* uc0 = uvec + (size_t)3 * WR->ch[cb].rows_off;
-    const double* uc1 = uvec + (size_t)3 * WR->ch[cb1].rows_off;
-    slab_issue(S0, g0, tid, U0, uc0, rg0, even_up(ra0), 0, s_rmap + cb * MAPW);
-    if (two) slab_issue(S1, g1, tid, U1, uc1, rg1, even_up(ra1), 0, s_rmap + cb1 * MAPW);
-    if (cb > 0) __syncthreads();
-    slab_scatter<WW>(S0, g0, tid, rg0, ra0, 0, s_rmap + cb * MAPW, s_cmap + cb * W, w, r0, nr, Ls);
-    if (two) {
-      __syncthreads();
-      slab_scatter<WW>(S1, g1, tid, rg1, ra1, 0, s_rmap + cb1 * MAPW, s_cmap + cb1 * W, w, r0, nr, Ls);
-    }
-    // children with more border rows than one block: the remaining row blocks, maps staged per block
-    for (int cc = cb; cc <= cb1; cc++) {
-      const int rg = 3 * WR->ch[cc].ns, ra = 3 * WR->ch[cc].na;
-      const SlabGeom g = slab_geom(tid, ra);
-      for (int row0 = g.rows; row0 < rg; row0 += g.rows) {
-        __syncthreads();
-        if (tid < g.rows && row0 + tid < rg)
-          s_rmap[cc * MAPW + tid] = map_dst<WW>(3 * rel[WR->ch[cc].rel_off + (row0 + tid) / 3] + (row0 + tid) % 3, w, r0, nr);
-        __syncthreads();
-        slab_issue(S0, g, tid, Ubuf + WR->ch[cc].U_off, uvec + (size_t)3 * WR->ch[cc].rows_off, rg, even_up(ra), row0,
-                   s_rmap + cc * MAPW);
-        slab_scatter<WW>(S0, g, tid, rg, ra, row0, s_rmap + cc * MAPW, s_cmap + cc * W, w, r0, nr, Ls);
-      }
-    }
-  }
-  // the small children: every load of every child first, then the adds child by child (fixed order, a barrier
-  // between two children: same sums as one child at a time, one memory round trip instead of one per pair)
-  if (nbig < ncb0) {
-    SlabLoadsT<SUS> T[MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-      if (c >= nbig && c < ncb0) {
-        const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
-        const SlabGeom g = slab_geom<SUS>(tid, ra);
-        slab_issue(T[c], g, tid, Ubuf + WR->ch[c].U_off, uvec + (size_t)3 * WR->ch[c].rows_off, rg, even_up(ra), 0,
-                   s_rmap + c * MAPW);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-      if (c >= nbig && c < ncb0) {
-        const int rg = 3 * WR->ch[c].ns, ra = 3 * WR->ch[c].na;
-        const SlabGeom g = slab_geom<SUS>(tid, ra);
-        if (c > 0) __syncthreads();
-        slab_scatter<WW>(T[c], g, tid, rg, ra, 0, s_rmap + c * MAPW, s_cmap + c * W, w, r0, nr, Ls);
-      }
-    }
-  }
-  // fronts with more than MAXC children: one at a time through map slot 0
-  for (int ci = MAXC; ci < nchild; ci++) {
-    const WorkChild G = get_child(WR, fronts, children, child_off, ci);
-    const int rg = 3 * G.ns, ra = 3 * G.na;
-    const SlabGeom g = slab_geom(tid, ra);
-    for (int row0 = 0; row0 < rg; row0 += g.rows) {
-      __syncthreads();
-      if (tid < g.rows && row0 + tid < rg) {
-        const short pos = (short)(3 * rel[G.rel_off + (row0 + tid) / 3] + (row0 + tid) % 3);
-        s_rmap[tid] = map_dst<WW>(pos, w, r0, nr);
-        if (row0 == 0 && tid < ra) s_cmap[tid] = pos;
-      }
-      __syncthreads();
-      SlabLoads S0;
-      slab_issue(S0, g, tid, Ubuf + G.U_off, uvec + (size_t)3 * G.rows_off, rg, even_up(ra), row0, s_rmap);
-      slab_scatter<WW>(S0, g, tid, rg, ra, row0, s_rmap, s_cmap, w, r0, nr, Ls);
-    }
-  }
-  __syncthreads();
-  }
   PHASE(3);
-  // ---- blocked factorisation of the panel [F11; F21 chunk; rhs row] where it was assembled, in LDS (panel_cholesky.h):
-  // per block column of 16 one elimination pass -- every wavefront factors the diagonal block in lanes 48..63 and
-  // solves 48 rows below it in lanes 0..47 -- and the trailing update on v_mfma_f64_16x16x4_f64.  The rhs row is the
-  // last row of the panel: what the eliminations leave there is y = L11^-1 (b + children), i.e. the forward solve.
-  // A non-positive pivot records the GN iteration in *status (first failure wins); the pose update kernel then leaves
-  // the poses alone -- g2o's early return.
+  // ---- blocked factorisation of the panel [F11; F21 chunk; rhs row] in LDS (panel_cholesky.h): per block column of 16
+  // one elimination pass -- every wavefront factors the diagonal block in lanes 48..63 and solves 48 rows below it in
+  // lanes 0..47 -- and the trailing update on v_mfma_f64_16x16x4_f64.  The rhs row is the last row of the panel: what the
+  // eliminations leave there is y = L11^-1 (b + children), i.e. the forward solve.  A non-positive pivot records the GN
+  // iteration in *status (first failure wins); the pose update kernel then leaves the poses alone -- g2o's early return.
   const int lane = tid & 63, wave = tid >> 6;
-  const int M = W + nr + 1;                                 // rows of the panel: F11, border rows of the chunk, rhs
-  // row r of the panel: F11 rows in Ls, the others in R (kRIdx doubles behind Ls)
-  auto roff = [](int r) -> int { return r * LDW + (r >= W ? kRIdx - W * LDW : 0); };
+  auto roff = [](int row) -> int { return row * LDW; };
   const int nbc = min(W / 16, (w + 15) >> 4);                // block columns that hold real columns
   FPHASE(0);
-  const int fail = panel_cholesky(Ls, roff, M, nbc, Dinv, lane, wave);
+  const int fail = panel_cholesky(P, roff, M, nbc, Dinv, lane, wave);
   FPHASE(1);
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);   // status[1]: GN iterations completed so far
   PHASE(4);
   // ---- stores, all from LDS: L11 (lower triangle, zeros above), 1/diag, L21 rows of this chunk, y, u
-  double* P = Lbuf + L_off;
+  double* Pn = Lbuf + L_off;
+  const double* R = P + W * LDW;                              // border rows of the chunk, then the rhs row
   if (chunk == 0) {
     for (int q = tid; q < W * W / 2; q += 256) {               // row-major copy (backward solve), two columns per 16-byte store
       const int i = q / (W / 2), k = 2 * (q - i * (W / 2));
-      const double a = (k <= i) ? Ls[i * LDW + k] : 0.0, b = (k + 1 <= i) ? Ls[i * LDW + k + 1] : 0.0;
-      *reinterpret_cast<double2*>(P + i * W + k) = make_double2(a, b);
+      const double a = (k <= i) ? P[i * LDW + k] : 0.0, b = (k + 1 <= i) ? P[i * LDW + k + 1] : 0.0;
+      *reinterpret_cast<double2*>(Pn + i * W + k) = make_double2(a, b);
     }
     if (write_l11c)                                           // column-major copy: only the multi-rhs forward solve of the marginals reads it
       for (int q = tid; q < W * W; q += 256) {
         const int i = q / W, k = q - i * W;
-        P[kL11c + q] = (i <= k) ? Ls[k * LDW + i] : 0.0;       // element (row k, col i)
+        Pn[kL11c + q] = (i <= k) ? P[k * LDW + i] : 0.0;       // element (row k, col i)
       }
-    if (tid < W) P[kDinv + tid] = (tid < w) ? Dinv[tid] : 1.0;
+    if (tid < W) Pn[kDinv + tid] = (tid < w) ? Dinv[tid] : 1.0;
     if (tid < w) yvec[3 * c0 + tid] = R[nr * LDW + tid];
   }
   for (int q = tid; q < nr * (W / 2); q += 256) {
     const int row = q / (W / 2), k = 2 * (q - row * (W / 2));
-    *reinterpret_cast<double2*>(P + kL21 + (size_t)(r0 + row) * W + k) = make_double2(R[row * LDW + k], R[row * LDW + k + 1]);
+    *reinterpret_cast<double2*>(Pn + kL21 + (size_t)(r0 + row) * W + k) = make_double2(R[row * LDW + k], R[row * LDW + k + 1]);
   }
   if (tid < nr) {                                             // border vector handed to the parent: u = ext_add(children) - L21 y
     const double* xr = R + tid * LDW;
@@ -639,59 +423,34 @@ __device__ __forceinline__ void front_factor_body(unsigned char* smem, const Wor
   PHASE(6);
 }
 
-template <int WW>
-__global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
-                                                         const FrontDesc* __restrict__ fronts,
-                                                         const int32_t* __restrict__ children,
-                                                         const int32_t* __restrict__ rel,
-                                                         const int32_t* __restrict__ apack,
-                                                         const double* __restrict__ Ablk, double* __restrict__ Lbuf,
-                                                         double* __restrict__ Ubuf, const double* __restrict__ bvec,
-                                                         double* __restrict__ yvec, double* __restrict__ uvec,
-                                                         int* __restrict__ status, int level_id,
-                                                         int write_l11c, int ch_rows, int chunk_rows) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  front_factor_body<false, WW>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec,
-                               status, level_id, write_l11c, ch_rows, chunk_rows);
-}
-
-// The leaves of the elimination tree (level 0: about half of all fronts) have no children: without the slab
-// streaming the kernel needs a quarter of the registers, and with short chunks three workgroups share a CU and
-// hide each other's round trips.
-__global__ __launch_bounds__(256, 2) void k_front_factor_leaf(const WorkRec* __restrict__ work, int work_begin,
-                                                                 const FrontDesc* __restrict__ fronts,
-                                                                 const int32_t* __restrict__ children,
-                                                                 const int32_t* __restrict__ rel,
-                                                                 const int32_t* __restrict__ apack,
-                                                                 const double* __restrict__ Ablk, double* __restrict__ Lbuf,
-                                                                 double* __restrict__ Ubuf, const double* __restrict__ bvec,
-                                                                 double* __restrict__ yvec, double* __restrict__ uvec,
-                                                                 int* __restrict__ status, int level_id,
-                                                                 int write_l11c, int ch_rows, int chunk_rows) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  front_factor_body<true, kFrontW>(smem, work, work_begin, fronts, children, rel, apack, Ablk, Lbuf, Ubuf, bvec, yvec, uvec,
-                                   status, level_id, write_l11c, ch_rows, chunk_rows);
-}
-
 // --------------------------------------------------------------------------- front update
 // Every front with a border: one workgroup per lower 32x32 tile of the update matrix,
 //   U = extend_add(children's trailing blocks) - L21 L21^T
 // Like the factor kernel this one is a chain of memory round trips, kept to four: tile entry -> the front's work
-// record (front + first MAXC children) -> the two 32-row slices of L21 and, for every child, the rows of its
-// trailing block that feed this tile (inv maps) -> the children's values; the product runs while they are in
-// flight.  Children are added in child order after the product: same sums as a sequential extend-add.
+// record (front + first MAXC children) -> the two 32-row slices of L21, the front's own row positions in its parent
+// and, for every child, the rows of its trailing block that feed this tile (inv maps) -> the children's values and the
+// cells of the parent's panel this tile adds into; the product runs while they are in flight.  Children are added in
+// child order after the product: same sums as a sequential extend-add.
+// Where the tile goes: cells whose column falls into the parent's own columns (the leading slab) are ADDED into the
+// parent's assembled panel Pan (F11 / F21 of the parent), the tiles of the first tile column add the front's border
+// vector as well; the other cells (the trailing block, which the parent's own update tiles gather later) are stored in
+// Ubuf.  A cell of a panel copy is touched by one workgroup per launch -- siblings that share a launch write different
+// copies -- and launches are ordered, so the sums are bit-reproducible without atomics.  A front whose parent lies in
+// the top block (ppan_off < 0) stores the whole matrix in Ubuf: k_top_block assembles its block itself.
 template <int WW>
 __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict__ work,
                                                       const int32_t* __restrict__ tiles, int tile_begin,
                                                       const FrontDesc* __restrict__ fronts,
                                                       const int32_t* __restrict__ children,
-                                                      const int32_t* __restrict__ inv,
-                                                      const double* __restrict__ Lbuf, double* __restrict__ Ubuf) {
+                                                      const int32_t* __restrict__ inv, const int32_t* __restrict__ rel,
+                                                      const double* __restrict__ Lbuf, double* __restrict__ Ubuf,
+                                                      double* __restrict__ Pan, const double* __restrict__ uvec) {
   CGMR_FRONT_CONSTS(WW);
   __shared__ double Ai[TS * LDW];
   __shared__ double Aj[TS * LDW];
   __shared__ __attribute__((aligned(8))) int s_rec[kRecInts];
   __shared__ short s_k[MAXC][2 * TS];                        // per child: child row of tile row i / tile column j, or -1
+  __shared__ int s_pp[2 * TS];                               // tile row i: offset (doubles) of its row in the parent's panel; tile column j: its column
   const int tid = threadIdx.x;
   const int32_t* tl = tiles + 3 * (size_t)(tile_begin + blockIdx.x);
   const int rec = tl[0], ti = tl[1], tj = tl[2];
@@ -700,12 +459,14 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   __syncthreads();
   const WorkRec* WR = reinterpret_cast<const WorkRec*>(s_rec);
   const int r = 3 * rfl(WR->F.ns), my_ra = 3 * rfl(WR->F.na), nchild = rfl(WR->F.nchild), child_off = rfl(WR->F.child_off);
-  const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off);
+  const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off), ppan = rfl64(WR->F.ppan_off);
+  const int p_w = 3 * rfl(WR->F.p_nc), p_r = 3 * rfl(WR->F.p_ns), my_rel = rfl(WR->F.rel_off), my_rows = rfl(WR->F.rows_off);
   const int ncb = min(nchild, MAXC);
   const double* L21 = Lbuf + L_off + kL21;
   const int i0 = ti * TS, j0 = tj * TS;
+  const bool to_pan = ppan >= 0 && j0 < my_ra;                // this tile holds cells of the leading slab
   // ---- the two L21 slices and every child's row lookups: all loads first, then the LDS writes
-  constexpr int LQ = TS * W / 256;                            // 6 (12) elements of each slice per thread
+  constexpr int LQ = TS * W / 256;                            // 6 elements of each slice per thread
   double li[LQ], lj[LQ];
 #pragma unroll
   for (int u = 0; u < LQ; u++) {
@@ -721,6 +482,8 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
     const int cs = min(c, max(ncb - 1, 0));
     kb[c] = (tid < 2 * TS && pq < r && c < ncb) ? inv[WR->ch[cs].inv_off + pq / 3] : -1;
   }
+  const int myrel = (ppan >= 0 && tid < 2 * TS && pq < r) ? rel[my_rel + pq / 3] : 0;   // my position in the parent's row list (block units)
+  const double uval = (ppan >= 0 && tj == 0 && tid < TS && pq < r) ? uvec[(size_t)3 * my_rows + pq] : 0.0;
 #pragma unroll
   for (int u = 0; u < LQ; u++) {
     const int q = tid + 256 * u;
@@ -731,13 +494,37 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   if (tid < 2 * TS) {
 #pragma unroll
     for (int c = 0; c < MAXC; c++) s_k[c][tid] = (short)(kb[c] < 0 ? -1 : 3 * kb[c] + pq % 3);
+    // parent's panel: row of position pos = pos (an own column of the parent: F11 row) or W + (pos - p_w) (a border row)
+    const int pos = 3 * myrel + pq % 3;
+    s_pp[tid] = tid < TS ? (pos < p_w ? pos : W + pos - p_w) * kPanStride : pos;
+  }
+  // the front's border vector rides on the tiles of the first tile column: into the rhs row (own columns of the parent)
+  // or the border-vector column (its border rows)
+  if (ppan >= 0 && tj == 0 && tid < TS && pq < r) {
+    const int pos = 3 * myrel + pq % 3;
+    double* dst = Pan + ppan + (pos < p_w ? (size_t)(W + p_r) * kPanStride + pos : (size_t)(W + pos - p_w) * kPanStride + W);
+    *dst += uval;
   }
   __syncthreads();
   // each thread: rows {ty, ty+16}, cols {tx, tx+16}
   const int tx = tid & 15, ty = tid >> 4;
   const int gi[2] = {i0 + ty, i0 + ty + 16}, gj[2] = {j0 + tx, j0 + tx + 16};
-  // ---- the children's values for my 4 cells (issued before the product, used after it)
+  // ---- the children's values for my 4 cells and the panel cells they are added into (issued before the product, used after it)
   double v[MAXC][4];
+  double oldv[4] = {0.0, 0.0, 0.0, 0.0};
+  double* pdst[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (to_pan) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const bool ok = gi[a] < r && gj[b] <= gi[a] && gj[b] < my_ra;
+        if (ok) {
+          pdst[2 * a + b] = Pan + ppan + s_pp[ty + 16 * a] + s_pp[TS + tx + 16 * b];
+          oldv[2 * a + b] = *pdst[2 * a + b];
+        }
+      }
+  }
 #pragma unroll
   for (int c = 0; c < MAXC; c++)
 #pragma unroll
@@ -796,8 +583,11 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++)
-      if (gi[a] < r && gj[b] <= gi[a]) Uo[uidx(gi[a], gj[b], r, my_ra)] = acc[2 * a + b];
+    for (int b = 0; b < 2; b++) {
+      if (!(gi[a] < r && gj[b] <= gi[a])) continue;
+      if (pdst[2 * a + b]) *pdst[2 * a + b] = oldv[2 * a + b] + acc[2 * a + b];
+      else Uo[uidx(gi[a], gj[b], r, my_ra)] = acc[2 * a + b];
+    }
 }
 
 // ------------------------------------------------------------------------------ top block
@@ -1095,7 +885,7 @@ void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
 void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
   hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256 + 1), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_slot, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.bvec, D.chi2, D.status);
+                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status);
 }
 
 // one-time kernel attributes (dynamic LDS above 64 KB): once per HIP device of the process (the attribute belongs to
@@ -1105,10 +895,8 @@ void gn_init_kernels() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 63], [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor<kFrontW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              factor_smem_bytes(kFrontW, kChunkRows + 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor_leaf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              factor_smem_bytes(kFrontW, kChunkRows + 1));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              factor_smem_bytes(kChunkRows + 1));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize), hipFuncAttributeMaxDynamicSharedMemorySize,
                               256 * 33 * (int)sizeof(double));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_block), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1119,25 +907,22 @@ void gn_init_kernels() {
 void launch_factor_level(hipStream_t st, const GnDevice& D, int l, bool write_l11c) {
   gn_init_kernels();
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
-  const int lw = kFrontW;
-  const int ch_rows = D.h_level_chrows[l];
-  auto kern = D.h_level_leaf[l] ? k_front_factor_leaf : k_front_factor<kFrontW>;
-  hipLaunchKernelGGL(kern, dim3(nw), dim3(256), factor_smem_bytes(lw, ch_rows), st, D.work, D.h_work_ptr[l], D.fronts,
-                     D.children, D.rel, D.apack, D.Ablk, D.Lbuf, D.Ubuf, D.bvec, D.yvec, D.uvec, D.status, l,
-                     write_l11c ? 1 : 0, ch_rows, D.h_level_chunk[l]);
+  if (nw <= 0) return;                   // (a level emptied by the children's schedule: its fronts moved up)
+  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), factor_smem_bytes(D.h_level_chrows[l]), st, D.work, D.h_work_ptr[l],
+                     D.Pan, D.Lbuf, D.yvec, D.uvec, D.status, l, write_l11c ? 1 : 0, D.h_level_chunk[l]);
 }
 
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
   int nt = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
   if (nt <= 0) return;
-  auto kern = k_front_update<kFrontW>;
-  hipLaunchKernelGGL(kern, dim3(nt), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children, D.inv, D.Lbuf,
-                     D.Ubuf);
+  hipLaunchKernelGGL(k_front_update<kFrontW>, dim3(nt), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children,
+                     D.inv, D.rel, D.Lbuf, D.Ubuf, D.Pan, D.uvec);
 }
 
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   gn_init_kernels();
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
+  if (nfr <= 0) return;
   const int lw = kFrontW;
   auto kern = k_solve_bwd<kFrontW>;
   hipLaunchKernelGGL(kern, dim3(nfr), dim3(256), bwd_smem_bytes(lw), st, D.fronts_lv, D.h_level_ptr[l], D.rows, D.Lbuf,

@@ -717,16 +717,44 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     kids.resize(nfr);
     for (int c = 0; c < nf; c++) S.col_front[c] = newid[S.col_front[c]];
   }
+  // Levels (0 = no children) and the schedule of the children's contributions.  A child adds the leading slab of its
+  // update matrix into its parent's assembled panel during ONE update launch t, level(child) <= t < level(parent); two
+  // children of a front that share a launch add into different copies of the panel (read-modify-write without
+  // atomics: every cell of a copy has one writer per launch, launches are ordered => bit-reproducible sums).  The
+  // children with the least slack are placed first, each into the launch with the fewest siblings so far; when more than
+  // kMaxPanSlots would share a launch the parent moves up a level.
   int nlev = 0;
-  for (int f = 0; f < nfr; f++) {     // levels: 0 = no children
-    int lv = 0;
-    for (int ch : kids[f]) lv = std::max(lv, S.fronts[ch].level + 1);
-    S.fronts[f].level = lv;
-    nlev = std::max(nlev, lv + 1);
+  {
+    std::vector<int32_t> cnt, ord;
+    for (int f = 0; f < nfr; f++) {
+      int lv = 0;
+      for (int ch : kids[f]) lv = std::max(lv, S.fronts[ch].level + 1);
+      ord.assign(kids[f].begin(), kids[f].end());
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return S.fronts[a].level > S.fronts[b].level; });
+      for (;;) {
+        cnt.assign(lv, 0);
+        bool ok = true;
+        for (int ch : ord) {
+          int best = -1;
+          for (int t = S.fronts[ch].level; t < lv; t++) if (best < 0 || cnt[t] < cnt[best]) best = t;
+          if (cnt[best] >= kMaxPanSlots) { ok = false; break; }
+          S.fronts[ch].sched_t = best;
+          S.fronts[ch].sched_slot = cnt[best]++;
+        }
+        if (ok) break;
+        lv++;
+      }
+      S.fronts[f].pan_slots = 1;
+      for (int c : cnt) S.fronts[f].pan_slots = std::max(S.fronts[f].pan_slots, c);
+      S.fronts[f].level = lv;
+      S.fronts[f].sched_t = lv;          // (roots: no update tiles)
+      S.fronts[f].sched_slot = 0;
+      nlev = std::max(nlev, lv + 1);
+    }
   }
   CK("borders + amalgamation");
   // children lists, rel / inv maps, A lists, offsets: the sizes first (serial, cheap), then the contents in parallel
-  int64_t Loff = 0, Uoff = 0;
+  int64_t Loff = 0, Uoff = 0, Panoff = 0;
   double flops = 0;
   {
     int64_t n_child = 0, n_rel = 0, n_inv = 0, n_a = 0;
@@ -757,6 +785,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       const int64_t lw = kFrontW;
       F.L_off = Loff; Loff += factor_header((int)lw) + r * lw;
       F.U_off = Uoff; Uoff += (r * r + r + 3) & ~int64_t(1);      // even offsets: the update matrices are read with 16-byte loads
+      F.pan_off = Panoff; Panoff += pan_size(F.ns) * F.pan_slots;
       flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
     }
     S.children.resize(n_child);
@@ -802,6 +831,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   CK("maps + A lists");
   S.L_doubles = Loff;
   S.U_doubles = Uoff;
+  S.pan_doubles = Panoff;
   S.flops = flops;
   // levels
   S.level_ptr.assign(nlev + 1, 0);
@@ -863,9 +893,43 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       for (int l = 0; l < nlev; l++) {
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++)
           if (!in_top[S.level_fronts[q]]) S.gn_level_fronts.push_back(S.level_fronts[q]);
-        if ((int)S.gn_level_fronts.size() > S.gn_level_ptr.back()) S.gn_level_ptr.push_back((int)S.gn_level_fronts.size());
-        else if (l < nlev - (int)chain.size()) S.gn_level_ptr.push_back((int)S.gn_level_fronts.size());   // (cannot happen: every lower level has a front)
+        S.gn_level_ptr.push_back((int)S.gn_level_fronts.size());      // (GN level index = tree level: the children's schedule counts in tree levels)
       }
+      while (S.gn_level_ptr.size() > 1 && S.gn_level_ptr[S.gn_level_ptr.size() - 1] == S.gn_level_ptr[S.gn_level_ptr.size() - 2])
+        S.gn_level_ptr.pop_back();                                     // the block's own levels
+    }
+  }
+  // ---- where every front's contribution and every H block goes
+  {
+    std::vector<uint8_t> in_top(nfr, 0);
+    for (int f : S.top_fronts) in_top[f] = 1;
+    for (int f = 0; f < nfr; f++) {
+      FrontDesc& F = S.fronts[f];
+      F.ppan_off = -1; F.p_nc = 0; F.p_ns = 0;
+      if (F.parent >= 0 && !in_top[F.parent]) {
+        const FrontDesc& Pf = S.fronts[F.parent];
+        F.ppan_off = Pf.pan_off + pan_size(Pf.ns) * F.sched_slot;
+        F.p_nc = Pf.nc; F.p_ns = Pf.ns;
+      } else {
+        F.sched_t = F.level;               // the whole update matrix goes to Ubuf, in the front's own launch
+        F.sched_slot = 0;
+      }
+    }
+    S.blk_dst.assign((size_t)nf + S.nb, 0);
+    S.b_dst.assign(nf, -1);
+    for (int f = 0; f < nfr; f++) {
+      const FrontDesc& F = S.fronts[f];
+      for (int k = 0; k < F.a_cnt; k++) {
+        const int32_t* al = S.alist.data() + 3 * (size_t)(F.a_off + k);
+        const int blk = al[0], lr = al[1], lc = al[2];
+        if (in_top[f]) { S.blk_dst[blk] = -(F.a_off + k + 1); continue; }
+        const int64_t row = lr < F.nc ? 3 * lr : kFrontW + 3 * (lr - F.nc);
+        const int64_t off = F.pan_off + row * kPanStride + 3 * lc;
+        if (off > 0x7fffffff) return -2;                     // (a graph two orders of magnitude beyond the benchmark configurations)
+        S.blk_dst[blk] = (int32_t)off;
+      }
+      if (!in_top[f])
+        for (int c = 0; c < F.nc; c++) S.b_dst[F.c0 + c] = (int32_t)(F.pan_off + (int64_t)(kFrontW + 3 * F.ns) * kPanStride + 3 * c);
     }
   }
   S.t_struct = now_s() - t1;

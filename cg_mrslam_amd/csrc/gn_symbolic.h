@@ -54,10 +54,25 @@ struct FrontDesc {                   // one per front, uploaded verbatim (all in
   int32_t inv_off;    // offset into inv[]: ns_parent entries, inv[p] = k such that rel[k]-nc_p == p, or -1
   int32_t a_off;      // offset into alist[] (triples) of the A blocks assembled by this front
   int32_t a_cnt;
-  int32_t pad;
-  int64_t L_off;      // offset (doubles) of this front's factor panel: header (factor_header(W)) then L21 (r x W), W = its level's width
+  int32_t pan_slots;  // copies of this front's assembled panel (see pan_off): children scheduled into the same update launch
+                      //   add into different copies, the factor kernel sums the copies in order
+  int64_t L_off;      // offset (doubles) of this front's factor panel: header (factor_header(W)) then L21 (r x W)
   int64_t U_off;      // offset (doubles) of this front's update matrix (r*r, row-major, lower part valid)
+  // Assembled panel (Pan + pan_off, pan_size(ns) doubles per copy): rows 0..47 = F11 (row = own scalar column), rows
+  // 48..48+3ns-1 = F21 (border rows), last row = right-hand side; kPanStride doubles per row: columns 0..47, column 48 =
+  // the border vector (sum of the children's u).  k_assemble writes the H blocks and b into copy 0, the update tiles of
+  // every child add the leading slab of its update matrix and its border vector into the copy the schedule assigned
+  // (sched_slot) during launch sched_t, so k_front_factor starts from one contiguous block instead of streaming children.
+  int64_t pan_off;
+  int64_t ppan_off;   // parent's panel copy this front adds into (-1: the parent is in the top block -- or there is none --
+                      //   and the whole update matrix goes to Ubuf as before)
+  int32_t p_nc, p_ns; // parent's own block columns / border block rows
+  int32_t sched_t;    // update launch (tree level index) in which this front's update tiles run: level <= sched_t < parent's level
+  int32_t sched_slot;
 };
+constexpr int kPanStride = 50;                                            // doubles per panel row (even: 16-byte rows)
+constexpr int64_t pan_size(int ns) { return (int64_t)(kFrontW + 3 * ns + 1) * kPanStride; }
+constexpr int kMaxPanSlots = 3;      // copies of a panel at most; more same-launch siblings push the parent up a level
 
 // Work item of the factorisation kernel: the front, its chunk, and the fields of its first children that the
 // kernel needs -- one record, one memory round trip (uploaded verbatim).
@@ -86,6 +101,9 @@ struct Symbolic {
   std::vector<int32_t> asm_ptr;        // nf+nb+1
   std::vector<int32_t> asm_src;        // edge*4 + code (0: Hii, 1: Hjj, 2: Hij, 3: Hij^T)
   std::vector<int32_t> off_row, off_col;  // per off-diagonal block: permuted row > col
+  std::vector<int32_t> blk_dst;        // per H block (nf diagonal, then nb off-diagonal): offset (doubles) in Pan of its element
+                                       //   (0, 0) (rows kPanStride apart), or -(slot + 1): slot in Ablk (fronts of the top block)
+  std::vector<int32_t> b_dst;          // per permuted block column: offset in Pan of its first right-hand-side entry, -1: top block
   // fronts
   std::vector<FrontDesc> fronts;
   std::vector<int32_t> rows, children, rel, inv;
@@ -102,7 +120,7 @@ struct Symbolic {
   std::vector<int32_t> top_children;   // fronts outside the block whose parent is inside, ascending id
   std::vector<int32_t> top_blocks;     // triples (slot in Ablk, local block row, local block column) of the block's H blocks
   std::vector<int32_t> gn_level_ptr, gn_level_fronts;   // levels without the top block
-  int64_t L_doubles = 0, U_doubles = 0;
+  int64_t L_doubles = 0, U_doubles = 0, pan_doubles = 0;
   int max_ns = 0;
   double flops = 0;                    // factorisation flops (dense fronts)
   double t_order = 0, t_struct = 0;    // seconds spent in ordering / structure

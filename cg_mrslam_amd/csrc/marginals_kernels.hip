@@ -224,6 +224,7 @@ void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* 
   hipLaunchKernelGGL(k_marg_init_rhs, dim3((nK + 127) / 128), dim3(128), 0, st, nK, d_qcol, m, Y);
   for (int l = 0; l < D.nlevels_full; l++) {            // every front, the top block's included
     int nfr = D.h_flevel_ptr[l + 1] - D.h_flevel_ptr[l];
+    if (nfr <= 0) continue;                              // (a level emptied by the children's schedule)
     auto kern = k_solve_fwd_multi<kFrontW>;
     hipLaunchKernelGGL(kern, dim3(nfr, m / MB), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_flevel_ptr[l], D.children,
                        D.rel, D.inv, D.Lbuf, m, Y, Uv);
