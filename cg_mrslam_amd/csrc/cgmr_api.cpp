@@ -163,6 +163,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_pan = N.add<double>((size_t)S.pan_doubles + 2);
   size_t o_chi = N.add<double>((size_t)iters + 2);
   size_t o_status = N.add<int>(4);
+  size_t o_done = N.add<unsigned int>(S.fronts.size() + 4);
   size_t o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
   size_t total = N.off + 256;
   int rc = arena_reserve(ctx, ctx->gn_arena, total);
@@ -289,6 +290,13 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.pan_doubles = S.pan_doubles;
   D.chi2 = (double*)(d + o_chi);
   D.status = (int*)(d + o_status);
+  D.done = (unsigned int*)(d + o_done);
+  // the upper levels of the tree are solved backwards in one chained launch: as many levels as fit the workgroups that
+  // are certainly resident together (the waits inside the launch cannot deadlock then); CGMR_BWD_CHAIN=0: one launch per level
+  static const int chain_env = getenv("CGMR_BWD_CHAIN") ? atoi(getenv("CGMR_BWD_CHAIN")) : -1;
+  const int chain_cap = chain_env >= 0 ? std::min(chain_env, bwd_chain_capacity()) : bwd_chain_capacity();
+  D.bwd_chain_level = D.nlevels;
+  while (D.bwd_chain_level > 0 && D.h_level_ptr[D.nlevels] - D.h_level_ptr[D.bwd_chain_level - 1] <= chain_cap) D.bwd_chain_level--;
   return 0;
 }
 
@@ -302,7 +310,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
          o_y = N.add<double>((size_t)3 * S.nf), o_x = N.add<double>((size_t)3 * S.nf), o_u = N.add<double>((size_t)3 * S.rows.size() + 3),
          o_L = N.add<double>((size_t)S.L_doubles + 1), o_U = N.add<double>((size_t)S.U_doubles + 1),
          o_pan = N.add<double>((size_t)S.pan_doubles + 2), o_chi = N.add<double>(8),
-         o_status = N.add<int>(4), o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
+         o_status = N.add<int>(4), o_done = N.add<unsigned int>(S.fronts.size() + 4), o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
   const size_t per = (N.off + 255) & ~size_t(255);
   int rc = arena_reserve(ctx, ctx->rep_arena, per * (size_t)std::max(n, 1) + 256);
   if (rc) return rc;
@@ -312,7 +320,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
     GnDevice& D = out[i];
     D.term = (double*)(d + o_term); D.Ablk = (double*)(d + o_A); D.bvec = (double*)(d + o_b); D.yvec = (double*)(d + o_y);
     D.xvec = (double*)(d + o_x); D.uvec = (double*)(d + o_u); D.Lbuf = (double*)(d + o_L); D.Ubuf = (double*)(d + o_U); D.Pan = (double*)(d + o_pan);
-    D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.cmask = (uint8_t*)(d + o_cmask);
+    D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.done = (unsigned int*)(d + o_done); D.cmask = (uint8_t*)(d + o_cmask);
   }
   return 0;
 }
@@ -474,7 +482,8 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
   if (D.top_nfronts > 0) T.run(5, 1, [&] { launch_top_block(st, D, /*store_l=*/write_l11c, write_l11c); });
   if (!solve_and_update) return;
   // (the forward solve L y = b rides through k_front_factor as an extra row of every front)
-  for (int l = D.nlevels - 1; l >= 0; l--) T.run(6, 1, [&] { launch_bwd_level(st, D, l); });
+  if (D.bwd_chain_level < D.nlevels) T.run(6, 1, [&] { launch_bwd_chain(st, D); });
+  for (int l = D.bwd_chain_level - 1; l >= 0; l--) T.run(6, 1, [&] { launch_bwd_level(st, D, l); });
   T.run(7, 1, [&] { launch_update(st, D, d_poses); });
 }
 

@@ -29,6 +29,8 @@ struct GnDevice {
   int64_t pan_doubles = 0;
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
+  unsigned int* done = nullptr;          // per front: its columns of x are final (the chained launch of the backward solve), zeroed by k_assemble
+  int bwd_chain_level = 0;               // GN levels >= this one are solved backwards in one chained launch (k_solve_bwd<.., true>)
   // top block (k_top_block): the last fronts of the root's chain, handled by one workgroup in LDS
   int top_nfronts = 0, top_c0 = 0, top_ncols = 0, top_nchild = 0, top_nblk = 0;
   int32_t *top_fronts = nullptr, *top_children = nullptr, *top_blocks = nullptr;
@@ -54,6 +56,8 @@ void gn_init_kernels();
 void launch_factor_level(hipStream_t st, const GnDevice& D, int level, bool write_l11c);
 void launch_update_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
+void launch_bwd_chain(hipStream_t st, const GnDevice& D);
+int bwd_chain_capacity();
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);
 void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c);
 // marginals_kernels.hip

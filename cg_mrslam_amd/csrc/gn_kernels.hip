@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "gn_symbolic.h"
@@ -186,8 +187,9 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
                                                   const double* __restrict__ term, double* __restrict__ Ablk,
                                                   double* __restrict__ Pan,
                                                   double* __restrict__ bvec, double* __restrict__ chi_out,
-                                                  const int* __restrict__ status) {
+                                                  const int* __restrict__ status, unsigned int* __restrict__ done, int nfronts) {
   if (blockIdx.x == gridDim.x - 1) {
+    for (int f = threadIdx.x; f < nfronts; f += 256) done[f] = 0u;                   // flags of the chained backward solve
     block_chi2_sum((nE + 255) / 256, term + (size_t)33 * nE, chi_out + status[1]);   // chi2 before iteration status[1]
     return;
   }
@@ -719,17 +721,31 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
 // in LDS and reads one row per step).
 constexpr int XB_CAP = 1536;         // border rows staged per pass
 constexpr int kBwdNL = 24;           // L21 rows per thread and pass
-constexpr int bwd_smem_bytes(int w) { return ((w > 64 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP) * 8; }
-template <int WW>
-__global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
+constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP) * 8; }
+// CHAIN: the upper levels of the tree -- a handful of fronts each, one launch each in round 2 (16 x 6.5 us of dependent
+// round trips and launch boundaries) -- run as ONE launch: workgroup b takes front (first - b) of the level order, i.e.
+// parents before children, and waits for its parent's flag (the parent's columns and, by induction, every ancestor's are
+// final then) while its loads of L are already in flight.  Hand-off per MI355X guide, Guideline 16 R1: x is stored
+// write-through (8-byte agent-scope atomic stores = global_store_dwordx2 sc1), the storing wavefront drains (s_waitcnt
+// vmcnt(0)), one lane stores the flag; the consumer polls that one word relaxed and then reads x with agent-scope loads
+// (sc1: past the L1, which another CU's stores never refresh).  The launch is at most 2 workgroups per CU (the host
+// picks the levels), so every workgroup is resident whatever the dispatch order; the spin is bounded all the same.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+#define CGMR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+template <int WW, bool CHAIN>
+__global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
-                                                   const double* __restrict__ yvec, double* __restrict__ xvec) {
+                                                   const double* __restrict__ yvec, double* xvec, unsigned int* done,
+                                                   int* status) {
   CGMR_FRONT_CONSTS(WW);
   constexpr int HP = W / 2;            // column pairs per row
   constexpr int G = 256 / HP;          // row groups of the border reduction (10 / 5)
-  constexpr int NL = kBwdNL;
+  // CHAIN: four workgroups per CU must be resident (<= 128 VGPRs): L11 goes through LDS instead of 96 registers of
+  // wavefront 0, half as many L21 rows per thread in flight
+  constexpr int NL = CHAIN ? kBwdNL / 2 : kBwdNL;
   constexpr int CPL = (W + 63) / 64;   // columns per lane in the triangular solve
-  constexpr bool LDS_L11 = W > 64;
+  constexpr bool LDS_L11 = W > 64 || CHAIN;
   constexpr int XQ = XB_CAP / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   double* Lt = reinterpret_cast<double*>(smem_b);            // [W][W] L11 row-major (96-column instance only)
@@ -737,7 +753,8 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__
   double* part = dinv + W;                                   // [G][W]
   double* xb = part + G * W;                                 // [XB_CAP]
   const int tid = threadIdx.x;
-  const FrontDesc F = fronts_lv[level_begin + blockIdx.x];    // descriptors in level order: no index hop
+  // descriptors in level order: no index hop (CHAIN: level_begin = the last front of the level order, walked downwards)
+  const FrontDesc F = fronts_lv[CHAIN ? level_begin - (int)blockIdx.x : level_begin + (int)blockIdx.x];
   const int w = 3 * F.nc, r = 3 * F.ns;
   const double* P = Lbuf + F.L_off;
   const double* L21 = P + kL21;
@@ -774,11 +791,30 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__
       const int p = g + G * u;
       l[u] = (active && p < np) ? *reinterpret_cast<const double2*>(L21 + (size_t)(p0 + p) * W + 2 * cp) : make_double2(0.0, 0.0);
     }
+    if constexpr (CHAIN) {
+      // wait for the parent (a front below the top block always has one; its parent in the top block: nothing to wait for)
+      if (p0 == 0 && F.ppan_off >= 0) {
+        if (tid == 0) {
+          gu32* flag = (gu32*)(done + F.parent);
+          unsigned spins = 0;
+          while (__hip_atomic_load(flag, CGMR_RLX_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) { atomicCAS(status, 0, status[1] + 1); status[2] = 1; break; }   // never hang the device
+          }
+        }
+        __syncthreads();
+      }
+    }
     double xr[XQ];
 #pragma unroll
     for (int u = 0; u < XQ; u++) {
       const int p = tid + 256 * u;
-      xr[u] = (p < np) ? xvec[3 * xi[u] + (p0 + p) % 3] : 0.0;
+      if constexpr (CHAIN) {
+        const unsigned long long bits = (p < np) ? __hip_atomic_load((gu64*)(xvec + 3 * xi[u] + (p0 + p) % 3), CGMR_RLX_AGENT) : 0ull;
+        xr[u] = __longlong_as_double((long long)bits);
+      } else {
+        xr[u] = (p < np) ? xvec[3 * xi[u] + (p0 + p) % 3] : 0.0;
+      }
     }
     if (p0 > 0) __syncthreads();
 #pragma unroll
@@ -845,7 +881,15 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const FrontDesc* __restrict__
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
       const int col = lane + 64 * c;
-      if (col < w) xvec[3 * F.c0 + col] = xv[c];
+      if constexpr (CHAIN) {
+        if (col < w) __hip_atomic_store((gu64*)(xvec + 3 * F.c0 + col), (unsigned long long)__double_as_longlong(xv[c]), CGMR_RLX_AGENT);
+      } else {
+        if (col < w) xvec[3 * F.c0 + col] = xv[c];
+      }
+    }
+    if constexpr (CHAIN) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the storing wavefront drains before the flag goes out
+      if (lane == 0) __hip_atomic_store((gu32*)(done + F.front_id), 1u, CGMR_RLX_AGENT);
     }
   }
 }
@@ -885,7 +929,7 @@ void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
 void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
   hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256 + 1), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status);
+                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.done, D.nfronts);
 }
 
 // one-time kernel attributes (dynamic LDS above 64 KB): once per HIP device of the process (the attribute belongs to
@@ -923,10 +967,37 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   gn_init_kernels();
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   if (nfr <= 0) return;
-  const int lw = kFrontW;
-  auto kern = k_solve_bwd<kFrontW>;
-  hipLaunchKernelGGL(kern, dim3(nfr), dim3(256), bwd_smem_bytes(lw), st, D.fronts_lv, D.h_level_ptr[l], D.rows, D.Lbuf,
-                     D.yvec, D.xvec);
+  hipLaunchKernelGGL((k_solve_bwd<kFrontW, false>), dim3(nfr), dim3(256), bwd_smem_bytes(kFrontW, false), st, D.fronts_lv, D.h_level_ptr[l], D.rows,
+                     D.Lbuf, D.yvec, D.xvec, D.done, D.status);
+}
+
+// Workgroups of the chained backward solve that are certainly resident together: the waits inside that launch must never
+// depend on the dispatch order.  What the occupancy query promises, at most 4 per CU: the kernel's budget is 128 VGPRs and
+// 35 KB of LDS; the query is known to over-report by one only where the SGPRs bind (MI355X guide: floor(800 / (ceil(sgpr /
+// 16) * 16 + 16)) blocks of 256 threads), and this kernel's 106 SGPRs admit 6.  The spin is bounded all the same.
+int bwd_chain_capacity() {
+  static int cap[64];
+  static std::once_flag once[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 63;
+  std::call_once(once[dev], [dev] {
+    int nb = 0, ncu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_solve_bwd<kFrontW, true>), 256,
+                                                     bwd_smem_bytes(kFrontW, true)) != hipSuccess) nb = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+    cap[dev] = std::max(0, std::min(nb, 4)) * ncu;
+  });
+  return cap[dev];
+}
+
+// GN levels bwd_chain_level .. nlevels-1 in one launch, parents first
+void launch_bwd_chain(hipStream_t st, const GnDevice& D) {
+  gn_init_kernels();
+  const int first = D.h_level_ptr[D.bwd_chain_level], last = D.h_level_ptr[D.nlevels];
+  if (last <= first) return;
+  hipLaunchKernelGGL((k_solve_bwd<kFrontW, true>), dim3(last - first), dim3(256), bwd_smem_bytes(kFrontW, true), st, D.fronts_lv, last - 1, D.rows,
+                     D.Lbuf, D.yvec, D.xvec, D.done, D.status);
 }
 
 void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c) {

@@ -905,6 +905,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     for (int f : S.top_fronts) in_top[f] = 1;
     for (int f = 0; f < nfr; f++) {
       FrontDesc& F = S.fronts[f];
+      F.front_id = f;
       F.ppan_off = -1; F.p_nc = 0; F.p_ns = 0;
       if (F.parent >= 0 && !in_top[F.parent]) {
         const FrontDesc& Pf = S.fronts[F.parent];
