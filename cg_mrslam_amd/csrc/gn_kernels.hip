@@ -31,6 +31,7 @@ namespace cgmr {
 namespace {
 
 constexpr int TS = 32;               // tile edge of k_front_update
+constexpr unsigned long long kXSentinel = 0x7ff8c67d00000a55ull;   // a NaN no computation produces: "this entry of x is not there yet" (k_solve_bwd, chained)
 constexpr int kRecIntsC = (int)(sizeof(WorkRec) / 4);
 
 // Factor panel layout in Lbuf (doubles, all strides padded to W = 48 columns; the kernels that touch it keep the width
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
                                                   const double* __restrict__ term, double* __restrict__ Ablk,
                                                   double* __restrict__ Pan,
                                                   double* __restrict__ bvec, double* __restrict__ chi_out,
-                                                  const int* __restrict__ status, unsigned int* __restrict__ done, int nfronts) {
+                                                  const int* __restrict__ status, unsigned int* __restrict__ done, int nfronts,
+                                                  double* __restrict__ xvec) {
   if (blockIdx.x == gridDim.x - 1) {
     for (int f = threadIdx.x; f < nfronts; f += 256) done[f] = 0u;                   // flags of the chained backward solve
     block_chi2_sum((nE + 255) / 256, term + (size_t)33 * nE, chi_out + status[1]);   // chi2 before iteration status[1]
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
     }
     acc = cmask[v] ? 0.0 : acc;
     bvec[t] = acc;
+    xvec[t] = __longlong_as_double((long long)kXSentinel);   // "not solved yet" (chained backward solve)
     const int dst = b_dst[v];
     if (dst >= 0) Pan[(size_t)dst + r] = acc;                  // right-hand-side row of the owning front's panel
   }
@@ -724,11 +727,12 @@ constexpr int kBwdNL = 24;           // L21 rows per thread and pass
 constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP) * 8; }
 // CHAIN: the upper levels of the tree -- a handful of fronts each, one launch each in round 2 (16 x 6.5 us of dependent
 // round trips and launch boundaries) -- run as ONE launch: workgroup b takes front (first - b) of the level order, i.e.
-// parents before children, and waits for its parent's flag (the parent's columns and, by induction, every ancestor's are
-// final then) while its loads of L are already in flight.  Hand-off per MI355X guide, Guideline 16 R1: x is stored
-// write-through (8-byte agent-scope atomic stores = global_store_dwordx2 sc1), the storing wavefront drains (s_waitcnt
-// vmcnt(0)), one lane stores the flag; the consumer polls that one word relaxed and then reads x with agent-scope loads
-// (sc1: past the L1, which another CU's stores never refresh).  The launch is at most 2 workgroups per CU (the host
+// parents before children, and waits for its parent's columns of x (they, and by induction every ancestor's, are final
+// then) while its loads of L are already in flight.  Hand-off per MI355X guide, Guideline 16 R2 -- the data is the flag:
+// k_assemble fills xvec with a NaN pattern no computation produces, x is stored write-through in naturally aligned 8-byte
+// granules (agent-scope atomic stores = global_store_dwordx2 sc1), the consumer polls one of them relaxed and reads
+// the others with agent-scope loads (sc1: past the L1, which another CU's stores never refresh), re-reading any that is
+// not there yet.  (A separate flag behind an s_waitcnt vmcnt(0) drain costs 0.3 us more per hop.)  The launch is at most 2 workgroups per CU (the host
 // picks the levels), so every workgroup is resident whatever the dispatch order; the spin is bounded all the same.
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
@@ -792,13 +796,15 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
       l[u] = (active && p < np) ? *reinterpret_cast<const double2*>(L21 + (size_t)(p0 + p) * W + 2 * cp) : make_double2(0.0, 0.0);
     }
     if constexpr (CHAIN) {
-      // wait for the parent (a front below the top block always has one; its parent in the top block: nothing to wait for)
+      // wait for the parent (a front below the top block always has one; its parent in the top block: nothing to wait for):
+      // the data is the flag -- k_assemble filled xvec with kXSentinel, the parent's 48 columns go out in one store
+      // instruction, so one lane polls the parent's first column and the values read afterwards are checked again below
       if (p0 == 0 && F.ppan_off >= 0) {
         if (tid == 0) {
-          gu32* flag = (gu32*)(done + F.parent);
+          gu64* flag = (gu64*)(xvec + 3 * (size_t)F.p_c0);
           unsigned spins = 0;
-          while (__hip_atomic_load(flag, CGMR_RLX_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(2);
+          while (__hip_atomic_load(flag, CGMR_RLX_AGENT) == kXSentinel) {
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 22)) { atomicCAS(status, 0, status[1] + 1); status[2] = 1; break; }   // never hang the device
           }
         }
@@ -810,7 +816,12 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
     for (int u = 0; u < XQ; u++) {
       const int p = tid + 256 * u;
       if constexpr (CHAIN) {
-        const unsigned long long bits = (p < np) ? __hip_atomic_load((gu64*)(xvec + 3 * xi[u] + (p0 + p) % 3), CGMR_RLX_AGENT) : 0ull;
+        unsigned long long bits = 0ull;
+        if (p < np) {
+          gu64* src = (gu64*)(xvec + 3 * xi[u] + (p0 + p) % 3);
+          unsigned spins = 0;
+          while ((bits = __hip_atomic_load(src, CGMR_RLX_AGENT)) == kXSentinel && F.ppan_off >= 0 && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+        }
         xr[u] = __longlong_as_double((long long)bits);
       } else {
         xr[u] = (p < np) ? xvec[3 * xi[u] + (p0 + p) % 3] : 0.0;
@@ -887,10 +898,6 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
         if (col < w) xvec[3 * F.c0 + col] = xv[c];
       }
     }
-    if constexpr (CHAIN) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the storing wavefront drains before the flag goes out
-      if (lane == 0) __hip_atomic_store((gu32*)(done + F.front_id), 1u, CGMR_RLX_AGENT);
-    }
   }
 }
 
@@ -929,7 +936,7 @@ void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
 void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
   hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256 + 1), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.done, D.nfronts);
+                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.done, D.nfronts, D.xvec);
 }
 
 // one-time kernel attributes (dynamic LDS above 64 KB): once per HIP device of the process (the attribute belongs to

@@ -906,6 +906,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     for (int f = 0; f < nfr; f++) {
       FrontDesc& F = S.fronts[f];
       F.front_id = f;
+      F.p_c0 = F.parent >= 0 ? S.fronts[F.parent].c0 : -1;
       F.ppan_off = -1; F.p_nc = 0; F.p_ns = 0;
       if (F.parent >= 0 && !in_top[F.parent]) {
         const FrontDesc& Pf = S.fronts[F.parent];

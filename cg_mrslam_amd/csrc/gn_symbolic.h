@@ -70,7 +70,7 @@ struct FrontDesc {                   // one per front, uploaded verbatim (all in
   int32_t sched_t;    // update launch (tree level index) in which this front's update tiles run: level <= sched_t < parent's level
   int32_t sched_slot;
   int32_t front_id;   // this front's index (the level-ordered copies of the descriptors carry it along)
-  int32_t pad2;
+  int32_t p_c0;       // parent's first block column (-1: no parent)
 };
 constexpr int kPanStride = 50;                                            // doubles per panel row (even: 16-byte rows)
 constexpr int64_t pan_size(int ns) { return (int64_t)(kFrontW + 3 * ns + 1) * kPanStride; }
