@@ -54,8 +54,8 @@ constexpr int kRecIntsC = (int)(sizeof(WorkRec) / 4);
 constexpr int factor_panel_rows(int rows) { return (kFrontW + rows + 15) / 16 * 16; }
 constexpr int factor_smem_bytes(int rows) { return (factor_panel_rows(rows) * (kFrontW + 1) + kFrontW) * 8; }
 static_assert(factor_smem_bytes(kChunkRows + 1) <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
-static_assert(3 * factor_smem_bytes(kLeafChunkRows + 1) <= 160 * 1024, "a level of leaves: three workgroups per CU");
-static_assert(2 * factor_smem_bytes(kMidChunkRows + 1) <= 160 * 1024, "above the leaves: two workgroups per CU");
+static_assert(kFrontW != 48 || 3 * factor_smem_bytes(kLeafChunkRows + 1) <= 160 * 1024, "a level of leaves: three workgroups per CU");
+static_assert(kFrontW != 48 || 2 * factor_smem_bytes(kMidChunkRows + 1) <= 160 * 1024, "above the leaves: two workgroups per CU");
 static_assert(kFrontW + kChunkRows + 1 <= 208, "panel_cholesky: at most 4 x 48 rows below a diagonal block");
 
 __device__ __forceinline__ double d_normalize_theta(double t) {
@@ -303,7 +303,7 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 // Then the blocked factorisation of the panel in LDS (panel_cholesky.h) and the stores.  Every work item of a front
 // factors F11 again (nobody waits for anybody) and owns its rows of L21.  The update matrix U = ext_add - L21 L21^T of
 // every front is formed by k_front_update, whose tiles spread over the idle CUs.
-constexpr int kPanLoads = 15;        // 16-byte loads per thread and round: 3840 double2 = a 95-row chunk's panel in one round
+constexpr int kPanLoads = (kFrontW + kMidChunkRows + 1) * (kPanStride / 2) / 256 + 1;   // 16-byte loads per thread and round: a 95-row chunk's panel in one round (15)
 __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
                                                       const double* __restrict__ Pan, double* __restrict__ Lbuf,
                                                       double* __restrict__ yvec, double* __restrict__ uvec,
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
       for (int u = 0; u < kPanLoads; u++) {
         const int q = base + tid + 256 * u;
         if (q >= nq) continue;
-        const int row = (q * 5243) >> 17;                    // q / 25 for q < 2^15
+        const int row = q / H2;
         const int c2 = 2 * (q - H2 * row);
         double vx = v[u].x, vy = v[u].y;
         if (row >= w && row < W) {                           // identity padding of the unused columns
@@ -387,19 +387,31 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   auto roff = [](int row) -> int { return row * LDW; };
   const int nbc = min(W / 16, (w + 15) >> 4);                // block columns that hold real columns
   FPHASE(0);
-  const int fail = panel_cholesky(P, roff, M, nbc, Dinv, lane, wave);
+  // stores, all from LDS: L11 row-major (lower triangle, zeros above: the backward solve reads whole columns) and this
+  // chunk's rows of L21 go out block column by block column as soon as the column is final, underneath the rest of the
+  // factorisation (5.4k cycles of stores at the end of every work item otherwise)
+  double* Pn = Lbuf + L_off;
+  const double* R = P + W * LDW;                              // border rows of the chunk, then the rhs row
+  auto store_block_column = [&](int K) {
+    const int c = 16 * K;
+    const int nrow = (chunk == 0 ? W : 0) + nr;               // F11 rows (first chunk only), then my rows of L21
+    for (int q = tid; q < nrow * 8; q += 256) {
+      const int rr = q >> 3, k = c + 2 * (q & 7);
+      if (chunk == 0 && rr < W) {
+        const double a = (k <= rr) ? P[rr * LDW + k] : 0.0, b = (k + 1 <= rr) ? P[rr * LDW + k + 1] : 0.0;
+        *reinterpret_cast<double2*>(Pn + rr * W + k) = make_double2(a, b);
+      } else {
+        const int row = rr - (chunk == 0 ? W : 0);
+        *reinterpret_cast<double2*>(Pn + kL21 + (size_t)(r0 + row) * W + k) = make_double2(R[row * LDW + k], R[row * LDW + k + 1]);
+      }
+    }
+  };
+  const int fail = panel_cholesky(P, roff, M, nbc, Dinv, lane, wave, store_block_column);
+  for (int K = nbc; K < W / 16; K++) store_block_column(K);    // block columns without real columns (identity padding)
   FPHASE(1);
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);   // status[1]: GN iterations completed so far
   PHASE(4);
-  // ---- stores, all from LDS: L11 (lower triangle, zeros above), 1/diag, L21 rows of this chunk, y, u
-  double* Pn = Lbuf + L_off;
-  const double* R = P + W * LDW;                              // border rows of the chunk, then the rhs row
   if (chunk == 0) {
-    for (int q = tid; q < W * W / 2; q += 256) {               // row-major copy (backward solve), two columns per 16-byte store
-      const int i = q / (W / 2), k = 2 * (q - i * (W / 2));
-      const double a = (k <= i) ? P[i * LDW + k] : 0.0, b = (k + 1 <= i) ? P[i * LDW + k + 1] : 0.0;
-      *reinterpret_cast<double2*>(Pn + i * W + k) = make_double2(a, b);
-    }
     if (write_l11c)                                           // column-major copy: only the multi-rhs forward solve of the marginals reads it
       for (int q = tid; q < W * W; q += 256) {
         const int i = q / W, k = q - i * W;
@@ -407,10 +419,6 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
       }
     if (tid < W) Pn[kDinv + tid] = (tid < w) ? Dinv[tid] : 1.0;
     if (tid < w) yvec[3 * c0 + tid] = R[nr * LDW + tid];
-  }
-  for (int q = tid; q < nr * (W / 2); q += 256) {
-    const int row = q / (W / 2), k = 2 * (q - row * (W / 2));
-    *reinterpret_cast<double2*>(Pn + kL21 + (size_t)(r0 + row) * W + k) = make_double2(R[row * LDW + k], R[row * LDW + k + 1]);
   }
   if (tid < nr) {                                             // border vector handed to the parent: u = ext_add(children) - L21 y
     const double* xr = R + tid * LDW;

@@ -16,10 +16,13 @@
 
 namespace cgmr {
 
-constexpr int kPanelW = 16;          // max poses (block columns) per front -> 48 scalar columns
-constexpr int kFrontW = 3 * kPanelW; // scalar columns per front (all panel strides are padded to this)
+#ifndef CGMR_PANEL_POSES
+#define CGMR_PANEL_POSES 16
+#endif
+constexpr int kPanelW = CGMR_PANEL_POSES;                  // max poses (block columns) per front
+constexpr int kFrontW = (3 * kPanelW + 15) / 16 * 16;      // scalar columns per front (all panel strides are padded to this): 48
 constexpr int64_t factor_header(int w) { return 2 * (int64_t)w * w + w; }   // L11 row-major, L11 column-major, 1/diag
-constexpr int kChunkRows = 159;      // most border rows a k_front_factor workgroup can take: the elimination passes of the
+constexpr int kChunkRows = 208 - kFrontW - 1;      // most border rows a k_front_factor workgroup can take: the elimination passes of the
                                      // panel factorisation hold 4 x 48 rows below a diagonal block (panel_cholesky.h)
 constexpr int kMidChunkRows = 95;    // border rows per work item above the leaves: a front with a wide border is cut into
                                      // several work items (each factors F11 again, fetches only the children's rows it owns):
@@ -72,7 +75,7 @@ struct FrontDesc {                   // one per front, uploaded verbatim (all in
   int32_t front_id;   // this front's index (the level-ordered copies of the descriptors carry it along)
   int32_t p_c0;       // parent's first block column (-1: no parent)
 };
-constexpr int kPanStride = 50;                                            // doubles per panel row (even: 16-byte rows)
+constexpr int kPanStride = kFrontW + 2;                                            // doubles per panel row (even: 16-byte rows)
 constexpr int64_t pan_size(int ns) { return (int64_t)(kFrontW + 3 * ns + 1) * kPanStride; }
 constexpr int kMaxPanSlots = 3;      // copies of a panel at most; more same-launch siblings push the parent up a level
 

@@ -54,8 +54,12 @@ typedef __attribute__((address_space(3))) double lds_f64;   // 32-bit LDS addres
 // P: the panel in LDS, roff(r) = offset (doubles) of row r.  Rows M .. 16 * ceil(M / 16) - 1 must exist (any finite or
 // non-finite content: they are computed along and never read by anyone else), so no access below is masked.
 // 256 threads; lane / wave = the caller's (logical) numbering.  At most 4 x 48 rows below a diagonal block: M <= 208.
-template <typename RowOff>
-__device__ __forceinline__ int panel_cholesky(double* Pg, RowOff roff, int M, int nbc, double* Dinv, int lane, int wave_v) {
+// done(K): called by every thread once block column K is final in LDS (behind a workgroup barrier), while later block
+// columns are still being worked on: the caller's stores of that block column run underneath the rest of the factorisation.
+struct PanelNoCallback { __device__ __forceinline__ void operator()(int) const {} };
+template <typename RowOff, typename ColumnDone = PanelNoCallback>
+__device__ __forceinline__ int panel_cholesky(double* Pg, RowOff roff, int M, int nbc, double* Dinv, int lane, int wave_v,
+                                              ColumnDone done = ColumnDone()) {
   lds_f64* P = (lds_f64*)Pg;
   const int wave = __builtin_amdgcn_readfirstlane(wave_v);    // wave-uniform by construction: keep it in a scalar register
   const int NB = (M + 15) >> 4, MP = 16 * NB;
@@ -167,9 +171,11 @@ __device__ __forceinline__ int panel_cholesky(double* Pg, RowOff roff, int M, in
       update(K);
       PANEL_TS(2 * K + 1);
       __syncthreads();
+      done(K);
     }
   }
   __syncthreads();                       // the last diagonal block is in place
+  done(nbc - 1);
   return fail;
 }
 
