@@ -2,6 +2,7 @@
 // UNTESTED: needs g2o + Eigen, which this project's build image does not have (see README.md in this directory).
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <vector>

@@ -61,8 +61,14 @@ void MRGraphSLAM::addInterRobotData(CondensedGraphMessage* gmsg) {
   int32_t accepted = 0;
   // requests for vertices this robot has -> out-closures + computeCondensedGraph(sender); edges whose end points exist
   // replace the set previously received from the sender (CondensedGraphBuffer::insertEdgesFromRobot)
-  (void)cgmr_graph_message_from(g, gmsg->robotId(), (int)e.size(), e.data(), (int)gmsg->closures.size(), gmsg->closures.data(),
-                                &accepted);
+  const int rc = cgmr_graph_message_from(g, gmsg->robotId(), (int)e.size(), e.data(), (int)gmsg->closures.size(),
+                                         gmsg->closures.data(), &accepted);
+  if (rc != CGMR_OK) std::fprintf(stderr, "cgmr: addInterRobotData from robot %d failed (%d): %s\n", gmsg->robotId(), rc, cgmr_graph_last_error(g));
+  // (A message beyond the graph's capacity is dropped and counted, cgmr_graph_skipped_messages, like a datagram beyond a
+  // reference node's MAX_LENGTH_MSG receive buffer.)
+  // The received edges live in the cgmr robot graph, not in _graph: VerticesFinder / checkCovariance / saveGraph of a node
+  // that keeps using the g2o optimiser for those searches read them back with cgmr_graph_received_edges (ids,
+  // measurement, information) and mirror them as EdgeSE2 of level 0 -- see INTEGRATION.md, "what stays in g2o".
   // GraphSLAM::optimize (graph_slam_gpu.cpp) then runs cgmr_graph_optimize on own + received edges and copies the
   // estimates back into the g2o vertices with cgmr_graph_get_poses.
 }

@@ -133,7 +133,8 @@ def team_leg(ctx, n_robots=4, n_steps=90):
     la = (team[0]["n_beams"], team[0]["angle_min"], team[0]["angle_inc"], team[0]["max_range"])
     slams = []
     for r in range(n_robots):
-        s = MRGraphSLAMDriver(ctx, ScanMatcher(ctx, *la), LCScanMatcher(ctx, *la), RobotGraph(ctx, r, n_robots), r, n_robots,
+        s = MRGraphSLAMDriver(ctx, ScanMatcher(ctx, *la), LCScanMatcher(ctx, *la),
+                              RobotGraph(ctx, r, n_robots, cap_edges=RobotGraph.REFERENCE_CAP_EDGES), r, n_robots,
                               windowLoopClosure=5, minInliers=4)
         s.setInterRobotClosureParams(0.15, 3, 5)
         s.setDetectRobotInRange(True)

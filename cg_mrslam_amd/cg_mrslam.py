@@ -58,7 +58,8 @@ def _make_slam(ctx, r, n, la, a):
     close = ScanMatcher(ctx, *la, resolution=a.resolution, kernel_range=a.kernelRadius)      # GraphSLAM::init, graph_slam.cpp:58-62
     close.initializeGrid((-15, -15), (15, 15), a.resolution)
     lc = LCScanMatcher(ctx, *la)
-    s = MRGraphSLAMDriver(ctx, close, lc, RobotGraph(ctx, r, n), r, n, windowLoopClosure=a.windowLoopClosure,
+    s = MRGraphSLAMDriver(ctx, close, lc, RobotGraph(ctx, r, n, cap_edges=RobotGraph.REFERENCE_CAP_EDGES), r, n,
+                          windowLoopClosure=a.windowLoopClosure,
                           maxScore=a.maxScore, inlierThreshold=a.inlierThreshold, minInliers=a.minInliers)
     s.setInterRobotClosureParams(a.maxScoreMR, a.minInliersMR, a.windowMRLoopClosure)
     s.setDetectRobotInRange(a.detectRobotInRange)
@@ -91,13 +92,16 @@ def main(argv=None):
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         if world != n:
             raise SystemExit(f"WORLD_SIZE={world} but -nRobots {n}: one rank per robot")
+        if a.idRobot is not None and a.idRobot != rank:
+            # the all-gather's slices are addressed by rank: another id would silently misroute every message
+            raise SystemExit(f"-idRobot {a.idRobot} on rank {rank}: under torch.distributed.run the robot id is the rank")
         dev = a.device if a.device is not None else int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
         backend = a.backend or "nccl"
         if backend == "nccl":
             torch.cuda.set_device(dev)
         dist.init_process_group(backend, rank=rank, world_size=world)
         ctx = Context(dev)
-        s = _make_slam(ctx, rank if a.idRobot is None else a.idRobot, n, la, a)
+        s = _make_slam(ctx, rank, n, la, a)
         tr = team[s.idRobot]
         comm = GraphCommRanks(s, device=torch.device("cuda", dev) if backend == "nccl" else None)
         run_cg_mrslam_rank(s, team, comm=comm, linearUpdate=a.linearUpdate, angularUpdate=a.angularUpdate)

@@ -38,10 +38,14 @@ def _p(a):
 class RobotGraph:
     """``cgmr_graph``: the g2o optimiser of one robot plus its ``CondensedGraphBuffer``."""
 
+    #: edges (and closure ids) per peer a reference message holds: MAX_LENGTH_MSG = 100000 bytes of 44-byte edges (msg_factory.h:115)
+    REFERENCE_CAP_EDGES = 2270
+
     def __init__(self, ctx: Context | None, robot: int, n_robots: int, base_id: int = 10000, cap_edges: int = 128):
         self.lib = ctx.lib if ctx is not None else load_library()
         self.lib.cgmr_graph_last_error.restype = C.c_char_p
         self.lib.cgmr_graph_wire_bytes.restype = C.c_int64
+        self.lib.cgmr_graph_skipped_messages.restype = C.c_int64
         self.lib.cgmr_graph_send_buffer.restype = C.c_void_p
         self.lib.cgmr_graph_recv_buffer.restype = C.c_void_p
         self.lib.cgmr_graph_destroy.restype = None
@@ -139,6 +143,11 @@ class RobotGraph:
         self._check(self.lib.cgmr_graph_set_condensed(self.h, C.c_int(peer), C.c_int(len(to)), C.c_int32(int(from_id)), _p(to), _p(e), _p(i)))
 
     # ------------------------------------------------------------------ wire
+    def skipped_messages(self) -> int:
+        """Messages left out, not built or dropped because they exceed ``cap_edges`` (the reference skips a send whose
+        ``toCharArray`` does not fit ``MAX_LENGTH_MSG``, graph_comm.cpp:112-122)."""
+        return int(self.lib.cgmr_graph_skipped_messages(self.h))
+
     def wire_bytes(self) -> int:
         return int(self.lib.cgmr_graph_wire_bytes(self.h))
 
@@ -250,29 +259,46 @@ class Exchange:
         self.transport = transport
         if transport == "torch":
             dev = torch.device("cuda", graph.ctx.device)
+            graph.lib.cgmr_ctx_stream.restype = C.c_void_p
+            # the context's stream as a torch stream: the two are ordered with events, the host never waits
+            self.ctx_stream = torch.cuda.ExternalStream(int(graph.lib.cgmr_ctx_stream(graph.ctx.h) or 0), device=dev)
             self.t_send = torch.zeros(self.wb, dtype=torch.uint8, device=dev)
             self.t_recv = torch.zeros(self.world * self.wb, dtype=torch.uint8, device=dev)
 
     def _init_rccl(self):
+        """Native RCCL communicator next to torch's.  Two guards against a hang (a rank that fails BEFORE the collective
+        ``ncclCommInitRank`` would leave the others inside it): every rank first probes librccl locally and the ranks agree
+        (MIN all-reduce) that all of them can go on; the collective initialisation itself runs under a timeout
+        (``CGMR_RCCL_INIT_TIMEOUT`` seconds, default 60) and a rank that runs out of time falls back to the torch
+        transport -- its peers, stuck in the same collective, time out the same way and the agreement in ``__init__``
+        settles on "torch" for everybody."""
+        import os
+        import threading
         torch, dist, g = self.torch, self.dist, self.g
         lib = g.lib
         dev = torch.device("cuda", g.ctx.device)
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-        ok = 0
-        if dist.get_rank(self.group) == 0:
-            h = np.zeros(128, dtype=np.uint8)
-            ok = lib.cgmr_comm_unique_id(_p(h))
-            uid = torch.from_numpy(h).to(dev)
-        st = torch.tensor([ok], device=dev)
-        dist.broadcast(st, src=0, group=self.group)
-        if int(st.item()) != 0:
-            raise CgmrError(int(st.item()), "cgmr_comm_unique_id failed on rank 0 (librccl not loadable)")
+        h = np.zeros(128, dtype=np.uint8)
+        ok_local = lib.cgmr_comm_unique_id(_p(h))            # loads librccl, asks it for an id (used on rank 0 only)
+        flag = torch.tensor([1 if ok_local == 0 else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            raise CgmrError(ok_local or -1, "librccl is not loadable on every rank")
+        uid = torch.from_numpy(h).to(dev)
         dist.broadcast(uid, src=0, group=self.group)
         h = np.ascontiguousarray(uid.cpu().numpy())
         comm = C.c_void_p()
-        rc = lib.cgmr_comm_create(g.ctx.h, C.c_int(self.world), C.c_int(dist.get_rank(self.group)), _p(h), C.byref(comm))
-        if rc != 0:
-            raise CgmrError(rc, g.ctx.lib.cgmr_last_error(g.ctx.h).decode())
+        res = {}
+
+        def create():
+            res["rc"] = lib.cgmr_comm_create(g.ctx.h, C.c_int(self.world), C.c_int(dist.get_rank(self.group)), _p(h), C.byref(comm))
+
+        t = threading.Thread(target=create, daemon=True)
+        t.start()
+        t.join(float(os.environ.get("CGMR_RCCL_INIT_TIMEOUT", "60")))
+        if t.is_alive():
+            raise TimeoutError("ncclCommInitRank did not return (native RCCL communicator); using torch.distributed instead")
+        if res.get("rc", -1) != 0:
+            raise CgmrError(res.get("rc", -1), g.ctx.lib.cgmr_last_error(g.ctx.h).decode())
         self.comm = comm
 
     def _destroy_comm(self):
@@ -297,7 +323,9 @@ class Exchange:
             self.pending = "rccl"
         elif self.transport == "torch":
             g.pack(self.t_send.data_ptr())
-            g.ctx.synchronize()                       # the context's stream is not torch's: order by the host
+            # the context's stream is not torch's: torch's stream waits (on the device) for the packed message, the
+            # collective then overlaps with whatever the context's stream does next -- as on the native transport
+            self.torch.cuda.current_stream(self.t_send.device).wait_stream(self.ctx_stream)
             self.pending = self.dist.all_gather_into_tensor(self.t_recv, self.t_send, group=self.group, async_op=True)
         else:
             send = self.torch.from_numpy(g.pack_host())
@@ -313,8 +341,8 @@ class Exchange:
             g.ctx._check(g.lib.cgmr_comm_wait(g.ctx.h, self.comm))
             n = g.ingest(0)
         elif self.transport == "torch":
-            self.pending.wait()
-            self.torch.cuda.current_stream().synchronize()
+            self.pending.wait()                                                   # torch's stream waits for the collective ...
+            self.ctx_stream.wait_stream(self.torch.cuda.current_stream(self.t_recv.device))   # ... and the context's stream for torch's
             n = g.ingest(self.t_recv.data_ptr())
         else:
             work, recv, _send = self.pending

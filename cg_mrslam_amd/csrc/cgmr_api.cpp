@@ -724,6 +724,8 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
 
 const char* cgmr_last_error(const cgmr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+void* cgmr_ctx_stream(const cgmr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 int cgmr_ctx_synchronize(cgmr_ctx* ctx) {
   if (!ctx) return CGMR_E_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

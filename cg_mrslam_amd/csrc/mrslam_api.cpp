@@ -55,6 +55,7 @@ struct PeerIn {                       // edges received from one peer (the accep
 struct cgmr_graph {
   cgmr_ctx* ctx = nullptr;            // null: host-only bookkeeping (no numeric entry point works)
   int robot = 0, n_robots = 1, base_id = 10000, cap = 128;
+  int64_t skipped_messages = 0;                   // messages left out / dropped because they exceed the wire capacity
   std::string err;
   // vertices
   std::vector<int32_t> ids;
@@ -512,8 +513,11 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
     W.peer = p;
     for (int32_t id : g->out_closures[p]) W.idx.push_back(g->index[id]);       // id order (VertexIDMap)
     if (W.idx.size() < 2) { g->out[p].n = 0; g->out[p].host.clear(); g->out[p].host_valid = true; continue; }
-    if ((int)W.idx.size() - 1 > cap)
-      return gerr(g, CGMR_E_INVALID, "a peer asked for more vertices than the wire buffer holds (cap_edges_per_peer)");
+    if ((int)W.idx.size() - 1 > cap) {                 // more edges than a message holds: nothing would be sent (see fill_header)
+      g->out[p].n = 0; g->out[p].host.clear(); g->out[p].host_valid = true;
+      g->skipped_messages++;
+      continue;
+    }
     wants.push_back(std::move(W));
   }
   if (wants.empty() || nA == 0) return 0;
@@ -628,12 +632,21 @@ void fill_header(const cgmr_graph* g, unsigned char* buf) {
   hdr[0] = g->robot; hdr[1] = R;
   int32_t* clos = reinterpret_cast<int32_t*>(buf + wire_clos_off(R, cap));
   for (int p = 0; p < R; p++) {
-    hdr[2 + p] = g->out[p].n;
     const std::vector<int32_t>& c = g->in_closures[p];
-    const int n = std::min((int)c.size(), cap);
+    // A message that does not fit the wire buffer is not sent at all -- the reference's toCharArray() returns 0 for a
+    // message beyond MAX_LENGTH_MSG and GraphComm::send skips it (graph_comm.cpp:112-122, msg_factory.h:115) -- instead
+    // of failing the round (every rank still contributes its fixed-size buffer to the all-gather).
+    if ((int)c.size() > cap || g->out[p].n > cap) { hdr[2 + p] = 0; hdr[2 + R + p] = 0; continue; }
+    hdr[2 + p] = g->out[p].n;
+    const int n = (int)c.size();
     hdr[2 + R + p] = n;
     for (int k = 0; k < n; k++) clos[(size_t)p * cap + k] = c[k];
   }
+}
+// counts the messages fill_header() is about to leave out
+void count_skipped(cgmr_graph* g) {
+  for (int p = 0; p < g->n_robots; p++)
+    if (p != g->robot && ((int)g->in_closures[p].size() > g->cap || g->out[p].n > g->cap)) g->skipped_messages++;
 }
 }  // namespace
 
@@ -647,8 +660,7 @@ int cgmr_graph_pack(cgmr_graph* g, void* d_send_out) {
   cgmr_ctx* ctx = g->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int R = g->n_robots, cap = g->cap;
-  for (int p = 0; p < R; p++)
-    if ((int)g->in_closures[p].size() > cap) return gerr(g, CGMR_E_INVALID, "more closure requests for a peer than the wire buffer holds (cap_edges_per_peer)");
+  count_skipped(g);
   const size_t wb = wire_bytes(R, cap);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));            // the pinned staging may still be in flight from the last round
   memset(g->pinned, 0, wb);
@@ -660,6 +672,8 @@ int cgmr_graph_pack(cgmr_graph* g, void* d_send_out) {
     HIP_TRY(ctx, hipMemcpyAsync(d_send_out, g->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
   return CGMR_OK;
 }
+
+int64_t cgmr_graph_skipped_messages(const cgmr_graph* g) { return g ? g->skipped_messages : -1; }
 
 void* cgmr_graph_send_buffer(cgmr_graph* g) { return g ? (void*)g->d_send : nullptr; }
 void* cgmr_graph_recv_buffer(cgmr_graph* g) { return g ? (void*)g->d_recv : nullptr; }
@@ -678,16 +692,15 @@ int cgmr_graph_pack_host(cgmr_graph* g, void* send_out) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CGMR_OK;
   }
-  for (int p = 0; p < R; p++) {
-    if ((int)g->in_closures[p].size() > cap) return gerr(g, CGMR_E_INVALID, "more closure requests for a peer than the wire buffer holds (cap_edges_per_peer)");
+  count_skipped(g);
+  for (int p = 0; p < R; p++)
     if (g->out[p].n > 0 && !g->out[p].host_valid) return gerr(g, CGMR_E_INVALID, "condensed graph not available on the host");
-  }
   unsigned char* buf = (unsigned char*)send_out;
   memset(buf, 0, wb);
   fill_header(g, buf);
   WireEdge* edges = reinterpret_cast<WireEdge*>(buf + wire_edges_off(R));
   for (int p = 0; p < R; p++)
-    for (int k = 0; k < g->out[p].n; k++) edges[(size_t)p * cap + k] = g->out[p].host[k];
+    for (int k = 0; k < g->out[p].n && k < cap; k++) edges[(size_t)p * cap + k] = g->out[p].host[k];
   return CGMR_OK;
 }
 
@@ -805,7 +818,11 @@ int cgmr_graph_message_from(cgmr_graph* g, int sender, int n_edges, const void* 
       (n_edges > 0 && !edges44) || (n_closures > 0 && !closure_ids))
     return CGMR_E_INVALID;
   const int R = g->n_robots, cap = g->cap;
-  if (n_edges > cap || n_closures > cap) return gerr(g, CGMR_E_INVALID, "cgmr_graph_message_from: message exceeds cap_edges_per_peer");
+  if (n_edges > cap || n_closures > cap) {           // beyond what a reference node's receive buffer holds: dropped, not an error
+    g->skipped_messages++;
+    if (n_accepted_out) *n_accepted_out = 0;
+    return CGMR_OK;
+  }
   const size_t wb = wire_bytes(R, cap);
   std::vector<unsigned char> buf((size_t)R * wb, 0);
   for (int s = 0; s < R; s++) {                                 // every block needs its sender id; only one carries data

@@ -48,6 +48,10 @@ int cgmr_version(void);
 int cgmr_ctx_create(int device, void* hip_stream, cgmr_ctx** out);
 void cgmr_ctx_destroy(cgmr_ctx* ctx);
 const char* cgmr_last_error(const cgmr_ctx* ctx);
+/* The context's hipStream_t (the one given to cgmr_ctx_create, or the one the context owns): for a caller that
+ * orders its own streams against the context's work with events instead of blocking the host. */
+void* cgmr_ctx_stream(const cgmr_ctx* ctx);
+
 /* Block until everything queued on the context's stream has finished. */
 int cgmr_ctx_synchronize(cgmr_ctx* ctx);
 
@@ -376,6 +380,10 @@ int cgmr_graph_set_condensed(cgmr_graph* g, int peer, int n, int32_t from_id, co
                              const float* info_upper);
 int64_t cgmr_graph_wire_bytes(const cgmr_graph* g);
 /* device buffers owned by the graph: wire_bytes / n_robots * wire_bytes */
+/* Messages this robot left out of its wire buffer, did not build, or dropped on receipt because they exceed
+ * cap_edges_per_peer -- the reference's ComboMessage::toCharArray returns 0 for a message beyond MAX_LENGTH_MSG and
+ * GraphComm::send skips it (src/mrslam/graph_comm.cpp:112-122, msg_factory.h:115); never an error. */
+int64_t cgmr_graph_skipped_messages(const cgmr_graph* g);
 void* cgmr_graph_send_buffer(cgmr_graph* g);
 void* cgmr_graph_recv_buffer(cgmr_graph* g);
 /* d_send_out NULL = the graph's own send buffer; d_recv NULL = the graph's own receive buffer */

@@ -99,15 +99,16 @@ class CondensedGraphBuffer:
         clos = np.zeros((R, cap), dtype=np.int32)
         for p in range(R):
             e = self.out_condensed.get(p)
+            c = self.in_closures.get(p)
+            # a message that does not fit is not sent at all: ComboMessage::toCharArray returns 0 beyond MAX_LENGTH_MSG and
+            # GraphComm::send skips it (graph_comm.cpp:112-122) -- never truncated
+            if (e is not None and len(e) > cap) or (c is not None and len(c) > cap):
+                self.skipped = getattr(self, "skipped", 0) + 1
+                continue
             if e is not None and len(e):
-                if len(e) > cap:
-                    raise ValueError(f"{len(e)} condensed edges for peer {p} exceed the wire capacity {cap}")
                 edges[p, :len(e)] = e
                 hdr[2 + p] = len(e)
-            c = self.in_closures.get(p)
             if c is not None and len(c):
-                if len(c) > cap:
-                    raise ValueError(f"{len(c)} closure requests for peer {p} exceed the wire capacity {cap}")
                 clos[p, :len(c)] = c
                 hdr[2 + R + p] = len(c)
         return np.concatenate([hdr.view(np.uint8), edges.reshape(-1).view(np.uint8), clos.reshape(-1).view(np.uint8)])

@@ -130,25 +130,37 @@ def test_one_peer_messages_equal_the_all_gather_path():
     c = RobotGraph(None, 0, 3)
     c.add_vertices([0, 1], np.zeros((2, 3)), [1, 0])
     assert c.message_for(2) is None
-    # a message over the capacity, from oneself or from an unknown robot is refused
-    for bad in (CondensedGraphMessage(0), CondensedGraphMessage(5), CondensedGraphMessage(1, np.zeros(200, dtype=EDGE_DTYPE))):
+    # a message from oneself or from an unknown robot is refused; one over the capacity is dropped (a reference node's
+    # receive buffer would not have held it either), not an error
+    for bad in (CondensedGraphMessage(0), CondensedGraphMessage(5)):
         with pytest.raises(Exception):
             a.message_from(bad)
+    assert a.message_from(CondensedGraphMessage(1, np.zeros(200, dtype=EDGE_DTYPE))) == 0 and a.skipped_messages() == 1
 
 
-def test_capacity_overflow_is_an_error_not_a_truncation():
-    g = RobotGraph(None, 0, 2, cap_edges=4)
+def test_capacity_overflow_skips_the_message_like_the_reference():
+    """A message beyond the wire capacity is left out whole -- ``toCharArray`` returns 0 beyond MAX_LENGTH_MSG and
+    ``GraphComm::send`` skips the send (graph_comm.cpp:112-122) -- never truncated, never an error that would leave the
+    other ranks waiting in the all-gather; a condensed graph that cannot fit is refused where it is set."""
+    g = RobotGraph(None, 0, 3, cap_edges=4)
     g.add_vertices(np.arange(10), np.zeros((10, 3)))
     from cg_mrslam_amd._lib import CgmrError
     with pytest.raises(CgmrError):
-        g.set_condensed(1, 0, np.arange(1, 7), *_fake(6, 1))             # 6 edges > cap 4
-    g.insertInClosure(1, 10000 + np.arange(5))                           # 5 requests > cap 4
-    with pytest.raises(CgmrError):
-        g.pack_host()
-    r = RefRobotGraph(None, 0, 2, cap_edges=4)
+        g.set_condensed(1, 0, np.arange(1, 7), *_fake(6, 1))             # 6 edges > cap 4: no such message can exist
+    g.insertInClosure(1, 10000 + np.arange(5))                           # 5 requests > cap 4: the message to robot 1 is skipped
+    g.insertInClosure(2, 20000 + np.arange(3))                           # the message to robot 2 fits
+    r = RefRobotGraph(None, 0, 3, cap_edges=4)
     r.insertInClosure(1, 10000 + np.arange(5))
-    with pytest.raises(ValueError):
-        r.pack_host()
+    r.insertInClosure(2, 20000 + np.arange(3))
+    buf, ref = g.pack_host(), r.pack_host()
+    assert np.array_equal(buf, ref)
+    robot, n_e, n_c, _edges, clos = unpack_wire(buf, 3, 4)
+    assert list(n_c) == [0, 0, 3] and list(clos[2, :3]) == [20000, 20001, 20002]
+    assert g.skipped_messages() == 1 and r.buf.skipped == 1
+    # the receiving side drops a message beyond its capacity instead of failing
+    from cg_mrslam_amd.messages import CondensedGraphMessage
+    big = CondensedGraphMessage(1, np.zeros(6, dtype=EDGE_DTYPE), np.zeros(0, dtype=np.int32))
+    assert g.message_from(big) == 0 and g.skipped_messages() == 2
 
 
 def test_select_gauge_centroid():

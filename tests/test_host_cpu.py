@@ -271,3 +271,58 @@ def test_symbolic_analysis_concurrent_callers():
     for i in range(len(graphs)):
         for rep in range(4):
             assert got[i][rep] == want[i]
+
+
+def _c_calls(text, prefix="cgmr_"):
+    """(name, number of arguments) of every call / prototype ``cgmr_xxx(...)`` in a C or C++ source text (comments and
+    string literals removed, parentheses balanced, commas counted at depth 0)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text)
+    out = []
+    for m in re.finditer(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text):
+        i, depth, commas, empty = m.end(), 1, 0, True
+        while i < len(text) and depth:
+            ch = text[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                commas += 1
+            if depth and not ch.isspace():
+                empty = False
+            i += 1
+        inner = text[m.end():i - 1].strip()
+        out.append((m.group(1), 0 if (empty or inner == "void") else commas + 1))
+    return out
+
+
+def test_adapters_call_the_c_abi_with_the_declared_names_and_argument_counts():
+    """adapters/g2o/*.cpp are the reference-side bindings a maintainer links; they need g2o + Eigen and have never seen a
+    compiler here.  At least every ``cgmr_*`` call in them must name an entry point include/cgmr.h declares and pass the
+    number of arguments its prototype has."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    protos = {}
+    for name, n in _c_calls(open(os.path.join(root, "include", "cgmr.h")).read()):
+        protos.setdefault(name, n)
+    assert len(protos) > 60 and protos["cgmr_gn_optimize"] == 11 and protos["cgmr_version"] == 0
+    files = sorted(glob.glob(os.path.join(root, "adapters", "g2o", "*.cpp")) + glob.glob(os.path.join(root, "adapters", "g2o", "*.h")))
+    assert len(files) >= 5
+    seen, bad = set(), []
+    for f in files:
+        for name, n in _c_calls(open(f).read()):
+            if name.startswith("cgmr_g2o"):                       # the adapters' own helpers (namespace cgmr_g2o)
+                continue
+            seen.add(name)
+            if name not in protos:
+                bad.append(f"{os.path.basename(f)}: {name} is not declared in include/cgmr.h")
+            elif protos[name] != n:
+                bad.append(f"{os.path.basename(f)}: {name} called with {n} arguments, declared with {protos[name]}")
+    assert not bad, "\n".join(bad)
+    # the seven entry points SURVEY.md 8(b) lists are all bound
+    for must in ("cgmr_gn_optimize", "cgmr_close_scan_matching", "cgmr_scan_matching_lc", "cgmr_global_matching", "cgmr_verify_matching",
+                 "cgmr_covariance_estimate", "cgmr_condense"):
+        assert must in seen, must
