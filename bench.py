@@ -39,9 +39,20 @@ sys.path.insert(0, ROOT)
 GN_ITERS = 10
 
 
+def kernel_sources_sha16():
+    """Fingerprint of the HIP sources the PMC passes profiled (tools/make_profile_summary.py stores it with the counters)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "cg_mrslam_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cg_mrslam_amd", "csrc", "*.h"))):
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
     """Per-launch HBM-side bytes from the committed rocprofv3 PMC passes of the same kernels (tools/profile_round.sh ->
-    tools/make_profile_summary.py): measured offline because PMC collection cannot run inside the timed region."""
+    tools/make_profile_summary.py): measured offline because PMC collection cannot run inside the timed region.  The
+    file records a fingerprint of the kernel sources it was measured on: ``_stale`` says they have changed since."""
     best = {}
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
@@ -50,7 +61,24 @@ def pmc_traffic():
             best["_source"] = os.path.relpath(path, ROOT)
         except (OSError, ValueError):
             pass
+    if best:
+        best["_stale"] = best.get("kernel_sources_sha16") != kernel_sources_sha16()
     return best
+
+
+def host_symbolic_ms_one_thread(V, E, seed):
+    """The ordering + symbolic analysis of the benchmark graph on ONE host thread (CGMR_HOST_THREADS is read once per
+    process, hence the subprocess; no GPU involved): best of 5, milliseconds."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cg_mrslam_amd import synth\nfrom cg_mrslam_amd._lib import gn_symbolic_info\n"
+            "g = synth.make_pose_graph(%d, %d, seed=%d, strict=True)\n"
+            "t = [gn_symbolic_info(%d, g['fixed'], g['edge_from'], g['edge_to']) for _ in range(5)]\n"
+            "print(min(i['order_us'] + i['structure_us'] for i in t) / 1e3)" % (ROOT, V, E, seed, V))
+    try:
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CGMR_HOST_THREADS="1"), capture_output=True, text=True, timeout=300)
+        return round(float(out.stdout.strip().splitlines()[-1]), 3)
+    except Exception:                                           # noqa: BLE001
+        return None
 
 
 def host_threads():
@@ -261,19 +289,38 @@ def matcher_leg(ctx, dev, args, with_cpu):
 
 
 # ----------------------------------------------------------------------------------------------- exchange leg (C5)
-def exchange_leg(ctx, rank, world, args, dry=False):
-    """BASELINE.json configs[4] (C5): ``world`` robots x ``--c5-vertices`` vertices, a round every ``--c5-chunk`` vertices."""
+def exchange_leg(ctx, rank, world, args, dry=False, solo=False):
+    """BASELINE.json configs[4] (C5): ``world`` robots x ``--c5-vertices`` vertices, a round every ``--c5-chunk`` vertices.
+    ``solo``: the same rounds of ONE robot with nobody to talk to (grow + optimize(5); no condensed graphs, no
+    collective) -- what the N = 1 line reports and what the rounds of N > 1 are measured against."""
     import torch
     import torch.distributed as dist
     from cg_mrslam_amd import synth
     from cg_mrslam_amd.condensed import Exchange, RobotGraph
     from cg_mrslam_amd.mrslam import RobotRounds, RobotWorld
-    robots = synth.make_multi_robot(world, args.c5_vertices, args.c5_edges, seed=777)
-    w = RobotWorld(robots, rank, chunk=args.c5_chunk)
+
+    class _NoDist:                                               # solo: no process group, nothing to wait for
+        @staticmethod
+        def barrier():
+            pass
+    have_pg = dist.is_initialized() and not solo
+    if not have_pg:
+        dist = _NoDist
+    nrob = 1 if solo else world
+    robots = synth.make_multi_robot(nrob, args.c5_vertices, args.c5_edges, seed=777 + (1000 * rank if solo else 0))
+    w = RobotWorld(robots, 0 if solo else rank, chunk=args.c5_chunk)
     n_rounds = w.n_rounds if args.c5_rounds <= 0 else min(args.c5_rounds, w.n_rounds)
-    g = RobotGraph(None if dry else ctx, rank, world, cap_edges=128)
+    g = RobotGraph(None if dry else ctx, 0 if solo else rank, nrob, cap_edges=128)
     rr = RobotRounds(g, w, iterations=5)
-    ex = Exchange(g)
+    ex = Exchange(g) if have_pg else None
+    if ex is None:
+        class _NoExchange:
+            transport, fallback_reason = "none (one robot)", None
+            def start(self): pass
+            def finish(self): return None
+            def last_collective_seconds(self): return None
+            def close(self): pass
+        ex = _NoExchange()
     if dry:
         # no device: the protocol with fake numerics (the books, the wire and the collective are real)
         rr.optimize = lambda: 0
@@ -315,19 +362,27 @@ def exchange_leg(ctx, rank, world, args, dry=False):
     sync(); dist.barrier()
     t_all = time.perf_counter() - t_all0
     stat = torch.tensor([t_all, float(np.mean(t_round)), float(np.mean(t_opt)), float(np.mean(t_cond)), float(n_in_total),
-                         float(built_total), float(g.counts()["received_edges"])], dtype=torch.float64)
-    cdev = torch.device("cpu") if (dry or dist.get_backend() == "gloo") else torch.device("cuda", ctx.device)
-    smax = stat.clone().to(cdev); dist.all_reduce(smax, op=dist.ReduceOp.MAX)
-    ssum = stat.clone().to(cdev); dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
-    smax, ssum = smax.cpu(), ssum.cpu()
+                         float(built_total), float(g.counts()["received_edges"]), float(g.skipped_messages())], dtype=torch.float64)
+    if have_pg:
+        cdev = torch.device("cpu") if (dry or dist.get_backend() == "gloo") else torch.device("cuda", ctx.device)
+        smax = stat.clone().to(cdev); dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+        ssum = stat.clone().to(cdev); dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        smax, ssum = smax.cpu(), ssum.cpu()
+    else:
+        smax = ssum = stat
     c = g.counts()
-    out = {"workload": f"C5: {world} robots x {args.c5_vertices} vertices / {args.c5_edges} edges, a round every {args.c5_chunk} vertices",
-           "robots": world, "rounds": n_rounds, "transport": ex.transport, "transport_fallback_reason": ex.fallback_reason,
+    out = {"workload": (f"C5 solo: one robot x {args.c5_vertices} vertices / {args.c5_edges} edges grown {args.c5_chunk} at a time, optimize(5) per round, no peers"
+                        if nrob == 1 else
+                        f"C5: {world} robots x {args.c5_vertices} vertices / {args.c5_edges} edges, a round every {args.c5_chunk} vertices"),
+           "robots": nrob, "rounds": n_rounds, "transport": ex.transport, "transport_fallback_reason": ex.fallback_reason,
+           "messages_skipped_over_capacity_total": int(ssum[7]),
+           "ingest_staleness_rounds": (1 if nrob > 1 else None),     # by design: the all-gather of round t is ingested in round t + 1
+           "symbolic_cache": ({k: int(v) for k, v in ctx.symbolic_cache_stats().items()} if not dry else None),
            "total_s_max": round(float(smax[0]), 4), "round_ms_mean_max": round(1e3 * float(smax[1]), 3),
            "optimize5_ms_mean_max": round(1e3 * float(smax[2]), 3), "condense_ms_mean_max": round(1e3 * float(smax[3]), 3),
            "allgather_device_ms_sampled": (round(1e3 * float(np.mean(t_coll)), 4) if t_coll else None),
-           "rounds_per_s_all_robots": round(world * n_rounds / float(smax[0]), 2),
-           "bytes_gathered_per_rank_per_round": int(world * g.wire_bytes()), "wire_bytes_per_edge": 44,
+           "rounds_per_s_all_robots": round(nrob * n_rounds / float(smax[0]), 2),
+           "bytes_gathered_per_rank_per_round": int(nrob * g.wire_bytes()) if nrob > 1 else 0, "wire_bytes_per_edge": 44,
            "condensed_graphs_built_total": int(ssum[5]), "condensed_edges_received_total": int(ssum[4]),
            "received_edges_in_graphs_at_end": int(ssum[6]), "final_vertices_rank0": c["vertices"],
            "chi2_after_rank0": (float(rr.last_chi2[-1]) if rr.last_chi2 is not None else None), "status_rank0": int(rr.last_status)}
@@ -444,9 +499,16 @@ def main():
             "cache": ctx.symbolic_cache_stats()}
 
     # ---- the C5 round protocol (N > 1): incremental sub-graphs, condensed graphs, one all-gather per round
-    exchange = None
+    # N = 1: the same rounds of one robot alone, so that the driver's 1 -> N lines compare C5 rounds with C5 rounds; N > 1:
+    # every rank first runs its solo rounds, then the real ones: weak_scaling_efficiency_vs_solo = solo / real time per round
+    solo = exchange_leg(ctx, rank, world, args, solo=True)
+    exchange = solo
     if world > 1:
         exchange = exchange_leg(ctx, rank, world, args)
+        t = torch.tensor([solo["round_ms_mean_max"]], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange["solo_round_ms_mean_max"] = round(float(t.item()), 3)
+        exchange["weak_scaling_efficiency_vs_solo"] = round(float(t.item()) / exchange["round_ms_mean_max"], 4)
 
     if rank != 0:
         if world > 1:
@@ -466,13 +528,12 @@ def main():
     ff_s, ff_n = kt["front_factor"]
     total_k = sum(v[0] for v in kt.values())
     dominant = max(kt.items(), key=lambda kv: kv[1][0])[0]
-    # algorithmic HBM bytes of one factorisation pass of k_front_factor (DESIGN.md "roofline"):
-    #   read the H blocks (72 B each) and the leading slabs of the children's update matrices (the columns that fall
-    #   into the parent's own columns; the trailing blocks go to k_front_update), write the factor panels (8 B per
-    #   stored double; the column-major copy of L11 is only written for the marginals: 48*48 doubles per front less)
-    nblk = info["free_poses"] + info["offdiag_blocks"]
+    # algorithmic HBM bytes of one factorisation pass of k_front_factor (DESIGN.md "roofline"): read every front's
+    # assembled panel once (8 B per double of F11, the border rows, the rhs row and the border-vector column, every copy),
+    # write the factor panels (8 B per stored double; the column-major copy of L11 is only written for the marginals:
+    # 48*48 doubles per front less)
     l_written = info["L_doubles"] - 48 * 48 * info["fronts"]
-    bytes_factor_iter = 72 * nblk + 8 * l_written + 8 * info["slab_doubles"]
+    bytes_factor_iter = 8 * l_written + 8 * info["panel_doubles"]
     launches_per_iter = ff_n / (nprof * GN_ITERS)
     avg_launch_s = ff_s / max(ff_n, 1)
     bytes_per_launch = bytes_factor_iter / max(launches_per_iter, 1)
@@ -483,14 +544,15 @@ def main():
         "kernel": "k_front_factor", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 6),
         "traffic": pmc.get("k_front_factor", {}).get("traffic_bytes_corrected"),
-        "traffic_source": pmc.get("_source"),
+        "traffic_source": pmc.get("_source"), "traffic_stale": pmc.get("_stale"),
         "avg_launch_us": round(1e6 * avg_launch_s, 2), "launches_per_gn_iter": round(launches_per_iter, 1),
         "tree_levels": info["levels"], "launched_levels": info["launch_levels"], "top_block_columns": info["top_block_cols"],
         "per_level_us": per_level_us,
         "algorithmic_bytes_per_launch": int(bytes_per_launch),
         "share_of_kernel_time": round(ff_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
-        "note": f"latency-bound: {info['launch_levels']} dependent tree levels (+ the top block) of FP64 pivot chains at one wave per SIMD; "
-                "memory-side traffic (PMC) ~ algorithmic bytes, i.e. no wasted re-reads; see DESIGN.md 2.3",
+        "note": f"latency-bound: {info['launch_levels']} dependent tree levels (+ the top block), per level one contiguous panel load, three "
+                "elimination passes of FP64 pivot chains and the stores; traffic_stale = the PMC passes under profiles/ were taken on "
+                "other kernel sources than the ones running now; see DESIGN.md 2.3",
     }
 
     cpu = None
@@ -501,7 +563,7 @@ def main():
         st, p_cpu, chi_cpu, tms = O.gn_optimize(g["poses"], fixed, ef, et, g["meas"], g["info"], GN_ITERS)
         tc = time.perf_counter() - tc0
         nproc = os.cpu_count() or 1
-        nthr = min(nproc, 64)
+        nthr = nproc                                            # every hardware thread of the host
         tm0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=nthr) as ex:        # robots are independent problems: one graph per core
             list(ex.map(lambda k: O.gn_optimize(g["poses"], fixed, ef, et, g["meas"], g["info"], GN_ITERS), range(nthr)))
@@ -512,6 +574,7 @@ def main():
                "all_cores": {"value": round(nthr * GN_ITERS / tm, 3), "cores": nthr, "nproc": nproc,
                              "sample": f"{nthr} concurrent optimize({GN_ITERS}) calls, one per host thread (independent graphs)"},
                "chi2_rel_diff_vs_gpu": float(abs(chi_cpu[-1] - chi[-1]) / chi_cpu[-1]),
+               "chi2_rel_diff_vs_gpu_per_iteration": [float(abs(a - b) / max(abs(a), 1e-300)) for a, b in zip(chi_cpu, chi_cold)],
                "max_pose_diff_vs_gpu": float(np.abs(p_cpu - d_p.cpu().numpy()).max())}
 
     def guarded(name, fn):
@@ -538,6 +601,7 @@ def main():
         "chi2_final": float(chi_cold[-1]), "chi2_initial": float(chi_cold[0]),
         "host_symbolic_ms_per_step": round(1e3 * host_sym / args.steps, 3),
         "host_threads": host_threads(),
+        "host_symbolic_ms_one_thread": (host_symbolic_ms_one_thread(V, E, 12345 + 17 * rank) if world == 1 else None),
         "device_ms_per_step": round(1e3 * dev_time / args.steps, 3),
         "warm": warm,
         "symbolic": {k: info[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")},

@@ -218,7 +218,7 @@ def gn_symbolic_info(nV, fixed, ef, et, want_perm=False):
     if rc != 0:
         raise CgmrError(rc, "cgmr_gn_symbolic_info rejected the graph")
     keys = ["free_poses", "offdiag_blocks", "fronts", "levels", "L_doubles", "U_doubles", "max_border",
-            "factor_flops", "order_us", "structure_us", "max_children", "max_children_small_border", "slab_doubles",
+            "factor_flops", "order_us", "structure_us", "max_children", "max_children_small_border", "panel_doubles",
             "launch_levels", "top_block_fronts", "top_block_cols"]
     info = dict(zip(keys, out.tolist()))
     return (info, perm) if want_perm else info

@@ -784,7 +784,7 @@ int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* f
   out[10] = out[11] = out[12] = 0;
   out[13] = (int64_t)S.gn_level_ptr.size() - 1; out[14] = (int64_t)S.top_fronts.size(); out[15] = 3 * (int64_t)S.top_nposes;
   for (const FrontDesc& F : S.fronts) {
-    if (F.parent >= 0) out[12] += (int64_t)3 * F.ns * ((3 * F.na + 1) & ~1);
+    out[12] += pan_size(F.ns) * F.pan_slots;
     out[10] = std::max<int64_t>(out[10], F.nchild);
     if (F.ns >= 1 && F.ns <= 32) out[11] = std::max<int64_t>(out[11], F.nchild);
   }

@@ -101,7 +101,7 @@ int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]);
  * [4]=doubles in L   [5]=doubles in update matrices  [6]=max border (poses)
  * [7]=factor flops   [8]=ordering microseconds  [9]=structure microseconds
  * [10]=max children of a front  [11]=max children of a front with 1..32 border poses
- * [12]=doubles of the update-matrix slabs the factor kernel reads (columns that fall into the parent's own columns)
+ * [12]=doubles of the fronts' assembled panels (F11, border rows, rhs row; every copy): what the factor kernel reads
  * [13]=tree levels that are launched one by one: the last fronts of the root's chain are handled together by one extra
  *   launch, the "top block"  [14]=fronts of the top block  [15]=its scalar columns
  * perm_out (nullable, nV entries): permuted block column of each vertex or -1.          */

@@ -17,7 +17,7 @@ from cg_mrslam_amd.graph import GraphSLAM, PoseGraph
 pytestmark = pytest.mark.gpu
 
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "gn_*.npz")))
-CHI_RTOL = 1e-5        # transient iterations
+CHI_RTOL = 1e-6        # every iteration: the bar SURVEY.md 8(d) / BASELINE.md state (round 2 asserted 1e-5 on the transient ones)
 CHI_FINAL_RTOL = 1e-8  # last iteration
 POS_ATOL = 1e-6
 ANG_ATOL = 1e-7
