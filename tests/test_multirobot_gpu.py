@@ -76,6 +76,95 @@ def test_two_robot_rounds_match_oracle_backend_edge_by_edge(ctx, oracle):
         assert np.abs(edges[1 - r, :k]["est"] - edges_b[1 - r, :k]["est"]).max() < 1e-5
 
 
+def test_three_robot_rounds_match_oracle_backend(ctx, oracle):
+    """R > 2: every robot addresses two peers, the wire buffers carry three slices each.  Three robots x 6 rounds on one
+    GPU against the same rounds on the oracle backend: what every robot built for every peer, what it holds from every
+    peer and its final poses."""
+    import oracle_backend as ob
+    from ref_condensed import RefRobotGraph
+    R = _meeting_world(3, 900, 3000, min_shared=4)
+    n_rounds, chunk, nr = 6, 150, 3
+    gpu = _rounds(lambda r: RobotGraph(ctx, r, nr), R, chunk, nr)
+    ref = _rounds(lambda r: RefRobotGraph(ob.OracleContext(), r, nr), R, chunk, nr)
+    log_g = run_rounds_loopback(gpu, n_rounds)
+    log_o = run_rounds_loopback(ref, n_rounds)
+    for t in range(n_rounds):
+        (n_in_g, built_g, chi_g), (n_in_o, built_o, chi_o) = log_g[t], log_o[t]
+        assert built_g == built_o
+        if n_in_g is not None:
+            assert [list(a) for a in n_in_g] == [list(a) for a in n_in_o]
+        assert np.allclose(chi_g, chi_o, rtol=1e-6)
+    pairs = 0
+    for r in range(nr):
+        a, b = gpu[r].g, ref[r].g
+        assert a.counts() == b.counts()
+        for q in range(nr):
+            if q == r:
+                continue
+            gid_a, to_a, est_a, iu_a = a.condensed(q)
+            gid_b, to_b, est_b, iu_b = b.condensed(q)
+            assert gid_a == gid_b and np.array_equal(to_a, to_b)
+            if len(to_a):
+                pairs += 1
+                assert np.abs(est_a - est_b).max() < 1e-6 and np.abs(iu_a - iu_b).max() <= 1e-4 * np.abs(iu_b).max()
+            fa, ta, ma, ia = a.received_edges(q)
+            fb, tb, mb, ib = b.received_edges(q)
+            assert np.array_equal(fa, fb) and np.array_equal(ta, tb)
+            if len(fa):
+                assert np.abs(ma - mb).max() < 1e-5 and np.abs(ia - ib).max() <= 2e-4 * np.abs(ib).max()
+        pa, pb = a.poses(), b.poses()
+        assert np.abs(pa[:, :2] - pb[:, :2]).max() < 1e-6 and np.abs(synth.normalize_theta(pa[:, 2] - pb[:, 2])).max() < 1e-6
+        robot, n_e, n_c, edges, clos = unpack_wire(a.pack_host(), nr, a.cap)
+        robot_b, n_e_b, n_c_b, edges_b, clos_b = unpack_wire(b.pack_host(), nr, b.cap)
+        assert robot == robot_b == r and np.array_equal(n_e, n_e_b) and np.array_equal(n_c, n_c_b) and np.array_equal(clos, clos_b)
+    assert pairs >= 4                                       # most ordered pairs exchanged condensed graphs
+
+
+def test_c5_shape_eight_robots_loopback_properties(ctx):
+    """BASELINE.json C5 at its real shape on one GPU: 8 robots x 5000 vertices, a round every 50 vertices, R = 8 wire slices
+    of 128 edges (49 KB per robot), 24 rounds in loopback.  No oracle at this size: properties -- every robot with requests
+    builds its condensed graphs, every slice addressed to a robot is ingested by it in the next round, no message is ever
+    left out for capacity, chi2 stays finite and each robot's solve does not diverge, the received edges are in the graphs."""
+    nr, n_rounds = 8, 24
+    R = synth.make_multi_robot(nr, 5000, 20000, seed=777)
+    rounds = _rounds(lambda r: RobotGraph(ctx, r, nr, cap_edges=128), R, 50, nr)
+    assert rounds[0].g.wire_bytes() == 4 * (2 + 2 * nr) + nr * 128 * 44 + nr * 128 * 4          # 49 224 bytes
+    from cg_mrslam_amd.mrslam import LoopbackExchange
+    ex = LoopbackExchange([r.g for r in rounds])
+    sent_prev = None
+    built_total, ingested_total = 0, 0
+    for t in range(n_rounds):
+        for r in rounds:
+            r.grow()
+            assert r.optimize() == 0
+            assert np.all(np.isfinite(r.last_chi2)) and r.last_chi2[-1] <= r.last_chi2[0] * (1 + 1e-9)
+        n_in = ex.finish_all()
+        if sent_prev is not None:
+            # slice p of robot q's buffer was addressed to robot p: p accepted exactly the edges whose end points it knows,
+            # and never more than were sent; a non-empty slice whose end points are all known is ingested whole
+            for p in range(nr):
+                for q in range(nr):
+                    if q != p:
+                        assert 0 <= n_in[p][q] <= sent_prev[q][p]
+            ingested_total += int(sum(int(np.sum(x)) for x in n_in))
+        built = [r.condense() for r in rounds]
+        for r, b in zip(rounds, built):
+            asked = sum(1 for q in range(nr) if q != r.g.robot and len(r.g.closures(q, "out")) >= 2)
+            assert b == asked                                # a condensed graph for every peer that asked for >= 2 vertices
+        built_total += sum(built)
+        ex.start_all()
+        sent_prev = []
+        for r in rounds:
+            robot, n_e, n_c, edges, clos = unpack_wire(r.g.pack_host(), nr, 128)
+            assert robot == r.g.robot and n_e[robot] == 0
+            sent_prev.append(n_e.copy())
+    ex.finish_all()
+    assert built_total > 50 and ingested_total > 100
+    assert all(r.g.skipped_messages() == 0 for r in rounds)
+    assert sum(r.g.counts()["received_edges"] for r in rounds) > 50
+    assert all(r.g.counts()["vertices"] >= n_rounds * 50 for r in rounds)
+
+
 def test_condense_on_c5_sized_subgraph_with_100_requested_vertices(ctx, oracle):
     """Row a7 at C5 size: a 5000-vertex / 20000-edge sub-graph, ~100 requested vertices (K ~ 100), against the oracle;
     and the same through the flat-array entry point cgmr_condense."""
