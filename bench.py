@@ -237,7 +237,7 @@ def matcher_leg(ctx, dev, args, with_cpu):
     clk = 2.4e9
     valu_issue_peak = 256 * 4 * clk                        # wave instructions / s
     useful_rate = P * byte_adds / 256.0 / ksec             # wave instructions / s that do algorithmic adds
-    lds_peak = 256 * 128 * clk                             # bytes / s: 128 B per CU and clock
+    lds_peak = 256 * 256 * clk                             # bytes / s: the gathers are ds_read_b64, 256 B per CU and clock (MI355X guide, LDS)
     gather_rate = P * byte_adds / ksec                     # algorithmic bytes gathered from the LDS-resident grid / s
     golden = None
     gpath = os.path.join(ROOT, "tests", "golden", "match_close4096.npz")
@@ -257,12 +257,19 @@ def matcher_leg(ctx, dev, args, with_cpu):
                         "hbm": {"achieved_GBps": round(P * 8.7e3 / ksec / 1e9, 3), "peak_GBps": 8000.0,
                                 "frac": round(P * 8.7e3 / ksec / 1e9 / 8000.0, 7),
                                 "traffic_bytes_per_launch": (round(pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096) * P) if pmc_m else None)},
+                        "bytes_fetched_per_useful_byte": round((32 + 8) / 24.0 * 64 / 60, 3),
+                        "lds_bank_conflict_frac": (pmc_m or {}).get("lds_bank_conflict_frac"),
+                        "valu_active_frac_of_wave_cycles": (pmc_m or {}).get("valu_active_frac"),
+                        "phase_cycles_per_pair": (pmc_m or {}).get("phase_cycles_per_pair"),
+                        "counters_stale": pmc_traffic().get("_stale"),
                         "note": "algorithmic = one grid byte per (64 angles x 24 x 24 offsets x k subsampled points) from the sparse "
-                                "grid in LDS, against 128 B per CU and clock; a lane fetches 32 + 8 bytes (four tile rows, four "
-                                "directory entries) for 24 useful ones and LDS instructions are charged for all 64 lanes, so the "
-                                "kernel saturates the LDS pipe at about a quarter of this figure; valu_issue = the same adds as "
-                                "packed-byte VALU instructions (256 per wave instruction) against one per SIMD and clock; HBM "
-                                "carries 8.7 KB per pair and is not the roof (DESIGN.md 3)"}}
+                                "grid in LDS, against the ds_read_b64 rate of 256 B per CU and clock; a lane fetches 32 + 8 bytes (four "
+                                "tile rows, four directory entries) for 24 useful ones and 60 of 64 lanes work "
+                                "(bytes_fetched_per_useful_byte), the 2-byte directory loads cost a 4-byte pass each and "
+                                "lds_bank_conflict_frac of the LDS-array cycles are bank conflicts (SQ_LDS_BANK_CONFLICT / "
+                                "SQ_LDS_IDX_ACTIVE of the committed PMC pass); valu_issue = the same adds as packed-byte VALU "
+                                "instructions (256 per wave instruction) against one per SIMD and clock; HBM carries 8.7 KB per pair "
+                                "and is not the roof (DESIGN.md 3)"}}
     if with_cpu:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O

@@ -16,3 +16,7 @@ for i, n in enumerate(names):
     print(f"{n:22s} {o[i+1]-o[i]:>10d}")
 print("total", o[8]-o[0])
 print("  of the first phase: load + keys", o[9]-o[0], " sort", o[1]-o[9])
+if len(sys.argv) > 1:
+    import json
+    json.dump({n: int(o[i + 1] - o[i]) for i, n in enumerate(names)} | {"total": int(o[8] - o[0]), "note": "cycles of one workgroup for one pair (timing build, tools/gpu_mphase.py)"},
+              open(sys.argv[1], "w"))

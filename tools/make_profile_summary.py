@@ -39,8 +39,28 @@ for k in ("k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_a
                   "traffic_bytes_corrected": round(2 * fe + wr), "launches": nl}
     if k == "k_match_close_batch":
         traffic[k]["pairs"] = 4096
+        conf, _ = avg(k, "SQ_LDS_BANK_CONFLICT"); act, _ = avg(k, "SQ_LDS_IDX_ACTIVE")
+        valu, _ = avg(k, "SQ_ACTIVE_INST_VALU"); wavec, _ = avg(k, "SQ_WAVE_CYCLES")
+        if act > 0: traffic[k]["lds_bank_conflict_frac"] = round(conf / act, 4)
+        if wavec > 0: traffic[k]["valu_active_frac"] = round(valu / wavec, 4)
+        ph = f"{O}/match_phases.json"                                       # tools/gpu_mphase.py on the timing build
+        if os.path.exists(ph): traffic[k]["phase_cycles_per_pair"] = json.load(open(ph))
+# FETCH_SIZE / WRITE_SIZE calibration (tools/ubench/fetch_calib_ubench.hip: every kernel moves a known byte count once)
+calib = {}
+for path in glob.glob(f"{O}/calib_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("k_read") or k.startswith("k_write"):
+            calib.setdefault(k, {})[r["Counter_Name"]] = float(r["Counter_Value"]) * 1024
+if calib:
+    known = 512 << 20
+    traffic["_calibration"] = {k: {c: round(v / known, 4) for c, v in d.items()} for k, d in sorted(calib.items())}
+    traffic["_calibration"]["_note"] = "counter bytes / known bytes moved (512 MiB per kernel); k_read8_records = k_assemble's access pattern"
 traffic["_note"] = ("per-launch averages from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh); "
                     "corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-count of wide streaming reads); matcher launch = 4096 pairs")
+sys.path.insert(0, os.getcwd())
+import bench as bench_py
+traffic["kernel_sources_sha16"] = bench_py.kernel_sources_sha16()              # bench.py flags the counters as stale when the sources change
 json.dump(traffic, open(f"{P}/{rnd}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 print({k: bench[k] for k in ("value", "ms_per_step")}, bench["roofline"], bench["matcher"]["value"])

@@ -20,7 +20,12 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/match_$i --output-format csv -- python $R/tools/match_profile_run.py 4096 > $O/match_$i.log 2>&1
 done
+# FETCH_SIZE / WRITE_SIZE against known byte counts, matcher phase cycles (timing build, if it was shipped)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 120 rocprofv3 --kernel-trace --pmc $c -d $O/calib_$c --output-format csv -- $R/tools/ubench/fetch_calib_ubench > $O/calib_$c.log 2>&1
+done
 cd $R
+[ -f cg_mrslam_amd/libcgmr_t.so ] && CGMR_LIB=cg_mrslam_amd/libcgmr_t.so timeout 120 python tools/gpu_mphase.py $O/match_phases.json > $O/match_phases.log 2>&1
 python tools/pmc_summarise.py $(find $O -name "*counter_collection.csv") > $O/pmc_summary.txt
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
 cat $O/pmc_summary.txt | head -60
