@@ -708,6 +708,7 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (ctx->gn_arena.ptr) (void)hipFree(ctx->gn_arena.ptr);
   if (ctx->io_arena.ptr) (void)hipFree(ctx->io_arena.ptr);
   if (ctx->mt_arena.ptr) (void)hipFree(ctx->mt_arena.ptr);
+  if (ctx->mtab_arena.ptr) (void)hipFree(ctx->mtab_arena.ptr);
   if (ctx->rep_arena.ptr) (void)hipFree(ctx->rep_arena.ptr);
   if (ctx->mg_arena.ptr) (void)hipFree(ctx->mg_arena.ptr);
   for (hipStream_t a : ctx->aux) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }

@@ -19,12 +19,16 @@ struct Arena {
 
 struct cgmr_ctx {
   int device = 0;
+  int n_cus = 0;                 // compute units of the device (queried once)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
   cgmr::Arena gn_arena;     // structure + numeric work space of the last analysed graph
   cgmr::Arena io_arena;     // staging for the host-pointer entry points
   cgmr::Arena mt_arena;     // matcher work space
+  cgmr::Arena mtab_arena;   // close matcher: beam table + kernel LUT, kept while the laser / kernel parameters stay the same
+  bool mtab_valid = false;
+  double mtab_key[6] = {0, 0, 0, 0, 0, 0};
   cgmr::Arena rep_arena;    // replicas of the GN numeric work space (concurrent passes on one structure)
   cgmr::Arena mg_arena;     // marginals work space of the concurrent passes
   std::vector<hipStream_t> aux;          // side streams of the concurrent passes

@@ -65,9 +65,17 @@ int setup_geometry(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, MatchParams& P
   return CGMR_OK;
 }
 
+// Host buffers of a call, staged through ONE pinned block each way (a handful of pairs -- the reference's one call per key
+// frame -- is dominated by the number of HIP calls, not by bytes): h_in is copied to d_in before the launch, d_out to
+// h_out after it, and the only host synchronisation of the call comes last.
+struct MatchIo {
+  const void* h_in = nullptr; char* d_in = nullptr; size_t in_bytes = 0;
+  void* h_out = nullptr; const char* d_out = nullptr; size_t out_bytes = 0;
+};
+
 int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_ref_scans, const float* d_ref,
               const double* d_xform, const float* d_qry, const double* d_guess, double max_score, double* d_xyt,
-              double* d_score, uint8_t* d_found, int32_t* d_nres) {
+              double* d_score, uint8_t* d_found, int32_t* d_nres, const MatchIo* io = nullptr) {
   if (!cfg || n_pairs < 0 || n_ref_scans < 1 || n_ref_scans > kMatchMaxRefScans)
     return set_err(ctx, CGMR_E_INVALID, "cgmr_match_close_batch: bad argument (1..%d reference scans per pair)", kMatchMaxRefScans);
   if (cfg->n_beams <= 0 || cfg->n_beams > kMatchMaxPoints)
@@ -98,42 +106,76 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
     P.scratch_stride += cellmap_bytes;
   }
   if (n_pairs == 0) return CGMR_OK;
-  hipDeviceProp_t prop;
-  HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-  int nblocks = std::min(n_pairs, prop.multiProcessorCount);      // one 160 KB-LDS workgroup per CU
-  // device work space: beam table, kernel LUT, scratch, error flag
+  if (ctx->n_cus <= 0) {
+    int ncu = 0;
+    HIP_TRY(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    ctx->n_cus = std::max(ncu, 1);
+  }
+  // A handful of pairs (the reference's call shape: one closeScanMatching per key frame) leave the chip idle at one
+  // workgroup per pair: up to 16 workgroups then share a pair's search angles (every split-th batch of 8 angles each)
+  static const int split_max = getenv("CGMR_MATCH_SPLIT") ? std::max(1, atoi(getenv("CGMR_MATCH_SPLIT"))) : 16;
+  P.split = std::max(1, std::min(split_max, ctx->n_cus / std::max(n_pairs, 1)));
+  const int n_items = n_pairs * P.split;
+  int nblocks = std::min(n_items, ctx->n_cus);                    // one 160 KB-LDS workgroup per CU
+  // ---- beam table (RawLaser::cartesian: alpha = firstBeamAngle + i * angularStep, host libm cos / sin [g2o-recalled]) and
+  // kernel LUT: on the device in an arena of their own, recomputed only when the laser / kernel parameters change
+  Layout T;
+  const size_t t_cos = T.add(sizeof(double) * P.n_beams), t_sin = T.add(sizeof(double) * P.n_beams), t_kern = T.add(kern.size());
+  const double tkey[6] = {(double)P.n_beams, cfg->angle_min, cfg->angle_inc, cfg->resolution, cfg->kernel_range, (double)cfg->kscale};
+  if (!ctx->mtab_valid || memcmp(tkey, ctx->mtab_key, sizeof tkey) != 0) {
+    int rc = arena_reserve(ctx, ctx->mtab_arena, T.off + 256);
+    if (rc) return rc;
+    std::vector<char> host(T.off);
+    double* hc = (double*)(host.data() + t_cos);
+    double* hs = (double*)(host.data() + t_sin);
+    for (int i = 0; i < P.n_beams; i++) {
+      double alpha = cfg->angle_min + i * cfg->angle_inc;
+      hc[i] = std::cos(alpha);
+      hs[i] = std::sin(alpha);
+    }
+    memcpy(host.data() + t_kern, kern.data(), kern.size());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->mtab_arena.ptr, host.data(), T.off, hipMemcpyHostToDevice));
+    memcpy(ctx->mtab_key, tkey, sizeof tkey);
+    ctx->mtab_valid = true;
+  }
+  const char* tab = ctx->mtab_arena.ptr;
+  // ---- device work space: error / work-counter words, the split pairs' shared bins + arrival counters, scratch
   Layout L;
-  size_t o_cos = L.add(sizeof(double) * P.n_beams), o_sin = L.add(sizeof(double) * P.n_beams);
-  size_t o_kern = L.add(kern.size()), o_err = L.add(16), o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
+  size_t o_err = L.add(16);
+  const size_t merge_bytes = P.split > 1 ? (size_t)n_pairs * (match_close_max_bins() * 8 + 8) : 0;
+  size_t o_merge = L.add(merge_bytes), o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
   int rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
   if (rc) return rc;
-  size_t hbytes = o_err + 16;
-  rc = pinned_reserve(ctx, hbytes);
+  const size_t io_in = io ? io->in_bytes : 0, io_out = io ? io->out_bytes : 0;
+  rc = pinned_reserve(ctx, 256 + io_in + io_out + 256);
   if (rc) return rc;
-  // RawLaser::cartesian: alpha = firstBeamAngle + i * angularStep, host libm cos / sin [g2o-recalled]
-  double* hc = (double*)(ctx->pinned + o_cos);
-  double* hs = (double*)(ctx->pinned + o_sin);
-  for (int i = 0; i < P.n_beams; i++) {
-    double alpha = cfg->angle_min + i * cfg->angle_inc;
-    hc[i] = std::cos(alpha);
-    hs[i] = std::sin(alpha);
-  }
-  memcpy(ctx->pinned + o_kern, kern.data(), kern.size());
-  memset(ctx->pinned + o_err, 0, 16);
-  ((int*)(ctx->pinned + o_err))[1] = nblocks;     // work counter: the first nblocks pairs are taken by blockIdx
   char* d = ctx->mt_arena.ptr;
-  HIP_TRY(ctx, hipMemcpyAsync(d, ctx->pinned, hbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));               // (the pinned block of the previous call may still be in flight)
+  int* h_err = (int*)ctx->pinned;
+  h_err[0] = 0; h_err[1] = nblocks; h_err[2] = 0; h_err[3] = 0;   // [1] work counter: the first nblocks items are taken by blockIdx
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_err, h_err, 16, hipMemcpyHostToDevice, ctx->stream));
+  if (io_in) {
+    memcpy(ctx->pinned + 256, io->h_in, io_in);
+    HIP_TRY(ctx, hipMemcpyAsync(io->d_in, ctx->pinned + 256, io_in, hipMemcpyHostToDevice, ctx->stream));
+  }
   if (cellmap_bytes)      // the arena is shared with the other matcher launches: the bitmaps start every launch cleared
     HIP_TRY(ctx, hipMemset2DAsync(d + o_scratch + P.cellmap_off, P.scratch_stride, 0, cellmap_bytes, (size_t)nblocks, ctx->stream));
+  if (merge_bytes)        // empty bins (all ones) and arrival counters at -1, in one fill
+    HIP_TRY(ctx, hipMemsetAsync(d + o_merge, 0xff, merge_bytes, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  launch_match_close_batch(ctx->stream, nblocks, P, d_ref, d_xform, d_qry, d_guess, (const double*)(d + o_cos),
-                           (const double*)(d + o_sin), (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch),
-                           d_xyt, d_score, d_found, d_nres, (int*)(d + o_err));
+  launch_match_close_batch(ctx->stream, nblocks, P, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
+                           (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
+                           d_xyt, d_score, d_found, d_nres, (int*)(d + o_err), (unsigned long long*)(d + o_merge),
+                           (int*)(d + o_merge + (size_t)n_pairs * match_close_max_bins() * 8));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  int errv[4] = {0, 0, 0, 0};
-  HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, sizeof errv, hipMemcpyDeviceToHost, ctx->stream));
+  int* errv = (int*)(ctx->pinned + 64);
+  HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 16, hipMemcpyDeviceToHost, ctx->stream));
+  char* h_out_stage = ctx->pinned + 256 + io_in + ((256 - io_in % 256) % 256);
+  if (io_out) HIP_TRY(ctx, hipMemcpyAsync(h_out_stage, io->d_out, io_out, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
+  if (io_out) memcpy(io->h_out, h_out_stage, io_out);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->match_seconds = 1e-3 * ms;
@@ -213,24 +255,46 @@ int cgmr_match_close_vset_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
   const size_t ns = (size_t)n_pairs * n_ref_scans, nbq = (size_t)n_pairs * cfg->n_beams, nbr = ns * cfg->n_beams;
   std::vector<double> xf(4 * ns);
   scan_transforms(cfg, ns, ref_rel_xyt, xf.data());
-  Layout L;
-  size_t o_ref = L.add(nbr * 4), o_xf = L.add(ns * 32), o_qry = L.add(nbq * 4), o_g = L.add((size_t)n_pairs * 24),
-         o_x = L.add((size_t)n_pairs * 24), o_s = L.add((size_t)n_pairs * 8), o_f = L.add(n_pairs), o_n = L.add((size_t)n_pairs * 4);
-  int rc = arena_reserve(ctx, ctx->io_arena, L.off + 256);
+  // device layout: inputs [reference ranges | transforms | query ranges | guesses], outputs [xyt | score | n results | found]
+  auto r8 = [](size_t v) { return (v + 7) & ~size_t(7); };
+  const size_t o_ref = 0, o_xf = r8(o_ref + nbr * 4), o_qry = o_xf + ns * 32, o_g = r8(o_qry + nbq * 4), in_bytes = o_g + (size_t)n_pairs * 24;
+  const size_t o_x = r8(in_bytes + 255) & ~size_t(255), o_s = o_x + (size_t)n_pairs * 24, o_n = o_s + (size_t)n_pairs * 8,
+               o_f = o_n + (size_t)n_pairs * 4, out_bytes = o_f + n_pairs - o_x;
+  int rc = arena_reserve(ctx, ctx->io_arena, o_x + out_bytes + 256);
   if (rc) return rc;
   char* d = ctx->io_arena.ptr;
-  HIP_TRY(ctx, hipMemcpyAsync(d + o_ref, ranges_ref, nbr * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d + o_xf, xf.data(), ns * 32, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d + o_qry, ranges_qry, nbq * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d + o_g, guess, (size_t)n_pairs * 24, hipMemcpyHostToDevice, ctx->stream));
+  if (in_bytes > (size_t(4) << 20)) {
+    // a real batch: the bytes dominate, copy straight from the caller's buffers
+    HIP_TRY(ctx, hipMemcpyAsync(d + o_ref, ranges_ref, nbr * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + o_xf, xf.data(), ns * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + o_qry, ranges_qry, nbq * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + o_g, guess, (size_t)n_pairs * 24, hipMemcpyHostToDevice, ctx->stream));
+    rc = match_run(ctx, cfg, n_pairs, n_ref_scans, (const float*)(d + o_ref), (const double*)(d + o_xf), (const float*)(d + o_qry),
+                   (const double*)(d + o_g), max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), (int32_t*)(d + o_n));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_xyt, d + o_x, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_score, d + o_s, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_found, d + o_f, n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_nres) HIP_TRY(ctx, hipMemcpyAsync(out_nres, d + o_n, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CGMR_OK;
+  }
+  std::vector<char> in(in_bytes);
+  memcpy(in.data() + o_ref, ranges_ref, nbr * 4);
+  memcpy(in.data() + o_xf, xf.data(), ns * 32);
+  memcpy(in.data() + o_qry, ranges_qry, nbq * 4);
+  memcpy(in.data() + o_g, guess, (size_t)n_pairs * 24);
+  std::vector<char> out(out_bytes);
+  MatchIo io;
+  io.h_in = in.data(); io.d_in = d; io.in_bytes = in_bytes;
+  io.h_out = out.data(); io.d_out = d + o_x; io.out_bytes = out_bytes;
   rc = match_run(ctx, cfg, n_pairs, n_ref_scans, (const float*)(d + o_ref), (const double*)(d + o_xf), (const float*)(d + o_qry),
-                 (const double*)(d + o_g), max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), (int32_t*)(d + o_n));
+                 (const double*)(d + o_g), max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), (int32_t*)(d + o_n), &io);
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(out_xyt, d + o_x, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(out_score, d + o_s, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(out_found, d + o_f, n_pairs, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_nres) HIP_TRY(ctx, hipMemcpyAsync(out_nres, d + o_n, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out_xyt, out.data(), (size_t)n_pairs * 24);
+  memcpy(out_score, out.data() + (o_s - o_x), (size_t)n_pairs * 8);
+  memcpy(out_found, out.data() + (o_f - o_x), n_pairs);
+  if (out_nres) memcpy(out_nres, out.data() + (o_n - o_x), (size_t)n_pairs * 4);
   return CGMR_OK;
 }
 

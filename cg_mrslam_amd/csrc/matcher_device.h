@@ -16,6 +16,8 @@ constexpr int kMatchMaxRefScans = 6;         // scans of a close-matching refere
 struct MatchParams {
   int n_pairs, n_beams;
   int n_ref_scans;                           // scans per reference set of the batched close matcher (1..kMatchMaxRefScans)
+  int split;                                 // close matcher: workgroups per pair (each takes every split-th batch of search angles);
+                                             // 1 in batch mode, > 1 for a single call's latency (k_match_close_batch)
   // grid (ScanMatcher::initializeGrid, src/matcher/scan_matcher.cpp:63-66; gridmap.h:196-214)
   float ll_x, ll_y, res, inv_res;
   int nx, ny;
@@ -73,6 +75,8 @@ void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, cons
 void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
-                              double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err);
+                              double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err,
+                              unsigned long long* gbins, int* arrive);
+int match_close_max_bins();
 
 }  // namespace cgmr

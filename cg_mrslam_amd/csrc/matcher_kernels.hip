@@ -369,7 +369,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
                                                            unsigned char* __restrict__ scratch,
                                                            double* __restrict__ out_xyt, double* __restrict__ out_score,
                                                            uint8_t* __restrict__ out_found, int* __restrict__ out_nres,
-                                                           int* __restrict__ err) {
+                                                           int* __restrict__ err, unsigned long long* gbins, int* arrive) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
@@ -391,7 +391,15 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 
   // pairs are handed out through a counter (err[1], starts at gridDim.x): a slow pair (generic path) does not
   // hold up the pairs a static stride would have queued behind it
-  for (int pair = blockIdx.x; pair < P.n_pairs;) {
+  // A work item is (pair, part): with P.split > 1 -- a single call, where the latency of ONE pair matters and 255 CUs
+  // would idle (the reference calls closeScanMatching once per key frame, src/slam/graph_slam.cpp:230-244) -- P.split
+  // workgroups prepare the same pair (query points, grid: deterministic, so identical) and each searches every split-th
+  // batch of angles; the per-bin minima meet in a global table (atomicMin on the same 64-bit keys: score bits << 32 |
+  // visit order, the visit order counted over ALL angles, so "first seen wins" holds across workgroups) and the
+  // workgroup that arrives last produces the result.
+  const int n_items = P.n_pairs * P.split;
+  for (int item = blockIdx.x; item < n_items;) {
+    const int pair = item / P.split, part = item - pair * P.split;
     __syncthreads();
     MPHASE(0);
     // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
@@ -631,8 +639,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     const bool v2 = fast && nj <= 24 && ni <= 12 * RPL && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u && K2 * PPI <= 255;
     MPHASE(6);
     // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
-    for (int tb = 0; tb < nth; tb += nsearch) {
-      const int ti = (wave < nsearch) ? tb + wave : nth;
+    for (int tb = part * nsearch; tb < nth; tb += nsearch * P.split) {
+      const int ti = (wave < nsearch) ? min(tb + wave, nth) : nth;
       int k = 0, k0p = 0, k1p = 0;
       if (ti < nth) {
         double c, s;
@@ -909,8 +917,24 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     }
     __syncthreads();
     MPHASE(7);
+    bool produce = true;                       // this workgroup writes the pair's result
+    if (P.split > 1) {
+      unsigned long long* gb = gbins + (size_t)pair * MAXBINS;
+      for (int q = tid; q < nbins; q += CB_THREADS)
+        if (S.bins[q] != ~0ULL) atomicMin(&gb[q], S.bins[q]);
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) S.misc[15] = atomicAdd(&arrive[pair], 1);      // the counters start at -1 (one memset of 0xff for the whole table)
+      __syncthreads();
+      produce = S.misc[15] == P.split - 2;
+      if (produce) {
+        __threadfence();
+        for (int q = tid; q < nbins; q += CB_THREADS) S.bins[q] = __hip_atomic_load(&gb[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+    }
     // ---------------- result: lowest score, ties -> first bin in map order (ix, iy, ith) -------------------
-    if (tid == 0) {
+    if (tid == 0 && produce) {
       unsigned long long best = ~0ULL;
       int nres = 0;
       for (int q = 0; q < nbins; q++) {
@@ -941,7 +965,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     __syncthreads();
     if (tid == 0) S.misc[13] = atomicAdd(err + 1, 1);
     __syncthreads();
-    pair = S.misc[13];
+    item = S.misc[13];
   }
 }
 
@@ -1159,11 +1183,13 @@ void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, cons
 void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
-                              double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err) {
+                              double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err,
+                              unsigned long long* gbins, int* arrive) {
   set_lds_attr_once<2>(reinterpret_cast<const void*>(k_match_close_batch));
   hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(CB_THREADS), sizeof(Smem), st, P, ranges_ref, ref_xform, ranges_qry, guess,
-                     beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err);
+                     beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err, gbins, arrive);
 }
+int match_close_max_bins() { return MAXBINS; }
 
 }  // namespace cgmr
 
