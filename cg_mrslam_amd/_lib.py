@@ -185,9 +185,9 @@ class Context:
         self._check(self.lib.cgmr_set_symbolic_cache(self.h, C.c_int(1 if on else 0)))
 
     def symbolic_cache_stats(self):
-        out = np.zeros(2, dtype=np.int64)
+        out = np.zeros(3, dtype=np.int64)
         self._check(self.lib.cgmr_symbolic_cache_stats(self.h, _ptr(out)))
-        return {"hits": int(out[0]), "misses": int(out[1])}
+        return {"hits": int(out[0]), "misses": int(out[1]), "extended": int(out[2])}
 
     def gn_last_timing(self):
         out = np.zeros(5)
@@ -203,6 +203,30 @@ class Context:
         self._check(self.lib.cgmr_gn_kernel_times(self.h, _ptr(sec), _ptr(n)))
         names = ["linearize", "assemble", "chi2", "front_factor", "front_update", "top_block", "solve_bwd", "update"]
         return {k: (float(s), int(c)) for k, s, c in zip(names, sec, n)}
+
+
+_SYM_KEYS = ["free_poses", "offdiag_blocks", "fronts", "levels", "L_doubles", "U_doubles", "max_border",
+             "factor_flops", "order_us", "structure_us", "max_children", "max_children_small_border", "panel_doubles",
+             "launch_levels", "top_block_fronts", "top_block_cols"]
+
+
+def gn_symbolic_info_grown(nV0, nE0, nV_steps, nE_steps, ef, et):
+    """Host-only: analyse the first (nV0, nE0) vertices / edges, then extend step by step (the key-frame pattern).  Returns
+    (info of the last analysis, its vertex -> column permutation, number of steps that re-used the ordering)."""
+    lib = load_library()
+    ef = np.ascontiguousarray(ef, dtype=np.int32)
+    et = np.ascontiguousarray(et, dtype=np.int32)
+    nv = np.ascontiguousarray(nV_steps, dtype=np.int32)
+    ne = np.ascontiguousarray(nE_steps, dtype=np.int32)
+    out = np.zeros(16, dtype=np.int64)
+    nV = int(nv[-1]) if len(nv) else nV0
+    perm = np.zeros(nV, dtype=np.int32)
+    next_ = C.c_int32(0)
+    rc = lib.cgmr_gn_symbolic_info_grown(C.c_int(nV0), C.c_int(nE0), C.c_int(len(nv)), _ptr(nv), _ptr(ne), _ptr(ef), _ptr(et),
+                                         _ptr(out), _ptr(perm), C.byref(next_))
+    if rc != 0:
+        raise CgmrError(rc, "cgmr_gn_symbolic_info_grown rejected the graph")
+    return dict(zip(_SYM_KEYS, out.tolist())), perm, int(next_.value)
 
 
 def gn_symbolic_info(nV, fixed, ef, et, want_perm=False):

@@ -354,9 +354,21 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
     ctx->sym.t_order = ctx->sym.t_struct = ctx->sym.t_upload = 0;
     return 0;
   }
-  ctx->sym_misses++;
+  // The key-frame pattern: the cached edge list plus vertices / edges appended at the end (graph_slam.cpp:197-267 adds a
+  // vertex and a few edges per key frame; a multi-robot round adds a chunk).  The ordering is then extended instead of
+  // recomputed (gn_symbolic.cpp: extend_order); everything downstream of the ordering is built as for a new graph.
+  const bool grown = ctx->sym_cache_on && ctx->sym_valid && nV >= ctx->sym_nV && nE >= (int)ctx->sym_ef.size() && !ctx->sym_ef.empty() &&
+                     memcmp(ctx->sym_ef.data(), ef, sizeof(int32_t) * ctx->sym_ef.size()) == 0 &&
+                     memcmp(ctx->sym_et.data(), et, sizeof(int32_t) * ctx->sym_et.size()) == 0;
   ctx->sym_valid = false;
-  int rc = analyze(nV, nullptr, nE, ef, et, ctx->sym);
+  int rc;
+  if (grown) {
+    Symbolic old = std::move(ctx->sym);
+    rc = analyze(nV, nullptr, nE, ef, et, ctx->sym, &old);
+  } else {
+    rc = analyze(nV, nullptr, nE, ef, et, ctx->sym);
+  }
+  if (rc == 0 && ctx->sym.extended) ctx->sym_extended++; else ctx->sym_misses++;
   if (rc) return set_err(ctx, CGMR_E_INVALID, "graph structure rejected (edge index out of range)");
   const int chi_cap = std::max(iters, 30);
   const double tu0 = wall_s();
@@ -772,13 +784,7 @@ int cgmr_gn_optimize(cgmr_ctx* ctx, int nV, double* poses, const uint8_t* fixed,
   return rc;
 }
 
-int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx, const int32_t* to_idx,
-                          int64_t out[16], int32_t* perm_out) {
-  if (nV < 0 || nE < 0 || !out) return CGMR_E_INVALID;
-  Symbolic S;
-  (void)fixed;          // the solver applies the fixed flags numerically: they are not part of the analysis
-  int rc = analyze(nV, nullptr, nE, from_idx, to_idx, S);
-  if (rc) return CGMR_E_INVALID;
+static void symbolic_info_out(const Symbolic& S, int nV, int64_t out[16], int32_t* perm_out) {
   out[0] = S.nf; out[1] = S.nb; out[2] = (int64_t)S.fronts.size(); out[3] = (int64_t)S.level_ptr.size() - 1;
   out[4] = S.L_doubles; out[5] = S.U_doubles; out[6] = S.max_ns; out[7] = (int64_t)S.flops;
   out[8] = (int64_t)(1e6 * S.t_order); out[9] = (int64_t)(1e6 * S.t_struct);
@@ -790,6 +796,35 @@ int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* f
     if (F.ns >= 1 && F.ns <= 32) out[11] = std::max<int64_t>(out[11], F.nchild);
   }
   if (perm_out) memcpy(perm_out, S.vperm.data(), sizeof(int32_t) * nV);
+}
+
+int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx, const int32_t* to_idx,
+                          int64_t out[16], int32_t* perm_out) {
+  if (nV < 0 || nE < 0 || !out) return CGMR_E_INVALID;
+  Symbolic S;
+  (void)fixed;          // the solver applies the fixed flags numerically: they are not part of the analysis
+  int rc = analyze(nV, nullptr, nE, from_idx, to_idx, S);
+  if (rc) return CGMR_E_INVALID;
+  symbolic_info_out(S, nV, out, perm_out);
+  return CGMR_OK;
+}
+
+int cgmr_gn_symbolic_info_grown(int nV0, int nE0, int n_steps, const int32_t* nV_step, const int32_t* nE_step,
+                                const int32_t* from_idx, const int32_t* to_idx, int64_t out[16], int32_t* perm_out,
+                                int32_t* n_extended_out) {
+  if (nV0 < 0 || nE0 < 0 || n_steps < 0 || !out || (n_steps > 0 && (!nV_step || !nE_step))) return CGMR_E_INVALID;
+  Symbolic S;
+  if (analyze(nV0, nullptr, nE0, from_idx, to_idx, S)) return CGMR_E_INVALID;
+  int nV = nV0, next = 0;
+  for (int k = 0; k < n_steps; k++) {
+    if (nV_step[k] < nV || nE_step[k] < S.nE) return CGMR_E_INVALID;
+    Symbolic old = std::move(S);
+    if (analyze(nV_step[k], nullptr, nE_step[k], from_idx, to_idx, S, &old)) return CGMR_E_INVALID;
+    nV = nV_step[k];
+    next += S.extended ? 1 : 0;
+  }
+  if (n_extended_out) *n_extended_out = next;
+  symbolic_info_out(S, nV, out, perm_out);
   return CGMR_OK;
 }
 
@@ -821,9 +856,9 @@ int cgmr_set_symbolic_cache(cgmr_ctx* ctx, int on) {
   return CGMR_OK;
 }
 
-int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]) {
+int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[3]) {
   if (!ctx || !out) return CGMR_E_INVALID;
-  out[0] = ctx->sym_hits; out[1] = ctx->sym_misses;
+  out[0] = ctx->sym_hits; out[1] = ctx->sym_misses; out[2] = ctx->sym_extended;
   return CGMR_OK;
 }
 

@@ -120,6 +120,16 @@ struct NDCtx {
   std::vector<int32_t> tmp;           // partition scratch, indexed by position
   std::atomic<int> next_label{1};
   int max_par_depth = 0;              // recursion levels that fork a thread for one half
+  // the dissection tree, recorded for the incremental analysis of a graph that grows (sizes only: positions follow from
+  // the root's, children may trade places after they were recorded)
+  struct Rec { int32_t a = -1, b = -1, n = 0, ssz = 0; };
+  std::vector<Rec> recs;              // preallocated: node ids are handed out by an atomic counter (the halves run in parallel)
+  std::atomic<int> n_recs{0};
+  int new_rec(int a, int b, int n, int ssz) {
+    const int id = n_recs.fetch_add(1);
+    if (id < (int)recs.size()) { recs[id].a = a; recs[id].b = b; recs[id].n = n; recs[id].ssz = ssz; }
+    return id;
+  }
 };
 
 // What a parent separator needs to know about an ordered range: the size of its last panel (the one the separator,
@@ -167,12 +177,15 @@ int bfs(NDCtx& C, int32_t* q, int root, int id, int visited_id, int32_t* lvl = n
 
 // Orders [begin, end) and marks its panels.
 // `start`: a vertex of the range known to lie at one end of it (the parent's sweep began or ended there), or -1.
-NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
+NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_out = nullptr) {
   int n = end - begin;
   static const bool nd_trace = getenv("CGMR_SYM_TRACE") != nullptr;
   const double t_in = nd_trace ? now_s() : 0;
+  int node_sink = -1;
+  int& node = node_out ? *node_out : node_sink;
+  node = -1;
   if (n <= 0) return NDRange();
-  if (n <= kPanelW) return emit_panels(C, begin, end);
+  if (n <= kPanelW) { node = C.new_rec(-1, -1, n, n); return emit_panels(C, begin, end); }
   int32_t* Q = C.queue.data() + begin;                  // this call's slice of the BFS queue
   int id = C.next_label.fetch_add(3);
   for (int p = begin; p < end; p++) C.vs[C.order[p]].label = id;
@@ -189,9 +202,11 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
     for (int q = 0; q < reached; q++) C.tmp[k++] = Q[q];
     for (int p = begin; p < end; p++) if (C.vs[C.order[p]].label == id) C.tmp[k++] = C.order[p];
     std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
-    NDRange r1 = nd(C, begin, begin + reached, depth);
-    NDRange r2 = nd(C, begin + reached, end, depth);
+    int n1 = -1, n2 = -1;
+    NDRange r1 = nd(C, begin, begin + reached, depth, -1, &n1);
+    NDRange r2 = nd(C, begin + reached, end, depth, -1, &n2);
     r2.height = std::max(r1.height, r2.height);
+    node = C.new_rec(n1, n2, n, 0);                       // independent components: two halves, no separator
     return r2;
   }
   if (!have_start) {
@@ -200,7 +215,7 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
     bfs(C, Q, far, vis1, vis2, LV);
   }
   int nlev = C.vs[Q[n - 1]].dist + 1;
-  if (nlev <= 2) return emit_panels(C, begin, end);  // clique-like: nothing to dissect
+  if (nlev <= 2) { node = C.new_rec(-1, -1, n, n); return emit_panels(C, begin, end); }  // clique-like: nothing to dissect
   thread_local std::vector<int32_t> lvl_cnt;            // (the sweep counted the levels into the partition scratch: keep a copy)
   lvl_cnt.assign(LV, LV + nlev);
   lvl_cnt.push_back(0);
@@ -294,15 +309,16 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
   if (nd_trace && depth <= 3) fprintf(stderr, "    nd depth %d n %5d own work %.1f us\n", depth, n, 1e6 * (now_s() - t_in));
   // the two halves touch disjoint vertices and disjoint position ranges: fork one of them near the top
   NDRange r1, r2;
+  int n1 = -1, n2 = -1;
   if (depth < C.max_par_depth && na > 512 && nb > 512) {
     HelperPool::Job job;
-    job.fn = [&C, &r1, begin, na, depth, start_a] { r1 = nd(C, begin, begin + na, depth + 1, start_a); };
+    job.fn = [&C, &r1, &n1, begin, na, depth, start_a] { r1 = nd(C, begin, begin + na, depth + 1, start_a, &n1); };
     pool().run(job);
-    r2 = nd(C, begin + na, begin + na + nb, depth + 1, start_b);
+    r2 = nd(C, begin + na, begin + na + nb, depth + 1, start_b, &n2);
     HelperPool::wait(job);
   } else {
-    r1 = nd(C, begin, begin + na, depth + 1, start_a);
-    r2 = nd(C, begin + na, begin + na + nb, depth + 1, start_b);
+    r1 = nd(C, begin, begin + na, depth + 1, start_a, &n1);
+    r2 = nd(C, begin + na, begin + na + nb, depth + 1, start_b, &n2);
   }
   // Only the half right in front of the separator can share a panel with it (see the amalgamation in analyze()):
   // that should be the taller one, so the two blocks trade places when the first turned out taller.
@@ -319,7 +335,9 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1) {
       }
     }
     std::swap(r1, r2);
+    std::swap(n1, n2);
   }
+  node = C.new_rec(n1, n2, n, end - s0);
   if (depth == kRangeDepth && na > 0 && nb > 0) {
     const int mid = begin + (swapped ? nb : na);
     std::lock_guard<std::mutex> lk(C.range_mu);
@@ -397,9 +415,169 @@ int host_threads() {
   return n;
 }
 
+// ------------------------------------------------------------------ incremental ordering
+// The previous dissection tree extended by the vertices prev.nf .. nf-1 (gn_symbolic.h: Symbolic::NDNode).  A vertex may live
+// in node X (a leaf, or the separator of an inner node) iff each of its neighbours lives in X's subtree or in the
+// separator of an ancestor of X -- then everything that couples two subtrees still sits in a separator above both.  The
+// new vertices are placed in index order (a new pose's neighbours are older poses and poses placed just before it):
+//   neighbours' nodes minus those that are ancestors of another one = the constraint set
+//   one node, a leaf            -> into that leaf
+//   one node, an inner one      -> below it: down the lighter child to a leaf (the neighbour sits in the separator above)
+//   several nodes               -> into the separator of their lowest common ancestor
+// A leaf that outgrows two panels is dissected again on its own vertices (a robot that keeps exploring appends to the same
+// leaf: without this the tree would grow a chain of panels there, one level per 16 poses).  Then the order and the panel
+// starts are emitted by a walk over the tree that cuts panels exactly like nd() does.  Returns false if the tree cannot
+// take the vertices (nothing is modified then).
+bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const std::vector<int32_t>& ai,
+                  std::vector<int32_t>& order, std::vector<uint8_t>& pstart, std::vector<std::pair<int, int>>& pos_ranges,
+                  Symbolic& S) {
+  typedef Symbolic::NDNode Node;
+  std::vector<Node> T = std::move(prev.nd_nodes);            // (the caller's previous analysis is discarded afterwards either way)
+  const int root = prev.nd_root;
+  if (root < 0 || T.empty()) return false;
+  std::vector<int32_t> where(nf, -1), depth(T.size(), 0);
+  {
+    std::vector<int> stack(1, root);
+    while (!stack.empty()) {
+      const int x = stack.back(); stack.pop_back();
+      for (int32_t v : T[x].verts) { if (v < 0 || v >= nf) return false; where[v] = x; }
+      for (int c : {T[x].a, T[x].b}) if (c >= 0) { depth[c] = depth[x] + 1; stack.push_back(c); }
+    }
+  }
+  auto is_ancestor = [&](int anc, int x) {               // anc == x counts
+    while (x >= 0 && depth[x] > depth[anc]) x = T[x].parent;
+    return x == anc;
+  };
+  auto lca = [&](int x, int y) {
+    while (x != y) { if (depth[x] >= depth[y]) x = T[x].parent; else y = T[y].parent; }
+    return x;
+  };
+  std::vector<int> grown;                                 // leaves to look at again
+  std::vector<int> cand;
+  for (int v = prev.nf; v < nf; v++) {
+    cand.clear();
+    for (int p = ap[v]; p < ap[v + 1]; p++) {
+      const int x = where[ai[p]];
+      if (x >= 0 && std::find(cand.begin(), cand.end(), x) == cand.end()) cand.push_back(x);
+    }
+    int target;
+    if (cand.empty()) target = root;                       // no placed neighbour: anywhere; the root's separator couples nothing
+    else {
+      // drop every node that is an ancestor of another candidate
+      std::vector<int> low;
+      for (int x : cand) {
+        bool anc = false;
+        for (int y : cand) if (y != x && is_ancestor(x, y)) { anc = true; break; }
+        if (!anc) low.push_back(x);
+      }
+      target = low[0];
+      for (size_t k = 1; k < low.size(); k++) target = lca(target, low[k]);
+      if (low.size() == 1) {
+        while (T[target].a >= 0 || T[target].b >= 0) {     // below an inner node: the lighter child, down to a leaf
+          const int a = T[target].a, b = T[target].b;
+          target = (a >= 0 && (b < 0 || T[a].count <= T[b].count)) ? a : b;
+        }
+      }
+    }
+    T[target].verts.push_back(v);
+    where[v] = target;
+    for (int x = target; x >= 0; x = T[x].parent) T[x].count++;
+    if (T[target].a < 0 && T[target].b < 0 && (int)T[target].verts.size() > 2 * kPanelW &&
+        std::find(grown.begin(), grown.end(), target) == grown.end()) grown.push_back(target);
+  }
+  // ---- leaves that outgrew two panels: dissect them again (their own vertices, the full adjacency)
+  if (!grown.empty()) {
+    std::vector<int32_t> lorder;
+    std::vector<uint8_t> lpstart;
+    for (int leaf : grown) {
+      const int n = (int)T[leaf].verts.size();
+      lorder = T[leaf].verts;
+      lpstart.assign(n, 0);
+      NDCtx C{ap, ai, lorder, lpstart};
+      C.vs.assign(nf, NDCtx::VState{0, 0});
+      C.queue.assign(n, 0);
+      C.tmp.assign(n, 0);
+      C.recs.assign(2 * (size_t)n + 4, NDCtx::Rec());
+      C.max_par_depth = 0;
+      int root_rec = -1;
+      nd(C, 0, n, kRangeDepth + 1, -1, &root_rec);         // (depth beyond kRangeDepth: records no subtree ranges)
+      if (root_rec < 0) continue;
+      const int parent = T[leaf].parent;
+      std::function<int(int, int, int, int)> build = [&](int rec, int begin, int par, int reuse) -> int {
+        if (rec < 0) return -1;
+        const NDCtx::Rec R = C.recs[rec];
+        int id = reuse;
+        if (id < 0) { id = (int)T.size(); T.emplace_back(); depth.push_back(0); }
+        T[id].parent = par;
+        T[id].count = R.n;
+        depth[id] = par >= 0 ? depth[par] + 1 : 0;
+        const int na = R.a >= 0 ? C.recs[R.a].n : 0, nb = R.b >= 0 ? C.recs[R.b].n : 0;
+        const int ca = build(R.a, begin, id, -1), cb = build(R.b, begin + na, id, -1);
+        T[id].a = ca; T[id].b = cb;
+        T[id].verts.assign(lorder.begin() + begin + na + nb, lorder.begin() + begin + na + nb + R.ssz);
+        return id;
+      };
+      build(root_rec, 0, parent, leaf);
+    }
+  }
+  // ---- order + panel starts: children, then the separator, panels cut as in nd()
+  struct Emit {
+    std::vector<Node>& T;
+    std::vector<int32_t>& order;
+    std::vector<uint8_t>& pstart;
+    std::vector<std::pair<int, int>>& ranges;
+    int pos = 0;
+    NDRange panels(int begin, int end) {
+      NDRange r;
+      for (int p = begin; p < end; p += kPanelW) { pstart[p] = 1; r.height++; }
+      r.last = end > begin ? (end - begin - 1) % kPanelW + 1 : 0;
+      return r;
+    }
+    NDRange walk(int x, int d) {
+      if (x < 0) return NDRange();
+      const Node& X = T[x];
+      const int begin = pos;
+      if (X.a < 0 && X.b < 0) {
+        for (int32_t v : X.verts) order[pos++] = v;
+        return panels(begin, pos);
+      }
+      const NDRange r1 = walk(X.a, d + 1);
+      const int mid = pos;
+      const NDRange r2 = walk(X.b, d + 1);
+      const int s0 = pos;
+      if (d == kRangeDepth && mid > begin && s0 > mid) { ranges.emplace_back(begin, mid); ranges.emplace_back(mid, s0); }
+      for (int32_t v : X.verts) order[pos++] = v;
+      const int end = pos, ssz = end - s0, rem = ssz % kPanelW;
+      NDRange out;
+      if (ssz == 0) { out = r2; out.height = std::max(r1.height, r2.height); return out; }
+      if (rem != 0 && X.b >= 0 && r2.last + rem <= kPanelW) {
+        pstart[s0] = 1;
+        const NDRange rest = panels(s0 + rem, end);
+        out.last = ssz == rem ? r2.last + rem : rest.last;
+        out.height = std::max(r1.height + 1, r2.height) + rest.height;
+      } else {
+        const NDRange all = panels(s0, end);
+        out.last = all.last;
+        out.height = std::max(r1.height, r2.height) + all.height;
+      }
+      return out;
+    }
+  };
+  std::fill(pstart.begin(), pstart.end(), 0);
+  pos_ranges.clear();
+  Emit E{T, order, pstart, pos_ranges};
+  E.walk(root, 0);
+  if (E.pos != nf) return false;
+  S.nd_nodes.swap(T);
+  S.nd_root = root;
+  S.nd_nf_full = prev.nd_nf_full;
+  S.nd_appended = prev.nd_appended + (nf - prev.nf);
+  return true;
+}
+
 }  // namespace
 
-int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S) {
+int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev) {
   double t0 = now_s();
   static const bool trace = getenv("CGMR_SYM_TRACE") != nullptr;
   double tc = t0;
@@ -456,22 +634,54 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     ai.resize(w);
   }
   CK("adjacency");
-  // nested dissection
+  // nested dissection -- from scratch, or the previous ordering extended by the new vertices
   const int NT = host_threads();
   std::vector<int32_t> order(nf), panel_start;
   std::vector<std::pair<int, int>> pos_ranges;
   for (int v = 0; v < nf; v++) order[v] = v;
-  {
-    std::vector<uint8_t> pstart(nf, 0);
+  std::vector<uint8_t> pstart(nf, 0);
+  bool extended = false;
+  if (prev && prev->nd_root >= 0 && prev->nf > 0 && prev->nf <= nf && prev->nV <= nV && !fixed) {
+    // the old vertices must keep their block indices: every old vertex that has an edge now had one before
+    bool same = true;
+    for (int v = 0; v < prev->nV && same; v++) same = (S.hidx[v] == prev->hidx[v]);
+    static const bool extend_on = !(getenv("CGMR_SYM_EXTEND") && atoi(getenv("CGMR_SYM_EXTEND")) == 0);
+    const int n_new = nf - prev->nf;
+    if (same && extend_on && prev->nd_appended + n_new <= std::max(64, prev->nd_nf_full / 4))
+      extended = extend_order(*prev, nf, ap, ai, order, pstart, pos_ranges, S);
+  }
+  if (!extended) {
     NDCtx C{ap, ai, order, pstart};
     C.vs.assign(nf, NDCtx::VState{0, 0});
     C.queue.assign(nf, 0);
     C.tmp.assign(nf, 0);
+    C.recs.assign(2 * (size_t)nf + 4, NDCtx::Rec());
     C.max_par_depth = NT >= 8 ? 3 : (NT >= 4 ? 2 : (NT >= 2 ? 1 : 0));
-    nd(C, 0, nf, 0);
-    for (int p = 0; p < nf; p++) if (pstart[p]) panel_start.push_back(p);
+    int root_rec = -1;
+    nd(C, 0, nf, 0, -1, &root_rec);
     pos_ranges.swap(C.subtree_ranges);
+    // the tree with its vertices, for the next extension
+    S.nd_nodes.clear();
+    S.nd_nodes.reserve((size_t)C.n_recs.load() + 8);
+    std::function<int(int, int, int)> build = [&](int rec, int begin, int parent) -> int {
+      if (rec < 0) return -1;
+      const NDCtx::Rec R = C.recs[rec];
+      const int id = (int)S.nd_nodes.size();
+      S.nd_nodes.emplace_back();
+      S.nd_nodes[id].parent = parent;
+      S.nd_nodes[id].count = R.n;
+      const int na = R.a >= 0 ? C.recs[R.a].n : 0, nb = R.b >= 0 ? C.recs[R.b].n : 0;
+      const int ca = build(R.a, begin, id), cb = build(R.b, begin + na, id);
+      S.nd_nodes[id].a = ca; S.nd_nodes[id].b = cb;
+      S.nd_nodes[id].verts.assign(order.begin() + begin + na + nb, order.begin() + begin + na + nb + R.ssz);
+      return id;
+    };
+    S.nd_root = build(root_rec, 0, -1);
+    S.nd_nf_full = nf;
+    S.nd_appended = 0;
   }
+  S.extended = extended;
+  for (int p = 0; p < nf; p++) if (pstart[p]) panel_start.push_back(p);
   std::vector<int32_t> iperm(nf);
   for (int p = 0; p < nf; p++) iperm[order[p]] = p;
   S.perm.assign(nf, -1);

@@ -126,6 +126,17 @@ struct Symbolic {
   std::vector<int32_t> top_blocks;     // triples (slot in Ablk, local block row, local block column) of the block's H blocks
   std::vector<int32_t> gn_level_ptr, gn_level_fronts;   // levels without the top block
   int64_t L_doubles = 0, U_doubles = 0, pan_doubles = 0;
+  // The nested-dissection tree of the ordering (leaf: its vertices in elimination order; inner node: its separator's;
+  // children a before b before the separator), kept so that a graph that GROWS -- the key-frame pattern: the cached edge
+  // list plus vertices / edges appended at the end (src/slam/graph_slam.cpp:197-267) -- is re-ordered incrementally: a new
+  // vertex goes into the leaf its neighbours live in, or into the separator of their lowest common ancestor when they
+  // live in different subtrees; a leaf that outgrows two panels is dissected again locally.  Block indices (hidx).
+  struct NDNode { int32_t parent = -1, a = -1, b = -1, count = 0; std::vector<int32_t> verts; };
+  std::vector<NDNode> nd_nodes;
+  int32_t nd_root = -1;
+  int32_t nd_nf_full = 0;              // free poses when the ordering was last computed from scratch
+  int32_t nd_appended = 0;             // vertices inserted incrementally since then
+  bool extended = false;               // this analysis re-used the previous ordering
   int max_ns = 0;
   double flops = 0;                    // factorisation flops (dense fronts)
   double t_order = 0, t_struct = 0;    // seconds spent in ordering / structure
@@ -139,6 +150,9 @@ struct Symbolic {
 // task(0) .. task(n - 1) on the analysis' helper threads (blocking)
 void host_run_tasks(int n, const std::function<void(int)>& task);
 
-int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S);
+// prev (nullable): the analysis of a graph whose edge list is a prefix of this one and whose vertices are the first
+// prev->nV of this one's -- the ordering is then extended instead of recomputed where that is possible (S.extended);
+// prev's dissection tree is consumed.
+int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev = nullptr);
 
 }  // namespace cgmr

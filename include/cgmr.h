@@ -91,9 +91,15 @@ int cgmr_gn_optimize_dev(cgmr_ctx* ctx, int nV, double* d_poses_xyt, const uint8
  * analysis, so the pre-solve, the covariance estimate and the optimize(n) of one key frame
  * (src/slam/graph_slam.cpp:392-393, 315-320; src/srslam.cpp:211) share one analysis.  Results are bit-identical
  * with the cache on or off.  on = 0 switches the reuse off (every call analyses, as g2o does); default on.
- * cgmr_symbolic_cache_stats: out[0] = calls served from the cache, out[1] = calls that analysed.        */
+ * A graph that GROWS -- the cached edge list plus vertices / edges appended at the end, the key-frame pattern of
+ * src/slam/graph_slam.cpp:197-267 and of a multi-robot round -- keeps its ordering: the new vertices are inserted into the
+ * cached nested-dissection tree (into the leaf their neighbours live in, or the separator above them), everything
+ * downstream of the ordering is rebuilt; after a quarter of the graph has been inserted that way the ordering is computed
+ * from scratch again.  Same results as a from-scratch analysis to rounding (another elimination order).
+ * cgmr_symbolic_cache_stats: out[0] = calls served from the cache, out[1] = calls that analysed from scratch,
+ * out[2] = calls that analysed by extending the cached ordering.                                          */
 int cgmr_set_symbolic_cache(cgmr_ctx* ctx, int on);
-int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]);
+int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[3]);
 
 /* Host-only: run the ordering / symbolic analysis and report its shape (no GPU needed).
  * out[0]=poses in the system (every vertex with an edge; `fixed` is ignored: fixed vertices are masked numerically)
@@ -107,6 +113,14 @@ int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]);
  * perm_out (nullable, nV entries): permuted block column of each vertex or -1.          */
 int cgmr_gn_symbolic_info(int nV, const uint8_t* fixed, int nE, const int32_t* from_idx,
                           const int32_t* to_idx, int64_t out[16], int32_t* perm_out);
+
+/* Host-only: the analysis of a graph that grows.  The first (nV0, nE0) vertices / edges are analysed from scratch, then
+ * step k extends the analysis to the first (nV_step[k], nE_step[k]) of them the way cgmr_gn_optimize* does for a context
+ * whose cached edge list is a prefix of the new one; out / perm_out describe the last analysis, n_extended_out counts the
+ * steps that re-used the ordering (the others fell back to a from-scratch ordering). */
+int cgmr_gn_symbolic_info_grown(int nV0, int nE0, int n_steps, const int32_t* nV_step, const int32_t* nE_step,
+                                const int32_t* from_idx, const int32_t* to_idx, int64_t out[16], int32_t* perm_out,
+                                int32_t* n_extended_out);
 
 /* Timing of the last cgmr_gn_optimize* call on this context, seconds:
  * out[0]=host ordering  [1]=host structure  [2]=upload+alloc  [3]=device GN iterations (stream time,

@@ -199,3 +199,38 @@ def test_symbolic_cache_is_bit_identical_and_ignores_the_fixed_set(ctx, oracle):
     assert np.array_equal(p3[700], g["poses"][700])       # the fixed vertex is not touched
     st, covo = oracle.covariance_estimate(p2, *a[2:], 1499, np.array([3, 700, 1200], dtype=np.int32))
     assert st == 0 and np.abs(cov - covo).max() <= 1e-6 * np.abs(covo).max()
+
+
+def test_growing_graph_extends_the_analysis_and_matches_the_oracle_every_round(ctx, oracle):
+    """The key-frame / multi-robot-round pattern: a 5000-vertex graph grown 50 vertices at a time (100 rounds, the edges of
+    a vertex appended with it; old vertices keep their optimised poses, new ones are dead-reckoned from the newest one),
+    optimize(4) after every round on the SAME context.  The cached ordering is extended round after round
+    (symbolic_cache_stats: `extended`), a few rounds re-order from scratch, and every checked round agrees with the oracle
+    on the same sub-graph and the same initial guess at the usual tolerances."""
+    g = synth.make_pose_graph(5000, 20000, seed=77)
+    odo = {(int(a), int(b)): g["meas"][k] for k, (a, b) in enumerate(zip(g["edge_from"], g["edge_to"])) if b == a + 1}
+    k = np.argsort(np.maximum(g["edge_from"], g["edge_to"]), kind="stable")
+    ef, et, meas, info = (np.ascontiguousarray(g[n][k]) for n in ("edge_from", "edge_to", "meas", "info"))
+    last = np.maximum(ef, et)
+    ctx.set_symbolic_cache(True)
+    s0 = ctx.symbolic_cache_stats()
+    cur = g["poses"].copy()
+    checked, nv_prev = 0, 1
+    for r in range(100):
+        nv = 50 * (r + 1)
+        for v in range(max(nv_prev, 1), nv):
+            cur[v] = synth.se2_compose(cur[v - 1][None], odo[(v - 1, v)][None])[0]
+        ne = int(np.searchsorted(last, nv, side="left"))
+        a = (cur[:nv].copy(), g["fixed"][:nv], ef[:ne], et[:ne], meas[:ne], info[:ne])
+        rc, p, chi = ctx.gn_optimize(*a, 4)
+        assert rc == 0
+        if r % 7 == 0 or r >= 97:                                   # the oracle on every 7th round and the last three (seconds, not minutes)
+            st, p2, chi2, _ = oracle.gn_optimize(*a, 4)
+            assert st == 0
+            _check(p, chi, p2, chi2)
+            checked += 1
+        cur[:nv] = p
+        nv_prev = nv
+    s1 = ctx.symbolic_cache_stats()
+    assert checked >= 17
+    assert s1["extended"] - s0["extended"] >= 80 and (s1["misses"] - s0["misses"]) + (s1["extended"] - s0["extended"]) == 100

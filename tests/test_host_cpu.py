@@ -326,3 +326,34 @@ def test_adapters_call_the_c_abi_with_the_declared_names_and_argument_counts():
     for must in ("cgmr_gn_optimize", "cgmr_close_scan_matching", "cgmr_scan_matching_lc", "cgmr_global_matching", "cgmr_verify_matching",
                  "cgmr_covariance_estimate", "cgmr_condense"):
         assert must in seen, must
+
+
+def _growing_graph(V, E, seed):
+    """A synthetic pose graph whose edges are ordered by their later end point: every prefix of the vertex list has its
+    edges as a prefix of the edge list (the key-frame pattern: a vertex and its edges are appended together)."""
+    g = synth.make_pose_graph(V, E, seed=seed)
+    k = np.argsort(np.maximum(g["edge_from"], g["edge_to"]), kind="stable")
+    for name in ("edge_from", "edge_to", "meas", "info"):
+        g[name] = np.ascontiguousarray(g[name][k])
+    last = np.maximum(g["edge_from"], g["edge_to"])
+    return g, last
+
+
+def test_incremental_ordering_of_a_growing_graph():
+    """The cached ordering extended by appended vertices (gn_symbolic.cpp: extend_order): the result is a valid elimination
+    order, most steps re-use the ordering, and the tree stays close to what a from-scratch analysis of the final graph
+    gives (levels, factorisation flops) -- for chunks of 50 (a multi-robot round) and of 1 (a key frame)."""
+    from cg_mrslam_amd._lib import gn_symbolic_info, gn_symbolic_info_grown
+    g, last = _growing_graph(3000, 11000, seed=8)
+    for chunk, v0 in ((50, 600), (1, 2900)):
+        nv = np.arange(v0 + chunk, 3000 + 1, chunk)
+        ne = np.searchsorted(last, nv, side="left")              # edges whose later end point < nv
+        ne0 = int(np.searchsorted(last, v0, side="left"))
+        info, perm, n_ext = gn_symbolic_info_grown(v0, ne0, nv, ne, g["edge_from"], g["edge_to"])
+        full = gn_symbolic_info(3000, g["fixed"], g["edge_from"], g["edge_to"])
+        active = perm >= 0
+        assert sorted(perm[active].tolist()) == list(range(int(active.sum())))          # a permutation of the active vertices
+        assert info["free_poses"] == full["free_poses"] and info["offdiag_blocks"] == full["offdiag_blocks"]
+        assert n_ext >= 0.7 * len(nv)                                                    # mostly extensions, a few re-orderings
+        assert info["levels"] <= full["levels"] + 6
+        assert info["factor_flops"] <= 1.6 * full["factor_flops"]

@@ -128,7 +128,9 @@ def test_four_robots_c4_sim_modality_matches_oracle_backend(ctx, oracle):
 def test_cg_mrslam_cli_one_rank_per_robot_equals_one_process(tmp_path):
     """``python -m cg_mrslam_amd.cg_mrslam`` (the cg_mrslam node, sim modality): two robots in one process, then one
     rank per robot (both ranks share this box's only GPU; the all-gather runs over gloo here, RCCL on a multi-GPU node).
-    The saved graphs (robot-<id>-<o>, cg_mrslam.cpp:199-202) must be identical."""
+    The saved graphs (robot-<id>-<o>, cg_mrslam.cpp:199-202) must agree: same vertices and edges, numbers to rounding -- the two
+    runs reach the solver with different call histories (one context shared by both robots never sees a graph grow, a rank's own
+    context does and extends its cached ordering: another elimination order, results equal to the last few ulps)."""
     base = [sys.executable, "-m", "cg_mrslam_amd.cg_mrslam", "-nRobots", "2", "-steps", "90", "-laps", "0.21", "-linearUpdate", "0.5",
             "-windowLoopClosure", "5", "-minInliers", "4", "-minInliersMR", "3", "-windowMRLoopClosure", "5"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
@@ -144,9 +146,16 @@ def test_cg_mrslam_cli_one_rank_per_robot_equals_one_process(tmp_path):
     assert p.returncode == 0, p.stderr[-3000:]
     ranks = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["robots"]
     for a, b in zip(one, sorted(ranks, key=lambda r: r["robot"])):
-        assert a["vertices"] == b["vertices"] and a["edges"] == b["edges"] and a["chi2"] == b["chi2"]
+        assert a["vertices"] == b["vertices"] and a["edges"] == b["edges"] and abs(a["chi2"] - b["chi2"]) <= 1e-9 * abs(a["chi2"])
     for r in range(2):
-        assert (tmp_path / f"robot-{r}-one.g2o").read_text() == (tmp_path / f"robot-{r}-ranks.g2o").read_text()
+        la = (tmp_path / f"robot-{r}-one.g2o").read_text().splitlines()
+        lb = (tmp_path / f"robot-{r}-ranks.g2o").read_text().splitlines()
+        assert len(la) == len(lb)
+        for x, y in zip(la, lb):
+            tx, ty = x.split(), y.split()
+            assert len(tx) == len(ty) and tx[0] == ty[0]
+            for u, v in zip(tx[1:], ty[1:]):
+                assert u == v or abs(float(u) - float(v)) <= 1e-7 * max(1.0, abs(float(u))), (x, y)
 
 
 def test_cg_mrslam_cli_rank_mode_over_rccl_single_rank(tmp_path):
