@@ -22,7 +22,7 @@ namespace cgmr {
 constexpr int kPanelW = CGMR_PANEL_POSES;                  // max poses (block columns) per front
 constexpr int kFrontW = (3 * kPanelW + 15) / 16 * 16;      // scalar columns per front (all panel strides are padded to this): 48
 constexpr int64_t factor_header(int w) { return 2 * (int64_t)w * w + w; }   // L11 row-major, L11 column-major, 1/diag
-constexpr int kChunkRows = 208 - kFrontW - 1;      // most border rows a k_front_factor workgroup can take: the elimination passes of the
+constexpr int kChunkRows = (kFrontW <= 48 ? 208 : 192) - kFrontW - 1;      // most border rows a k_front_factor workgroup can take: the elimination passes of the
                                      // panel factorisation hold 4 x 48 rows below a diagonal block (panel_cholesky.h)
 constexpr int kMidChunkRows = 95;    // border rows per work item above the leaves: a front with a wide border is cut into
                                      // several work items (each factors F11 again, fetches only the children's rows it owns):
