@@ -25,7 +25,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 120 rocprofv3 --kernel-trace --pmc $c -d $O/calib_$c --output-format csv -- $R/tools/ubench/fetch_calib_ubench > $O/calib_$c.log 2>&1
 done
 cd $R
-[ -f cg_mrslam_amd/libcgmr_t.so ] && CGMR_LIB=cg_mrslam_amd/libcgmr_t.so timeout 120 python tools/gpu_mphase.py $O/match_phases.json > $O/match_phases.log 2>&1
+[ -f cg_mrslam_amd/libcgmr_t.so ] && CGMR_MATCH_SPLIT=1 CGMR_LIB=cg_mrslam_amd/libcgmr_t.so timeout 120 python tools/gpu_mphase.py $O/match_phases.json > $O/match_phases.log 2>&1
 python tools/pmc_summarise.py $(find $O -name "*counter_collection.csv") > $O/pmc_summary.txt
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
 cat $O/pmc_summary.txt | head -60
