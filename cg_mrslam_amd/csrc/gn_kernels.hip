@@ -303,8 +303,10 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 // Then the blocked factorisation of the panel in LDS (panel_cholesky.h) and the stores.  Every work item of a front
 // factors F11 again (nobody waits for anybody) and owns its rows of L21.  The update matrix U = ext_add - L21 L21^T of
 // every front is formed by k_front_update, whose tiles spread over the idle CUs.
-constexpr int kPanLoads = (kFrontW + kMidChunkRows + 1) * (kPanStride / 2) / 256 + 1;   // 16-byte loads per thread and round: a 95-row chunk's panel in one round (15)
-__global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
+constexpr int kFT = 512;             // threads of a k_front_factor workgroup: 8 wavefronts (the elimination passes use as many as there are 48-row
+                                     // groups, the MFMA updates, the loads and the stores all of them; 256 threads: +4k cycles per work item)
+constexpr int kPanLoads = (kFrontW + kMidChunkRows + 1) * (kPanStride / 2) / kFT + 1;   // 16-byte loads per thread and round: a 95-row chunk's panel in one round (8)
+__global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
                                                       const double* __restrict__ Pan, double* __restrict__ Lbuf,
                                                       double* __restrict__ yvec, double* __restrict__ uvec,
                                                       int* __restrict__ status, int level_id, int write_l11c, int chunk_rows) {
@@ -332,19 +334,19 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
     const int nA = W * H2, nB = nr * H2, nq = nA + nB + H2;
     const double2* src = reinterpret_cast<const double2*>(Pan + pan_off);
     const size_t slot2 = (size_t)pan_size(ns) / 2;
-    for (int base = 0; base < nq; base += 256 * kPanLoads) {
+    for (int base = 0; base < nq; base += kFT * kPanLoads) {
       double2 v[kPanLoads], v1[kPanLoads];
       int so[kPanLoads];
 #pragma unroll
       for (int u = 0; u < kPanLoads; u++) {
-        const int q = base + tid + 256 * u;
+        const int q = base + tid + kFT * u;
         so[u] = q < nA ? q : (q < nA + nB ? (W + r0) * H2 + (q - nA) : (W + r) * H2 + (q - nA - nB));
         v[u] = q < nq ? src[so[u]] : make_double2(0.0, 0.0);
       }
       if (slots > 1) {
 #pragma unroll
         for (int u = 0; u < kPanLoads; u++) {
-          const int q = base + tid + 256 * u;
+          const int q = base + tid + kFT * u;
           v1[u] = q < nq ? src[slot2 + so[u]] : make_double2(0.0, 0.0);
         }
 #pragma unroll
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
         for (int sl = 2; sl < slots; sl++) {
 #pragma unroll
           for (int u = 0; u < kPanLoads; u++) {
-            const int q = base + tid + 256 * u;
+            const int q = base + tid + kFT * u;
             v1[u] = q < nq ? src[sl * slot2 + so[u]] : make_double2(0.0, 0.0);
           }
 #pragma unroll
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
       }
 #pragma unroll
       for (int u = 0; u < kPanLoads; u++) {
-        const int q = base + tid + 256 * u;
+        const int q = base + tid + kFT * u;
         if (q >= nq) continue;
         const int row = q / H2;
         const int c2 = 2 * (q - H2 * row);
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
   auto store_block_column = [&](int K) {
     const int c = 16 * K;
     const int nrow = (chunk == 0 ? W : 0) + nr;               // F11 rows (first chunk only), then my rows of L21
-    for (int q = tid; q < nrow * 8; q += 256) {
+    for (int q = tid; q < nrow * 8; q += kFT) {
       const int rr = q >> 3, k = c + 2 * (q & 7);
       if (chunk == 0 && rr < W) {
         const double a = (k <= rr) ? P[rr * LDW + k] : 0.0, b = (k + 1 <= rr) ? P[rr * LDW + k + 1] : 0.0;
@@ -406,14 +408,14 @@ __global__ __launch_bounds__(256) void k_front_factor(const WorkRec* __restrict_
       }
     }
   };
-  const int fail = panel_cholesky(P, roff, M, nbc, Dinv, lane, wave, store_block_column);
+  const int fail = panel_cholesky<kFT / 64>(P, roff, M, nbc, Dinv, lane, wave, store_block_column);
   for (int K = nbc; K < W / 16; K++) store_block_column(K);    // block columns without real columns (identity padding)
   FPHASE(1);
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);   // status[1]: GN iterations completed so far
   PHASE(4);
   if (chunk == 0) {
     if (write_l11c)                                           // column-major copy: only the multi-rhs forward solve of the marginals reads it
-      for (int q = tid; q < W * W; q += 256) {
+      for (int q = tid; q < W * W; q += kFT) {
         const int i = q / W, k = q - i * W;
         Pn[kL11c + q] = (i <= k) ? P[k * LDW + i] : 0.0;       // element (row k, col i)
       }
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
   }
   // ---- factorisation (the rhs row becomes y = L^-1 b)
   auto roff = [](int r) -> int { return r * LD; };
-  const int fail = panel_cholesky(P, roff, M, nbc, Dinv, lane, wave);
+  const int fail = panel_cholesky<4>(P, roff, M, nbc, Dinv, lane, wave);
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);
   __syncthreads();
   // ---- backward solve L^T x = y of the block's columns (nothing above them): wavefront 0, lane = columns lane, lane + 64
@@ -967,7 +969,7 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int l, bool write_l1
   gn_init_kernels();
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
   if (nw <= 0) return;                   // (a level emptied by the children's schedule: its fronts moved up)
-  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(256), factor_smem_bytes(D.h_level_chrows[l]), st, D.work, D.h_work_ptr[l],
+  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(kFT), factor_smem_bytes(D.h_level_chrows[l]), st, D.work, D.h_work_ptr[l],
                      D.Pan, D.Lbuf, D.yvec, D.uvec, D.status, l, write_l11c ? 1 : 0, D.h_level_chunk[l]);
 }
 

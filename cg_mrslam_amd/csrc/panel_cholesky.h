@@ -53,11 +53,12 @@ typedef __attribute__((address_space(3))) double lds_f64;   // 32-bit LDS addres
 
 // P: the panel in LDS, roff(r) = offset (doubles) of row r.  Rows M .. 16 * ceil(M / 16) - 1 must exist (any finite or
 // non-finite content: they are computed along and never read by anyone else), so no access below is masked.
-// 256 threads; lane / wave = the caller's (logical) numbering.  At most 4 x 48 rows below a diagonal block: M <= 208.
+// 64 * NW threads (NW wavefronts: 4 or 8); lane / wave = the caller's numbering.  At most NW x 48 rows below a diagonal
+// block: M <= 16 + 48 NW.
 // done(K): called by every thread once block column K is final in LDS (behind a workgroup barrier), while later block
 // columns are still being worked on: the caller's stores of that block column run underneath the rest of the factorisation.
 struct PanelNoCallback { __device__ __forceinline__ void operator()(int) const {} };
-template <typename RowOff, typename ColumnDone = PanelNoCallback>
+template <int NW = 4, typename RowOff, typename ColumnDone = PanelNoCallback>
 __device__ __forceinline__ int panel_cholesky(double* Pg, RowOff roff, int M, int nbc, double* Dinv, int lane, int wave_v,
                                               ColumnDone done = ColumnDone()) {
   lds_f64* P = (lds_f64*)Pg;
@@ -114,7 +115,7 @@ __device__ __forceinline__ int panel_cholesky(double* Pg, RowOff roff, int M, in
     }
   };
   // C[I][Jt] -= L[I][K] L[Jt][K]^T for the row blocks I >= Jt of every later block column Jt.  The tiles of a step are
-  // numbered t = 0 .. and dealt round-robin to the four wavefronts, two per wavefront in flight (independent accumulator
+  // numbered t = 0 .. and dealt round-robin to the NW wavefronts, two per wavefront in flight (independent accumulator
   // chains; a single wavefront issues one v_mfma_f64_16x16x4 per 64 cycles, 81 back to back on one accumulator).
   // MFMA operand layout: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], C[i = (lane >> 4) + 4 rg][j = lane & 15].
   auto update = [&](int K) {
@@ -128,11 +129,11 @@ __device__ __forceinline__ int panel_cholesky(double* Pg, RowOff roff, int M, in
       I = Jt + t;
     };
     const int lr = lane & 15, lk = lane >> 4;
-    for (int t0 = wave; t0 < ntile; t0 += 8) {
+    for (int t0 = wave; t0 < ntile; t0 += 2 * NW) {
       int J0, I0, J1, I1;
       tile_of(t0, J0, I0);
-      const bool two = t0 + 4 < ntile;
-      tile_of(two ? t0 + 4 : t0, J1, I1);
+      const bool two = t0 + NW < ntile;
+      tile_of(two ? t0 + NW : t0, J1, I1);
       lds_f64* a0p = P + roff(16 * I0 + lr) + cs + lk;
       lds_f64* b0p = P + roff(16 * J0 + lr) + cs + lk;
       lds_f64* a1p = P + roff(16 * I1 + lr) + cs + lk;
