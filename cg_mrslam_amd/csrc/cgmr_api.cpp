@@ -906,6 +906,20 @@ extern "C" int cgmr_debug_fronts(int nV, const uint8_t* fixed, int nE, const int
   return n;
 }
 
+// The children's schedule of every front (tests): out[4 f ..] = sched_t, sched_slot, pan_slots, 1 if the front adds into its
+// parent's panel (0: root, or child of the top block)
+extern "C" int cgmr_debug_schedule(int nV, int nE, const int32_t* ef, const int32_t* et, int cap, int32_t* out) {
+  Symbolic S;
+  if (analyze(nV, nullptr, nE, ef, et, S)) return -1;
+  int n = (int)S.fronts.size();
+  for (int f = 0; f < n && f < cap; f++) {
+    const FrontDesc& F = S.fronts[f];
+    int32_t* o = out + 4 * f;
+    o[0] = F.sched_t; o[1] = F.sched_slot; o[2] = F.pan_slots; o[3] = F.ppan_off >= 0 ? 1 : 0;
+  }
+  return n;
+}
+
 // Debugging aid: the (front, chunk) of every work item of the last analysed graph, and each front's parent / level.
 extern "C" int cgmr_debug_worklist(const cgmr_ctx* ctx, int32_t* front_out, int32_t* chunk_out, int cap, int32_t* parent_out,
                                    int32_t* level_out, int32_t* ns_out, int fcap) {

@@ -357,3 +357,51 @@ def test_incremental_ordering_of_a_growing_graph():
         assert n_ext >= 0.7 * len(nv)                                                    # mostly extensions, a few re-orderings
         assert info["levels"] <= full["levels"] + 6
         assert info["factor_flops"] <= 1.6 * full["factor_flops"]
+
+
+@pytest.mark.parametrize("shape", ["walk", "hub"])
+def test_children_schedule_has_one_writer_per_panel_copy_and_launch(shape):
+    """The assembled-panel hand-off (gn_symbolic.cpp): every child adds into its parent's panel during one
+    update launch t with level(child) <= t < level(parent), and two children of a front never share (launch, copy) -- that
+    is what makes the read-modify-write sums race-free and bit-reproducible without atomics.  On a random-walk graph and on a
+    hub graph whose fronts have dozens of same-level children (the parent then moves up a level)."""
+    import ctypes as C
+    from cg_mrslam_amd._lib import load_library
+    lib = load_library()
+    if shape == "walk":
+        g = synth.make_pose_graph(4000, 15000, seed=5)
+        V, ef, et = 4000, g["edge_from"], g["edge_to"]
+    else:                                                    # 40 chains of 30 poses hanging off one hub chain
+        ef, et, V = [], [], 0
+        hub = list(range(30)); V = 30
+        ef += hub[:-1]; et += hub[1:]
+        for k in range(40):
+            chain = list(range(V, V + 30)); V += 30
+            ef += chain[:-1]; et += chain[1:]
+            ef.append(hub[k % 30]); et.append(chain[0])
+    ef, et = np.ascontiguousarray(ef, dtype=np.int32), np.ascontiguousarray(et, dtype=np.int32)
+    fx = np.zeros(V, dtype=np.uint8)
+    cap = 20000
+    fr = np.zeros(cap * 6, dtype=np.int32)
+    n = lib.cgmr_debug_fronts(C.c_int(V), C.c_void_p(fx.ctypes.data), C.c_int(len(ef)), C.c_void_p(ef.ctypes.data),
+                              C.c_void_p(et.ctypes.data), C.c_int(cap), C.c_void_p(fr.ctypes.data))
+    sc = np.zeros(cap * 4, dtype=np.int32)
+    n2 = lib.cgmr_debug_schedule(C.c_int(V), C.c_int(len(ef)), C.c_void_p(ef.ctypes.data), C.c_void_p(et.ctypes.data), C.c_int(cap),
+                                 C.c_void_p(sc.ctypes.data))
+    assert n == n2 and 0 < n < cap
+    fr, sc = fr[:6 * n].reshape(n, 6), sc[:4 * n].reshape(n, 4)
+    parent, level = fr[:, 3], fr[:, 4]
+    seen = set()
+    for f in range(n):
+        p = int(parent[f])
+        if p < 0:
+            continue
+        assert level[p] > level[f] and p > f                  # parents after children, strictly higher
+        if not sc[f, 3]:
+            continue                                         # child of the top block: whole update matrix through Ubuf
+        t, slot = int(sc[f, 0]), int(sc[f, 1])
+        assert level[f] <= t < level[p]
+        assert 0 <= slot < sc[p, 2] <= 3                      # kMaxPanSlots
+        assert (p, t, slot) not in seen
+        seen.add((p, t, slot))
+    assert len(seen) > 10
