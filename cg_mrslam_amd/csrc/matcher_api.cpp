@@ -60,6 +60,31 @@ int setup_geometry(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, MatchParams& P
   P.kdim = make_kernel(cfg->resolution, cfg->kernel_range, cfg->kscale, kern);
   if (P.kdim < 0) return set_err(ctx, CGMR_E_INVALID, "kernel (range %g, res %g) not representable", cfg->kernel_range, cfg->resolution);
   P.fill = (int)(cfg->kernel_range * cfg->kscale);
+  // Distance-transform rasteriser (matcher_kernels.hip, build_grid): valid when the kernel value of an offset (i, j) depends
+  // on i^2 + j^2 only, does not decrease with it, and the radius is at most 8 cells (one byte per squared column distance).
+  // initializeKernel's table (scan_matcher.cpp:38-61) is K1 * sqrt(i^2 + j^2) truncated and capped: it qualifies, but the
+  // property is checked on the table itself.
+  {
+    static const bool edt_on = !(getenv("CGMR_MATCH_EDT") && atoi(getenv("CGMR_MATCH_EDT")) == 0);
+    const int dim = P.kdim, c = (dim - 1) / 2;
+    bool ok = edt_on && c <= 8 && c >= 1;
+    std::vector<int> by_d2(2 * c * c + 1, -1);
+    for (int j = -c; ok && j <= c; j++)
+      for (int i = -c; i <= c; i++) {
+        const int v = kern[(size_t)(j + c) * dim + (i + c)], d2 = i * i + j * j;
+        if (by_d2[d2] >= 0 && by_d2[d2] != v) { ok = false; break; }
+        by_d2[d2] = v;
+      }
+    int last = -1;
+    for (int d2 = 0; ok && d2 <= 2 * c * c; d2++) {
+      if (by_d2[d2] < 0) continue;
+      if (by_d2[d2] < last || by_d2[d2] > P.fill) ok = false;
+      last = by_d2[d2];
+    }
+    // beyond the square nothing is stamped: the value along an axis at the edge of the square must already be the fill value
+    // or the neighbours just outside would be cut off differently -- not needed: both rasterisers only look inside the square
+    P.edt = ok ? 1 : 0;
+  }
   P.overflow_tiles = ntx * nty;
   P.x_steps = 1; P.y_steps = 1;
   return CGMR_OK;
@@ -115,6 +140,10 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   // workgroup per pair: up to 16 workgroups then share a pair's search angles (every split-th batch of 8 angles each)
   static const int split_max = getenv("CGMR_MATCH_SPLIT") ? std::max(1, atoi(getenv("CGMR_MATCH_SPLIT"))) : 16;
   P.split = std::max(1, std::min(split_max, ctx->n_cus / std::max(n_pairs, 1)));
+  // A caller that does not ask for the number of populated result bins (the reference only prints it,
+  // scan_matcher.cpp:155-157) gets the pruned search: same winner, candidates that cannot win dropped early
+  static const bool prune_on = !(getenv("CGMR_MATCH_PRUNE") && atoi(getenv("CGMR_MATCH_PRUNE")) == 0);
+  P.prune = (prune_on && !d_nres) ? 1 : 0;
   const int n_items = n_pairs * P.split;
   int nblocks = std::min(n_items, ctx->n_cus);                    // one 160 KB-LDS workgroup per CU
   // ---- beam table (RawLaser::cartesian: alpha = firstBeamAngle + i * angularStep, host libm cos / sin [g2o-recalled]) and
@@ -270,7 +299,7 @@ int cgmr_match_close_vset_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
     HIP_TRY(ctx, hipMemcpyAsync(d + o_qry, ranges_qry, nbq * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d + o_g, guess, (size_t)n_pairs * 24, hipMemcpyHostToDevice, ctx->stream));
     rc = match_run(ctx, cfg, n_pairs, n_ref_scans, (const float*)(d + o_ref), (const double*)(d + o_xf), (const float*)(d + o_qry),
-                   (const double*)(d + o_g), max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), (int32_t*)(d + o_n));
+                   (const double*)(d + o_g), max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), out_nres ? (int32_t*)(d + o_n) : nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_xyt, d + o_x, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(out_score, d + o_s, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -289,7 +318,7 @@ int cgmr_match_close_vset_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
   io.h_in = in.data(); io.d_in = d; io.in_bytes = in_bytes;
   io.h_out = out.data(); io.d_out = d + o_x; io.out_bytes = out_bytes;
   rc = match_run(ctx, cfg, n_pairs, n_ref_scans, (const float*)(d + o_ref), (const double*)(d + o_xf), (const float*)(d + o_qry),
-                 (const double*)(d + o_g), max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), (int32_t*)(d + o_n), &io);
+                 (const double*)(d + o_g), max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), out_nres ? (int32_t*)(d + o_n) : nullptr, &io);
   if (rc) return rc;
   memcpy(out_xyt, out.data(), (size_t)n_pairs * 24);
   memcpy(out_score, out.data() + (o_s - o_x), (size_t)n_pairs * 8);
@@ -323,7 +352,7 @@ int cgmr_match_close_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_
   HIP_TRY(ctx, hipMemcpyAsync(d + o_qry, ranges_qry, nb * 4, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d + o_g, guess, (size_t)n_pairs * 24, hipMemcpyHostToDevice, ctx->stream));
   rc = match_run(ctx, cfg, n_pairs, 1, (const float*)(d + o_ref), nullptr, (const float*)(d + o_qry), (const double*)(d + o_g),
-                 max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), (int32_t*)(d + o_n));
+                 max_score, (double*)(d + o_x), (double*)(d + o_s), (uint8_t*)(d + o_f), out_nres ? (int32_t*)(d + o_n) : nullptr);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(out_xyt, d + o_x, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(out_score, d + o_s, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -9,19 +9,22 @@ namespace cgmr {
 constexpr int kMatchMaxPoints = 1088;        // beams per scan (1081 for the reference's laser), multiple of 64
 constexpr int kMatchDirGuardY = 7;           // directory guard band along y: 3 tile columns below, 4 above
 constexpr int kMatchMaxDir = 152 * 157;      // 8x8-cell tiles of the largest grid (1200 x 1200 cells) + guard band
-constexpr int kMatchTilesLds = 1408;         // tiles resident in LDS; the rest spills to HBM
+constexpr int kMatchTilesLds = 1264;         // tiles resident in LDS; the rest spills to HBM
 constexpr int kMatchMaxTheta = 80;           // search angles per region
 constexpr int kMatchMaxRefScans = 6;         // scans of a close-matching reference set (graph_slam.cpp:230-244: last vertex + 5)
 
 struct MatchParams {
   int n_pairs, n_beams;
   int n_ref_scans;                           // scans per reference set of the batched close matcher (1..kMatchMaxRefScans)
+  int prune;                                 // close matcher: 1 = pruned search (exact winner; the per-pair count of populated bins is not produced)
   int split;                                 // close matcher: workgroups per pair (each takes every split-th batch of search angles);
                                              // 1 in batch mode, > 1 for a single call's latency (k_match_close_batch)
   // grid (ScanMatcher::initializeGrid, src/matcher/scan_matcher.cpp:63-66; gridmap.h:196-214)
   float ll_x, ll_y, res, inv_res;
   int nx, ny;
   int kscale, fill, kdim;                    // fill = K2 = int(kernelRange * kscale)
+  int edt;                                   // 1: the kernel value is a non-decreasing function of the squared cell distance (radius <= 8):
+                                             // grids are rasterised by an exact distance transform instead of stamping
   // laser (RobotLaser / LaserParameters) and the pose of the laser on the robot
   double max_range, min_range;
   double lp_c, lp_s, lp_x, lp_y;             // cos/sin of the laser pose angle (host libm), translation

@@ -47,6 +47,8 @@ constexpr int CAND_U = 9;                    // candidates per lane per block (6
 constexpr int MAXBINS = 128;                  // close matching: 0.6 m / 0.5 m bins x 0.4 rad / 0.2 rad -> at most 27
 constexpr int MAXTHETA = kMatchMaxTheta;
 constexpr int kKcolOff = 320;                // Smem::kernel: the kdim x kdim table at 0 (<= 289 bytes), 17 padded columns behind it
+constexpr int kEdtLutOff = 864;              // ... and the kernel value by squared cell distance (0 .. 2 * 8^2, one entry beyond: fill)
+constexpr int kEdtLutN = 130;
 
 struct Smem {
   // the directory comes first: its byte addresses then fit the 16-bit field of the fast search path's list entries
@@ -57,6 +59,10 @@ struct Smem {
   double theta[MAXTHETA];
   uint8_t kernel[1024];
   int misc[16];
+  uint32_t best_bits;                        // pruned search: lowest accepted score so far (float bits)
+  uint32_t pad_[3];
+  uint32_t totals[NTH][24 * 12];             // fast search path: per wavefront, the totals of the 24 x 24 offsets of its angle, two
+                                             // 16-bit sums per word (y offsets 2j, 2j + 1 of an x row)
 };
 static_assert((sizeof(uint16_t) * kMatchMaxDir) % 16 == 0, "tile pool must stay 16-byte aligned behind the directory");
 // block_scan_excl scratch (one int per thread + total): the last point list, idle whenever a scan runs
@@ -65,10 +71,17 @@ static_assert(LISTCAP >= 516, "scan scratch needs 516 ints");
 static_assert(sizeof(Smem) <= 160 * 1024, "matcher LDS plan exceeds 160 KiB");
 
 #ifdef CGMR_PHASE_TIMING
-__device__ unsigned long long g_mphase[16];
+__device__ unsigned long long g_mphase[32];
 #define MPHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mphase[i] = __builtin_readcyclecounter(); } while (0)
+// wavefront 0 of workgroup 0: cycles between marks of the fast search path, summed over the angles (slots 10..15)
+#define MSTAT_T0() unsigned long long mst_ = __builtin_readcyclecounter()
+#define MSTAT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_mphase[i] += n_ - mst_; mst_ = n_; } while (0)
+#define MSTAT_ADD(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mphase[i] += (v); } while (0)
 #else
 #define MPHASE(i)
+#define MSTAT_T0()
+#define MSTAT(i)
+#define MSTAT_ADD(i, v)
 #endif
 
 __device__ __forceinline__ uint32_t bytemin4(uint32_t a, uint32_t b) {
@@ -106,13 +119,27 @@ typedef __attribute__((address_space(3))) const u32x2 lds_cu2;
 // and four tile-row loads and six packed-byte adds.
 constexpr int GRP = 5;                         // point subsets per wavefront
 constexpr int RPL = 2;                         // x rows per lane
-constexpr int PPI = 2;                         // points per lane and iteration
-template <bool HI>
-__device__ __forceinline__ void gather_rows2(const uint32_t* list, int n, int grp, int a18, int hi_clamp, uint32_t dw2,
-                                             uint32_t tiles_base, uint32_t (&part)[RPL][6], int (&acc)[RPL][24], int& npart,
-                                             int flush_iters) {
-  for (int q = PPI * grp; q < n; q += PPI * GRP) {
-    const uint2 pk2 = *reinterpret_cast<const uint2*>(&list[q]);
+constexpr int PPI = 2;                         // points per lane and iteration ("slot" = PPI consecutive list entries)
+constexpr int PH = 4;                          // pruned search: the first pass adds every PH-th block of GRP slots (a quarter of the points,
+                                               // spread over the whole list: the list is in the subsample's cell order, i.e. sorted in space)
+// MODE 0: every slot (lane group g of G takes slots g, g + G, ..); MODE 1: the slots of the first pass (blocks of GRP * PH
+// slots: the first GRP of every block); MODE 2: the others.  a18[w] = (x offset of the lane's row w) << 18.
+template <bool HI, int MODE>
+__device__ __forceinline__ void gather_rows2(const uint32_t* list, int nslots, int g, int G, const int (&a18)[RPL], int hi_clamp,
+                                             uint32_t dw2, uint32_t tiles_base, uint32_t (&part)[RPL][6], int (&acc)[RPL][24],
+                                             int& npart, int flush_iters) {
+  constexpr int BLK = GRP * PH;
+  int nj = nslots;
+  if (MODE != 0) {
+    const int nb = nslots / BLK, rem = nslots - nb * BLK;
+    const int n1 = nb * GRP + min(rem, GRP);
+    nj = MODE == 1 ? n1 : nslots - n1;
+  }
+  for (int j = g; j < nj; j += G) {
+    int sl = j;
+    if (MODE == 1) { const int b = j / GRP; sl = b * BLK + (j - b * GRP); }
+    if (MODE == 2) { const int b = j / (BLK - GRP); sl = b * BLK + GRP + (j - b * (BLK - GRP)); }
+    const uint2 pk2 = *reinterpret_cast<const uint2*>(&list[PPI * sl]);
     const uint32_t pk[PPI] = {pk2.x, pk2.y};
     uint32_t d[PPI][RPL][4], rowoff[PPI][RPL];
 #pragma unroll
@@ -120,7 +147,7 @@ __device__ __forceinline__ void gather_rows2(const uint32_t* list, int n, int gr
       const uint32_t da0 = pk[u] & 0xffffu;
 #pragma unroll
       for (int w = 0; w < RPL; w++) {
-        int t = (int)pk[u] + a18 + ((12 * w) << 18);               // (px8 + r + 12 w) << 18, the low 18 bits ride along
+        int t = (int)pk[u] + a18[w];                               // (px8 + row offset) << 18, the low 18 bits ride along
         asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(t), "s"(hi_clamp));       // x clamp into the guard band
         const uint32_t tx1 = (uint32_t)t >> 21;                    // tile row + 1
         uint32_t r8;
@@ -163,6 +190,19 @@ __device__ __forceinline__ void gather_rows2(const uint32_t* list, int n, int gr
       npart = 0;
     }
   }
+}
+
+// One grid byte through a fast-path list entry: the cell of the entry's point at x offset a, y offset b of the window
+// (the same clamps and lookups as gather_rows2, one cell instead of 2 x 24).
+typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+__device__ __forceinline__ int entry_cell(uint32_t e, bool hi, int a, int b, int hi_clamp, uint32_t dw2, uint32_t tiles_base) {
+  int t = (int)e + (a << 18);
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(t), "s"(hi_clamp));
+  const uint32_t tx1 = (uint32_t)t >> 21, r8 = ((uint32_t)t >> 18) & 7u;
+  const uint32_t yy = ((e >> 16) & 3u) + (hi ? 4u : 0u) + (uint32_t)b;
+  const uint32_t d = *(lds_cu16*)(size_t)(__umul24(tx1, dw2) + (e & 0xffffu) + 2u * (yy >> 3));
+  return *(lds_cu8*)(size_t)(d * 64u + r8 * 8u + tiles_base + (yy & 7u));
 }
 
 // block-wide exclusive scan of one int per thread (any power-of-two block size <= 512); returns the exclusive prefix, total in *total
@@ -227,7 +267,13 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
       const int ki = q >> 5, b = q & 31, dy = b - 4;
       S.kernel[kKcolOff + q] = (dy >= 0 && dy < P.kdim) ? S.kernel[dy * P.kdim + ki] : (uint8_t)0xff;
     }
+  if (P.edt && tid < kEdtLutN) S.kernel[kEdtLutOff + tid] = (uint8_t)K2;
   __syncthreads();
+  if (P.edt)                                                     // (every decomposition of a squared distance holds the same value: checked on the host)
+    for (int q = tid; q < P.kdim * P.kdim; q += NTHR) {
+      const int i = q % P.kdim - ctr, j = q / P.kdim - ctr;
+      S.kernel[kEdtLutOff + i * i + j * j] = S.kernel[q];
+    }
   for (int i = tid; i < n; i += NTHR) {
     uint32_t packed = rcell[i];
     if (packed == 0x80008000u) continue;
@@ -244,6 +290,7 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     const int b0 = tid * per, b1 = min(ndir, b0 + per);
     int cnt = 0;
     for (int q = b0; q < b1; q++) cnt += S.dir[q];
+    uint16_t* const tile_slot = reinterpret_cast<uint16_t*>(&S.totals[0][0]);     // (idle until the search)
     int ntile;
     int base = block_scan_excl(cnt, scan_scratch(S), &ntile);
     // fast path: every tile (plus an all-fill and an all-zero tile) is resident in LDS and the grid is a
@@ -254,7 +301,10 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     int row = b0 / DW, col = b0 - row * DW;
     for (int q = b0; q < b1; q++) {
       const bool guard = row == 0 || row == ntx + 1 || col < 3 || col >= nty + 3;
-      if (S.dir[q]) S.dir[q] = (uint16_t)base++;
+      if (S.dir[q]) {
+        if (base < NT_LDS) tile_slot[base] = (uint16_t)q;          // tile -> directory slot (the distance-transform rasteriser walks the tiles)
+        S.dir[q] = (uint16_t)base++;
+      }
       else S.dir[q] = fastp ? (uint16_t)(guard ? ntile + 1 : ntile) : (uint16_t)0xFFFF;
       if (++col == DW) { col = 0; row++; }
     }
@@ -269,6 +319,139 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   for (int q = tid; q < max(0, ntile - NT_LDS) * 16; q += NTHR) gtiles[q] = fill4;
   __syncthreads();
   MPHASE(4);
+  // ---- rasteriser, all tiles resident in LDS: exact distance transform instead of stamping.  The kernel value of an offset
+  // depends on its squared length only and does not decrease with it (P.edt: checked on the host), so the minimum of the
+  // stamps over a cell = the kernel value of the squared distance to the NEAREST reference cell inside the kernel's square:
+  //   (1) every tile gets a 64-bit map of the reference cells in it (its first two words, bit = byte index of the cell);
+  //   (2) along y: g^2 = squared distance to the nearest reference cell of the same x column within the kernel radius, from
+  //       the 24 map bits of the column in this tile and its two y neighbours -- one byte per cell, written into the tile
+  //       (the lines of x row 0, which take the place of the maps, after a barrier);
+  //   (3) along x: d^2 = min over dx of dx^2 + g^2(x + dx, y), kernel value by table; the finished lines go through the
+  //       workgroup's (otherwise unused) overflow pool in HBM and come back after a barrier, since the neighbours still read
+  //       the g^2 lines.
+  // Cost: proportional to the tiles (about 11 lines of 8 cells per thread), not to points x kernel area through
+  // compare-and-swap (139k of a pair's 595k cycles).  Reference cells outside the grid (their stamps reach into it) and
+  // grids with overflow tiles keep the stamping below.
+  const bool edt = P.edt && ntile <= NT_LDS && ntile > 0;
+  MPHASE(16);
+  if (edt) {
+    const uint16_t* const tile_slot = reinterpret_cast<const uint16_t*>(&S.totals[0][0]);
+    for (int d = tid; d < ntile; d += NTHR) { S.tiles[d * 16] = 0u; S.tiles[d * 16 + 1] = 0u; }
+    if (tid == 0) S.misc[15] = 0;
+    __syncthreads();
+    int noff = 0;
+    for (int i = tid; i < n; i += NTHR) {
+      const uint32_t packed = rcell[i];
+      if (packed == 0x80008000u) continue;
+      const int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+      if ((unsigned)rx >= (unsigned)P.nx || (unsigned)ry >= (unsigned)P.ny) { noff++; continue; }
+      const int d = S.dir[((rx >> 3) + 1) * DW + (ry >> 3) + 3];
+      const int bit = (rx & 7) * 8 + (ry & 7);
+      atomicOr(&S.tiles[d * 16 + (bit >> 5)], 1u << (bit & 31));
+    }
+    if (noff) atomicAdd(&S.misc[15], noff);
+    __syncthreads();
+    MPHASE(17);
+    const uint8_t* const lut = &S.kernel[kEdtLutOff];
+    // g^2 of the 8 cells of an x row from the row's 24 map bits (tile below, this tile, tile above): 8 bytes, 255 = no
+    // reference cell within the radius
+    auto line_g2 = [&](uint32_t m24, uint32_t& w0, uint32_t& w1) {
+      uint32_t w[2] = {0u, 0u};
+#pragma unroll
+      for (int y = 0; y < 8; y++) {
+        const uint32_t up = m24 >> (8 + y);                        // bit k: a reference cell k cells above
+        const uint32_t lo = m24 & ((2u << (8 + y)) - 1u);          // bits 0 .. 8 + y: cells at or below
+        const int du = up ? __ffs(up) - 1 : 99;
+        const int dd = lo ? (8 + y) - (31 - __clz(lo)) : 99;
+        const int g = min(du, dd);
+        const uint32_t g2 = g <= ctr ? (uint32_t)(g * g) : 255u;
+        w[y >> 2] |= g2 << (8 * (y & 3));
+      }
+      w0 = w[0]; w1 = w[1];
+    };
+    // (2) one tile per thread and round: the three maps once, x rows 1..7 straight into the tile; x row 0 takes the place of
+    // the map and waits in registers for the barrier
+    constexpr int R0 = (NT_LDS + 255) / 256;                       // tiles per thread, whatever the workgroup size
+    uint32_t r0w[R0][2];
+#pragma unroll
+    for (int u = 0; u < R0; u++) {
+      const int d = tid + NTHR * u;
+      r0w[u][0] = r0w[u][1] = 0u;
+      if (d >= ntile) continue;
+      const int q = tile_slot[d];
+      const int dn = S.dir[q - 1], dp = S.dir[q + 1];
+      const uint2 m0 = *reinterpret_cast<const uint2*>(&S.tiles[d * 16]);
+      const uint2 mn = dn < ntile ? *reinterpret_cast<const uint2*>(&S.tiles[dn * 16]) : make_uint2(0u, 0u);
+      const uint2 mp = dp < ntile ? *reinterpret_cast<const uint2*>(&S.tiles[dp * 16]) : make_uint2(0u, 0u);
+      for (int xr = 0; xr < 8; xr++) {
+        const uint32_t sh = 8u * (uint32_t)(xr & 3);
+        const uint32_t a = xr < 4 ? mn.x : mn.y, b = xr < 4 ? m0.x : m0.y, c = xr < 4 ? mp.x : mp.y;
+        const uint32_t m24 = ((a >> sh) & 0xffu) | (((b >> sh) & 0xffu) << 8) | (((c >> sh) & 0xffu) << 16);
+        uint32_t w0, w1;
+        line_g2(m24, w0, w1);
+        if (xr == 0) { r0w[u][0] = w0; r0w[u][1] = w1; }
+        else *reinterpret_cast<uint2*>(&S.tiles[d * 16 + 2 * xr]) = make_uint2(w0, w1);
+      }
+    }
+    MPHASE(18);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < R0; u++) {
+      const int d = tid + NTHR * u;
+      if (d < ntile) *reinterpret_cast<uint2*>(&S.tiles[d * 16]) = make_uint2(r0w[u][0], r0w[u][1]);
+    }
+    __syncthreads();
+    MPHASE(19);
+    // (3) along x, half a tile (4 x rows) per thread and round: the 20 g^2 lines the four rows see (8 to the left of the
+    // first, 8 to the right of the last) are fetched once and at once.  The finished lines go through the workgroup's
+    // (otherwise unused) overflow pool in HBM and come back after a barrier: the neighbours still read the g^2 lines, and
+    // holding them in registers instead made the compiler spill.
+    for (int hi = tid; hi < 2 * ntile; hi += NTHR) {
+      const int d = hi >> 1, h4 = 4 * (hi & 1);
+      const int q = tile_slot[d];
+      const int dm = S.dir[q - DW], dpl = S.dir[q + DW];
+      uint2 wv[20];
+#pragma unroll
+      for (int t = 0; t < 20; t++) {
+        const int gl = h4 - 8 + t;                                 // x row relative to the tile's first: -8 .. 15
+        const int dt = gl < 0 ? dm : (gl >= 8 ? dpl : d);
+        const bool ok = dt < ntile;
+        const uint2 v = *reinterpret_cast<const uint2*>(&S.tiles[(ok ? dt : d) * 16 + 2 * (gl & 7)]);
+        wv[t] = ok ? v : make_uint2(0xffffffffu, 0xffffffffu);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int d2[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++) d2[y] = 1 << 20;
+#pragma unroll
+        for (int t = j; t <= j + 16; t++) {
+          const int dx = t - j - 8;
+          const int c2 = dx * dx + ((dx < -ctr || dx > ctr) ? (1 << 16) : 0);     // (a radius below 8 leaves the outer lines out)
+#pragma unroll
+          for (int y = 0; y < 4; y++) {
+            d2[y] = min(d2[y], (int)((wv[t].x >> (8 * y)) & 0xffu) + c2);
+            d2[4 + y] = min(d2[4 + y], (int)((wv[t].y >> (8 * y)) & 0xffu) + c2);
+          }
+        }
+        uint32_t v0 = 0u, v1 = 0u;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          v0 |= (uint32_t)lut[min(d2[y], kEdtLutN - 1)] << (8 * y);
+          v1 |= (uint32_t)lut[min(d2[4 + y], kEdtLutN - 1)] << (8 * y);
+        }
+        *reinterpret_cast<uint2*>(&gtiles[d * 16 + 2 * (h4 + j)]) = make_uint2(v0, v1);
+      }
+    }
+    // (workgroup scope is enough and cheap: the lines come back to the CU that wrote them)
+    __syncthreads();
+    MPHASE(20);
+    for (int w = tid; w < 4 * ntile; w += NTHR)
+      reinterpret_cast<uint4*>(S.tiles)[w] = reinterpret_cast<const uint4*>(gtiles)[w];
+    __syncthreads();
+    MPHASE(21);
+    if (S.misc[15] == 0) return;                                   // (no reference cell outside the grid: done)
+  }
   // stamp: work item = (reference point, kernel row); byte-min through compare-and-swap on 32-bit words.
   // Neighbouring beams stamp overlapping cells; spread concurrently processed items over far-apart points
   // (stride 67 modulo an odd count) so that the compare-and-swap rarely has to retry.
@@ -289,6 +472,7 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     if (packed == 0x80008000u) continue;
     if (p > 0 && rcell[p - 1] == packed) continue;       // neighbouring beams in one cell: the min is idempotent
     int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+    if (edt && (unsigned)rx < (unsigned)P.nx && (unsigned)ry < (unsigned)P.ny) continue;   // (in the grid: the distance transform did it)
     int x = rx + ki - ctr;
     if (x < 0 || x >= P.nx) continue;
     int y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
@@ -402,6 +586,9 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     const int pair = item / P.split, part = item - pair * P.split;
     __syncthreads();
     MPHASE(0);
+#ifdef CGMR_PHASE_TIMING
+    if (blockIdx.x == 0 && tid == 0) { for (int q = 10; q < 16; q++) g_mphase[q] = 0; g_mphase[22] = g_mphase[23] = 0; }
+#endif
     // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
     // sort keys live in the (not yet used) tile pool: 2048 x u64
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(S.tiles);
@@ -528,6 +715,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     }
     __syncthreads();
     uint32_t* const cellmap = P.cellmap_off ? reinterpret_cast<uint32_t*>(my + P.cellmap_off) : nullptr;
+    const uint32_t* gcells = nullptr;
+    int gn = 0;
     if (NS == 1) {
       // valid beams whose cell differs from the previous beam's, compacted behind the raw list (the rasteriser's work
       // items are (point, kernel row): a quarter of the raw list's items would be skipped one by one)
@@ -543,9 +732,9 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       __syncthreads();
       const int nkept1 = S.misc[14];
       __syncthreads();
-      build_grid(S, P, cl1, nkept1, gtiles, /*allow_fast=*/true, err);
+      gcells = cl1; gn = nkept1;
     }
-    else if (!cellmap) build_grid(S, P, rcell_g, NS * B, gtiles, /*allow_fast=*/true, err);
+    else if (!cellmap) { gcells = rcell_g; gn = NS * B; }
     else {
       // A cell is rasterised for the first point that claims it (byte-min stamps are idempotent): the other scans' copies
       // of the same wall are dropped, the survivors are compacted into the idle point lists in LDS (all but the last
@@ -572,8 +761,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       __syncthreads();
       const int nkept = S.misc[14];
       __syncthreads();
-      if (nkept <= LCAP) build_grid(S, P, clist, nkept, gtiles, /*allow_fast=*/true, err);
-      else build_grid(S, P, rcell_g, NS * B, gtiles, /*allow_fast=*/true, err);               // more distinct cells than the lists hold
+      if (nkept <= LCAP) { gcells = clist; gn = nkept; }
+      else { gcells = rcell_g; gn = NS * B; }                                                 // more distinct cells than the lists hold
       // every surviving point clears its word: the bitmap is all zero again for the next pair
       if (nkept <= LCAP) {
         for (int i = tid; i < nkept; i += CB_THREADS) {
@@ -593,6 +782,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       }
       __syncthreads();
     }
+    // one call for all three shapes of the cell list (LDS or the HBM scratch: the rasteriser reads it through a generic pointer)
+    build_grid(S, P, gcells, gn, gtiles, /*allow_fast=*/true, err);
     const bool fast = S.misc[12] != 0;
     if (!fast && tid == 0) atomicAdd(err + 2, 1);          // pairs whose tiles did not fit LDS (generic search path)
     MPHASE(5);
@@ -625,6 +816,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     const int bx0 = S.misc[6], by0 = S.misc[7], bt0 = S.misc[8], nbx = S.misc[9], nby = S.misc[10], nbt = S.misc[11];
     const int nbins = nbx * nby * nbt;
     for (int q = tid; q < nbins; q += CB_THREADS) S.bins[q] = ~0ULL;
+    if (tid == 0) S.best_bits = 0x7f800000u;                   // best accepted score so far (float bits): +inf
     __syncthreads();
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
@@ -636,10 +828,16 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     // list entries of the fast path carry LDS addresses of the directory in 16 bits (gather_class)
     const uint32_t lds_dir = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.dir);
     const uint32_t lds_tiles = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.tiles);
-    const bool v2 = fast && nj <= 24 && ni <= 12 * RPL && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u && K2 * PPI <= 255;
+    const bool prune = P.prune != 0;
+    const bool v2 = fast && nj <= 24 && ni <= 12 * RPL && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u && K2 * PPI <= 255 &&
+                    K2 * (nq + 2 * PPI * GRP) < 65536;          // (16-bit totals)
     MPHASE(6);
     // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
-    for (int tb = part * nsearch; tb < nth; tb += nsearch * P.split) {
+    // batches of nsearch angles, the ones around the guess first (the visit order inside the keys stays the reference's): the
+    // pruned search has a good score to prune with from the first batch on
+    const int nbat = (nth + nsearch - 1) / nsearch;
+    for (int bi = part; bi < nbat; bi += P.split) {
+      const int tb = nsearch * ((bi & 1) ? (nbat - 1) / 2 + (bi + 1) / 2 : (nbat - 1) / 2 - bi / 2);
       const int ti = (wave < nsearch) ? min(tb + wave, nth) : nth;
       int k = 0, k0p = 0, k1p = 0;
       if (ti < nth) {
@@ -712,30 +910,146 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         int npart = 0;
         const int flush_iters = max(1, (255 / K2) / PPI);    // packed-byte partial sums cannot overflow before this
         const int hi_clamp = ((P.nx + 15) << 18) | 0x3ffff;
-        gather_rows2<false>(pl, act ? k0p : 0, grp, r << 18, hi_clamp, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
-        gather_rows2<true>(pl + lcap - k1p, act ? k1p : 0, grp, r << 18, hi_clamp, 2u * (uint32_t)DW, lds_tiles, part, acc, npart, flush_iters);
+        const uint32_t dw2 = 2u * (uint32_t)DW;
+        const uint32_t* const pl1 = pl + lcap - k1p;           // class 1 (upper half of the tile row), padded like class 0
+        uint32_t* totals = S.totals[wave];
+        auto total_of = [&](int a, int b) -> int { return (int)((totals[a * 12 + (b >> 1)] >> (16 * (b & 1))) & 0xffffu); };
+        for (int q = lane; q < 24 * 12; q += 64) totals[q] = 0;
+        const int a18[RPL] = {r << 18, (r + 12) << 18};
+        MSTAT_T0();
+        if (prune) {
+          gather_rows2<false, 1>(pl, act ? k0p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+          gather_rows2<true, 1>(pl1, act ? k1p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+        } else {
+          gather_rows2<false, 0>(pl, act ? k0p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+          gather_rows2<true, 0>(pl1, act ? k1p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+        }
 #pragma unroll
         for (int w = 0; w < RPL; w++)
 #pragma unroll
           for (int t = 0; t < 6; t++)
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[w][4 * t + c] += (part[w][t] >> (8 * c)) & 0xff;
-        // the five subsets' sums meet in LDS: the wavefront's list is not needed any more, its first 576 words take the
-        // totals of the 24 x 24 offsets (row-major, 24 per row)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        int* totals = reinterpret_cast<int*>(pl);
-        for (int q = lane; q < 24 * 24; q += 64) totals[q] = 0;
+        // the subsets' sums meet in LDS: the totals of the 24 x 24 offsets (row-major, 24 per row)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (act) {
 #pragma unroll
           for (int w = 0; w < RPL; w++)
 #pragma unroll
-            for (int c = 0; c < 24; c++) atomicAdd(&totals[(r + 12 * w) * 24 + c], acc[w][c]);
+            for (int c = 0; c < 12; c++) atomicAdd(&totals[(r + 12 * w) * 12 + c], (uint32_t)acc[w][2 * c] | ((uint32_t)acc[w][2 * c + 1] << 16));
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // Pruned search (the caller does not ask for the number of populated bins): the totals so far are sums over a
+        // quarter of the points, i.e. LOWER bounds of the final totals (every grid byte is >= 0), and the score is
+        // monotone in the total.  A candidate whose bound already scores worse than the best ACCEPTED score seen so far
+        // (any angle, this workgroup) can neither win nor tie: rows of the window where every candidate is out are dropped,
+        // the lanes regroup over the surviving rows and add the remaining three quarters for those only.  The best score is
+        // made tight right away by finishing the most promising candidate of this angle (lowest bound) on its own.  What
+        // survives is evaluated exactly as before, so the winner -- lowest score, first bin in map order, first visit
+        // inside the bin -- is the reference's.
+        uint32_t rowmask = 0xffffffu;
+        MSTAT(10);
+        if (prune) {
+          // (a) every lane of 0..47 takes half a row of the window: the lowest bound among its 12 candidates
+          uint32_t mykey = 0xffffffffu;
+          if (lane < 48) {
+            const int aa = lane >> 1, b0 = 12 * (lane & 1);
+            if (aa < ni) {
+#pragma unroll
+              for (int c = 0; c < 6; c++) {
+                const uint32_t wv = totals[aa * 12 + (b0 >> 1) + c];
+                const int bb = b0 + 2 * c;
+                if (bb < nj) mykey = min(mykey, ((wv & 0xffffu) << 10) | (uint32_t)(aa * nj + bb));
+                if (bb + 1 < nj) mykey = min(mykey, ((wv >> 16) << 10) | (uint32_t)(aa * nj + bb + 1));
+              }
+            }
+          }
+          uint32_t bestc = mykey;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) bestc = min(bestc, (uint32_t)__shfl_xor((int)bestc, o, 64));
+          // smallest total that scores worse than the best accepted score so far (the score is monotone in the total): the
+          // lanes try the 64 totals around best * k * kscale; with no accepted score yet, or the estimate off by more than
+          // that, nothing is dropped at this angle
+          auto first_dead_total = [&]() -> int {
+            const uint32_t bound = *(volatile uint32_t*)&S.best_bits;
+            if (bound == 0x7f800000u) return 0x7fffffff;
+            const int guess = (int)((double)__uint_as_float(bound) * (double)k * (double)P.kscale);
+            const int tt = max(0, guess - 31 + lane);
+            float ds = (float)tt * ikscale;
+            ds = k ? (float)((double)ds / (double)k) : (float)(P.max_score + 1);
+            const unsigned long long worse = __ballot(__float_as_uint(ds) > bound);   // (scores are >= 0: their bit patterns order like the values)
+            return (worse != 0 && (worse & 1ULL) == 0) ? max(0, guess - 31) + (__ffsll((long long)worse) - 1) : 0x7fffffff;
+          };
+          int tdead = first_dead_total();
+          if (bestc != 0xffffffffu && (int)(bestc >> 10) < tdead) {
+            // (b) the most promising candidate of this angle is finished on its own: the best score is tight before the rows are judged
+            const int q = (int)(bestc & 1023u), aa = q / nj, bb = q - aa * nj;
+            int sum = 0;
+            for (int e = lane; e < k0p; e += 64) sum += entry_cell(pl[e], false, aa, bb, hi_clamp, dw2, lds_tiles);
+            for (int e = lane; e < k1p; e += 64) sum += entry_cell(pl1[e], true, aa, bb, hi_clamp, dw2, lds_tiles);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            float ds = (float)sum * ikscale;
+            ds = k ? (float)((double)ds / (double)k) : (float)(P.max_score + 1);
+            if (lane == 0 && (double)ds < P.max_score) atomicMin(&S.best_bits, __float_as_uint(ds));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            tdead = first_dead_total();
+          }
+          const unsigned long long am = __ballot(mykey != 0xffffffffu && (int)(mykey >> 10) < tdead);
+          rowmask = 0;
+          for (int aa = 0; aa < 24; aa++) rowmask |= ((am >> (2 * aa)) & 3ULL) ? (1u << aa) : 0u;
+          // (c) the other three quarters of the points for the surviving rows: pairs of rows over floor(64 / pairs) point subsets
+          const int nlive = __popc(rowmask);
+          MSTAT(11);
+          MSTAT_ADD(14, (unsigned long long)nlive);
+          MSTAT_ADD(15, 1ULL);
+          if (nlive > 0) {
+            const int npairs = (nlive + 1) >> 1, G2 = 64 / npairs;
+            const int pr = lane / G2, g2 = lane - pr * G2;
+            const bool act2 = pr < npairs;
+            int rows2[RPL] = {0, 0};
+            {
+              uint32_t m = rowmask;
+              for (int i = 0; i < 2 * pr && m; i++) m &= m - 1;      // drop the rows of the pairs before mine
+              rows2[0] = m ? __ffs(m) - 1 : 0;
+              m &= m - 1;
+              rows2[1] = m ? __ffs(m) - 1 : -1;                        // an odd row out: the pair's second row stays empty
+            }
+            const bool two = rows2[1] >= 0;
+            const int b18[RPL] = {rows2[0] << 18, (two ? rows2[1] : rows2[0]) << 18};
+#pragma unroll
+            for (int w = 0; w < RPL; w++) {
+#pragma unroll
+              for (int c = 0; c < 6; c++) part[w][c] = 0;
+#pragma unroll
+              for (int c = 0; c < 24; c++) acc[w][c] = 0;
+            }
+            npart = 0;
+            gather_rows2<false, 2>(pl, act2 ? k0p / PPI : 0, g2, G2, b18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+            gather_rows2<true, 2>(pl1, act2 ? k1p / PPI : 0, g2, G2, b18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+#pragma unroll
+            for (int w = 0; w < RPL; w++)
+#pragma unroll
+              for (int t = 0; t < 6; t++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[w][4 * t + c] += (part[w][t] >> (8 * c)) & 0xff;
+            if (act2) {
+#pragma unroll
+              for (int c = 0; c < 12; c++) atomicAdd(&totals[rows2[0] * 12 + c], (uint32_t)acc[0][2 * c] | ((uint32_t)acc[0][2 * c + 1] << 16));
+              if (two) {
+#pragma unroll
+                for (int c = 0; c < 12; c++) atomicAdd(&totals[rows2[1] * 12 + c], (uint32_t)acc[1][2 * c] | ((uint32_t)acc[1][2 * c + 1] << 16));
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        MSTAT(12);
+        if (rowmask != 0) {
         // the acceptance test dsum(total) < maxScore is monotone in the integer total: find the smallest total that
         // fails it once per angle (lanes try the totals around maxScore * k * kscale) and compare integers per candidate
         int tfail;
@@ -749,12 +1063,14 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
           // means the guess was off by more than the probed range -- then every candidate takes the exact test
           tfail = (fails != 0 && (fails & 1ULL) == 0) ? max(0, guess - 31) + (__ffsll((long long)fails) - 1) : -1;
         }
+        uint32_t wbest = 0xffffffffu;
 #pragma unroll
         for (int u = 0; u < CAND_U; u++) {
           const int cidx = u * 64 + lane;
           if (cidx >= ncand) continue;
           const int a = cidx / nj, b = cidx - a * nj;
-          const int total = totals[a * 24 + b];
+          if (!((rowmask >> a) & 1u)) continue;                       // (pruned search: a dropped row's totals are incomplete)
+          const int total = total_of(a, b);
           if (tfail >= 0 && total >= tfail) continue;
           float dsum = (float)total * ikscale;
           dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
@@ -766,8 +1082,16 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
             unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
                                      (unsigned long long)(unsigned)(ti * ncand + cidx);
             atomicMin(&S.bins[(bx * nby + by) * nbt + bt], key);
+            wbest = min(wbest, __float_as_uint(dsum));
           }
         }
+        if (prune) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) wbest = min(wbest, (uint32_t)__shfl_xor((int)wbest, o, 64));
+          if (lane == 0 && wbest != 0xffffffffu) atomicMin(&S.best_bits, wbest);
+        }
+        }
+        MSTAT(13);
       } else if (ti < nth && fast) {
         // ---- fast path, any window: lane = (half h of the wavefront, x-row a, segment of 24 consecutive y offsets).
         // Both halves work on the same 32 (row, segment) jobs; half h takes points 8i+4h .. 8i+4h+3 of the list,
@@ -1195,6 +1519,6 @@ int match_close_max_bins() { return MAXBINS; }
 
 #ifdef CGMR_PHASE_TIMING
 extern "C" int cgmr_debug_mphase(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_mphase), sizeof(unsigned long long) * 16);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_mphase), sizeof(unsigned long long) * 32);
 }
 #endif

@@ -276,7 +276,7 @@ class ScanMatcher(_GenericSearch, _BatchedSearch):
                                                  C.c_void_p(rq.ctypes.data), C.c_void_p(g.ctypes.data),
                                                  C.c_double(maxScore), C.c_void_p(xyt.ctypes.data),
                                                  C.c_void_p(score.ctypes.data), C.c_void_p(found.ctypes.data),
-                                                 C.c_void_p(nres.ctypes.data))
+                                                 C.c_void_p(nres.ctypes.data if want_nresults else 0))
         self.ctx._check(rc)
         if want_nresults:
             return found.astype(bool), xyt, score, nres
