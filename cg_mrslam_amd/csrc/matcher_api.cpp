@@ -144,6 +144,7 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   // scan_matcher.cpp:155-157) gets the pruned search: same winner, candidates that cannot win dropped early
   static const bool prune_on = !(getenv("CGMR_MATCH_PRUNE") && atoi(getenv("CGMR_MATCH_PRUNE")) == 0);
   P.prune = (prune_on && !d_nres) ? 1 : 0;
+  P.sort32 = (P.n_beams < 2048 && P.sub_res > 0 && P.max_range / P.sub_res < 500.0) ? 1 : 0;
   const int n_items = n_pairs * P.split;
   int nblocks = std::min(n_items, ctx->n_cus);                    // one 160 KB-LDS workgroup per CU
   // ---- beam table (RawLaser::cartesian: alpha = firstBeamAngle + i * angularStep, host libm cos / sin [g2o-recalled]) and

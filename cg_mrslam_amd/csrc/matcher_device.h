@@ -9,7 +9,7 @@ namespace cgmr {
 constexpr int kMatchMaxPoints = 1088;        // beams per scan (1081 for the reference's laser), multiple of 64
 constexpr int kMatchDirGuardY = 7;           // directory guard band along y: 3 tile columns below, 4 above
 constexpr int kMatchMaxDir = 152 * 157;      // 8x8-cell tiles of the largest grid (1200 x 1200 cells) + guard band
-constexpr int kMatchTilesLds = 1264;         // tiles resident in LDS; the rest spills to HBM
+constexpr int kMatchTilesLds = 1248;         // tiles resident in LDS; the rest spills to HBM
 constexpr int kMatchMaxTheta = 80;           // search angles per region
 constexpr int kMatchMaxRefScans = 6;         // scans of a close-matching reference set (graph_slam.cpp:230-244: last vertex + 5)
 
@@ -23,6 +23,7 @@ struct MatchParams {
   float ll_x, ll_y, res, inv_res;
   int nx, ny;
   int kscale, fill, kdim;                    // fill = K2 = int(kernelRange * kscale)
+  int sort32;                                // close matcher: the subsample's sort keys fit 32 bits (cells within +-512, beams < 2048)
   int edt;                                   // 1: the kernel value is a non-decreasing function of the squared cell distance (radius <= 8):
                                              // grids are rasterised by an exact distance transform instead of stamping
   // laser (RobotLaser / LaserParameters) and the pose of the laser on the robot

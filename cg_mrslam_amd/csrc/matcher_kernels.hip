@@ -57,6 +57,7 @@ struct Smem {
   uint32_t plist[NTH][LISTCAP];              // per-angle point lists (16-B aligned)
   unsigned long long bins[MAXBINS];          // (score bits << 32 | visit order), min = best, first seen
   double theta[MAXTHETA];
+  double theta_cs[MAXTHETA][2];              // cos / sin of the search angles (all of a pair's angles at once, one thread each)
   uint8_t kernel[1024];
   int misc[16];
   uint32_t best_bits;                        // pruned search: lowest accepted score so far (float bits)
@@ -120,7 +121,10 @@ typedef __attribute__((address_space(3))) const u32x2 lds_cu2;
 constexpr int GRP = 5;                         // point subsets per wavefront
 constexpr int RPL = 2;                         // x rows per lane
 constexpr int PPI = 2;                         // points per lane and iteration ("slot" = PPI consecutive list entries)
-constexpr int PH = 4;                          // pruned search: the first pass adds every PH-th block of GRP slots (a quarter of the points,
+#ifndef CGMR_MATCH_PH
+#define CGMR_MATCH_PH 4
+#endif
+constexpr int PH = CGMR_MATCH_PH;                          // pruned search: the first pass adds every PH-th block of GRP slots (a quarter of the points,
                                                // spread over the whole list: the list is in the subsample's cell order, i.e. sorted in space)
 // MODE 0: every slot (lane group g of G takes slots g, g + G, ..); MODE 1: the slots of the first pass (blocks of GRP * PH
 // slots: the first GRP of every block); MODE 2: the others.  a18[w] = (x offset of the lane's row w) << 18.
@@ -155,7 +159,7 @@ __device__ __forceinline__ void gather_rows2(const uint32_t* list, int nslots, i
         rowoff[u][w] = r8 * 8u + tiles_base;
         const uint32_t da = __umul24(tx1, dw2) + da0;
         const lds_vu16* dp = (const lds_vu16*)(size_t)da;
-        d[u][w][0] = dp[0]; d[u][w][1] = dp[1]; d[u][w][2] = dp[2]; d[u][w][3] = dp[3];
+        d[u][w][0] = dp[0]; d[u][w][1] = dp[1]; d[u][w][2] = dp[2]; d[u][w][3] = dp[3];   // (one unaligned ds_read_b64 instead: works, 35 % slower)
       }
     }
     uint32_t D[PPI][RPL][8];
@@ -536,6 +540,123 @@ __device__ __forceinline__ int grid_cell(const Smem& S, const MatchParams& P, co
   return tile_byte(S, gtiles, d, boff);
 }
 
+// Query scan of one pair: cartesian -> CharGrid::subsample(0.1) (chargrid.cpp:98-122: cells in (x, y) order, members added in beam
+// order) -> laser pose.  KT = key type of the sort: cell x | cell y | beam index.  Returns the number of subsampled points.
+template <typename KT>
+__device__ __forceinline__ int subsample_query(Smem& S, const MatchParams& P, int pair, const float* __restrict__ ranges_qry,
+                                               const double* __restrict__ beam_cos, const double* __restrict__ beam_sin,
+                                               double* qraw, double* qpts) {
+  constexpr bool K32 = sizeof(KT) == 4;
+  constexpr int CELL_BITS = K32 ? 10 : 21, CELL_SHIFT = K32 ? 11 : 21, CELL_OFF = K32 ? 512 : (1 << 20);
+  const KT INVALID = (KT)~(KT)0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = P.n_beams;
+  const double ires = 1. / P.sub_res;
+// sort keys live in the (not yet used) tile pool: 2048 keys
+KT* keys = reinterpret_cast<KT*>(S.tiles);
+  // bitonic sort of 2048 keys in registers: lane l of wavefront w holds keys 256 w + 64 u + l (u = 0..3).  Exchanges at
+  // distance 64 / 128 pair two registers of a lane, smaller distances go through the cross-lane network, and only the
+  // six exchanges at distance 256 / 512 / 1024 cross wavefronts (through LDS, with workgroup barriers).
+  static_assert(CB_THREADS == 512, "the sort's ownership map assumes 8 wavefronts x 256 keys");
+  KT key[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = wave * 256 + u * 64 + lane;
+    key[u] = INVALID;
+    if (i < B) {
+      double r = (double)ranges_qry[(size_t)pair * B + i];
+      if (r < P.max_range && r > P.min_range) {
+        double x = beam_cos[i] * r, y = beam_sin[i] * r;
+        qraw[2 * i] = x; qraw[2 * i + 1] = y;
+        int kx = (int)(ires * x), ky = (int)(ires * y);
+        key[u] = ((KT)(unsigned)(kx + CELL_OFF) << (CELL_BITS + CELL_SHIFT)) | ((KT)(unsigned)(ky + CELL_OFF) << CELL_SHIFT) | (KT)i;
+      }
+    }
+  }
+  MPHASE(9);
+  for (int k = 2; k <= 2048; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 256) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) keys[wave * 256 + u * 64 + lane] = key[u];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = wave * 256 + u * 64 + lane;
+          const KT other = keys[i ^ j];
+          const bool keep_min = ((i & j) == 0) == ((i & k) == 0);      // the lower index keeps the minimum in an ascending run
+          key[u] = keep_min ? (other < key[u] ? other : key[u]) : (other > key[u] ? other : key[u]);
+        }
+      } else if (j >= 64) {
+        const int du = j >> 6;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int v = u ^ du;
+          if (v > u) {
+            const int i = wave * 256 + u * 64 + lane;
+            const KT a = key[u], b = key[v];
+            const bool up = (i & k) == 0;
+            const bool swap = (a > b) == up;
+            key[u] = swap ? b : a;
+            key[v] = swap ? a : b;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = wave * 256 + u * 64 + lane;
+          const KT other = __shfl_xor(key[u], j, 64);
+          const bool keep_min = ((lane & j) == 0) == ((i & k) == 0);
+          key[u] = keep_min ? (other < key[u] ? other : key[u]) : (other > key[u] ? other : key[u]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; u++) keys[wave * 256 + u * 64 + lane] = key[u];
+  __syncthreads();
+  MPHASE(1);
+  // bucket leaders: sorted position i starts a bucket if its (kx,ky) differs from position i-1
+  int nlead = 0;
+  constexpr int LPT = 2048 / CB_THREADS;     // sorted positions per thread
+  int lead_pos[LPT];
+#pragma unroll
+  for (int u = 0; u < LPT; u++) {
+    int i = tid * LPT + u;                  // contiguous ranges so that the scan yields bucket ranks in order
+    KT a = keys[i];
+    bool lead = (a != INVALID) && (i == 0 || (keys[i - 1] >> CELL_SHIFT) != (a >> CELL_SHIFT));
+    lead_pos[u] = lead ? i : -1;
+    nlead += lead ? 1 : 0;
+  }
+  int nq;
+  int rank = block_scan_excl(nlead, scan_scratch(S), &nq);
+  {
+    const double lc = P.lp_c, ls = P.lp_s, ltx = P.lp_x, lty = P.lp_y;
+#pragma unroll
+    for (int u = 0; u < LPT; u++) {
+      int i = lead_pos[u];
+      if (i < 0) continue;
+      KT kk = keys[i] >> CELL_SHIFT;
+      double ax = 0, ay = 0;
+      int cnt = 0;
+      for (int m = i; m < 2048 && (keys[m] >> CELL_SHIFT) == kk && keys[m] != INVALID; m++) {
+        int idx = (int)(keys[m] & (KT)((1u << CELL_SHIFT) - 1u));
+        ax += qraw[2 * idx];
+        ay += qraw[2 * idx + 1];
+        cnt++;
+      }
+      double wgt = 1. / (double)cnt;
+      double mx = ax * wgt, myy = ay * wgt;
+      qpts[2 * rank] = (lc * mx - ls * myy) + ltx;       // applyTransfToScan(laserPose, ...)
+      qpts[2 * rank + 1] = (ls * mx + lc * myy) + lty;
+      rank++;
+    }
+  }
+  return nq;
+}
+
 }  // namespace
 
 // One workgroup per scan pair (persistent stride over the batch).
@@ -587,113 +708,13 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     __syncthreads();
     MPHASE(0);
 #ifdef CGMR_PHASE_TIMING
-    if (blockIdx.x == 0 && tid == 0) { for (int q = 10; q < 16; q++) g_mphase[q] = 0; g_mphase[22] = g_mphase[23] = 0; }
+    if (blockIdx.x == 0 && tid == 0) { for (int q = 10; q < 16; q++) g_mphase[q] = 0; g_mphase[22] = g_mphase[23] = g_mphase[24] = 0; }
 #endif
     // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
-    // sort keys live in the (not yet used) tile pool: 2048 x u64
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(S.tiles);
-    const double ires = 1. / P.sub_res;
-    // bitonic sort of 2048 keys in registers: lane l of wavefront w holds keys 256 w + 64 u + l (u = 0..3).  Exchanges at
-    // distance 64 / 128 pair two registers of a lane, smaller distances go through the cross-lane network, and only the
-    // six exchanges at distance 256 / 512 / 1024 cross wavefronts (through LDS, with workgroup barriers).
-    static_assert(CB_THREADS == 512, "the sort's ownership map assumes 8 wavefronts x 256 keys");
-    unsigned long long key[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = wave * 256 + u * 64 + lane;
-      key[u] = ~0ULL;
-      if (i < B) {
-        double r = (double)ranges_qry[(size_t)pair * B + i];
-        if (r < P.max_range && r > P.min_range) {
-          double x = beam_cos[i] * r, y = beam_sin[i] * r;
-          qraw[2 * i] = x; qraw[2 * i + 1] = y;
-          int kx = (int)(ires * x), ky = (int)(ires * y);
-          key[u] = ((unsigned long long)(unsigned)(kx + (1 << 20)) << 42) | ((unsigned long long)(unsigned)(ky + (1 << 20)) << 21) |
-                   (unsigned long long)i;
-        }
-      }
-    }
-    MPHASE(9);
-    for (int k = 2; k <= 2048; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        if (j >= 256) {
-          __syncthreads();
-#pragma unroll
-          for (int u = 0; u < 4; u++) keys[wave * 256 + u * 64 + lane] = key[u];
-          __syncthreads();
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int i = wave * 256 + u * 64 + lane;
-            const unsigned long long other = keys[i ^ j];
-            const bool keep_min = ((i & j) == 0) == ((i & k) == 0);      // the lower index keeps the minimum in an ascending run
-            key[u] = keep_min ? (other < key[u] ? other : key[u]) : (other > key[u] ? other : key[u]);
-          }
-        } else if (j >= 64) {
-          const int du = j >> 6;
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int v = u ^ du;
-            if (v > u) {
-              const int i = wave * 256 + u * 64 + lane;
-              const unsigned long long a = key[u], b = key[v];
-              const bool up = (i & k) == 0;
-              const bool swap = (a > b) == up;
-              key[u] = swap ? b : a;
-              key[v] = swap ? a : b;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int i = wave * 256 + u * 64 + lane;
-            const unsigned long long other = __shfl_xor(key[u], j, 64);
-            const bool keep_min = ((lane & j) == 0) == ((i & k) == 0);
-            key[u] = keep_min ? (other < key[u] ? other : key[u]) : (other > key[u] ? other : key[u]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++) keys[wave * 256 + u * 64 + lane] = key[u];
-    __syncthreads();
-    MPHASE(1);
-    // bucket leaders: sorted position i starts a bucket if its (kx,ky) differs from position i-1
-    int nlead = 0;
-    constexpr int LPT = 2048 / CB_THREADS;     // sorted positions per thread
-    int lead_pos[LPT];
-#pragma unroll
-    for (int u = 0; u < LPT; u++) {
-      int i = tid * LPT + u;                  // contiguous ranges so that the scan yields bucket ranks in order
-      unsigned long long a = keys[i];
-      bool lead = (a != ~0ULL) && (i == 0 || (keys[i - 1] >> 21) != (a >> 21));
-      lead_pos[u] = lead ? i : -1;
-      nlead += lead ? 1 : 0;
-    }
-    int nq;
-    int rank = block_scan_excl(nlead, scan_scratch(S), &nq);
-    {
-      const double lc = P.lp_c, ls = P.lp_s, ltx = P.lp_x, lty = P.lp_y;
-#pragma unroll
-      for (int u = 0; u < LPT; u++) {
-        int i = lead_pos[u];
-        if (i < 0) continue;
-        unsigned long long kk = keys[i] >> 21;
-        double ax = 0, ay = 0;
-        int cnt = 0;
-        for (int m = i; m < 2048 && (keys[m] >> 21) == kk && keys[m] != ~0ULL; m++) {
-          int idx = (int)(keys[m] & 0x1fffff);
-          ax += qraw[2 * idx];
-          ay += qraw[2 * idx + 1];
-          cnt++;
-        }
-        double wgt = 1. / (double)cnt;
-        double mx = ax * wgt, myy = ay * wgt;
-        qpts[2 * rank] = (lc * mx - ls * myy) + ltx;       // applyTransfToScan(laserPose, ...)
-        qpts[2 * rank + 1] = (ls * mx + lc * myy) + lty;
-        rank++;
-      }
-    }
+    // sort keys: (cell x, cell y, beam) -- 32 bits when the cells fit 10 bits each (any laser up to 51 m at the reference's 0.1 m
+    // subsample cells) and the beam index 11, else 64
+    const int nq = P.sort32 ? subsample_query<uint32_t>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts)
+                            : subsample_query<unsigned long long>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts);
     __syncthreads();
     MPHASE(2);
     // ---------------- reference scan -> cells -----------------------------------------------------------------
@@ -816,6 +837,11 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     const int bx0 = S.misc[6], by0 = S.misc[7], bt0 = S.misc[8], nbx = S.misc[9], nby = S.misc[10], nbt = S.misc[11];
     const int nbins = nbx * nby * nbt;
     for (int q = tid; q < nbins; q += CB_THREADS) S.bins[q] = ~0ULL;
+    if (tid < nth) {
+      double sn, cs;
+      portable_sincos(S.theta[tid], &sn, &cs);
+      S.theta_cs[tid][0] = cs; S.theta_cs[tid][1] = sn;
+    }
     if (tid == 0) S.best_bits = 0x7f800000u;                   // best accepted score so far (float bits): +inf
     __syncthreads();
     const float ikscale = (float)(1. / (float)P.kscale);
@@ -840,18 +866,24 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       const int tb = nsearch * ((bi & 1) ? (nbat - 1) / 2 + (bi + 1) / 2 : (nbat - 1) / 2 - bi / 2);
       const int ti = (wave < nsearch) ? min(tb + wave, nth) : nth;
       int k = 0, k0p = 0, k1p = 0;
+      MSTAT_T0();
       if (ti < nth) {
-        double c, s;
-        portable_sincos(S.theta[ti], &s, &c);
+        const double c = S.theta_cs[ti][0], s = S.theta_cs[ti][1];
         uint32_t prev = 0x7fff7fffu;       // (-10000,-10000) can never match: use an impossible packed value
         bool have_prev = false;
         int k0 = 0, k1 = 0;
+        // (the points come from the workgroup's HBM scratch: the next 64 are fetched while these are turned and packed)
+        const double2* const qp2 = reinterpret_cast<const double2*>(qpts);
+        double2 nxt = lane < nq ? qp2[lane] : make_double2(0., 0.);
+#pragma unroll 2
         for (int base = 0; base < nq; base += 64) {
           int q = base + lane;
           uint32_t packed = 0;
           bool valid = q < nq;
+          const double2 cur = nxt;
+          if (q + 64 < nq) nxt = qp2[q + 64];
           if (valid) {
-            double x = qpts[2 * q], y = qpts[2 * q + 1];
+            double x = cur.x, y = cur.y;
             double px = c * x - s * y, py = s * x + c * y;
             int ix = (int)(px * (double)P.inv_res), iy = (int)(py * (double)P.inv_res);
             packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
@@ -894,6 +926,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         } else if (lane < 2 * PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
       }
       __builtin_amdgcn_wave_barrier();
+      MSTAT(24);
       if (ti < nth && v2) {
         // ---- fast path, window of at most 24 x 24 offsets: lane = (point subset g of 5, x rows r and r + 12), see gather_rows2
         const int grp = lane / 12, r = lane - 12 * grp;
@@ -916,7 +949,6 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         auto total_of = [&](int a, int b) -> int { return (int)((totals[a * 12 + (b >> 1)] >> (16 * (b & 1))) & 0xffffu); };
         for (int q = lane; q < 24 * 12; q += 64) totals[q] = 0;
         const int a18[RPL] = {r << 18, (r + 12) << 18};
-        MSTAT_T0();
         if (prune) {
           gather_rows2<false, 1>(pl, act ? k0p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
           gather_rows2<true, 1>(pl1, act ? k1p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);

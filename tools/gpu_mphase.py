@@ -17,8 +17,8 @@ for i, n in enumerate(names):
 print("total", o[8]-o[0])
 print("  of the first phase: load + keys", o[9]-o[0], " sort", o[1]-o[9])
 if o[15] > 0:
-    print("  fast search path, wavefront 0, summed over its %d angles: first pass %d, probe + liveness %d, second pass %d, candidates %d cycles; live rows per angle %.2f of 24"
-          % (o[15], o[10], o[11], o[12], o[13], o[14] / o[15]))
+    print("  fast search path, wavefront 0, summed over its %d angles: list %d, first pass %d, probe + liveness %d, second pass %d, candidates %d cycles; live rows per angle %.2f of 24"
+          % (o[15], o[24], o[10], o[11], o[12], o[13], o[14] / o[15]))
 if o[21] > o[16] > 0:
     print("  distance-transform rasteriser: cell maps %d, along y %d (+ %d barrier, row 0), along x %d, write back %d" % (o[17]-o[16], o[18]-o[17], o[19]-o[18], o[20]-o[19], o[21]-o[20]), " before it (tile init -> here)", o[16]-o[4])
 if len(sys.argv) > 1:
