@@ -52,7 +52,7 @@ constexpr int kEdtLutN = 130;
 
 struct Smem {
   // the directory comes first: its byte addresses then fit the 16-bit field of the fast search path's list entries
-  uint16_t dir[kMatchMaxDir];                // tile directory: 0xFFFF = untouched (all cells = fill)
+  uint16_t dir[kMatchMaxDir];                // tile directory: tile id per 8x8 cells; 0 = untouched (the all-fill tile), 1 = outside the grid (all zero)
   uint32_t tiles[NT_LDS * 16];               // 64-byte tiles, cell (x&7, y&7) at byte (x&7)*8 + (y&7)   (16-B aligned)
   uint32_t plist[NTH][LISTCAP];              // per-angle point lists (16-B aligned)
   unsigned long long bins[MAXBINS];          // (score bits << 32 | visit order), min = best, first seen
@@ -106,6 +106,8 @@ __device__ __forceinline__ int clamp_med3(int x, int hi) {     // min(max(x, LO)
 }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 typedef __attribute__((address_space(3))) const u32x2 lds_cu2;
 
 // Fast search path, one class of a per-angle point list (entries whose first search cell sits in the lower / upper half
@@ -250,8 +252,8 @@ __device__ __forceinline__ void stamp_word(uint32_t* wp, uint32_t kv) {
   }
 }
 
-// resetGrid + addAndConvolvePoints for n packed reference cells: directory marking, tile slot assignment (block
-// scan), tile initialisation, compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
+// resetGrid + addAndConvolvePoints for n packed reference cells: tiles claimed and numbered by the points that reach them,
+// then the distance-transform rasteriser or compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
 __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
                            int* err) {
   const int tid = threadIdx.x;
@@ -262,7 +264,18 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   const int K2 = P.fill;
   const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
   const int ctr = (P.kdim - 1) / 2;
-  for (int q = tid; q < (ndir + 1) / 2; q += NTHR) reinterpret_cast<uint32_t*>(S.dir)[q] = 0;
+  // Tile ids: 0 = the all-fill tile (every directory entry no stamp reaches), 1 = the all-zero tile (the guard band around
+  // the grid: the fast search path looks up cells outside the grid without a bounds test), 2 .. ntile + 1 = the tiles some
+  // stamp reaches, numbered in the order their first point claims them (an atomic counter; the numbering differs from run
+  // to run, nothing that is computed depends on it).  Round 2 numbered them in directory order: two serial walks over the
+  // 24k-entry directory per thread and a block scan, 30k cycles per pair.
+  uint16_t* const tile_slot = reinterpret_cast<uint16_t*>(&S.totals[0][0]);       // tile -> directory slot    (idle until the search)
+  uint32_t* const claimed = reinterpret_cast<uint32_t*>(tile_slot + NT_LDS);       // one bit per directory slot (the same)
+  static_assert(NT_LDS * 2 + (kMatchMaxDir + 31) / 32 * 4 <= (int)sizeof(S.totals) && (NT_LDS & 1) == 0, "tile_slot + claim bits");
+  for (int q = tid; q < (ndir + 7) / 8; q += NTHR) reinterpret_cast<uint4*>(S.dir)[q] = make_uint4(0u, 0u, 0u, 0u);
+  for (int q = tid; q < (ndir + 31) / 32; q += NTHR) claimed[q] = 0u;
+  if (tid == 0) { S.misc[0] = 0; S.misc[15] = 0; }
+  if (tid < 16) { S.tiles[tid] = fill4; S.tiles[16 + tid] = 0u; }
   // kernel columns for the stamping below: column ki as 32 bytes = 4 x 0xff, the kdim values along y, 0xff padding, so
   // that the 32-bit word that covers four consecutive cells of a stamp is two aligned words and a byte alignment
   const bool kcols = P.kdim <= 17;
@@ -278,6 +291,13 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
       const int i = q % P.kdim - ctr, j = q / P.kdim - ctr;
       S.kernel[kEdtLutOff + i * i + j * j] = S.kernel[q];
     }
+  // guard band: rows 0 and ntx + 1, columns 0..2 and nty + 3 .. DW - 1 of every row
+  for (int q = tid; q < 2 * DW; q += NTHR) S.dir[q < DW ? q : (ntx + 1) * DW + (q - DW)] = 1;
+  for (int q = tid; q < ntx * kMatchDirGuardY; q += NTHR) {
+    const int row = 1 + q / kMatchDirGuardY, c = q - (row - 1) * kMatchDirGuardY;
+    S.dir[row * DW + (c < 3 ? c : nty + c)] = 1;
+  }
+  const bool edt_maps = P.edt != 0;                               // the claimer clears its tile's cell map (the first two words)
   for (int i = tid; i < n; i += NTHR) {
     uint32_t packed = rcell[i];
     if (packed == 0x80008000u) continue;
@@ -285,42 +305,33 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     int x0 = max(rx - ctr, 0), x1 = min(rx + ctr, P.nx - 1), y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
     if (x0 <= x1 && y0 <= y1)
       for (int tx = x0 >> 3; tx <= (x1 >> 3); tx++)
-        for (int ty = y0 >> 3; ty <= (y1 >> 3); ty++) S.dir[(tx + 1) * DW + ty + 3] = 1;
+        for (int ty = y0 >> 3; ty <= (y1 >> 3); ty++) {
+          const int e = (tx + 1) * DW + ty + 3;
+          const uint32_t bit = 1u << (e & 31);
+          if (claimed[e >> 5] & bit) continue;                     // (most stamps land on tiles a neighbouring beam claimed)
+          if (atomicOr(&claimed[e >> 5], bit) & bit) continue;
+          const int id = 2 + atomicAdd(&S.misc[0], 1);
+          S.dir[e] = (uint16_t)id;
+          if (id < NT_LDS) {
+            tile_slot[id] = (uint16_t)e;
+            if (edt_maps) { S.tiles[id * 16] = 0u; S.tiles[id * 16 + 1] = 0u; }
+          }
+        }
   }
   __syncthreads();
   MPHASE(3);
-  {
-    const int per = (ndir + NTHR - 1) / NTHR;
-    const int b0 = tid * per, b1 = min(ndir, b0 + per);
-    int cnt = 0;
-    for (int q = b0; q < b1; q++) cnt += S.dir[q];
-    uint16_t* const tile_slot = reinterpret_cast<uint16_t*>(&S.totals[0][0]);     // (idle until the search)
-    int ntile;
-    int base = block_scan_excl(cnt, scan_scratch(S), &ntile);
-    // fast path: every tile (plus an all-fill and an all-zero tile) is resident in LDS and the grid is a
-    // whole number of tiles, so the search can gather without branches: untouched directory entries
-    // point at the all-fill tile, cells outside the grid are redirected to the all-zero tile.
-    const bool fastp = allow_fast && (ntile + 2 <= NT_LDS) && ((P.nx & 7) == 0) && ((P.ny & 7) == 0) &&
-                       P.x_steps == 1 && P.y_steps == 1 && K2 * PT <= 255;
-    int row = b0 / DW, col = b0 - row * DW;
-    for (int q = b0; q < b1; q++) {
-      const bool guard = row == 0 || row == ntx + 1 || col < 3 || col >= nty + 3;
-      if (S.dir[q]) {
-        if (base < NT_LDS) tile_slot[base] = (uint16_t)q;          // tile -> directory slot (the distance-transform rasteriser walks the tiles)
-        S.dir[q] = (uint16_t)base++;
-      }
-      else S.dir[q] = fastp ? (uint16_t)(guard ? ntile + 1 : ntile) : (uint16_t)0xFFFF;
-      if (++col == DW) { col = 0; row++; }
-    }
-    if (tid == 0) { S.misc[0] = ntile; S.misc[12] = fastp ? 1 : 0; }
-    if (ntile > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
+  const int ntile = S.misc[0];                                     // tiles 2 .. ntile + 1
+  // fast path: every tile is resident in LDS and the grid is a whole number of tiles, so the search can gather without
+  // branches: untouched directory entries point at the all-fill tile, cells outside the grid at the all-zero tile.
+  const bool fast = allow_fast && (ntile + 2 <= NT_LDS) && ((P.nx & 7) == 0) && ((P.ny & 7) == 0) &&
+                    P.x_steps == 1 && P.y_steps == 1 && K2 * PT <= 255;
+  if (tid == 0) S.misc[12] = fast ? 1 : 0;
+  if (ntile + 2 > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
+  const bool edt = P.edt && ntile + 2 <= NT_LDS && ntile > 0;
+  if (!edt) {                                                      // (the distance transform writes every cell of every tile)
+    for (int q = 32 + tid; q < min(ntile + 2, NT_LDS) * 16; q += NTHR) S.tiles[q] = fill4;
+    for (int q = tid; q < max(0, ntile + 2 - NT_LDS) * 16; q += NTHR) gtiles[q] = fill4;
   }
-  __syncthreads();
-  const int ntile = S.misc[0];
-  const bool fast = S.misc[12] != 0;
-  if (fast && tid < 16) { S.tiles[ntile * 16 + tid] = fill4; S.tiles[(ntile + 1) * 16 + tid] = 0u; }
-  for (int q = tid; q < min(ntile, NT_LDS) * 16; q += NTHR) S.tiles[q] = fill4;
-  for (int q = tid; q < max(0, ntile - NT_LDS) * 16; q += NTHR) gtiles[q] = fill4;
   __syncthreads();
   MPHASE(4);
   // ---- rasteriser, all tiles resident in LDS: exact distance transform instead of stamping.  The kernel value of an offset
@@ -336,13 +347,8 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   // Cost: proportional to the tiles (about 11 lines of 8 cells per thread), not to points x kernel area through
   // compare-and-swap (139k of a pair's 595k cycles).  Reference cells outside the grid (their stamps reach into it) and
   // grids with overflow tiles keep the stamping below.
-  const bool edt = P.edt && ntile <= NT_LDS && ntile > 0;
   MPHASE(16);
   if (edt) {
-    const uint16_t* const tile_slot = reinterpret_cast<const uint16_t*>(&S.totals[0][0]);
-    for (int d = tid; d < ntile; d += NTHR) { S.tiles[d * 16] = 0u; S.tiles[d * 16 + 1] = 0u; }
-    if (tid == 0) S.misc[15] = 0;
-    __syncthreads();
     int noff = 0;
     for (int i = tid; i < n; i += NTHR) {
       const uint32_t packed = rcell[i];
@@ -379,14 +385,14 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     uint32_t r0w[R0][2];
 #pragma unroll
     for (int u = 0; u < R0; u++) {
-      const int d = tid + NTHR * u;
+      const int d = 2 + tid + NTHR * u;
       r0w[u][0] = r0w[u][1] = 0u;
-      if (d >= ntile) continue;
+      if (d >= ntile + 2) continue;
       const int q = tile_slot[d];
       const int dn = S.dir[q - 1], dp = S.dir[q + 1];
       const uint2 m0 = *reinterpret_cast<const uint2*>(&S.tiles[d * 16]);
-      const uint2 mn = dn < ntile ? *reinterpret_cast<const uint2*>(&S.tiles[dn * 16]) : make_uint2(0u, 0u);
-      const uint2 mp = dp < ntile ? *reinterpret_cast<const uint2*>(&S.tiles[dp * 16]) : make_uint2(0u, 0u);
+      const uint2 mn = dn >= 2 ? *reinterpret_cast<const uint2*>(&S.tiles[dn * 16]) : make_uint2(0u, 0u);
+      const uint2 mp = dp >= 2 ? *reinterpret_cast<const uint2*>(&S.tiles[dp * 16]) : make_uint2(0u, 0u);
       for (int xr = 0; xr < 8; xr++) {
         const uint32_t sh = 8u * (uint32_t)(xr & 3);
         const uint32_t a = xr < 4 ? mn.x : mn.y, b = xr < 4 ? m0.x : m0.y, c = xr < 4 ? mp.x : mp.y;
@@ -401,8 +407,8 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < R0; u++) {
-      const int d = tid + NTHR * u;
-      if (d < ntile) *reinterpret_cast<uint2*>(&S.tiles[d * 16]) = make_uint2(r0w[u][0], r0w[u][1]);
+      const int d = 2 + tid + NTHR * u;
+      if (d < ntile + 2) *reinterpret_cast<uint2*>(&S.tiles[d * 16]) = make_uint2(r0w[u][0], r0w[u][1]);
     }
     __syncthreads();
     MPHASE(19);
@@ -411,46 +417,55 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     // (otherwise unused) overflow pool in HBM and come back after a barrier: the neighbours still read the g^2 lines, and
     // holding them in registers instead made the compiler spill.
     for (int hi = tid; hi < 2 * ntile; hi += NTHR) {
-      const int d = hi >> 1, h4 = 4 * (hi & 1);
+      const int d = 2 + (hi >> 1), h4 = 4 * (hi & 1);
       const int q = tile_slot[d];
       const int dm = S.dir[q - DW], dpl = S.dir[q + DW];
-      uint2 wv[20];
+      // the 20 lines, each as four words of two 16-bit values: cells (0, 2), (1, 3), (4, 6), (5, 7)
+      us2 U[20][4];
 #pragma unroll
       for (int t = 0; t < 20; t++) {
         const int gl = h4 - 8 + t;                                 // x row relative to the tile's first: -8 .. 15
         const int dt = gl < 0 ? dm : (gl >= 8 ? dpl : d);
-        const bool ok = dt < ntile;
-        const uint2 v = *reinterpret_cast<const uint2*>(&S.tiles[(ok ? dt : d) * 16 + 2 * (gl & 7)]);
-        wv[t] = ok ? v : make_uint2(0xffffffffu, 0xffffffffu);
+        const bool ok = dt >= 2;
+        uint2 v = *reinterpret_cast<const uint2*>(&S.tiles[(ok ? dt : d) * 16 + 2 * (gl & 7)]);
+        if (!ok) v = make_uint2(0xffffffffu, 0xffffffffu);
+        U[t][0] = as_us2(__builtin_amdgcn_perm(0u, v.x, 0x0c020c00u));
+        U[t][1] = as_us2(__builtin_amdgcn_perm(0u, v.x, 0x0c030c01u));
+        U[t][2] = as_us2(__builtin_amdgcn_perm(0u, v.y, 0x0c020c00u));
+        U[t][3] = as_us2(__builtin_amdgcn_perm(0u, v.y, 0x0c030c01u));
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        int d2[8];
+        // d^2 = min over dx of dx^2 + g^2(x + dx): the lines at -dx and +dx share the dx^2, so their minimum is taken first
+        us2 acc[4];
 #pragma unroll
-        for (int y = 0; y < 8; y++) d2[y] = 1 << 20;
+        for (int c = 0; c < 4; c++) acc[c] = U[j + 8][c];
 #pragma unroll
-        for (int t = j; t <= j + 16; t++) {
-          const int dx = t - j - 8;
-          const int c2 = dx * dx + ((dx < -ctr || dx > ctr) ? (1 << 16) : 0);     // (a radius below 8 leaves the outer lines out)
+        for (int k = 1; k <= 8; k++) {
+          const unsigned short c2 = (unsigned short)(k <= ctr ? k * k : 0x4000);      // (a radius below 8 leaves the outer lines out)
+          const us2 cc = {c2, c2};
 #pragma unroll
-          for (int y = 0; y < 4; y++) {
-            d2[y] = min(d2[y], (int)((wv[t].x >> (8 * y)) & 0xffu) + c2);
-            d2[4 + y] = min(d2[4 + y], (int)((wv[t].y >> (8 * y)) & 0xffu) + c2);
-          }
+          for (int c = 0; c < 4; c++)
+            acc[c] = __builtin_elementwise_min(acc[c], __builtin_elementwise_min(U[j + 8 - k][c], U[j + 8 + k][c]) + cc);
         }
-        uint32_t v0 = 0u, v1 = 0u;
+        const us2 cap = {(unsigned short)(kEdtLutN - 1), (unsigned short)(kEdtLutN - 1)};
+        uint32_t kv[8];
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-          v0 |= (uint32_t)lut[min(d2[y], kEdtLutN - 1)] << (8 * y);
-          v1 |= (uint32_t)lut[min(d2[4 + y], kEdtLutN - 1)] << (8 * y);
+        for (int c = 0; c < 4; c++) {
+          const us2 a = __builtin_elementwise_min(acc[c], cap);
+          kv[2 * c] = lut[a.x];
+          kv[2 * c + 1] = lut[a.y];
         }
+        // acc[0] = cells (0, 2), acc[1] = (1, 3), acc[2] = (4, 6), acc[3] = (5, 7)
+        const uint32_t v0 = kv[0] | (kv[2] << 8) | (kv[1] << 16) | (kv[3] << 24);
+        const uint32_t v1 = kv[4] | (kv[6] << 8) | (kv[5] << 16) | (kv[7] << 24);
         *reinterpret_cast<uint2*>(&gtiles[d * 16 + 2 * (h4 + j)]) = make_uint2(v0, v1);
       }
     }
     // (workgroup scope is enough and cheap: the lines come back to the CU that wrote them)
     __syncthreads();
     MPHASE(20);
-    for (int w = tid; w < 4 * ntile; w += NTHR)
+    for (int w = 8 + tid; w < 4 * (ntile + 2); w += NTHR)
       reinterpret_cast<uint4*>(S.tiles)[w] = reinterpret_cast<const uint4*>(gtiles)[w];
     __syncthreads();
     MPHASE(21);
