@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "cgmr_ctx.h"
@@ -420,6 +421,8 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
                              std::vector<std::vector<cgmr_match_result>>& out) {
   const int nj = (int)jobs.size();
   out.assign(nj, {});
+  static const bool trace = getenv("CGMR_MATCH_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
   if (!cfg || !(theta_res > 0) || !(dx > 0) || !(dy > 0) || !(dth > 0)) return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
   for (const SearchJob& J : jobs) {
     if (J.n_ref < 0 || J.n_qry < 0 || J.n_regions < 0 || (J.n_ref > 0 && !J.ref) || (J.n_qry > 0 && !J.qry) || (J.n_regions > 0 && !J.regions))
@@ -534,6 +537,7 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
   memcpy(h + o_kern, kern.data(), kern.size());
   memset(h + o_err, 0, 16);
   char* d = ctx->mt_arena.ptr;
+  const auto t_staged = std::chrono::steady_clock::now();
   HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(d + o_bins, 0xff, 8 * total_bins, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -551,7 +555,17 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->match_seconds = 1e-3 * ms;
+  const auto t_back = std::chrono::steady_clock::now();
   if (err != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", err);
+  struct TraceAtExit {
+    bool on; std::chrono::steady_clock::time_point a, b, c; float ms; int nj, nblocks; size_t bins, items, hbytes;
+    ~TraceAtExit() {
+      if (!on) return;
+      auto us = [](auto x, auto y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+      fprintf(stderr, "[greedy] jobs %d blocks %d items %zu bins %zu upload %zu B: stage %.0f us, device+sync %.0f us (kernel %.0f), decode %.0f us\n",
+              nj, nblocks, items, bins, hbytes, us(a, b), us(b, c), 1e3 * ms, us(c, std::chrono::steady_clock::now()));
+    }
+  } trace_at_exit{trace, t_begin, t_staged, t_back, ms, nj, nblocks, total_bins, items.size() / 2, hbytes};
   // decode: thread maps in thread order, each in (ix, iy, ith) order; then a stable sort on the score
   for (int j = 0; j < nj; j++) {
     const GreedyJob& D0 = G[j];
