@@ -127,6 +127,48 @@ def test_batch_recovers_truth_and_is_order_independent(ctx):
     assert np.array_equal(x2, xyt[perm]) and np.array_equal(s2, score[perm]) and np.array_equal(f2, found[perm])
 
 
+def test_pruned_search_returns_the_exhaustive_winner(ctx, oracle):
+    """A caller that asks for the number of populated result bins gets the exhaustive search, everybody else the pruned
+    one (partial sums as lower bounds, rows of the window that cannot win dropped): same transform, score and flag on
+    ordinary pairs, on the edge cases, with loose and tight acceptance thresholds, and for single calls (16 workgroups
+    share a pair, each with its own bound)."""
+    sp = synth.make_scan_pairs(40, seed=91)
+    rr, rq, g = sp["ranges_ref"].copy(), sp["ranges_qry"].copy(), sp["guess"].copy()
+    rr[0] = 100.0; rq[1] = 100.0; rr[2, ::2] = 100.0; rq[3, 100:900] = 0.0
+    g[4] += [0.31, -0.29, 0.21]; g[5] = [14.9, -14.95, 3.1]; rr[6] = 29.99; rq[6] = 29.99
+    m = _matcher(ctx, sp)
+    for max_score in (0.02, 0.15, 5.0):
+        f1, x1, s1 = m.closeScanMatching(rr, rq, g, maxScore=max_score)
+        f2, x2, s2, nres = m.closeScanMatching(rr, rq, g, maxScore=max_score, want_nresults=True)
+        assert np.array_equal(f1, f2) and np.array_equal(x1, x2) and np.array_equal(s1, s2)
+        assert np.array_equal(nres > 0, f2)
+        _assert_same((f1, x1, s1), _oracle(oracle, sp, rr, rq, g, max_score=max_score))
+    for i in (7, 8, 9):
+        a = m.closeScanMatching(rr[i], rq[i], g[i])
+        b = m.closeScanMatching(rr[i], rq[i], g[i], want_nresults=True)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
+
+
+def test_fallback_rasteriser_and_exhaustive_search_match_the_golden_fixture():
+    """The library read with CGMR_MATCH_EDT=0 CGMR_MATCH_PRUNE=0 (compare-and-swap stamping instead of the distance
+    transform, every candidate evaluated): the paths grids with overflow tiles, unusual kernels and bin counts fall back
+    to must stay bit-identical too.  The switches are read once per process, hence the child."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, numpy as np\n"
+        "from cg_mrslam_amd import Context\n"
+        "from cg_mrslam_amd.matcher import ScanMatcher\n"
+        "d = np.load(os.path.join('tests', 'golden', 'match_close12.npz'))\n"
+        "m = ScanMatcher(Context(0), d['ranges_ref'].shape[1], float(d['angle_min']), float(d['angle_inc']), float(d['max_range']))\n"
+        "f, x, s = m.closeScanMatching(d['ranges_ref'], d['ranges_qry'], d['guess'])\n"
+        "assert np.array_equal(f, d['found'].astype(bool)) and np.array_equal(x, d['xyt']) and np.array_equal(s, d['score'])\n"
+        "print('fallback ok')\n")
+    env = dict(os.environ, CGMR_MATCH_EDT="0", CGMR_MATCH_PRUNE="0", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_rejects_bad_configuration(ctx):
     from cg_mrslam_amd import CgmrError
     sp = synth.make_scan_pairs(1, seed=82)
