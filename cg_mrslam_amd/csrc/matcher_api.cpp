@@ -450,7 +450,7 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
   int max_ref = 1, nblocks = 0, live = 0;
   auto w2g = [&](float w, float ll) { return (int)std::lrint((w - ll) * P.inv_res); };
   for (const SearchJob& J : jobs) live += J.n_regions > 0 ? 1 : 0;
-  const int blocks_cap = std::max(1, std::min(128, 1024 / std::max(live, 1)));     // few jobs: several workgroups each
+  const int blocks_cap = std::max(1, std::min(256, 2048 / std::max(live, 1)));     // few jobs: several workgroups each
   for (int j = 0; j < nj; j++) {
     const SearchJob& J = jobs[j];
     GreedyJob& D0 = G[j];
@@ -505,7 +505,7 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
     if (nbins * num_threads > (size_t)1 << 26) return set_err(ctx, CGMR_E_INVALID, "result discretisation too fine for the search volume");
     D0.bins_off = (int64_t)total_bins;
     total_bins += nbins * num_threads;
-    D0.n_blocks = std::max(1, std::min(blocks_cap, (D0.n_items + 3) / 4));      // one (region, angle) item per wavefront and round
+    D0.n_blocks = std::max(1, std::min(blocks_cap, D0.n_items));                // one (region, angle) item per workgroup and round
     for (int b = 0; b < D0.n_blocks; b++) block_job.push_back(j);
     nblocks += D0.n_blocks;
   }
@@ -517,12 +517,15 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
   size_t o_ref = L.add(16 * std::max<size_t>(n_refs, 1)), o_q = L.add(16 * std::max<size_t>(n_qrys, 1)),
          o_reg = L.add(sizeof(RegionDesc) * std::max<size_t>(R.size(), 1)), o_th = L.add(8 * std::max<size_t>(theta.size(), 1)),
          o_it = L.add(4 * std::max<size_t>(items.size(), 1)), o_job = L.add(sizeof(GreedyJob) * (size_t)nj),
-         o_bj = L.add(4 * block_job.size()), o_kern = L.add(kern.size()), o_err = L.add(16);
+         o_bj = L.add(4 * block_job.size()), o_kern = L.add(kern.size());
   size_t hbytes = L.off;
-  size_t o_bins = L.add(8 * total_bins), o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
+  // the error word sits right in front of the result maps: one copy brings both back, into a part of the pinned block the
+  // upload does not use (no synchronisation between the two directions)
+  size_t o_err = L.add(256 + 8 * total_bins), o_bins = o_err + 256, o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
   rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
   if (rc) return rc;
-  rc = pinned_reserve(ctx, std::max(hbytes, 8 * total_bins));
+  const size_t h_back = (hbytes + 255) & ~size_t(255);
+  rc = pinned_reserve(ctx, h_back + 256 + 8 * total_bins);
   if (rc) return rc;
   char* h = ctx->pinned;
   for (int j = 0; j < nj; j++) {
@@ -535,10 +538,10 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
   memcpy(h + o_job, G.data(), sizeof(GreedyJob) * (size_t)nj);
   memcpy(h + o_bj, block_job.data(), 4 * block_job.size());
   memcpy(h + o_kern, kern.data(), kern.size());
-  memset(h + o_err, 0, 16);
   char* d = ctx->mt_arena.ptr;
   const auto t_staged = std::chrono::steady_clock::now();
   HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d + o_err, 0, 256, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(d + o_bins, 0xff, 8 * total_bins, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   launch_match_greedy(ctx->stream, nblocks, P, (const GreedyJob*)(d + o_job), (const int32_t*)(d + o_bj), (const double*)(d + o_ref),
@@ -546,11 +549,9 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
                       (const int32_t*)(d + o_it), (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch),
                       (unsigned long long*)(d + o_bins), (int*)(d + o_err));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  int err = 0;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer is reused for the read-back below
-  HIP_TRY(ctx, hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(h, d + o_bins, 8 * total_bins, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h + h_back, d + o_err, 256 + 8 * total_bins, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int err = *reinterpret_cast<const int*>(h + h_back);
   HIP_TRY(ctx, hipGetLastError());
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -571,7 +572,7 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
     const GreedyJob& D0 = G[j];
     if (D0.n_items == 0) continue;
     const size_t nbins = (size_t)D0.nbx * D0.nby * D0.nbt;
-    const unsigned long long* bins = (const unsigned long long*)h + D0.bins_off;
+    const unsigned long long* bins = (const unsigned long long*)(h + h_back + 256) + D0.bins_off;
     std::vector<cgmr_match_result>& res = out[j];
     for (int th = 0; th < nthreads[j]; th++)
       for (size_t q = 0; q < nbins; q++) {

@@ -1381,9 +1381,14 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const Greed
   const float ikscale = (float)(1. / (float)P.kscale);
   const int nbins = J.nbx * J.nby * J.nbt;
   uint32_t* const pl = &S.plist[0][0] + wave * (2 * LISTCAP);     // 4 wavefronts: two lists each
-  for (int it0 = jb * GR_WAVES; it0 < J.n_items; it0 += J.n_blocks * GR_WAVES) {
-    const int it = it0 + wave;
-    if (it >= J.n_items) continue;
+  // One (region, angle) item per workgroup and round.  Every wavefront turns all the query points and builds the same
+  // kept-point list (the consecutive-duplicate rule runs along the whole list; this is a hundredth of the work), then
+  // gathers one quarter of it for all the candidates; the quarters meet in LDS.  Round 2 gave every wavefront an item of
+  // its own: with the 30-60 items of a key frame's searches that left the kernel waiting ~180 us for one wavefront's
+  // serial walk over ~1000 points while 240 CUs idled.
+  int* const totals = reinterpret_cast<int*>(&S.totals[0][0]);     // 64 * CAND_U candidate sums (tile_slot / claim bits are done with)
+  static_assert(64 * CAND_U * 4 <= (int)sizeof(S.totals), "candidate sums of one item");
+  for (int it = jb; it < J.n_items; it += J.n_blocks) {
     const RegionDesc R = regions[items[2 * (size_t)(J.item_off + it)]];
     const int ti = items[2 * (size_t)(J.item_off + it) + 1];
     const double t = theta[R.th_off + ti];
@@ -1400,6 +1405,8 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const Greed
         cj[u] = R.lo_y + b * P.y_steps;
         sum[u] = 0;
       }
+      __syncthreads();                                            // (the previous pass' sums have been read)
+      for (int q = tid; q < 64 * CAND_U; q += 256) totals[q] = 0;
       // the point list is rebuilt in chunks of at most MAXPTS - 4 kept points
       int k = 0;
       uint32_t prev = 0;
@@ -1431,7 +1438,8 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const Greed
           have_prev = true;
         }
         __builtin_amdgcn_wave_barrier();
-        for (int q = 0; q < kc; q++) {
+        const int q0 = (int)(((long long)kc * wave) / GR_WAVES), q1 = (int)(((long long)kc * (wave + 1)) / GR_WAVES);
+        for (int q = q0; q < q1; q++) {
           uint32_t packed = pl[q];
           int px = (int16_t)(packed & 0xffff), py = (int16_t)(packed >> 16);
 #pragma unroll
@@ -1440,15 +1448,22 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const Greed
         __builtin_amdgcn_wave_barrier();
         k += kc;
       }
+      __syncthreads();                                            // (totals are zero)
 #pragma unroll
-      for (int u = 0; u < CAND_U; u++) {
-        int cidx = cb + u * 64 + lane;
+      for (int u = 0; u < CAND_U; u++)
+        if (sum[u]) atomicAdd(&totals[u * 64 + lane], sum[u]);
+      __syncthreads();
+      // the candidates of the pass over the workgroup's 256 threads
+      for (int c = tid; c < 64 * CAND_U; c += 256) {
+        const int cidx = cb + c;
         if (cidx >= ncand) continue;
-        float dsum = (float)sum[u] * ikscale;
+        const int a = cidx / R.nj, b = cidx - a * R.nj;
+        const int cix = R.lo_x + a * P.x_steps, cjy = R.lo_y + b * P.y_steps;
+        float dsum = (float)totals[c] * ikscale;
         dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
         if ((double)dsum < P.max_score) {
-          float wx = P.ll_x + (P.res * (float)ci[u]);
-          float wyy = P.ll_y + (P.res * (float)cj[u]);
+          float wx = P.ll_x + (P.res * (float)cix);
+          float wyy = P.ll_y + (P.res * (float)cjy);
           int bx = (int)((double)wx / P.dx) - J.bx0, by = (int)((double)wyy / P.dy) - J.by0;
           int bt = (int)(t / P.dth) - J.bt0;
           if (bx < 0 || bx >= J.nbx || by < 0 || by >= J.nby || bt < 0 || bt >= J.nbt) { atomicExch(err, 4); continue; }
