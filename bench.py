@@ -252,6 +252,9 @@ def matcher_leg(ctx, dev, args, with_cpu):
     useful_rate = nx * byte_adds / 256.0 / ksec_x          # wave instructions / s that do algorithmic adds (exhaustive run)
     lds_peak = 256 * 256 * clk                             # bytes / s: the gathers are ds_read_b64, 256 B per CU and clock (MI355X guide, LDS)
     gather_rate = nx * byte_adds / ksec_x                  # algorithmic bytes gathered from the LDS-resident grid / s (exhaustive run)
+    # HBM per pair: 8.7 KB of ranges / guess / results + the rasteriser's finished lines, which go out to the workgroup's scratch
+    # and come back (64 B per 8x8 tile each way, ~720 tiles): ~100 KB; the committed PMC pass (2 x FETCH_SIZE + WRITE_SIZE) if present
+    hbm_pp = (pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096)) if pmc_m else 8.7e3 + 2 * 64 * 720
     golden = None
     gpath = os.path.join(ROOT, "tests", "golden", "match_close4096.npz")
     if os.path.exists(gpath) and base == 4096:
@@ -272,8 +275,8 @@ def matcher_leg(ctx, dev, args, with_cpu):
                         "valu_issue": {"achieved_G_wave_instr_per_s": round(useful_rate / 1e9, 2), "peak": round(valu_issue_peak / 1e9, 1),
                                        "frac": round(useful_rate / valu_issue_peak, 4)},
                         "pruned_equivalent_TBps": round(P * byte_adds / ksec / 1e12, 3),
-                        "hbm": {"achieved_GBps": round(P * 8.7e3 / ksec / 1e9, 3), "peak_GBps": 8000.0,
-                                "frac": round(P * 8.7e3 / ksec / 1e9 / 8000.0, 7),
+                        "hbm": {"achieved_GBps": round(P * hbm_pp / ksec / 1e9, 3), "peak_GBps": 8000.0,
+                                "frac": round(P * hbm_pp / ksec / 1e9 / 8000.0, 7), "bytes_per_pair": int(hbm_pp),
                                 "traffic_bytes_per_launch": (round(pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096) * P) if pmc_m else None)},
                         "bytes_fetched_per_useful_byte": round((32 + 8) / 24.0 * 64 / 60, 3),
                         "lds_bank_conflict_frac": (pmc_m or {}).get("lds_bank_conflict_frac"),
@@ -286,8 +289,8 @@ def matcher_leg(ctx, dev, args, with_cpu):
                                 "(bytes_fetched_per_useful_byte), the 2-byte directory loads cost a 4-byte pass each and "
                                 "lds_bank_conflict_frac of the LDS-array cycles are bank conflicts (SQ_LDS_BANK_CONFLICT / "
                                 "SQ_LDS_IDX_ACTIVE of the committed PMC pass); valu_issue = the same adds as packed-byte VALU "
-                                "instructions (256 per wave instruction) against one per SIMD and clock; HBM carries 8.7 KB per pair "
-                                "and is not the roof (DESIGN.md 3); pruned_equivalent = the candidates of the exhaustive search per second of the pruned one (not bytes that move)"}}
+                                "instructions (256 per wave instruction) against one per SIMD and clock; HBM carries ~100 KB per pair "
+                                "(8.7 KB of inputs / results, the rest the rasteriser's lines through the scratch pool) and is not the roof (DESIGN.md 3); pruned_equivalent = the candidates of the exhaustive search per second of the pruned one (not bytes that move)"}}
     if with_cpu:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
