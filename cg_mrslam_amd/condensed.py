@@ -182,7 +182,7 @@ class RobotGraph:
         """``constructCondensedGraphMessage(peer)``: a ``messages.CondensedGraphMessage`` or None (nothing to send)."""
         from .messages import EDGE_DTYPE, CondensedGraphMessage
         cap = self.cap
-        edges, clos = np.zeros(cap, dtype=EDGE_DTYPE), np.zeros(cap, dtype=np.int32)
+        edges, clos = np.empty(cap, dtype=EDGE_DTYPE), np.empty(cap, dtype=np.int32)
         ne, nc = C.c_int32(0), C.c_int32(0)
         rc = self._check(self.lib.cgmr_graph_message_for(self.h, C.c_int(peer), C.c_int(cap), _p(edges), C.byref(ne), C.c_int(cap),
                                                          _p(clos), C.byref(nc)))

@@ -792,17 +792,29 @@ int cgmr_graph_message_for(cgmr_graph* g, int peer, int cap_edges, void* edges44
   if (!g || peer < 0 || peer >= g->n_robots || cap_edges < 0 || cap_closures < 0 || !n_edges_out || !n_closures_out)
     return CGMR_E_INVALID;
   const int R = g->n_robots, cap = g->cap;
-  const size_t wb = wire_bytes(R, cap);
-  std::vector<unsigned char> buf(wb);
-  int rc = cgmr_graph_pack_host(g, buf.data());
-  if (rc) return rc;
-  const int32_t* hdr = reinterpret_cast<const int32_t*>(buf.data());
-  const int n_e = hdr[2 + peer], n_c = hdr[2 + R + peer];
+  // one peer's part of the round message: the counts and the closure requests are host bookkeeping (what fill_header()
+  // writes), the edges are this peer's slice of the send buffer -- on the device when there is one: only that slice comes
+  // back (round 2 packed and downloaded the whole buffer, 400 KB for four robots, for every peer and tick)
+  const std::vector<int32_t>& cl = g->in_closures[peer];
+  const bool skip = (int)cl.size() > cap || g->out[peer].n > cap;          // beyond a reference node's buffers: not sent (fill_header)
+  if (skip && peer != g->robot) g->skipped_messages++;
+  const int n_e = skip ? 0 : g->out[peer].n, n_c = skip ? 0 : (int)cl.size();
   if (n_e > cap_edges || n_c > cap_closures) return gerr(g, CGMR_E_INVALID, "cgmr_graph_message_for: output capacity too small");
   if (n_e > 0 && !edges44_out) return CGMR_E_INVALID;
   if (n_c > 0 && !closure_ids_out) return CGMR_E_INVALID;
-  if (n_e > 0) memcpy(edges44_out, buf.data() + wire_edges_off(R) + (size_t)peer * cap * sizeof(WireEdge), (size_t)n_e * sizeof(WireEdge));
-  if (n_c > 0) memcpy(closure_ids_out, buf.data() + wire_clos_off(R, cap) + (size_t)peer * cap * 4, (size_t)n_c * 4);
+  if (n_e > 0) {
+    if (g->ctx) {
+      cgmr_ctx* ctx = g->ctx;
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      const WireEdge* src = reinterpret_cast<const WireEdge*>(g->d_send + wire_edges_off(R)) + (size_t)cap * peer;
+      HIP_TRY(ctx, hipMemcpyAsync(edges44_out, src, (size_t)n_e * sizeof(WireEdge), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+      if (!g->out[peer].host_valid) return gerr(g, CGMR_E_INVALID, "condensed graph not available on the host");
+      memcpy(edges44_out, g->out[peer].host.data(), (size_t)n_e * sizeof(WireEdge));
+    }
+  }
+  if (n_c > 0) memcpy(closure_ids_out, cl.data(), (size_t)n_c * 4);
   *n_edges_out = n_e;
   *n_closures_out = n_c;
   return (n_e > 0 || !g->in_closures[peer].empty()) ? 1 : 0;
