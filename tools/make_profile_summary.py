@@ -1,20 +1,25 @@
 """Turn gpurun_out/prof_round (tools/profile_round.sh) into the committed files under profiles/ for round NN."""
 import csv, glob, json, os, sys, collections
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+rnd = args[0] if args else "r01"
+pmc_only = "--pmc-only" in sys.argv      # on the GPU box, between the counter passes and the profiled bench run: bench.py then
+                                         # reads counters that belong to the sources it runs (tools/profile_round.sh)
 O = "gpurun_out/prof_round"
 P = "profiles"
-# bench line
-line = [l for l in open(f"{O}/bench.log") if l.startswith('{"metric"')][-1]
-bench = json.loads(line)
-open(f"{P}/{rnd}_bench_line.json", "w").write(line)
-# kernel stats (shortened names)
-rows = list(csv.DictReader(open(f"{O}/bench_kernel_stats.csv")))
-with open(f"{P}/{rnd}_bench_kernel_stats.csv", "w") as f:
-    f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
-    for r in rows:
-        name = r["Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
-        if len(name) > 60: name = name[:57] + "..."
-        f.write(f'{name},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.1f},{float(r["Percentage"]):.3f},{r["MinNs"]},{r["MaxNs"]}\n')
+bench = None
+if not pmc_only:
+    # bench line
+    line = [l for l in open(f"{O}/bench.log") if l.startswith('{"metric"')][-1]
+    bench = json.loads(line)
+    open(f"{P}/{rnd}_bench_line.json", "w").write(line)
+    # kernel stats (shortened names)
+    rows = list(csv.DictReader(open(f"{O}/bench_kernel_stats.csv")))
+    with open(f"{P}/{rnd}_bench_kernel_stats.csv", "w") as f:
+        f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
+        for r in rows:
+            name = r["Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
+            if len(name) > 60: name = name[:57] + "..."
+            f.write(f'{name},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.1f},{float(r["Percentage"]):.3f},{r["MinNs"]},{r["MaxNs"]}\n')
 # PMC summary: avg per launch per (kernel, counter)
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
 for path in glob.glob(f"{O}/*/*/*counter_collection.csv"):
@@ -62,5 +67,6 @@ sys.path.insert(0, os.getcwd())
 import bench as bench_py
 traffic["kernel_sources_sha16"] = bench_py.kernel_sources_sha16()              # bench.py flags the counters as stale when the sources change
 json.dump(traffic, open(f"{P}/{rnd}_pmc_traffic.json", "w"), indent=1)
-print(json.dumps(traffic, indent=1))
-print({k: bench[k] for k in ("value", "ms_per_step")}, bench["roofline"], bench["matcher"]["value"])
+if bench is not None:
+    print(json.dumps(traffic, indent=1))
+    print({k: bench[k] for k in ("value", "ms_per_step")}, bench["roofline"], bench["matcher"]["value"])

@@ -1,13 +1,14 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   kernel-trace + stats of bench.py, PMC passes (each its own run, kernel-trace only) for the GN and matcher kernels.
+# Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root; ROUND=rNN names the files):
+#   PMC passes first (each its own run, kernel-trace only) for the GN and matcher kernels, condensed on the box into
+#   profiles/rNN_pmc_*.json so that the profiled bench run that follows reads counters of the sources it runs; then
+#   kernel-trace + stats of bench.py.  tools/make_profile_summary.py rNN turns the merged gpurun_out/prof_round into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+RND=${ROUND:-r03}
 O=$R/gpurun_out/prof_round
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/bench --output-format csv -- python $R/bench.py > $O/bench.log 2>&1
-grep "^{\"metric\"" $O/bench.log | tail -1 > $O/bench_line.json
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/gn_$n --output-format csv -- python $R/tools/gn_profile_run.py > $O/gn_$n.log 2>&1
@@ -26,6 +27,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 [ -f cg_mrslam_amd/libcgmr_t.so ] && CGMR_MATCH_SPLIT=1 CGMR_LIB=cg_mrslam_amd/libcgmr_t.so timeout 120 python tools/gpu_mphase.py $O/match_phases.json > $O/match_phases.log 2>&1
+python tools/make_profile_summary.py $RND --pmc-only > $O/pmc_only.log 2>&1
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/bench --output-format csv -- python $R/bench.py > $O/bench.log 2>&1
+grep "^{\"metric\"" $O/bench.log | tail -1 > $O/bench_line.json
+cd $R
 python tools/pmc_summarise.py $(find $O -name "*counter_collection.csv") > $O/pmc_summary.txt
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
-cat $O/pmc_summary.txt | head -60
+head -40 $O/pmc_summary.txt
