@@ -11,6 +11,8 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <sched.h>
+#include <pthread.h>
 #include <thread>
 #include <unistd.h>
 
@@ -35,6 +37,7 @@ class HelperPool {
   };
   explicit HelperPool(int nhelpers) : owner_(getpid()) {
     for (int i = 0; i < nhelpers; i++) threads_.emplace_back([this] { loop(); });
+    pin_near_caller();
   }
   ~HelperPool() {
     if (getpid() != owner_) {                      // a forked child inherits the object but not the threads
@@ -63,6 +66,81 @@ class HelperPool {
   }
 
  private:
+  // The helpers work on the caller's arrays (adjacency, queue slices, the permutation) a few hundred microseconds at a time:
+  // on a two-socket / many-CCX host a helper that wakes up far from the caller pays for every line twice.  Each helper is
+  // pinned to its own core among those that share the last-level cache with the CPU the pool is created from (read from
+  // sysfs; nothing happens when that fails, when CGMR_HOST_PIN=0, or when the process's affinity mask excludes the cores).
+  void pin_near_caller() {
+    static const bool off = getenv("CGMR_HOST_PIN") && atoi(getenv("CGMR_HOST_PIN")) == 0;
+    if (off || threads_.empty() || getpid() != owner_) return;
+    const int me = sched_getcpu();
+    if (me < 0) return;
+    pinned_for_cpu_ = me;
+    auto read_list = [](const std::string& path, std::vector<int>& out) {
+      FILE* f = fopen(path.c_str(), "r");
+      if (!f) return false;
+      char buf[4096];
+      const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+      fclose(f);
+      if (!ok) return false;
+      for (char* q = buf; *q;) {                                  // "0-7,128-135"
+        char* end;
+        long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        if (*end == '-') { q = end + 1; b = strtol(q, &end, 10); }
+        for (long c = a; c <= b && c < 4096; c++) out.push_back((int)c);
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',') break;
+      }
+      return !out.empty();
+    };
+    const std::string base = "/sys/devices/system/cpu/cpu";
+    std::vector<int> l3;
+    if (!read_list(base + std::to_string(me) + "/cache/index3/shared_cpu_list", l3)) return;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    // one CPU per physical core (the first hardware thread listed for it), the caller's own core left to the caller
+    std::vector<int> sib_me;
+    read_list(base + std::to_string(me) + "/topology/thread_siblings_list", sib_me);
+    std::vector<int> picks;
+    std::vector<uint8_t> taken(4096, 0);
+    for (int c : sib_me) taken[c] = 1;
+    for (int c : l3) {
+      if (taken[c] || !CPU_ISSET(c, &allowed)) continue;
+      std::vector<int> sib;
+      if (!read_list(base + std::to_string(c) + "/topology/thread_siblings_list", sib)) sib.assign(1, c);
+      for (int q : sib) taken[q] = 1;
+      picks.push_back(c);
+    }
+    if ((int)picks.size() < (int)threads_.size()) return;         // fewer cores behind this cache than helpers: leave the scheduler alone
+    group_.assign(4096, 0);
+    for (int c : l3) group_[c] = 1;                               // 1: shares the cache, 2: a helper (or its sibling) sits there
+    for (size_t i = 0; i < threads_.size(); i++) {
+      cpu_set_t one;
+      CPU_ZERO(&one);
+      CPU_SET(picks[i], &one);
+      if (pthread_setaffinity_np(threads_[i].native_handle(), sizeof one, &one) == 0) {
+        std::vector<int> sib;
+        if (!read_list(base + std::to_string(picks[i]) + "/topology/thread_siblings_list", sib)) sib.assign(1, picks[i]);
+        for (int q : sib) group_[q] = 2;
+      }
+    }
+  }
+
+ public:
+  // called at the start of an analysis: the helpers follow the caller when the scheduler has moved it to another
+  // last-level cache (or onto a helper's core) since they were pinned
+  void follow_caller() {
+    const int me = sched_getcpu();
+    if (me < 0 || me == pinned_for_cpu_ || me >= 4096) return;
+    if (!group_.empty() && group_[me] == 1) { pinned_for_cpu_ = me; return; }       // same cache, a free core: nothing to do
+    std::unique_lock<std::mutex> lk(pin_mu_, std::try_to_lock);
+    if (lk.owns_lock()) pin_near_caller();
+  }
+
+ private:
   void loop() {
     for (;;) {
       Job* job = nullptr;
@@ -85,6 +163,9 @@ class HelperPool {
     }
   }
   std::vector<std::thread> threads_;
+  std::vector<uint8_t> group_;
+  std::mutex pin_mu_;
+  int pinned_for_cpu_ = -1;
   std::vector<Job*> queue_;
   std::mutex mu_;
   std::condition_variable cv_;
@@ -580,6 +661,7 @@ bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const 
 int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev) {
   double t0 = now_s();
   static const bool trace = getenv("CGMR_SYM_TRACE") != nullptr;
+  if (host_threads() > 1) pool().follow_caller();
   double tc = t0;
   auto CK = [&](const char* what) { if (trace) { double t = now_s(); fprintf(stderr, "  sym %-28s %7.1f us\n", what, 1e6 * (t - tc)); tc = t; } };
   S = Symbolic();
