@@ -163,7 +163,6 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_pan = N.add<double>((size_t)S.pan_doubles + 2);
   size_t o_chi = N.add<double>((size_t)iters + 2);
   size_t o_status = N.add<int>(4);
-  size_t o_done = N.add<unsigned int>(S.fronts.size() + 4);
   size_t o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
   size_t total = N.off + 256;
   int rc = arena_reserve(ctx, ctx->gn_arena, total);
@@ -290,7 +289,6 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.pan_doubles = S.pan_doubles;
   D.chi2 = (double*)(d + o_chi);
   D.status = (int*)(d + o_status);
-  D.done = (unsigned int*)(d + o_done);
   // the upper levels of the tree are solved backwards in one chained launch: as many levels as fit the workgroups that
   // are certainly resident together (the waits inside the launch cannot deadlock then); CGMR_BWD_CHAIN=0: one launch per level
   static const int chain_env = getenv("CGMR_BWD_CHAIN") ? atoi(getenv("CGMR_BWD_CHAIN")) : -1;
@@ -310,7 +308,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
          o_y = N.add<double>((size_t)3 * S.nf), o_x = N.add<double>((size_t)3 * S.nf), o_u = N.add<double>((size_t)3 * S.rows.size() + 3),
          o_L = N.add<double>((size_t)S.L_doubles + 1), o_U = N.add<double>((size_t)S.U_doubles + 1),
          o_pan = N.add<double>((size_t)S.pan_doubles + 2), o_chi = N.add<double>(8),
-         o_status = N.add<int>(4), o_done = N.add<unsigned int>(S.fronts.size() + 4), o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
+         o_status = N.add<int>(4), o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
   const size_t per = (N.off + 255) & ~size_t(255);
   int rc = arena_reserve(ctx, ctx->rep_arena, per * (size_t)std::max(n, 1) + 256);
   if (rc) return rc;
@@ -320,7 +318,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
     GnDevice& D = out[i];
     D.term = (double*)(d + o_term); D.Ablk = (double*)(d + o_A); D.bvec = (double*)(d + o_b); D.yvec = (double*)(d + o_y);
     D.xvec = (double*)(d + o_x); D.uvec = (double*)(d + o_u); D.Lbuf = (double*)(d + o_L); D.Ubuf = (double*)(d + o_U); D.Pan = (double*)(d + o_pan);
-    D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.done = (unsigned int*)(d + o_done); D.cmask = (uint8_t*)(d + o_cmask);
+    D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.cmask = (uint8_t*)(d + o_cmask);
   }
   return 0;
 }

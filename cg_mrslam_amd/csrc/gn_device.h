@@ -29,7 +29,6 @@ struct GnDevice {
   int64_t pan_doubles = 0;
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
-  unsigned int* done = nullptr;          // per front: its columns of x are final (the chained launch of the backward solve), zeroed by k_assemble
   int bwd_chain_level = 0;               // GN levels >= this one are solved backwards in one chained launch (k_solve_bwd<.., true>)
   // top block (k_top_block): the last fronts of the root's chain, handled by one workgroup in LDS
   int top_nfronts = 0, top_c0 = 0, top_ncols = 0, top_nchild = 0, top_nblk = 0;

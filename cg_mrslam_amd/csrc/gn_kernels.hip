@@ -188,10 +188,9 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
                                                   const double* __restrict__ term, double* __restrict__ Ablk,
                                                   double* __restrict__ Pan,
                                                   double* __restrict__ bvec, double* __restrict__ chi_out,
-                                                  const int* __restrict__ status, unsigned int* __restrict__ done, int nfronts,
+                                                  const int* __restrict__ status, int nfronts,
                                                   double* __restrict__ xvec) {
   if (blockIdx.x == gridDim.x - 1) {
-    for (int f = threadIdx.x; f < nfronts; f += 256) done[f] = 0u;                   // flags of the chained backward solve
     block_chi2_sum((nE + 255) / 256, term + (size_t)33 * nE, chi_out + status[1]);   // chi2 before iteration status[1]
     return;
   }
@@ -750,7 +749,7 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 template <int WW, bool CHAIN>
 __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
-                                                   const double* __restrict__ yvec, double* xvec, unsigned int* done,
+                                                   const double* __restrict__ yvec, double* xvec,
                                                    int* status) {
   CGMR_FRONT_CONSTS(WW);
   constexpr int HP = W / 2;            // column pairs per row
@@ -946,7 +945,7 @@ void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
 void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
   hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256 + 1), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.done, D.nfronts, D.xvec);
+                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.nfronts, D.xvec);
 }
 
 // one-time kernel attributes (dynamic LDS above 64 KB): once per HIP device of the process (the attribute belongs to
@@ -985,7 +984,7 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   if (nfr <= 0) return;
   hipLaunchKernelGGL((k_solve_bwd<kFrontW, false>), dim3(nfr), dim3(256), bwd_smem_bytes(kFrontW, false), st, D.fronts_lv, D.h_level_ptr[l], D.rows,
-                     D.Lbuf, D.yvec, D.xvec, D.done, D.status);
+                     D.Lbuf, D.yvec, D.xvec, D.status);
 }
 
 // Workgroups of the chained backward solve that are certainly resident together: the waits inside that launch must never
@@ -1014,7 +1013,7 @@ void launch_bwd_chain(hipStream_t st, const GnDevice& D) {
   const int first = D.h_level_ptr[D.bwd_chain_level], last = D.h_level_ptr[D.nlevels];
   if (last <= first) return;
   hipLaunchKernelGGL((k_solve_bwd<kFrontW, true>), dim3(last - first), dim3(256), bwd_smem_bytes(kFrontW, true), st, D.fronts_lv, last - 1, D.rows,
-                     D.Lbuf, D.yvec, D.xvec, D.done, D.status);
+                     D.Lbuf, D.yvec, D.xvec, D.status);
 }
 
 void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c) {
