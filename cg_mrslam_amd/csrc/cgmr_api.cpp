@@ -286,6 +286,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.Lbuf = (double*)(d + o_L);
   D.Ubuf = (double*)(d + o_U);
   D.Pan = (double*)(d + o_pan);
+  D.pan_clean = false;
   D.pan_doubles = S.pan_doubles;
   D.chi2 = (double*)(d + o_chi);
   D.status = (int*)(d + o_status);
@@ -317,7 +318,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
     char* d = ctx->rep_arena.ptr + per * (size_t)i;
     GnDevice& D = out[i];
     D.term = (double*)(d + o_term); D.Ablk = (double*)(d + o_A); D.bvec = (double*)(d + o_b); D.yvec = (double*)(d + o_y);
-    D.xvec = (double*)(d + o_x); D.uvec = (double*)(d + o_u); D.Lbuf = (double*)(d + o_L); D.Ubuf = (double*)(d + o_U); D.Pan = (double*)(d + o_pan);
+    D.xvec = (double*)(d + o_x); D.uvec = (double*)(d + o_u); D.Lbuf = (double*)(d + o_L); D.Ubuf = (double*)(d + o_U); D.Pan = (double*)(d + o_pan); D.pan_clean = false;
     D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.cmask = (uint8_t*)(d + o_cmask);
   }
   return 0;
@@ -462,7 +463,9 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
   // the assembled panels start from zero: H blocks and b (k_assemble), then the children's contributions level by level
   // (zeroing them for the next pass on a side stream underneath this pass's backward solve was measured slower: 5.79
   // instead of 5.47 ms per optimize(10) -- the 36 MB of writes slow the chained solve's hops more than the 8 us they hide)
-  if (D.pan_doubles > 0) (void)hipMemsetAsync(D.Pan, 0, sizeof(double) * (size_t)D.pan_doubles, st);
+  // ... but the top-block launch, one workgroup on an idle chip, clears them for the next pass with its other workgroups
+  if (D.pan_doubles > 0 && !D.pan_clean) (void)hipMemsetAsync(D.Pan, 0, sizeof(double) * (size_t)D.pan_doubles, st);
+  D.pan_clean = false;
   T.run(1, 1, [&] { launch_assemble(st, D); });                // + the chi2 sum of this iteration (slot = iterations done)
   static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;
   if (trace)
@@ -491,7 +494,11 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
     if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
   }
   // the top of the tree in one launch: assembly, factorisation, forward and backward solve of the block's columns
-  if (D.top_nfronts > 0) T.run(5, 1, [&] { launch_top_block(st, D, /*store_l=*/write_l11c, write_l11c); });
+  static const bool clear_in_top = !(getenv("CGMR_CLEAR_IN_TOP") && atoi(getenv("CGMR_CLEAR_IN_TOP")) == 0);
+  if (D.top_nfronts > 0) {
+    T.run(5, 1, [&] { launch_top_block(st, D, /*store_l=*/write_l11c, write_l11c, clear_in_top); });
+    D.pan_clean = clear_in_top && D.pan_doubles > 0;
+  }
   if (!solve_and_update) return;
   // (the forward solve L y = b rides through k_front_factor as an extra row of every front)
   if (D.bwd_chain_level < D.nlevels) T.run(6, 1, [&] { launch_bwd_chain(st, D); });

@@ -27,6 +27,7 @@ struct GnDevice {
   double *Lbuf = nullptr, *Ubuf = nullptr;
   double* Pan = nullptr;                 // assembled panels of all fronts (gn_symbolic.h: FrontDesc::pan_off), zeroed before every assembly
   int64_t pan_doubles = 0;
+  bool pan_clean = false;                // the panels are all zero (the last pass's top-block launch cleared them behind itself)
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
   int bwd_chain_level = 0;               // GN levels >= this one are solved backwards in one chained launch (k_solve_bwd<.., true>)
@@ -58,7 +59,7 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_chain(hipStream_t st, const GnDevice& D);
 int bwd_chain_capacity();
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);
-void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c);
+void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels);
 // marginals_kernels.hip
 void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* d_qcol, int m, double* Y, double* Uv,
                       double* part, double* G, double* cov, int chunk, int nchunk);

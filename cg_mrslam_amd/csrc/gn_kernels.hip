@@ -628,7 +628,17 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
                                                     const double* __restrict__ Ubuf, const double* __restrict__ uvec,
                                                     double* __restrict__ Lbuf, double* __restrict__ yvec,
                                                     double* __restrict__ xvec, int* __restrict__ status, int store_l,
-                                                    int write_l11c) {
+                                                    int write_l11c, double* __restrict__ zero_ptr, long long zero_n) {
+  if (blockIdx.x > 0) {
+    // The top block is one workgroup; the chip is idle beside it.  The other workgroups of the launch clear the assembled
+    // panels for the NEXT pass (nobody reads them any more in this one): the 8 us memset in front of every k_assemble goes.
+    const long long n2 = zero_n / 2, per = (n2 + gridDim.x - 2) / (gridDim.x - 1);
+    const long long lo = per * (blockIdx.x - 1), hi = min(n2, lo + per);
+    double2* z = reinterpret_cast<double2*>(zero_ptr);
+    for (long long q = lo + threadIdx.x; q < hi; q += 256) z[q] = make_double2(0.0, 0.0);
+    if (blockIdx.x == 1 && threadIdx.x == 0 && (zero_n & 1)) zero_ptr[zero_n - 1] = 0.0;
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LD = kTopLD;
   const int n16 = (ncols + 15) / 16 * 16, M = n16 + 1, nbc = n16 / 16;
@@ -1016,12 +1026,14 @@ void launch_bwd_chain(hipStream_t st, const GnDevice& D) {
                      D.Lbuf, D.yvec, D.xvec, D.status);
 }
 
-void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c) {
+void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels) {
   gn_init_kernels();
   if (D.top_nfronts <= 0) return;
-  hipLaunchKernelGGL(k_top_block, dim3(1), dim3(256), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols, D.top_nfronts,
-                     D.top_fronts, D.top_nchild, D.top_children, D.top_nblk, D.top_blocks, D.fronts, D.rows, D.Ablk, D.bvec, D.Ubuf,
-                     D.uvec, D.Lbuf, D.yvec, D.xvec, D.status, store_l ? 1 : 0, write_l11c ? 1 : 0);
+  const bool zero = clear_panels && D.pan_doubles > 0;
+  hipLaunchKernelGGL(k_top_block, dim3(zero ? 1 + 240 : 1), dim3(256), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols,
+                     D.top_nfronts, D.top_fronts, D.top_nchild, D.top_children, D.top_nblk, D.top_blocks, D.fronts, D.rows, D.Ablk,
+                     D.bvec, D.Ubuf, D.uvec, D.Lbuf, D.yvec, D.xvec, D.status, store_l ? 1 : 0, write_l11c ? 1 : 0, D.Pan,
+                     (long long)D.pan_doubles);
 }
 
 void launch_update(hipStream_t st, const GnDevice& D, double* poses) {

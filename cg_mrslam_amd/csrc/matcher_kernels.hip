@@ -890,7 +890,6 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         // (the points come from the workgroup's HBM scratch: the next 64 are fetched while these are turned and packed)
         const double2* const qp2 = reinterpret_cast<const double2*>(qpts);
         double2 nxt = lane < nq ? qp2[lane] : make_double2(0., 0.);
-#pragma unroll 2
         for (int base = 0; base < nq; base += 64) {
           int q = base + lane;
           uint32_t packed = 0;
