@@ -75,7 +75,6 @@ class HelperPool {
     if (off || threads_.empty() || getpid() != owner_) return;
     const int me = sched_getcpu();
     if (me < 0) return;
-    pinned_for_cpu_ = me;
     auto read_list = [](const std::string& path, std::vector<int>& out) {
       FILE* f = fopen(path.c_str(), "r");
       if (!f) return false;
@@ -115,30 +114,41 @@ class HelperPool {
       picks.push_back(c);
     }
     if ((int)picks.size() < (int)threads_.size()) return;         // fewer cores behind this cache than helpers: leave the scheduler alone
-    group_.assign(4096, 0);
-    for (int c : l3) group_[c] = 1;                               // 1: shares the cache, 2: a helper (or its sibling) sits there
+    bool all = true;
     for (size_t i = 0; i < threads_.size(); i++) {
       cpu_set_t one;
       CPU_ZERO(&one);
       CPU_SET(picks[i], &one);
-      if (pthread_setaffinity_np(threads_[i].native_handle(), sizeof one, &one) == 0) {
-        std::vector<int> sib;
-        if (!read_list(base + std::to_string(picks[i]) + "/topology/thread_siblings_list", sib)) sib.assign(1, picks[i]);
-        for (int q : sib) group_[q] = 2;
-      }
+      all = all && pthread_setaffinity_np(threads_[i].native_handle(), sizeof one, &one) == 0;
     }
+    if (all) home_ = sib_me.empty() ? std::vector<int>(1, me) : sib_me;
   }
 
  public:
-  // called at the start of an analysis: the helpers follow the caller when the scheduler has moved it to another
-  // last-level cache (or onto a helper's core) since they were pinned
-  void follow_caller() {
-    const int me = sched_getcpu();
-    if (me < 0 || me == pinned_for_cpu_ || me >= 4096) return;
-    if (!group_.empty() && group_[me] == 1) { pinned_for_cpu_ = me; return; }       // same cache, a free core: nothing to do
-    std::unique_lock<std::mutex> lk(pin_mu_, std::try_to_lock);
-    if (lk.owns_lock()) pin_near_caller();
-  }
+  // For the duration of an analysis the calling thread is held on the core the helpers were placed around (its "home": the
+  // CPU the pool was created from, one core of that cache group that no helper uses, with its hardware-thread sibling).  A
+  // caller that blocks between solves (a stream synchronisation, a collective) is woken up wherever the scheduler likes;
+  // letting the seven helpers follow it across cache groups, or leaving it on a core where a pinned helper spins, made the
+  // analysis 2.4 or 7.6 ms from one process to the next.  The caller's affinity mask is restored when the scope ends.
+  class CallerAtHome {
+   public:
+    explicit CallerAtHome(HelperPool& p) {
+      if (p.home_.empty()) return;
+      if (sched_getaffinity(0, sizeof saved_, &saved_) != 0) return;
+      cpu_set_t home;
+      CPU_ZERO(&home);
+      bool any = false;
+      for (int c : p.home_) if (CPU_ISSET(c, &saved_)) { CPU_SET(c, &home); any = true; }
+      if (!any) return;                                          // (the caller may not run there: leave it alone)
+      active_ = sched_setaffinity(0, sizeof home, &home) == 0;
+    }
+    ~CallerAtHome() { if (active_) (void)sched_setaffinity(0, sizeof saved_, &saved_); }
+    CallerAtHome(const CallerAtHome&) = delete;
+    CallerAtHome& operator=(const CallerAtHome&) = delete;
+   private:
+    cpu_set_t saved_;
+    bool active_ = false;
+  };
 
  private:
   void loop() {
@@ -163,9 +173,7 @@ class HelperPool {
     }
   }
   std::vector<std::thread> threads_;
-  std::vector<uint8_t> group_;
-  std::mutex pin_mu_;
-  int pinned_for_cpu_ = -1;
+  std::vector<int> home_;                // the caller's core while it analyses (empty: the helpers are not pinned)
   std::vector<Job*> queue_;
   std::mutex mu_;
   std::condition_variable cv_;
@@ -661,7 +669,7 @@ bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const 
 int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev) {
   double t0 = now_s();
   static const bool trace = getenv("CGMR_SYM_TRACE") != nullptr;
-  if (host_threads() > 1) pool().follow_caller();
+  HelperPool::CallerAtHome at_home(pool());
   double tc = t0;
   auto CK = [&](const char* what) { if (trace) { double t = now_s(); fprintf(stderr, "  sym %-28s %7.1f us\n", what, 1e6 * (t - tc)); tc = t; } };
   S = Symbolic();
