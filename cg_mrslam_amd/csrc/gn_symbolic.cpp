@@ -73,7 +73,7 @@ class HelperPool {
   void pin_near_caller() {
     static const bool off = getenv("CGMR_HOST_PIN") && atoi(getenv("CGMR_HOST_PIN")) == 0;
     if (off || threads_.empty() || getpid() != owner_) return;
-    const int me = sched_getcpu();
+    int me = sched_getcpu();
     if (me < 0) return;
     auto read_list = [](const std::string& path, std::vector<int>& out) {
       FILE* f = fopen(path.c_str(), "r");
@@ -95,11 +95,34 @@ class HelperPool {
       return !out.empty();
     };
     const std::string base = "/sys/devices/system/cpu/cpu";
-    std::vector<int> l3;
-    if (!read_list(base + std::to_string(me) + "/cache/index3/shared_cpu_list", l3)) return;
     cpu_set_t allowed;
     CPU_ZERO(&allowed);
     if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    // Several ranks on one node (one process per GPU, LOCAL_RANK / LOCAL_WORLD_SIZE set by the launcher): the ranks' callers
+    // may well sit in the same cache group when their pools are created (they were forked from one parent), and two pools
+    // pinned to the same eight cores would share them for good.  Rank k of n takes the (k * groups / n)-th cache group of
+    // the machine instead of the one it happens to run in.
+    {
+      const char* lr = getenv("LOCAL_RANK");
+      const char* lw = getenv("LOCAL_WORLD_SIZE");
+      const int k = lr ? atoi(lr) : 0, n = lw ? atoi(lw) : 1;
+      if (lr && n > 1 && k >= 0 && k < n) {
+        std::vector<int> firsts;                                  // first allowed CPU of every cache group, in CPU order
+        std::vector<uint8_t> seen(4096, 0);
+        const long ncpu = std::min(4096L, sysconf(_SC_NPROCESSORS_CONF));
+        for (int c = 0; c < ncpu; c++) {
+          if (seen[c]) continue;
+          std::vector<int> grp;
+          if (!read_list(base + std::to_string(c) + "/cache/index3/shared_cpu_list", grp)) { seen[c] = 1; continue; }
+          int first = -1;
+          for (int q : grp) { seen[q] = 1; if (first < 0 && CPU_ISSET(q, &allowed)) first = q; }
+          if (first >= 0) firsts.push_back(first);
+        }
+        if ((int)firsts.size() >= n) me = firsts[(size_t)k * firsts.size() / n];
+      }
+    }
+    std::vector<int> l3;
+    if (!read_list(base + std::to_string(me) + "/cache/index3/shared_cpu_list", l3)) return;
     // one CPU per physical core (the first hardware thread listed for it), the caller's own core left to the caller
     std::vector<int> sib_me;
     read_list(base + std::to_string(me) + "/topology/thread_siblings_list", sib_me);
