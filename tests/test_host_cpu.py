@@ -220,6 +220,29 @@ def test_elimination_tree_valid_special_shapes():
     _assert_valid_elimination_tree(600, fixed, ef, et)
 
 
+def test_symbolic_analysis_leaves_the_callers_affinity_alone():
+    """The analysis holds the calling thread on its home core while it runs (the helper threads sit around it); the
+    affinity mask must be the caller's own again afterwards, whatever the analysis did, and also in a child process started
+    with the library's switches off."""
+    import subprocess, sys
+    from cg_mrslam_amd._lib import gn_symbolic_info
+    g = synth.make_pose_graph(3000, 9000, seed=5)
+    before = os.sched_getaffinity(0)
+    for _ in range(3):
+        gn_symbolic_info(3000, g["fixed"], g["edge_from"], g["edge_to"])
+        assert os.sched_getaffinity(0) == before
+    code = ("import os\nfrom cg_mrslam_amd import synth\nfrom cg_mrslam_amd._lib import gn_symbolic_info\n"
+            "g = synth.make_pose_graph(3000, 9000, seed=5)\nb = os.sched_getaffinity(0)\n"
+            "i = gn_symbolic_info(3000, g['fixed'], g['edge_from'], g['edge_to'])\nassert os.sched_getaffinity(0) == b\nprint('ok', i['levels'])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({"CGMR_HOST_THREADS": "8"}, {"CGMR_HOST_THREADS": "8", "CGMR_HOST_PIN": "0"}, {"CGMR_HOST_THREADS": "8", "LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr[-1500:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2]                      # same tree whatever the placement
+
+
 def test_symbolic_analysis_survives_fork():
     """The helper threads do not exist in a forked child: the analysis must fall back to the calling thread there
     instead of queueing work for them (gloo / multiprocessing workers fork after the parent has used the library)."""
