@@ -876,10 +876,21 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
     // batches of nsearch angles, the ones around the guess first (the visit order inside the keys stays the reference's): the
     // pruned search has a good score to prune with from the first batch on
+    // The workgroup's angles -- the batches bi = part, part + split, .. of nsearch angles, in that order -- are handed to
+    // its wavefronts one at a time through a counter: an angle with rows left for the second pass takes several times as
+    // long as a dead one, and with a fixed angle-to-wavefront map the others waited for the unlucky wavefront at the end.
     const int nbat = (nth + nsearch - 1) / nsearch;
-    for (int bi = part; bi < nbat; bi += P.split) {
+    const int my_batches = part < nbat ? (nbat - 1 - part) / P.split + 1 : 0;
+    if (tid == 0) S.misc[14] = 0;                                 // (the compaction counter of the grid phase: free now)
+    __syncthreads();
+    for (;;) {
+      int sq = 0;
+      if (lane == 0 && wave < nsearch) sq = atomicAdd(&S.misc[14], 1);
+      sq = __builtin_amdgcn_readfirstlane(sq);
+      if (wave >= nsearch || sq >= my_batches * nsearch) break;
+      const int bi = part + P.split * (sq / nsearch);
       const int tb = nsearch * ((bi & 1) ? (nbat - 1) / 2 + (bi + 1) / 2 : (nbat - 1) / 2 - bi / 2);
-      const int ti = (wave < nsearch) ? min(tb + wave, nth) : nth;
+      const int ti = min(tb + sq % nsearch, nth);
       int k = 0, k0p = 0, k1p = 0;
       MSTAT_T0();
       if (ti < nth) {
