@@ -176,7 +176,10 @@ void cgmr_matcher_config_close(cgmr_matcher_config* cfg, int n_beams, double ang
  *   out_xyt    [n_pairs * 3]   matched relative pose (mresvec[0]); zeros when not found
  *   out_score  [n_pairs]       score of that result
  *   out_found  [n_pairs]       the bool return value
- *   out_nresults (nullable) [n_pairs]  number of entries mresvec would have had
+ *   out_nresults (nullable) [n_pairs]  number of entries mresvec would have had (the reference only prints it,
+ *                              scan_matcher.cpp:155-157).  NULL -- the reference's call -- selects the pruned search:
+ *                              candidates that provably cannot be mresvec[0] are dropped early, xyt / score / found
+ *                              are the exhaustive search's bit for bit; with a pointer every candidate is evaluated.
  * Host-pointer variant copies in and out; the _dev variant takes device pointers for every array.   */
 int cgmr_match_close_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, const float* ranges_ref,
                            const float* ranges_qry, const double* guess_xyt, double max_score, double* out_xyt,
