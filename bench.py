@@ -129,7 +129,7 @@ def maybe_spawn(args):
     port = free_port()
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -254,7 +254,7 @@ def matcher_leg(ctx, dev, args, with_cpu):
     gather_rate = nx * byte_adds / ksec_x                  # algorithmic bytes gathered from the LDS-resident grid / s (exhaustive run)
     # HBM per pair: 8.7 KB of ranges / guess / results + the rasteriser's finished lines, which go out to the workgroup's scratch
     # and come back (64 B per 8x8 tile each way, ~720 tiles): ~100 KB; the committed PMC pass (2 x FETCH_SIZE + WRITE_SIZE) if present
-    hbm_pp = (pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096)) if pmc_m else 8.7e3 + 2 * 64 * 720
+    hbm_pp = (pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096)) if pmc_m else 273e3
     golden = None
     gpath = os.path.join(ROOT, "tests", "golden", "match_close4096.npz")
     if os.path.exists(gpath) and base == 4096:
@@ -289,8 +289,8 @@ def matcher_leg(ctx, dev, args, with_cpu):
                                 "(bytes_fetched_per_useful_byte), the 2-byte directory loads cost a 4-byte pass each and "
                                 "lds_bank_conflict_frac of the LDS-array cycles are bank conflicts (SQ_LDS_BANK_CONFLICT / "
                                 "SQ_LDS_IDX_ACTIVE of the committed PMC pass); valu_issue = the same adds as packed-byte VALU "
-                                "instructions (256 per wave instruction) against one per SIMD and clock; HBM carries ~100 KB per pair "
-                                "(8.7 KB of inputs / results, the rest the rasteriser's lines through the scratch pool) and is not the roof (DESIGN.md 3); pruned_equivalent = the candidates of the exhaustive search per second of the pruned one (not bytes that move)"}}
+                                "instructions (256 per wave instruction) against one per SIMD and clock; HBM carries ~270 KB per pair "
+                                "(8.7 KB of inputs / results, the rest per-workgroup scratch: query points, the rasteriser's lines) and is not the roof (DESIGN.md 3); pruned_equivalent = the candidates of the exhaustive search per second of the pruned one (not bytes that move)"}}
     if with_cpu:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O

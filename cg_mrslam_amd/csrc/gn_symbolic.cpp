@@ -104,7 +104,7 @@ class HelperPool {
     // the machine instead of the one it happens to run in.
     {
       const char* lr = getenv("LOCAL_RANK");
-      const char* lw = getenv("LOCAL_WORLD_SIZE");
+      const char* lw = getenv("LOCAL_WORLD_SIZE") ? getenv("LOCAL_WORLD_SIZE") : getenv("WORLD_SIZE");   // (one node)
       const int k = lr ? atoi(lr) : 0, n = lw ? atoi(lw) : 1;
       if (lr && n > 1 && k >= 0 && k < n) {
         std::vector<int> firsts;                                  // first allowed CPU of every cache group, in CPU order
