@@ -22,7 +22,14 @@ if not pmc_only:
             f.write(f'{name},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.1f},{float(r["Percentage"]):.3f},{r["MinNs"]},{r["MaxNs"]}\n')
 # PMC summary: avg per launch per (kernel, counter)
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
-for path in glob.glob(f"{O}/*/*/*counter_collection.csv"):
+def newest_per_pass(pattern):
+    """One counter file per pass directory: the newest (gpurun merges a session's files into what earlier sessions left)."""
+    best = {}
+    for path in glob.glob(pattern):
+        key = path.split(os.sep)[-3]
+        if key not in best or os.path.getmtime(path) > os.path.getmtime(best[key]): best[key] = path
+    return sorted(best.values())
+for path in newest_per_pass(f"{O}/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
         if "rocclr" in k or "at::" in k: continue
@@ -52,7 +59,7 @@ for k in ("k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_a
         if os.path.exists(ph): traffic[k]["phase_cycles_per_pair"] = json.load(open(ph))
 # FETCH_SIZE / WRITE_SIZE calibration (tools/ubench/fetch_calib_ubench.hip: every kernel moves a known byte count once)
 calib = {}
-for path in glob.glob(f"{O}/calib_*/*/*counter_collection.csv"):
+for path in newest_per_pass(f"{O}/calib_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0]
         if k.startswith("k_read") or k.startswith("k_write"):
