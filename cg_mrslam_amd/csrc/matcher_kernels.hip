@@ -13,10 +13,13 @@
 // (1.44 MB) does not fit the 160 KB LDS, but only cells within the kernel radius of a reference point
 // differ from the fill value, so the grid is held *sparsely*: a directory of 8x8-cell tiles (uint16 per
 // tile, 45 KB for 150x150 tiles) plus a pool of 64-byte tiles in LDS (overflow tiles spill to a per-
-// workgroup HBM pool, same format).  Stamping uses a compare-and-swap byte-min on 32-bit words; the
-// search assigns one wavefront per search angle and one lane per (x,y) offset, gathers bytes through the
-// directory, and keeps the per-bin minimum with a 64-bit LDS atomic-min on (score bits, visit order),
-// which reproduces addToPrunedMap's "first seen wins" exactly.  All arithmetic that decides a cell index
+// workgroup HBM pool, same format).  The grid is rasterised by an exact distance transform over the resident tiles
+// when the kernel table allows it (a non-decreasing function of the squared cell distance), else by compare-and-swap
+// byte-min stamps on 32-bit words (build_grid).  The search assigns one wavefront per search angle and lanes to rows
+// of (x,y) offsets, gathers bytes through the directory, and keeps the per-bin minimum with a 64-bit LDS atomic-min on
+// (score bits, visit order), which reproduces addToPrunedMap's "first seen wins" exactly; a caller that only wants
+// the best result gets the pruned variant (partial sums over a quarter of the points as lower bounds: rows of the
+// window that cannot win are dropped before the other points are added).  All arithmetic that decides a cell index
 // is done in the reference's types (double rotation without FMA contraction, float world2grid with
 // round-to-nearest-even), so results are bit-identical to the CPU restatement.
 //
