@@ -542,7 +542,7 @@ int host_threads() {
 // take the vertices (nothing is modified then).
 bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const std::vector<int32_t>& ai,
                   std::vector<int32_t>& order, std::vector<uint8_t>& pstart, std::vector<std::pair<int, int>>& pos_ranges,
-                  Symbolic& S) {
+                  Symbolic& S, int n_new_edges, const int32_t* new_ef, const int32_t* new_et, const std::vector<int32_t>& hidx) {
   typedef Symbolic::NDNode Node;
   std::vector<Node> T = std::move(prev.nd_nodes);            // (the caller's previous analysis is discarded afterwards either way)
   const int root = prev.nd_root;
@@ -596,6 +596,18 @@ bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const 
     for (int x = target; x >= 0; x = T[x].parent) T[x].count++;
     if (T[target].a < 0 && T[target].b < 0 && (int)T[target].verts.size() > 2 * kPanelW &&
         std::find(grown.begin(), grown.end(), target) == grown.end()) grown.push_back(target);
+  }
+  // ---- the new edges may also join two vertices the tree already held (a loop closure between old poses, a condensed edge
+  // from a peer): their nodes must lie on one root path, or the two subtrees are not independent any more -- the parallel
+  // border computation below hands "independent" subtrees to different threads and produced a wrong structure for such a
+  // graph (found with the C5 rounds of two robots with a context each: Cholesky failure in round 40).  Then: full analysis.
+  static const bool check_new_edges = !(getenv("CGMR_SYM_EXTEND_CHECK") && atoi(getenv("CGMR_SYM_EXTEND_CHECK")) == 0);   // (0: the round-3 bug, for its test)
+  for (int k = 0; check_new_edges && k < n_new_edges; k++) {
+    const int a = hidx[new_ef[k]], b = hidx[new_et[k]];
+    if (a < 0 || b < 0 || a == b) continue;
+    const int x = where[a], y = where[b];
+    if (x < 0 || y < 0) return false;
+    if (x != y && !is_ancestor(x, y) && !is_ancestor(y, x)) return false;
   }
   // ---- leaves that outgrew two panels: dissect them again (their own vertices, the full adjacency)
   if (!grown.empty()) {
@@ -761,7 +773,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     static const bool extend_on = !(getenv("CGMR_SYM_EXTEND") && atoi(getenv("CGMR_SYM_EXTEND")) == 0);
     const int n_new = nf - prev->nf;
     if (same && extend_on && prev->nd_appended + n_new <= std::max(64, prev->nd_nf_full / 4))
-      extended = extend_order(*prev, nf, ap, ai, order, pstart, pos_ranges, S);
+      extended = prev->nE <= nE && extend_order(*prev, nf, ap, ai, order, pstart, pos_ranges, S, nE - prev->nE, ef + prev->nE, et + prev->nE, S.hidx);
   }
   if (!extended) {
     NDCtx C{ap, ai, order, pstart};

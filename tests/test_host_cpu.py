@@ -382,6 +382,43 @@ def test_incremental_ordering_of_a_growing_graph():
         assert info["factor_flops"] <= 1.6 * full["factor_flops"]
 
 
+def test_extension_is_refused_when_new_edges_join_old_vertices_of_different_subtrees():
+    """A grown graph may also get edges between vertices the cached ordering already holds (a loop closure between old
+    poses, a condensed edge from a peer).  If their dissection-tree nodes are not on one root path the subtrees stop being
+    independent: the ordering must then be rebuilt, not extended -- the parallel border computation relied on the
+    independence and produced a wrong structure with more than one host thread (round 3: Cholesky failure in round 40 of
+    the two-robot C5 rounds).  Checked here as: the analysis of such a sequence is the same with 1 and with 8 threads, and
+    the sequence with a far cross edge is not counted as extended while the one without it is."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np\nfrom cg_mrslam_amd import synth\nfrom cg_mrslam_amd._lib import gn_symbolic_info_grown\n"
+        "g = synth.make_pose_graph(3000, 9000, seed=21, strict=True)\n"
+        "ef, et = g['edge_from'], g['edge_to']\n"
+        "ko = np.argsort(np.maximum(ef, et), kind='stable'); ef, et = ef[ko], et[ko]\n"
+        "v0 = 2900; e0 = int(np.searchsorted(np.maximum(ef, et), v0, side='left'))\n"
+        "for cross in (0, 1):\n"
+        "    tail_f, tail_t = list(ef[e0:]), list(et[e0:])\n"
+        "    if cross:\n"
+        "        rng = np.random.default_rng(3)\n"
+        "        for _ in range(40):\n"
+        "            a, b = rng.integers(1, v0, size=2)\n"
+        "            tail_f.append(int(min(a, b))); tail_t.append(int(max(a, b)))\n"
+        "    f2 = np.concatenate([ef[:e0], np.array(tail_f, dtype=np.int32)]).astype(np.int32)\n"
+        "    t2 = np.concatenate([et[:e0], np.array(tail_t, dtype=np.int32)]).astype(np.int32)\n"
+        "    info, perm, next_ = gn_symbolic_info_grown(v0, e0, [3000], [len(f2)], f2, t2)\n"
+        "    print(cross, next_, info['fronts'], info['levels'], info['L_doubles'], info['U_doubles'], info['factor_flops'], int(perm.sum()), int((perm * np.arange(len(perm))).sum() % 1000003))\n")
+    outs = {}
+    for nt in ("1", "8"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root, CGMR_HOST_THREADS=nt),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs[nt] = r.stdout.strip().splitlines()
+    assert outs["1"] == outs["8"], (outs["1"], outs["8"])
+    plain, crossed = outs["8"][0].split(), outs["8"][1].split()
+    assert plain[1] == "1" and crossed[1] == "0"             # extended without the cross edges, rebuilt with them
+
+
 @pytest.mark.parametrize("shape", ["walk", "hub"])
 def test_children_schedule_has_one_writer_per_panel_copy_and_launch(shape):
     """The assembled-panel hand-off (gn_symbolic.cpp): every child adds into its parent's panel during one

@@ -165,6 +165,33 @@ def test_c5_shape_eight_robots_loopback_properties(ctx):
     assert all(r.g.counts()["vertices"] >= n_rounds * 50 for r in rounds)
 
 
+def test_c5_rounds_with_a_context_per_robot_as_one_rank_per_robot_has():
+    """The C5 rounds of two robots, each with a context (and so an analysis cache) of its own -- what one rank per robot
+    gives; the tests above share one context, where every solve sees another robot's graph and the cached ordering is
+    never extended.  Round 3's incremental ordering took graphs whose new edges joined two old vertices of different
+    dissection subtrees and handed a wrong structure to the factorisation: a Cholesky failure in robot 0's condensed graph
+    in round 40.  Sixty rounds here: every solve and every condensed graph succeeds, edges arrive."""
+    from cg_mrslam_amd import Context
+    from cg_mrslam_amd.mrslam import LoopbackExchange
+    nr, n_rounds = 2, 60
+    ctxs = [Context(0) for _ in range(nr)]
+    R = synth.make_multi_robot(nr, 5000, 20000, seed=777)
+    rounds = [RobotRounds(RobotGraph(ctxs[r], r, nr, cap_edges=128), RobotWorld(R, r, chunk=50)) for r in range(nr)]
+    ex = LoopbackExchange([r.g for r in rounds])
+    built = 0
+    for t in range(n_rounds):
+        for r in rounds:
+            r.grow()
+            assert r.optimize() == 0, (t, r.g.robot)
+            assert np.all(np.isfinite(r.last_chi2)) and r.last_chi2[-1] <= r.last_chi2[0] * (1 + 1e-9)
+        ex.finish_all()
+        built += sum(r.condense() for r in rounds)            # raises on a failed factorisation
+        ex.start_all()
+    ex.finish_all()
+    assert built > 40 and sum(r.g.counts()["received_edges"] for r in rounds) > 20
+    assert any(c.symbolic_cache_stats()["extended"] > 0 for c in ctxs)
+
+
 def test_condense_on_c5_sized_subgraph_with_100_requested_vertices(ctx, oracle):
     """Row a7 at C5 size: a 5000-vertex / 20000-edge sub-graph, ~100 requested vertices (K ~ 100), against the oracle;
     and the same through the flat-array entry point cgmr_condense."""
