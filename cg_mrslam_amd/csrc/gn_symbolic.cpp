@@ -782,8 +782,34 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     C.tmp.assign(nf, 0);
     C.recs.assign(2 * (size_t)nf + 4, NDCtx::Rec());
     C.max_par_depth = NT >= 8 ? 3 : (NT >= 4 ? 2 : (NT >= 2 ? 1 : 0));
+    // Hubs -- vertices with far more neighbours than a pose has, i.e. the gauge vertices of the condensed stars received from
+    // the peers (30-60 edges each) -- are kept out of the dissection and eliminated last, as one more piece of the root's
+    // separator: left inside, a star ties the subtrees its ends lie in together, level by level (robot 0 of the eight-robot
+    // C5 rounds: 38 tree levels and 95 MFLOP with them inside, 10-11 levels and 47 MFLOP with the own edges alone).  The
+    // sweeps never enter a vertex outside the range being ordered, so leaving the hubs out of the range is all it takes.
+    std::vector<int32_t> hubs;
+    {
+      static const int hub_min = getenv("CGMR_HUB_DEGREE") ? atoi(getenv("CGMR_HUB_DEGREE")) : 32;
+      const int thr = std::max(hub_min, (int)(4 * (ai.size() / (size_t)std::max(nf, 1))));
+      if (hub_min > 0)
+        for (int v = 0; v < nf; v++) if (ap[v + 1] - ap[v] > thr) hubs.push_back(v);
+      if ((int)hubs.size() > 3 * kPanelW) {                      // (a graph that is dense all over has no hubs)
+        std::sort(hubs.begin(), hubs.end(), [&](int a, int b) { const int da = ap[a + 1] - ap[a], db = ap[b + 1] - ap[b]; return da != db ? da > db : a < b; });
+        hubs.resize(3 * kPanelW);
+        std::sort(hubs.begin(), hubs.end());
+      }
+      if (!hubs.empty()) {
+        std::vector<uint8_t> is_hub(nf, 0);
+        for (int v : hubs) is_hub[v] = 1;
+        int k = 0;
+        for (int v = 0; v < nf; v++) if (!is_hub[v]) order[k++] = v;
+        for (int v : hubs) order[k++] = v;
+      }
+    }
+    const int n_nd = nf - (int)hubs.size();
     int root_rec = -1;
-    nd(C, 0, nf, 0, -1, &root_rec);
+    nd(C, 0, n_nd, 0, -1, &root_rec);
+    for (int p = n_nd; p < nf; p += kPanelW) pstart[p] = 1;
     pos_ranges.swap(C.subtree_ranges);
     // the tree with its vertices, for the next extension
     S.nd_nodes.clear();
@@ -802,6 +828,12 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       return id;
     };
     S.nd_root = build(root_rec, 0, -1);
+    if (!hubs.empty()) {
+      if (S.nd_root < 0) { S.nd_nodes.emplace_back(); S.nd_root = (int)S.nd_nodes.size() - 1; S.nd_nodes[S.nd_root].parent = -1; }
+      Symbolic::NDNode& Rn = S.nd_nodes[S.nd_root];
+      Rn.verts.insert(Rn.verts.end(), hubs.begin(), hubs.end());
+      Rn.count += (int)hubs.size();
+    }
     S.nd_nf_full = nf;
     S.nd_appended = 0;
   }

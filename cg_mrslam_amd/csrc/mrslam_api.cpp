@@ -288,6 +288,15 @@ int cgmr_graph_add_edges(cgmr_graph* g, int n, const int32_t* from_ids, const in
   return CGMR_OK;
 }
 
+// Debugging aid: the level-0 edge list (vertex indices) the solver sees: own edges first, then the received ones.
+int cgmr_graph_debug_edges(const cgmr_graph* g, int cap, int32_t* from_out, int32_t* to_out, int32_t* n_own_out) {
+  if (!g || cap < 0) return CGMR_E_INVALID;
+  const int n = (int)g->all_ef.size();
+  for (int k = 0; k < n && k < cap; k++) { from_out[k] = g->all_ef[k]; to_out[k] = g->all_et[k]; }
+  if (n_own_out) *n_own_out = (int32_t)g->ef.size();
+  return n;
+}
+
 int cgmr_graph_counts(const cgmr_graph* g, int32_t out[4]) {
   if (!g || !out) return CGMR_E_INVALID;
   out[0] = (int32_t)g->ids.size(); out[1] = (int32_t)g->ef.size(); out[2] = g->nB;
@@ -386,8 +395,12 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), nE = (int)g->all_ef.size(), cap = g->cap;
   const int nj = (int)jobs.size();
   if (nj == 0) return 0;
+  static const bool trace = getenv("CGMR_COND_TRACE") != nullptr;
+  const double tt0 = wall_s();
+  double t_guess = 0, t_mask = 0;
   int rc = prepare_structure(ctx, nV, nE, g->all_ef.data(), g->all_et.data(), 1);
   if (rc) return rc;
+  const double tt1 = wall_s();
   const Symbolic& S = ctx->sym;
   const int nstreams = std::min(nj, 8);
   rc = aux_streams(ctx, nstreams);
@@ -430,12 +443,16 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     // initial guess over my own edges, one Gauss-Newton iteration; the marginals are those of that iteration's Hessian
     std::fill(fixed.begin(), fixed.end(), 0);
     fixed[J.gauge] = 1;
+    const double tg0 = wall_s();
     work = g->h_poses;
     initial_guess_host(nV, work.data(), fixed.data(), nA, g->ef.data(), g->et.data(), g->h_meas.data());
+    t_guess += wall_s() - tg0;
     double* d_work = (double*)(g->d_work.ptr + 24 * (size_t)nV * i);
     HIP_TRY(ctx, hipMemcpyAsync(d_work, work.data(), 24 * (size_t)nV, hipMemcpyHostToDevice, sj));
+    const double tm0 = wall_s();
     rc = prepare_pass_on(ctx, D, sj, fixed.data(), nE, g->all_ef.data(), g->all_et.data(), nA, i, nj);
     if (rc) return rc;
+    t_mask += wall_s() - tm0;
     qcol.resize(nq);
     for (int k = 0; k < nq; k++) qcol[k] = ctx->vmask[J.q[k]] ? -1 : S.vperm[J.q[k]];
     int32_t* d_qc = (int32_t*)(d + o_qc);
@@ -468,8 +485,12 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       HIP_TRY(ctx, hipMemcpyAsync((*info_out)[i].data(), d + o_i64, 48 * jobs[i].q.size(), hipMemcpyDeviceToHost, st));
     }
   }
+  const double tt2 = wall_s();
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
+  if (trace)
+    fprintf(stderr, "[cond] %d jobs, nV %d nE %d: structure %.0f us, queueing %.0f us (initial guesses %.0f, masks %.0f), waiting %.0f us\n", nj, nV,
+            nE, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * (wall_s() - tt2));
   for (int i = 0; i < nj; i++)
     if (status[i] != 0) return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
   return 0;

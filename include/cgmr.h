@@ -374,6 +374,8 @@ int cgmr_graph_add_vertices(cgmr_graph* g, int n, const int32_t* ids, const doub
 int cgmr_graph_add_edges(cgmr_graph* g, int n, const int32_t* from_ids, const int32_t* to_ids, const double* meas_xyt,
                          const double* info_upper);
 /* out[0] = vertices, [1] = own edges, [2] = received edges currently in the graph, [3] = peers with out-closures */
+/* debugging aid: the level-0 edge list (vertex indices) the solver sees, own edges first; returns their number */
+int cgmr_graph_debug_edges(const cgmr_graph* g, int cap, int32_t* from_out, int32_t* to_out, int32_t* n_own_out);
 int cgmr_graph_counts(const cgmr_graph* g, int32_t out[4]);
 /* GraphSLAM::optimize(iters); chi2_out nullable [iters+1]; returns like cgmr_gn_optimize */
 int cgmr_graph_optimize(cgmr_graph* g, int iters, double* chi2_out);
