@@ -70,6 +70,11 @@ struct cgmr_graph {
   std::vector<std::vector<int32_t>> out_closures, in_closures;   // sorted unique ids
   std::vector<int32_t> all_ef, all_et;                           // A then B
   int nB = 0;
+  // the edge list of the last optimize(): the condensed graphs that follow use the own edges only, so the structure analysed
+  // for that solve serves them as long as no vertex or own edge has been added since -- whatever the exchange has done to
+  // the received edges in between (they are switched off in those passes)
+  std::vector<int32_t> solved_ef, solved_et;
+  int solved_nV = -1, solved_nA = -1;
   // host staging of received numeric data (host-only mode and getters): slot-indexed like the device staging
   std::vector<double> hs_meas, hs_info;
   // device
@@ -321,6 +326,8 @@ int cgmr_graph_optimize(cgmr_graph* g, int iters, double* chi2_out) {
   const double t0 = wall_s();
   int rc = gn_run(ctx, nV, (double*)g->d_poses.ptr, g->fixed.data(), nE, g->all_ef.data(), g->all_et.data(), Ed, iters, chi2_out);
   g->last_optimize_seconds = wall_s() - t0;
+  g->solved_ef = g->all_ef; g->solved_et = g->all_et;
+  g->solved_nV = nV; g->solved_nA = (int)g->ef.size();
   return rc;
 }
 
@@ -392,13 +399,19 @@ struct CondJob {
 int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::vector<std::vector<double>>* info_out) {
   cgmr_ctx* ctx = g->ctx;
   hipStream_t st = ctx->stream;
-  const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), nE = (int)g->all_ef.size(), cap = g->cap;
+  const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), cap = g->cap;
   const int nj = (int)jobs.size();
   if (nj == 0) return 0;
   static const bool trace = getenv("CGMR_COND_TRACE") != nullptr;
   const double tt0 = wall_s();
-  double t_guess = 0, t_mask = 0;
-  int rc = prepare_structure(ctx, nV, nE, g->all_ef.data(), g->all_et.data(), 1);
+  double t_guess = 0, t_mask = 0, t_up = 0, t_gn = 0, t_marg = 0;
+  // the edge list the structure is analysed for: the last solve's if nothing of mine has changed since (a hit in the
+  // analysis cache; own edges are only ever appended, so equal counts mean equal lists), else the current one
+  const bool reuse = g->solved_nV == nV && g->solved_nA == nA && (int)g->solved_ef.size() >= nA;
+  const std::vector<int32_t>& s_ef = reuse ? g->solved_ef : g->all_ef;
+  const std::vector<int32_t>& s_et = reuse ? g->solved_et : g->all_et;
+  const int nE = (int)s_ef.size();
+  int rc = prepare_structure(ctx, nV, nE, s_ef.data(), s_et.data(), 1);
   if (rc) return rc;
   const double tt1 = wall_s();
   const Symbolic& S = ctx->sym;
@@ -428,8 +441,19 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   Ed.meas_b = g->d_meas_b; Ed.info_b = g->d_info_b;
   Ed.nA = nA; Ed.n_active = nA;                                  // getMyEdges: the received edges are switched off
   std::vector<uint8_t> fixed(nV);
-  std::vector<double> work(3 * (size_t)nV);
   std::vector<int32_t> qcol;
+  // the spanning-tree initial guess of every job (its own gauge as the root: 0.3 ms of host work each) on the helper threads
+  std::vector<std::vector<double>> works(nj);
+  {
+    const double tg0 = wall_s();
+    host_run_tasks(nj, [&](int i) {
+      std::vector<uint8_t> fx(nV, 0);
+      fx[jobs[i].gauge] = 1;
+      works[i] = g->h_poses;
+      initial_guess_host(nV, works[i].data(), fx.data(), nA, g->ef.data(), g->et.data(), g->h_meas.data());
+    });
+    t_guess = wall_s() - tg0;
+  }
   WireEdge* send_edges = reinterpret_cast<WireEdge*>(g->d_send + wire_edges_off(g->n_robots));
   HIP_TRY(ctx, hipEventRecord(ctx->aux_fork, st));
   for (int k = 0; k < nstreams; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->aux_fork, 0));
@@ -443,14 +467,13 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     // initial guess over my own edges, one Gauss-Newton iteration; the marginals are those of that iteration's Hessian
     std::fill(fixed.begin(), fixed.end(), 0);
     fixed[J.gauge] = 1;
-    const double tg0 = wall_s();
-    work = g->h_poses;
-    initial_guess_host(nV, work.data(), fixed.data(), nA, g->ef.data(), g->et.data(), g->h_meas.data());
-    t_guess += wall_s() - tg0;
+    const std::vector<double>& work = works[i];
     double* d_work = (double*)(g->d_work.ptr + 24 * (size_t)nV * i);
+    const double tu0 = wall_s();
     HIP_TRY(ctx, hipMemcpyAsync(d_work, work.data(), 24 * (size_t)nV, hipMemcpyHostToDevice, sj));
+    t_up += wall_s() - tu0;
     const double tm0 = wall_s();
-    rc = prepare_pass_on(ctx, D, sj, fixed.data(), nE, g->all_ef.data(), g->all_et.data(), nA, i, nj);
+    rc = prepare_pass_on(ctx, D, sj, fixed.data(), nE, s_ef.data(), s_et.data(), nA, i, nj);
     if (rc) return rc;
     t_mask += wall_s() - tm0;
     qcol.resize(nq);
@@ -459,7 +482,10 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     int32_t* d_qv = (int32_t*)(d + o_qv);
     HIP_TRY(ctx, hipMemcpyAsync(d_qc, qcol.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, sj));
     HIP_TRY(ctx, hipMemcpyAsync(d_qv, J.q.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, sj));
+    const double tp0 = wall_s();
     gn_pass_on(ctx, D, sj, d_work, Ed, 0, false, true, /*write_l11c=*/true);
+    const double tp1 = wall_s();
+    t_gn += tp1 - tp0;
     const int m = ((4 * nq + 15) / 16) * 16;
     launch_marginals(sj, D, nq, d_qc, m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part), (double*)(d + o_G),
                      (double*)(d + o_cov), chunk, nchunk);
@@ -470,6 +496,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       launch_wire_write_edges(sj, nq, g->ids[J.gauge], d_qv, (const int32_t*)g->d_vids.ptr, est64, info64,
                               send_edges + (size_t)cap * J.peer);
     HIP_TRY(ctx, hipMemcpyAsync(d + o_st, D.status, 4, hipMemcpyDeviceToDevice, sj));
+    t_marg += wall_s() - tp1;
   }
   for (int k = 0; k < nstreams; k++) {
     HIP_TRY(ctx, hipEventRecord(ctx->aux_done[k], ctx->aux[k]));
@@ -489,8 +516,8 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
   if (trace)
-    fprintf(stderr, "[cond] %d jobs, nV %d nE %d: structure %.0f us, queueing %.0f us (initial guesses %.0f, masks %.0f), waiting %.0f us\n", nj, nV,
-            nE, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * (wall_s() - tt2));
+    fprintf(stderr, "[cond] %d jobs, nV %d nE %d: structure %.0f us, queueing %.0f us (initial guesses %.0f, masks %.0f, pose upload %.0f, GN pass %.0f, marginals + labels %.0f), waiting %.0f us\n", nj, nV,
+            nE, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * t_up, 1e6 * t_gn, 1e6 * t_marg, 1e6 * (wall_s() - tt2));
   for (int i = 0; i < nj; i++)
     if (status[i] != 0) return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
   return 0;
