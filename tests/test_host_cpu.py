@@ -382,6 +382,37 @@ def test_incremental_ordering_of_a_growing_graph():
         assert info["factor_flops"] <= 1.6 * full["factor_flops"]
 
 
+def test_star_centres_are_eliminated_last():
+    """The condensed graph a peer sends is a star: its gauge vertex gets 30-60 edges.  Such hubs stay out of the nested
+    dissection and are eliminated last (they would tie the subtrees their ends lie in together level by level): the tree of
+    a pose graph with six stars is about as tall as without them, and much taller when the rule is switched off."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np\nfrom cg_mrslam_amd import synth\nfrom cg_mrslam_amd._lib import gn_symbolic_info\n"
+        "g = synth.make_pose_graph(5000, 20000, seed=9, strict=True)\n"
+        "ef, et = list(g['edge_from']), list(g['edge_to'])\n"
+        "base = gn_symbolic_info(5000, g['fixed'], np.array(ef, np.int32), np.array(et, np.int32))\n"
+        "rng = np.random.default_rng(4)\n"
+        "hubs = []\n"
+        "for h in range(6):\n"
+        "    c = int(rng.integers(0, 5000)); hubs.append(c)\n"
+        "    for v in rng.choice(5000, size=50, replace=False):\n"
+        "        if int(v) != c: ef.append(min(c, int(v))); et.append(max(c, int(v)))\n"
+        "info, perm = gn_symbolic_info(5000, g['fixed'], np.array(ef, np.int32), np.array(et, np.int32), want_perm=True)\n"
+        "print(base['levels'], info['levels'], base['factor_flops'], info['factor_flops'], min(int(perm[c]) for c in hubs), len(perm))\n")
+    out = {}
+    for hub in ("32", "0"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root, CGMR_HUB_DEGREE=hub),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        out[hub] = [float(x) for x in r.stdout.split()]
+    base_levels, levels, base_flops, flops, first_hub_col, n = out["32"]
+    assert levels <= base_levels + 2 and flops <= 1.5 * base_flops
+    assert first_hub_col >= n - 64                                   # the hubs sit in the last columns
+    assert out["0"][1] >= levels + 5                                 # without the rule: a much taller tree
+
+
 def test_extension_is_refused_when_new_edges_join_old_vertices_of_different_subtrees():
     """A grown graph may also get edges between vertices the cached ordering already holds (a loop closure between old
     poses, a condensed edge from a peer).  If their dissection-tree nodes are not on one root path the subtrees stop being
