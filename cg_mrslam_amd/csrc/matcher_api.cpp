@@ -756,10 +756,28 @@ void apply_transf(const Se2& T, const std::vector<double>& pts, std::vector<doub
   }
 }
 
+// RawLaser::cartesian for one scan.  The beam directions depend on the laser only: the table of (cos, sin) -- libm, as the
+// reference computes them -- is kept per thread for the last laser seen (a reference set of 21 scans took 45k libm calls per
+// global matching, more host time than the search's four kernel launches).
 std::vector<double> cartesian_of(const cgmr_matcher_config* cfg, const float* ranges) {
-  std::vector<double> v(2 * (size_t)cfg->n_beams);
-  int n = cgmr_scan_cartesian(cfg->n_beams, ranges, cfg->angle_min, cfg->angle_inc, cfg->max_range, cfg->min_range, v.data());
-  v.resize(2 * (size_t)std::max(n, 0));
+  thread_local std::vector<double> tab;
+  thread_local double key[3] = {-1, 0, 0};
+  const int B = cfg->n_beams;
+  if (key[0] != (double)B || key[1] != cfg->angle_min || key[2] != cfg->angle_inc || (int)tab.size() != 2 * B) {
+    tab.resize(2 * (size_t)B);
+    for (int i = 0; i < B; i++) {
+      const double alpha = cfg->angle_min + i * cfg->angle_inc;       // (the expression of cgmr_scan_cartesian)
+      tab[2 * i] = std::cos(alpha); tab[2 * i + 1] = std::sin(alpha);
+    }
+    key[0] = (double)B; key[1] = cfg->angle_min; key[2] = cfg->angle_inc;
+  }
+  std::vector<double> v(2 * (size_t)B);
+  int n = 0;
+  for (int i = 0; i < B; i++) {
+    const double r = (double)ranges[i];
+    if (r < cfg->max_range && r > cfg->min_range) { v[2 * n] = tab[2 * i] * r; v[2 * n + 1] = tab[2 * i + 1] * r; n++; }
+  }
+  v.resize(2 * (size_t)n);
   return v;
 }
 
@@ -1057,18 +1075,30 @@ int cgmr_global_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
   const float region[6] = {-10.f, -5.f, -pi_f, 10.f, 5.f, pi_f};                   // scan_matcher.cpp:383-391
   std::vector<SearchJob> jobs(n_jobs);
   std::vector<int> ref_alias(n_jobs, 0);
+  static const bool gm_trace = getenv("CGMR_MATCH_TRACE") != nullptr;
+  const auto tg0 = std::chrono::steady_clock::now();
+  double us_ref = 0, us_cur = 0, us_sub = 0;
+  auto us_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
   for (int j = 0; j < n_jobs; j++) {
     std::vector<double> cur;
+    auto ta = std::chrono::steady_clock::now();
     const std::vector<double>& rj = reference_points(cfg, ref_sets, j, ref, ref_alias);
+    us_ref += us_since(ta); ta = std::chrono::steady_clock::now();
     points_from_vset(cfg, cur_sets + j, nullptr, cur);
+    us_cur += us_since(ta); ta = std::chrono::steady_clock::now();
     qry[j] = subsample_of(cur, 0.1);
+    us_sub += us_since(ta);
     jobs[j].ref = rj.data(); jobs[j].n_ref = (int)(rj.size() / 2);
     jobs[j].qry = qry[j].data(); jobs[j].n_qry = (int)(qry[j].size() / 2);
     jobs[j].regions = region; jobs[j].n_regions = 1;
   }
   std::vector<std::vector<cgmr_match_result>> res;
+  const auto th0 = std::chrono::steady_clock::now();
   int rc = hierarchical_batch_core(ctx, cfg, jobs, 0.025, max_score, 0.5, 0.5, 0.2, 4, res);
   if (rc) return rc;
+  if (gm_trace)
+    fprintf(stderr, "[global] %d jobs: reference points %.0f us, current points %.0f us, subsample %.0f us, hierarchy %.0f us, total %.0f us\n", n_jobs,
+            us_ref, us_cur, us_sub, us_since(th0), us_since(tg0));
   for (int j = 0; j < n_jobs; j++) {
     double* t = trel_out + 3 * (size_t)j;
     t[0] = t[1] = t[2] = 0;
