@@ -884,21 +884,46 @@ int cgmr_graph_message_from(cgmr_graph* g, int sender, int n_edges, const void* 
     return CGMR_OK;
   }
   const size_t wb = wire_bytes(R, cap);
-  std::vector<unsigned char> buf((size_t)R * wb, 0);
-  for (int s = 0; s < R; s++) {                                 // every block needs its sender id; only one carries data
-    int32_t* h = reinterpret_cast<int32_t*>(buf.data() + (size_t)s * wb);
-    h[0] = s; h[1] = R;
-  }
-  unsigned char* blk = buf.data() + (size_t)sender * wb;
-  int32_t* hdr = reinterpret_cast<int32_t*>(blk);
-  hdr[2 + g->robot] = n_edges;
-  hdr[2 + R + g->robot] = n_closures;
-  if (n_edges) memcpy(blk + wire_edges_off(R) + (size_t)g->robot * cap * sizeof(WireEdge), edges44, (size_t)n_edges * sizeof(WireEdge));
-  if (n_closures) memcpy(blk + wire_clos_off(R, cap) + (size_t)g->robot * cap * 4, closure_ids, (size_t)n_closures * 4);
   bool any_known = false;
   for (int k = 0; k < n_closures; k++) any_known = any_known || g->index.count(closure_ids[k]);
   std::vector<int32_t> acc(R, 0);
-  int rc = cgmr_graph_ingest_host(g, buf.data(), acc.data());
+  int rc;
+  if (g->ctx) {
+    // The receive buffer holds R wire buffers (1.7 MB for four robots at the reference's capacity); one message fills the
+    // header and two slices of one of them.  Only those travel: the headers of all blocks are cleared on the device (a
+    // block whose header does not carry its own index is ignored by k_wire_read), then the sender's header, its edges for me
+    // and its closure requests are copied in.  (Round 2 built and uploaded the whole 1.7 MB for every message.)
+    cgmr_ctx* ctx = g->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t hdr_bytes = 4 * (size_t)(2 + 2 * R);
+    HIP_TRY(ctx, hipMemset2DAsync(g->d_recv, wb, 0, hdr_bytes, (size_t)R, ctx->stream));
+    std::vector<int32_t> hdr(2 + 2 * (size_t)R, 0);
+    hdr[0] = sender; hdr[1] = R;
+    hdr[2 + g->robot] = n_edges;
+    hdr[2 + R + g->robot] = n_closures;
+    unsigned char* blk = g->d_recv + (size_t)sender * wb;
+    HIP_TRY(ctx, hipMemcpyAsync(blk, hdr.data(), hdr_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (n_edges)
+      HIP_TRY(ctx, hipMemcpyAsync(blk + wire_edges_off(R) + (size_t)g->robot * cap * sizeof(WireEdge), edges44, (size_t)n_edges * sizeof(WireEdge),
+                                  hipMemcpyHostToDevice, ctx->stream));
+    if (n_closures)
+      HIP_TRY(ctx, hipMemcpyAsync(blk + wire_clos_off(R, cap) + (size_t)g->robot * cap * 4, closure_ids, (size_t)n_closures * 4,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    rc = cgmr_graph_ingest(g, nullptr, acc.data());
+  } else {
+    std::vector<unsigned char> buf((size_t)R * wb, 0);
+    for (int s = 0; s < R; s++) {                               // every block needs its sender id; only one carries data
+      int32_t* h = reinterpret_cast<int32_t*>(buf.data() + (size_t)s * wb);
+      h[0] = s; h[1] = R;
+    }
+    unsigned char* blk = buf.data() + (size_t)sender * wb;
+    int32_t* hdr = reinterpret_cast<int32_t*>(blk);
+    hdr[2 + g->robot] = n_edges;
+    hdr[2 + R + g->robot] = n_closures;
+    if (n_edges) memcpy(blk + wire_edges_off(R) + (size_t)g->robot * cap * sizeof(WireEdge), edges44, (size_t)n_edges * sizeof(WireEdge));
+    if (n_closures) memcpy(blk + wire_clos_off(R, cap) + (size_t)g->robot * cap * 4, closure_ids, (size_t)n_closures * 4);
+    rc = cgmr_graph_ingest_host(g, buf.data(), acc.data());
+  }
   if (rc) return rc;
   if (n_accepted_out) *n_accepted_out = acc[sender];
   if (any_known && g->ctx) {
