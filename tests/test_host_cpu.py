@@ -382,6 +382,42 @@ def test_incremental_ordering_of_a_growing_graph():
         assert info["factor_flops"] <= 1.6 * full["factor_flops"]
 
 
+def test_points_of_a_scan_set_with_changing_lasers():
+    """transformPointsFromVSet on the host (no GPU): the beam directions come from a per-thread table keyed by the laser
+    (beam count, first angle, step); lasers alternating between calls must each get their own directions, equal to the
+    libm expression of ``cgmr_scan_cartesian`` point for point."""
+    import ctypes as C
+    import math
+    from cg_mrslam_amd._lib import load_library
+    from cg_mrslam_amd.matcher import MatcherConfig, ScanSet, _se2_inv, _se2_mul
+    lib = load_library()
+    rng = np.random.default_rng(8)
+    lasers = [(181, -1.2, 0.0133), (1081, -2.35619449, 0.00436332313), (181, -1.0, 0.0133), (361, -1.57, 0.0087)]
+    for rep in range(2):
+        for (B, a0, da) in lasers:
+            cfg = MatcherConfig()
+            cfg.n_beams, cfg.angle_min, cfg.angle_inc, cfg.max_range, cfg.min_range = B, a0, da, 20.0, 0.1
+            cfg.laser_pose[0], cfg.laser_pose[1], cfg.laser_pose[2] = 0.1, -0.05, 0.2
+            ranges = np.ascontiguousarray(rng.uniform(0.0, 25.0, size=(3, B)).astype(np.float32))
+            poses = np.ascontiguousarray(rng.uniform(-1, 1, size=(3, 3)))
+            s = ScanSet(3, C.c_void_p(ranges.ctypes.data), C.c_void_p(poses.ctypes.data), 1)
+            out = np.zeros((3 * B, 2))
+            n = lib.cgmr_transform_points_from_vset(C.byref(cfg), C.byref(s), C.c_void_p(out.ctypes.data), C.c_int(3 * B))
+            want = []
+            lp = np.array([0.1, -0.05, 0.2])
+            for k in range(3):
+                T = lp if k == 1 else _se2_mul(_se2_mul(_se2_inv(poses[1]), poses[k]), lp)
+                c, sn = math.cos(T[2]), math.sin(T[2])
+                for i in range(B):
+                    r = float(ranges[k, i])
+                    if r < 20.0 and r > 0.1:
+                        al = a0 + i * da
+                        x, y = math.cos(al) * r, math.sin(al) * r
+                        want.append((T[0] + (c * x - sn * y), T[1] + (sn * x + c * y)))
+            assert n == len(want)
+            assert np.array_equal(out[:n], np.array(want))
+
+
 def test_star_centres_are_eliminated_last():
     """The condensed graph a peer sends is a star: its gauge vertex gets 30-60 edges.  Such hubs stay out of the nested
     dissection and are eliminated last (they would tie the subtrees their ends lie in together level by level): the tree of
