@@ -383,14 +383,29 @@ int cgmr_scan_cartesian(int n_beams, const float* ranges, double angle_min, doub
 int cgmr_subsample(int n, const double* pts, double res, double* out) {
   if (n < 0 || (n > 0 && (!pts || !out))) return CGMR_E_INVALID;
   double ires = 1. / res;
+  // (cell x, cell y, index) packed into one 64-bit key when the cells fit 21 bits each and the index 22 -- any real scan set
+  // -- so that the sort compares integers; the order is the lexicographic one either way
   struct Key { int kx, ky, idx; };
   std::vector<Key> keys(n);
-  for (int i = 0; i < n; i++) keys[i] = {(int)(ires * pts[2 * i]), (int)(ires * pts[2 * i + 1]), i};
-  std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-    if (a.kx != b.kx) return a.kx < b.kx;
-    if (a.ky != b.ky) return a.ky < b.ky;
-    return a.idx < b.idx;
-  });
+  bool fits = n < (1 << 22);
+  for (int i = 0; i < n; i++) {
+    keys[i] = {(int)(ires * pts[2 * i]), (int)(ires * pts[2 * i + 1]), i};
+    fits = fits && keys[i].kx > -(1 << 20) && keys[i].kx < (1 << 20) && keys[i].ky > -(1 << 20) && keys[i].ky < (1 << 20);
+  }
+  if (fits) {
+    std::vector<uint64_t> pk(n);
+    for (int i = 0; i < n; i++)
+      pk[i] = ((uint64_t)(uint32_t)(keys[i].kx + (1 << 20)) << 43) | ((uint64_t)(uint32_t)(keys[i].ky + (1 << 20)) << 22) | (uint64_t)(uint32_t)i;
+    std::sort(pk.begin(), pk.end());
+    for (int i = 0; i < n; i++)
+      keys[i] = {(int)(pk[i] >> 43) - (1 << 20), (int)((pk[i] >> 22) & ((1u << 21) - 1)) - (1 << 20), (int)(pk[i] & ((1u << 22) - 1))};
+  } else {
+    std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+      if (a.kx != b.kx) return a.kx < b.kx;
+      if (a.ky != b.ky) return a.ky < b.ky;
+      return a.idx < b.idx;
+    });
+  }
   int m = 0;
   for (int i = 0; i < n;) {
     int j = i, cnt = 0;
