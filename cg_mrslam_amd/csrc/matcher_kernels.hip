@@ -43,7 +43,8 @@ constexpr int NT_LDS = kMatchTilesLds;       // tiles held in LDS
 constexpr int MAXPTS = kMatchMaxPoints;      // max beams / points per scan
 constexpr int NTH = 8;                       // search angles processed concurrently (one per wavefront, 512 threads)
 constexpr int CB_THREADS = 64 * NTH;            // workgroup size of k_match_close_batch
-constexpr int GR_WAVES = 4;                  // wavefronts of the generic kernels (256 threads)
+constexpr int GR_WAVES = 8;                  // wavefronts of k_match_greedy (512 threads: the rasteriser and an item's gathers both scale with them)
+constexpr int GR_THREADS = 64 * GR_WAVES;
 constexpr int LISTCAP = 704;                 // kept points per angle on the fast path (more -> generic path)
 constexpr int PT = 4;                        // points gathered per inner iteration of the fast search path
 constexpr int CAND_U = 9;                    // candidates per lane per block (64*9 = 576 = 24x24)
@@ -1363,7 +1364,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 // work items round-robin, one per wavefront; the pruned result maps are global tables of 64-bit keys updated with
 // atomicMin (score bits << 32 | visit order inside the reference's per-thread map), decoded on the host.
 // Any grid size / step; cell reads go through the bounds-checked directory lookup.
-__global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const GreedyJob* __restrict__ jobs,
+__global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, const GreedyJob* __restrict__ jobs,
                                                       const int32_t* __restrict__ block_job,
                                                       const double* __restrict__ ref_pts_all,
                                                       const double* __restrict__ qry_pts_all,
@@ -1387,13 +1388,14 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const Greed
   uint32_t* gtiles = rcell + P.ref_cap;
   const int nty = (P.ny + 7) >> 3;
   const int DW = nty + kMatchDirGuardY;
-  for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
-  for (int i = tid; i < J.n_ref; i += 256) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
+  for (int q = tid; q < P.kdim * P.kdim; q += GR_THREADS) S.kernel[q] = kernel_lut[q];
+  for (int i = tid; i < J.n_ref; i += GR_THREADS) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
   __syncthreads();
   build_grid(S, P, rcell, J.n_ref, gtiles, /*allow_fast=*/false, err);
   const float ikscale = (float)(1. / (float)P.kscale);
   const int nbins = J.nbx * J.nby * J.nbt;
-  uint32_t* const pl = &S.plist[0][0] + wave * (2 * LISTCAP);     // 4 wavefronts: two lists each
+  uint32_t* const pl = &S.plist[0][0] + (wave >> 1) * (2 * LISTCAP);   // 8 wavefronts in pairs: the two of a pair build the same list
+                                                                          // (identical stores) in one double-length slot, each reads what it wrote
   // One (region, angle) item per workgroup and round.  Every wavefront turns all the query points and builds the same
   // kept-point list (the consecutive-duplicate rule runs along the whole list; this is a hundredth of the work), then
   // gathers one quarter of it for all the candidates; the quarters meet in LDS.  Round 2 gave every wavefront an item of
@@ -1419,7 +1421,7 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const Greed
         sum[u] = 0;
       }
       __syncthreads();                                            // (the previous pass' sums have been read)
-      for (int q = tid; q < 64 * CAND_U; q += 256) totals[q] = 0;
+      for (int q = tid; q < 64 * CAND_U; q += GR_THREADS) totals[q] = 0;
       // the point list is rebuilt in chunks of at most MAXPTS - 4 kept points
       int k = 0;
       uint32_t prev = 0;
@@ -1460,14 +1462,15 @@ __global__ __launch_bounds__(256) void k_match_greedy(MatchParams P, const Greed
         }
         __builtin_amdgcn_wave_barrier();
         k += kc;
+        if (c1 < J.n_qry) __syncthreads();                        // (the next chunk's list goes into the slot the pair's other wavefront may still read)
       }
       __syncthreads();                                            // (totals are zero)
 #pragma unroll
       for (int u = 0; u < CAND_U; u++)
         if (sum[u]) atomicAdd(&totals[u * 64 + lane], sum[u]);
       __syncthreads();
-      // the candidates of the pass over the workgroup's 256 threads
-      for (int c = tid; c < 64 * CAND_U; c += 256) {
+      // the candidates of the pass over the workgroup's threads
+      for (int c = tid; c < 64 * CAND_U; c += GR_THREADS) {
         const int cidx = cb + c;
         if (cidx >= ncand) continue;
         const int a = cidx / R.nj, b = cidx - a * R.nj;
@@ -1575,7 +1578,7 @@ void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, cons
                          const int32_t* items, const uint8_t* kernel_lut, unsigned char* scratch, unsigned long long* bins,
                          int* err) {
   set_lds_attr_once<1>(reinterpret_cast<const void*>(k_match_greedy));
-  hipLaunchKernelGGL(k_match_greedy, dim3(nblocks), dim3(256), sizeof(Smem), st, P, jobs, block_job, ref_pts, qry_pts, regions,
+  hipLaunchKernelGGL(k_match_greedy, dim3(nblocks), dim3(GR_THREADS), sizeof(Smem), st, P, jobs, block_job, ref_pts, qry_pts, regions,
                      theta, items, kernel_lut, scratch, bins, err);
 }
 
