@@ -1495,7 +1495,8 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
 
 // Numeric core of ScanMatcher::verifyMatching (scan_matcher.cpp:430-505), one workgroup per job: grid from pts2, the
 // points of pts1 the grid does not explain, a second grid from those, mean cell value over a window.
-__global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const VerifyJob* __restrict__ jobs,
+constexpr int VF_THREADS = 512;               // threads of k_match_verify (two rasterisations per job: they scale with the wavefronts)
+__global__ __launch_bounds__(VF_THREADS) void k_match_verify(MatchParams P, const VerifyJob* __restrict__ jobs,
                                                       const double* __restrict__ pts2_all,
                                                       const double* __restrict__ pts1_all, double nonmatched_score,
                                                       const uint8_t* __restrict__ kernel_lut,
@@ -1512,17 +1513,19 @@ __global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const Verif
   uint32_t* rcell2 = rcell + P.ref_cap;                              // cells of the unexplained points
   uint32_t* gtiles = rcell2 + P.ref_cap;
   const int DW = ((P.ny + 7) >> 3) + kMatchDirGuardY;
-  for (int q = tid; q < P.kdim * P.kdim; q += 256) S.kernel[q] = kernel_lut[q];
-  for (int i = tid; i < J.n2; i += 256) rcell[i] = world_to_packed_cell(P, pts2[2 * i], pts2[2 * i + 1]);
+  for (int q = tid; q < P.kdim * P.kdim; q += VF_THREADS) S.kernel[q] = kernel_lut[q];
+  for (int i = tid; i < J.n2; i += VF_THREADS) rcell[i] = world_to_packed_cell(P, pts2[2 * i], pts2[2 * i + 1]);
   __syncthreads();
   build_grid(S, P, rcell, J.n2, gtiles, /*allow_fast=*/false, err);
   const float ikscale = (float)(1. / (float)P.kscale);
-  // unexplained points: ordered compaction (the stamp is order independent, the count is reported)
-  int base = 0;
-  for (int i0 = 0; i0 < J.n1; i0 += 256) {
+  // unexplained points: compacted through a counter, a wavefront's survivors at a time (the rasteriser does not care about
+  // the order, only the count is reported; round 2 kept the order with a block scan -- 18 barriers -- per 256 points)
+  if (tid == 0) S.misc[14] = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < J.n1; i0 += VF_THREADS) {
     int i = i0 + tid;
     uint32_t packed = 0x80008000u;
-    int keep = 0;
+    bool keep = false;
     if (i < J.n1) {
       packed = world_to_packed_cell(P, pts1[2 * i], pts1[2 * i + 1]);
       int gx = (int16_t)(packed & 0xffff), gy = (int16_t)(packed >> 16);
@@ -1531,17 +1534,21 @@ __global__ __launch_bounds__(256) void k_match_verify(MatchParams P, const Verif
         keep = value > nonmatched_score;
       }
     }
-    int total;
-    int pos = block_scan_excl(keep, scan_scratch(S), &total);
-    if (keep) rcell2[base + pos] = packed;
-    base += total;
+    const unsigned long long m = __ballot(keep);
+    const int lane = tid & 63;
+    int wbase = 0;
+    if (lane == 0 && m) wbase = atomicAdd(&S.misc[14], __popcll(m));
+    wbase = __shfl(wbase, 0, 64);
+    if (keep) rcell2[wbase + __popcll(m & ((1ULL << lane) - 1ULL))] = packed;
   }
+  __syncthreads();
+  const int base = S.misc[14];
   __syncthreads();
   const int nnm = base;
   build_grid(S, P, rcell2, nnm, gtiles, /*allow_fast=*/false, err);
   int isum = 0;
   const int ni = max(0, J.hi_x - J.lo_x), nj = max(0, J.hi_y - J.lo_y);
-  for (int q = tid; q < ni * nj; q += 256) {
+  for (int q = tid; q < ni * nj; q += VF_THREADS) {
     int a = q / nj, b = q - a * nj;
     isum += grid_cell(S, P, gtiles, DW, J.lo_x + a, J.lo_y + b);
   }
@@ -1569,7 +1576,7 @@ void launch_match_verify(hipStream_t st, int n_jobs, const MatchParams& P, const
                          double nonmatched_score, const uint8_t* kernel_lut, unsigned char* scratch, double* score_out,
                          int* nnm_out, int* err) {
   set_lds_attr_once<0>(reinterpret_cast<const void*>(k_match_verify));
-  hipLaunchKernelGGL(k_match_verify, dim3(n_jobs), dim3(256), sizeof(Smem), st, P, jobs, pts2, pts1, nonmatched_score, kernel_lut,
+  hipLaunchKernelGGL(k_match_verify, dim3(n_jobs), dim3(VF_THREADS), sizeof(Smem), st, P, jobs, pts2, pts1, nonmatched_score, kernel_lut,
                      scratch, score_out, nnm_out, err);
 }
 
