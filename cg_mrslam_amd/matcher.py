@@ -56,9 +56,22 @@ class ScanSet(C.Structure):
     _fields_ = [("n_scans", C.c_int), ("ranges", C.c_void_p), ("poses_xyt", C.c_void_p), ("ref_index", C.c_int)]
 
 
+_STACKED = {}                 # tuple of id(ranges array) -> (the arrays themselves, their stack): a key-frame driver passes the same
+_STACKED_MAX = 512            # scans of the same vertices again and again (up to 21 x 1081 floats per set)
+
+
 def _scan_set(scans, ref_index):
     """scans: list of (ranges, pose).  Returns (ScanSet, keep-alive arrays)."""
-    ranges = np.ascontiguousarray(np.stack([np.asarray(r, dtype=np.float32) for r, _ in scans]), dtype=np.float32)
+    key = tuple(id(r) for r, _ in scans)
+    hit = _STACKED.get(key)
+    if hit is not None and all(a is r for a, (r, _) in zip(hit[0], scans)):
+        ranges = hit[1]
+    else:
+        ranges = np.ascontiguousarray(np.stack([np.asarray(r, dtype=np.float32) for r, _ in scans]), dtype=np.float32)
+        if all(isinstance(r, np.ndarray) and not r.flags.writeable for r, _ in scans):   # (only scans nobody can change behind the cache)
+            if len(_STACKED) >= _STACKED_MAX:
+                _STACKED.clear()
+            _STACKED[key] = ([r for r, _ in scans], ranges)
     poses = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for _, p in scans]), dtype=np.float64)
     s = ScanSet(len(scans), C.c_void_p(ranges.ctypes.data), C.c_void_p(poses.ctypes.data), int(ref_index))
     return s, (ranges, poses)

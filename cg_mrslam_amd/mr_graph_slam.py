@@ -265,6 +265,7 @@ class MRGraphSLAMDriver(GraphSLAMDriver):
             if vid == cmsg.nodeId:                               # new vertex, comes with its scan
                 r = np.array(cmsg.readings, dtype=np.float32)
                 r[r >= PEER_LASER_MAX_RANGE] = np.float32(2.0 * self.lc_matcher.cfg.max_range)   # LaserParameters(.., 8.0, ..)
+                r.setflags(write=False)
                 self.peer[vid] = {"pose": vest, "ranges": r}
                 vset.append(vid)
         if not vset or cmsg.nodeId not in vset:

@@ -246,7 +246,9 @@ class GraphSLAMDriver(GraphSLAM):
         g.fixed = np.append(g.fixed, np.uint8(1 if fixed else 0))
         idx = g.n_vertices - 1
         self._id_index[int(vid)] = idx
-        self.lasers[idx] = np.ascontiguousarray(ranges, dtype=np.float32)
+        scan = np.array(ranges, dtype=np.float32)                 # own, read-only copy: the matcher wrappers may cache the scan sets built from it
+        scan.setflags(write=False)
+        self.lasers[idx] = scan
         return idx
 
     def _add_edge(self, i, j, meas, info, kind, eid):
