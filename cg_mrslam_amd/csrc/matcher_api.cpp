@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "cgmr_ctx.h"
+#include "gn_symbolic.h"
 #include "matcher_device.h"
 
 using namespace cgmr;
@@ -1092,17 +1093,31 @@ int cgmr_global_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
   std::vector<int> ref_alias(n_jobs, 0);
   static const bool gm_trace = getenv("CGMR_MATCH_TRACE") != nullptr;
   const auto tg0 = std::chrono::steady_clock::now();
-  double us_ref = 0, us_cur = 0, us_sub = 0;
+  double us_ref = 0;
   auto us_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+  // host preparation of the jobs -- reference points of every distinct reference set (jobs that pass the very same set share
+  // them), points and subsample of every current set -- on the helper threads, one job each
   for (int j = 0; j < n_jobs; j++) {
-    std::vector<double> cur;
+    ref_alias[j] = j;
+    for (int k = 0; k < j; k++)
+      if (ref_sets[k].ranges == ref_sets[j].ranges && ref_sets[k].poses_xyt == ref_sets[j].poses_xyt &&
+          ref_sets[k].n_scans == ref_sets[j].n_scans && ref_sets[k].ref_index == ref_sets[j].ref_index) { ref_alias[j] = ref_alias[k]; break; }
+  }
+  {
     auto ta = std::chrono::steady_clock::now();
-    const std::vector<double>& rj = reference_points(cfg, ref_sets, j, ref, ref_alias);
-    us_ref += us_since(ta); ta = std::chrono::steady_clock::now();
-    points_from_vset(cfg, cur_sets + j, nullptr, cur);
-    us_cur += us_since(ta); ta = std::chrono::steady_clock::now();
-    qry[j] = subsample_of(cur, 0.1);
-    us_sub += us_since(ta);
+    host_run_tasks(n_jobs, [&](int j) {
+      if (ref_alias[j] == j) {
+        points_from_vset(cfg, ref_sets + j, nullptr, ref[j]);
+        keep_first_point_per_cell(cfg, ref[j]);
+      }
+      std::vector<double> cur;
+      points_from_vset(cfg, cur_sets + j, nullptr, cur);
+      qry[j] = subsample_of(cur, 0.1);
+    });
+    us_ref = us_since(ta);
+  }
+  for (int j = 0; j < n_jobs; j++) {
+    const std::vector<double>& rj = ref[ref_alias[j]];
     jobs[j].ref = rj.data(); jobs[j].n_ref = (int)(rj.size() / 2);
     jobs[j].qry = qry[j].data(); jobs[j].n_qry = (int)(qry[j].size() / 2);
     jobs[j].regions = region; jobs[j].n_regions = 1;
@@ -1112,8 +1127,8 @@ int cgmr_global_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
   int rc = hierarchical_batch_core(ctx, cfg, jobs, 0.025, max_score, 0.5, 0.5, 0.2, 4, res);
   if (rc) return rc;
   if (gm_trace)
-    fprintf(stderr, "[global] %d jobs: reference points %.0f us, current points %.0f us, subsample %.0f us, hierarchy %.0f us, total %.0f us\n", n_jobs,
-            us_ref, us_cur, us_sub, us_since(th0), us_since(tg0));
+    fprintf(stderr, "[global] %d jobs: points + subsample (helper threads) %.0f us, hierarchy %.0f us, total %.0f us\n", n_jobs, us_ref, us_since(th0),
+            us_since(tg0));
   for (int j = 0; j < n_jobs; j++) {
     double* t = trel_out + 3 * (size_t)j;
     t[0] = t[1] = t[2] = 0;
