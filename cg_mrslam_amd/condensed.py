@@ -198,10 +198,16 @@ class RobotGraph:
         return int(n.value)
 
     def received_edges(self, peer):
-        cap = self.cap
-        f, t, m, i = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32), np.zeros((cap, 3)), np.zeros((cap, 6))
-        n = self._check(self.lib.cgmr_graph_received_edges(self.h, C.c_int(peer), C.c_int(cap), _p(f), _p(t), _p(m), _p(i)))
-        return f[:n].astype(np.int64), t[:n].astype(np.int64), m[:n].copy(), i[:n].copy()
+        n = self.counts_received(peer)
+        if n == 0:
+            return (np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros((0, 3)), np.zeros((0, 6)))
+        f, t, m, i = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32), np.empty((n, 3)), np.empty((n, 6))
+        n = self._check(self.lib.cgmr_graph_received_edges(self.h, C.c_int(peer), C.c_int(n), _p(f), _p(t), _p(m), _p(i)))
+        return f[:n].astype(np.int64), t[:n].astype(np.int64), m[:n], i[:n]
+
+    def counts_received(self, peer):
+        """Edges currently held from ``peer`` (no data moved)."""
+        return int(self._check(self.lib.cgmr_graph_received_edges(self.h, C.c_int(peer), C.c_int(0), None, None, None, None)))
 
     def last_seconds(self):
         out = np.zeros(2)

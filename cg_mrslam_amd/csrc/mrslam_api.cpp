@@ -947,8 +947,12 @@ int cgmr_graph_received_edges(cgmr_graph* g, int peer, int cap, int32_t* from_id
     if (g->ctx) {
       cgmr_ctx* ctx = g->ctx;
       HIP_TRY(ctx, hipSetDevice(ctx->device));
-      HIP_TRY(ctx, hipMemcpyAsync(g->hs_meas.data(), g->d_stage_meas, 24 * (size_t)g->n_robots * g->cap, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(ctx, hipMemcpyAsync(g->hs_info.data(), g->d_stage_info, 48 * (size_t)g->n_robots * g->cap, hipMemcpyDeviceToHost, ctx->stream));
+      // only the staging slots this peer's edges occupy (round 2 fetched the staging of all peers: 650 KB per call at the
+      // reference's capacity)
+      size_t lo = (size_t)I.slot[0], hi = (size_t)I.slot[0] + 1;
+      for (int k = 1; k < (int)I.slot.size(); k++) { lo = std::min(lo, (size_t)I.slot[k]); hi = std::max(hi, (size_t)I.slot[k] + 1); }
+      HIP_TRY(ctx, hipMemcpyAsync(g->hs_meas.data() + 3 * lo, g->d_stage_meas + 3 * lo, 24 * (hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(g->hs_info.data() + 6 * lo, g->d_stage_info + 6 * lo, 48 * (hi - lo), hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     for (int k = 0; k < n; k++) {

@@ -72,7 +72,7 @@ def _scan_set(scans, ref_index):
             if len(_STACKED) >= _STACKED_MAX:
                 _STACKED.clear()
             _STACKED[key] = ([r for r, _ in scans], ranges)
-    poses = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for _, p in scans]), dtype=np.float64)
+    poses = np.array([p for _, p in scans], dtype=np.float64).reshape(len(scans), 3)
     s = ScanSet(len(scans), C.c_void_p(ranges.ctypes.data), C.c_void_p(poses.ctypes.data), int(ref_index))
     return s, (ranges, poses)
 

@@ -135,18 +135,20 @@ class MRGraphSLAMDriver(GraphSLAMDriver):
         487-510) as the tail of the host edge arrays: the graph searches and the covariance estimate see them."""
         self._pop_received()
         f, t, m, i = [], [], [], []
+        idx = self._id_index
         for p in range(self.nRobots):
             if p == self.idRobot:
                 continue
             pf, pt, pm, pi = self.rg.received_edges(p)
-            for a, b, mm, ii in zip(pf, pt, pm, pi):
-                f.append(self._index_of_id(int(a)))
-                t.append(self._index_of_id(int(b)))
-                m.append(mm)
-                i.append(ii)
+            if len(pf) == 0:
+                continue
+            f.append(np.fromiter((idx[int(a)] for a in pf), dtype=np.int32, count=len(pf)))
+            t.append(np.fromiter((idx[int(b)] for b in pt), dtype=np.int32, count=len(pt)))
+            m.append(pm)
+            i.append(pi)
         if f:
-            self._push_received((np.asarray(f, dtype=np.int32), np.asarray(t, dtype=np.int32), np.asarray(m).reshape(-1, 3),
-                                 np.asarray(i).reshape(-1, 6), np.zeros(len(f), dtype=np.int32)))
+            f, t = np.concatenate(f), np.concatenate(t)
+            self._push_received((f, t, np.concatenate(m).reshape(-1, 3), np.concatenate(i).reshape(-1, 6), np.zeros(len(f), dtype=np.int32)))
 
     def _add_vertex(self, vid, pose, fixed, ranges):
         idx = super()._add_vertex(vid, pose, fixed, ranges)
