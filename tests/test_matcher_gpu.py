@@ -210,6 +210,27 @@ def test_greedy_multi_region_matches_oracle(ctx, oracle):
     assert len(m.greedySearch(ref, np.zeros((0, 2)), regs, 0.025, 0.3, 0.5, 0.5, 0.2)) == 0
 
 
+def test_greedy_with_more_query_points_than_one_list_holds(ctx, oracle):
+    """A current set of several scans: ~2500 subsampled query points, i.e. three chunks of the kept-point list per (region,
+    angle) item.  The wavefront pairs of the 512-thread search kernel share a list slot, so a chunk must not be rebuilt
+    while the pair's other wavefront still reads the previous one: full result list against the oracle."""
+    sp = synth.make_scan_pairs(6, seed=93)
+    m = _lc(ctx, sp)
+    ref = m.cartesian(sp["ranges_ref"][0])
+    rng = np.random.default_rng(2)
+    parts = []
+    for p in range(6):                                            # six scans of different rooms, shifted: few points share a 0.1 m cell
+        pts = m.cartesian(sp["ranges_qry"][p]) + rng.uniform(-0.05, 0.05, size=2)
+        parts.append(pts)
+    q = m.subsample(np.concatenate(parts))
+    assert len(q) > 2200
+    g = sp["guess"][0]
+    regs = np.array([[-.5 + g[0], -1.0 + g[1], -.4 + g[2], .5 + g[0], 1.0 + g[1], .4 + g[2]]], dtype=np.float32)
+    got = m.greedySearch(ref, q, regs, 0.025, 0.6, 0.5, 0.5, 0.2)
+    n, want = oracle.greedy_search((-35, -35), (35, 35), 0.1, 0.1, 0.5, ref, q, regs, 0.1, 0.025, 0.6, 0.5, 0.5, 0.2)
+    assert len(got) == n > 0 and np.array_equal(got, want)
+
+
 def test_hierarchical_and_global_matching(ctx, oracle):
     sp = synth.make_scan_pairs(2, seed=91)
     m = _lc(ctx, sp)
