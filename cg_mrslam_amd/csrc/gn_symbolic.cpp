@@ -722,21 +722,43 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   S.vperm.assign(nV, -1);
   if (nf == 0) { S.level_ptr.assign(1, 0); return 0; }
   // adjacency CSR over block indices (deduplicated, sorted)
+  // (counting and filling: every thread walks the whole edge list and takes the end points that fall into its own range of
+  // block indices -- the reads are shared and sequential, the scattered writes are private: no atomics, same lists as a
+  // one-thread pass)
   std::vector<int32_t> ap(nf + 1, 0), ai;
-  for (int k = 0; k < nE; k++) {
-    int a = S.hidx[ef[k]], b = S.hidx[et[k]];
-    if (a < 0 || b < 0 || a == b) continue;
-    ap[a + 1]++; ap[b + 1]++;
-  }
+  const int NTA = (nE >= 16384 && nf >= 2048) ? host_threads() : 1;
+  auto in_ranges = [&](auto&& body) {
+    if (NTA <= 1) { body(0, nf); return; }
+    std::vector<HelperPool::Job> jobs(NTA - 1);
+    const int per = (nf + NTA - 1) / NTA;
+    for (int t = 1; t < NTA; t++) {
+      const int lo = t * per, hi = std::min(nf, lo + per);
+      jobs[t - 1].fn = [&body, lo, hi] { if (lo < hi) body(lo, hi); };
+      pool().run(jobs[t - 1]);
+    }
+    body(0, std::min(nf, per));
+    for (auto& j : jobs) HelperPool::wait(j);
+  };
+  in_ranges([&](int lo, int hi) {
+    for (int k = 0; k < nE; k++) {
+      const int a = S.hidx[ef[k]], b = S.hidx[et[k]];
+      if (a < 0 || b < 0 || a == b) continue;
+      if (a >= lo && a < hi) ap[a + 1]++;
+      if (b >= lo && b < hi) ap[b + 1]++;
+    }
+  });
   for (int v = 0; v < nf; v++) ap[v + 1] += ap[v];
   ai.resize(ap[nf]);
   {
     std::vector<int32_t> pos(ap.begin(), ap.end() - 1);
-    for (int k = 0; k < nE; k++) {
-      int a = S.hidx[ef[k]], b = S.hidx[et[k]];
-      if (a < 0 || b < 0 || a == b) continue;
-      ai[pos[a]++] = b; ai[pos[b]++] = a;
-    }
+    in_ranges([&](int lo, int hi) {
+      for (int k = 0; k < nE; k++) {
+        const int a = S.hidx[ef[k]], b = S.hidx[et[k]];
+        if (a < 0 || b < 0 || a == b) continue;
+        if (a >= lo && a < hi) ai[pos[a]++] = b;
+        if (b >= lo && b < hi) ai[pos[b]++] = a;
+      }
+    });
     // sort + dedupe each row (in parallel), then compact in place
     std::vector<int32_t> len(nf);
     parallel_for(nf, host_threads(), [&](int lo, int hi) {
