@@ -803,10 +803,12 @@ bool scan_set_ok(const cgmr_scan_set* S) {
 
 // ScanMatcher::transformPointsFromVSet (scan_matcher.cpp:89-110): every scan of the set in the frame of the reference
 // vertex, `pre` applied on the left of every transform (verifyMatching moves set 2 by trel12 first)
-void points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* S, const Se2* pre, std::vector<double>& out) {
+void points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* S, const Se2* pre, std::vector<double>& out,
+                      int k_begin = 0, int k_end = -1) {
   const Se2 lp = se2_of(cfg->laser_pose);
   const Se2 ref = se2_of(S->poses_xyt + 3 * (size_t)S->ref_index);
-  for (int k = 0; k < S->n_scans; k++) {
+  if (k_end < 0) k_end = S->n_scans;
+  for (int k = k_begin; k < k_end; k++) {
     std::vector<double> v = cartesian_of(cfg, S->ranges + (size_t)k * cfg->n_beams);
     Se2 T = lp;
     if (k != S->ref_index) T = se2_mul(se2_mul(se2_inv(ref), se2_of(S->poses_xyt + 3 * (size_t)k)), lp);
@@ -819,9 +821,9 @@ void points_from_vset(const cgmr_matcher_config* cfg, const cgmr_scan_set* S, co
 // Reference points of a multi-scan set hit the same walls once per scan; the rasteriser's byte-min is idempotent, so only
 // the first point of every distinct grid cell has to be stamped.  Cells exactly as the kernel computes them
 // (world_to_packed_cell: double -> float, world2grid in float, round to nearest even).
-void keep_first_point_per_cell(const cgmr_matcher_config* cfg, std::vector<double>& pts) {
+void keep_first_point_per_cell(const cgmr_matcher_config* cfg, std::vector<double>& pts, size_t at_least = 2048) {
   const size_t n = pts.size() / 2;
-  if (n < 2048) return;
+  if (n < at_least) return;
   const float ll_x = (float)cfg->grid_ll_x, ll_y = (float)cfg->grid_ll_y;
   const float inv_res = (float)(1. / (float)cfg->resolution);
   size_t cap = 1;
@@ -848,23 +850,62 @@ void keep_first_point_per_cell(const cgmr_matcher_config* cfg, std::vector<doubl
   pts.resize(2 * w);
 }
 
-// the reference points of job j's scan set; jobs that pass the very same set (same arrays) share one computation
-const std::vector<double>& reference_points(const cgmr_matcher_config* cfg, const cgmr_scan_set* sets, int j,
-                                            std::vector<std::vector<double>>& store, std::vector<int>& alias) {
-  for (int k = 0; k < j; k++)
-    if (sets[k].ranges == sets[j].ranges && sets[k].poses_xyt == sets[j].poses_xyt && sets[k].n_scans == sets[j].n_scans &&
-        sets[k].ref_index == sets[j].ref_index) { alias[j] = alias[k]; return store[alias[j]]; }
-  alias[j] = j;
-  points_from_vset(cfg, sets + j, nullptr, store[j]);
-  keep_first_point_per_cell(cfg, store[j]);
-  return store[j];
-}
-
 std::vector<double> subsample_of(const std::vector<double>& pts, double res) {
   std::vector<double> out(pts.size());
   int n = cgmr_subsample((int)(pts.size() / 2), pts.data(), res, out.data());
   out.resize(2 * (size_t)std::max(n, 0));
   return out;
+}
+
+// Host preparation of a batch of searches over scan sets: the reference points of every distinct reference set (jobs that
+// pass the very same set share them: ref_alias), points and 0.1 m subsample of every current set (scan_matcher.cpp:216-217,
+// 376-381).  Tasks for the helper threads: the scans of a reference set in runs of a few scans (a 21-scan set is 150 us of
+// host work in one piece), every current set with its subsample; then the runs of a set are joined in scan order and
+// thinned out (a robot that stays in the same rooms hits the same cells again and again: 13k points -> 600).
+void prepare_scan_sets(const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* ref_sets, const cgmr_scan_set* cur_sets,
+                       std::vector<std::vector<double>>& ref, std::vector<std::vector<double>>& qry, std::vector<int>& ref_alias,
+                       bool trace) {
+  auto us_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+  ref.assign(n_jobs, {}); qry.assign(n_jobs, {}); ref_alias.assign(n_jobs, 0);
+  for (int j = 0; j < n_jobs; j++) {
+    ref_alias[j] = j;
+    for (int k = 0; k < j; k++)
+      if (ref_sets[k].ranges == ref_sets[j].ranges && ref_sets[k].poses_xyt == ref_sets[j].poses_xyt &&
+          ref_sets[k].n_scans == ref_sets[j].n_scans && ref_sets[k].ref_index == ref_sets[j].ref_index) { ref_alias[j] = ref_alias[k]; break; }
+  }
+  const auto ta = std::chrono::steady_clock::now();
+  struct Run { int job, k0, k1; std::vector<double> pts; };
+  std::vector<Run> runs;
+  const int kRun = 3;
+  for (int j = 0; j < n_jobs; j++)
+    if (ref_alias[j] == j)
+      for (int k0 = 0; k0 < ref_sets[j].n_scans; k0 += kRun) runs.push_back({j, k0, std::min(ref_sets[j].n_scans, k0 + kRun), {}});
+  const int n_runs = (int)runs.size();
+  host_run_tasks(n_runs + n_jobs, [&](int t) {
+    if (t < n_runs) {
+      Run& r = runs[t];
+      points_from_vset(cfg, ref_sets + r.job, nullptr, r.pts, r.k0, r.k1);
+      if (ref_sets[r.job].n_scans > kRun) keep_first_point_per_cell(cfg, r.pts, 0);   // (first of a cell in its run, then first over the runs
+      return;                                                                         //  = first of the set)
+    }
+    const int j = t - n_runs;
+    std::vector<double> cur;
+    points_from_vset(cfg, cur_sets + j, nullptr, cur);
+    qry[j] = subsample_of(cur, 0.1);
+  });
+  const double us_runs = us_since(ta);
+  std::vector<int> owners;
+  for (int j = 0; j < n_jobs; j++) if (ref_alias[j] == j) owners.push_back(j);
+  host_run_tasks((int)owners.size(), [&](int q) {
+    const int j = owners[q];
+    size_t total = 0;
+    for (const Run& r : runs) if (r.job == j) total += r.pts.size();
+    ref[j].reserve(total);
+    for (const Run& r : runs) if (r.job == j) ref[j].insert(ref[j].end(), r.pts.begin(), r.pts.end());
+    keep_first_point_per_cell(cfg, ref[j], ref_sets[j].n_scans > kRun ? 0 : 2048);
+  });
+  if (trace)
+    fprintf(stderr, "[sets] %d runs + %d current sets %.0f us, join + thin out %.0f us\n", n_runs, n_jobs, us_runs, us_since(ta) - us_runs);
 }
 
 // CharGrid::hierarchicalSearch (chargrid.cpp:310-344, 376-400) for a batch of searches: levels n-1 .. 0, step 2^i
@@ -1013,14 +1054,12 @@ int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
   for (int j = 0; j < n_jobs; j++)
     if (!scan_set_ok(ref_sets + j) || !scan_set_ok(cur_sets + j)) return set_err(ctx, CGMR_E_INVALID, "cgmr_scan_matching_lc: bad scan set");
   struct Key { int a, b, c; bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); } };
-  std::vector<std::vector<double>> ref(n_jobs), qry(n_jobs);
+  std::vector<std::vector<double>> ref, qry;
   std::vector<std::vector<float>> regions(n_jobs), regionspi(n_jobs);
-  std::vector<int> ref_alias(n_jobs, 0);
+  std::vector<int> ref_alias;
+  static const bool lc_trace = getenv("CGMR_MATCH_TRACE") != nullptr;
+  prepare_scan_sets(cfg, n_jobs, ref_sets, cur_sets, ref, qry, ref_alias, lc_trace);
   for (int j = 0; j < n_jobs; j++) {
-    std::vector<double> cur;
-    (void)reference_points(cfg, ref_sets, j, ref, ref_alias);
-    points_from_vset(cfg, cur_sets + j, nullptr, cur);
-    qry[j] = subsample_of(cur, 0.1);                                               // scan_matcher.cpp:216-217
     const cgmr_scan_set* S = ref_sets + j;
     const Se2 refp = se2_of(S->poses_xyt + 3 * (size_t)S->ref_index);
     for (int k = 0; k < S->n_scans; k++) {                                         // :219-256
@@ -1036,21 +1075,26 @@ int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
   const double theta_res = 0.025, dx = 0.5, dy = 0.5, dth = 0.2;                   // :258-263
   const double step = (double)(float)cfg->resolution;
   std::vector<std::vector<std::pair<Key, cgmr_match_result>>> merged(n_jobs);      // addToPrunedMap, chargrid.cpp:36-46
-  for (int pass = 0; pass < 2; pass++) {
-    std::vector<SearchJob> jobs(n_jobs);
+  // the two searches of a job (the regions, the regions turned by pi) are independent: both go into ONE launch, as jobs
+  // j and n_jobs + j; their best results are merged in the reference's order (first search first)
+  std::vector<SearchJob> jobs(2 * (size_t)n_jobs);
+  for (int pass = 0; pass < 2; pass++)
     for (int j = 0; j < n_jobs; j++) {
       const std::vector<float>& rg = pass ? regionspi[j] : regions[j];
       const std::vector<double>& rj = ref[ref_alias[j]];
-      jobs[j].ref = rj.data(); jobs[j].n_ref = (int)(rj.size() / 2);
-      jobs[j].qry = qry[j].data(); jobs[j].n_qry = (int)(qry[j].size() / 2);
-      jobs[j].regions = rg.data(); jobs[j].n_regions = (int)(rg.size() / 6);
+      SearchJob& J = jobs[(size_t)pass * n_jobs + j];
+      J.ref = rj.data(); J.n_ref = (int)(rj.size() / 2);
+      J.qry = qry[j].data(); J.n_qry = (int)(qry[j].size() / 2);
+      J.regions = rg.data(); J.n_regions = (int)(rg.size() / 6);
     }
-    std::vector<std::vector<cgmr_match_result>> res;
-    int rc = greedy_batch_core(ctx, cfg, jobs, step, step, theta_res, max_score, dx, dy, dth, res);
-    if (rc) return rc;
+  std::vector<std::vector<cgmr_match_result>> res;
+  int rc = greedy_batch_core(ctx, cfg, jobs, step, step, theta_res, max_score, dx, dy, dth, res);
+  if (rc) return rc;
+  for (int pass = 0; pass < 2; pass++)
     for (int j = 0; j < n_jobs; j++) {
-      if (res[j].empty()) continue;
-      cgmr_match_result best = res[j][0];
+      const std::vector<cgmr_match_result>& rj = res[(size_t)pass * n_jobs + j];
+      if (rj.empty()) continue;
+      cgmr_match_result best = rj[0];
       best.theta = norm_theta(best.theta);
       const Key key = {(int)(best.x / dx), (int)(best.y / dy), (int)(best.theta / dth)};
       bool seen = false;
@@ -1058,7 +1102,6 @@ int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
         if (!(kv.first < key) && !(key < kv.first)) { seen = true; if (kv.second.score > best.score) kv.second = best; }
       if (!seen) merged[j].emplace_back(key, best);
     }
-  }
   for (int j = 0; j < n_jobs; j++) {
     auto& mj = merged[j];
     std::sort(mj.begin(), mj.end(), [](const std::pair<Key, cgmr_match_result>& a, const std::pair<Key, cgmr_match_result>& b) { return a.first < b.first; });
@@ -1095,27 +1138,9 @@ int cgmr_global_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
   const auto tg0 = std::chrono::steady_clock::now();
   double us_ref = 0;
   auto us_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
-  // host preparation of the jobs -- reference points of every distinct reference set (jobs that pass the very same set share
-  // them), points and subsample of every current set -- on the helper threads, one job each
-  for (int j = 0; j < n_jobs; j++) {
-    ref_alias[j] = j;
-    for (int k = 0; k < j; k++)
-      if (ref_sets[k].ranges == ref_sets[j].ranges && ref_sets[k].poses_xyt == ref_sets[j].poses_xyt &&
-          ref_sets[k].n_scans == ref_sets[j].n_scans && ref_sets[k].ref_index == ref_sets[j].ref_index) { ref_alias[j] = ref_alias[k]; break; }
-  }
-  {
-    auto ta = std::chrono::steady_clock::now();
-    host_run_tasks(n_jobs, [&](int j) {
-      if (ref_alias[j] == j) {
-        points_from_vset(cfg, ref_sets + j, nullptr, ref[j]);
-        keep_first_point_per_cell(cfg, ref[j]);
-      }
-      std::vector<double> cur;
-      points_from_vset(cfg, cur_sets + j, nullptr, cur);
-      qry[j] = subsample_of(cur, 0.1);
-    });
-    us_ref = us_since(ta);
-  }
+  const auto ta = std::chrono::steady_clock::now();
+  prepare_scan_sets(cfg, n_jobs, ref_sets, cur_sets, ref, qry, ref_alias, gm_trace);
+  us_ref = us_since(ta);
   for (int j = 0; j < n_jobs; j++) {
     const std::vector<double>& rj = ref[ref_alias[j]];
     jobs[j].ref = rj.data(); jobs[j].n_ref = (int)(rj.size() / 2);
@@ -1155,11 +1180,29 @@ int cgmr_verify_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, in
     if (!scan_set_ok(sets1 + j) || !scan_set_ok(sets2 + j)) return set_err(ctx, CGMR_E_INVALID, "cgmr_verify_matching: bad scan set");
   std::vector<std::vector<double>> p2(n_jobs), p1(n_jobs);
   std::vector<VerifyIn> in(n_jobs);
+  // the points of both sets of every job, in runs of a few scans on the helper threads, joined in scan order
+  struct Run { int job, which, k0, k1; std::vector<double> pts; };
+  std::vector<Run> runs;
+  const int kRun = 3;
+  for (int j = 0; j < n_jobs; j++) {
+    for (int k0 = 0; k0 < sets2[j].n_scans; k0 += kRun) runs.push_back({j, 2, k0, std::min(sets2[j].n_scans, k0 + kRun), {}});
+    for (int k0 = 0; k0 < sets1[j].n_scans; k0 += kRun) runs.push_back({j, 1, k0, std::min(sets1[j].n_scans, k0 + kRun), {}});
+  }
+  host_run_tasks((int)runs.size(), [&](int t) {
+    Run& r = runs[t];
+    if (r.which == 2) {
+      const Se2 t12 = se2_of(trel12 + 3 * (size_t)r.job);
+      points_from_vset(cfg, sets2 + r.job, &t12, r.pts, r.k0, r.k1);               // scan_matcher.cpp:441-458
+    } else {
+      points_from_vset(cfg, sets1 + r.job, nullptr, r.pts, r.k0, r.k1);
+    }
+  });
+  for (const Run& r : runs) {
+    std::vector<double>& dst = r.which == 2 ? p2[r.job] : p1[r.job];
+    dst.insert(dst.end(), r.pts.begin(), r.pts.end());
+  }
   for (int j = 0; j < n_jobs; j++) {
     const double* t = trel12 + 3 * (size_t)j;
-    const Se2 t12 = se2_of(t);
-    points_from_vset(cfg, sets2 + j, &t12, p2[j]);                                 // scan_matcher.cpp:441-458
-    points_from_vset(cfg, sets1 + j, nullptr, p1[j]);
     in[j].pts2 = p2[j].data(); in[j].n2 = (int)(p2[j].size() / 2);
     in[j].pts1 = p1[j].data(); in[j].n1 = (int)(p1[j].size() / 2);
     in[j].lower[0] = (float)(-.3 + t[0]); in[j].lower[1] = (float)(-.3 + t[1]);    // :486-489

@@ -84,8 +84,11 @@ struct cgmr_graph {
   double *d_meas_b = nullptr, *d_info_b = nullptr, *d_est64 = nullptr, *d_info64 = nullptr, *d_qposes = nullptr;
   int32_t *d_ids_out = nullptr, *d_slot = nullptr, *d_qidx = nullptr, *d_status_all = nullptr;
   unsigned char *d_send = nullptr, *d_recv = nullptr;
-  char* pinned = nullptr;             // header + closures staging, ids read-back, slot lists
-  size_t pinned_bytes = 0;
+  char* pinned = nullptr;             // header + closures staging, ids read-back, slot lists, one message's numbers
+  size_t pinned_bytes = 0, pinned_msg_off = 0;
+  hipEvent_t ev_msg = nullptr;        // the uploads of the last cgmr_graph_message_from have left the pinned block
+  bool msg_in_flight = false;
+  std::vector<uint8_t> hs_fresh;      // per peer: hs_meas / hs_info hold what the device staging holds
   double last_condense_seconds = 0, last_optimize_seconds = 0;
   bool optimal_gauge = false;         // computeCondensedGraph(robot, optimal)
 };
@@ -137,7 +140,10 @@ int alloc_fixed(cgmr_graph* g) {
   g->d_status_all = (int32_t*)(d + o_st);
   g->d_send = (unsigned char*)(d + o_send); g->d_recv = (unsigned char*)(d + o_recv);
   g->pinned_bytes = round256(wb) + round256(4 * R * (2 + 3 * cap)) + round256(4 * slots) + round256(24 * slots) + 4096;
+  g->pinned_msg_off = g->pinned_bytes;
+  g->pinned_bytes += round256(72 * cap);
   HIP_TRY(ctx, hipHostMalloc((void**)&g->pinned, g->pinned_bytes, hipHostMallocDefault));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&g->ev_msg, hipEventDisableTiming));
   return 0;
 }
 
@@ -177,27 +183,34 @@ int select_gauge_centroid(const std::vector<int32_t>& idx, const double* poses) 
 // Shared tail of the two ingest paths.  per sender s: n_e / n_c and the ids as read from its buffer (ids layout of
 // k_wire_read).  Decides what is accepted (mr_graph_slam.cpp:331-395), refreshes the host structure and returns the
 // staging slots of the compact second edge segment.
+// one sender's part: (from, to) id pairs of its n_e edges, its n_c closure requests
+bool ingest_decide_sender(cgmr_graph* g, int s, int n_e, const int32_t* from_to, int n_c, const int32_t* closures) {
+  const int cap = g->cap;
+  // closure requests: only vertices I have (mr_graph_slam.cpp:336-343); an empty set changes nothing (:345)
+  std::vector<int32_t> known;
+  for (int k = 0; k < n_c; k++) { const int32_t id = closures[k]; if (g->index.count(id)) known.push_back(id); }
+  if (!known.empty()) insert_sorted_unique(g->out_closures[s], known.data(), (int)known.size());
+  // edges: both end points must exist (:360-363); the set replaces the previous one only if it is not empty (:393-394)
+  PeerIn nw;
+  for (int k = 0; k < n_e; k++) {
+    auto a = g->index.find(from_to[2 * k]), b = g->index.find(from_to[2 * k + 1]);
+    if (a == g->index.end() || b == g->index.end()) continue;
+    nw.slot.push_back(s * cap + k);
+    nw.from_idx.push_back(a->second);
+    nw.to_idx.push_back(b->second);
+  }
+  if (nw.slot.empty()) return false;
+  g->in[s] = std::move(nw);
+  return true;
+}
+
 void ingest_decide(cgmr_graph* g, const int32_t* ids, std::vector<uint8_t>& accepted) {
   const int R = g->n_robots, cap = g->cap;
   accepted.assign(R, 0);
   for (int s = 0; s < R; s++) {
     if (s == g->robot) continue;
     const int32_t* io = ids + (size_t)s * (2 + 3 * (size_t)cap);
-    const int n_e = io[0], n_c = io[1];
-    // closure requests: only vertices I have (mr_graph_slam.cpp:336-343); an empty set changes nothing (:345)
-    std::vector<int32_t> known;
-    for (int k = 0; k < n_c; k++) { const int32_t id = io[2 + 2 * cap + k]; if (g->index.count(id)) known.push_back(id); }
-    if (!known.empty()) insert_sorted_unique(g->out_closures[s], known.data(), (int)known.size());
-    // edges: both end points must exist (:360-363); the set replaces the previous one only if it is not empty (:393-394)
-    PeerIn nw;
-    for (int k = 0; k < n_e; k++) {
-      auto a = g->index.find(io[2 + 2 * k]), b = g->index.find(io[2 + 2 * k + 1]);
-      if (a == g->index.end() || b == g->index.end()) continue;
-      nw.slot.push_back(s * cap + k);
-      nw.from_idx.push_back(a->second);
-      nw.to_idx.push_back(b->second);
-    }
-    if (!nw.slot.empty()) { g->in[s] = std::move(nw); accepted[s] = 1; }
+    accepted[s] = ingest_decide_sender(g, s, io[0], io + 2, io[1], io + 2 + 2 * cap) ? 1 : 0;
   }
   rebuild_all_edges(g);
 }
@@ -218,6 +231,7 @@ int cgmr_graph_create(cgmr_ctx* ctx, int robot_id, int n_robots, int base_id, in
   g->out_closures.resize(n_robots); g->in_closures.resize(n_robots);
   g->hs_meas.assign(3 * (size_t)n_robots * g->cap, 0.0);
   g->hs_info.assign(6 * (size_t)n_robots * g->cap, 0.0);
+  g->hs_fresh.assign(n_robots, 1);
   if (ctx) {
     if (hipSetDevice(ctx->device) != hipSuccess) { delete g; return CGMR_E_NO_DEVICE; }
     int rc = alloc_fixed(g);
@@ -236,6 +250,7 @@ void cgmr_graph_destroy(cgmr_graph* g) {
       if (b->ptr) (void)hipFree(b->ptr);
     if (g->d_fixed_block) (void)hipFree(g->d_fixed_block);
     if (g->pinned) (void)hipHostFree(g->pinned);
+    if (g->ev_msg) (void)hipEventDestroy(g->ev_msg);
   }
   delete g;
 }
@@ -768,6 +783,7 @@ int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
   const int R = g->n_robots, cap = g->cap;
   const size_t wb = wire_bytes(R, cap), ids_bytes = 4 * (size_t)R * (2 + 3 * (size_t)cap);
   const unsigned char* recv = d_recv ? (const unsigned char*)d_recv : g->d_recv;
+  g->msg_in_flight = false;            // (the synchronisation below covers a message's uploads: same stream)
   launch_wire_read(st, R, cap, g->robot, wb, recv, g->d_tmp_meas, g->d_tmp_info, g->d_ids_out);
   char* h_ids = g->pinned + round256(wb);
   HIP_TRY(ctx, hipMemcpyAsync(h_ids, g->d_ids_out, ids_bytes, hipMemcpyDeviceToHost, st));
@@ -777,6 +793,7 @@ int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
   for (int s = 0; s < R; s++) {
     if (n_edges_out) n_edges_out[s] = accepted[s] ? (int32_t)g->in[s].slot.size() : 0;
     if (!accepted[s]) continue;
+    g->hs_fresh[s] = 0;
     const int n_e = ((const int32_t*)h_ids)[(size_t)s * (2 + 3 * (size_t)cap)];
     HIP_TRY(ctx, hipMemcpyAsync(g->d_stage_meas + 3 * (size_t)s * cap, g->d_tmp_meas + 3 * (size_t)s * cap, 24 * (size_t)n_e, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(g->d_stage_info + 6 * (size_t)s * cap, g->d_tmp_info + 6 * (size_t)s * cap, 48 * (size_t)n_e, hipMemcpyDeviceToDevice, st));
@@ -889,27 +906,46 @@ int cgmr_graph_message_from(cgmr_graph* g, int sender, int n_edges, const void* 
   std::vector<int32_t> acc(R, 0);
   int rc;
   if (g->ctx) {
-    // The receive buffer holds R wire buffers (1.7 MB for four robots at the reference's capacity); one message fills the
-    // header and two slices of one of them.  Only those travel: the headers of all blocks are cleared on the device (a
-    // block whose header does not carry its own index is ignored by k_wire_read), then the sender's header, its edges for me
-    // and its closure requests are copied in.  (Round 2 built and uploaded the whole 1.7 MB for every message.)
+    // One message: the host holds everything the decision needs (the end point ids are in the wire records), and widening
+    // 9 floats per edge is no work for it.  So nothing is read back: the accepted set's numbers go to the sender's staging
+    // slots (and to the host mirror of the staging), the slot list of the compact second segment follows, the gather is
+    // queued behind them -- no synchronisation.  (Round 2 built and uploaded the whole receive buffer, 1.7 MB for four
+    // robots, for every message; until the end of round 3 the message went through k_wire_read with a 109 KB read-back of
+    // ids per message: 156 us per call in the C4 leg.)
     cgmr_ctx* ctx = g->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t hdr_bytes = 4 * (size_t)(2 + 2 * R);
-    HIP_TRY(ctx, hipMemset2DAsync(g->d_recv, wb, 0, hdr_bytes, (size_t)R, ctx->stream));
-    std::vector<int32_t> hdr(2 + 2 * (size_t)R, 0);
-    hdr[0] = sender; hdr[1] = R;
-    hdr[2 + g->robot] = n_edges;
-    hdr[2 + R + g->robot] = n_closures;
-    unsigned char* blk = g->d_recv + (size_t)sender * wb;
-    HIP_TRY(ctx, hipMemcpyAsync(blk, hdr.data(), hdr_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (n_edges)
-      HIP_TRY(ctx, hipMemcpyAsync(blk + wire_edges_off(R) + (size_t)g->robot * cap * sizeof(WireEdge), edges44, (size_t)n_edges * sizeof(WireEdge),
-                                  hipMemcpyHostToDevice, ctx->stream));
-    if (n_closures)
-      HIP_TRY(ctx, hipMemcpyAsync(blk + wire_clos_off(R, cap) + (size_t)g->robot * cap * 4, closure_ids, (size_t)n_closures * 4,
-                                  hipMemcpyHostToDevice, ctx->stream));
-    rc = cgmr_graph_ingest(g, nullptr, acc.data());
+    hipStream_t st = ctx->stream;
+    std::vector<int32_t> ft(2 * (size_t)n_edges);
+    const unsigned char* eb = (const unsigned char*)edges44;
+    for (int k = 0; k < n_edges; k++) memcpy(&ft[2 * (size_t)k], eb + (size_t)k * sizeof(WireEdge), 8);   // from, to lead the record
+    static_assert(offsetof(WireEdge, from) == 0 && offsetof(WireEdge, to) == 4, "wire record layout");
+    const bool ok = ingest_decide_sender(g, sender, n_edges, ft.data(), n_closures, closure_ids);
+    rebuild_all_edges(g);
+    acc[sender] = ok ? (int32_t)g->in[sender].slot.size() : 0;
+    if (ok) {
+      if (g->msg_in_flight) { HIP_TRY(ctx, hipEventSynchronize(g->ev_msg)); g->msg_in_flight = false; }
+      double* pm = (double*)(g->pinned + g->pinned_msg_off);
+      double* pi = pm + 3 * (size_t)cap;
+      for (int k = 0; k < n_edges; k++) {
+        WireEdge w;
+        memcpy(&w, eb + (size_t)k * sizeof(WireEdge), sizeof w);
+        for (int a = 0; a < 3; a++) pm[3 * (size_t)k + a] = (double)w.est[a];
+        for (int a = 0; a < 6; a++) pi[6 * (size_t)k + a] = (double)w.info[a];
+      }
+      memcpy(g->hs_meas.data() + 3 * (size_t)sender * cap, pm, 24 * (size_t)n_edges);
+      memcpy(g->hs_info.data() + 6 * (size_t)sender * cap, pi, 48 * (size_t)n_edges);
+      g->hs_fresh[sender] = 1;
+      HIP_TRY(ctx, hipMemcpyAsync(g->d_stage_meas + 3 * (size_t)sender * cap, pm, 24 * (size_t)n_edges, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(g->d_stage_info + 6 * (size_t)sender * cap, pi, 48 * (size_t)n_edges, hipMemcpyHostToDevice, st));
+      int32_t* h_slot = (int32_t*)(g->pinned + round256(wb) + round256(4 * (size_t)R * (2 + 3 * (size_t)cap)));
+      int j = 0;
+      for (int s = 0; s < R; s++) for (int32_t sl : g->in[s].slot) h_slot[j++] = sl;
+      HIP_TRY(ctx, hipMemcpyAsync(g->d_slot, h_slot, 4 * (size_t)j, hipMemcpyHostToDevice, st));
+      launch_gather_edges(st, j, g->d_slot, g->d_stage_meas, g->d_stage_info, g->d_meas_b, g->d_info_b);
+      HIP_TRY(ctx, hipEventRecord(g->ev_msg, st));
+      g->msg_in_flight = true;
+    }
+    rc = CGMR_OK;
   } else {
     std::vector<unsigned char> buf((size_t)R * wb, 0);
     for (int s = 0; s < R; s++) {                               // every block needs its sender id; only one carries data
@@ -944,9 +980,10 @@ int cgmr_graph_received_edges(cgmr_graph* g, int peer, int cap, int32_t* from_id
     if (to_ids_out) to_ids_out[k] = g->ids[I.to_idx[k]];
   }
   if ((meas_out || info_upper_out) && n > 0) {
-    if (g->ctx) {
+    if (g->ctx && !g->hs_fresh[peer]) {
       cgmr_ctx* ctx = g->ctx;
       HIP_TRY(ctx, hipSetDevice(ctx->device));
+      // (a set that arrived through cgmr_graph_message_from is mirrored on the host: nothing to fetch)
       // only the staging slots this peer's edges occupy (round 2 fetched the staging of all peers: 650 KB per call at the
       // reference's capacity)
       size_t lo = (size_t)I.slot[0], hi = (size_t)I.slot[0] + 1;
