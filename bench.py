@@ -186,6 +186,15 @@ def team_leg(ctx, n_robots=4, n_steps=90):
             "max_distance_to_true_path_m": round(err, 4)}
 
 
+def team_leg_repeated(ctx, runs=3):
+    """The C4 leg `runs` times in this process (0.3 s each): the last run is the reported one, the rate of every run is
+    listed (the first one pays the growth of the context's arenas and cold host caches)."""
+    outs = [team_leg(ctx) for _ in range(runs)]
+    out = dict(outs[-1])
+    out["runs_key_frames_per_s"] = [o["key_frames_per_s"] for o in outs]
+    return out
+
+
 def matcher_leg(ctx, dev, args, with_cpu):
     """C3: batched closeScanMatching on synthetic 1081-beam scan pairs resident in HBM, all pairs distinct.  The first
     4096 are the numpy recipe's pairs (tests/golden/match_close4096.npz pins their results), the rest come from the
@@ -666,7 +675,7 @@ def main():
         "symbolic": {k: info[k] for k in ("fronts", "levels", "L_doubles", "U_doubles", "max_border", "factor_flops")},
         "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},
         "roofline": roofline, "cpu_baseline": cpu, "matcher": matcher, "exchange": exchange,
-        "team": (guarded("team", lambda: team_leg(ctx)) if world == 1 and not args.no_team else None),
+        "team": (guarded("team", lambda: team_leg_repeated(ctx)) if world == 1 and not args.no_team else None),
     }
     if cpu:
         out["speedup_vs_cpu_1thread"] = round(out["value"] / cpu["value"], 2)
