@@ -301,7 +301,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
 
 // `n` extra copies of the numeric work space of the uploaded structure (the structure arrays are shared): independent
 // numeric passes on the same graph -- one condensed graph per peer -- run concurrently on streams of their own.
-int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
+int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out, size_t* stride_out) {
   const Symbolic& S = ctx->sym;
   const GnDevice& D0 = ctx->gn;
   BlobLayout N;
@@ -314,6 +314,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out) {
   int rc = arena_reserve(ctx, ctx->rep_arena, per * (size_t)std::max(n, 1) + 256);
   if (rc) return rc;
   out.assign(n, D0);
+  if (stride_out) *stride_out = per;
   for (int i = 0; i < n; i++) {
     char* d = ctx->rep_arena.ptr + per * (size_t)i;
     GnDevice& D = out[i];
@@ -392,7 +393,7 @@ int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef,
 }
 
 int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et,
-                    int n_active, int slot, int nslots) {
+                    int n_active, int slot, int nslots, bool upload) {
   const Symbolic& S = ctx->sym;
   ctx->vmask.assign(S.nV, 0);
   if (fixed) for (int v = 0; v < S.nV; v++) ctx->vmask[v] = fixed[v] ? 1 : 0;
@@ -401,7 +402,7 @@ int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* f
     for (int k = 0; k < n_active; k++) { live[ef[k]] = 1; live[et[k]] = 1; }
     for (int v = 0; v < S.nV; v++) if (!live[v]) ctx->vmask[v] = 1;
   }
-  HIP_TRY(ctx, hipMemsetAsync(D.status, 0, 16, st));
+  if (upload) HIP_TRY(ctx, hipMemsetAsync(D.status, 0, 16, st));
   if (S.nf == 0) return 0;
   // several passes may be queued without a host synchronisation in between (one condensed graph per peer): each
   // stages its mask in a slot of its own
@@ -409,7 +410,16 @@ int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* f
   if (rc) return rc;
   char* pm = ctx->pinned_mask + (size_t)S.nf * slot;
   for (int c = 0; c < S.nf; c++) pm[c] = (char)ctx->vmask[S.perm[c]];
-  HIP_TRY(ctx, hipMemcpyAsync(D.cmask, pm, (size_t)S.nf, hipMemcpyHostToDevice, st));
+  if (upload) HIP_TRY(ctx, hipMemcpyAsync(D.cmask, pm, (size_t)S.nf, hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+// the passes of a batch (GnDevice::njobs) start from the masks staged in slots 0 .. njobs-1 and from clean status words
+int prepare_batch_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st) {
+  const Symbolic& S = ctx->sym;
+  HIP_TRY(ctx, hipMemset2DAsync(D.status, (size_t)D.job_stride, 0, 16, (size_t)D.njobs, st));
+  if (S.nf == 0) return 0;
+  HIP_TRY(ctx, hipMemcpy2DAsync(D.cmask, (size_t)D.job_stride, ctx->pinned_mask, (size_t)S.nf, (size_t)S.nf, (size_t)D.njobs, hipMemcpyHostToDevice, st));
   return 0;
 }
 
@@ -464,7 +474,10 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
   // (zeroing them for the next pass on a side stream underneath this pass's backward solve was measured slower: 5.79
   // instead of 5.47 ms per optimize(10) -- the 36 MB of writes slow the chained solve's hops more than the 8 us they hide)
   // ... but the top-block launch, one workgroup on an idle chip, clears them for the next pass with its other workgroups
-  if (D.pan_doubles > 0 && !D.pan_clean) (void)hipMemsetAsync(D.Pan, 0, sizeof(double) * (size_t)D.pan_doubles, st);
+  if (D.pan_doubles > 0 && !D.pan_clean) {
+    if (D.njobs > 1) (void)hipMemset2DAsync(D.Pan, (size_t)D.job_stride, 0, sizeof(double) * (size_t)D.pan_doubles, (size_t)D.njobs, st);
+    else (void)hipMemsetAsync(D.Pan, 0, sizeof(double) * (size_t)D.pan_doubles, st);
+  }
   D.pan_clean = false;
   T.run(1, 1, [&] { launch_assemble(st, D); });                // + the chi2 sum of this iteration (slot = iterations done)
   static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;
@@ -643,7 +656,8 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   size_t o_p = L.add(24 * (size_t)nV), o_m = L.add(24 * (size_t)nE), o_i = L.add(48 * (size_t)nE), o_qc = L.add(4 * (size_t)nq),
          o_qv = L.add(4 * (size_t)nq), o_Y = L.add(8 * (size_t)n * m), o_U = L.add(8 * ((size_t)3 * S.rows.size() + 3) * m),
          o_part = L.add(8 * (size_t)nchunk * 16 * m), o_G = L.add(8 * (size_t)16 * m), o_cov = L.add(72 * (size_t)nq),
-         o_est = L.add(24 * (size_t)nq), o_io = L.add(48 * (size_t)nq), o_fl = L.add(4 * (size_t)nq);
+         o_est = L.add(24 * (size_t)nq), o_io = L.add(48 * (size_t)nq), o_fl = L.add(4 * (size_t)nq),
+         o_live = L.add((size_t)std::max(ctx->gn.nfronts, 1) * (m / 16));
   rc = arena_reserve(ctx, ctx->io_arena, L.off + 256);
   if (rc) return rc;
   char* d = ctx->io_arena.ptr;
@@ -661,7 +675,7 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   Ed.meas_a = (const double*)(d + o_m); Ed.info_a = (const double*)(d + o_i); Ed.nA = nE; Ed.n_active = nE;
   gn_pass(ctx, dp, Ed, 0, false, mode == 2, /*write_l11c=*/true);
   launch_marginals(st, D, nq, (const int32_t*)(d + o_qc), m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part),
-                   (double*)(d + o_G), (double*)(d + o_cov), chunk, nchunk);
+                   (double*)(d + o_G), (double*)(d + o_cov), chunk, nchunk, (uint8_t*)(d + o_live));
   if (mode == 2)
     launch_label(st, nq, (const int32_t*)(d + o_qv), gauge, dp, (const double*)(d + o_cov), (double*)(d + o_est),
                  (double*)(d + o_io), (int*)(d + o_fl));

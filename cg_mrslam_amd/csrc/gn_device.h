@@ -31,6 +31,10 @@ struct GnDevice {
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
   int bwd_chain_level = 0;               // GN levels >= this one are solved backwards in one chained launch (k_solve_bwd<.., true>)
+  // a batch of passes on the same structure (gn_kernels.hip: CGMR_JOB): job j works in this view's numeric buffers moved by
+  // j * job_stride bytes, on the poses moved by j * pose_stride bytes; every launch gets a job dimension
+  int njobs = 1;
+  long long job_stride = 0, pose_stride = 0;
   // top block (k_top_block): the last fronts of the root's chain, handled by one workgroup in LDS
   int top_nfronts = 0, top_c0 = 0, top_ncols = 0, top_nchild = 0, top_nblk = 0;
   int32_t *top_fronts = nullptr, *top_children = nullptr, *top_blocks = nullptr;
@@ -61,9 +65,19 @@ int bwd_chain_capacity();
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);
 void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels);
 // marginals_kernels.hip
+// A batch of marginals / labelling passes, one per job of a batched GnDevice (D.njobs): job j's query list, Y, U, Gram and
+// covariance buffers are the first job's moved by j * marg_stride bytes; its query count, gauge and output slot come from
+// jobs[j] (device memory); est / info of job j go to the given pointers moved by out_slot * est_stride / info_stride bytes.
+struct CondJobDev { int32_t nq, gauge, gauge_id, out_slot; };
+struct MargBatch {
+  const CondJobDev* jobs = nullptr;
+  long long marg_stride = 0, est_stride = 0, info_stride = 0, wire_stride = 0;
+};
+// nK: the query count (batch: the largest of the jobs); batch == nullptr: one pass.  live: D.nfronts * (m / 16) bytes of
+// scratch (which fronts carry anything of a group of right-hand sides), no initialisation needed
 void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* d_qcol, int m, double* Y, double* Uv,
-                      double* part, double* G, double* cov, int chunk, int nchunk);
+                      double* part, double* G, double* cov, int chunk, int nchunk, uint8_t* live, const MargBatch* batch = nullptr);
 void launch_label(hipStream_t st, int nK, const int32_t* d_qvert, int gauge, const double* poses, const double* cov,
-                  double* est, double* info, int* flags);
+                  double* est, double* info, int* flags, const GnDevice* D = nullptr, const MargBatch* batch = nullptr);
 
 }  // namespace cgmr

@@ -12,9 +12,13 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
 int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int n_active, int slot,
                  int nslots);
 int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et,
-                    int n_active, int slot, int nslots);
-// n extra copies of the numeric work space of the uploaded structure; side streams for concurrent passes
-int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out);
+                    int n_active, int slot, int nslots, bool upload = true);
+// a batch of passes (D.njobs, D.job_stride): the masks staged with prepare_pass_on(.., slot j, njobs, upload = false) and
+// clean status words for every job, two 2-D copies
+int prepare_batch_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st);
+// n extra copies of the numeric work space of the uploaded structure (stride_out: bytes from one copy to the next); side
+// streams for concurrent passes
+int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out, size_t* stride_out = nullptr);
 int aux_streams(cgmr_ctx* ctx, int n);
 void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, const GnEdges& Ed, int it, bool chi_only,
                 bool solve_and_update, bool write_l11c);

@@ -67,6 +67,15 @@ __device__ __forceinline__ double d_normalize_theta(double t) {
 
 }  // namespace
 
+// Passes batched over a job dimension (blockIdx.z): the condensed graphs a robot builds for its peers are the same
+// structure with another gauge -- one launch per step serves all of them instead of one stream of launches each (the
+// device dispatches ~7 us per kernel when several short chains run side by side: 455 launches for 7 peers).  The numeric
+// work space of job j is the first job's moved by j * js bytes (cgmr_api.cpp: gn_replicas), its poses by j * ps bytes;
+// the structure is shared.
+// (Moving a kernel argument pointer costs the loads through it their no-alias / invariant standing -- 3 % of a whole solve
+// when tried unconditionally -- so the batch is a template parameter and a plain solve runs the code it always ran.)
+#define CGMR_JOB(p, stride) if constexpr (BATCH) p = (decltype(p))((unsigned long long)(p) + (unsigned long long)blockIdx.z * (unsigned long long)(stride))
+
 // ------------------------------------------------------------------------------ linearise
 // One thread per edge.  Writes the edge's quadratic-form terms as one 264-byte record per edge (term[edge * 33 + comp]):
 // the assembly gathers whole 3x3 blocks (9 adjacent threads read 72 contiguous bytes), and the three blocks an edge
@@ -81,11 +90,13 @@ __device__ __forceinline__ double d_normalize_theta(double t) {
 // device-resident robot graph keeps the edges received from other robots in a buffer of their own.  Edges
 // [n_active, nE) are switched off for this pass (the condensed graph is built on the robot's own edges only,
 // condensed_graph_buffer.cpp:347-366): they contribute exact zeros to H, b and chi2.
+template <bool BATCH>
 __global__ __launch_bounds__(256) void k_linearize(int nE, int nA, int n_active, const double* __restrict__ poses,
                                                    const int32_t* __restrict__ ef, const int32_t* __restrict__ et,
                                                    const double* __restrict__ meas, const double* __restrict__ info,
                                                    const double* __restrict__ meas_b, const double* __restrict__ info_b,
-                                                   double* __restrict__ term, int chi_only) {
+                                                   double* __restrict__ term, int chi_only, long long js, long long ps) {
+  CGMR_JOB(poses, ps); CGMR_JOB(term, js);
   __shared__ double s_chi[4];
   const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = k0 < n_active;
@@ -178,6 +189,7 @@ __device__ __forceinline__ void block_chi2_sum(int nP, const double* __restrict_
 // only and is reused whatever is fixed -- and are taken out of the system numerically: cmask[c] != 0 turns row /
 // column c of H into the identity and its right-hand side into zero, so its dx is exactly zero and nothing
 // couples to it.  The same mask removes vertices all of whose edges are switched off for this pass.
+template <bool BATCH>
 __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const int32_t* __restrict__ asm_ptr,
                                                   const int32_t* __restrict__ asm_src,
                                                   const int32_t* __restrict__ blk_dst,
@@ -189,7 +201,9 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
                                                   double* __restrict__ Pan,
                                                   double* __restrict__ bvec, double* __restrict__ chi_out,
                                                   const int* __restrict__ status, int nfronts,
-                                                  double* __restrict__ xvec) {
+                                                  double* __restrict__ xvec, long long js) {
+  CGMR_JOB(cmask, js); CGMR_JOB(term, js); CGMR_JOB(Ablk, js); CGMR_JOB(Pan, js); CGMR_JOB(bvec, js); CGMR_JOB(chi_out, js);
+  CGMR_JOB(status, js); CGMR_JOB(xvec, js);
   if (blockIdx.x == gridDim.x - 1) {
     block_chi2_sum((nE + 255) / 256, term + (size_t)33 * nE, chi_out + status[1]);   // chi2 before iteration status[1]
     return;
@@ -246,7 +260,9 @@ __device__ __forceinline__ void block_chi2_sum(int nP, const double* __restrict_
   if (threadIdx.x == 0) *out = sh[0];
 }
 
-__global__ __launch_bounds__(256) void k_chi2_reduce(int nP, const double* __restrict__ part, double* __restrict__ out) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_chi2_reduce(int nP, const double* __restrict__ part, double* __restrict__ out, long long js) {
+  CGMR_JOB(part, js); CGMR_JOB(out, js);
   block_chi2_sum(nP, part, out);
 }
 
@@ -305,10 +321,13 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 constexpr int kFT = 512;             // threads of a k_front_factor workgroup: 8 wavefronts (the elimination passes use as many as there are 48-row
                                      // groups, the MFMA updates, the loads and the stores all of them; 256 threads: +4k cycles per work item)
 constexpr int kPanLoads = (kFrontW + kMidChunkRows + 1) * (kPanStride / 2) / kFT + 1;   // 16-byte loads per thread and round: a 95-row chunk's panel in one round (8)
+template <bool BATCH>
 __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
                                                       const double* __restrict__ Pan, double* __restrict__ Lbuf,
                                                       double* __restrict__ yvec, double* __restrict__ uvec,
-                                                      int* __restrict__ status, int level_id, int write_l11c, int chunk_rows) {
+                                                      int* __restrict__ status, int level_id, int write_l11c, int chunk_rows,
+                                                      long long js) {
+  CGMR_JOB(Pan, js); CGMR_JOB(Lbuf, js); CGMR_JOB(yvec, js); CGMR_JOB(uvec, js); CGMR_JOB(status, js);
   CGMR_FRONT_CONSTS(kFrontW);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* P = reinterpret_cast<double*>(smem);
@@ -451,14 +470,15 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
 // Ubuf.  A cell of a panel copy is touched by one workgroup per launch -- siblings that share a launch write different
 // copies -- and launches are ordered, so the sums are bit-reproducible without atomics.  A front whose parent lies in
 // the top block (ppan_off < 0) stores the whole matrix in Ubuf: k_top_block assembles its block itself.
-template <int WW>
+template <int WW, bool BATCH>
 __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict__ work,
                                                       const int32_t* __restrict__ tiles, int tile_begin,
                                                       const FrontDesc* __restrict__ fronts,
                                                       const int32_t* __restrict__ children,
                                                       const int32_t* __restrict__ inv, const int32_t* __restrict__ rel,
                                                       const double* __restrict__ Lbuf, double* __restrict__ Ubuf,
-                                                      double* __restrict__ Pan, const double* __restrict__ uvec) {
+                                                      double* __restrict__ Pan, const double* __restrict__ uvec, long long js) {
+  CGMR_JOB(Lbuf, js); CGMR_JOB(Ubuf, js); CGMR_JOB(Pan, js); CGMR_JOB(uvec, js);
   CGMR_FRONT_CONSTS(WW);
   __shared__ double Ai[TS * LDW];
   __shared__ double Aj[TS * LDW];
@@ -620,6 +640,7 @@ constexpr int top_smem_bytes(int ncols) {
 }
 static_assert(kTopMaxCols % 16 == 0 && top_smem_bytes(kTopMaxCols) <= 160 * 1024, "top block exceeds the LDS");
 
+template <bool BATCH>
 __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfronts, const int32_t* __restrict__ top_fronts,
                                                     int nchild, const int32_t* __restrict__ top_children, int nblk,
                                                     const int32_t* __restrict__ top_blocks,
@@ -628,7 +649,9 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
                                                     const double* __restrict__ Ubuf, const double* __restrict__ uvec,
                                                     double* __restrict__ Lbuf, double* __restrict__ yvec,
                                                     double* __restrict__ xvec, int* __restrict__ status, int store_l,
-                                                    int write_l11c, double* __restrict__ zero_ptr, long long zero_n) {
+                                                    int write_l11c, double* __restrict__ zero_ptr, long long zero_n, long long js) {
+  CGMR_JOB(Ablk, js); CGMR_JOB(bvec, js); CGMR_JOB(Ubuf, js); CGMR_JOB(uvec, js); CGMR_JOB(Lbuf, js); CGMR_JOB(yvec, js);
+  CGMR_JOB(xvec, js); CGMR_JOB(status, js); CGMR_JOB(zero_ptr, js);
   if (blockIdx.x > 0) {
     // The top block is one workgroup; the chip is idle beside it.  The other workgroups of the launch clear the assembled
     // panels for the NEXT pass (nobody reads them any more in this one): the 8 us memset in front of every k_assemble goes.
@@ -756,11 +779,12 @@ constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define CGMR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-template <int WW, bool CHAIN>
+template <int WW, bool CHAIN, bool BATCH>
 __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
                                                    const double* __restrict__ yvec, double* xvec,
-                                                   int* status) {
+                                                   int* status, long long js) {
+  CGMR_JOB(Lbuf, js); CGMR_JOB(yvec, js); CGMR_JOB(xvec, js); CGMR_JOB(status, js);
   CGMR_FRONT_CONSTS(WW);
   constexpr int HP = W / 2;            // column pairs per row
   constexpr int G = 256 / HP;          // row groups of the border reduction (10 / 5)
@@ -921,10 +945,12 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
 }
 
 // poses (+)= dx  (VertexSE2::oplusImpl: translation added in the global frame, angle wrapped)
+template <bool BATCH>
 __global__ __launch_bounds__(256) void k_update_poses(int nV, const int32_t* __restrict__ vperm,
                                                       const uint8_t* __restrict__ cmask,
                                                       const double* __restrict__ xvec, double* __restrict__ poses,
-                                                      int* __restrict__ status) {
+                                                      int* __restrict__ status, long long js, long long ps) {
+  CGMR_JOB(cmask, js); CGMR_JOB(xvec, js); CGMR_JOB(status, js); CGMR_JOB(poses, ps);
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nV) return;
   const int failed = status[0];
@@ -941,21 +967,24 @@ __global__ __launch_bounds__(256) void k_update_poses(int nV, const int32_t* __r
 
 // ------------------------------------------------------------------------------ launchers
 
+// the instance of a kernel for a plain pass or a batch
+#define CGMR_KERN(D, name) ((D).njobs > 1 ? name<true> : name<false>)
+
 void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const GnEdges& Ed, int chi_only) {
   if (D.nE == 0) return;
   gn_init_kernels();
-  hipLaunchKernelGGL(k_linearize, dim3((D.nE + 255) / 256), dim3(256), chi_only ? 0 : 256 * 33 * sizeof(double), st, D.nE, Ed.nA, Ed.n_active, poses, D.ef, D.et,
-                     Ed.meas_a, Ed.info_a, Ed.meas_b, Ed.info_b, D.term, chi_only);
+  hipLaunchKernelGGL(CGMR_KERN(D, k_linearize), dim3((D.nE + 255) / 256, 1, D.njobs), dim3(256), chi_only ? 0 : 256 * 33 * sizeof(double), st, D.nE, Ed.nA, Ed.n_active, poses, D.ef, D.et,
+                     Ed.meas_a, Ed.info_a, Ed.meas_b, Ed.info_b, D.term, chi_only, D.job_stride, D.pose_stride);
 }
 
 void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
-  hipLaunchKernelGGL(k_chi2_reduce, dim3(1), dim3(256), 0, st, (D.nE + 255) / 256, D.term + (size_t)33 * D.nE, out);
+  hipLaunchKernelGGL(CGMR_KERN(D, k_chi2_reduce), dim3(1, 1, D.njobs), dim3(256), 0, st, (D.nE + 255) / 256, D.term + (size_t)33 * D.nE, out, D.job_stride);
 }
 
 void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
-  hipLaunchKernelGGL(k_assemble, dim3((total + 255) / 256 + 1), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.nfronts, D.xvec);
+  hipLaunchKernelGGL(CGMR_KERN(D, k_assemble), dim3((total + 255) / 256 + 1, 1, D.njobs), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
+                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.nfronts, D.xvec, D.job_stride);
 }
 
 // one-time kernel attributes (dynamic LDS above 64 KB): once per HIP device of the process (the attribute belongs to
@@ -965,12 +994,12 @@ void gn_init_kernels() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 63], [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              factor_smem_bytes(kChunkRows + 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              256 * 33 * (int)sizeof(double));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_block), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              top_smem_bytes(kTopMaxCols));
+    for (const void* f : {reinterpret_cast<const void*>(k_front_factor<false>), reinterpret_cast<const void*>(k_front_factor<true>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, factor_smem_bytes(kChunkRows + 1));
+    for (const void* f : {reinterpret_cast<const void*>(k_linearize<false>), reinterpret_cast<const void*>(k_linearize<true>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 33 * (int)sizeof(double));
+    for (const void* f : {reinterpret_cast<const void*>(k_top_block<false>), reinterpret_cast<const void*>(k_top_block<true>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, top_smem_bytes(kTopMaxCols));
   });
 }
 
@@ -978,23 +1007,23 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int l, bool write_l1
   gn_init_kernels();
   int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l];
   if (nw <= 0) return;                   // (a level emptied by the children's schedule: its fronts moved up)
-  hipLaunchKernelGGL(k_front_factor, dim3(nw), dim3(kFT), factor_smem_bytes(D.h_level_chrows[l]), st, D.work, D.h_work_ptr[l],
-                     D.Pan, D.Lbuf, D.yvec, D.uvec, D.status, l, write_l11c ? 1 : 0, D.h_level_chunk[l]);
+  hipLaunchKernelGGL(CGMR_KERN(D, k_front_factor), dim3(nw, 1, D.njobs), dim3(kFT), factor_smem_bytes(D.h_level_chrows[l]), st, D.work, D.h_work_ptr[l],
+                     D.Pan, D.Lbuf, D.yvec, D.uvec, D.status, l, write_l11c ? 1 : 0, D.h_level_chunk[l], D.job_stride);
 }
 
 void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
   int nt = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
   if (nt <= 0) return;
-  hipLaunchKernelGGL(k_front_update<kFrontW>, dim3(nt), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children,
-                     D.inv, D.rel, D.Lbuf, D.Ubuf, D.Pan, D.uvec);
+  hipLaunchKernelGGL((D.njobs > 1 ? k_front_update<kFrontW, true> : k_front_update<kFrontW, false>), dim3(nt, 1, D.njobs), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children,
+                     D.inv, D.rel, D.Lbuf, D.Ubuf, D.Pan, D.uvec, D.job_stride);
 }
 
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   gn_init_kernels();
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   if (nfr <= 0) return;
-  hipLaunchKernelGGL((k_solve_bwd<kFrontW, false>), dim3(nfr), dim3(256), bwd_smem_bytes(kFrontW, false), st, D.fronts_lv, D.h_level_ptr[l], D.rows,
-                     D.Lbuf, D.yvec, D.xvec, D.status);
+  hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, false, true> : k_solve_bwd<kFrontW, false, false>), dim3(nfr, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, false), st, D.fronts_lv, D.h_level_ptr[l], D.rows,
+                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride);
 }
 
 // Workgroups of the chained backward solve that are certainly resident together: the waits inside that launch must never
@@ -1009,7 +1038,7 @@ int bwd_chain_capacity() {
   dev &= 63;
   std::call_once(once[dev], [dev] {
     int nb = 0, ncu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_solve_bwd<kFrontW, true>), 256,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_solve_bwd<kFrontW, true, false>), 256,
                                                      bwd_smem_bytes(kFrontW, true)) != hipSuccess) nb = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
     cap[dev] = std::max(0, std::min(nb, 4)) * ncu;
@@ -1022,23 +1051,23 @@ void launch_bwd_chain(hipStream_t st, const GnDevice& D) {
   gn_init_kernels();
   const int first = D.h_level_ptr[D.bwd_chain_level], last = D.h_level_ptr[D.nlevels];
   if (last <= first) return;
-  hipLaunchKernelGGL((k_solve_bwd<kFrontW, true>), dim3(last - first), dim3(256), bwd_smem_bytes(kFrontW, true), st, D.fronts_lv, last - 1, D.rows,
-                     D.Lbuf, D.yvec, D.xvec, D.status);
+  hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, true, true> : k_solve_bwd<kFrontW, true, false>), dim3(last - first, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, true), st, D.fronts_lv, last - 1, D.rows,
+                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride);
 }
 
 void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels) {
   gn_init_kernels();
   if (D.top_nfronts <= 0) return;
   const bool zero = clear_panels && D.pan_doubles > 0;
-  hipLaunchKernelGGL(k_top_block, dim3(zero ? 1 + 240 : 1), dim3(256), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols,
+  hipLaunchKernelGGL(CGMR_KERN(D, k_top_block), dim3(zero ? 1 + 240 : 1, 1, D.njobs), dim3(256), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols,
                      D.top_nfronts, D.top_fronts, D.top_nchild, D.top_children, D.top_nblk, D.top_blocks, D.fronts, D.rows, D.Ablk,
                      D.bvec, D.Ubuf, D.uvec, D.Lbuf, D.yvec, D.xvec, D.status, store_l ? 1 : 0, write_l11c ? 1 : 0, D.Pan,
-                     (long long)D.pan_doubles);
+                     (long long)D.pan_doubles, D.job_stride);
 }
 
 void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
-  hipLaunchKernelGGL(k_update_poses, dim3((D.nV + 255) / 256), dim3(256), 0, st, D.nV, D.vperm, D.cmask, D.xvec, poses,
-                     D.status);
+  hipLaunchKernelGGL(CGMR_KERN(D, k_update_poses), dim3((D.nV + 255) / 256, 1, D.njobs), dim3(256), 0, st, D.nV, D.vperm, D.cmask, D.xvec, poses,
+                     D.status, D.job_stride, D.pose_stride);
 }
 
 }  // namespace cgmr

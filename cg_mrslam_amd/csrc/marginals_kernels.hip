@@ -32,8 +32,14 @@ __device__ __forceinline__ double d_norm_theta(double t) {
 }
 }  // namespace
 
+// job dimension (blockIdx.z) of a batch of passes: gn_device.h MargBatch, gn_kernels.hip CGMR_JOB
+#define CGMR_MJOB(p, stride) p = (decltype(p))((unsigned long long)(p) + (unsigned long long)blockIdx.z * (unsigned long long)(stride))
+#define CGMR_MSLOT(p, slot, stride) p = (decltype(p))((unsigned long long)(p) + (unsigned long long)(slot) * (unsigned long long)(stride))
+
 // E[3*vperm[q]+a][4k+a] = 1 for query k (others zero); Y is n x m row-major, 4 columns per query, m padded to 16
-__global__ void k_marg_init_rhs(int nK, const int32_t* __restrict__ qcol, int m, double* __restrict__ Y) {
+__global__ void k_marg_init_rhs(int nK, const int32_t* __restrict__ qcol, int m, double* __restrict__ Y,
+                                const CondJobDev* __restrict__ jobs, long long ms) {
+  if (jobs) { nK = jobs[blockIdx.z].nq; CGMR_MJOB(qcol, ms); CGMR_MJOB(Y, ms); }
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nK) return;
   int c = qcol[k];
@@ -44,25 +50,45 @@ __global__ void k_marg_init_rhs(int nK, const int32_t* __restrict__ qcol, int m,
 
 // Forward solve L Y = E for MB right-hand sides at a time: grid (fronts of the level, m / MB).
 // thread = (column c = tid % 16, row lane g = tid / 16).  W = panel width of the level (gn_kernels.hip).
-template <int W>
+template <int W, bool BATCH>
 __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __restrict__ fronts,
                                                          const int32_t* __restrict__ level_fronts, int level_begin,
                                                          const int32_t* __restrict__ children,
                                                          const int32_t* __restrict__ rel, const int32_t* __restrict__ inv,
                                                          const double* __restrict__ Lbuf, int m,
-                                                         double* __restrict__ Y, double* __restrict__ Uv) {
+                                                         double* __restrict__ Y, double* __restrict__ Uv,
+                                                         uint8_t* __restrict__ live, long long js, long long ms) {
+  if constexpr (BATCH) { CGMR_MJOB(Lbuf, js); CGMR_MJOB(Y, ms); CGMR_MJOB(Uv, ms); CGMR_MJOB(live, ms); }
   constexpr int kL11c = W * W, kDinv = 2 * W * W, kL21 = 2 * W * W + W;
   __shared__ double t1[W][MB + 1];
   const int tid = threadIdx.x;
   const int c = tid & 15, g = tid >> 4;
   const int col = blockIdx.y * MB + c;
-  const FrontDesc F = fronts[level_fronts[level_begin + blockIdx.x]];
+  const int fid = level_fronts[level_begin + blockIdx.x];
+  const FrontDesc F = fronts[fid];
   const int w = 3 * F.nc, r = 3 * F.ns;
   const double* P = Lbuf + F.L_off;
-  for (int j = g; j < W; j += 16) t1[j][c] = (j < w) ? Y[(size_t)(3 * F.c0 + j) * m + col] : 0.0;
-  __syncthreads();
+  // The right-hand sides are unit columns: a group of 16 of them is all zero in every front that is not on the way from one
+  // of its 4 query poses to the root.  live[front][group] says whether the front produced anything for the group; a front
+  // whose own rows are zero and whose children all reported nothing reports nothing and stops here -- its rows of Y stay
+  // zero, its border vector is never read (most workgroups of the lower levels: 6 jobs x 13 groups x 100 fronts per launch).
+  const int ngroups = gridDim.y;
+  int any = 0;
+  for (int j = g; j < W; j += 16) {
+    const double v = (j < w) ? Y[(size_t)(3 * F.c0 + j) * m + col] : 0.0;
+    t1[j][c] = v;
+    any |= v != 0.0;
+  }
+  for (int ci = 0; ci < F.nchild; ci++) any |= live[(size_t)children[F.child_off + ci] * ngroups + blockIdx.y];
+  if (!__syncthreads_or(any)) {
+    if (tid == 0) live[(size_t)fid * ngroups + blockIdx.y] = 0;
+    return;
+  }
+  if (tid == 0) live[(size_t)fid * ngroups + blockIdx.y] = 1;
   for (int ci = 0; ci < F.nchild; ci++) {
-    const FrontDesc G = fronts[children[F.child_off + ci]];
+    const int child = children[F.child_off + ci];
+    if (!live[(size_t)child * ngroups + blockIdx.y]) continue;                 // (uniform: nothing came up from this child)
+    const FrontDesc G = fronts[child];
     const double* ug = Uv + (size_t)3 * G.rows_off * m;
     const int ra = 3 * G.na;
     for (int q = g; q < ra; q += 16) t1[3 * rel[G.rel_off + q / 3] + q % 3][c] += ug[(size_t)q * m + col];
@@ -81,7 +107,9 @@ __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __rest
   for (int p = g; p < r; p += 16) {
     double acc = 0;
     for (int ci = 0; ci < F.nchild; ci++) {
-      const FrontDesc G = fronts[children[F.child_off + ci]];
+      const int child = children[F.child_off + ci];
+      if (!live[(size_t)child * ngroups + blockIdx.y]) continue;
+      const FrontDesc G = fronts[child];
       int kb = inv[G.inv_off + p / 3];
       if (kb >= 0) acc += Uv[((size_t)3 * G.rows_off + 3 * kb + p % 3) * m + col];
     }
@@ -100,7 +128,8 @@ __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __rest
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_gram_diag_partial(int n, int m, int chunk, const double* __restrict__ Y,
-                                                           double* __restrict__ part) {
+                                                           double* __restrict__ part, long long ms) {
+  CGMR_MJOB(Y, ms); CGMR_MJOB(part, ms);
   __shared__ double red[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = m / 16;
@@ -123,7 +152,8 @@ __global__ __launch_bounds__(256) void k_gram_diag_partial(int n, int m, int chu
 }
 
 // G[I][row][col] = sum over the row chunks, in chunk order
-__global__ void k_gram_diag_reduce(int T, int nchunk, const double* __restrict__ part, double* __restrict__ G) {
+__global__ void k_gram_diag_reduce(int T, int nchunk, const double* __restrict__ part, double* __restrict__ G, long long ms) {
+  CGMR_MJOB(part, ms); CGMR_MJOB(G, ms);
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)T * 256;
   if (q >= total) return;
@@ -133,7 +163,9 @@ __global__ void k_gram_diag_reduce(int T, int nchunk, const double* __restrict__
 }
 
 // cov_out[k] = the 3x3 block of query k inside its diagonal tile (4 queries per tile, 4 columns per query)
-__global__ void k_marg_extract(int nK, const double* __restrict__ G, double* __restrict__ cov) {
+__global__ void k_marg_extract(int nK, const double* __restrict__ G, double* __restrict__ cov,
+                               const CondJobDev* __restrict__ jobs, long long ms) {
+  if (jobs) { nK = jobs[blockIdx.z].nq; CGMR_MJOB(G, ms); CGMR_MJOB(cov, ms); }
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nK * 9) return;
   const int k = q / 9, e = q - 9 * k;
@@ -144,7 +176,14 @@ __global__ void k_marg_extract(int nK, const double* __restrict__ G, double* __r
 // EdgeLabeler::labelEdge for star edges gauge -> v (SURVEY.md Appendix A [g2o-recalled]); one thread per edge.
 __global__ void k_label_edges(int nK, const int32_t* __restrict__ qvert, int gauge, const double* __restrict__ poses,
                               const double* __restrict__ cov, double* __restrict__ est, double* __restrict__ info,
-                              int* __restrict__ flags) {
+                              int* __restrict__ flags, const CondJobDev* __restrict__ jobs, long long ms, long long ps,
+                              long long est_stride, long long info_stride) {
+  if (jobs) {
+    const CondJobDev J = jobs[blockIdx.z];
+    nK = J.nq; gauge = J.gauge;
+    CGMR_MJOB(qvert, ms); CGMR_MJOB(cov, ms); CGMR_MJOB(flags, ms); CGMR_MJOB(poses, ps);
+    CGMR_MSLOT(est, J.out_slot, est_stride); CGMR_MSLOT(info, J.out_slot, info_stride);
+  }
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nK) return;
   const double* xg = poses + 3 * (size_t)gauge;
@@ -219,26 +258,33 @@ __global__ void k_label_edges(int nK, const int32_t* __restrict__ qvert, int gau
 
 // ----------------------------------------------------------------------------------- launchers
 void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* d_qcol, int m, double* Y, double* Uv,
-                      double* part, double* G, double* cov, int chunk, int nchunk) {
-  (void)hipMemsetAsync(Y, 0, sizeof(double) * (size_t)3 * D.nf * m, st);
-  hipLaunchKernelGGL(k_marg_init_rhs, dim3((nK + 127) / 128), dim3(128), 0, st, nK, d_qcol, m, Y);
+                      double* part, double* G, double* cov, int chunk, int nchunk, uint8_t* live, const MargBatch* batch) {
+  const int nj = batch ? D.njobs : 1;
+  const long long ms = batch ? batch->marg_stride : 0, js = batch ? D.job_stride : 0;
+  const CondJobDev* jd = batch ? batch->jobs : nullptr;
+  if (batch) (void)hipMemset2DAsync(Y, (size_t)ms, 0, sizeof(double) * (size_t)3 * D.nf * m, (size_t)nj, st);
+  else (void)hipMemsetAsync(Y, 0, sizeof(double) * (size_t)3 * D.nf * m, st);
+  hipLaunchKernelGGL(k_marg_init_rhs, dim3((nK + 127) / 128, 1, nj), dim3(128), 0, st, nK, d_qcol, m, Y, jd, ms);
   for (int l = 0; l < D.nlevels_full; l++) {            // every front, the top block's included
     int nfr = D.h_flevel_ptr[l + 1] - D.h_flevel_ptr[l];
     if (nfr <= 0) continue;                              // (a level emptied by the children's schedule)
-    auto kern = k_solve_fwd_multi<kFrontW>;
-    hipLaunchKernelGGL(kern, dim3(nfr, m / MB), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_flevel_ptr[l], D.children,
-                       D.rel, D.inv, D.Lbuf, m, Y, Uv);
+    auto kern = batch ? k_solve_fwd_multi<kFrontW, true> : k_solve_fwd_multi<kFrontW, false>;
+    hipLaunchKernelGGL(kern, dim3(nfr, m / MB, nj), dim3(256), 0, st, D.fronts, D.level_fronts, D.h_flevel_ptr[l], D.children,
+                       D.rel, D.inv, D.Lbuf, m, Y, Uv, live, js, ms);
   }
   const int T = m / 16;
-  hipLaunchKernelGGL(k_gram_diag_partial, dim3(T, nchunk), dim3(256), 0, st, 3 * D.nf, m, chunk, Y, part);
-  hipLaunchKernelGGL(k_gram_diag_reduce, dim3((T * 256 + 255) / 256), dim3(256), 0, st, T, nchunk, part, G);
-  hipLaunchKernelGGL(k_marg_extract, dim3((nK * 9 + 255) / 256), dim3(256), 0, st, nK, G, cov);
+  hipLaunchKernelGGL(k_gram_diag_partial, dim3(T, nchunk, nj), dim3(256), 0, st, 3 * D.nf, m, chunk, Y, part, ms);
+  hipLaunchKernelGGL(k_gram_diag_reduce, dim3((T * 256 + 255) / 256, 1, nj), dim3(256), 0, st, T, nchunk, part, G, ms);
+  hipLaunchKernelGGL(k_marg_extract, dim3((nK * 9 + 255) / 256, 1, nj), dim3(256), 0, st, nK, G, cov, jd, ms);
 }
 
 void launch_label(hipStream_t st, int nK, const int32_t* d_qvert, int gauge, const double* poses, const double* cov,
-                  double* est, double* info, int* flags) {
+                  double* est, double* info, int* flags, const GnDevice* D, const MargBatch* batch) {
   if (nK <= 0) return;
-  hipLaunchKernelGGL(k_label_edges, dim3((nK + 63) / 64), dim3(64), 0, st, nK, d_qvert, gauge, poses, cov, est, info, flags);
+  const bool b = batch && D;
+  hipLaunchKernelGGL(k_label_edges, dim3((nK + 63) / 64, 1, b ? D->njobs : 1), dim3(64), 0, st, nK, d_qvert, gauge, poses, cov, est, info, flags,
+                     b ? batch->jobs : nullptr, b ? batch->marg_stride : 0, b ? D->pose_stride : 0, b ? batch->est_stride : 0,
+                     b ? batch->info_stride : 0);
 }
 
 }  // namespace cgmr

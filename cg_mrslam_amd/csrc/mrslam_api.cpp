@@ -434,7 +434,8 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   rc = aux_streams(ctx, nstreams);
   if (rc) return rc;
   std::vector<GnDevice> reps;
-  rc = gn_replicas(ctx, nj, reps);
+  size_t rep_stride = 0;
+  rc = gn_replicas(ctx, nj, reps, &rep_stride);
   if (rc) return rc;
   rc = dev_grow(g, g->d_work, 0, 24 * (size_t)nV * nj);
   if (rc) return rc;
@@ -447,9 +448,11 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   const size_t o_qc = L.add(4 * (size_t)maxq), o_qv = L.add(4 * (size_t)maxq), o_Y = L.add(8 * (size_t)n * m_max),
                o_U = L.add(8 * ((size_t)3 * S.rows.size() + 3) * m_max), o_part = L.add(8 * (size_t)nchunk * 16 * m_max),
                o_G = L.add(8 * (size_t)16 * m_max), o_cov = L.add(72 * (size_t)maxq), o_fl = L.add(4 * (size_t)maxq),
-               o_e64 = L.add(24 * (size_t)maxq), o_i64 = L.add(48 * (size_t)maxq), o_st = L.add(16);
+               o_e64 = L.add(24 * (size_t)maxq), o_i64 = L.add(48 * (size_t)maxq), o_st = L.add(16),
+               o_live = L.add((size_t)std::max(ctx->gn.nfronts, 1) * (m_max / 16));
   const size_t per_job = (L.off + 255) & ~size_t(255);
-  rc = arena_reserve(ctx, ctx->mg_arena, per_job * (size_t)nj + 256);
+  const size_t o_jd = per_job * (size_t)nj;                      // job descriptors of a batched run behind the jobs' blocks
+  rc = arena_reserve(ctx, ctx->mg_arena, o_jd + sizeof(CondJobDev) * (size_t)nj + 256);
   if (rc) return rc;
   GnEdges Ed;
   Ed.meas_a = (const double*)g->d_meas_a.ptr; Ed.info_a = (const double*)g->d_info_a.ptr;
@@ -470,6 +473,100 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     t_guess = wall_s() - tg0;
   }
   WireEdge* send_edges = reinterpret_cast<WireEdge*>(g->d_send + wire_edges_off(g->n_robots));
+  // Several passes: ONE sequence of launches with a job dimension (gn_kernels.hip CGMR_JOB) instead of a stream of ~65
+  // launches per job side by side -- next to each other the device dispatched the small kernels of 7 jobs at ~7 us apiece
+  // (3.9 ms for the condensed graphs of a round with 8 robots); CGMR_COND_BATCH=0: the streams
+  static const bool batch_on = !(getenv("CGMR_COND_BATCH") && atoi(getenv("CGMR_COND_BATCH")) == 0);
+  const bool batched = batch_on && nj > 1 && nf > 0;
+  std::vector<int32_t> status(nj, 0);
+  if (batched) {
+    // staging (the context's mask block: nothing else is in flight from it): masks | initial guesses | query columns |
+    // query vertices | job descriptors
+    auto up256 = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t s_work = up256((size_t)nf * nj), s_qc = s_work + up256((size_t)24 * nV * nj), s_qv = s_qc + up256((size_t)4 * maxq * nj),
+                 s_jd = s_qv + up256((size_t)4 * maxq * nj), s_st = s_jd + up256(sizeof(CondJobDev) * (size_t)nj), s_end = s_st + 4 * (size_t)nj;
+    rc = pinned_mask_reserve(ctx, s_end);
+    if (rc) return rc;
+    GnDevice DB = reps[0];
+    DB.njobs = nj; DB.job_stride = (long long)rep_stride; DB.pose_stride = 24LL * nV;
+    // the chained backward solve needs its workgroups resident together: the chain of the batch takes nj times the slots
+    {
+      const int cap_blocks = bwd_chain_capacity() / nj;
+      DB.bwd_chain_level = DB.nlevels;
+      while (DB.bwd_chain_level > 0 && DB.h_level_ptr[DB.nlevels] - DB.h_level_ptr[DB.bwd_chain_level - 1] <= cap_blocks) DB.bwd_chain_level--;
+    }
+    const double tm0 = wall_s();
+    for (int i = 0; i < nj; i++) {
+      std::fill(fixed.begin(), fixed.end(), 0);
+      fixed[jobs[i].gauge] = 1;
+      rc = prepare_pass_on(ctx, reps[i], st, fixed.data(), nE, s_ef.data(), s_et.data(), nA, i, nj, /*upload=*/false);
+      if (rc) return rc;
+      char* h = ctx->pinned_mask;
+      memcpy(h + s_work + (size_t)24 * nV * i, works[i].data(), (size_t)24 * nV);
+      const int nq = (int)jobs[i].q.size();
+      int32_t* qc = (int32_t*)(h + s_qc) + (size_t)maxq * i;
+      int32_t* qv = (int32_t*)(h + s_qv) + (size_t)maxq * i;
+      for (int k = 0; k < nq; k++) { qc[k] = ctx->vmask[jobs[i].q[k]] ? -1 : S.vperm[jobs[i].q[k]]; qv[k] = jobs[i].q[k]; }
+      CondJobDev& jd = ((CondJobDev*)(h + s_jd))[i];
+      jd.nq = nq; jd.gauge = jobs[i].gauge; jd.gauge_id = g->ids[jobs[i].gauge]; jd.out_slot = to_wire ? jobs[i].peer : i;
+    }
+    t_mask = wall_s() - tm0;
+    const double tu0 = wall_s();
+    char* h = ctx->pinned_mask;
+    char* d0 = ctx->mg_arena.ptr;
+    double* d_work0 = (double*)g->d_work.ptr;
+    rc = prepare_batch_on(ctx, DB, st);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_work0, h + s_work, (size_t)24 * nV * nj, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpy2DAsync(d0 + o_qc, per_job, h + s_qc, 4 * (size_t)maxq, 4 * (size_t)maxq, (size_t)nj, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpy2DAsync(d0 + o_qv, per_job, h + s_qv, 4 * (size_t)maxq, 4 * (size_t)maxq, (size_t)nj, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d0 + o_jd, h + s_jd, sizeof(CondJobDev) * (size_t)nj, hipMemcpyHostToDevice, st));
+    t_up = wall_s() - tu0;
+    hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (trace) for (auto& e : evs) (void)hipEventCreate(&e);
+    if (trace) (void)hipEventRecord(evs[0], st);
+    const double tp0 = wall_s();
+    gn_pass_on(ctx, DB, st, d_work0, Ed, 0, false, true, /*write_l11c=*/true);
+    const double tp1 = wall_s();
+    t_gn = tp1 - tp0;
+    if (trace) (void)hipEventRecord(evs[1], st);
+    MargBatch MBt;
+    MBt.jobs = (const CondJobDev*)(d0 + o_jd);
+    MBt.marg_stride = (long long)per_job;
+    double *est0, *info0;
+    if (to_wire) { est0 = g->d_est64; info0 = g->d_info64; MBt.est_stride = 24LL * cap; MBt.info_stride = 48LL * cap; MBt.wire_stride = (long long)sizeof(WireEdge) * cap; }
+    else { est0 = (double*)(d0 + o_e64); info0 = (double*)(d0 + o_i64); MBt.est_stride = MBt.info_stride = (long long)per_job; }
+    launch_marginals(st, DB, maxq, (const int32_t*)(d0 + o_qc), m_max, (double*)(d0 + o_Y), (double*)(d0 + o_U), (double*)(d0 + o_part),
+                     (double*)(d0 + o_G), (double*)(d0 + o_cov), chunk, nchunk, (uint8_t*)(d0 + o_live), &MBt);
+    if (trace) (void)hipEventRecord(evs[2], st);
+    launch_label(st, maxq, (const int32_t*)(d0 + o_qv), 0, d_work0, (const double*)(d0 + o_cov), est0, info0, (int*)(d0 + o_fl), &DB, &MBt);
+    if (to_wire)
+      launch_wire_write_edges(st, maxq, 0, (const int32_t*)(d0 + o_qv), (const int32_t*)g->d_vids.ptr, est0, info0, send_edges, nj, &MBt);
+    if (trace) (void)hipEventRecord(evs[3], st);
+    HIP_TRY(ctx, hipMemcpy2DAsync(h + s_st, 4, DB.status, (size_t)DB.job_stride, 4, (size_t)nj, hipMemcpyDeviceToHost, st));
+    t_marg = wall_s() - tp1;
+    if (info_out) info_out->assign(nj, {});
+    for (int i = 0; i < nj && info_out && !to_wire; i++) {
+      (*info_out)[i].resize(6 * jobs[i].q.size());
+      HIP_TRY(ctx, hipMemcpyAsync((*info_out)[i].data(), d0 + per_job * (size_t)i + o_i64, 48 * jobs[i].q.size(), hipMemcpyDeviceToHost, st));
+    }
+    const double tt2 = wall_s();
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    memcpy(status.data(), h + s_st, 4 * (size_t)nj);
+    if (trace) {
+      float a = 0, b = 0, c = 0;
+      (void)hipEventElapsedTime(&a, evs[0], evs[1]); (void)hipEventElapsedTime(&b, evs[1], evs[2]); (void)hipEventElapsedTime(&c, evs[2], evs[3]);
+      fprintf(stderr, "[cond]   device: GN pass %.0f us, marginals %.0f us (m %d, %d levels), labels + wire %.0f us\n", 1e3 * a, 1e3 * b, m_max, DB.nlevels_full, 1e3 * c);
+      for (auto& e : evs) (void)hipEventDestroy(e);
+    }
+    if (trace)
+      fprintf(stderr, "[cond] %d jobs in one batch, nV %d nE %d: structure %.0f us, queueing %.0f us (initial guesses %.0f, masks %.0f, uploads %.0f, GN pass %.0f, marginals + labels %.0f), waiting %.0f us\n",
+              nj, nV, nE, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * t_up, 1e6 * t_gn, 1e6 * t_marg, 1e6 * (wall_s() - tt2));
+    for (int i = 0; i < nj; i++)
+      if (status[i] != 0) return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
+    return 0;
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->aux_fork, st));
   for (int k = 0; k < nstreams; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->aux_fork, 0));
   for (int i = 0; i < nj; i++) {
@@ -503,7 +600,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     t_gn += tp1 - tp0;
     const int m = ((4 * nq + 15) / 16) * 16;
     launch_marginals(sj, D, nq, d_qc, m, (double*)(d + o_Y), (double*)(d + o_U), (double*)(d + o_part), (double*)(d + o_G),
-                     (double*)(d + o_cov), chunk, nchunk);
+                     (double*)(d + o_cov), chunk, nchunk, (uint8_t*)(d + o_live));
     double* est64 = to_wire ? g->d_est64 + 3 * (size_t)cap * J.peer : (double*)(d + o_e64);
     double* info64 = to_wire ? g->d_info64 + 6 * (size_t)cap * J.peer : (double*)(d + o_i64);
     launch_label(sj, nq, d_qv, J.gauge, d_work, (const double*)(d + o_cov), est64, info64, (int*)(d + o_fl));
@@ -517,7 +614,6 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     HIP_TRY(ctx, hipEventRecord(ctx->aux_done[k], ctx->aux[k]));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->aux_done[k], 0));
   }
-  std::vector<int32_t> status(nj, 0);
   if (info_out) info_out->assign(nj, {});
   for (int i = 0; i < nj; i++) {
     char* d = ctx->mg_arena.ptr + per_job * (size_t)i;

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "gn_device.h"
+
 namespace cgmr {
 
 // EdgeArrayMessage::ESE2Data as it travels (src/mrslam/msg_factory.h:200-205, doubles narrowed to float32 by
@@ -24,7 +26,7 @@ inline size_t wire_edges_off(int n_robots) { return 4 * (size_t)(2 + 2 * n_robot
 inline size_t wire_clos_off(int n_robots, int cap) { return wire_edges_off(n_robots) + (size_t)n_robots * cap * sizeof(WireEdge); }
 
 void launch_wire_write_edges(hipStream_t st, int n, int from_id, const int32_t* to_vertex, const int32_t* vertex_ids,
-                             const double* est, const double* info, WireEdge* out);
+                             const double* est, const double* info, WireEdge* out, int njobs = 1, const MargBatch* batch = nullptr);
 void launch_wire_read(hipStream_t st, int n_ranks, int cap, int me, size_t wire_bytes, const unsigned char* recv,
                       double* stage_meas, double* stage_info, int32_t* ids_out);
 void launch_gather_edges(hipStream_t st, int n, const int32_t* slot, const double* src_meas, const double* src_info,

@@ -15,9 +15,20 @@
 namespace cgmr {
 
 // condensed edges of one peer, labelled in FP64 (k_label_edges) -> 44-byte wire records in the send buffer
+// (batch: job blockIdx.z of gn_device.h MargBatch -- its count, gauge id and the peer whose slices it fills from jobs[z])
 __global__ void k_wire_write_edges(int n, int from_id, const int32_t* __restrict__ to_vertex,
                                    const int32_t* __restrict__ vertex_ids, const double* __restrict__ est,
-                                   const double* __restrict__ info, WireEdge* __restrict__ out) {
+                                   const double* __restrict__ info, WireEdge* __restrict__ out,
+                                   const CondJobDev* __restrict__ jobs, long long ms, long long est_stride,
+                                   long long info_stride, long long wire_stride) {
+  if (jobs) {
+    const CondJobDev J = jobs[blockIdx.z];
+    n = J.nq; from_id = J.gauge_id;
+    to_vertex = (const int32_t*)((const char*)to_vertex + (long long)blockIdx.z * ms);
+    est = (const double*)((const char*)est + (long long)J.out_slot * est_stride);
+    info = (const double*)((const char*)info + (long long)J.out_slot * info_stride);
+    out = (WireEdge*)((char*)out + (long long)J.out_slot * wire_stride);
+  }
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   WireEdge w;
@@ -85,9 +96,11 @@ __global__ void k_gather_poses(int n, const int32_t* __restrict__ idx, const dou
 }
 
 void launch_wire_write_edges(hipStream_t st, int n, int from_id, const int32_t* to_vertex, const int32_t* vertex_ids,
-                             const double* est, const double* info, WireEdge* out) {
+                             const double* est, const double* info, WireEdge* out, int njobs, const MargBatch* batch) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_wire_write_edges, dim3((n + 127) / 128), dim3(128), 0, st, n, from_id, to_vertex, vertex_ids, est, info, out);
+  hipLaunchKernelGGL(k_wire_write_edges, dim3((n + 127) / 128, 1, batch ? njobs : 1), dim3(128), 0, st, n, from_id, to_vertex, vertex_ids, est,
+                     info, out, batch ? batch->jobs : nullptr, batch ? batch->marg_stride : 0, batch ? batch->est_stride : 0,
+                     batch ? batch->info_stride : 0, batch ? batch->wire_stride : 0);
 }
 
 void launch_wire_read(hipStream_t st, int n_ranks, int cap, int me, size_t wire_bytes, const unsigned char* recv,
