@@ -22,6 +22,8 @@
 
 namespace cgmr {
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 namespace {
 constexpr int MB = 16;            // right-hand sides per workgroup in the multi-RHS forward solve
 
@@ -48,8 +50,8 @@ __global__ void k_marg_init_rhs(int nK, const int32_t* __restrict__ qcol, int m,
   for (int a = 0; a < 3; a++) Y[(size_t)(3 * c + a) * m + 4 * k + a] = 1.0;
 }
 
-// Forward solve L Y = E for MB right-hand sides at a time: grid (fronts of the level, m / MB).
-// thread = (column c = tid % 16, row lane g = tid / 16).  W = panel width of the level (gn_kernels.hip).
+// Forward solve L Y = E for MB right-hand sides at a time: grid (fronts of the level, m / MB [, jobs]).
+// thread = (column c = tid % 16, row lane g = tid / 16) for the loads and stores.  W = panel width (gn_kernels.hip).
 template <int W, bool BATCH>
 __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __restrict__ fronts,
                                                          const int32_t* __restrict__ level_fronts, int level_begin,
@@ -61,6 +63,10 @@ __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __rest
   if constexpr (BATCH) { CGMR_MJOB(Lbuf, js); CGMR_MJOB(Y, ms); CGMR_MJOB(Uv, ms); CGMR_MJOB(live, ms); }
   constexpr int kL11c = W * W, kDinv = 2 * W * W, kL21 = 2 * W * W + W;
   __shared__ double t1[W][MB + 1];
+  __shared__ double sL[W * W + W];
+  constexpr int kLiveCap = 64;
+  __shared__ int s_live[kLiveCap][4];                   // rows_off, rel_off, inv_off, na of the live children
+  __shared__ int s_nlive;
   const int tid = threadIdx.x;
   const int c = tid & 15, g = tid >> 4;
   const int col = blockIdx.y * MB + c;
@@ -79,44 +85,101 @@ __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __rest
     t1[j][c] = v;
     any |= v != 0.0;
   }
-  for (int ci = 0; ci < F.nchild; ci++) any |= live[(size_t)children[F.child_off + ci] * ngroups + blockIdx.y];
+  // the children that reported something for this group, in child order, with what the loops below need of them (a group
+  // is 4 query poses: at most 4 children of a front are live, whatever the front's fan-out -- the star centres of received
+  // condensed graphs sit on fronts with 75 children; walking all of them per border row was most of a level's time)
+  if (tid < 64) {
+    int cnt = 0;
+    for (int base = 0; base < F.nchild; base += 64) {
+      const int ci = base + tid;
+      const int child = ci < F.nchild ? children[F.child_off + ci] : -1;
+      const bool on = child >= 0 && live[(size_t)child * ngroups + blockIdx.y] != 0;
+      const unsigned long long mask = __ballot(on);
+      if (on) {
+        const int pos = cnt + __popcll(mask & ((1ull << tid) - 1ull));
+        if (pos < kLiveCap) {
+          const FrontDesc G = fronts[child];
+          s_live[pos][0] = G.rows_off; s_live[pos][1] = G.rel_off; s_live[pos][2] = G.inv_off; s_live[pos][3] = G.na;
+        }
+      }
+      cnt += __popcll(mask);
+    }
+    if (tid == 0) s_nlive = cnt;
+  }
   if (!__syncthreads_or(any)) {
-    if (tid == 0) live[(size_t)fid * ngroups + blockIdx.y] = 0;
-    return;
+    if (s_nlive == 0) {
+      if (tid == 0) live[(size_t)fid * ngroups + blockIdx.y] = 0;
+      return;
+    }
   }
+  const int nlive = s_nlive;
+  if (nlive > kLiveCap) __builtin_trap();                                        // (cannot happen: see above)
   if (tid == 0) live[(size_t)fid * ngroups + blockIdx.y] = 1;
-  for (int ci = 0; ci < F.nchild; ci++) {
-    const int child = children[F.child_off + ci];
-    if (!live[(size_t)child * ngroups + blockIdx.y]) continue;                 // (uniform: nothing came up from this child)
-    const FrontDesc G = fronts[child];
-    const double* ug = Uv + (size_t)3 * G.rows_off * m;
-    const int ra = 3 * G.na;
-    for (int q = g; q < ra; q += 16) t1[3 * rel[G.rel_off + q / 3] + q % 3][c] += ug[(size_t)q * m + col];
+  for (int ci = 0; ci < nlive; ci++) {
+    const double* ug = Uv + (size_t)3 * s_live[ci][0] * m;
+    const int ra = 3 * s_live[ci][3], rel_off = s_live[ci][1];
+    for (int q = g; q < ra; q += 16) t1[3 * rel[rel_off + q / 3] + q % 3][c] += ug[(size_t)q * m + col];
     __syncthreads();
   }
-  for (int j = 0; j < w; j++) {
-    double yj = t1[j][c] * P[kDinv + j];
-    __syncthreads();
-    if (g == 0) t1[j][c] = yj;
-    for (int i = j + 1 + g; i < w; i += 16) t1[i][c] -= P[kL11c + j * W + i] * yj;
-    __syncthreads();
+  // L11 (its column-major copy) and 1 / diagonal into LDS; what lies outside the front's w columns as zeros
+  for (int e = tid; e < W * W; e += 256) {
+    const int jc = e / W, ir = e - jc * W;
+    sL[e] = (ir < w && jc < w) ? P[kL11c + e] : 0.0;
   }
-  for (int j = g; j < w; j += 16) Y[(size_t)(3 * F.c0 + j) * m + col] = t1[j][c];
+  if (tid < W) sL[W * W + tid] = tid < w ? P[kDinv + tid] : 0.0;
+  __syncthreads();
+  // The triangular solve of the 16 columns in ONE wavefront, no barriers: lane = (column c, quarter q) keeps rows 4 s + q of
+  // its column in registers (all W steps run: beyond the front's w columns they multiply zeros); step j: the owner's t[j] / L[j][j] goes to the column's other three lanes through a lane
+  // shuffle, every lane updates its rows below j.  (Round 1-3: all 256 threads, two barriers per pivot -- 96 barriers,
+  // 30 us of the 60 us a level of the multi-RHS solve took.)
+  if (tid < 64) {
+    constexpr int R = W / 4;
+    const int q = tid >> 4;
+    double t[R];
+#pragma unroll
+    for (int sI = 0; sI < R; sI++) t[sI] = t1[4 * sI + q][c];
+#pragma unroll
+    for (int jj = 0; jj < W; jj++) {
+      const int sj = jj >> 2, qj = jj & 3;
+      const double cand = t[sj] * sL[W * W + jj];
+      const double yj = __shfl(cand, qj * 16 + c, 64);
+      const double lsame = sL[jj * W + 4 * sj + q];
+      t[sj] = q == qj ? yj : (q > qj ? t[sj] - lsame * yj : t[sj]);
+#pragma unroll
+      for (int sI = sj + 1; sI < R; sI++) t[sI] -= sL[jj * W + 4 * sI + q] * yj;
+    }
+#pragma unroll
+    for (int sI = 0; sI < R; sI++) t1[4 * sI + q][c] = t[sI];
+  }
+  __syncthreads();
+  for (int jr = g; jr < w; jr += 16) Y[(size_t)(3 * F.c0 + jr) * m + col] = t1[jr][c];
+  // border rows: uf = (children's border vectors) - L21 y, the product as 16 x 16 tiles on v_mfma_f64_16x16x4_f64
+  // (A[i = lane & 15][k = lane >> 4] = L21 rows, B[k = lane >> 4][j = lane & 15] = y, D[i = (lane >> 4) + 4 rg][j = lane & 15])
   const double* L21 = P + kL21;
   double* uf = Uv + (size_t)3 * F.rows_off * m;
-  for (int p = g; p < r; p += 16) {
-    double acc = 0;
-    for (int ci = 0; ci < F.nchild; ci++) {
-      const int child = children[F.child_off + ci];
-      if (!live[(size_t)child * ngroups + blockIdx.y]) continue;
-      const FrontDesc G = fronts[child];
-      int kb = inv[G.inv_off + p / 3];
-      if (kb >= 0) acc += Uv[((size_t)3 * G.rows_off + 3 * kb + p % 3) * m + col];
+  const int lane = tid & 63, wave = tid >> 6, kk = lane >> 4, ii = lane & 15;
+  for (int p0 = 16 * wave; p0 < r; p0 += 64) {
+    double4_t accm = {0, 0, 0, 0};
+    const int prow = p0 + ii;
+    const double* rowp = L21 + (size_t)prow * W;
+#pragma unroll
+    for (int k0 = 0; k0 < W; k0 += 4) {
+      const int k = k0 + kk;
+      const double a = (prow < r && k < w) ? rowp[k] : 0.0;
+      accm = __builtin_amdgcn_mfma_f64_16x16x4f64(a, t1[k][ii], accm, 0, 0, 0);
     }
-    const double* row = L21 + (size_t)p * W;
-    double dot = 0;
-    for (int k = 0; k < w; k++) dot += row[k] * t1[k][c];
-    uf[(size_t)p * m + col] = acc - dot;
+    const int ocol = blockIdx.y * MB + ii;
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int pr = p0 + kk + 4 * rg;
+      if (pr >= r) continue;
+      double acc = 0;
+      for (int ci = 0; ci < nlive; ci++) {
+        const int kb = inv[s_live[ci][2] + pr / 3];
+        if (kb >= 0) acc += Uv[((size_t)3 * s_live[ci][0] + 3 * kb + pr % 3) * m + ocol];
+      }
+      uf[(size_t)pr * m + ocol] = acc - accm[rg];
+    }
   }
 }
 
@@ -125,8 +188,6 @@ __global__ __launch_bounds__(256) void k_solve_fwd_multi(const FrontDesc* __rest
 // order.  A and B operands are the same 4 x 16 slice of Y:
 //   lane l holds Y[k0 + (l >> 4)][16 I + (l & 15)]
 //   C/D: 4 doubles per lane, element (row = (l >> 4) + 4 * reg, col = l & 15)
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
 __global__ __launch_bounds__(256) void k_gram_diag_partial(int n, int m, int chunk, const double* __restrict__ Y,
                                                            double* __restrict__ part, long long ms) {
   CGMR_MJOB(Y, ms); CGMR_MJOB(part, ms);
