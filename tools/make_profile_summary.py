@@ -14,12 +14,13 @@ if not pmc_only:
     open(f"{P}/{rnd}_bench_line.json", "w").write(line)
     # kernel stats (shortened names)
     rows = list(csv.DictReader(open(f"{O}/bench_kernel_stats.csv")))
-    with open(f"{P}/{rnd}_bench_kernel_stats.csv", "w") as f:
-        f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
+    with open(f"{P}/{rnd}_bench_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)                      # (template arguments carry commas: quoted fields)
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent", "min_ns", "max_ns"])
         for r in rows:
             name = r["Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
             if len(name) > 60: name = name[:57] + "..."
-            f.write(f'{name},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.1f},{float(r["Percentage"]):.3f},{r["MinNs"]},{r["MaxNs"]}\n')
+            w.writerow([name, r["Calls"], r["TotalDurationNs"], f'{float(r["AverageNs"]):.1f}', f'{float(r["Percentage"]):.3f}', r["MinNs"], r["MaxNs"]])
 # PMC summary: avg per launch per (kernel, counter)
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
 def newest_per_pass(pattern):
@@ -34,10 +35,11 @@ for path in newest_per_pass(f"{O}/*/*/*counter_collection.csv"):
         k = r["Kernel_Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
         if "rocclr" in k or "at::" in k: continue
         acc[(k, r["Counter_Name"])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
-with open(f"{P}/{rnd}_pmc_summary.csv", "w") as f:
-    f.write("kernel,counter,launches,avg_per_launch\n")
+with open(f"{P}/{rnd}_pmc_summary.csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "launches", "avg_per_launch"])
     for (k, c) in sorted(acc):
-        f.write(f"{k},{c},{n[(k, c)]},{acc[(k, c)] / n[(k, c)]:.1f}\n")
+        w.writerow([k, c, n[(k, c)], f"{acc[(k, c)] / n[(k, c)]:.1f}"])
 def avg(k, c):
     # per-launch average over every instance of the kernel (k_front_factor<48>, k_front_factor_leaf, ...)
     keys = [q for q in acc if q[1] == c and (q[0] == k or q[0].startswith(k + "<") or q[0].startswith(k + "_"))]
