@@ -120,6 +120,64 @@ def test_three_robot_rounds_match_oracle_backend(ctx, oracle):
     assert pairs >= 4                                       # most ordered pairs exchanged condensed graphs
 
 
+_BATCH_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, 'tests')
+from cg_mrslam_amd import synth, Context
+from cg_mrslam_amd.condensed import RobotGraph
+from cg_mrslam_amd.mrslam import RobotRounds, RobotWorld, run_rounds_loopback
+import test_multirobot_gpu as T
+nr = 4
+R = T._meeting_world(nr, 900, 3000, min_shared=4)
+ctx = Context(0)
+rounds = T._rounds(lambda r: RobotGraph(ctx, r, nr), R, 150, nr)
+log = run_rounds_loopback(rounds, 6)
+out = {}
+for r in range(nr):
+    out['wire%d' % r] = np.frombuffer(rounds[r].g.pack_host(), dtype=np.uint8).copy()
+    out['poses%d' % r] = rounds[r].g.poses()
+    for q in range(nr):
+        if q != r:
+            gid, to, est, iu = rounds[r].g.condensed(q)
+            out['to%d_%d' % (r, q)] = np.asarray(to); out['est%d_%d' % (r, q)] = np.asarray(est); out['iu%d_%d' % (r, q)] = np.asarray(iu)
+out['built'] = np.array([b for (_, b, _) in log], dtype=np.int64)
+np.savez(sys.argv[1], **out)
+print('rounds ok')
+"""
+
+
+def test_condensed_graphs_as_one_batch_equal_the_passes_on_streams(tmp_path):
+    """The condensed graphs of a round run as ONE batch of launches with a job dimension (mrslam_api.cpp run_cond_jobs); with
+    CGMR_COND_BATCH=0 every pass gets its stream of launches as in round 2.  Four robots x 6 rounds each way (the switch is
+    read once per process: two children): same graphs built, same requested vertices, condensed edges and poses equal to
+    rounding (the batch splits the backward solve's chained launch at another level: other summation order in the border
+    reductions), the float32 wire records equal to a float32 ulp."""
+    res = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / ("batch%s.npz" % mode))
+        env = dict(os.environ, CGMR_COND_BATCH=mode, PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", _BATCH_CHILD, path], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "rounds ok" in r.stdout, r.stderr[-2000:]
+        res[mode] = dict(np.load(path))
+    a, b = res["1"], res["0"]
+    assert sorted(a) == sorted(b) and np.array_equal(a["built"], b["built"]) and a["built"].sum() > 10
+    n_edges = 0
+    for k in a:
+        if k.startswith("to"):
+            assert np.array_equal(a[k], b[k])
+            n_edges += len(a[k])
+        elif k.startswith("wire"):
+            assert a[k].shape == b[k].shape
+            fa, fb = a[k][: len(a[k]) // 4 * 4].view(np.float32), b[k][: len(b[k]) // 4 * 4].view(np.float32)
+            ia, ib = a[k][: len(a[k]) // 4 * 4].view(np.int32), b[k][: len(b[k]) // 4 * 4].view(np.int32)
+            same = ia == ib
+            ok = np.isfinite(fa) & np.isfinite(fb)
+            assert np.all(same | (ok & (np.abs(fa - fb) <= 2e-6 * np.maximum(1e-3, np.abs(fb)))))   # ints equal; floats to an ulp or two
+        elif len(a[k]):
+            assert np.abs(a[k] - b[k]).max() <= 1e-9 * max(1.0, np.abs(b[k]).max()), k
+    assert n_edges > 30
+
+
 def test_c5_shape_eight_robots_loopback_properties(ctx):
     """BASELINE.json C5 at its real shape on one GPU: 8 robots x 5000 vertices, a round every 50 vertices, R = 8 wire slices
     of 128 edges (49 KB per robot), 24 rounds in loopback.  No oracle at this size: properties -- every robot with requests
