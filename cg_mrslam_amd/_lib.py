@@ -184,6 +184,12 @@ class Context:
         """Reuse of the ordering / symbolic analysis / structure upload across calls on the same edge list (default on)."""
         self._check(self.lib.cgmr_set_symbolic_cache(self.h, C.c_int(1 if on else 0)))
 
+    def host_threads_info(self):
+        """Threads behind the symbolic analysis: {threads, pinned, home_cpu, cpus_allowed} (cgmr_host_threads_info)."""
+        out = np.zeros(4, dtype=np.int32)
+        self._check(self.lib.cgmr_host_threads_info(_ptr(out)))
+        return {"threads": int(out[0]), "pinned": bool(out[1]), "home_cpu": int(out[2]), "cpus_allowed": int(out[3])}
+
     def symbolic_cache_stats(self):
         out = np.zeros(3, dtype=np.int64)
         self._check(self.lib.cgmr_symbolic_cache_stats(self.h, _ptr(out)))

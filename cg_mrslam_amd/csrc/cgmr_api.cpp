@@ -875,6 +875,14 @@ int cgmr_set_symbolic_cache(cgmr_ctx* ctx, int on) {
   return CGMR_OK;
 }
 
+int cgmr_host_threads_info(int32_t out[4]) {
+  if (!out) return CGMR_E_INVALID;
+  int v[4];
+  host_pool_info(v);
+  for (int k = 0; k < 4; k++) out[k] = v[k];
+  return CGMR_OK;
+}
+
 int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[3]) {
   if (!ctx || !out) return CGMR_E_INVALID;
   out[0] = ctx->sym_hits; out[1] = ctx->sym_misses; out[2] = ctx->sym_extended;

@@ -49,6 +49,7 @@ class HelperPool {
     for (auto& t : threads_) t.join();
   }
   int helpers() const { return (int)threads_.size(); }
+  int home_cpu() const { return home_.empty() ? -1 : home_[0]; }
   // run `job` on a helper if one is idle, else right here; wait() returns when it is done
   void run(Job& job) {
     job.done.store(0, std::memory_order_relaxed);
@@ -61,8 +62,25 @@ class HelperPool {
     pending_.fetch_add(1, std::memory_order_release);
     cv_.notify_one();
   }
-  static void wait(Job& job) {
-    while (!job.done.load(std::memory_order_acquire)) std::this_thread::yield();
+  // Returns when `job` is done.  While it is not, the waiting thread takes queued jobs nobody has started yet (this one or
+  // any other) and runs them itself: a helper whose core is busy with somebody else's work -- the GPU boxes are shared --
+  // then costs its share of the section, not a scheduler time slice.
+  static void wait(Job& job);
+  void help_until(Job& job) {
+    static const bool steal = !(getenv("CGMR_HOST_STEAL") && atoi(getenv("CGMR_HOST_STEAL")) == 0);
+    while (!job.done.load(std::memory_order_acquire)) {
+      Job* other = nullptr;
+      if (steal && pending_.load(std::memory_order_acquire) > 0 && getpid() == owner_) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!queue_.empty()) { other = queue_.front(); queue_.erase(queue_.begin()); pending_.fetch_sub(1); }
+      }
+      if (other) {
+        other->fn();
+        other->done.store(1, std::memory_order_release);
+      } else {
+        std::this_thread::yield();
+      }
+    }
   }
 
  private:
@@ -211,6 +229,7 @@ HelperPool& pool() {
   static HelperPool p(host_threads() - 1);
   return p;
 }
+void HelperPool::wait(Job& job) { pool().help_until(job); }
 
 // ------------------------------------------------------------------ nested dissection
 // Recursive bisection by breadth-first level structures: pick the level that splits the
@@ -526,6 +545,20 @@ int host_threads() {
   }();
   return n;
 }
+
+}  // namespace
+
+void host_pool_info(int out[4]) {
+  HelperPool& p = pool();
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  out[0] = p.helpers() + 1;
+  out[1] = p.home_cpu() >= 0 ? 1 : 0;
+  out[2] = p.home_cpu();
+  out[3] = sched_getaffinity(0, sizeof allowed, &allowed) == 0 ? CPU_COUNT(&allowed) : -1;
+}
+
+namespace {
 
 // ------------------------------------------------------------------ incremental ordering
 // The previous dissection tree extended by the vertices prev.nf .. nf-1 (gn_symbolic.h: Symbolic::NDNode).  A vertex may live

@@ -220,6 +220,21 @@ def test_elimination_tree_valid_special_shapes():
     _assert_valid_elimination_tree(600, fixed, ef, et)
 
 
+def test_host_threads_info_reports_the_pool_as_it_runs():
+    """cgmr_host_threads_info: thread count as CGMR_HOST_THREADS / the core count give it, a home CPU exactly when pinned, a
+    home the process may run on (what the bench line carries as `host_pool`)."""
+    import ctypes as C
+    lib = _lib.load_library()
+    out = (C.c_int32 * 4)()
+    assert lib.cgmr_host_threads_info(out) == 0
+    threads, pinned, home, allowed = list(out)
+    assert 1 <= threads <= 16 and allowed == len(os.sched_getaffinity(0))
+    assert (home >= 0) == bool(pinned)
+    if pinned:
+        assert home in os.sched_getaffinity(0)
+    assert lib.cgmr_host_threads_info(None) != 0
+
+
 def test_symbolic_analysis_leaves_the_callers_affinity_alone():
     """The analysis holds the calling thread on its home core while it runs (the helper threads sit around it); the
     affinity mask must be the caller's own again afterwards, whatever the analysis did, and also in a child process started
