@@ -875,6 +875,14 @@ int cgmr_set_symbolic_cache(cgmr_ctx* ctx, int on) {
   return CGMR_OK;
 }
 
+}  // extern "C"
+namespace cgmr {
+// gn_symbolic.cpp: the helper pool as it runs -- threads an analysis uses (caller included), 1 if the helpers are pinned around
+// a last-level cache, the caller's home CPU while it analyses (-1: not pinned), CPUs the process may use
+void host_pool_info(int out[4]);
+}
+extern "C" {
+
 int cgmr_host_threads_info(int32_t out[4]) {
   if (!out) return CGMR_E_INVALID;
   int v[4];

@@ -149,9 +149,6 @@ struct Symbolic {
 // sets); otherwise fixed vertices are eliminated structurally.
 // task(0) .. task(n - 1) on the analysis' helper threads (blocking)
 void host_run_tasks(int n, const std::function<void(int)>& task);
-// the helper pool as it runs: out[0] = threads an analysis uses (caller included), out[1] = 1 if the helpers are pinned
-// around a last-level cache, out[2] = the caller's home CPU while it analyses (-1: not pinned), out[3] = CPUs the process may use
-void host_pool_info(int out[4]);
 
 // prev (nullable): the analysis of a graph whose edge list is a prefix of this one and whose vertices are the first
 // prev->nV of this one's -- the ordering is then extended instead of recomputed where that is possible (S.extended);
