@@ -32,6 +32,23 @@ def test_marginals_match_oracle(ctx, oracle, V, E, nq):
         assert np.all(np.linalg.eigvalsh(cov[k]) > 0)
 
 
+@pytest.mark.parametrize("K,Lc,H,nq", [(40, 30, 1, 30), (100, 12, 2, 90)])
+def test_marginals_on_hub_graphs(ctx, oracle, K, Lc, H, nq):
+    """Fronts with dozens of children (100 chains on 2 hubs: more children than one 64-lane scan of the multi-RHS forward
+    solve's live-children list takes in), queries spread over many chains: most (front, group) pairs carry nothing, the live
+    ones collect from one child among many."""
+    from cg_mrslam_amd._lib import gn_symbolic_info
+    g = synth.make_hub_graph(K, Lc, H)
+    assert gn_symbolic_info(len(g["poses"]), g["fixed"], g["edge_from"], g["edge_to"])["max_children"] > (64 if K >= 100 else 8)
+    p, a = _opt(ctx, g, iters=5)
+    V = len(g["poses"])
+    query = np.unique(np.linspace(0, V - 2, nq).astype(np.int32))
+    cov = ctx.marginals(p, g["fixed"], *a, query)
+    st, want = oracle.marginals(p, g["fixed"], *a, query)
+    assert st == 0
+    assert np.abs(cov - want).max() <= 1e-6 * np.abs(want).max()
+
+
 def test_covariance_estimate_matches_oracle(ctx, oracle):
     g = synth.make_pose_graph(800, 2600, seed=44)
     p, a = _opt(ctx, g)
