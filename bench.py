@@ -149,7 +149,7 @@ def maybe_spawn(args):
 
 
 # ----------------------------------------------------------------------------------------------- matcher leg (C3)
-def team_leg(ctx, n_robots=4, n_steps=90):
+def team_leg(ctx, n_robots=4, n_steps=90, concurrent=False):
     """C4: the cg_mrslam node in sim modality, four robots in one process on this GPU (each a device-resident robot
     graph + the GPU matchers; inter-robot closures through batched global / verify matching, condensed graphs exchanged
     as the reference's own messages).  Reported, not part of `value`."""
@@ -161,6 +161,9 @@ def team_leg(ctx, n_robots=4, n_steps=90):
     la = (team[0]["n_beams"], team[0]["angle_min"], team[0]["angle_inc"], team[0]["max_range"])
     slams = []
     for r in range(n_robots):
+        if concurrent:                                           # a context (stream, arenas, analysis cache) per robot, a thread each
+            from cg_mrslam_amd import Context
+            ctx = Context(0)
         s = MRGraphSLAMDriver(ctx, ScanMatcher(ctx, *la), LCScanMatcher(ctx, *la),
                               RobotGraph(ctx, r, n_robots, cap_edges=RobotGraph.REFERENCE_CAP_EDGES), r, n_robots,
                               windowLoopClosure=5, minInliers=4)
@@ -169,7 +172,7 @@ def team_leg(ctx, n_robots=4, n_steps=90):
         slams.append(s)
     comm = GraphCommSim(slams)
     t0 = time.perf_counter()
-    loops = run_cg_mrslam(slams, team, comm=comm, linearUpdate=0.5)
+    loops = run_cg_mrslam(slams, team, comm=comm, linearUpdate=0.5, concurrent=concurrent)
     dt = time.perf_counter() - t0
     kf = sum(lp.key_frames for lp in loops)
     err = 0.0
@@ -192,6 +195,12 @@ def team_leg_repeated(ctx, runs=3):
     outs = [team_leg(ctx) for _ in range(runs)]
     out = dict(outs[-1])
     out["runs_key_frames_per_s"] = [o["key_frames_per_s"] for o in outs]
+    # the same team with a context and a thread per robot between the communication cycles (what one process per robot
+    # does; `key_frames_per_s` above is the robots one after the other on one context)
+    conc = [team_leg(ctx, concurrent=True) for _ in range(2)]
+    same = all(conc[-1][k] == out[k] for k in ("key_frames", "messages_delivered", "bytes_sent", "inter_robot_edges", "condensed_edges_held"))
+    out["one_thread_per_robot"] = {"key_frames_per_s": conc[-1]["key_frames_per_s"], "runs_key_frames_per_s": [o["key_frames_per_s"] for o in conc],
+                                   "same_key_frames_messages_and_edges": bool(same)}
     return out
 
 

@@ -175,6 +175,10 @@ class HelperPool {
    public:
     explicit CallerAtHome(HelperPool& p) {
       if (p.home_.empty()) return;
+      // one caller at a time: a second thread of the process that analyses meanwhile (a context per robot, a thread each)
+      // stays where it is instead of queueing up for the same core
+      if (p.home_busy_.exchange(true, std::memory_order_acquire)) return;
+      pool_ = &p;
       if (sched_getaffinity(0, sizeof saved_, &saved_) != 0) return;
       cpu_set_t home;
       CPU_ZERO(&home);
@@ -183,12 +187,16 @@ class HelperPool {
       if (!any) return;                                          // (the caller may not run there: leave it alone)
       active_ = sched_setaffinity(0, sizeof home, &home) == 0;
     }
-    ~CallerAtHome() { if (active_) (void)sched_setaffinity(0, sizeof saved_, &saved_); }
+    ~CallerAtHome() {
+      if (active_) (void)sched_setaffinity(0, sizeof saved_, &saved_);
+      if (pool_) pool_->home_busy_.store(false, std::memory_order_release);
+    }
     CallerAtHome(const CallerAtHome&) = delete;
     CallerAtHome& operator=(const CallerAtHome&) = delete;
    private:
     cpu_set_t saved_;
     bool active_ = false;
+    HelperPool* pool_ = nullptr;
   };
 
  private:
@@ -215,6 +223,7 @@ class HelperPool {
   }
   std::vector<std::thread> threads_;
   std::vector<int> home_;                // the caller's core while it analyses (empty: the helpers are not pinned)
+  std::atomic<bool> home_busy_{false};   // a caller is held there right now
   std::vector<Job*> queue_;
   std::mutex mu_;
   std::condition_variable cv_;

@@ -442,15 +442,22 @@ class GraphCommSim:
         self.senders = [_Sender(s, comm_range) for s in slams]
         self.delivered = 0
 
-    def cycle(self, truth_now):
+    def cycle(self, truth_now, pool=None):
+        """pool (a ``concurrent.futures`` executor, optional): the robots build their outboxes side by side, then process
+        their queues side by side -- what one process per robot does; every robot needs a context of its own then.  Same
+        messages in the same per-robot order either way."""
+        run = (lambda f, xs: list(pool.map(f, xs))) if pool is not None else (lambda f, xs: [f(x) for x in xs])
         queues = [[] for _ in self.slams]
-        for snd in self.senders:
-            for dest, b in snd.outbox(truth_now):
+        for out in run(lambda snd: snd.outbox(truth_now), self.senders):
+            for dest, b in out:
                 queues[dest].append(b)
-        for s, q in zip(self.slams, queues):                     # receiveFromThrd + processQueueThrd
+
+        def process(sq):                                         # receiveFromThrd + processQueueThrd
+            s, q = sq
             for b in q:
                 s.addInterRobotData(from_bytes(b), s.lastVertex())
-                self.delivered += 1
+            return len(q)
+        self.delivered += sum(run(process, list(zip(self.slams, queues))))
 
 
 def pack_outbox(out, cap_bytes):
@@ -520,19 +527,30 @@ class GraphCommRanks:
                     self.delivered += 1
 
 
-def run_cg_mrslam(slams, trajectories, comm=None, linearUpdate=0.25, angularUpdate=math.pi / 4, iterations=5, n_steps=None):   # noqa: N803
+def run_cg_mrslam(slams, trajectories, comm=None, linearUpdate=0.25, angularUpdate=math.pi / 4, iterations=5, n_steps=None,   # noqa: N803
+                  concurrent=False):
     """``cg_mrslam -modality sim`` for several robots in one process: every robot's main loop ticks through its recorded
     trajectory (``odom``, ``scans``, ``truth``), a communication cycle after every tick.  Returns the ``RobotLoop``s."""
     loops = [RobotLoop(s, tr["odom"], tr["scans"], tr["truth"][0], linearUpdate, angularUpdate, iterations)
              for s, tr in zip(slams, trajectories)]
     comm = comm or GraphCommSim(slams)
     n = min(len(tr["odom"]) for tr in trajectories) if n_steps is None else n_steps
-    for k in range(1, n):
+    if not concurrent:
+        for k in range(1, n):
+            for lp in loops:
+                lp.tick(k)
+            comm.cycle([tr["truth"][k] for tr in trajectories])
         for lp in loops:
-            lp.tick(k)
-        comm.cycle([tr["truth"][k] for tr in trajectories])
-    for lp in loops:
-        lp.finish()
+            lp.finish()
+        return loops
+    # one thread per robot between the communication cycles (the C-ABI calls release the interpreter lock): the robots of the
+    # reference are processes of their own.  Every robot must have been built on a context of its own.
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(loops)) as pool:
+        for k in range(1, n):
+            list(pool.map(lambda lp: lp.tick(k), loops))
+            comm.cycle([tr["truth"][k] for tr in trajectories], pool=pool)
+        list(pool.map(lambda lp: lp.finish(), loops))
     return loops
 
 

@@ -125,6 +125,25 @@ def test_four_robots_c4_sim_modality_matches_oracle_backend(ctx, oracle):
     print(f"4 robots: GPU run {t_gpu:.1f} s, {comm_a.delivered} messages")
 
 
+def test_four_robots_a_thread_and_a_context_each_equal_the_sequential_run(ctx):
+    """run_cg_mrslam(concurrent=True): between the communication cycles every robot ticks on a thread of its own (the C-ABI
+    calls release the interpreter lock), on a context of its own -- what one process per robot does.  Same key frames,
+    messages, closures and logs as the robots one after the other on one context; estimates to the Gauss-Newton tolerance
+    (a context of its own extends its cached ordering as the graph grows: another elimination order)."""
+    from cg_mrslam_amd import Context
+    team = synth.make_robot_team(4, n_steps=90, laps=0.21, gap=3.0, body=0.5)
+    la = (team[0]["n_beams"], team[0]["angle_min"], team[0]["angle_inc"], team[0]["max_range"])
+    a, comm_a, _ = _run(ctx, team, True, detect=True)
+    b = [_make(Context(0), r, 4, la, True) for r in range(4)]
+    for s in b:
+        s.setDetectRobotInRange(True)
+    comm_b = GraphCommSim(b)
+    run_cg_mrslam(b, team, comm=comm_b, linearUpdate=0.5, concurrent=True)
+    assert comm_a.delivered == comm_b.delivered > 100
+    assert [s.bytes_sent for s in comm_a.senders] == [s.bytes_sent for s in comm_b.senders]
+    _compare(a, b)
+
+
 def test_cg_mrslam_cli_one_rank_per_robot_equals_one_process(tmp_path):
     """``python -m cg_mrslam_amd.cg_mrslam`` (the cg_mrslam node, sim modality): two robots in one process, then one
     rank per robot (both ranks share this box's only GPU; the all-gather runs over gloo here, RCCL on a multi-GPU node).
