@@ -98,7 +98,7 @@ def parse():
     ap.add_argument("--vertices", type=int, default=10000)
     ap.add_argument("--edges", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-team", action="store_true", help="skip the C4 leg (four robots of the cg_mrslam node on this GPU)")
+    ap.add_argument("--no-team", action="store_true", help="skip the C4 leg (four robots of the cg_mrslam node on this GPU) and the 8-robot C5 loopback leg")
     ap.add_argument("--match-pairs", type=int, default=1000000, help="distinct scan pairs of the matcher leg (0 = skip)")
     ap.add_argument("--c5-vertices", type=int, default=5000, help="vertices per robot of the exchange leg (N > 1)")
     ap.add_argument("--c5-edges", type=int, default=20000)
@@ -187,6 +187,43 @@ def team_leg(ctx, n_robots=4, n_steps=90, concurrent=False):
             "inter_robot_edges": int(sum(s.edge_kind.count("mr") for s in slams)),
             "condensed_edges_held": int(sum(s.edge_kind.count("cond") for s in slams)),
             "max_distance_to_true_path_m": round(err, 4)}
+
+
+def loopback_leg(args, n_robots=8):
+    """C5 with peers on ONE GPU: `n_robots` robots x `--c5-vertices` vertices, a context each (as one rank per robot has),
+    taking turns, their wire buffers exchanged by copies instead of the all-gather (`LoopbackExchange`).  Per robot and round:
+    what a rank of an N-GPU run spends beside the solo round of `exchange` -- grow, optimize(5) with the received condensed
+    edges in the graph, ingest, the condensed graphs for all peers that asked (one batch of launches), pack.  Reported, not
+    part of `value`."""
+    from cg_mrslam_amd import Context, synth
+    from cg_mrslam_amd.condensed import RobotGraph
+    from cg_mrslam_amd.mrslam import LoopbackExchange, RobotRounds, RobotWorld
+    ctxs = [Context(0) for _ in range(n_robots)]
+    R = synth.make_multi_robot(n_robots, args.c5_vertices, args.c5_edges, seed=777)
+    rounds = [RobotRounds(RobotGraph(ctxs[r], r, n_robots, cap_edges=128), RobotWorld(R, r, chunk=args.c5_chunk)) for r in range(n_robots)]
+    ex = LoopbackExchange([r.g for r in rounds])
+    n_rounds = rounds[0].w.n_rounds if args.c5_rounds <= 0 else min(args.c5_rounds, rounds[0].w.n_rounds)
+    T = {"grow": 0.0, "optimize5": 0.0, "ingest": 0.0, "condense": 0.0, "pack": 0.0}
+    built, status = 0, 0
+    for _ in range(n_rounds):
+        for r in rounds:
+            t0 = time.perf_counter(); r.grow(); t1 = time.perf_counter(); status |= int(r.optimize() != 0); t2 = time.perf_counter()
+            T["grow"] += t1 - t0; T["optimize5"] += t2 - t1
+        t0 = time.perf_counter(); ex.finish_all(); t1 = time.perf_counter()
+        built += sum(r.condense() for r in rounds); t2 = time.perf_counter()
+        ex.start_all(); t3 = time.perf_counter()
+        T["ingest"] += t1 - t0; T["condense"] += t2 - t1; T["pack"] += t3 - t2
+    ex.finish_all()
+    n = n_rounds * n_robots
+    return {"workload": f"C5 loopback: {n_robots} robots x {args.c5_vertices} vertices / {args.c5_edges} edges on one GPU (a context each), "
+                        f"grown {args.c5_chunk} at a time, {n_rounds} rounds, wire buffers copied instead of gathered",
+            "robots": n_robots, "rounds": n_rounds,
+            "ms_per_robot_and_round": {k: round(1e3 * v / n, 3) for k, v in T.items()},
+            "round_ms_per_robot": round(1e3 * sum(T.values()) / n, 3),
+            "condensed_graphs_per_robot_and_round": round(built / n, 2),
+            "received_edges_in_graphs_at_end": int(sum(r.g.counts()["received_edges"] for r in rounds)),
+            "messages_skipped_over_capacity_total": int(sum(r.g.skipped_messages() for r in rounds)),
+            "status": status}
 
 
 def team_leg_repeated(ctx, runs=3):
@@ -686,6 +723,7 @@ def main():
         "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},
         "roofline": roofline, "cpu_baseline": cpu, "matcher": matcher, "exchange": exchange,
         "team": (guarded("team", lambda: team_leg_repeated(ctx)) if world == 1 and not args.no_team else None),
+        "exchange_loopback": (guarded("exchange_loopback", lambda: loopback_leg(args)) if world == 1 and not args.no_team else None),
     }
     if cpu:
         out["speedup_vs_cpu_1thread"] = round(out["value"] / cpu["value"], 2)

@@ -185,10 +185,11 @@ class Context:
         self._check(self.lib.cgmr_set_symbolic_cache(self.h, C.c_int(1 if on else 0)))
 
     def host_threads_info(self):
-        """Threads behind the symbolic analysis: {threads, pinned, home_cpu, cpus_allowed} (cgmr_host_threads_info)."""
-        out = np.zeros(4, dtype=np.int32)
+        """Threads behind the symbolic analysis: {threads, pinned, home_cpu, cpus_allowed, moves} (cgmr_host_threads_info)."""
+        out = np.zeros(5, dtype=np.int32)
         self._check(self.lib.cgmr_host_threads_info(_ptr(out)))
-        return {"threads": int(out[0]), "pinned": bool(out[1]), "home_cpu": int(out[2]), "cpus_allowed": int(out[3])}
+        return {"threads": int(out[0]), "pinned": bool(out[1]), "home_cpu": int(out[2]), "cpus_allowed": int(out[3]),
+                "moves": int(out[4])}
 
     def symbolic_cache_stats(self):
         out = np.zeros(3, dtype=np.int64)

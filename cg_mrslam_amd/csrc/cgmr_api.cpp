@@ -878,16 +878,16 @@ int cgmr_set_symbolic_cache(cgmr_ctx* ctx, int on) {
 }  // extern "C"
 namespace cgmr {
 // gn_symbolic.cpp: the helper pool as it runs -- threads an analysis uses (caller included), 1 if the helpers are pinned around
-// a last-level cache, the caller's home CPU while it analyses (-1: not pinned), CPUs the process may use
-void host_pool_info(int out[4]);
+// a last-level cache, the caller's home CPU while it analyses (-1: not pinned), CPUs the process may use, moves of the pool
+void host_pool_info(int out[5]);
 }
 extern "C" {
 
-int cgmr_host_threads_info(int32_t out[4]) {
+int cgmr_host_threads_info(int32_t out[5]) {
   if (!out) return CGMR_E_INVALID;
-  int v[4];
+  int v[5];
   host_pool_info(v);
-  for (int k = 0; k < 4; k++) out[k] = v[k];
+  for (int k = 0; k < 5; k++) out[k] = v[k];
   return CGMR_OK;
 }
 

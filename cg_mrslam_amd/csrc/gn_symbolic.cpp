@@ -49,6 +49,38 @@ class HelperPool {
     for (auto& t : threads_) t.join();
   }
   int helpers() const { return (int)threads_.size(); }
+  int moves() const { return moves_; }
+  void account_caller(long long wall_ns, long long cpu_ns) {
+    wall_ns_.fetch_add(wall_ns, std::memory_order_relaxed);
+    cpu_ns_.fetch_add(cpu_ns, std::memory_order_relaxed);
+  }
+  static long long now_ns(clockid_t id) { return clock_ns(id); }
+  // The GPU boxes are shared: when another process keeps the helpers' cores busy (every process of this library started
+  // from the same launcher CPU would pick the same cache group), a helper's job takes its wall time in time slices and an
+  // analysis on 8 threads costs what it costs on one (seen as one bench run in five at 3.5-5.4 ms of analysis instead of
+  // 2.3).  The helpers time themselves while they spin or work, the caller its analysis -- elapsed against thread CPU time;
+  // after two analyses in a row in which they were off their cores for more than a third of that time the pool moves to another cache group (the caller's
+  // home with it).  Called by analyze() once the caller is back on its own affinity mask.
+  void rebalance() {
+    static const bool off = getenv("CGMR_HOST_MOVE") && atoi(getenv("CGMR_HOST_MOVE")) == 0;
+    const long long w = wall_ns_.exchange(0, std::memory_order_relaxed), c = cpu_ns_.exchange(0, std::memory_order_relaxed);
+    if (off || home_.empty() || group_cur_ < 0 || group_firsts_.size() < 2 || getpid() != owner_) return;
+    if (w < 200000) return;                                       // (less than 0.2 ms of helper work: no verdict)
+    if (3 * c >= 2 * w) { strikes_ = 0; return; }
+    if (++strikes_ < 2) return;
+    strikes_ = 0;
+    if (home_busy_.exchange(true, std::memory_order_acquire)) return;      // (another caller is at home right now: next time)
+    const int n = (int)group_firsts_.size();
+    // far away, by an odd number of groups (every group comes up; ranks placed on even groups are not met), and not by the
+    // number a neighbour that started on the same group moves by
+    const int step = n > 4 ? ((n / 2 + 1) | 1) + 2 * (int)(getpid() % 3) : 1;
+    for (int k = 1; k < n; k++) {
+      const int g = (group_cur_ + k * step) % n;
+      if (g == group_cur_) continue;
+      if (pin_around(group_firsts_[g])) { group_cur_ = g; moves_++; break; }
+    }
+    home_busy_.store(false, std::memory_order_release);
+  }
   int home_cpu() const { return home_.empty() ? -1 : home_[0]; }
   // run `job` on a helper if one is idle, else right here; wait() returns when it is done
   void run(Job& job) {
@@ -88,30 +120,30 @@ class HelperPool {
   // on a two-socket / many-CCX host a helper that wakes up far from the caller pays for every line twice.  Each helper is
   // pinned to its own core among those that share the last-level cache with the CPU the pool is created from (read from
   // sysfs; nothing happens when that fails, when CGMR_HOST_PIN=0, or when the process's affinity mask excludes the cores).
+  static bool read_list(const std::string& path, std::vector<int>& out) {      // a sysfs CPU list: "0-7,128-135"
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096];
+    const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    for (char* q = buf; *q;) {
+      char* end;
+      long a = strtol(q, &end, 10);
+      if (end == q) break;
+      long b = a;
+      if (*end == '-') { q = end + 1; b = strtol(q, &end, 10); }
+      for (long c = a; c <= b && c < 4096; c++) out.push_back((int)c);
+      q = (*end == ',') ? end + 1 : end;
+      if (*end != ',') break;
+    }
+    return !out.empty();
+  }
   void pin_near_caller() {
     static const bool off = getenv("CGMR_HOST_PIN") && atoi(getenv("CGMR_HOST_PIN")) == 0;
     if (off || threads_.empty() || getpid() != owner_) return;
     int me = sched_getcpu();
     if (me < 0) return;
-    auto read_list = [](const std::string& path, std::vector<int>& out) {
-      FILE* f = fopen(path.c_str(), "r");
-      if (!f) return false;
-      char buf[4096];
-      const bool ok = fgets(buf, sizeof buf, f) != nullptr;
-      fclose(f);
-      if (!ok) return false;
-      for (char* q = buf; *q;) {                                  // "0-7,128-135"
-        char* end;
-        long a = strtol(q, &end, 10);
-        if (end == q) break;
-        long b = a;
-        if (*end == '-') { q = end + 1; b = strtol(q, &end, 10); }
-        for (long c = a; c <= b && c < 4096; c++) out.push_back((int)c);
-        q = (*end == ',') ? end + 1 : end;
-        if (*end != ',') break;
-      }
-      return !out.empty();
-    };
     const std::string base = "/sys/devices/system/cpu/cpu";
     cpu_set_t allowed;
     CPU_ZERO(&allowed);
@@ -139,8 +171,32 @@ class HelperPool {
         if ((int)firsts.size() >= n) me = firsts[(size_t)k * firsts.size() / n];
       }
     }
+    // the cache groups of the machine (first allowed CPU of each), for a later move of the pool (rebalance())
+    {
+      std::vector<uint8_t> seen(4096, 0);
+      const long ncpu = std::min(4096L, sysconf(_SC_NPROCESSORS_CONF));
+      for (int c = 0; c < ncpu; c++) {
+        if (seen[c]) continue;
+        std::vector<int> grp;
+        if (!read_list(base + std::to_string(c) + "/cache/index3/shared_cpu_list", grp)) { seen[c] = 1; continue; }
+        int first = -1;
+        bool mine = false;
+        for (int q : grp) { seen[q] = 1; if (first < 0 && CPU_ISSET(q, &allowed)) first = q; mine = mine || q == me; }
+        if (first >= 0) { if (mine) group_cur_ = (int)group_firsts_.size(); group_firsts_.push_back(mine ? me : first); }
+      }
+    }
+    (void)pin_around(me);
+  }
+
+  // helpers onto the cores that share the last-level cache with CPU `me` (one per physical core, `me`'s own core left to
+  // the caller); false and nothing changed if that group cannot take them
+  bool pin_around(int me) {
+    const std::string base = "/sys/devices/system/cpu/cpu";
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
     std::vector<int> l3;
-    if (!read_list(base + std::to_string(me) + "/cache/index3/shared_cpu_list", l3)) return;
+    if (!read_list(base + std::to_string(me) + "/cache/index3/shared_cpu_list", l3)) return false;
     // one CPU per physical core (the first hardware thread listed for it), the caller's own core left to the caller
     std::vector<int> sib_me;
     read_list(base + std::to_string(me) + "/topology/thread_siblings_list", sib_me);
@@ -154,7 +210,7 @@ class HelperPool {
       for (int q : sib) taken[q] = 1;
       picks.push_back(c);
     }
-    if ((int)picks.size() < (int)threads_.size()) return;         // fewer cores behind this cache than helpers: leave the scheduler alone
+    if ((int)picks.size() < (int)threads_.size()) return false;   // fewer cores behind this cache than helpers: leave the scheduler alone
     bool all = true;
     for (size_t i = 0; i < threads_.size(); i++) {
       cpu_set_t one;
@@ -163,6 +219,7 @@ class HelperPool {
       all = all && pthread_setaffinity_np(threads_[i].native_handle(), sizeof one, &one) == 0;
     }
     if (all) home_ = sib_me.empty() ? std::vector<int>(1, me) : sib_me;
+    return all;
   }
 
  public:
@@ -201,6 +258,15 @@ class HelperPool {
 
  private:
   void loop() {
+    // awake = spinning for work or working: the thread wants its core all of that time, so elapsed time beyond its CPU time
+    // is time somebody else had the core (rebalance())
+    long long w0 = clock_ns(CLOCK_MONOTONIC), c0 = clock_ns(CLOCK_THREAD_CPUTIME_ID);
+    auto account = [&] {
+      const long long w1 = clock_ns(CLOCK_MONOTONIC), c1 = clock_ns(CLOCK_THREAD_CPUTIME_ID);
+      wall_ns_.fetch_add(w1 - w0, std::memory_order_relaxed);
+      cpu_ns_.fetch_add(c1 - c0, std::memory_order_relaxed);
+      w0 = w1; c0 = c1;
+    };
     for (;;) {
       Job* job = nullptr;
       // spin for a while on the pending counter before sleeping on the condition variable
@@ -211,19 +277,30 @@ class HelperPool {
         }
       }
       if (!job) {
+        account();
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
         if (stop_) return;
         job = queue_.front(); queue_.erase(queue_.begin()); busy_++; pending_.fetch_sub(1);
+        w0 = clock_ns(CLOCK_MONOTONIC); c0 = clock_ns(CLOCK_THREAD_CPUTIME_ID);
       }
       job->fn();
+      account();
       { std::lock_guard<std::mutex> lk(mu_); busy_--; }
       job->done.store(1, std::memory_order_release);
     }
   }
+  static long long clock_ns(clockid_t id) {
+    timespec ts;
+    clock_gettime(id, &ts);
+    return (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+  }
   std::vector<std::thread> threads_;
   std::vector<int> home_;                // the caller's core while it analyses (empty: the helpers are not pinned)
   std::atomic<bool> home_busy_{false};   // a caller is held there right now
+  std::vector<int> group_firsts_;        // a CPU of every last-level-cache group the process may use (the pool's own: the home CPU)
+  int group_cur_ = -1, strikes_ = 0, moves_ = 0;
+  std::atomic<long long> wall_ns_{0}, cpu_ns_{0};   // the helpers' awake time (and the callers' analyses) since the last look: elapsed against CPU time
   std::vector<Job*> queue_;
   std::mutex mu_;
   std::condition_variable cv_;
@@ -557,7 +634,7 @@ int host_threads() {
 
 }  // namespace
 
-void host_pool_info(int out[4]) {
+void host_pool_info(int out[5]) {
   HelperPool& p = pool();
   cpu_set_t allowed;
   CPU_ZERO(&allowed);
@@ -565,6 +642,7 @@ void host_pool_info(int out[4]) {
   out[1] = p.home_cpu() >= 0 ? 1 : 0;
   out[2] = p.home_cpu();
   out[3] = sched_getaffinity(0, sizeof allowed, &allowed) == 0 ? CPU_COUNT(&allowed) : -1;
+  out[4] = p.moves();
 }
 
 namespace {
@@ -746,6 +824,13 @@ bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const 
 int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev) {
   double t0 = now_s();
   static const bool trace = getenv("CGMR_SYM_TRACE") != nullptr;
+  struct Rebalance {                                             // (destroyed after at_home: the caller's own mask is back)
+    long long w0 = HelperPool::now_ns(CLOCK_MONOTONIC), c0 = HelperPool::now_ns(CLOCK_THREAD_CPUTIME_ID);
+    ~Rebalance() {
+      pool().account_caller(HelperPool::now_ns(CLOCK_MONOTONIC) - w0, HelperPool::now_ns(CLOCK_THREAD_CPUTIME_ID) - c0);
+      pool().rebalance();
+    }
+  } rebalance_when_done;
   HelperPool::CallerAtHome at_home(pool());
   double tc = t0;
   auto CK = [&](const char* what) { if (trace) { double t = now_s(); fprintf(stderr, "  sym %-28s %7.1f us\n", what, 1e6 * (t - tc)); tc = t; } };

@@ -104,8 +104,10 @@ int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[3]);
 /* The host threads behind the symbolic analysis (no reference counterpart: g2o's analysis is one thread).
  * out[0] = threads an analysis uses, the caller included (CGMR_HOST_THREADS, default by core count); out[1] = 1 if the
  * helper threads are pinned around one last-level cache (CGMR_HOST_PIN=0 or an affinity mask that excludes the cores: 0);
- * out[2] = the CPU the caller is held on while it analyses (-1: nowhere); out[3] = CPUs the process may run on.           */
-int cgmr_host_threads_info(int32_t out[4]);
+ * out[2] = the CPU the caller is held on while it analyses (-1: nowhere); out[3] = CPUs the process may run on;
+ * out[4] = times the pool has moved to another cache group because its helpers kept losing their cores to other
+ * processes (CGMR_HOST_MOVE=0: never).                                                                                     */
+int cgmr_host_threads_info(int32_t out[5]);
 
 /* Host-only: run the ordering / symbolic analysis and report its shape (no GPU needed).
  * out[0]=poses in the system (every vertex with an edge; `fixed` is ignored: fixed vertices are masked numerically)

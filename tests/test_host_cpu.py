@@ -225,9 +225,10 @@ def test_host_threads_info_reports_the_pool_as_it_runs():
     home the process may run on (what the bench line carries as `host_pool`)."""
     import ctypes as C
     lib = _lib.load_library()
-    out = (C.c_int32 * 4)()
+    out = (C.c_int32 * 5)()
     assert lib.cgmr_host_threads_info(out) == 0
-    threads, pinned, home, allowed = list(out)
+    threads, pinned, home, allowed, moves = list(out)
+    assert moves >= 0
     assert 1 <= threads <= 16 and allowed == len(os.sched_getaffinity(0))
     assert (home >= 0) == bool(pinned)
     if pinned:

@@ -1,0 +1,60 @@
+"""The analysis helper pool on a shared many-core host (the GPU boxes: 2 x 64 cores, 16 last-level-cache groups): when other
+processes sit on the cores the helpers are pinned to, the pool moves to another cache group (gn_symbolic.cpp
+HelperPool::rebalance).  Host code only, but it needs a host with several cache groups: run with the GPU suite."""
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+import pytest
+
+from cg_mrslam_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _spin(cpu, seconds):
+    os.sched_setaffinity(0, {cpu})
+    e = time.time() + seconds
+    while time.time() < e:
+        pass
+
+
+def _info():
+    import ctypes as C
+    out = (C.c_int32 * 5)()
+    assert _lib.load_library().cgmr_host_threads_info(out) == 0
+    return dict(zip(("threads", "pinned", "home", "allowed", "moves"), list(out)))
+
+
+def test_pool_moves_away_from_a_neighbour_on_its_cores():
+    g = synth.make_pose_graph(10000, 40000, seed=12345, strict=True)
+    a = (10000, g["fixed"], g["edge_from"], g["edge_to"])
+
+    def analysis_ms(n):
+        out = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            _lib.gn_symbolic_info(*a)
+            out.append(1e3 * (time.perf_counter() - t0))
+        return out
+    alone = float(np.median(analysis_ms(20)))
+    i0 = _info()
+    if not i0["pinned"] or i0["allowed"] < 32:
+        pytest.skip("helpers not pinned on this host")
+    grp = open(f"/sys/devices/system/cpu/cpu{i0['home']}/cache/index3/shared_cpu_list").read().strip()
+    cpus = set()
+    for part in grp.split(","):
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    hogs = [mp.Process(target=_spin, args=(c, 20.0)) for c in sorted(cpus)]
+    [h.start() for h in hogs]
+    try:
+        time.sleep(0.5)
+        series = analysis_ms(30)
+        i1 = _info()
+    finally:
+        [h.terminate() for h in hogs]
+        [h.join() for h in hogs]
+    assert i1["moves"] >= i0["moves"] + 1 and i1["home"] not in cpus, (i0, i1, series[:6])
+    assert float(np.median(series[10:])) < 2.0 * alone, (alone, series)      # back to the speed of an undisturbed pool
