@@ -67,7 +67,7 @@ class HelperPool {
     if (off || home_.empty() || group_cur_ < 0 || group_firsts_.size() < 2 || getpid() != owner_) return;
     if (w < 200000) return;                                       // (less than 0.2 ms of helper work: no verdict)
     if (3 * c >= 2 * w) { strikes_ = 0; return; }
-    if (++strikes_ < 2) return;
+    if (++strikes_ < (2 << std::min(moves_, 6))) return;           // (every move makes the next one harder: a host that is busy everywhere is not fled from)
     strikes_ = 0;
     if (home_busy_.exchange(true, std::memory_order_acquire)) return;      // (another caller is at home right now: next time)
     const int n = (int)group_firsts_.size();
