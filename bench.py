@@ -715,6 +715,7 @@ def main():
         "chi2_final": float(chi_cold[-1]), "chi2_initial": float(chi_cold[0]),
         "host_symbolic_ms_per_step": round(1e3 * host_sym / args.steps, 3),
         "host_threads": host_threads(),
+        "host_loadavg_1min": round(os.getloadavg()[0], 1),   # runnable threads on the (shared) host, this process's included: a busy neighbour shows here
         "host_pool": ctx.host_threads_info(),          # as the library runs them: pinned around a last-level cache or not, where
         "host_symbolic_ms_one_thread": (host_symbolic_ms_one_thread(V, E, 12345 + 17 * rank) if world == 1 else None),
         "device_ms_per_step": round(1e3 * dev_time / args.steps, 3),

@@ -59,21 +59,21 @@ class HelperPool {
   // from the same launcher CPU would pick the same cache group), a helper's job takes its wall time in time slices and an
   // analysis on 8 threads costs what it costs on one (seen as one bench run in five at 3.5-5.4 ms of analysis instead of
   // 2.3).  The helpers time themselves while they spin or work, the caller its analysis -- elapsed against thread CPU time;
-  // after two analyses in a row in which they were off their cores for more than a third of that time the pool moves to another cache group (the caller's
-  // home with it).  Called by analyze() once the caller is back on its own affinity mask.
+  // after four analyses in a row in which they were off their cores for more than a third of that time the pool moves to another cache group of the same
+  // socket (the caller's home with it).  Called by analyze() once the caller is back on its own affinity mask.
   void rebalance() {
     static const bool off = getenv("CGMR_HOST_MOVE") && atoi(getenv("CGMR_HOST_MOVE")) == 0;
     const long long w = wall_ns_.exchange(0, std::memory_order_relaxed), c = cpu_ns_.exchange(0, std::memory_order_relaxed);
     if (off || home_.empty() || group_cur_ < 0 || group_firsts_.size() < 2 || getpid() != owner_) return;
     if (w < 200000) return;                                       // (less than 0.2 ms of helper work: no verdict)
     if (3 * c >= 2 * w) { strikes_ = 0; return; }
-    if (++strikes_ < (2 << std::min(moves_, 6))) return;           // (every move makes the next one harder: a host that is busy everywhere is not fled from)
+    if (++strikes_ < (4 << std::min(moves_, 5))) return;           // (every move makes the next one harder: a host that is busy everywhere is not fled from)
     strikes_ = 0;
     if (home_busy_.exchange(true, std::memory_order_acquire)) return;      // (another caller is at home right now: next time)
     const int n = (int)group_firsts_.size();
     // far away, by an odd number of groups (every group comes up; ranks placed on even groups are not met), and not by the
     // number a neighbour that started on the same group moves by
-    const int step = n > 4 ? ((n / 2 + 1) | 1) + 2 * (int)(getpid() % 3) : 1;
+    const int step = n > 4 ? ((n / 2 + 1) | 1) + 2 * (int)(getpid() % 3) : 1 + (int)(getpid() % 2);
     for (int k = 1; k < n; k++) {
       const int g = (group_cur_ + k * step) % n;
       if (g == group_cur_) continue;
@@ -120,6 +120,10 @@ class HelperPool {
   // on a two-socket / many-CCX host a helper that wakes up far from the caller pays for every line twice.  Each helper is
   // pinned to its own core among those that share the last-level cache with the CPU the pool is created from (read from
   // sysfs; nothing happens when that fails, when CGMR_HOST_PIN=0, or when the process's affinity mask excludes the cores).
+  static int package_of(int cpu) {
+    std::vector<int> v;
+    return read_list("/sys/devices/system/cpu/cpu" + std::to_string(cpu) + "/topology/physical_package_id", v) ? v[0] : -1;
+  }
   static bool read_list(const std::string& path, std::vector<int>& out) {      // a sysfs CPU list: "0-7,128-135"
     FILE* f = fopen(path.c_str(), "r");
     if (!f) return false;
@@ -182,7 +186,12 @@ class HelperPool {
         int first = -1;
         bool mine = false;
         for (int q : grp) { seen[q] = 1; if (first < 0 && CPU_ISSET(q, &allowed)) first = q; mine = mine || q == me; }
-        if (first >= 0) { if (mine) group_cur_ = (int)group_firsts_.size(); group_firsts_.push_back(mine ? me : first); }
+        if (first < 0) continue;
+        // only groups of the caller's own socket: its arrays, the pinned staging buffers and the GPU's host memory live there
+        // (a pool that moved to the other socket analysed in 5.5-8.4 ms instead of 2.3)
+        if (!mine && package_of(first) != package_of(me)) continue;
+        if (mine) group_cur_ = (int)group_firsts_.size();
+        group_firsts_.push_back(mine ? me : first);
       }
     }
     (void)pin_around(me);
@@ -212,11 +221,19 @@ class HelperPool {
     }
     if ((int)picks.size() < (int)threads_.size()) return false;   // fewer cores behind this cache than helpers: leave the scheduler alone
     bool all = true;
+    static const int pin_mode = getenv("CGMR_HOST_PIN") ? atoi(getenv("CGMR_HOST_PIN")) : 1;
+    cpu_set_t whole;                                               // CGMR_HOST_PIN=2: every helper anywhere in the group but on the caller's core
+    CPU_ZERO(&whole);
+    for (int c : l3) {
+      bool mine = false;
+      for (int q : sib_me) mine = mine || q == c;
+      if (!mine && c != me && CPU_ISSET(c, &allowed)) CPU_SET(c, &whole);
+    }
     for (size_t i = 0; i < threads_.size(); i++) {
       cpu_set_t one;
       CPU_ZERO(&one);
       CPU_SET(picks[i], &one);
-      all = all && pthread_setaffinity_np(threads_[i].native_handle(), sizeof one, &one) == 0;
+      all = all && pthread_setaffinity_np(threads_[i].native_handle(), sizeof one, pin_mode == 2 ? &whole : &one) == 0;
     }
     if (all) home_ = sib_me.empty() ? std::vector<int>(1, me) : sib_me;
     return all;
