@@ -45,6 +45,7 @@ class HelperPool {
       return;
     }
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    stop_flag_.store(true, std::memory_order_relaxed);
     cv_.notify_all();
     for (auto& t : threads_) t.join();
   }
@@ -286,11 +287,19 @@ class HelperPool {
     };
     for (;;) {
       Job* job = nullptr;
-      // spin for a while on the pending counter before sleeping on the condition variable
-      for (int spin = 0; spin < 100000 && !job; spin++) {
+      // Spin on the pending counter before sleeping on the condition variable -- for as long as a solve loop takes to come
+      // back with the next analysis (CGMR_HOST_SPIN_US, default 10 ms after the last job; an OpenMP runtime's default is
+      // 200 ms): a helper that sleeps through the 5 ms of device work between two analyses pays a futex wake-up each time,
+      // and on a shared host its core has been given to somebody else in the meantime.
+      static const long long spin_ns = 1000LL * (getenv("CGMR_HOST_SPIN_US") ? std::max(0, atoi(getenv("CGMR_HOST_SPIN_US"))) : 10000);
+      const long long spin_until = clock_ns(CLOCK_MONOTONIC) + spin_ns;
+      for (unsigned spin = 0; !job; spin++) {
         if (pending_.load(std::memory_order_acquire) > 0) {
           std::lock_guard<std::mutex> lk(mu_);
           if (!queue_.empty()) { job = queue_.front(); queue_.erase(queue_.begin()); busy_++; pending_.fetch_sub(1); }
+        } else {
+          __builtin_ia32_pause();
+          if ((spin & 255) == 255 && (stop_flag_.load(std::memory_order_relaxed) || clock_ns(CLOCK_MONOTONIC) >= spin_until)) break;
         }
       }
       if (!job) {
@@ -324,6 +333,7 @@ class HelperPool {
   std::atomic<int> pending_{0};
   int busy_ = 0;
   bool stop_ = false;
+  std::atomic<bool> stop_flag_{false};
   pid_t owner_;
 };
 
