@@ -477,7 +477,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   // launches per job side by side -- next to each other the device dispatched the small kernels of 7 jobs at ~7 us apiece
   // (3.9 ms for the condensed graphs of a round with 8 robots); CGMR_COND_BATCH=0: the streams
   static const bool batch_on = !(getenv("CGMR_COND_BATCH") && atoi(getenv("CGMR_COND_BATCH")) == 0);
-  const bool batched = batch_on && nj > 1 && nf > 0;
+  const bool batched = batch_on && nf > 0;            // (a single pass as a batch of one: no side stream to fork and join, staging from pinned memory)
   std::vector<int32_t> status(nj, 0);
   if (batched) {
     // staging (the context's mask block: nothing else is in flight from it): masks | initial guesses | query columns |
