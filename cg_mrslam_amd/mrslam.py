@@ -62,6 +62,22 @@ class RobotWorld:
         return v0, v1, self.e_order[self.e_ptr[t]:self.e_ptr[t + 1]], self.c_order[self.c_ptr[t]:self.c_ptr[t + 1]]
 
 
+def _dead_reckon(start, increments):
+    """start * inc[0], start * inc[0] * inc[1], ...: ``synth.se2_compose`` step by step on scalars (same operations in the
+    same order, bit for bit -- tests/test_host_cpu.py -- without an array round trip per pose: a round's 50 new poses were
+    0.4 ms of a 2.5 ms solo round)."""
+    x, y, th = float(start[0]), float(start[1]), float(start[2])
+    two_pi = 2 * np.pi
+    out = np.empty((len(increments), 3), dtype=np.float64)
+    for k, (bx, by, bt) in enumerate(np.asarray(increments, dtype=np.float64).tolist()):
+        c, s = float(np.cos(np.float64(th))), float(np.sin(np.float64(th)))
+        x, y = x + c * bx - s * by, y + s * bx + c * by
+        t = th + bt
+        th = t if (-np.pi <= t < np.pi) else t - two_pi * float(np.floor((t + np.pi) / two_pi))
+        out[k, 0], out[k, 1], out[k, 2] = x, y, th
+    return list(out)
+
+
 class RobotRounds:
     """One robot of the round protocol above on ``graph`` (``RobotGraph`` interface)."""
 
@@ -84,9 +100,10 @@ class RobotRounds:
         else:
             prev = g.poses(self._own_slot[v0 - 1], 1)[0]
             new, first = [], v0
-        for k in range(first, v1):
-            prev = synth.se2_compose(prev[None], w.meas[k - 1][None])[0]       # odometry edge k-1: (k-1) -> k
-            new.append(prev)
+        if v1 > first:
+            chain = _dead_reckon(prev, w.meas[first - 1:v1 - 1])               # odometry edge k-1: (k-1) -> k
+            new.extend(chain)
+            prev = chain[-1]
         fixed = np.zeros(v1 - v0, dtype=np.uint8)
         if v0 == 0:
             fixed[0] = 1                                                        # the robot's first vertex is its gauge

@@ -548,3 +548,17 @@ def test_children_schedule_has_one_writer_per_panel_copy_and_launch(shape):
         assert (p, t, slot) not in seen
         seen.add((p, t, slot))
     assert len(seen) > 10
+
+
+def test_dead_reckoning_chain_equals_se2_compose_bit_for_bit():
+    """mrslam._dead_reckon (scalar steps) against synth.se2_compose pose by pose, angles that wrap included."""
+    from cg_mrslam_amd.mrslam import _dead_reckon
+    rng = np.random.default_rng(5)
+    inc = np.stack([rng.normal(0, 1.0, 400), rng.normal(0, 0.3, 400), rng.normal(0.4, 1.5, 400)], axis=1)
+    start = np.array([0.3, -2.0, 3.0])
+    got = np.array(_dead_reckon(start, inc))
+    prev, want = start, []
+    for k in range(len(inc)):
+        prev = synth.se2_compose(prev[None], inc[k][None])[0]
+        want.append(prev)
+    assert np.array_equal(got, np.array(want))
