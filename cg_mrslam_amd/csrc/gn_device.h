@@ -76,7 +76,8 @@ struct MargBatch {
 // nK: the query count (batch: the largest of the jobs); batch == nullptr: one pass.  live: D.nfronts * (m / 16) bytes of
 // scratch (which fronts carry anything of a group of right-hand sides), no initialisation needed
 void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* d_qcol, int m, double* Y, double* Uv,
-                      double* part, double* G, double* cov, int chunk, int nchunk, uint8_t* live, const MargBatch* batch = nullptr);
+                      double* part, double* G, double* cov, int chunk, int nchunk, uint8_t* live, const MargBatch* batch = nullptr,
+                      bool y_is_zero = false);   // y_is_zero: the caller has cleared Y already
 void launch_label(hipStream_t st, int nK, const int32_t* d_qvert, int gauge, const double* poses, const double* cov,
                   double* est, double* info, int* flags, const GnDevice* D = nullptr, const MargBatch* batch = nullptr);
 

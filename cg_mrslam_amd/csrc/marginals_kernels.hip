@@ -319,11 +319,12 @@ __global__ void k_label_edges(int nK, const int32_t* __restrict__ qvert, int gau
 
 // ----------------------------------------------------------------------------------- launchers
 void launch_marginals(hipStream_t st, const GnDevice& D, int nK, const int32_t* d_qcol, int m, double* Y, double* Uv,
-                      double* part, double* G, double* cov, int chunk, int nchunk, uint8_t* live, const MargBatch* batch) {
+                      double* part, double* G, double* cov, int chunk, int nchunk, uint8_t* live, const MargBatch* batch, bool y_is_zero) {
   const int nj = batch ? D.njobs : 1;
   const long long ms = batch ? batch->marg_stride : 0, js = batch ? D.job_stride : 0;
   const CondJobDev* jd = batch ? batch->jobs : nullptr;
-  if (batch) (void)hipMemset2DAsync(Y, (size_t)ms, 0, sizeof(double) * (size_t)3 * D.nf * m, (size_t)nj, st);
+  if (y_is_zero) {}
+  else if (batch) (void)hipMemset2DAsync(Y, (size_t)ms, 0, sizeof(double) * (size_t)3 * D.nf * m, (size_t)nj, st);
   else (void)hipMemsetAsync(Y, 0, sizeof(double) * (size_t)3 * D.nf * m, st);
   hipLaunchKernelGGL(k_marg_init_rhs, dim3((nK + 127) / 128, 1, nj), dim3(128), 0, st, nK, d_qcol, m, Y, jd, ms);
   for (int l = 0; l < D.nlevels_full; l++) {            // every front, the top block's included

@@ -451,8 +451,11 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
                o_e64 = L.add(24 * (size_t)maxq), o_i64 = L.add(48 * (size_t)maxq), o_st = L.add(16),
                o_live = L.add((size_t)std::max(ctx->gn.nfronts, 1) * (m_max / 16));
   const size_t per_job = (L.off + 255) & ~size_t(255);
-  const size_t o_jd = per_job * (size_t)nj;                      // job descriptors of a batched run behind the jobs' blocks
-  rc = arena_reserve(ctx, ctx->mg_arena, o_jd + sizeof(CondJobDev) * (size_t)nj + 256);
+  // behind the jobs' blocks: the staging block of a batched run (masks | initial guesses | query columns | query vertices |
+  // job descriptors), one copy from the pinned block
+  const size_t o_stage = per_job * (size_t)nj;
+  const size_t stage_cap = (size_t)nf * nj + (size_t)24 * nV * nj + 2 * (size_t)4 * maxq * nj + sizeof(CondJobDev) * (size_t)nj + 5 * 256;
+  rc = arena_reserve(ctx, ctx->mg_arena, o_stage + stage_cap + 256);
   if (rc) return rc;
   GnEdges Ed;
   Ed.meas_a = (const double*)g->d_meas_a.ptr; Ed.info_a = (const double*)g->d_info_a.ptr;
@@ -514,13 +517,19 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     const double tu0 = wall_s();
     char* h = ctx->pinned_mask;
     char* d0 = ctx->mg_arena.ptr;
-    double* d_work0 = (double*)g->d_work.ptr;
-    rc = prepare_batch_on(ctx, DB, st);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(d_work0, h + s_work, (size_t)24 * nV * nj, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpy2DAsync(d0 + o_qc, per_job, h + s_qc, 4 * (size_t)maxq, 4 * (size_t)maxq, (size_t)nj, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpy2DAsync(d0 + o_qv, per_job, h + s_qv, 4 * (size_t)maxq, 4 * (size_t)maxq, (size_t)nj, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(d0 + o_jd, h + s_jd, sizeof(CondJobDev) * (size_t)nj, hipMemcpyHostToDevice, st));
+    char* ds = d0 + o_stage;                                     // device copy of the staging block
+    double* d_work0 = (double*)(ds + s_work);                    // the passes work on the poses where they landed
+    HIP_TRY(ctx, hipMemcpyAsync(ds, h, s_st, hipMemcpyHostToDevice, st));
+    {
+      CondPrepare P;
+      P.njobs = nj; P.nf = nf; P.maxq = maxq;
+      P.stage_mask = (const uint8_t*)ds; P.stage_qc = (const int32_t*)(ds + s_qc); P.stage_qv = (const int32_t*)(ds + s_qv);
+      P.cmask = DB.cmask; P.qc = (int32_t*)(d0 + o_qc); P.qv = (int32_t*)(d0 + o_qv); P.status = DB.status;
+      P.pan = DB.Pan; P.pan_doubles = DB.pan_doubles; P.Y = (double*)(d0 + o_Y); P.y_doubles = (long long)n * m_max;
+      P.rep_stride = DB.job_stride; P.marg_stride = (long long)per_job;
+      launch_cond_prepare(st, P);
+      DB.pan_clean = DB.pan_doubles > 0;                         // (gn_pass_on: no memset in front of the assembly)
+    }
     t_up = wall_s() - tu0;
     hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};
     if (trace) for (auto& e : evs) (void)hipEventCreate(&e);
@@ -531,13 +540,13 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     t_gn = tp1 - tp0;
     if (trace) (void)hipEventRecord(evs[1], st);
     MargBatch MBt;
-    MBt.jobs = (const CondJobDev*)(d0 + o_jd);
+    MBt.jobs = (const CondJobDev*)(ds + s_jd);
     MBt.marg_stride = (long long)per_job;
     double *est0, *info0;
     if (to_wire) { est0 = g->d_est64; info0 = g->d_info64; MBt.est_stride = 24LL * cap; MBt.info_stride = 48LL * cap; MBt.wire_stride = (long long)sizeof(WireEdge) * cap; }
     else { est0 = (double*)(d0 + o_e64); info0 = (double*)(d0 + o_i64); MBt.est_stride = MBt.info_stride = (long long)per_job; }
     launch_marginals(st, DB, maxq, (const int32_t*)(d0 + o_qc), m_max, (double*)(d0 + o_Y), (double*)(d0 + o_U), (double*)(d0 + o_part),
-                     (double*)(d0 + o_G), (double*)(d0 + o_cov), chunk, nchunk, (uint8_t*)(d0 + o_live), &MBt);
+                     (double*)(d0 + o_G), (double*)(d0 + o_cov), chunk, nchunk, (uint8_t*)(d0 + o_live), &MBt, /*y_is_zero=*/true);
     if (trace) (void)hipEventRecord(evs[2], st);
     launch_label(st, maxq, (const int32_t*)(d0 + o_qv), 0, d_work0, (const double*)(d0 + o_cov), est0, info0, (int*)(d0 + o_fl), &DB, &MBt);
     if (to_wire)

@@ -32,5 +32,19 @@ void launch_wire_read(hipStream_t st, int n_ranks, int cap, int me, size_t wire_
 void launch_gather_edges(hipStream_t st, int n, const int32_t* slot, const double* src_meas, const double* src_info,
                          double* dst_meas, double* dst_info);
 void launch_gather_poses(hipStream_t st, int n, const int32_t* idx, const double* poses, double* out);
+// Everything a batch of condensed-graph passes needs before its first kernel, in one launch behind ONE staging copy: job j's
+// column mask (nf bytes at stage_mask + j * nf) to cmask + j * rep_stride, its query columns / vertices (maxq int32 each at
+// stage_qc / stage_qv + j * maxq) to qc / qv + j * marg_stride, clean status words (4 int32 at status + j * rep_stride), and
+// zeros in its assembled panels (pan_doubles at pan + j * rep_stride) and in its right-hand sides (y_doubles at
+// Y + j * marg_stride).  (Six small copies and three memsets before: they shared the device timeline with the ~20 launches of
+// a pass on a 15-vertex graph and were as long as the kernels.)
+struct CondPrepare {
+  int njobs = 0, nf = 0, maxq = 0;
+  const uint8_t* stage_mask = nullptr; const int32_t *stage_qc = nullptr, *stage_qv = nullptr;
+  uint8_t* cmask = nullptr; int32_t *qc = nullptr, *qv = nullptr; int* status = nullptr;
+  double *pan = nullptr, *Y = nullptr;
+  long long pan_doubles = 0, y_doubles = 0, rep_stride = 0, marg_stride = 0;
+};
+void launch_cond_prepare(hipStream_t st, const CondPrepare& P);
 
 }  // namespace cgmr

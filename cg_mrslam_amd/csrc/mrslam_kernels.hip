@@ -8,6 +8,8 @@
 //   condensed_graph_buffer.cpp:487-510  insertEdgesFromRobot: the newest set from a robot replaces the previous one
 // All of it is HBM-bound byte shuffling on a few KB per round: one thread per edge, coalesced 44-byte records.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "mrslam_device.h"
@@ -93,6 +95,37 @@ __global__ void k_gather_poses(int n, const int32_t* __restrict__ idx, const dou
   const int v = idx[k];
 #pragma unroll
   for (int a = 0; a < 3; a++) out[3 * (size_t)k + a] = poses[3 * (size_t)v + a];
+}
+
+__global__ __launch_bounds__(256) void k_cond_prepare(CondPrepare P) {
+  const int j = blockIdx.z;
+  const long long rs = (long long)j * P.rep_stride, ms = (long long)j * P.marg_stride;
+  const int nb = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0) {
+    uint8_t* cm = P.cmask + rs;
+    for (int c = tid; c < P.nf; c += 256) cm[c] = P.stage_mask[(size_t)j * P.nf + c];
+    int32_t* qc = (int32_t*)((char*)P.qc + ms);
+    int32_t* qv = (int32_t*)((char*)P.qv + ms);
+    for (int k = tid; k < P.maxq; k += 256) { qc[k] = P.stage_qc[(size_t)j * P.maxq + k]; qv[k] = P.stage_qv[(size_t)j * P.maxq + k]; }
+    if (tid < 4) ((int*)((char*)P.status + rs))[tid] = 0;
+  }
+  // zeros: the panels, then the right-hand sides, each cut into the launch's workgroups (16-byte stores; both are 16-byte aligned
+  // and the tails are handled one double at a time)
+  auto zero = [&](double* p, long long n) {
+    const long long n2 = n / 2, per = (n2 + nb - 1) / nb, lo = per * b, hi = lo + per < n2 ? lo + per : n2;
+    double2* z = reinterpret_cast<double2*>(p);
+    for (long long q = lo + tid; q < hi; q += 256) z[q] = make_double2(0.0, 0.0);
+    if (b == 0 && tid == 0 && (n & 1)) p[n - 1] = 0.0;
+  };
+  if (P.pan_doubles > 0) zero((double*)((char*)P.pan + rs), P.pan_doubles);
+  if (P.y_doubles > 0) zero((double*)((char*)P.Y + ms), P.y_doubles);
+}
+
+void launch_cond_prepare(hipStream_t st, const CondPrepare& P) {
+  if (P.njobs <= 0) return;
+  const long long work = (P.pan_doubles + P.y_doubles) / 2;                       // 16-byte stores per job
+  const int nb = (int)std::max(1LL, std::min(240LL, work / (256 * 8)));           // a small graph: one workgroup per job does it all
+  hipLaunchKernelGGL(k_cond_prepare, dim3(nb, 1, P.njobs), dim3(256), 0, st, P);
 }
 
 void launch_wire_write_edges(hipStream_t st, int n, int from_id, const int32_t* to_vertex, const int32_t* vertex_ids,
