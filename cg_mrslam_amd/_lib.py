@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 CGMR_E_CHOLESKY_BASE = -100
+CGMR_E_TIMEOUT = -5
 
 
 class CgmrError(RuntimeError):
@@ -193,8 +194,13 @@ class Context:
 
     def symbolic_cache_stats(self):
         out = np.zeros(3, dtype=np.int64)
-        self._check(self.lib.cgmr_symbolic_cache_stats(self.h, _ptr(out)))
+        self._check(self.lib.cgmr_symbolic_cache_stats3(self.h, _ptr(out)))
         return {"hits": int(out[0]), "misses": int(out[1]), "extended": int(out[2])}
+
+    def gn_timeouts(self) -> int:
+        """Bounded device-side waits of the chained backward solve that ran out on this context (cgmr_gn_timeouts)."""
+        self.lib.cgmr_gn_timeouts.restype = C.c_int64
+        return int(self.lib.cgmr_gn_timeouts(self.h))
 
     def gn_last_timing(self):
         out = np.zeros(5)

@@ -339,12 +339,31 @@ int aux_streams(cgmr_ctx* ctx, int n) {
   return 0;
 }
 
+// The analysis of (nV, ef, et) into `sym`, which holds the analysis of (prev_nV, pef, pet) when have_prev: extended from it
+// where the two lists allow that, from scratch otherwise (shared by prepare_structure and the host-only test hook).
+int analyze_next(Symbolic& sym, bool have_prev, int prev_nV, const std::vector<int32_t>& pef, const std::vector<int32_t>& pet, int nV,
+                 int nE, const int32_t* ef, const int32_t* et, const int32_t* hub_vertices, int n_hub_vertices) {
+  int n_common = 0;
+  if (have_prev && nV >= prev_nV && !pef.empty()) {
+    const int lim = std::min(nE, (int)pef.size());
+    while (n_common < lim && pef[n_common] == ef[n_common] && pet[n_common] == et[n_common]) n_common++;
+  }
+  const int old_nE = (int)pef.size();
+  const bool grown = n_common > 0 && (n_common == old_nE || (n_hub_vertices > 0 && 2 * n_common >= old_nE));
+  if (grown) {
+    Symbolic old = std::move(sym);
+    return analyze(nV, nullptr, nE, ef, et, sym, &old, n_common == old_nE && nE >= old_nE ? -1 : n_common, hub_vertices, n_hub_vertices);
+  }
+  return analyze(nV, nullptr, nE, ef, et, sym, nullptr, -1, hub_vertices, n_hub_vertices);
+}
+
 // Ordering + symbolic analysis + structure upload for the edge list (ef, et), or nothing at all when the context
 // still holds them for exactly this list (g2o redoes buildStructure + cs_schol on every optimize() call,
 // SURVEY.md 3.2; within one key frame -- optimize(1), covariance estimate, optimize(5), graph_slam.cpp:392-393,
 // 315-320 -- and within one multi-robot round the list does not change).  The analysis does not look at the fixed
 // flags (they are applied numerically, prepare_pass()), so a hit is bit-identical to a miss by construction.
-int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const int32_t* et, int iters) {
+int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const int32_t* et, int iters, const int32_t* hub_vertices,
+                      int n_hub_vertices) {
   const bool hit = ctx->sym_cache_on && ctx->sym_valid && ctx->sym_nV == nV && (int)ctx->sym_ef.size() == nE &&
                    iters <= ctx->sym_chi_cap &&
                    (nE == 0 || (memcmp(ctx->sym_ef.data(), ef, sizeof(int32_t) * nE) == 0 &&
@@ -357,17 +376,12 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
   // The key-frame pattern: the cached edge list plus vertices / edges appended at the end (graph_slam.cpp:197-267 adds a
   // vertex and a few edges per key frame; a multi-robot round adds a chunk).  The ordering is then extended instead of
   // recomputed (gn_symbolic.cpp: extend_order); everything downstream of the ordering is built as for a new graph.
-  const bool grown = ctx->sym_cache_on && ctx->sym_valid && nV >= ctx->sym_nV && nE >= (int)ctx->sym_ef.size() && !ctx->sym_ef.empty() &&
-                     memcmp(ctx->sym_ef.data(), ef, sizeof(int32_t) * ctx->sym_ef.size()) == 0 &&
-                     memcmp(ctx->sym_et.data(), et, sizeof(int32_t) * ctx->sym_et.size()) == 0;
+  // A robot's list (hub_vertices given: cgmr_graph_optimize) is its own edges, appended to, followed by the edges received
+  // from the peers, replaced every round: the two lists share their front only, the rest of the new one is checked against
+  // the tree edge by edge (an edge to a hub -- the gauge of a received star -- always passes).
+  const bool have_prev = ctx->sym_cache_on && ctx->sym_valid;
   ctx->sym_valid = false;
-  int rc;
-  if (grown) {
-    Symbolic old = std::move(ctx->sym);
-    rc = analyze(nV, nullptr, nE, ef, et, ctx->sym, &old);
-  } else {
-    rc = analyze(nV, nullptr, nE, ef, et, ctx->sym);
-  }
+  int rc = analyze_next(ctx->sym, have_prev, ctx->sym_nV, ctx->sym_ef, ctx->sym_et, nV, nE, ef, et, hub_vertices, n_hub_vertices);
   if (rc == 0 && ctx->sym.extended) ctx->sym_extended++; else ctx->sym_misses++;
   if (rc) return set_err(ctx, CGMR_E_INVALID, "graph structure rejected (edge index out of range)");
   const int chi_cap = std::max(iters, 30);
@@ -520,10 +534,10 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
 }
 
 int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE, const int32_t* ef,
-           const int32_t* et, const GnEdges& Ed, int iters, double* chi2_out) {
+           const int32_t* et, const GnEdges& Ed, int iters, double* chi2_out, const int32_t* hub_vertices, int n_hub_vertices) {
   double t0 = wall_s();
   Symbolic& S = ctx->sym;
-  int rc = prepare_structure(ctx, nV, nE, ef, et, iters);
+  int rc = prepare_structure(ctx, nV, nE, ef, et, iters, hub_vertices, n_hub_vertices);
   if (rc) return rc;
   double t1 = wall_s();
   rc = prepare_pass(ctx, fixed, nE, ef, et, Ed.n_active, 0, 1);
@@ -552,13 +566,33 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
   // read back chi2 + status
   std::vector<double> chi(iters + 1);
-  int status = 0;
+  int status4[4] = {0, 0, 0, 0};
   HIP_TRY(ctx, hipMemcpyAsync(chi.data(), D.chi2, sizeof(double) * (iters + 1), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(&status, D.status, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(status4, D.status, sizeof status4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
   if (graph) (void)hipGraphDestroy(graph);
+  if (status4[2] != 0 && status4[0] > 0) {
+    // A bounded wait of the chained backward solve ran out (status[2]): a hand-off between workgroups that never arrived,
+    // not a numerical failure.  The iteration it happened in (status[0] - 1) and the later ones were not applied
+    // (k_update_poses leaves the poses alone once status[0] is set), so they are repeated from the poses as they stand with
+    // one backward launch per tree level -- no in-kernel waits -- and the call goes on as if nothing had happened.
+    ctx->gn_timeouts++;
+    const int it0 = status4[0] - 1;
+    const int chain_was = D.bwd_chain_level;
+    D.bwd_chain_level = D.nlevels;
+    const int fresh[4] = {0, it0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(D.status, fresh, sizeof fresh, hipMemcpyHostToDevice, st));
+    for (int it = it0; it <= iters; it++) gn_pass(ctx, d_poses, Ed, it, it == iters, true, false);
+    HIP_TRY(ctx, hipMemcpyAsync(chi.data(), D.chi2, sizeof(double) * (iters + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(status4, D.status, sizeof status4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    D.bwd_chain_level = chain_was;
+    if (status4[2] != 0) return set_err(ctx, CGMR_E_TIMEOUT, "backward solve: a bounded device-side wait ran out twice");
+  }
+  const int status = status4[0];
   if (ctx->profiling) profile_collect(ctx);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -679,17 +713,18 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   if (mode == 2)
     launch_label(st, nq, (const int32_t*)(d + o_qv), gauge, dp, (const double*)(d + o_cov), (double*)(d + o_est),
                  (double*)(d + o_io), (int*)(d + o_fl));
-  int status = 0;
+  int status4[4] = {0, 0, 0, 0};
   std::vector<double> cov(9 * (size_t)nq);
   HIP_TRY(ctx, hipMemcpyAsync(cov.data(), d + o_cov, 72 * (size_t)nq, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(&status, D.status, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(status4, D.status, sizeof status4, hipMemcpyDeviceToHost, st));
   if (mode == 2) {
     HIP_TRY(ctx, hipMemcpyAsync(est_out, d + o_est, 24 * (size_t)nq, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(info_out, d + o_io, 48 * (size_t)nq, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
-  if (status != 0) return set_err(ctx, CGMR_E_CHOLESKY_BASE, "Cholesky failed while computing marginals");
+  if (status4[2] != 0) { ctx->gn_timeouts++; return set_err(ctx, CGMR_E_TIMEOUT, "backward solve: a bounded device-side wait ran out"); }
+  if (status4[0] != 0) return set_err(ctx, CGMR_E_CHOLESKY_BASE, "Cholesky failed while computing marginals");
   if (mode == 2) {
     for (int k = 0; k < nq; k++) to_out[k] = q[k];
     if (cov_out) memcpy(cov_out, cov.data(), 72 * (size_t)nq);
@@ -707,7 +742,7 @@ using namespace cgmr;
 
 extern "C" {
 
-int cgmr_version(void) { return 100; }
+int cgmr_version(void) { return 101; }
 
 int cgmr_ctx_create(int device, void* hip_stream, cgmr_ctx** out) {
   if (!out) return CGMR_E_INVALID;
@@ -891,11 +926,19 @@ int cgmr_host_threads_info(int32_t out[5]) {
   return CGMR_OK;
 }
 
-int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[3]) {
+int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]) {     // the two-value ABI of version 100
+  if (!ctx || !out) return CGMR_E_INVALID;
+  out[0] = ctx->sym_hits; out[1] = ctx->sym_misses + ctx->sym_extended;
+  return CGMR_OK;
+}
+
+int cgmr_symbolic_cache_stats3(const cgmr_ctx* ctx, int64_t out[3]) {
   if (!ctx || !out) return CGMR_E_INVALID;
   out[0] = ctx->sym_hits; out[1] = ctx->sym_misses; out[2] = ctx->sym_extended;
   return CGMR_OK;
 }
+
+int64_t cgmr_gn_timeouts(const cgmr_ctx* ctx) { return ctx ? ctx->gn_timeouts : -1; }
 
 int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]) {
   if (!ctx || !out) return CGMR_E_INVALID;
@@ -970,5 +1013,39 @@ extern "C" int cgmr_debug_worklist(const cgmr_ctx* ctx, int32_t* front_out, int3
       for (int c = 0; c < nchunk; c++) { if (n < cap) { front_out[n] = f; chunk_out[n] = c; } n++; }
     }
   for (int f = 0; f < (int)S.fronts.size() && f < fcap; f++) { parent_out[f] = S.fronts[f].parent; level_out[f] = S.fronts[f].level; ns_out[f] = S.fronts[f].ns; }
+  return n;
+}
+
+// Host-only test hook: a sequence of complete edge lists analysed one after the other the way a context with the analysis
+// cache on does (step k: vertices nV[k], edges e_ptr[k] .. e_ptr[k+1] of ef / et, hub hints h_ptr[k] .. h_ptr[k+1] of hubs).
+// out / perm_out / fronts_out (6 ints per front as cgmr_debug_fronts) describe the last analysis; returns its front count.
+extern "C" int cgmr_debug_symbolic_steps(int n_steps, const int32_t* nV, const int32_t* e_ptr, const int32_t* ef, const int32_t* et,
+                                         const int32_t* h_ptr, const int32_t* hubs, int64_t out[16], int32_t* perm_out,
+                                         int32_t* n_extended_out, int fcap, int32_t* fronts_out, int64_t* per_step_out) {
+  if (n_steps < 1 || !nV || !e_ptr || !out) return -1;
+  Symbolic S;
+  std::vector<int32_t> pef, pet;
+  int prev_nV = 0, next = 0;
+  for (int k = 0; k < n_steps; k++) {
+    const int nE = e_ptr[k + 1] - e_ptr[k];
+    const int nh = h_ptr ? h_ptr[k + 1] - h_ptr[k] : 0;
+    if (analyze_next(S, k > 0, prev_nV, pef, pet, nV[k], nE, ef + e_ptr[k], et + e_ptr[k], nh ? hubs + h_ptr[k] : nullptr, nh)) return -1;
+    if (k > 0 && S.extended) next++;
+    if (per_step_out) {                                     // per step: levels, extended, ordering us, structure us, factor flops
+      int64_t* o = per_step_out + 5 * (size_t)k;
+      o[0] = (int64_t)S.level_ptr.size() - 1; o[1] = S.extended ? 1 : 0; o[2] = (int64_t)(1e6 * S.t_order); o[3] = (int64_t)(1e6 * S.t_struct); o[4] = (int64_t)S.flops;
+    }
+    pef.assign(ef + e_ptr[k], ef + e_ptr[k + 1]);
+    pet.assign(et + e_ptr[k], et + e_ptr[k + 1]);
+    prev_nV = nV[k];
+  }
+  if (n_extended_out) *n_extended_out = next;
+  symbolic_info_out(S, nV[n_steps - 1], out, perm_out);
+  const int n = (int)S.fronts.size();
+  for (int f = 0; f < n && f < fcap && fronts_out; f++) {
+    const FrontDesc& F = S.fronts[f];
+    int32_t* o = fronts_out + 6 * f;
+    o[0] = F.c0; o[1] = F.nc; o[2] = F.ns; o[3] = F.parent; o[4] = F.level; o[5] = F.nchild;
+  }
   return n;
 }

@@ -44,6 +44,7 @@ struct cgmr_ctx {
   int sym_nV = 0;
   int sym_chi_cap = 0;
   std::vector<int32_t> sym_ef, sym_et;
+  int64_t gn_timeouts = 0;       // bounded device-side waits that ran out (cgmr_gn_timeouts)
   int64_t sym_hits = 0, sym_misses = 0, sym_extended = 0;   // calls served from the cache / analysed from scratch / analysed by extending the cached ordering
   std::vector<uint8_t> vmask;    // per vertex: masked in the current pass
   cgmr::Symbolic sym;

@@ -783,7 +783,7 @@ template <int WW, bool CHAIN, bool BATCH>
 __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
                                                    const double* __restrict__ yvec, double* xvec,
-                                                   int* status, long long js) {
+                                                   int* status, long long js, unsigned spin_limit) {
   CGMR_JOB(Lbuf, js); CGMR_JOB(yvec, js); CGMR_JOB(xvec, js); CGMR_JOB(status, js);
   CGMR_FRONT_CONSTS(WW);
   constexpr int HP = W / 2;            // column pairs per row
@@ -848,7 +848,13 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
           unsigned spins = 0;
           while (__hip_atomic_load(flag, CGMR_RLX_AGENT) == kXSentinel) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22)) { atomicCAS(status, 0, status[1] + 1); status[2] = 1; break; }   // never hang the device
+            // never hang the device: a wait that runs out marks the pass (status[2]: a time-out, not a Cholesky failure --
+            // the host repeats the iteration with one launch per level); once one wait has run out the others stop early
+            if (++spins > spin_limit || ((spins & 1023u) == 0 && __hip_atomic_load(status + 2, CGMR_RLX_AGENT) != 0)) {
+              atomicCAS(status, 0, status[1] + 1);
+              __hip_atomic_store(status + 2, 1, CGMR_RLX_AGENT);
+              break;
+            }
           }
         }
         __syncthreads();
@@ -863,7 +869,8 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
         if (p < np) {
           gu64* src = (gu64*)(xvec + 3 * xi[u] + (p0 + p) % 3);
           unsigned spins = 0;
-          while ((bits = __hip_atomic_load(src, CGMR_RLX_AGENT)) == kXSentinel && F.ppan_off >= 0 && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+          while ((bits = __hip_atomic_load(src, CGMR_RLX_AGENT)) == kXSentinel && F.ppan_off >= 0 && ++spins < spin_limit &&
+                 ((spins & 1023u) != 0 || __hip_atomic_load(status + 2, CGMR_RLX_AGENT) == 0)) __builtin_amdgcn_s_sleep(1);
         }
         xr[u] = __longlong_as_double((long long)bits);
       } else {
@@ -1023,7 +1030,7 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   if (nfr <= 0) return;
   hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, false, true> : k_solve_bwd<kFrontW, false, false>), dim3(nfr, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, false), st, D.fronts_lv, D.h_level_ptr[l], D.rows,
-                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride);
+                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride, 0u);
 }
 
 // Workgroups of the chained backward solve that are certainly resident together: the waits inside that launch must never
@@ -1051,8 +1058,11 @@ void launch_bwd_chain(hipStream_t st, const GnDevice& D) {
   gn_init_kernels();
   const int first = D.h_level_ptr[D.bwd_chain_level], last = D.h_level_ptr[D.nlevels];
   if (last <= first) return;
+  // CGMR_BWD_SPIN_LIMIT: polls a wait may take (tests force the time-out path with a tiny value)
+  const char* sl = getenv("CGMR_BWD_SPIN_LIMIT");               // (read per launch: a test switches it inside one process)
+  const unsigned spin_limit = sl ? (unsigned)std::max(1, atoi(sl)) : (1u << 22);
   hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, true, true> : k_solve_bwd<kFrontW, true, false>), dim3(last - first, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, true), st, D.fronts_lv, last - 1, D.rows,
-                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride);
+                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride, spin_limit);
 }
 
 void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels) {

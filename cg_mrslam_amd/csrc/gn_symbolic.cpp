@@ -34,7 +34,9 @@ class HelperPool {
   struct Job {
     std::function<void()> fn;
     std::atomic<int> done{0};
+    const void* owner = nullptr;         // the submitting thread (help_until() only takes its own thread's queued jobs)
   };
+  static const void* self() { static thread_local char tag; return &tag; }
   explicit HelperPool(int nhelpers) : owner_(getpid()) {
     for (int i = 0; i < nhelpers; i++) threads_.emplace_back([this] { loop(); });
     pin_near_caller();
@@ -50,7 +52,7 @@ class HelperPool {
     for (auto& t : threads_) t.join();
   }
   int helpers() const { return (int)threads_.size(); }
-  int moves() const { return moves_; }
+  int moves() { std::lock_guard<std::mutex> lk(state_mu_); return moves_; }
   void account_caller(long long wall_ns, long long cpu_ns) {
     wall_ns_.fetch_add(wall_ns, std::memory_order_relaxed);
     cpu_ns_.fetch_add(cpu_ns, std::memory_order_relaxed);
@@ -63,9 +65,12 @@ class HelperPool {
   // after four analyses in a row in which they were off their cores for more than a third of that time the pool moves to another cache group of the same
   // socket (the caller's home with it).  Called by analyze() once the caller is back on its own affinity mask.
   void rebalance() {
-    static const bool off = getenv("CGMR_HOST_MOVE") && atoi(getenv("CGMR_HOST_MOVE")) == 0;
+    // opt-in (CGMR_HOST_MOVE=1): a library inside somebody else's process does not move threads around on its own account
+    static const bool on = getenv("CGMR_HOST_MOVE") && atoi(getenv("CGMR_HOST_MOVE")) != 0;
     const long long w = wall_ns_.exchange(0, std::memory_order_relaxed), c = cpu_ns_.exchange(0, std::memory_order_relaxed);
-    if (off || home_.empty() || group_cur_ < 0 || group_firsts_.size() < 2 || getpid() != owner_) return;
+    if (!on || getpid() != owner_) return;
+    std::lock_guard<std::mutex> lk(state_mu_);                    // (several caller threads analyse: a context per robot, a thread each)
+    if (home_.empty() || group_cur_ < 0 || group_firsts_.size() < 2) return;
     if (w < 200000) return;                                       // (less than 0.2 ms of helper work: no verdict)
     if (3 * c >= 2 * w) { strikes_ = 0; return; }
     if (++strikes_ < (4 << std::min(moves_, 5))) return;           // (every move makes the next one harder: a host that is busy everywhere is not fled from)
@@ -82,10 +87,11 @@ class HelperPool {
     }
     home_busy_.store(false, std::memory_order_release);
   }
-  int home_cpu() const { return home_.empty() ? -1 : home_[0]; }
+  int home_cpu() { std::lock_guard<std::mutex> lk(state_mu_); return home_.empty() ? -1 : home_[0]; }
   // run `job` on a helper if one is idle, else right here; wait() returns when it is done
   void run(Job& job) {
     job.done.store(0, std::memory_order_relaxed);
+    job.owner = self();
     bool queued = false;
     if (getpid() == owner_) {
       std::lock_guard<std::mutex> lk(mu_);
@@ -95,9 +101,10 @@ class HelperPool {
     pending_.fetch_add(1, std::memory_order_release);
     cv_.notify_one();
   }
-  // Returns when `job` is done.  While it is not, the waiting thread takes queued jobs nobody has started yet (this one or
-  // any other) and runs them itself: a helper whose core is busy with somebody else's work -- the GPU boxes are shared --
-  // then costs its share of the section, not a scheduler time slice.
+  // Returns when `job` is done.  While it is not, the waiting thread takes queued jobs of its OWN that nobody has started yet
+  // and runs them itself: a helper whose core is busy with somebody else's work -- the GPU boxes are shared -- then costs
+  // its share of the section, not a scheduler time slice.  (Jobs of other caller threads are left alone: taking another
+  // robot's long job would hold this caller up behind work it never asked for.)
   static void wait(Job& job);
   void help_until(Job& job) {
     static const bool steal = !(getenv("CGMR_HOST_STEAL") && atoi(getenv("CGMR_HOST_STEAL")) == 0);
@@ -105,7 +112,9 @@ class HelperPool {
       Job* other = nullptr;
       if (steal && pending_.load(std::memory_order_acquire) > 0 && getpid() == owner_) {
         std::lock_guard<std::mutex> lk(mu_);
-        if (!queue_.empty()) { other = queue_.front(); queue_.erase(queue_.begin()); pending_.fetch_sub(1); }
+        const void* me = self();
+        for (size_t k = 0; k < queue_.size(); k++)
+          if (queue_[k]->owner == me) { other = queue_[k]; queue_.erase(queue_.begin() + k); pending_.fetch_sub(1); break; }
       }
       if (other) {
         other->fn();
@@ -236,7 +245,7 @@ class HelperPool {
       CPU_SET(picks[i], &one);
       all = all && pthread_setaffinity_np(threads_[i].native_handle(), sizeof one, pin_mode == 2 ? &whole : &one) == 0;
     }
-    if (all) home_ = sib_me.empty() ? std::vector<int>(1, me) : sib_me;
+    if (all) home_ = sib_me.empty() ? std::vector<int>(1, me) : sib_me;     // (callers hold state_mu_ or are the constructor)
     return all;
   }
 
@@ -249,16 +258,22 @@ class HelperPool {
   class CallerAtHome {
    public:
     explicit CallerAtHome(HelperPool& p) {
-      if (p.home_.empty()) return;
+      // opt-in (CGMR_HOST_PIN_CALLER=1): by default the library never touches the affinity of a thread it does not own -- a
+      // ROS node that links it has its own ideas about where its threads run
+      static const bool on = getenv("CGMR_HOST_PIN_CALLER") && atoi(getenv("CGMR_HOST_PIN_CALLER")) != 0;
+      if (!on) return;
       // one caller at a time: a second thread of the process that analyses meanwhile (a context per robot, a thread each)
       // stays where it is instead of queueing up for the same core
       if (p.home_busy_.exchange(true, std::memory_order_acquire)) return;
       pool_ = &p;
+      std::vector<int> home_cpus;
+      { std::lock_guard<std::mutex> lk(p.state_mu_); home_cpus = p.home_; }   // (read under the flag and the lock: a move rewrites it)
+      if (home_cpus.empty()) return;
       if (sched_getaffinity(0, sizeof saved_, &saved_) != 0) return;
       cpu_set_t home;
       CPU_ZERO(&home);
       bool any = false;
-      for (int c : p.home_) if (CPU_ISSET(c, &saved_)) { CPU_SET(c, &home); any = true; }
+      for (int c : home_cpus) if (CPU_ISSET(c, &saved_)) { CPU_SET(c, &home); any = true; }
       if (!any) return;                                          // (the caller may not run there: leave it alone)
       active_ = sched_setaffinity(0, sizeof home, &home) == 0;
     }
@@ -287,11 +302,12 @@ class HelperPool {
     };
     for (;;) {
       Job* job = nullptr;
-      // Spin on the pending counter before sleeping on the condition variable -- for as long as a solve loop takes to come
-      // back with the next analysis (CGMR_HOST_SPIN_US, default 10 ms after the last job; an OpenMP runtime's default is
-      // 200 ms): a helper that sleeps through the 5 ms of device work between two analyses pays a futex wake-up each time,
-      // and on a shared host its core has been given to somebody else in the meantime.
-      static const long long spin_ns = 1000LL * (getenv("CGMR_HOST_SPIN_US") ? std::max(0, atoi(getenv("CGMR_HOST_SPIN_US"))) : 10000);
+      // Spin on the pending counter before sleeping on the condition variable (CGMR_HOST_SPIN_US after the last job, default
+      // 200 us: the sections of one analysis follow each other within microseconds).  A dedicated solve loop can ask for as
+      // long as it takes to come back with the next analysis (the bench sets 10 ms: a helper that sleeps through the 5 ms of
+      // device work between two analyses pays a futex wake-up each time, and on a shared host its core has been given to
+      // somebody else in the meantime) -- not the default, because 8 ranks x 7 helpers would then never sleep.
+      static const long long spin_ns = 1000LL * (getenv("CGMR_HOST_SPIN_US") ? std::max(0, atoi(getenv("CGMR_HOST_SPIN_US"))) : 200);
       const long long spin_until = clock_ns(CLOCK_MONOTONIC) + spin_ns;
       for (unsigned spin = 0; !job; spin++) {
         if (pending_.load(std::memory_order_acquire) > 0) {
@@ -329,6 +345,7 @@ class HelperPool {
   std::atomic<long long> wall_ns_{0}, cpu_ns_{0};   // the helpers' awake time (and the callers' analyses) since the last look: elapsed against CPU time
   std::vector<Job*> queue_;
   std::mutex mu_;
+  std::mutex state_mu_;                  // home_, group_cur_, strikes_, moves_ (several caller threads analyse and rebalance)
   std::condition_variable cv_;
   std::atomic<int> pending_{0};
   int busy_ = 0;
@@ -686,10 +703,11 @@ namespace {
 // A leaf that outgrows two panels is dissected again on its own vertices (a robot that keeps exploring appends to the same
 // leaf: without this the tree would grow a chain of panels there, one level per 16 poses).  Then the order and the panel
 // starts are emitted by a walk over the tree that cuts panels exactly like nd() does.  Returns false if the tree cannot
-// take the vertices (nothing is modified then).
+// take the vertices (order / pstart / pos_ranges are not modified then; prev's tree is consumed either way).
 bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const std::vector<int32_t>& ai,
                   std::vector<int32_t>& order, std::vector<uint8_t>& pstart, std::vector<std::pair<int, int>>& pos_ranges,
-                  Symbolic& S, int n_new_edges, const int32_t* new_ef, const int32_t* new_et, const std::vector<int32_t>& hidx) {
+                  Symbolic& S, int n_new_edges, const int32_t* new_ef, const int32_t* new_et, const std::vector<int32_t>& hidx,
+                  const std::vector<int32_t>& forced_hubs) {
   typedef Symbolic::NDNode Node;
   std::vector<Node> T = std::move(prev.nd_nodes);            // (the caller's previous analysis is discarded afterwards either way)
   const int root = prev.nd_root;
@@ -711,9 +729,29 @@ bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const 
     while (x != y) { if (depth[x] >= depth[y]) x = T[x].parent; else y = T[y].parent; }
     return x;
   };
+  // ---- forced hubs (the caller names them: the gauge vertices of the condensed stars received from the peers) live in the
+  // root's separator: a vertex may always move UP the tree (it is eliminated later; whatever it couples is then coupled
+  // through a separator above both), and an edge to a vertex of the root lies on a root path whatever its other end
+  std::vector<uint8_t> placed(nf, 0);
+  for (int h : forced_hubs) {
+    if (h < 0 || h >= nf) continue;
+    const int x = where[h];
+    if (x == root) continue;
+    if (x >= 0) {
+      std::vector<int32_t>& vx = T[x].verts;
+      vx.erase(std::find(vx.begin(), vx.end(), h));
+      for (int y = x; y >= 0 && y != root; y = T[y].parent) T[y].count--;
+    } else {
+      T[root].count++;
+    }
+    T[root].verts.push_back(h);
+    where[h] = root;
+    placed[h] = 1;
+  }
   std::vector<int> grown;                                 // leaves to look at again
   std::vector<int> cand;
   for (int v = prev.nf; v < nf; v++) {
+    if (placed[v]) continue;
     cand.clear();
     for (int p = ap[v]; p < ap[v + 1]; p++) {
       const int x = where[ai[p]];
@@ -834,11 +872,34 @@ bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const 
       return out;
     }
   };
-  std::fill(pstart.begin(), pstart.end(), 0);
-  pos_ranges.clear();
-  Emit E{T, order, pstart, pos_ranges};
-  E.walk(root, 0);
+  // (into temporaries: `order` and `pstart` stay the caller's identity order / zeros unless the tree takes every vertex
+  // exactly once -- the from-scratch ordering that follows a refusal starts from them)
+  {
+    size_t held = 0;
+    std::vector<int> stack(1, root);
+    while (!stack.empty()) {
+      const int x = stack.back(); stack.pop_back();
+      held += T[x].verts.size();
+      for (int c : {T[x].a, T[x].b}) if (c >= 0) stack.push_back(c);
+    }
+    if (held != (size_t)nf) return false;
+  }
+  std::vector<int32_t> order2(nf);
+  std::vector<uint8_t> pstart2(nf, 0);
+  std::vector<std::pair<int, int>> ranges2;
+  Emit E{T, order2, pstart2, ranges2};
+  const NDRange whole = E.walk(root, 0);
   if (E.pos != nf) return false;
+  // The device pays per tree level (one factor + one update launch and a backward hop, ~26 us per Gauss-Newton pass), an
+  // extension saves ~0.35 ms of ordering: a tree that has grown more than a few panels taller than the last from-scratch
+  // ordering's is not worth keeping (CGMR_SYM_EXTEND_SLACK panels, default 2; the simulated C5 rounds of eight robots: mean
+  // tree height 13.5 levels extended without the bound, 11.2 from scratch every round).
+  static const int slack = getenv("CGMR_SYM_EXTEND_SLACK") ? atoi(getenv("CGMR_SYM_EXTEND_SLACK")) : 2;
+  if (slack >= 0 && prev.nd_height_full > 0 && whole.height > prev.nd_height_full + slack) return false;
+  S.nd_height_full = prev.nd_height_full;
+  order.swap(order2);
+  pstart.swap(pstart2);
+  pos_ranges.swap(ranges2);
   S.nd_nodes.swap(T);
   S.nd_root = root;
   S.nd_nf_full = prev.nd_nf_full;
@@ -848,7 +909,8 @@ bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const 
 
 }  // namespace
 
-int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev) {
+int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev,
+            int n_common, const int32_t* hub_vertices, int n_hub_vertices) {
   double t0 = now_s();
   static const bool trace = getenv("CGMR_SYM_TRACE") != nullptr;
   struct Rebalance {                                             // (destroyed after at_home: the caller's own mask is back)
@@ -948,8 +1010,18 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     for (int v = 0; v < prev->nV && same; v++) same = (S.hidx[v] == prev->hidx[v]);
     static const bool extend_on = !(getenv("CGMR_SYM_EXTEND") && atoi(getenv("CGMR_SYM_EXTEND")) == 0);
     const int n_new = nf - prev->nf;
-    if (same && extend_on && prev->nd_appended + n_new <= std::max(64, prev->nd_nf_full / 4))
-      extended = prev->nE <= nE && extend_order(*prev, nf, ap, ai, order, pstart, pos_ranges, S, nE - prev->nE, ef + prev->nE, et + prev->nE, S.hidx);
+    // edges [0, n_common) are the previous list's first n_common (default: all of it -- a grown list); the others are checked
+    // against the tree one by one; edges the previous list had beyond that and this one has not are simply gone (a tree
+    // that separates a graph separates every graph with fewer edges)
+    const int nc = n_common < 0 ? prev->nE : std::min(n_common, std::min(prev->nE, nE));
+    if (same && extend_on && (n_common >= 0 || prev->nE <= nE) && prev->nd_appended + n_new <= std::max(64, prev->nd_nf_full / 4)) {
+      std::vector<int32_t> fh;
+      for (int k = 0; k < n_hub_vertices; k++) {
+        const int v = hub_vertices[k];
+        if (v >= 0 && v < nV && S.hidx[v] >= 0 && std::find(fh.begin(), fh.end(), S.hidx[v]) == fh.end()) fh.push_back(S.hidx[v]);
+      }
+      extended = extend_order(*prev, nf, ap, ai, order, pstart, pos_ranges, S, nE - nc, ef + nc, et + nc, S.hidx, fh);
+    }
   }
   if (!extended) {
     NDCtx C{ap, ai, order, pstart};
@@ -974,6 +1046,16 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
         hubs.resize(3 * kPanelW);
         std::sort(hubs.begin(), hubs.end());
       }
+      // ... and the vertices the caller names (a star of fewer than `thr` edges ties subtrees together just the same: the
+      // eight-robot C5 rounds had trees of 13-31 levels on 2100 vertices where the own edges alone give 9-10)
+      if (hub_min > 0 && n_hub_vertices > 0) {
+        for (int k = 0; k < n_hub_vertices; k++) {
+          const int v = hub_vertices[k];
+          if (v >= 0 && v < nV && S.hidx[v] >= 0) hubs.push_back(S.hidx[v]);
+        }
+        std::sort(hubs.begin(), hubs.end());
+        hubs.erase(std::unique(hubs.begin(), hubs.end()), hubs.end());
+      }
       if (!hubs.empty()) {
         std::vector<uint8_t> is_hub(nf, 0);
         for (int v : hubs) is_hub[v] = 1;
@@ -984,7 +1066,8 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     }
     const int n_nd = nf - (int)hubs.size();
     int root_rec = -1;
-    nd(C, 0, n_nd, 0, -1, &root_rec);
+    const NDRange whole = nd(C, 0, n_nd, 0, -1, &root_rec);
+    S.nd_height_full = whole.height + (nf - n_nd + kPanelW - 1) / kPanelW;
     for (int p = n_nd; p < nf; p += kPanelW) pstart[p] = 1;
     pos_ranges.swap(C.subtree_ranges);
     // the tree with its vertices, for the next extension

@@ -136,6 +136,7 @@ struct Symbolic {
   int32_t nd_root = -1;
   int32_t nd_nf_full = 0;              // free poses when the ordering was last computed from scratch
   int32_t nd_appended = 0;             // vertices inserted incrementally since then
+  int32_t nd_height_full = 0;          // height of that ordering's tree, in panels (before amalgamation)
   bool extended = false;               // this analysis re-used the previous ordering
   int max_ns = 0;
   double flops = 0;                    // factorisation flops (dense fronts)
@@ -153,6 +154,12 @@ void host_run_tasks(int n, const std::function<void(int)>& task);
 // prev (nullable): the analysis of a graph whose edge list is a prefix of this one and whose vertices are the first
 // prev->nV of this one's -- the ordering is then extended instead of recomputed where that is possible (S.extended);
 // prev's dissection tree is consumed.
-int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev = nullptr);
+// n_common (>= 0): only the first n_common edges are known to be prev's first n_common -- the rest of this list is new or
+// moved, the rest of prev's may be gone (a robot's graph: own edges, appended, then the edges received from the peers,
+// replaced every round); default: all of prev's edge list is a prefix of this one.
+// hub_vertices (nullable): vertices to keep out of the dissection and eliminate last whatever their degree (the gauge
+// vertices of the condensed stars received from the peers: every received edge has one of them at an end).
+int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev = nullptr,
+            int n_common = -1, const int32_t* hub_vertices = nullptr, int n_hub_vertices = 0);
 
 }  // namespace cgmr

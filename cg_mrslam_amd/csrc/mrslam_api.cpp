@@ -339,7 +339,12 @@ int cgmr_graph_optimize(cgmr_graph* g, int iters, double* chi2_out) {
   Ed.meas_b = g->d_meas_b; Ed.info_b = g->d_info_b;
   Ed.nA = (int)g->ef.size(); Ed.n_active = nE;
   const double t0 = wall_s();
-  int rc = gn_run(ctx, nV, (double*)g->d_poses.ptr, g->fixed.data(), nE, g->all_ef.data(), g->all_et.data(), Ed, iters, chi2_out);
+  // the gauge vertices of the stars received from the peers (every received edge starts at one): hubs of the ordering
+  std::vector<int32_t> hubs;
+  for (int p = 0; p < g->n_robots; p++)
+    for (int32_t v : g->in[p].from_idx) if (std::find(hubs.begin(), hubs.end(), v) == hubs.end()) hubs.push_back(v);
+  int rc = gn_run(ctx, nV, (double*)g->d_poses.ptr, g->fixed.data(), nE, g->all_ef.data(), g->all_et.data(), Ed, iters, chi2_out,
+                  hubs.data(), (int)hubs.size());
   g->last_optimize_seconds = wall_s() - t0;
   g->solved_ef = g->all_ef; g->solved_et = g->all_et;
   g->solved_nV = nV; g->solved_nA = (int)g->ef.size();

@@ -37,6 +37,7 @@ extern "C" {
 #define CGMR_E_NO_DEVICE (-2)    /* no usable HIP device */
 #define CGMR_E_HIP (-3)          /* HIP runtime error */
 #define CGMR_E_ALLOC (-4)
+#define CGMR_E_TIMEOUT (-5)      /* a bounded in-kernel wait ran out (a device-side hand-off that never arrived): NOT a numerical failure */
 #define CGMR_E_CHOLESKY_BASE (-100) /* Cholesky failed in GN iteration it: returns CGMR_E_CHOLESKY_BASE - it */
 
 typedef struct cgmr_ctx cgmr_ctx;
@@ -96,10 +97,17 @@ int cgmr_gn_optimize_dev(cgmr_ctx* ctx, int nV, double* d_poses_xyt, const uint8
  * cached nested-dissection tree (into the leaf their neighbours live in, or the separator above them), everything
  * downstream of the ordering is rebuilt; after a quarter of the graph has been inserted that way the ordering is computed
  * from scratch again.  Same results as a from-scratch analysis to rounding (another elimination order).
- * cgmr_symbolic_cache_stats: out[0] = calls served from the cache, out[1] = calls that analysed from scratch,
- * out[2] = calls that analysed by extending the cached ordering.                                          */
+ * cgmr_symbolic_cache_stats (ABI of version 100, two values): out[0] = calls served from the cache, out[1] = calls that
+ * analysed (from scratch or by extending the cached ordering).  cgmr_symbolic_cache_stats3 (version >= 101) splits the
+ * second: out[1] = analysed from scratch, out[2] = analysed by extending the cached ordering.               */
 int cgmr_set_symbolic_cache(cgmr_ctx* ctx, int on);
-int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[3]);
+int cgmr_symbolic_cache_stats(const cgmr_ctx* ctx, int64_t out[2]);
+int cgmr_symbolic_cache_stats3(const cgmr_ctx* ctx, int64_t out[3]);
+/* The chained backward solve waits, inside one launch, for values other workgroups produce; every wait is bounded.  When
+ * one runs out the call does not report a Cholesky failure: cgmr_gn_optimize* repeats the iterations that were not applied
+ * with one backward launch per tree level (no in-kernel waits) and returns CGMR_OK; the batched condensed-graph /
+ * marginals paths return CGMR_E_TIMEOUT.  cgmr_gn_timeouts: how often that has happened on this context.           */
+int64_t cgmr_gn_timeouts(const cgmr_ctx* ctx);
 
 /* The host threads behind the symbolic analysis (no reference counterpart: g2o's analysis is one thread).
  * out[0] = threads an analysis uses, the caller included (CGMR_HOST_THREADS, default by core count); out[1] = 1 if the

@@ -234,3 +234,27 @@ def test_growing_graph_extends_the_analysis_and_matches_the_oracle_every_round(c
     s1 = ctx.symbolic_cache_stats()
     assert checked >= 17
     assert s1["extended"] - s0["extended"] >= 80 and (s1["misses"] - s0["misses"]) + (s1["extended"] - s0["extended"]) == 100
+
+
+def test_backward_solve_timeout_is_not_a_cholesky_failure(oracle):
+    """A bounded wait of the chained backward solve that runs out (forced here: CGMR_BWD_SPIN_LIMIT=1, one poll per wait)
+    must not look like a singular system: cgmr_gn_optimize repeats the iterations that were not applied with one backward
+    launch per level and returns OK with the oracle's result; the context counts the event (cgmr_gn_timeouts)."""
+    from cg_mrslam_amd import Context
+    g = synth.make_pose_graph(2500, 9000, seed=5)
+    a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+    st, p2, chi2, _ = oracle.gn_optimize(*a, 6)
+    c = Context(0)
+    rc0, p0, chi0 = c.gn_optimize(*a, 6)
+    assert rc0 == 0 and c.gn_timeouts() == 0
+    os.environ["CGMR_BWD_SPIN_LIMIT"] = "1"
+    try:
+        rc, p, chi = c.gn_optimize(*a, 6)
+    finally:
+        del os.environ["CGMR_BWD_SPIN_LIMIT"]
+    assert rc == 0 and st == 0
+    assert c.gn_timeouts() >= 1, "the forced time-out did not happen: the test checks nothing"
+    _check(p, chi, p2, chi2)
+    np.testing.assert_allclose(chi, chi0, rtol=1e-9)
+    rc, p, chi = c.gn_optimize(*a, 6)                        # and the chained launch is back afterwards
+    assert rc == 0 and np.array_equal(chi, chi0)

@@ -163,11 +163,11 @@ def _front_table(V, fixed, ef, et):
     return out[:6 * n].reshape(n, 6), info, perm
 
 
-def _assert_valid_elimination_tree(V, fixed, ef, et):
+def _assert_valid_elimination_tree(V, fixed, ef, et, table=None):
     """Front table = (c0, nc, ns, parent, level, nchild).  The fronts tile the permuted columns, hold <= 16 poses, parents
     come later and sit on a higher level, and for every edge the front of the later column is an ancestor (or the
     front itself) of the front of the earlier one -- the property the level-by-level factorisation relies on."""
-    F, info, perm = _front_table(V, fixed, ef, et)
+    F, info, perm = table if table is not None else _front_table(V, fixed, ef, et)
     nf = info["free_poses"]
     n = len(F)
     assert n == info["fronts"]
@@ -500,6 +500,41 @@ def test_extension_is_refused_when_new_edges_join_old_vertices_of_different_subt
     assert outs["1"] == outs["8"], (outs["1"], outs["8"])
     plain, crossed = outs["8"][0].split(), outs["8"][1].split()
     assert plain[1] == "1" and crossed[1] == "0"             # extended without the cross edges, rebuilt with them
+
+
+def test_robot_graph_rounds_extend_the_ordering_with_the_received_stars_as_hubs():
+    """A robot's edge list is its own edges (appended to) followed by the stars received from the peers (replaced every
+    round): never a grown prefix.  With the stars' gauge vertices named as hubs (cgmr_graph_optimize does) they live in the
+    root's separator, every received edge lies on a root path, and the cached ordering is extended over the own part as for
+    a robot alone.  Checked on host-only C5 rounds of three robots: most rounds extend, the last analysis is a valid
+    elimination tree about as tall as a from-scratch one (the height bound of the extension), the hubs sit in the last
+    columns, and the sequence gives the same analysis with 1 and with 8 host threads."""
+    import subprocess, sys
+    from robot_sequences import robot_sequences, run_steps
+    seq = robot_sequences(3, 1500, 5000, seed=31)
+    for steps in seq:
+        nV, ef, et, n_own, hubs = steps[-1]
+        assert len(ef) > n_own and len(hubs) >= 1                               # the peers' stars are in the list
+        info, perm, n_ext, fronts, per = run_steps(steps, use_hubs=True)
+        _assert_valid_elimination_tree(nV, None, ef, et, table=(fronts, info, perm))
+        assert n_ext >= 0.6 * (len(steps) - 1), n_ext
+        scratch = run_steps([steps[-1]], use_hubs=True)[0]
+        assert info["levels"] <= scratch["levels"] + 4 and info["factor_flops"] <= 1.5 * scratch["factor_flops"]
+        assert perm[hubs].min() >= info["free_poses"] - 16 * 4                   # eliminated last
+        assert run_steps(steps, use_hubs=False)[2] <= n_ext                      # without the hints: (almost) nothing extends
+    code = ("import sys, numpy as np\nsys.path.insert(0, 'tests')\nfrom robot_sequences import robot_sequences, run_steps\n"
+            "seq = robot_sequences(3, 1500, 5000, seed=31)\n"
+            "for steps in seq:\n"
+            "    info, perm, n_ext, fronts, per = run_steps(steps)\n"
+            "    print(n_ext, info['fronts'], info['levels'], info['L_doubles'], info['U_doubles'], int((perm * np.arange(len(perm))).sum() % 1000003), int(fronts.sum()))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for nt in ("1", "8"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root, CGMR_HOST_THREADS=nt),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1], outs
 
 
 @pytest.mark.parametrize("shape", ["walk", "hub"])
