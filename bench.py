@@ -36,6 +36,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The library's host-side defaults are those of a guest in somebody else's process (helpers pinned around one last-level
+# cache, the CALLER's affinity never touched, no pool moves, helpers asleep 200 us after their last job: INTEGRATION.md).  The
+# bench is a dedicated solve loop and opts into what such a loop wants -- stated here and in the JSON line (`host_pool.opt_in`);
+# set any of them in the environment to override.
+HOST_OPT_IN = {"CGMR_HOST_PIN_CALLER": "1", "CGMR_HOST_MOVE": "1", "CGMR_HOST_SPIN_US": "10000"}
+for _k, _v in HOST_OPT_IN.items():
+    os.environ.setdefault(_k, _v)
+
 GN_ITERS = 10
 
 
@@ -716,7 +724,7 @@ def main():
         "host_symbolic_ms_per_step": round(1e3 * host_sym / args.steps, 3),
         "host_threads": host_threads(),
         "host_loadavg_1min": round(os.getloadavg()[0], 1),   # runnable threads on the (shared) host, this process's included: a busy neighbour shows here
-        "host_pool": ctx.host_threads_info(),          # as the library runs them: pinned around a last-level cache or not, where
+        "host_pool": dict(ctx.host_threads_info(), opt_in={k: os.environ.get(k) for k in HOST_OPT_IN}),          # as the library runs them: pinned around a last-level cache or not, where
         "host_symbolic_ms_one_thread": (host_symbolic_ms_one_thread(V, E, 12345 + 17 * rank) if world == 1 else None),
         "device_ms_per_step": round(1e3 * dev_time / args.steps, 3),
         "warm": warm, "keyframe": keyframe,

@@ -41,7 +41,8 @@ class RobotGraph:
     #: edges (and closure ids) per peer a reference message holds: MAX_LENGTH_MSG = 100000 bytes of 44-byte edges (msg_factory.h:115)
     REFERENCE_CAP_EDGES = 2270
 
-    def __init__(self, ctx: Context | None, robot: int, n_robots: int, base_id: int = 10000, cap_edges: int = 128):
+    def __init__(self, ctx: Context | None, robot: int, n_robots: int, base_id: int = 10000, cap_edges: int = 128,
+                 async_condense: bool = False):
         self.lib = ctx.lib if ctx is not None else load_library()
         self.lib.cgmr_graph_last_error.restype = C.c_char_p
         self.lib.cgmr_graph_wire_bytes.restype = C.c_int64
@@ -56,6 +57,11 @@ class RobotGraph:
         if rc != 0:
             raise CgmrError(rc, "cgmr_graph_create failed")
         self.h = h
+        # computeCondensedGraph queues its passes on the context's side stream and returns (cgmr_graph_compute_condensed_async):
+        # they run beside the next round's grow / analysis / solve; pack, the all-gather and deliver() follow them on the device
+        self.async_condense = bool(async_condense) and ctx is not None
+        if self.async_condense:
+            self._check(self.lib.cgmr_graph_set_async(self.h, C.c_int(1)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -126,7 +132,17 @@ class RobotGraph:
 
     def computeCondensedGraph(self, peer: int = -1):   # noqa: N802
         """``computeCondensedGraph`` for one peer or (``peer < 0``) for every peer that has asked; returns the number built."""
+        if self.async_condense:
+            return self._check(self.lib.cgmr_graph_compute_condensed_async(self.h, C.c_int(peer)))
         return self._check(self.lib.cgmr_graph_compute_condensed(self.h, C.c_int(peer)))
+
+    def condensed_wait(self):
+        """Wait for the passes ``computeCondensedGraph`` queued (``async_condense``); raises if one of them failed."""
+        self._check(self.lib.cgmr_graph_condensed_wait(self.h))
+
+    def deliver(self, dst: "RobotGraph"):
+        """My packed message (``pack()`` first) into ``dst``'s receive buffer, on the device (robots sharing a GPU)."""
+        self._check(self.lib.cgmr_graph_deliver(self.h, dst.h))
 
     def condensed(self, peer):
         """(gauge id, to ids[n], est[n,3], info_upper[n,6]) of the condensed graph built for ``peer``, double precision."""
@@ -329,6 +345,7 @@ class Exchange:
             self.pending = "rccl"
         elif self.transport == "torch":
             g.pack(self.t_send.data_ptr())
+            g.ctx._check(g.lib.cgmr_ctx_join_side(g.ctx.h))     # (a batch queued on the context's side stream: the packed message sits behind it)
             # the context's stream is not torch's: torch's stream waits (on the device) for the packed message, the
             # collective then overlaps with whatever the context's stream does next -- as on the native transport
             self.torch.cuda.current_stream(self.t_send.device).wait_stream(self.ctx_stream)

@@ -35,9 +35,44 @@ int set_err(cgmr_ctx* ctx, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return set_err(ctx, CGMR_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
+int side_stream(cgmr_ctx* ctx) {
+  if (ctx->side) return 0;
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_tail, hipEventDisableTiming));
+  return 0;
+}
+
+int side_fork(cgmr_ctx* ctx) {
+  int rc = side_stream(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_fork, 0));
+  return 0;
+}
+
+int side_mark(cgmr_ctx* ctx) {
+  HIP_TRY(ctx, hipEventRecord(ctx->side_tail, ctx->side));
+  ctx->side_busy = true;
+  return 0;
+}
+
+int side_join_host(cgmr_ctx* ctx) {
+  if (!ctx->side_busy) return 0;
+  HIP_TRY(ctx, hipEventSynchronize(ctx->side_tail));
+  ctx->side_busy = false;
+  return 0;
+}
+
+int side_join_stream(cgmr_ctx* ctx, hipStream_t st) {
+  if (!ctx->side_busy) return 0;
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->side_tail, 0));
+  return 0;
+}
+
 int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes) {
   if (bytes <= A.cap) return 0;
-  if (A.ptr) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(A.ptr); A.ptr = nullptr; A.cap = 0; }
+  if (A.ptr) { (void)hipStreamSynchronize(ctx->stream); (void)side_join_host(ctx); (void)hipFree(A.ptr); A.ptr = nullptr; A.cap = 0; }
   size_t want = bytes + bytes / 4 + (1 << 20);
   hipError_t e = hipMalloc((void**)&A.ptr, want);
   if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
@@ -47,7 +82,7 @@ int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes) {
 
 int pinned_reserve(cgmr_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->pinned_cap) return 0;
-  if (ctx->pinned) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+  if (ctx->pinned) { (void)hipStreamSynchronize(ctx->stream); (void)side_join_host(ctx); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
   size_t want = bytes + bytes / 4 + (1 << 16);
   hipError_t e = hipHostMalloc((void**)&ctx->pinned, want, hipHostMallocDefault);
   if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
@@ -57,7 +92,7 @@ int pinned_reserve(cgmr_ctx* ctx, size_t bytes) {
 
 int pinned_mask_reserve(cgmr_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->pinned_mask_cap) return 0;
-  if (ctx->pinned_mask) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pinned_mask); ctx->pinned_mask = nullptr; ctx->pinned_mask_cap = 0; }
+  if (ctx->pinned_mask) { (void)hipStreamSynchronize(ctx->stream); (void)side_join_host(ctx); (void)hipHostFree(ctx->pinned_mask); ctx->pinned_mask = nullptr; ctx->pinned_mask_cap = 0; }
   size_t want = bytes + bytes / 2 + 4096;
   hipError_t e = hipHostMalloc((void**)&ctx->pinned_mask, want, hipHostMallocDefault);
   if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
@@ -254,6 +289,9 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
     }
   });
   char* d = ctx->gn_arena.ptr;
+  // a batch on the side stream still reads the structure this upload replaces
+  rc = side_join_stream(ctx, ctx->stream);
+  if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(d, h, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
   D.fronts = (FrontDesc*)(d + o_fronts);
   D.fronts_lv = (FrontDesc*)(d + o_fronts_lv);
@@ -293,7 +331,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   // the upper levels of the tree are solved backwards in one chained launch: as many levels as fit the workgroups that
   // are certainly resident together (the waits inside the launch cannot deadlock then); CGMR_BWD_CHAIN=0: one launch per level
   static const int chain_env = getenv("CGMR_BWD_CHAIN") ? atoi(getenv("CGMR_BWD_CHAIN")) : -1;
-  const int chain_cap = chain_env >= 0 ? std::min(chain_env, bwd_chain_capacity()) : bwd_chain_capacity();
+  const int chain_all = bwd_chain_capacity() / (ctx->side_used ? 2 : 1);      // (the other half: the side stream's batches)
+  const int chain_cap = chain_env >= 0 ? std::min(chain_env, chain_all) : chain_all;
   D.bwd_chain_level = D.nlevels;
   while (D.bwd_chain_level > 0 && D.h_level_ptr[D.nlevels] - D.h_level_ptr[D.bwd_chain_level - 1] <= chain_cap) D.bwd_chain_level--;
   return 0;
@@ -407,7 +446,7 @@ int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef,
 }
 
 int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et,
-                    int n_active, int slot, int nslots, bool upload) {
+                    int n_active, int slot, int nslots, bool upload, char* stage) {
   const Symbolic& S = ctx->sym;
   ctx->vmask.assign(S.nV, 0);
   if (fixed) for (int v = 0; v < S.nV; v++) ctx->vmask[v] = fixed[v] ? 1 : 0;
@@ -420,9 +459,12 @@ int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* f
   if (S.nf == 0) return 0;
   // several passes may be queued without a host synchronisation in between (one condensed graph per peer): each
   // stages its mask in a slot of its own
-  int rc = pinned_mask_reserve(ctx, (size_t)S.nf * std::max(nslots, 1));
-  if (rc) return rc;
-  char* pm = ctx->pinned_mask + (size_t)S.nf * slot;
+  if (!stage) {
+    int rc = pinned_mask_reserve(ctx, (size_t)S.nf * std::max(nslots, 1));
+    if (rc) return rc;
+    stage = ctx->pinned_mask;
+  }
+  char* pm = stage + (size_t)S.nf * slot;
   for (int c = 0; c < S.nf; c++) pm[c] = (char)ctx->vmask[S.perm[c]];
   if (upload) HIP_TRY(ctx, hipMemcpyAsync(D.cmask, pm, (size_t)S.nf, hipMemcpyHostToDevice, st));
   return 0;
@@ -569,6 +611,11 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   int status4[4] = {0, 0, 0, 0};
   HIP_TRY(ctx, hipMemcpyAsync(chi.data(), D.chi2, sizeof(double) * (iters + 1), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(status4, D.status, sizeof status4, hipMemcpyDeviceToHost, st));
+  // the caller's host copy of the estimates, in the same wait (a robot graph whose peers have asked for condensed graphs
+  // picks their gauges from it right after the solve)
+  double* const poses_host = ctx->poses_out_host;
+  ctx->poses_out_host = nullptr;
+  if (poses_host && nV > 0) HIP_TRY(ctx, hipMemcpyAsync(poses_host, d_poses, 24 * (size_t)nV, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -587,6 +634,7 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
     for (int it = it0; it <= iters; it++) gn_pass(ctx, d_poses, Ed, it, it == iters, true, false);
     HIP_TRY(ctx, hipMemcpyAsync(chi.data(), D.chi2, sizeof(double) * (iters + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(status4, D.status, sizeof status4, hipMemcpyDeviceToHost, st));
+    if (poses_host && nV > 0) HIP_TRY(ctx, hipMemcpyAsync(poses_host, d_poses, 24 * (size_t)nV, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
     D.bwd_chain_level = chain_was;
@@ -778,6 +826,8 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (ctx->rep_arena.ptr) (void)hipFree(ctx->rep_arena.ptr);
   if (ctx->mg_arena.ptr) (void)hipFree(ctx->mg_arena.ptr);
   for (hipStream_t a : ctx->aux) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+  for (hipEvent_t e : {ctx->side_fork, ctx->side_tail}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->aux_done) (void)hipEventDestroy(e);
   if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -34,6 +34,15 @@ struct cgmr_ctx {
   std::vector<hipStream_t> aux;          // side streams of the concurrent passes
   std::vector<hipEvent_t> aux_done;
   hipEvent_t aux_fork = nullptr;
+  // Side stream: batches of condensed-graph passes queued without waiting for them (cgmr_graph_compute_condensed_async) run
+  // beside whatever the context's stream does next -- the next round's structure analysis on the host, its solve on the
+  // device.  They work in replicas of the numeric buffers and READ the uploaded structure: a new structure upload, a
+  // reallocation of any arena and the next batch order themselves behind side_tail.
+  hipStream_t side = nullptr;
+  hipEvent_t side_fork = nullptr, side_tail = nullptr;   // side_tail: behind everything queued on the side stream so far
+  bool side_busy = false;        // the side stream may still be working (cleared by a host wait on side_tail)
+  bool side_used = false;        // asynchronous batches are in use on this context: the chained backward solves of the two
+                                 // streams share the workgroups that are certainly resident together, half each
   char* pinned = nullptr;
   size_t pinned_cap = 0;
   char* pinned_mask = nullptr;   // staging of the per-pass column mask (own buffer: the blob staging above is shared)
@@ -49,6 +58,7 @@ struct cgmr_ctx {
   std::vector<uint8_t> vmask;    // per vertex: masked in the current pass
   cgmr::Symbolic sym;
   cgmr::GnDevice gn;
+  double* poses_out_host = nullptr;   // set by a caller of gn_run: host buffer the final estimates are copied to (one-shot)
   double timing[5] = {0, 0, 0, 0, 0};
   double match_seconds = 0;
   int64_t match_pairs = 0, match_slow_pairs = 0;   // last batched close-matching launch: pairs, pairs off the LDS fast path
@@ -67,4 +77,9 @@ double wall_s();
 int set_err(cgmr_ctx* ctx, int code, const char* fmt, ...);
 int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes);
 int pinned_reserve(cgmr_ctx* ctx, size_t bytes);
+int side_stream(cgmr_ctx* ctx);                     // creates the side stream on first use
+int side_fork(cgmr_ctx* ctx);                       // the side stream waits for everything queued on the context's stream so far
+int side_mark(cgmr_ctx* ctx);                       // call after queueing on the side stream: moves side_tail behind it
+int side_join_host(cgmr_ctx* ctx);                  // the host waits until the side stream is idle
+int side_join_stream(cgmr_ctx* ctx, hipStream_t st);   // st waits (on the device) for what is on the side stream now
 }  // namespace cgmr

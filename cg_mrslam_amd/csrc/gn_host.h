@@ -14,7 +14,7 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
 int prepare_pass(cgmr_ctx* ctx, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, int n_active, int slot,
                  int nslots);
 int prepare_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et,
-                    int n_active, int slot, int nslots, bool upload = true);
+                    int n_active, int slot, int nslots, bool upload = true, char* stage = nullptr);   // stage: the masks' staging block (default: the context's)
 // a batch of passes (D.njobs, D.job_stride): the masks staged with prepare_pass_on(.., slot j, njobs, upload = false) and
 // clean status words for every job, two 2-D copies
 int prepare_batch_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st);

@@ -91,6 +91,21 @@ struct cgmr_graph {
   std::vector<uint8_t> hs_fresh;      // per peer: hs_meas / hs_info hold what the device staging holds
   double last_condense_seconds = 0, last_optimize_seconds = 0;
   bool optimal_gauge = false;         // computeCondensedGraph(robot, optimal)
+  bool h_poses_fresh = false;         // h_poses holds the estimates as the last optimize() left them
+  // a batch of condensed-graph passes queued on the context's side stream and not waited for yet
+  // (cgmr_graph_compute_condensed_async): what is needed to finish it
+  bool cond_pending = false;
+  std::vector<int32_t> cond_peers;    // peer of every job of the batch
+  const int32_t* cond_status = nullptr;   // pinned: 4 status words per job, valid after ev_cond_done
+  const CondJobDev* cond_jobs_dev = nullptr;    // the batch's job table on the device (peer of job j = out_slot)
+  const int* cond_status_dev = nullptr;         // first job's status words on the device; cond_status_stride bytes to the next
+  long long cond_status_stride = 0;
+  char* cond_pinned = nullptr;        // staging block of an asynchronous batch (the context's is the solver's)
+  size_t cond_pinned_cap = 0;
+  hipEvent_t ev_cond_done = nullptr, ev_pack = nullptr, ev_packed = nullptr;
+  bool pack_in_flight = false;        // the uploads of the last cgmr_graph_pack may not have left the pinned block yet
+  std::vector<hipEvent_t> ev_consumed;          // per destination robot: its copy of my send buffer is done (cgmr_graph_deliver)
+  std::vector<uint8_t> consumed_pending;
 };
 
 namespace {
@@ -111,6 +126,8 @@ int dev_grow(cgmr_graph* g, DevBuf& B, size_t used_bytes, size_t need_bytes) {
   if (B.ptr) {
     if (used_bytes) HIP_TRY(ctx, hipMemcpyAsync(p, B.ptr, used_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = side_join_host(ctx);                  // (a batch on the side stream reads the measurements / vertex ids)
+    if (rc) { (void)hipFree(p); return rc; }
     (void)hipFree(B.ptr);
   }
   B.ptr = p;
@@ -144,6 +161,37 @@ int alloc_fixed(cgmr_graph* g) {
   g->pinned_bytes += round256(72 * cap);
   HIP_TRY(ctx, hipHostMalloc((void**)&g->pinned, g->pinned_bytes, hipHostMallocDefault));
   HIP_TRY(ctx, hipEventCreateWithFlags(&g->ev_msg, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&g->ev_cond_done, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&g->ev_pack, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&g->ev_packed, hipEventDisableTiming));
+  g->ev_consumed.assign(g->n_robots, nullptr);
+  g->consumed_pending.assign(g->n_robots, 0);
+  for (hipEvent_t& e : g->ev_consumed) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return 0;
+}
+
+// Finish the pending asynchronous batch: wait for it, look at the status words.  A failed pass leaves nothing to send to any
+// peer of the batch (as the synchronous call does); the header of a message packed meanwhile was corrected on the device.
+int cond_finish(cgmr_graph* g) {
+  if (!g->cond_pending) return 0;
+  cgmr_ctx* ctx = g->ctx;
+  g->cond_pending = false;
+  HIP_TRY(ctx, hipEventSynchronize(g->ev_cond_done));
+  bool failed = false, timed_out = false;
+  for (size_t j = 0; j < g->cond_peers.size(); j++) {
+    if (g->cond_status[4 * j] != 0) failed = true;
+    if (g->cond_status[4 * j + 2] != 0) timed_out = true;
+  }
+  if (!failed) return 0;
+  for (int32_t p : g->cond_peers) { g->out[p].n = 0; g->out[p].host_valid = false; }
+  if (timed_out) { ctx->gn_timeouts++; return gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
+  return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
+}
+
+// whatever is about to overwrite my send buffer waits for the robots that are still copying it (cgmr_graph_deliver)
+int wait_consumers(cgmr_graph* g, hipStream_t st) {
+  for (size_t d = 0; d < g->consumed_pending.size(); d++)
+    if (g->consumed_pending[d]) { HIP_TRY(g->ctx, hipStreamWaitEvent(st, g->ev_consumed[d], 0)); g->consumed_pending[d] = 0; }
   return 0;
 }
 
@@ -246,11 +294,14 @@ void cgmr_graph_destroy(cgmr_graph* g) {
   if (g->ctx) {
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
+    (void)side_join_host(g->ctx);
     for (DevBuf* b : {&g->d_poses, &g->d_meas_a, &g->d_info_a, &g->d_vids, &g->d_work})
       if (b->ptr) (void)hipFree(b->ptr);
     if (g->d_fixed_block) (void)hipFree(g->d_fixed_block);
     if (g->pinned) (void)hipHostFree(g->pinned);
-    if (g->ev_msg) (void)hipEventDestroy(g->ev_msg);
+    if (g->cond_pinned) (void)hipHostFree(g->cond_pinned);
+    for (hipEvent_t e : {g->ev_msg, g->ev_cond_done, g->ev_pack, g->ev_packed}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_consumed) if (e) (void)hipEventDestroy(e);
   }
   delete g;
 }
@@ -343,8 +394,14 @@ int cgmr_graph_optimize(cgmr_graph* g, int iters, double* chi2_out) {
   std::vector<int32_t> hubs;
   for (int p = 0; p < g->n_robots; p++)
     for (int32_t v : g->in[p].from_idx) if (std::find(hubs.begin(), hubs.end(), v) == hubs.end()) hubs.push_back(v);
+  // the host copy of the estimates comes back in the solve's own final wait: the condensed graphs that follow pick their
+  // gauges from it, the caller's next key frame dead-reckons from it (cgmr_graph_get_poses: no device round trip then)
+  const bool asked = true;
+  ctx->poses_out_host = g->h_poses.data();
   int rc = gn_run(ctx, nV, (double*)g->d_poses.ptr, g->fixed.data(), nE, g->all_ef.data(), g->all_et.data(), Ed, iters, chi2_out,
                   hubs.data(), (int)hubs.size());
+  ctx->poses_out_host = nullptr;
+  g->h_poses_fresh = asked && (rc == CGMR_OK || rc <= CGMR_E_CHOLESKY_BASE);
   g->last_optimize_seconds = wall_s() - t0;
   g->solved_ef = g->all_ef; g->solved_et = g->all_et;
   g->solved_nV = nV; g->solved_nA = (int)g->ef.size();
@@ -353,7 +410,7 @@ int cgmr_graph_optimize(cgmr_graph* g, int iters, double* chi2_out) {
 
 int cgmr_graph_get_poses(cgmr_graph* g, int first, int n, double* poses_out) {
   if (!g || first < 0 || n < 0 || first + n > (int)g->ids.size() || (n > 0 && !poses_out)) return CGMR_E_INVALID;
-  if (g->ctx && n > 0) {
+  if (g->ctx && n > 0 && !g->h_poses_fresh) {          // (fresh: the last optimize() left them on the host as well)
     cgmr_ctx* ctx = g->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(g->h_poses.data() + 3 * (size_t)first, g->d_poses.ptr + 24 * (size_t)first, 24 * (size_t)n,
@@ -416,9 +473,14 @@ struct CondJob {
 // a side stream: one pass keeps a handful of workgroups busy per tree level, so the passes overlap almost perfectly.
 // to_wire: the labelled edges go to the peer's slots (double-precision copy + 44-byte wire records in the send
 // buffer); otherwise only the information matrices come back (info_out[i], 6 doubles per edge: gauge search).
-int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::vector<std::vector<double>>* info_out) {
+// async_out (nullable): on entry true = queue the batch on the context's side stream and return without waiting (the
+// caller finishes it later: cond_finish); set to false when the batch could not be queued that way and was waited for.
+int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::vector<std::vector<double>>* info_out,
+                  bool* async_out = nullptr) {
   cgmr_ctx* ctx = g->ctx;
   hipStream_t st = ctx->stream;
+  bool go_async = async_out && *async_out;
+  if (async_out) *async_out = false;
   const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), cap = g->cap;
   const int nj = (int)jobs.size();
   if (nj == 0) return 0;
@@ -487,19 +549,53 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   static const bool batch_on = !(getenv("CGMR_COND_BATCH") && atoi(getenv("CGMR_COND_BATCH")) == 0);
   const bool batched = batch_on && nf > 0;            // (a single pass as a batch of one: no side stream to fork and join, staging from pinned memory)
   std::vector<int32_t> status(nj, 0);
+  go_async = go_async && batched && to_wire && !info_out;
+  // whatever ran on the side stream before (another graph of this context, this graph's previous batch) used the replicas
+  // and the marginals work space this batch is about to fill
+  if (go_async) {
+    rc = side_fork(ctx);
+    if (rc) return rc;
+    st = ctx->side;
+    rc = wait_consumers(g, st);
+    if (rc) return rc;
+  } else {
+    rc = side_join_stream(ctx, st);
+    if (rc) return rc;
+    rc = wait_consumers(g, st);
+    if (rc) return rc;
+  }
   if (batched) {
     // staging (the context's mask block: nothing else is in flight from it): masks | initial guesses | query columns |
     // query vertices | job descriptors
     auto up256 = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t s_work = up256((size_t)nf * nj), s_qc = s_work + up256((size_t)24 * nV * nj), s_qv = s_qc + up256((size_t)4 * maxq * nj),
-                 s_jd = s_qv + up256((size_t)4 * maxq * nj), s_st = s_jd + up256(sizeof(CondJobDev) * (size_t)nj), s_end = s_st + 4 * (size_t)nj;
-    rc = pinned_mask_reserve(ctx, s_end);
-    if (rc) return rc;
+                 s_jd = s_qv + up256((size_t)4 * maxq * nj), s_st = s_jd + up256(sizeof(CondJobDev) * (size_t)nj), s_end = s_st + 16 * (size_t)nj;
+    // staging block: the context's (the solver's mask staging -- nothing of it is in flight now) or, for a batch that is
+    // not waited for, the graph's own: the next solve stages its mask while this batch's copy may still be queued
+    char* hstage = nullptr;
+    if (go_async) {
+      if (s_end > g->cond_pinned_cap) {
+        if (g->cond_pinned) {
+          rc = side_join_host(ctx);
+          if (rc) return rc;
+          (void)hipHostFree(g->cond_pinned);
+          g->cond_pinned = nullptr; g->cond_pinned_cap = 0;
+        }
+        const size_t want = s_end + s_end / 2 + 4096;
+        HIP_TRY(ctx, hipHostMalloc((void**)&g->cond_pinned, want, hipHostMallocDefault));
+        g->cond_pinned_cap = want;
+      }
+      hstage = g->cond_pinned;
+    } else {
+      rc = pinned_mask_reserve(ctx, s_end);
+      if (rc) return rc;
+      hstage = ctx->pinned_mask;
+    }
     GnDevice DB = reps[0];
     DB.njobs = nj; DB.job_stride = (long long)rep_stride; DB.pose_stride = 24LL * nV;
     // the chained backward solve needs its workgroups resident together: the chain of the batch takes nj times the slots
     {
-      const int cap_blocks = bwd_chain_capacity() / nj;
+      const int cap_blocks = bwd_chain_capacity() / (ctx->side_used ? 2 : 1) / nj;
       DB.bwd_chain_level = DB.nlevels;
       while (DB.bwd_chain_level > 0 && DB.h_level_ptr[DB.nlevels] - DB.h_level_ptr[DB.bwd_chain_level - 1] <= cap_blocks) DB.bwd_chain_level--;
     }
@@ -507,9 +603,9 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     for (int i = 0; i < nj; i++) {
       std::fill(fixed.begin(), fixed.end(), 0);
       fixed[jobs[i].gauge] = 1;
-      rc = prepare_pass_on(ctx, reps[i], st, fixed.data(), nE, s_ef.data(), s_et.data(), nA, i, nj, /*upload=*/false);
+      rc = prepare_pass_on(ctx, reps[i], st, fixed.data(), nE, s_ef.data(), s_et.data(), nA, i, nj, /*upload=*/false, hstage);
       if (rc) return rc;
-      char* h = ctx->pinned_mask;
+      char* h = hstage;
       memcpy(h + s_work + (size_t)24 * nV * i, works[i].data(), (size_t)24 * nV);
       const int nq = (int)jobs[i].q.size();
       int32_t* qc = (int32_t*)(h + s_qc) + (size_t)maxq * i;
@@ -520,7 +616,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     }
     t_mask = wall_s() - tm0;
     const double tu0 = wall_s();
-    char* h = ctx->pinned_mask;
+    char* h = hstage;
     char* d0 = ctx->mg_arena.ptr;
     char* ds = d0 + o_stage;                                     // device copy of the staging block
     double* d_work0 = (double*)(ds + s_work);                    // the passes work on the poses where they landed
@@ -557,8 +653,29 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     if (to_wire)
       launch_wire_write_edges(st, maxq, 0, (const int32_t*)(d0 + o_qv), (const int32_t*)g->d_vids.ptr, est0, info0, send_edges, nj, &MBt);
     if (trace) (void)hipEventRecord(evs[3], st);
-    HIP_TRY(ctx, hipMemcpy2DAsync(h + s_st, 4, DB.status, (size_t)DB.job_stride, 4, (size_t)nj, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpy2DAsync(h + s_st, 16, DB.status, (size_t)DB.job_stride, 16, (size_t)nj, hipMemcpyDeviceToHost, st));
     t_marg = wall_s() - tp1;
+    if (go_async) {
+      // not waited for: the status words are looked at by cond_finish(); a message packed before that gets its counts
+      // corrected on the device (cgmr_graph_pack)
+      HIP_TRY(ctx, hipEventRecord(g->ev_cond_done, st));
+      rc = side_mark(ctx);
+      if (rc) return rc;
+      g->cond_pending = true;
+      g->cond_peers.clear();
+      for (CondJob& J : jobs) g->cond_peers.push_back(J.peer);
+      g->cond_status = (const int32_t*)(h + s_st);
+      g->cond_jobs_dev = (const CondJobDev*)(ds + s_jd);
+      g->cond_status_dev = DB.status;
+      g->cond_status_stride = DB.job_stride;
+      if (trace) {
+        for (auto& e : evs) if (e) (void)hipEventDestroy(e);
+        fprintf(stderr, "[cond] %d jobs queued on the side stream, nV %d nE %d: structure %.0f us, queueing %.0f us (initial guesses %.0f, masks %.0f, uploads %.0f, GN pass %.0f, marginals + labels %.0f)\n",
+                nj, nV, nE, 1e6 * (tt1 - tt0), 1e6 * (wall_s() - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * t_up, 1e6 * t_gn, 1e6 * t_marg);
+      }
+      *async_out = true;
+      return 0;
+    }
     if (info_out) info_out->assign(nj, {});
     for (int i = 0; i < nj && info_out && !to_wire; i++) {
       (*info_out)[i].resize(6 * jobs[i].q.size());
@@ -567,7 +684,8 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     const double tt2 = wall_s();
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
-    memcpy(status.data(), h + s_st, 4 * (size_t)nj);
+    bool timed_out = false;
+    for (int i = 0; i < nj; i++) { status[i] = ((const int32_t*)(h + s_st))[4 * i]; timed_out = timed_out || ((const int32_t*)(h + s_st))[4 * i + 2] != 0; }
     if (trace) {
       float a = 0, b = 0, c = 0;
       (void)hipEventElapsedTime(&a, evs[0], evs[1]); (void)hipEventElapsedTime(&b, evs[1], evs[2]); (void)hipEventElapsedTime(&c, evs[2], evs[3]);
@@ -577,6 +695,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     if (trace)
       fprintf(stderr, "[cond] %d jobs in one batch, nV %d nE %d: structure %.0f us, queueing %.0f us (initial guesses %.0f, masks %.0f, uploads %.0f, GN pass %.0f, marginals + labels %.0f), waiting %.0f us\n",
               nj, nV, nE, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * t_up, 1e6 * t_gn, 1e6 * t_marg, 1e6 * (wall_s() - tt2));
+    if (timed_out) { ctx->gn_timeouts++; return gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
     for (int i = 0; i < nj; i++)
       if (status[i] != 0) return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
     return 0;
@@ -670,12 +789,19 @@ extern "C" {
 // uncertainty, every candidate's condensed graph being built for that) --, edges = getMyEdges (own edges only),
 // CondensedGraphCreator::compute per peer.  The passes of all peers (and of the gauge candidates) are queued on side
 // streams back to back; the labelled edges land in the send buffer as wire records.  Returns the number of peers built.
-int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
+}  // extern "C"
+
+namespace {
+int compute_condensed_impl(cgmr_graph* g, int peer, bool go_async) {
   if (!g || peer >= g->n_robots) return CGMR_E_INVALID;
   if (!g->ctx) return gerr(g, CGMR_E_NO_DEVICE, "cgmr_graph_compute_condensed: the graph was created without a device context");
   cgmr_ctx* ctx = g->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  {
+    int rc = cond_finish(g);                      // the previous batch, if it was not waited for (its failure surfaces here)
+    if (rc) return rc;
+  }
   const double t0 = wall_s();
   const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), cap = g->cap;
   struct Want { int peer; std::vector<int32_t> idx; };
@@ -694,9 +820,12 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
     wants.push_back(std::move(W));
   }
   if (wants.empty() || nA == 0) return 0;
-  // current estimates -> host (gauge selection, spanning-tree initial guess)
-  HIP_TRY(ctx, hipMemcpyAsync(g->h_poses.data(), g->d_poses.ptr, 24 * (size_t)nV, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  // current estimates -> host (gauge selection, spanning-tree initial guess); the last optimize() brought them along when
+  // it knew that condensed graphs would follow
+  if (!g->h_poses_fresh) {
+    HIP_TRY(ctx, hipMemcpyAsync(g->h_poses.data(), g->d_poses.ptr, 24 * (size_t)nV, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
   std::vector<CondJob> jobs;
   for (Want& W : wants) {
     CondJob J;
@@ -726,7 +855,8 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
     for (int v : W.idx) if (v != J.gauge) J.q.push_back(v);
     jobs.push_back(std::move(J));
   }
-  int rc = run_cond_jobs(g, jobs, /*to_wire=*/true, nullptr);
+  bool queued = go_async;
+  int rc = run_cond_jobs(g, jobs, /*to_wire=*/true, nullptr, &queued);
   if (rc) { for (CondJob& J : jobs) { g->out[J.peer].n = 0; g->out[J.peer].host_valid = false; } return rc; }
   for (CondJob& J : jobs) {
     PeerOut& O = g->out[J.peer];
@@ -737,6 +867,41 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) {
   }
   g->last_condense_seconds = wall_s() - t0;
   return (int)jobs.size();
+}
+}  // namespace
+
+extern "C" {
+
+int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) { return compute_condensed_impl(g, peer, false); }
+
+// The same, queued on the context's side stream and NOT waited for: the call returns once the passes are queued (the host
+// part -- gauges, spanning-tree guesses, masks -- is done), the device part runs beside whatever the caller does next on the
+// context's stream (the reference builds its condensed graphs on the communication thread, src/mrslam/graph_comm.cpp:195-207,
+// beside the main loop).  The batch reads a snapshot: the estimates and own edges as they are now; vertices / edges added and
+// solves run afterwards do not touch it.  cgmr_graph_pack / cgmr_allgather_condensed / cgmr_graph_deliver order themselves
+// behind it on the device; every entry point that hands results to the HOST (cgmr_graph_get_condensed, _pack_host,
+// _message_for, the next _compute_condensed*) waits for it first.  A failed pass (Cholesky, time-out) is reported by
+// cgmr_graph_condensed_wait or by the next call that waits; the message packed meanwhile carries no edges for the batch's peers.
+// Returns the number of peers whose condensed graph is being built.
+int cgmr_graph_compute_condensed_async(cgmr_graph* g, int peer) {
+  if (g && g->ctx) g->ctx->side_used = true;
+  return compute_condensed_impl(g, peer, true);
+}
+
+// Wait for the batch queued by cgmr_graph_compute_condensed_async (nothing to wait for: CGMR_OK) and report how it ended.
+int cgmr_graph_condensed_wait(cgmr_graph* g) {
+  if (!g) return CGMR_E_INVALID;
+  if (!g->ctx) return CGMR_OK;
+  HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+  return cond_finish(g);
+}
+
+// Announce that this graph will use cgmr_graph_compute_condensed_async (call before the first solve: the chained backward
+// solves of the context's stream and of the side stream then share the resident workgroups from the start).
+int cgmr_graph_set_async(cgmr_graph* g, int on) {
+  if (!g) return CGMR_E_INVALID;
+  if (g->ctx && on) g->ctx->side_used = true;
+  return CGMR_OK;
 }
 
 // optimal = 1: computeCondensedGraph picks the gauge with selectOptimalGauge instead of selectGaugeCentroid (the
@@ -752,6 +917,11 @@ int cgmr_graph_set_optimal_gauge(cgmr_graph* g, int optimal) {
 int cgmr_graph_get_condensed(cgmr_graph* g, int peer, int cap, int32_t* from_id_out, int32_t* to_ids_out, double* est_out,
                              double* info_upper_out) {
   if (!g || peer < 0 || peer >= g->n_robots || cap < 0) return CGMR_E_INVALID;
+  if (g->ctx && g->cond_pending) {
+    HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+    int rc = cond_finish(g);
+    if (rc) return rc;
+  }
   PeerOut& O = g->out[peer];
   const int n = std::min(O.n, cap);
   if (from_id_out) *from_id_out = O.gauge_id;
@@ -778,6 +948,11 @@ int cgmr_graph_get_condensed(cgmr_graph* g, int peer, int cap, int32_t* from_id_
 int cgmr_graph_set_condensed(cgmr_graph* g, int peer, int n, int32_t from_id, const int32_t* to_ids, const float* est,
                              const float* info_upper) {
   if (!g || peer < 0 || peer >= g->n_robots || n < 0 || n > g->cap || (n > 0 && (!to_ids || !est || !info_upper))) return CGMR_E_INVALID;
+  if (g->ctx && g->cond_pending) {
+    HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+    int rc = cond_finish(g);
+    if (rc) return rc;
+  }
   PeerOut& O = g->out[peer];
   O.n = n; O.gauge_id = from_id; O.host.resize(n); O.host_valid = true; O.to_idx.clear();
   for (int k = 0; k < n; k++) {
@@ -789,6 +964,8 @@ int cgmr_graph_set_condensed(cgmr_graph* g, int peer, int n, int32_t from_id, co
     cgmr_ctx* ctx = g->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     WireEdge* dst = reinterpret_cast<WireEdge*>(g->d_send + wire_edges_off(g->n_robots)) + (size_t)g->cap * peer;
+    int rcw = wait_consumers(g, ctx->stream);
+    if (rcw) return rcw;
     HIP_TRY(ctx, hipMemcpyAsync(dst, O.host.data(), sizeof(WireEdge) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
@@ -835,14 +1012,54 @@ int cgmr_graph_pack(cgmr_graph* g, void* d_send_out) {
   const int R = g->n_robots, cap = g->cap;
   count_skipped(g);
   const size_t wb = wire_bytes(R, cap);
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));            // the pinned staging may still be in flight from the last round
+  // the pinned staging may still be in flight from the last round (its own event: no wait for the stream's other work)
+  if (g->pack_in_flight) { HIP_TRY(ctx, hipEventSynchronize(g->ev_pack)); g->pack_in_flight = false; }
+  // A batch of condensed graphs that has not been waited for is still writing its edges into the send buffer: the message
+  // is completed on the side stream, behind it, with the counts the batch WILL produce -- and a kernel that takes them
+  // back for the batch's peers should one of its passes have failed (what the synchronous path decides on the host).
+  const bool behind_batch = g->cond_pending;
+  hipStream_t st = ctx->stream;
+  if (behind_batch) {
+    int rc = side_stream(ctx);
+    if (rc) return rc;
+    st = ctx->side;
+  }
+  {
+    int rc = wait_consumers(g, st);
+    if (rc) return rc;
+  }
   memset(g->pinned, 0, wb);
   fill_header(g, (unsigned char*)g->pinned);
-  HIP_TRY(ctx, hipMemcpyAsync(g->d_send, g->pinned, wire_edges_off(R), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(g->d_send, g->pinned, wire_edges_off(R), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(g->d_send + wire_clos_off(R, cap), g->pinned + wire_clos_off(R, cap), (size_t)R * cap * 4,
-                              hipMemcpyHostToDevice, ctx->stream));
+                              hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipEventRecord(g->ev_pack, st));
+  g->pack_in_flight = true;
+  if (behind_batch)
+    launch_wire_fix_counts(st, (int32_t*)g->d_send, R, (int)g->cond_peers.size(), g->cond_jobs_dev, g->cond_status_dev, g->cond_status_stride);
   if (d_send_out && d_send_out != (void*)g->d_send)
-    HIP_TRY(ctx, hipMemcpyAsync(d_send_out, g->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_send_out, g->d_send, wb, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(ctx, hipEventRecord(g->ev_packed, st));
+  if (behind_batch) {
+    int rc = side_mark(ctx);
+    if (rc) return rc;
+  }
+  return CGMR_OK;
+}
+
+// In-process transport for robots that share a device (loopback runs, several robots of one node in one process): src's
+// packed message (cgmr_graph_pack(src, NULL) before this) goes into slot src->robot of dst's receive buffer, a device copy
+// on dst's stream behind src's pack -- what the all-gather does between ranks.  Nothing waits on the host; dst's next
+// cgmr_graph_ingest(dst, NULL) is ordered behind the copy, src's next write into its send buffer behind it as well.
+int cgmr_graph_deliver(cgmr_graph* src, cgmr_graph* dst) {
+  if (!src || !dst || !src->ctx || !dst->ctx || src->n_robots != dst->n_robots || src->cap != dst->cap) return CGMR_E_INVALID;
+  cgmr_ctx* ctx = dst->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t wb = wire_bytes(src->n_robots, src->cap);
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, src->ev_packed, 0));
+  HIP_TRY(ctx, hipMemcpyAsync(dst->d_recv + (size_t)src->robot * wb, src->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(src->ev_consumed[dst->robot], ctx->stream));
+  src->consumed_pending[dst->robot] = 1;
   return CGMR_OK;
 }
 
@@ -858,7 +1075,10 @@ int cgmr_graph_pack_host(cgmr_graph* g, void* send_out) {
   const int R = g->n_robots, cap = g->cap;
   const size_t wb = wire_bytes(R, cap);
   if (g->ctx) {
-    int rc = cgmr_graph_pack(g, nullptr);
+    HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+    int rc = cond_finish(g);
+    if (rc && rc != CGMR_E_CHOLESKY_BASE && rc != CGMR_E_TIMEOUT) return rc;     // (a failed batch: its peers get no edges, the message still goes out)
+    rc = cgmr_graph_pack(g, nullptr);
     if (rc) return rc;
     cgmr_ctx* ctx = g->ctx;
     HIP_TRY(ctx, hipMemcpyAsync(send_out, g->d_send, wb, hipMemcpyDeviceToHost, ctx->stream));
@@ -967,6 +1187,11 @@ int cgmr_graph_message_for(cgmr_graph* g, int peer, int cap_edges, void* edges44
   if (!g || peer < 0 || peer >= g->n_robots || cap_edges < 0 || cap_closures < 0 || !n_edges_out || !n_closures_out)
     return CGMR_E_INVALID;
   const int R = g->n_robots, cap = g->cap;
+  if (g->ctx && g->cond_pending) {
+    HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+    int rc = cond_finish(g);
+    if (rc) return rc;
+  }
   // one peer's part of the round message: the counts and the closure requests are host bookkeeping (what fill_header()
   // writes), the edges are this peer's slice of the send buffer -- on the device when there is one: only that slice comes
   // back (round 2 packed and downloaded the whole buffer, 400 KB for four robots, for every peer and tick)

@@ -46,5 +46,9 @@ struct CondPrepare {
   long long pan_doubles = 0, y_doubles = 0, rep_stride = 0, marg_stride = 0;
 };
 void launch_cond_prepare(hipStream_t st, const CondPrepare& P);
+// A message packed behind a batch that was not waited for: if a pass of the batch failed (status word 0 of any job), the
+// edge counts of the batch's peers (jobs[j].out_slot) in the header go back to zero -- nothing of a failed batch is sent.
+void launch_wire_fix_counts(hipStream_t st, int32_t* header, int n_robots, int njobs, const CondJobDev* jobs, const int* status0,
+                            long long status_stride_bytes);
 
 }  // namespace cgmr

@@ -128,6 +128,24 @@ void launch_cond_prepare(hipStream_t st, const CondPrepare& P) {
   hipLaunchKernelGGL(k_cond_prepare, dim3(nb, 1, P.njobs), dim3(256), 0, st, P);
 }
 
+__global__ void k_wire_fix_counts(int32_t* header, int n_robots, int njobs, const CondJobDev* __restrict__ jobs, const int* status0,
+                                  long long stride) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bool failed = false;
+  for (int j = 0; j < njobs; j++) failed = failed || *(const int*)((const char*)status0 + (long long)j * stride) != 0;
+  if (!failed) return;
+  for (int j = 0; j < njobs; j++) {
+    const int p = jobs[j].out_slot;
+    if (p >= 0 && p < n_robots) header[2 + p] = 0;
+  }
+}
+
+void launch_wire_fix_counts(hipStream_t st, int32_t* header, int n_robots, int njobs, const CondJobDev* jobs, const int* status0,
+                            long long status_stride_bytes) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(k_wire_fix_counts, dim3(1), dim3(64), 0, st, header, n_robots, njobs, jobs, status0, status_stride_bytes);
+}
+
 void launch_wire_write_edges(hipStream_t st, int n, int from_id, const int32_t* to_vertex, const int32_t* vertex_ids,
                              const double* est, const double* info, WireEdge* out, int njobs, const MargBatch* batch) {
   if (n <= 0) return;

@@ -130,6 +130,8 @@ int cgmr_allgather_condensed(cgmr_ctx* ctx, cgmr_comm* comm, const void* d_send,
   if (hipSetDevice(ctx->device) != hipSuccess) return set_err(ctx, CGMR_E_NO_DEVICE, "hipSetDevice failed");
   if (hipEventRecord(comm->ready, ctx->stream) != hipSuccess || hipStreamWaitEvent(comm->stream, comm->ready, 0) != hipSuccess)
     return set_err(ctx, CGMR_E_HIP, "event ordering failed");
+  // ... and behind the context's side stream: a batch of condensed graphs that was not waited for, the message packed behind it
+  if (side_join_stream(ctx, comm->stream) != 0) return CGMR_E_HIP;
   (void)hipEventRecord(comm->t0, comm->stream);
   int rc = R.all_gather(d_send, d_recv, bytes_per_rank, /*ncclUint8*/ 1, comm->comm, comm->stream);
   if (rc != 0) return set_err(ctx, CGMR_E_HIP, "ncclAllGather: %s", R.get_error_string ? R.get_error_string(rc) : "error");
@@ -143,6 +145,11 @@ int cgmr_comm_wait(cgmr_ctx* ctx, cgmr_comm* comm) {
   if (!ctx || !comm || comm->ctx != ctx) return CGMR_E_INVALID;
   if (hipStreamWaitEvent(ctx->stream, comm->done, 0) != hipSuccess) return set_err(ctx, CGMR_E_HIP, "hipStreamWaitEvent failed");
   return CGMR_OK;
+}
+
+int cgmr_ctx_join_side(cgmr_ctx* ctx) {
+  if (!ctx) return CGMR_E_INVALID;
+  return side_join_stream(ctx, ctx->stream);
 }
 
 // Device time of the last all-gather (HIP events on the side stream); blocks until it has finished.

@@ -151,16 +151,35 @@ class RobotRounds:
 
 
 class LoopbackExchange:
-    """All robots in one process (tests, single-GPU dry runs): the 'all-gather' is a concatenation of host buffers."""
+    """All robots in one process (tests, single-GPU dry runs).  ``device=False``: the 'all-gather' is a concatenation of host
+    buffers (any object with ``pack_host`` / ``ingest_host``).  ``device=True`` (robots that share a GPU, a context each): every
+    robot's packed message is copied into the others' receive buffers on the device (``RobotGraph.deliver``), nothing waits on
+    the host -- what the all-gather on the communicator's stream does between ranks."""
 
-    def __init__(self, graphs):
+    def __init__(self, graphs, device: bool = False):
         self.graphs = graphs
         self.wire = None
+        self.device = device
+        self.pending = False
 
     def start_all(self):
+        if self.device:
+            for g in self.graphs:
+                g.pack(0)
+            for src in self.graphs:
+                for dst in self.graphs:
+                    if dst is not src:
+                        src.deliver(dst)
+            self.pending = True
+            return
         self.wire = np.concatenate([g.pack_host() for g in self.graphs])
 
     def finish_all(self):
+        if self.device:
+            if not self.pending:
+                return None
+            self.pending = False
+            return [g.ingest(0) for g in self.graphs]
         if self.wire is None:
             return None
         out = [g.ingest_host(self.wire) for g in self.graphs]
@@ -168,10 +187,10 @@ class LoopbackExchange:
         return out
 
 
-def run_rounds_loopback(rounds, n_rounds):
+def run_rounds_loopback(rounds, n_rounds, device: bool = False):
     """Drive several ``RobotRounds`` (one per robot, same process) through ``n_rounds`` rounds with a loopback exchange,
     in the order a real run has: everybody grows and solves, then ingests the previous round, condenses, exchanges."""
-    ex = LoopbackExchange([r.g for r in rounds])
+    ex = LoopbackExchange([r.g for r in rounds], device=device)
     log = []
     for _ in range(n_rounds):
         for r in rounds:

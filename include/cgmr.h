@@ -370,7 +370,7 @@ int cgmr_match_verify(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n2, con
  *
  * Round protocol (C5: every 50 new vertices):
  *   cgmr_graph_optimize(g, 5)                      local solve on own + received level-0 edges
- *   cgmr_graph_compute_condensed(g, -1)            one star of condensed edges per peer that asked (own edges only)
+ *   cgmr_graph_compute_condensed[_async](g, -1)    one star of condensed edges per peer that asked (own edges only)
  *   cgmr_graph_pack(g, send)                       my message: edges for every peer + my closure requests
  *   cgmr_allgather_condensed(ctx, comm, ...)       one RCCL all-gather on a side stream (overlaps the next solve)
  *   cgmr_comm_wait + cgmr_graph_ingest(g, recv)    requests -> out-closures; newest edge set per peer replaces the old
@@ -404,6 +404,19 @@ int cgmr_graph_insert_out_closure(cgmr_graph* g, int peer, int n, const int32_t*
 int cgmr_graph_closures(const cgmr_graph* g, int peer, int which, int cap, int32_t* ids_out);
 /* computeCondensedGraph for `peer`, or for every peer with out-closures when peer < 0; returns the number built */
 int cgmr_graph_compute_condensed(cgmr_graph* g, int peer);
+/* The same, queued on the context's SIDE stream and not waited for: returns once the passes are queued; they run beside
+ * whatever the caller does next on the context's stream -- the next round's grow, structure analysis and solve (the
+ * reference builds its condensed graphs on the communication thread, src/mrslam/graph_comm.cpp:195-207, beside the main
+ * loop).  The batch works on a snapshot (the estimates and own edges as they are at the call); cgmr_graph_pack,
+ * cgmr_allgather_condensed and cgmr_graph_deliver order themselves behind it on the device; an entry point that hands
+ * results to the HOST (cgmr_graph_get_condensed, _pack_host, _message_for, the next _compute_condensed*) waits for it.
+ * A failed pass (Cholesky, time-out) is reported by cgmr_graph_condensed_wait or by the next call that waits; the message
+ * packed meanwhile then carries no edges for the batch's peers (the counts are taken back on the device).
+ * cgmr_graph_set_async(g, 1) before the first solve announces the use (the chained backward solves of the two streams then
+ * share the workgroups that are certainly resident together from the start).  Same results as the synchronous call. */
+int cgmr_graph_compute_condensed_async(cgmr_graph* g, int peer);
+int cgmr_graph_condensed_wait(cgmr_graph* g);
+int cgmr_graph_set_async(cgmr_graph* g, int on);
 /* optimal = 1: pick the gauge with selectOptimalGauge (condensed_graph_buffer.cpp:252-288: every requested vertex in turn,
  * smallest sum of det(information^-1) over the star wins) instead of selectGaugeCentroid; the reference's default is 0 */
 int cgmr_graph_set_optimal_gauge(cgmr_graph* g, int optimal);
@@ -423,6 +436,11 @@ void* cgmr_graph_send_buffer(cgmr_graph* g);
 void* cgmr_graph_recv_buffer(cgmr_graph* g);
 /* d_send_out NULL = the graph's own send buffer; d_recv NULL = the graph's own receive buffer */
 int cgmr_graph_pack(cgmr_graph* g, void* d_send_out);
+/* In-process transport for robots that share a device (loopback runs; several robots of one node in one process): src's
+ * packed message (cgmr_graph_pack(src, NULL) first) is copied into slot src->robot of dst's own receive buffer on dst's
+ * stream, behind src's pack -- what the all-gather does between ranks.  No host wait; dst's next cgmr_graph_ingest(dst,
+ * NULL) and src's next write into its send buffer are ordered behind the copy. */
+int cgmr_graph_deliver(cgmr_graph* src, cgmr_graph* dst);
 int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out);
 /* the same through host memory (gloo; CPU tests on a graph without a device) */
 int cgmr_graph_pack_host(cgmr_graph* g, void* send_out);
@@ -445,12 +463,16 @@ int cgmr_graph_last_seconds(const cgmr_graph* g, double out[2]);
 /* Exchange (replaces GraphComm's pairwise UDP, src/mrslam/graph_comm.cpp:103-208, by one collective per round).
  * A communicator wraps an RCCL communicator over the ranks' GPUs (xGMI inside a node) and a side stream:
  *   rank 0: cgmr_comm_unique_id(id) -> distribute the 128 bytes out of band -> every rank: cgmr_comm_create.
- * cgmr_allgather_condensed queues ncclAllGather(d_send, d_recv, bytes_per_rank) on the side stream behind everything
- * already queued on the context's stream and returns; cgmr_comm_wait makes the context's stream wait for it. */
+ * cgmr_allgather_condensed queues ncclAllGather(d_send, d_recv, bytes_per_rank) on the communicator's stream behind
+ * everything already queued on the context's stream -- and on its side stream (a batch of condensed graphs queued with
+ * cgmr_graph_compute_condensed_async, the message packed behind it) -- and returns; cgmr_comm_wait makes the context's
+ * stream wait for it.  cgmr_ctx_join_side: everything queued on the context's stream from now on runs after what is on
+ * its side stream (for a caller that moves the send buffer with a transport of its own). */
 int cgmr_comm_unique_id(void* id_out_128);
 int cgmr_comm_create(cgmr_ctx* ctx, int n_ranks, int rank, const void* unique_id_128, cgmr_comm** out);
 void cgmr_comm_destroy(cgmr_comm* comm);
 int cgmr_allgather_condensed(cgmr_ctx* ctx, cgmr_comm* comm, const void* d_send, size_t bytes_per_rank, void* d_recv);
+int cgmr_ctx_join_side(cgmr_ctx* ctx);
 int cgmr_comm_wait(cgmr_ctx* ctx, cgmr_comm* comm);
 int cgmr_comm_last_seconds(cgmr_comm* comm, double* seconds);
 

@@ -233,7 +233,9 @@ def test_growing_graph_extends_the_analysis_and_matches_the_oracle_every_round(c
         nv_prev = nv
     s1 = ctx.symbolic_cache_stats()
     assert checked >= 17
-    assert s1["extended"] - s0["extended"] >= 80 and (s1["misses"] - s0["misses"]) + (s1["extended"] - s0["extended"]) == 100
+    # (round 4: an extension whose tree has grown more than two panels taller than the last from-scratch ordering's is
+    # refused -- the device pays per level --, so a few more rounds re-order than the vertex budget alone would make)
+    assert s1["extended"] - s0["extended"] >= 65 and (s1["misses"] - s0["misses"]) + (s1["extended"] - s0["extended"]) == 100
 
 
 def test_backward_solve_timeout_is_not_a_cholesky_failure(oracle):

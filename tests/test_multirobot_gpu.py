@@ -349,3 +349,58 @@ def test_select_optimal_gauge_matches_oracle_backend(ctx, oracle):
     graphs[0].set_optimal_gauge(False)
     graphs[0].computeCondensedGraph(0)
     assert graphs[0].condensed(0)[0] != gid_a or len(set(graphs[1].uncertainties.values())) == 1
+
+
+def test_async_condensed_graphs_on_the_side_stream_equal_the_synchronous_ones():
+    """cgmr_graph_compute_condensed_async: the round's condensed graphs queued on the context's side stream and not waited for,
+    the message packed and delivered behind them on the device (RobotGraph.deliver), the next round's grow / analysis / solve
+    running meanwhile.  Three robots with a context each, 10 rounds: every round's condensed graphs, every ingest and the
+    final poses equal those of the synchronous rounds with the host loopback (same kernels on the same snapshot; 1e-9: the
+    two runs may split the chained backward solve at another level)."""
+    from cg_mrslam_amd import Context
+    nr, n_rounds, chunk = 3, 10, 120
+    R = _meeting_world(nr, 1200, 4000, min_shared=6)
+
+    def run(async_on):
+        ctxs = [Context(0) for _ in range(nr)]
+        rounds = [RobotRounds(RobotGraph(ctxs[r], r, nr, cap_edges=128, async_condense=async_on), RobotWorld(R, r, chunk=chunk))
+                  for r in range(nr)]
+        from cg_mrslam_amd.mrslam import LoopbackExchange
+        ex = LoopbackExchange([r.g for r in rounds], device=async_on)
+        log = []
+        for t in range(n_rounds):
+            for r in rounds:
+                r.grow()
+                assert r.optimize() == 0
+            n_in = ex.finish_all()
+            built = [r.condense() for r in rounds]
+            ex.start_all()
+            # (reading the condensed graphs waits for the batch: done AFTER the exchange was queued, so the asynchronous run
+            # has packed and delivered behind a batch that was still in flight)
+            cond = [[r.g.condensed(p) for p in range(nr) if p != r.g.robot] for r in rounds]
+            log.append((n_in, built, cond, [r.last_chi2.copy() for r in rounds]))
+        ex.finish_all()
+        for r in rounds:
+            r.g.condensed_wait()
+        return log, [r.g.poses() for r in rounds], [r.g.counts() for r in rounds]
+
+    log_s, poses_s, counts_s = run(False)
+    log_a, poses_a, counts_a = run(True)
+    assert counts_s == counts_a
+    edges = 0
+    for (n_in_s, built_s, cond_s, chi_s), (n_in_a, built_a, cond_a, chi_a) in zip(log_s, log_a):
+        assert built_s == built_a
+        assert (n_in_s is None) == (n_in_a is None)
+        if n_in_s is not None:
+            assert [list(x) for x in n_in_s] == [list(x) for x in n_in_a]
+        for cs, ca in zip(cond_s, cond_a):
+            for (gid_s, to_s, est_s, iu_s), (gid_a, to_a, est_a, iu_a) in zip(cs, ca):
+                assert gid_s == gid_a and np.array_equal(to_s, to_a)
+                edges += len(to_s)
+                if len(to_s):
+                    assert np.abs(est_s - est_a).max() <= 1e-9 and np.abs(iu_s - iu_a).max() <= 1e-9 * np.abs(iu_s).max()
+        for a, b in zip(chi_s, chi_a):
+            np.testing.assert_allclose(a, b, rtol=1e-9)
+    assert edges > 30
+    for a, b in zip(poses_s, poses_a):
+        assert np.abs(a - b).max() <= 1e-9
