@@ -74,6 +74,23 @@ def pmc_traffic():
     return best
 
 
+def rocprof_c2_stats():
+    """Average durations of the GN kernels from the committed rocprofv3 --kernel-trace --stats run of the C2 solve ALONE
+    (tools/gn_profile_run.py; profiles/r04_gn_c2_kernel_stats.csv): the cross-check of the live HIP-event figure."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r04_gn_c2_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    out = {"source": os.path.relpath(path, ROOT)}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get("Name", "")
+            for key in ("k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_assemble", "k_linearize"):
+                if key in name and "leaf" not in name and key not in out:
+                    out[key] = {"calls": int(row["Calls"]), "avg_us": round(float(row["AverageNs"]) / 1e3, 2)}
+    return out
+
+
 def host_symbolic_ms_one_thread(V, E, seed):
     """The ordering + symbolic analysis of the benchmark graph on ONE host thread (CGMR_HOST_THREADS is read once per
     process, hence the subprocess; no GPU involved): best of 5, milliseconds."""
@@ -205,26 +222,57 @@ def loopback_leg(args, n_robots=8):
     part of `value`."""
     from cg_mrslam_amd import Context, synth
     from cg_mrslam_amd.condensed import RobotGraph
-    from cg_mrslam_amd.mrslam import LoopbackExchange, RobotRounds, RobotWorld
+    from cg_mrslam_amd.mrslam import RobotRounds, RobotWorld, TakeTurns
     ctxs = [Context(0) for _ in range(n_robots)]
     R = synth.make_multi_robot(n_robots, args.c5_vertices, args.c5_edges, seed=777)
-    rounds = [RobotRounds(RobotGraph(ctxs[r], r, n_robots, cap_edges=128), RobotWorld(R, r, chunk=args.c5_chunk)) for r in range(n_robots)]
-    ex = LoopbackExchange([r.g for r in rounds])
-    n_rounds = rounds[0].w.n_rounds if args.c5_rounds <= 0 else min(args.c5_rounds, rounds[0].w.n_rounds)
+    n_rounds = (args.c5_vertices + args.c5_chunk - 1) // args.c5_chunk if args.c5_rounds <= 0 else args.c5_rounds
+    # The one-rank reference of the weak-scaling figure: the SAME eight sub-graphs, each robot alone (its own vertices and
+    # edges, no peers) -- the robots' walks differ (robot 0's, the graph of the `exchange` leg at N = 1, is the easiest of the
+    # eight: 8 tree levels where the others have 10-14), and an efficiency compares a rank's round with peers with the same
+    # rank's round without.
+    solo_ms = []
+    for r in range(n_robots):
+        rr = RobotRounds(RobotGraph(ctxs[r], 0, 1, cap_edges=128), RobotWorld(R, r, chunk=args.c5_chunk, closures=False))
+        t0 = time.perf_counter()
+        for _ in range(min(n_rounds, rr.w.n_rounds)):
+            rr.grow(); rr.optimize()
+        solo_ms.append(1e3 * (time.perf_counter() - t0) / min(n_rounds, rr.w.n_rounds))
+        rr.g.close()
+    for c in ctxs:
+        c.set_symbolic_cache(False); c.set_symbolic_cache(True)             # (nothing of the solo rounds stays cached)
+    # as the ranks of an N-GPU run do it: the round's condensed graphs are queued on the context's side stream and not waited
+    # for (they run beside the next round's grow / analysis / solve), the message is packed behind them and delivered on the
+    # device -- no host buffer, no host wait, like the all-gather on the communicator's stream
+    rounds = [RobotRounds(RobotGraph(ctxs[r], r, n_robots, cap_edges=128, async_condense=True), RobotWorld(R, r, chunk=args.c5_chunk))
+              for r in range(n_robots)]
+    # ... and the robots take turns with whole rounds (cg_mrslam_amd/mrslam.py: TakeTurns), as the ranks' timelines run: a
+    # robot's batch has the rest of the round to finish beside its next grow / analysis / solve
+    n_rounds = min(n_rounds, rounds[0].w.n_rounds)
     T = {"grow": 0.0, "optimize5": 0.0, "ingest": 0.0, "condense": 0.0, "pack": 0.0}
     built, status = 0, 0
-    for _ in range(n_rounds):
+    for t in range(n_rounds):
         for r in rounds:
+            g = r.g
             t0 = time.perf_counter(); r.grow(); t1 = time.perf_counter(); status |= int(r.optimize() != 0); t2 = time.perf_counter()
-            T["grow"] += t1 - t0; T["optimize5"] += t2 - t1
-        t0 = time.perf_counter(); ex.finish_all(); t1 = time.perf_counter()
-        built += sum(r.condense() for r in rounds); t2 = time.perf_counter()
-        ex.start_all(); t3 = time.perf_counter()
-        T["ingest"] += t1 - t0; T["condense"] += t2 - t1; T["pack"] += t3 - t2
-    ex.finish_all()
+            if t > 0:
+                g.ingest_delivered()
+            t3 = time.perf_counter(); built += r.condense(); t4 = time.perf_counter()
+            g.pack(0)
+            for other in rounds:
+                if other is not r:
+                    g.deliver(other.g)
+            t5 = time.perf_counter()
+            T["grow"] += t1 - t0; T["optimize5"] += t2 - t1; T["ingest"] += t3 - t2; T["condense"] += t4 - t3; T["pack"] += t5 - t4
+    for r in rounds:
+        r.g.ingest_delivered()
+        r.g.condensed_wait()
     n = n_rounds * n_robots
     return {"workload": f"C5 loopback: {n_robots} robots x {args.c5_vertices} vertices / {args.c5_edges} edges on one GPU (a context each), "
-                        f"grown {args.c5_chunk} at a time, {n_rounds} rounds, wire buffers copied instead of gathered",
+                        f"grown {args.c5_chunk} at a time, {n_rounds} rounds, the robots taking turns with whole rounds, condensed graphs on "
+                        "the side streams, wire buffers copied on the device instead of gathered",
+            "solo_round_ms_same_robots": {"mean": round(float(np.mean(solo_ms)), 3), "max": round(float(np.max(solo_ms)), 3),
+                                          "per_robot": [round(float(v), 3) for v in solo_ms],
+                                          "note": "each of the eight sub-graphs grown and solved alone (no closures, no peers), same rounds"},
             "robots": n_robots, "rounds": n_rounds,
             "ms_per_robot_and_round": {k: round(1e3 * v / n, 3) for k, v in T.items()},
             "round_ms_per_robot": round(1e3 * sum(T.values()) / n, 3),
@@ -398,10 +446,12 @@ def exchange_leg(ctx, rank, world, args, dry=False, solo=False):
     if not have_pg:
         dist = _NoDist
     nrob = 1 if solo else world
-    robots = synth.make_multi_robot(nrob, args.c5_vertices, args.c5_edges, seed=777 + (1000 * rank if solo else 0))
-    w = RobotWorld(robots, 0 if solo else rank, chunk=args.c5_chunk)
+    # solo: this rank's robot of the SAME world, alone (own vertices and edges, no closures): the one-rank reference of the
+    # weak-scaling figure is the same sub-graph without the peers
+    robots = synth.make_multi_robot(world, args.c5_vertices, args.c5_edges, seed=777)
+    w = RobotWorld(robots, rank, chunk=args.c5_chunk, closures=not solo)
     n_rounds = w.n_rounds if args.c5_rounds <= 0 else min(args.c5_rounds, w.n_rounds)
-    g = RobotGraph(None if dry else ctx, 0 if solo else rank, nrob, cap_edges=128)
+    g = RobotGraph(None if dry else ctx, 0 if solo else rank, nrob, cap_edges=128, async_condense=(not dry and not solo))
     rr = RobotRounds(g, w, iterations=5)
     ex = Exchange(g) if have_pg else None
     if ex is None:
@@ -450,6 +500,8 @@ def exchange_leg(ctx, rank, world, args, dry=False, solo=False):
             t_coll.append(cs)
         t_round.append(t5 - t0); t_opt.append(t2 - t1); t_cond.append(t4 - t3)
     ex.finish()
+    if not dry:
+        g.condensed_wait()
     sync(); dist.barrier()
     t_all = time.perf_counter() - t_all0
     stat = torch.tensor([t_all, float(np.mean(t_round)), float(np.mean(t_opt)), float(np.mean(t_cond)), float(n_in_total),
@@ -527,7 +579,7 @@ def main():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from cg_mrslam_amd import Context, synth
-    from cg_mrslam_amd._lib import gn_symbolic_info
+    from cg_mrslam_amd._lib import gn_front_table, gn_symbolic_info
 
     ctx = Context(local)
     g = synth.make_pose_graph(args.vertices, args.edges, seed=12345 + 17 * rank, id_base=10000 * rank, strict=True)
@@ -632,6 +684,11 @@ def main():
         exchange["solo_round_ms_mean_max"] = round(float(t.item()), 3)
         exchange["weak_scaling_efficiency_vs_solo"] = round(float(t.item()) / exchange["round_ms_mean_max"], 4)
 
+    # every rank's helper pool as the library runs it (ranks of one node take different cache groups: LOCAL_RANK)
+    host_pools = None
+    if world > 1:
+        host_pools = [None] * world
+        dist.all_gather_object(host_pools, dict(ctx.host_threads_info(), rank=rank, loadavg_1min=round(os.getloadavg()[0], 1)))
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -655,11 +712,29 @@ def main():
     # write the factor panels (8 B per stored double; the column-major copy of L11 is only written for the marginals:
     # 48*48 doubles per front less)
     l_written = info["L_doubles"] - 48 * 48 * info["fronts"]
-    bytes_factor_iter = 8 * l_written + 8 * info["panel_doubles"]
+    layout_bytes_factor_iter = 8 * l_written + 8 * info["panel_doubles"]       # what THIS layout moves (rounds 1-3 priced on it)
+    # Round 4: a numerator that does not move when the data layout does.  What the factorisation of a front must touch
+    # whatever the layout: read its pivot block column of the frontal matrix -- the lower triangle of F11 (w columns), F21
+    # (r x w) and the w right-hand-side entries that ride along -- and write the same cells of the factor (L11, L21, y).
+    # w = 3 * (poses of the front), r = 3 * (border poses): no 48-column padding, no panel copies, no zero rows.
+    ft = gn_front_table(V, fixed, ef, et)
+    w_f, r_f = 3 * ft[:, 1].astype(np.int64), 3 * ft[:, 2].astype(np.int64)
+    in_top = np.zeros(len(ft), dtype=bool)
+    if info["top_block_fronts"] > 0:
+        in_top[-info["top_block_fronts"]:] = True                              # (the root chain's last fronts: k_top_block's, not this kernel's)
+    cells = (w_f * (w_f + 1) // 2 + r_f * w_f + w_f)[~in_top]
+    bytes_factor_iter = int(2 * 8 * cells.sum())
     launches_per_iter = ff_n / (nprof * GN_ITERS)
     avg_launch_s = ff_s / max(ff_n, 1)
     bytes_per_launch = bytes_factor_iter / max(launches_per_iter, 1)
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    # SURVEY.md 8(d)'s whole-iteration figure: B_iter = 96 V + 80 E + 144 (V + E) bytes of graph / Hessian / rhs traffic plus
+    # read + write of the stored factor, over the device time of one Gauss-Newton iteration
+    b_iter = 96 * V + 80 * E + 144 * (V + E)
+    l_cells = int((w_f * (w_f + 1) // 2 + r_f * w_f).sum())
+    dev_ms_iter = 1e3 * dev_time / args.steps / GN_ITERS
+    b_iter_gbs = (b_iter + 2 * 8 * l_cells) / (dev_ms_iter * 1e-3) / 1e9
+    rocprof = rocprof_c2_stats()
     pmc = pmc_traffic()
     per_level_us = {k: round(1e6 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if k in ("front_factor", "front_update", "solve_bwd")}
     roofline = {
@@ -671,6 +746,15 @@ def main():
         "tree_levels": info["levels"], "launched_levels": info["launch_levels"], "top_block_columns": info["top_block_cols"],
         "per_level_us": per_level_us,
         "algorithmic_bytes_per_launch": int(bytes_per_launch),
+        "algorithmic_bytes_definition": "per front: read + write of its pivot block column -- lower triangle of F11, F21, right-hand side -- at "
+                                        "its true width (no padding, no panel copies); layout-independent since round 4",
+        "layout_bytes_per_launch": int(layout_bytes_factor_iter / max(launches_per_iter, 1)),
+        "frac_on_layout_bytes": round(layout_bytes_factor_iter / max(launches_per_iter, 1) / avg_launch_s / 8e12, 6) if avg_launch_s > 0 else None,
+        "B_iter_frac": round(b_iter_gbs / 8000.0, 6),
+        "B_iter": {"bytes_graph_hessian_rhs": int(b_iter), "factor_cells": l_cells, "device_ms_per_gn_iteration": round(dev_ms_iter, 4),
+                   "achieved_GBps": round(b_iter_gbs, 2),
+                   "definition": "(96 V + 80 E + 144 (V + E) + 2 * 8 * stored factor cells) / device time of one GN iteration / 8 TB/s (SURVEY.md 8d)"},
+        "rocprofv3": rocprof,
         "share_of_kernel_time": round(ff_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
         "note": f"latency-bound: {info['launch_levels']} dependent tree levels (+ the top block), per level one contiguous panel load, three "
                 "elimination passes of FP64 pivot chains and the stores; traffic_stale = the PMC passes under profiles/ were taken on "
@@ -711,6 +795,7 @@ def main():
     matcher = (guarded("matcher", lambda: matcher_leg(ctx, dev, args, with_cpu=(world == 1 and not args.no_cpu_baseline)))
                if args.match_pairs > 0 else None)
 
+    loopback = guarded("exchange_loopback", lambda: loopback_leg(args)) if world == 1 and not args.no_team else None
     total_iters = GN_ITERS * args.steps * world
     out = {
         "metric": "GN iterations/sec on 10k-vertex SE2 graph (final chi2 reported)",
@@ -732,7 +817,13 @@ def main():
         "kernel_seconds_profiled": {k: round(v[0] / nprof, 6) for k, v in kt.items()},
         "roofline": roofline, "cpu_baseline": cpu, "matcher": matcher, "exchange": exchange,
         "team": (guarded("team", lambda: team_leg_repeated(ctx)) if world == 1 and not args.no_team else None),
-        "exchange_loopback": (guarded("exchange_loopback", lambda: loopback_leg(args)) if world == 1 and not args.no_team else None),
+        "exchange_loopback": loopback,
+        # what the one-GPU proxy says about the 8-GPU weak-scaling figure: one robot's round alone / a robot's round among eight
+        "predicted_weak_scaling_efficiency_8": (round(loopback["solo_round_ms_same_robots"]["mean"] / loopback["round_ms_per_robot"], 4)
+                                                if (loopback and "round_ms_per_robot" in loopback and world == 1) else None),
+        "predicted_weak_scaling_efficiency_8_vs_robot0_alone": (round(exchange["round_ms_mean_max"] / loopback["round_ms_per_robot"], 4)
+                                                               if (loopback and "round_ms_per_robot" in loopback and world == 1) else None),
+        "host_pool_of_every_rank": host_pools,
     }
     if cpu:
         out["speedup_vs_cpu_1thread"] = round(out["value"] / cpu["value"], 2)

@@ -242,6 +242,21 @@ def gn_symbolic_info_grown(nV0, nE0, nV_steps, nE_steps, ef, et):
     return dict(zip(_SYM_KEYS, out.tolist())), perm, int(next_.value)
 
 
+def gn_front_table(nV, fixed, ef, et):
+    """Host-only: the fronts of the elimination tree, one row each: (first block column, block columns, border block
+    rows, parent, level, children) -- cgmr_debug_fronts."""
+    lib = load_library()
+    fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+    ef = np.ascontiguousarray(ef, dtype=np.int32)
+    et = np.ascontiguousarray(et, dtype=np.int32)
+    cap = max(64, int(nV))
+    out = np.zeros(6 * cap, dtype=np.int32)
+    n = lib.cgmr_debug_fronts(C.c_int(nV), _ptr(fixed), C.c_int(len(ef)), _ptr(ef), _ptr(et), C.c_int(cap), _ptr(out))
+    if n < 0 or n > cap:
+        raise CgmrError(n, "cgmr_debug_fronts rejected the graph")
+    return out[:6 * n].reshape(n, 6)
+
+
 def gn_symbolic_info(nV, fixed, ef, et, want_perm=False):
     """Host-only ordering / symbolic analysis statistics (no GPU needed)."""
     lib = load_library()

@@ -181,6 +181,12 @@ class RobotGraph:
         self._check(self.lib.cgmr_graph_ingest(self.h, C.c_void_p(d_recv), _p(n)))
         return n
 
+    def ingest_delivered(self):
+        """The ingest that goes with ``deliver``: the k-th call digests the k-th message of every peer."""
+        n = np.zeros(self.n_robots, dtype=np.int32)
+        self._check(self.lib.cgmr_graph_ingest_delivered(self.h, _p(n)))
+        return n
+
     def pack_host(self) -> np.ndarray:
         buf = np.zeros(self.wire_bytes(), dtype=np.uint8)
         self._check(self.lib.cgmr_graph_pack_host(self.h, _p(buf)))

@@ -70,10 +70,15 @@ int side_join_stream(cgmr_ctx* ctx, hipStream_t st) {
   return 0;
 }
 
+// An arena that has to grow is not freed on the spot: hipFree waits for the whole device -- every stream of every context
+// of the process, e.g. the other robots' batches on their side streams -- and work queued on this context's streams may
+// still read the old block.  The old block goes to the context's graveyard (freed with the context); the arena at least
+// doubles, so the graveyard never holds more than the live blocks do (sized for 288 GB of HBM, not for thrift).
 int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes) {
   if (bytes <= A.cap) return 0;
-  if (A.ptr) { (void)hipStreamSynchronize(ctx->stream); (void)side_join_host(ctx); (void)hipFree(A.ptr); A.ptr = nullptr; A.cap = 0; }
-  size_t want = bytes + bytes / 4 + (1 << 20);
+  if (A.ptr) { ctx->graveyard.push_back(A.ptr); A.ptr = nullptr; }
+  size_t want = std::max(bytes + bytes / 2, 2 * A.cap) + (1 << 20);
+  A.cap = 0;
   hipError_t e = hipMalloc((void**)&A.ptr, want);
   if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
   A.cap = want;
@@ -606,6 +611,7 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
     for (int it = 0; it <= iters; it++) gn_pass(ctx, d_poses, Ed, it, it == iters, true, false);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+  const double t3 = wall_s();
   // read back chi2 + status
   std::vector<double> chi(iters + 1);
   int status4[4] = {0, 0, 0, 0};
@@ -618,6 +624,14 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
   if (poses_host && nV > 0) HIP_TRY(ctx, hipMemcpyAsync(poses_host, d_poses, 24 * (size_t)nV, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
+  {
+    // CGMR_GN_TRACE: where a solve's wall time goes beside the analysis -- queueing the launches, waiting for the stream
+    static const bool gn_trace = getenv("CGMR_GN_TRACE") != nullptr;
+    if (gn_trace) {
+      const double t4 = wall_s();
+      ctx->trace_n++; ctx->trace_sum[0] += t1 - t0; ctx->trace_sum[1] += t2 - t1; ctx->trace_sum[2] += t3 - t2; ctx->trace_sum[3] += t4 - t3;
+    }
+  }
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
   if (graph) (void)hipGraphDestroy(graph);
   if (status4[2] != 0 && status4[0] > 0) {
@@ -819,6 +833,10 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   // teardown: nothing useful can be done with a failing free, the statuses are dropped on purpose
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->trace_n > 0)
+    fprintf(stderr, "[gn] %lld solves: analysis + upload %.3f ms, masks %.3f ms, queueing the launches %.3f ms, waiting %.3f ms per solve\n", (long long)ctx->trace_n,
+            1e3 * ctx->trace_sum[0] / ctx->trace_n, 1e3 * ctx->trace_sum[1] / ctx->trace_n, 1e3 * ctx->trace_sum[2] / ctx->trace_n, 1e3 * ctx->trace_sum[3] / ctx->trace_n);
+  for (void* q : ctx->graveyard) (void)hipFree(q);
   if (ctx->gn_arena.ptr) (void)hipFree(ctx->gn_arena.ptr);
   if (ctx->io_arena.ptr) (void)hipFree(ctx->io_arena.ptr);
   if (ctx->mt_arena.ptr) (void)hipFree(ctx->mt_arena.ptr);

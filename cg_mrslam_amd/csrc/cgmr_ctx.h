@@ -23,6 +23,7 @@ struct cgmr_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
+  std::vector<void*> graveyard;   // device blocks an arena / growable array has outgrown: freed with the context (see arena_reserve)
   cgmr::Arena gn_arena;     // structure + numeric work space of the last analysed graph
   cgmr::Arena io_arena;     // staging for the host-pointer entry points
   cgmr::Arena mt_arena;     // matcher work space
@@ -60,6 +61,8 @@ struct cgmr_ctx {
   cgmr::GnDevice gn;
   double* poses_out_host = nullptr;   // set by a caller of gn_run: host buffer the final estimates are copied to (one-shot)
   double timing[5] = {0, 0, 0, 0, 0};
+  long long trace_n = 0;         // CGMR_GN_TRACE: solves and the sums of their phases (printed when the context goes)
+  double trace_sum[4] = {0, 0, 0, 0};
   double match_seconds = 0;
   int64_t match_pairs = 0, match_slow_pairs = 0;   // last batched close-matching launch: pairs, pairs off the LDS fast path
   bool profiling = false;

@@ -84,6 +84,10 @@ struct cgmr_graph {
   double *d_meas_b = nullptr, *d_info_b = nullptr, *d_est64 = nullptr, *d_info64 = nullptr, *d_qposes = nullptr;
   int32_t *d_ids_out = nullptr, *d_slot = nullptr, *d_qidx = nullptr, *d_status_all = nullptr;
   unsigned char *d_send = nullptr, *d_recv = nullptr;
+  unsigned char* d_recv2 = nullptr;   // second receive buffer of the in-process transport (cgmr_graph_deliver): round t's messages land
+                                      // in buffer t & 1 while round t - 1's may not have been ingested yet
+  std::vector<int64_t> n_delivered;   // per destination robot: messages delivered to it so far
+  int64_t n_ingested_delivered = 0;
   char* pinned = nullptr;             // header + closures staging, ids read-back, slot lists, one message's numbers
   size_t pinned_bytes = 0, pinned_msg_off = 0;
   hipEvent_t ev_msg = nullptr;        // the uploads of the last cgmr_graph_message_from have left the pinned block
@@ -92,6 +96,8 @@ struct cgmr_graph {
   double last_condense_seconds = 0, last_optimize_seconds = 0;
   bool optimal_gauge = false;         // computeCondensedGraph(robot, optimal)
   bool h_poses_fresh = false;         // h_poses holds the estimates as the last optimize() left them
+  double* pinned_poses = nullptr;     // landing zone of that read-back (page-locked: a copy into the pageable h_poses goes through the runtime's staging path)
+  size_t pinned_poses_cap = 0;        // in poses
   // a batch of condensed-graph passes queued on the context's side stream and not waited for yet
   // (cgmr_graph_compute_condensed_async): what is needed to finish it
   bool cond_pending = false;
@@ -119,16 +125,16 @@ int gerr(cgmr_graph* g, int code, const char* msg) {
 int dev_grow(cgmr_graph* g, DevBuf& B, size_t used_bytes, size_t need_bytes) {
   if (need_bytes <= B.cap) return 0;
   cgmr_ctx* ctx = g->ctx;
-  size_t want = std::max(need_bytes + need_bytes / 2, (size_t)1 << 16);
+  size_t want = std::max(std::max(need_bytes + need_bytes / 2, 2 * B.cap), (size_t)1 << 16);
   char* p = nullptr;
   hipError_t e = hipMalloc((void**)&p, want);
   if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
   if (B.ptr) {
+    // the contents move on the context's stream (whatever is appended next follows on the same stream); the old block is
+    // not freed here -- a batch on the side stream may still read it, and hipFree waits for the whole device -- but with
+    // the context (cgmr_ctx.h: graveyard)
     if (used_bytes) HIP_TRY(ctx, hipMemcpyAsync(p, B.ptr, used_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    int rc = side_join_host(ctx);                  // (a batch on the side stream reads the measurements / vertex ids)
-    if (rc) { (void)hipFree(p); return rc; }
-    (void)hipFree(B.ptr);
+    ctx->graveyard.push_back(B.ptr);
   }
   B.ptr = p;
   B.cap = want;
@@ -145,7 +151,7 @@ int alloc_fixed(cgmr_graph* g) {
   const size_t o_sm = add(24 * slots), o_si = add(48 * slots), o_tm = add(24 * slots), o_ti = add(48 * slots),
                o_mb = add(24 * slots), o_ib = add(48 * slots), o_e64 = add(24 * slots), o_i64 = add(48 * slots),
                o_qp = add(24 * slots), o_ids = add(4 * R * (2 + 3 * cap)), o_slot = add(4 * slots), o_qi = add(4 * slots),
-               o_st = add(4 * R * 4), o_send = add(wb), o_recv = add(R * wb);
+               o_st = add(4 * R * 4), o_send = add(wb), o_recv = add(R * wb), o_recv2 = add(R * wb);
   HIP_TRY(ctx, hipMalloc((void**)&g->d_fixed_block, off));
   HIP_TRY(ctx, hipMemsetAsync(g->d_fixed_block, 0, off, ctx->stream));
   char* d = g->d_fixed_block;
@@ -155,7 +161,8 @@ int alloc_fixed(cgmr_graph* g) {
   g->d_est64 = (double*)(d + o_e64); g->d_info64 = (double*)(d + o_i64); g->d_qposes = (double*)(d + o_qp);
   g->d_ids_out = (int32_t*)(d + o_ids); g->d_slot = (int32_t*)(d + o_slot); g->d_qidx = (int32_t*)(d + o_qi);
   g->d_status_all = (int32_t*)(d + o_st);
-  g->d_send = (unsigned char*)(d + o_send); g->d_recv = (unsigned char*)(d + o_recv);
+  g->d_send = (unsigned char*)(d + o_send); g->d_recv = (unsigned char*)(d + o_recv); g->d_recv2 = (unsigned char*)(d + o_recv2);
+  g->n_delivered.assign(R, 0);
   g->pinned_bytes = round256(wb) + round256(4 * R * (2 + 3 * cap)) + round256(4 * slots) + round256(24 * slots) + 4096;
   g->pinned_msg_off = g->pinned_bytes;
   g->pinned_bytes += round256(72 * cap);
@@ -300,6 +307,7 @@ void cgmr_graph_destroy(cgmr_graph* g) {
     if (g->d_fixed_block) (void)hipFree(g->d_fixed_block);
     if (g->pinned) (void)hipHostFree(g->pinned);
     if (g->cond_pinned) (void)hipHostFree(g->cond_pinned);
+    if (g->pinned_poses) (void)hipHostFree(g->pinned_poses);
     for (hipEvent_t e : {g->ev_msg, g->ev_cond_done, g->ev_pack, g->ev_packed}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->ev_consumed) if (e) (void)hipEventDestroy(e);
   }
@@ -397,11 +405,18 @@ int cgmr_graph_optimize(cgmr_graph* g, int iters, double* chi2_out) {
   // the host copy of the estimates comes back in the solve's own final wait: the condensed graphs that follow pick their
   // gauges from it, the caller's next key frame dead-reckons from it (cgmr_graph_get_poses: no device round trip then)
   const bool asked = true;
-  ctx->poses_out_host = g->h_poses.data();
+  if ((size_t)nV > g->pinned_poses_cap) {
+    if (g->pinned_poses) (void)hipHostFree(g->pinned_poses);
+    g->pinned_poses = nullptr;
+    g->pinned_poses_cap = (size_t)nV + (size_t)nV / 2 + 1024;
+    HIP_TRY(ctx, hipHostMalloc((void**)&g->pinned_poses, 24 * g->pinned_poses_cap, hipHostMallocDefault));
+  }
+  ctx->poses_out_host = g->pinned_poses;
   int rc = gn_run(ctx, nV, (double*)g->d_poses.ptr, g->fixed.data(), nE, g->all_ef.data(), g->all_et.data(), Ed, iters, chi2_out,
                   hubs.data(), (int)hubs.size());
   ctx->poses_out_host = nullptr;
   g->h_poses_fresh = asked && (rc == CGMR_OK || rc <= CGMR_E_CHOLESKY_BASE);
+  if (g->h_poses_fresh) memcpy(g->h_poses.data(), g->pinned_poses, 24 * (size_t)nV);
   g->last_optimize_seconds = wall_s() - t0;
   g->solved_ef = g->all_ef; g->solved_et = g->all_et;
   g->solved_nV = nV; g->solved_nA = (int)g->ef.size();
@@ -504,8 +519,6 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   size_t rep_stride = 0;
   rc = gn_replicas(ctx, nj, reps, &rep_stride);
   if (rc) return rc;
-  rc = dev_grow(g, g->d_work, 0, 24 * (size_t)nV * nj);
-  if (rc) return rc;
   // marginals work space per pass, sized for the largest query set
   int maxq = 1;
   for (CondJob& J : jobs) maxq = std::max(maxq, (int)J.q.size());
@@ -524,6 +537,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   const size_t stage_cap = (size_t)nf * nj + (size_t)24 * nV * nj + 2 * (size_t)4 * maxq * nj + sizeof(CondJobDev) * (size_t)nj + 5 * 256;
   rc = arena_reserve(ctx, ctx->mg_arena, o_stage + stage_cap + 256);
   if (rc) return rc;
+  const double tt1b = wall_s();                                  // (streams, replicas, work space: allocations when something grew)
   GnEdges Ed;
   Ed.meas_a = (const double*)g->d_meas_a.ptr; Ed.info_a = (const double*)g->d_info_a.ptr;
   Ed.meas_b = g->d_meas_b; Ed.info_b = g->d_info_b;
@@ -581,7 +595,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
           (void)hipHostFree(g->cond_pinned);
           g->cond_pinned = nullptr; g->cond_pinned_cap = 0;
         }
-        const size_t want = s_end + s_end / 2 + 4096;
+        const size_t want = 2 * s_end + (64 << 10);           // (page-locking is slow: rarely)
         HIP_TRY(ctx, hipHostMalloc((void**)&g->cond_pinned, want, hipHostMallocDefault));
         g->cond_pinned_cap = want;
       }
@@ -670,8 +684,8 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       g->cond_status_stride = DB.job_stride;
       if (trace) {
         for (auto& e : evs) if (e) (void)hipEventDestroy(e);
-        fprintf(stderr, "[cond] %d jobs queued on the side stream, nV %d nE %d: structure %.0f us, queueing %.0f us (initial guesses %.0f, masks %.0f, uploads %.0f, GN pass %.0f, marginals + labels %.0f)\n",
-                nj, nV, nE, 1e6 * (tt1 - tt0), 1e6 * (wall_s() - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * t_up, 1e6 * t_gn, 1e6 * t_marg);
+        fprintf(stderr, "[cond] %d jobs queued on the side stream, nV %d nE %d: structure %.0f us, queueing %.0f us (work space %.0f, initial guesses %.0f, masks %.0f, uploads %.0f, GN pass %.0f, marginals + labels %.0f)\n",
+                nj, nV, nE, 1e6 * (tt1 - tt0), 1e6 * (wall_s() - tt1), 1e6 * (tt1b - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * t_up, 1e6 * t_gn, 1e6 * t_marg);
       }
       *async_out = true;
       return 0;
@@ -700,6 +714,8 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       if (status[i] != 0) return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
     return 0;
   }
+  rc = dev_grow(g, g->d_work, 0, 24 * (size_t)nV * nj);       // (the passes on streams work on uploaded copies of the poses)
+  if (rc) return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->aux_fork, st));
   for (int k = 0; k < nstreams; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->aux_fork, 0));
   for (int i = 0; i < nj; i++) {
@@ -1048,16 +1064,20 @@ int cgmr_graph_pack(cgmr_graph* g, void* d_send_out) {
 }
 
 // In-process transport for robots that share a device (loopback runs, several robots of one node in one process): src's
-// packed message (cgmr_graph_pack(src, NULL) before this) goes into slot src->robot of dst's receive buffer, a device copy
-// on dst's stream behind src's pack -- what the all-gather does between ranks.  Nothing waits on the host; dst's next
-// cgmr_graph_ingest(dst, NULL) is ordered behind the copy, src's next write into its send buffer behind it as well.
+// packed message (cgmr_graph_pack(src, NULL) before this) goes into slot src->robot of one of dst's two receive buffers
+// (the k-th message for dst into buffer k & 1), a device copy on dst's stream behind src's pack -- what the all-gather does
+// between ranks.  Nothing waits on the host; dst's k-th cgmr_graph_ingest_delivered is ordered behind the copy, src's next
+// write into its send buffer behind it as well.  Every robot delivers to every other once per round.
 int cgmr_graph_deliver(cgmr_graph* src, cgmr_graph* dst) {
   if (!src || !dst || !src->ctx || !dst->ctx || src->n_robots != dst->n_robots || src->cap != dst->cap) return CGMR_E_INVALID;
   cgmr_ctx* ctx = dst->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t wb = wire_bytes(src->n_robots, src->cap);
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, src->ev_packed, 0));
-  HIP_TRY(ctx, hipMemcpyAsync(dst->d_recv + (size_t)src->robot * wb, src->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
+  // two receive buffers taking turns: a robot may deliver its round-t message before the destination has ingested round t - 1's
+  // (robots that take turns on one device run their rounds one after the other, not in lock step)
+  unsigned char* recv = (src->n_delivered[dst->robot]++ & 1) ? dst->d_recv2 : dst->d_recv;
+  HIP_TRY(ctx, hipMemcpyAsync(recv + (size_t)src->robot * wb, src->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(src->ev_consumed[dst->robot], ctx->stream));
   src->consumed_pending[dst->robot] = 1;
   return CGMR_OK;
@@ -1136,6 +1156,13 @@ int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
     launch_gather_edges(st, j, g->d_slot, g->d_stage_meas, g->d_stage_info, g->d_meas_b, g->d_info_b);
   }
   return CGMR_OK;
+}
+
+// The ingest that goes with cgmr_graph_deliver: the k-th call digests the k-th message of every peer (receive buffer k & 1).
+int cgmr_graph_ingest_delivered(cgmr_graph* g, int32_t* n_edges_out) {
+  if (!g || !g->ctx) return CGMR_E_INVALID;
+  const unsigned char* recv = (g->n_ingested_delivered++ & 1) ? g->d_recv2 : g->d_recv;
+  return cgmr_graph_ingest(g, recv, n_edges_out);
 }
 
 int cgmr_graph_ingest_host(cgmr_graph* g, const void* recv, int32_t* n_edges_out) {

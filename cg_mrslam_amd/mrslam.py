@@ -33,7 +33,9 @@ INTER_ROBOT_INFO = np.array([100.0, 0, 0, 100.0, 0, 1000.0])     # mr_graph_slam
 class RobotWorld:
     """Robot ``r``'s share of a ``synth.make_multi_robot`` world, served in increments of ``chunk`` vertices."""
 
-    def __init__(self, robots, r, chunk=50, base_id=10000):
+    def __init__(self, robots, r, chunk=50, base_id=10000, closures=True):
+        """``closures=False``: the robot alone in the same world -- its own vertices and edges, nobody to close loops with
+        (the one-rank reference of a weak-scaling figure: the same sub-graph without the peers)."""
         g = robots[r]
         self.r, self.chunk, self.base_id = r, chunk, base_id
         self.n_own = int(g["n_own"])
@@ -52,6 +54,11 @@ class RobotWorld:
         fid = g["ids"][g["et_all"][n_e:]].astype(np.int64)
         self.c_own, self.c_fid = ci, fid
         self.c_meas, self.c_info = g["meas_all"][n_e:], g["info_all"][n_e:]
+        if not closures:
+            keep = np.zeros(len(ci), dtype=bool)
+            ci, fid = ci[keep], fid[keep]
+            self.c_own, self.c_fid = ci, fid
+            self.c_meas, self.c_info = self.c_meas[keep], self.c_info[keep]
         self.c_round = np.maximum(ci, fid % base_id) // chunk
         self.c_order = np.argsort(self.c_round, kind="stable")
         self.c_ptr = np.searchsorted(self.c_round[self.c_order], np.arange(self.n_rounds + 1))
@@ -179,11 +186,40 @@ class LoopbackExchange:
             if not self.pending:
                 return None
             self.pending = False
-            return [g.ingest(0) for g in self.graphs]
+            return [g.ingest_delivered() for g in self.graphs]
         if self.wire is None:
             return None
         out = [g.ingest_host(self.wire) for g in self.graphs]
         self.wire = None
+        return out
+
+
+class TakeTurns:
+    """Robots that share a GPU run their rounds ONE AFTER THE OTHER -- robot r: grow, solve, ingest what the others delivered
+    in their previous round, condensed graphs, pack, deliver -- instead of in lock step: what the timeline of one rank of an
+    N-GPU run looks like (its batch of condensed graphs has the rest of the round to finish beside the next grow / analysis /
+    solve), on one device.  Same data flow as the lock-step order: the round-t message of robot r is ingested by robot q in
+    its round t + 1 (``RobotGraph.deliver`` keeps two receive buffers in turn).  Device transport only."""
+
+    def __init__(self, rounds):
+        self.rounds = rounds
+        self.t = 0
+
+    def robot_round(self, rr):
+        """One robot's whole round; returns (edges accepted per sender or None, condensed graphs built)."""
+        rr.grow()
+        rr.optimize()
+        n_in = rr.g.ingest_delivered() if self.t > 0 else None
+        built = rr.condense()
+        rr.g.pack(0)
+        for other in self.rounds:
+            if other is not rr:
+                rr.g.deliver(other.g)
+        return n_in, built
+
+    def round(self):
+        out = [self.robot_round(rr) for rr in self.rounds]
+        self.t += 1
         return out
 
 

@@ -438,9 +438,12 @@ void* cgmr_graph_recv_buffer(cgmr_graph* g);
 int cgmr_graph_pack(cgmr_graph* g, void* d_send_out);
 /* In-process transport for robots that share a device (loopback runs; several robots of one node in one process): src's
  * packed message (cgmr_graph_pack(src, NULL) first) is copied into slot src->robot of dst's own receive buffer on dst's
- * stream, behind src's pack -- what the all-gather does between ranks.  No host wait; dst's next cgmr_graph_ingest(dst,
- * NULL) and src's next write into its send buffer are ordered behind the copy. */
+ * stream, behind src's pack -- what the all-gather does between ranks.  No host wait; dst's matching
+ * cgmr_graph_ingest_delivered and src's next write into its send buffer are ordered behind the copy. */
 int cgmr_graph_deliver(cgmr_graph* src, cgmr_graph* dst);
+/* the ingest that goes with cgmr_graph_deliver: the k-th call digests the k-th message every peer has delivered (two
+ * receive buffers take turns, so a robot may deliver round t before the destination has ingested round t - 1) */
+int cgmr_graph_ingest_delivered(cgmr_graph* g, int32_t* n_edges_out);
 int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out);
 /* the same through host memory (gloo; CPU tests on a graph without a device) */
 int cgmr_graph_pack_host(cgmr_graph* g, void* send_out);

@@ -322,6 +322,32 @@ def test_bench_two_ranks_on_one_gpu():
     assert ex["condensed_graphs_built_total"] > 0 and ex["condensed_edges_received_total"] > 0 and ex["status_rank0"] == 0
 
 
+def test_bench_eight_ranks_on_one_gpu():
+    """``bench.py --gpus 8`` on ONE GPU (all ranks share cuda:0, collectives over gloo): everything of the 8-rank run except
+    xGMI -- eight Python ranks, eight helper pools placed by LOCAL_RANK on different cache groups (where the host has them),
+    R = 8 addressing through the real rank path (8 wire slices per buffer), the solo-vs-real accounting of the exchange
+    leg.  Reduced sizes; the full-size line is kept under profiles/ (tools/bench_8ranks_one_gpu.sh)."""
+    env = dict(os.environ, CGMR_BENCH_SINGLE_DEVICE="1", CGMR_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--vertices", "2000",
+           "--edges", "7000", "--match-pairs", "0", "--c5-vertices", "600", "--c5-edges", "2100", "--c5-chunk", "50", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["value"] > 0 and out["warm"]["bit_identical_to_cold"]
+    ex = out["exchange"]
+    assert ex["robots"] == 8 and ex["rounds"] == 12 and ex["transport"] == "host"
+    assert ex["bytes_gathered_per_rank_per_round"] == 8 * (4 * (2 + 16) + 8 * 128 * 44 + 8 * 128 * 4)
+    assert ex["condensed_graphs_built_total"] > 0 and ex["condensed_edges_received_total"] > 0 and ex["status_rank0"] == 0
+    assert ex["messages_skipped_over_capacity_total"] == 0 and 0 < ex["weak_scaling_efficiency_vs_solo"] < 2
+    pools = out["host_pool_of_every_rank"]
+    assert len(pools) == 8 and sorted(q["rank"] for q in pools) == list(range(8))
+    pinned = [q for q in pools if q["pinned"]]
+    if len(pinned) == 8 and pools[0]["cpus_allowed"] >= 128:       # a host with >= 8 cache groups: no two pools around the same core
+        assert len({q["home_cpu"] for q in pinned}) == 8, pools
+
+
 def test_select_optimal_gauge_matches_oracle_backend(ctx, oracle):
     """computeCondensedGraph(robot, optimal = true): selectOptimalGauge (condensed_graph_buffer.cpp:252-288) -- every
     requested vertex in turn as the gauge, the star with the smallest sum of det(information^-1) wins -- against the same
@@ -404,3 +430,51 @@ def test_async_condensed_graphs_on_the_side_stream_equal_the_synchronous_ones():
     assert edges > 30
     for a, b in zip(poses_s, poses_a):
         assert np.abs(a - b).max() <= 1e-9
+
+
+def test_robots_taking_turns_with_whole_rounds_equal_the_lock_step_rounds():
+    """``TakeTurns``: robot after robot does its whole round (grow, solve, ingest, condensed graphs, pack, deliver) instead of
+    everybody solving, then everybody ingesting, ... -- a rank's timeline on one device.  Two receive buffers in turn keep the
+    data flow that of the lock-step order (round t's message is ingested in round t + 1): same condensed graphs, same ingests,
+    same final poses."""
+    from cg_mrslam_amd import Context
+    from cg_mrslam_amd.mrslam import LoopbackExchange, TakeTurns
+    nr, n_rounds, chunk = 3, 8, 120
+    R = _meeting_world(nr, 1200, 4000, min_shared=6)
+
+    def make():
+        ctxs = [Context(0) for _ in range(nr)]
+        return [RobotRounds(RobotGraph(ctxs[r], r, nr, cap_edges=128, async_condense=True), RobotWorld(R, r, chunk=chunk)) for r in range(nr)]
+    a = make()
+    ex = LoopbackExchange([r.g for r in a], device=True)
+    log_a = []
+    for t in range(n_rounds):
+        for r in a:
+            r.grow(); assert r.optimize() == 0
+        n_in = ex.finish_all()
+        built = [r.condense() for r in a]
+        ex.start_all()
+        log_a.append((n_in, built))
+    b = make()
+    tt = TakeTurns(b)
+    log_b = [tt.round() for _ in range(n_rounds)]
+    got = 0
+    for t in range(n_rounds):
+        n_in_a, built_a = log_a[t]
+        for r in range(nr):
+            n_in_b, built_b = log_b[t][r]
+            assert built_b == built_a[r]
+            assert (n_in_b is None) == (n_in_a is None)
+            if n_in_b is not None:
+                assert list(n_in_b) == list(n_in_a[r])
+                got += int(np.sum(n_in_b))
+    assert got > 20
+    for ra, rb in zip(a, b):
+        ra.g.condensed_wait(); rb.g.condensed_wait()
+        for p in range(nr):
+            if p != ra.g.robot:
+                ga, gb = ra.g.condensed(p), rb.g.condensed(p)
+                assert ga[0] == gb[0] and np.array_equal(ga[1], gb[1])
+                if len(ga[1]):
+                    assert np.abs(ga[2] - gb[2]).max() <= 1e-9 and np.abs(ga[3] - gb[3]).max() <= 1e-9 * np.abs(ga[3]).max()
+        assert np.abs(ra.g.poses() - rb.g.poses()).max() <= 1e-9
