@@ -41,6 +41,12 @@ sys.path.insert(0, ROOT)
 # bench is a dedicated solve loop and opts into what such a loop wants -- stated here and in the JSON line (`host_pool.opt_in`);
 # set any of them in the environment to override.
 HOST_OPT_IN = {"CGMR_HOST_PIN_CALLER": "1", "CGMR_HOST_MOVE": "1", "CGMR_HOST_SPIN_US": "10000"}
+# several ranks on one node are placed on different cache groups by LOCAL_RANK: a pool that moves can only land on another
+# rank's group (seen in the first 8-rank run on one GPU: two pools around the same core after a move) -- no moves then
+_multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 or any(a == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1] not in ("0", "1")
+                                                          for i, a in enumerate(sys.argv)) or any(a.startswith("--gpus=") and a[7:] not in ("0", "1") for a in sys.argv)
+if _multi:
+    HOST_OPT_IN["CGMR_HOST_MOVE"] = "0"
 for _k, _v in HOST_OPT_IN.items():
     os.environ.setdefault(_k, _v)
 

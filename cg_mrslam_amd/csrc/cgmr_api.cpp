@@ -37,6 +37,10 @@ int set_err(cgmr_ctx* ctx, int code, const char* fmt, ...) {
 
 int side_stream(cgmr_ctx* ctx) {
   if (ctx->side) return 0;
+  // (default priority.  Round 4 tried the lowest priority here and the highest for the context's stream -- the batches as
+  // gap fillers of the solve's dependent chain of small launches --: with eight robots on one device a starved batch held
+  // up its own robot's next structure upload, optimize(5) 2.57 -> 4.49 ms in the loopback; without peers on the device no
+  // gain either way.)
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_tail, hipEventDisableTiming));

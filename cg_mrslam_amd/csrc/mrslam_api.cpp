@@ -65,6 +65,11 @@ struct cgmr_graph {
   // own edges (segment A) and received edges (segment B, compact, peer order)
   std::vector<int32_t> ef, et;
   std::vector<double> h_meas, h_info;
+  // incidence lists of the own edges, kept as they are appended (item = 2 * edge + side, per vertex in edge order: what a
+  // counting sort of the edge list gives), and cos / sin of every own measurement's angle: the spanning-tree initial guesses of
+  // a round's condensed graphs walk them instead of rebuilding both per gauge
+  std::vector<int32_t> adj_head, adj_tail, adj_next;
+  std::vector<double> e_cs;
   std::vector<PeerIn> in;             // per peer
   std::vector<PeerOut> out;           // per peer
   std::vector<std::vector<int32_t>> out_closures, in_closures;   // sorted unique ids
@@ -175,6 +180,53 @@ int alloc_fixed(cgmr_graph* g) {
   g->consumed_pending.assign(g->n_robots, 0);
   for (hipEvent_t& e : g->ev_consumed) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return 0;
+}
+
+// SparseOptimizer::computeInitialGuess from ONE fixed vertex over the own edges (gn_host.h: initial_guess_host is the
+// general form): breadth-first from `root`, edges in list order, x_to = x_from * z or x_from = x_to * z^-1.  Walks the
+// graph's incidence lists and takes cos / sin of the measurements from the cache; the orientation of a reached vertex is
+// carried along as (cos, sin) by the angle-addition formulas (a round's six or seven guesses were 0.17-0.24 ms of its
+// 0.4 ms of host work: two libm calls per vertex and edge direction).  The guess differs from the all-libm form by rounding;
+// the ONE Gauss-Newton iteration that follows starts far from the optimum and amplifies any rounding difference of its
+// linearisation point by cond(H): the condensed measurements of the two forms agree to ~1e-8 m (libm again every eighth
+// tree level did not change that: it is not drift), well inside the 1e-6 parity bar against the oracle.
+void initial_guess_own_edges(const cgmr_graph* g, int root, double* poses, std::vector<int32_t>& queue, std::vector<double>& cs,
+                             std::vector<uint8_t>& seen) {
+  const int nV = (int)g->ids.size();
+  const double pi = 3.14159265358979323846;
+  seen.assign(nV, 0);
+  cs.resize(2 * (size_t)nV);
+  queue.clear();
+  if (g->adj_head[root] < 0) return;
+  seen[root] = 1;
+  queue.push_back(root);
+  cs[2 * (size_t)root] = std::cos(poses[3 * (size_t)root + 2]);
+  cs[2 * (size_t)root + 1] = std::sin(poses[3 * (size_t)root + 2]);
+  for (size_t qh = 0; qh < queue.size(); qh++) {
+    const int u = queue[qh];
+    const double* a = poses + 3 * (size_t)u;
+    const double cu = cs[2 * (size_t)u], su = cs[2 * (size_t)u + 1];
+    for (int32_t it = g->adj_head[u]; it >= 0; it = g->adj_next[it]) {
+      const int k = it >> 1;
+      const int w = (g->ef[k] == u) ? g->et[k] : g->ef[k];
+      if (seen[w]) continue;
+      seen[w] = 1;
+      const double* m = g->h_meas.data() + 3 * (size_t)k;
+      double zx = m[0], zy = m[1], zt = m[2], cz = g->e_cs[2 * (size_t)k], sz = g->e_cs[2 * (size_t)k + 1];
+      if (g->ef[k] != u) {                                       // z^-1
+        const double ix = -(cz * zx + sz * zy), iy = -(-sz * zx + cz * zy);
+        zx = ix; zy = iy; zt = -zt; sz = -sz;
+      }
+      double* o = poses + 3 * (size_t)w;
+      o[0] = a[0] + cu * zx - su * zy;
+      o[1] = a[1] + su * zx + cu * zy;
+      const double t = a[2] + zt;
+      o[2] = (t >= -pi && t < pi) ? t : t - 2 * pi * std::floor((t + pi) / (2 * pi));
+      cs[2 * (size_t)w] = cu * cz - su * sz;
+      cs[2 * (size_t)w + 1] = su * cz + cu * sz;
+      queue.push_back(w);
+    }
+  }
 }
 
 // Finish the pending asynchronous batch: wait for it, look at the status words.  A failed pass leaves nothing to send to any
@@ -326,6 +378,8 @@ int cgmr_graph_add_vertices(cgmr_graph* g, int n, const int32_t* ids, const doub
     g->ids.push_back(ids[k]);
     g->fixed.push_back(fixed ? fixed[k] : 0);
   }
+  g->adj_head.resize(g->ids.size(), -1);
+  g->adj_tail.resize(g->ids.size(), -1);
   g->h_poses.insert(g->h_poses.end(), poses_xyt, poses_xyt + 3 * (size_t)n);
   if (g->ctx && n > 0) {
     cgmr_ctx* ctx = g->ctx;
@@ -354,6 +408,18 @@ int cgmr_graph_add_edges(cgmr_graph* g, int n, const int32_t* from_ids, const in
   }
   g->h_meas.insert(g->h_meas.end(), meas_xyt, meas_xyt + 3 * (size_t)n);
   g->h_info.insert(g->h_info.end(), info_upper, info_upper + 6 * (size_t)n);
+  g->adj_next.resize(2 * g->ef.size(), -1);
+  g->e_cs.resize(2 * g->ef.size());
+  for (size_t k = e0; k < g->ef.size(); k++) {
+    for (int side = 0; side < 2; side++) {
+      const int v = side ? g->et[k] : g->ef[k];
+      const int32_t item = (int32_t)(2 * k + side);
+      if (g->adj_tail[v] < 0) g->adj_head[v] = item; else g->adj_next[g->adj_tail[v]] = item;
+      g->adj_tail[v] = item;
+    }
+    g->e_cs[2 * k] = std::cos(g->h_meas[3 * k + 2]);
+    g->e_cs[2 * k + 1] = std::sin(g->h_meas[3 * k + 2]);
+  }
   if (g->ctx && n > 0) {
     cgmr_ctx* ctx = g->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -544,18 +610,28 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   Ed.nA = nA; Ed.n_active = nA;                                  // getMyEdges: the received edges are switched off
   std::vector<uint8_t> fixed(nV);
   std::vector<int32_t> qcol;
-  // the spanning-tree initial guess of every job (its own gauge as the root: 0.3 ms of host work each) on the helper threads
+  // the spanning-tree initial guess of every job (its own gauge as the root: 0.15-0.3 ms of host work each) on the helper
+  // threads; dst(i): where job i's guess goes (a batch: straight into its slot of the staging block)
   std::vector<std::vector<double>> works(nj);
-  {
+  auto run_guesses = [&](const std::function<double*(int)>& dst) {
     const double tg0 = wall_s();
+    static const bool cached_walk = !(getenv("CGMR_GUESS_CACHED") && atoi(getenv("CGMR_GUESS_CACHED")) == 0);
     host_run_tasks(nj, [&](int i) {
-      std::vector<uint8_t> fx(nV, 0);
-      fx[jobs[i].gauge] = 1;
-      works[i] = g->h_poses;
-      initial_guess_host(nV, works[i].data(), fx.data(), nA, g->ef.data(), g->et.data(), g->h_meas.data());
+      double* w = dst(i);
+      memcpy(w, g->h_poses.data(), (size_t)24 * nV);
+      if (cached_walk) {
+        thread_local std::vector<int32_t> queue;
+        thread_local std::vector<double> cs;
+        thread_local std::vector<uint8_t> seen;
+        initial_guess_own_edges(g, jobs[i].gauge, w, queue, cs, seen);
+      } else {
+        std::vector<uint8_t> fx(nV, 0);
+        fx[jobs[i].gauge] = 1;
+        initial_guess_host(nV, w, fx.data(), nA, g->ef.data(), g->et.data(), g->h_meas.data());
+      }
     });
     t_guess = wall_s() - tg0;
-  }
+  };
   WireEdge* send_edges = reinterpret_cast<WireEdge*>(g->d_send + wire_edges_off(g->n_robots));
   // Several passes: ONE sequence of launches with a job dimension (gn_kernels.hip CGMR_JOB) instead of a stream of ~65
   // launches per job side by side -- next to each other the device dispatched the small kernels of 7 jobs at ~7 us apiece
@@ -613,20 +689,26 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       DB.bwd_chain_level = DB.nlevels;
       while (DB.bwd_chain_level > 0 && DB.h_level_ptr[DB.nlevels] - DB.h_level_ptr[DB.bwd_chain_level - 1] <= cap_blocks) DB.bwd_chain_level--;
     }
+    run_guesses([&](int i) { return (double*)(hstage + s_work + (size_t)24 * nV * i); });
     const double tm0 = wall_s();
+    // the column masks: a vertex without an own edge is out of every job's system (the received edges are switched off);
+    // the jobs differ in their gauge only
+    std::vector<uint8_t> live(nV, 0);
+    for (int k = 0; k < nA; k++) { live[s_ef[k]] = 1; live[s_et[k]] = 1; }
+    std::vector<char> base(nf);
+    for (int c = 0; c < nf; c++) base[c] = live[S.perm[c]] ? 0 : 1;
     for (int i = 0; i < nj; i++) {
-      std::fill(fixed.begin(), fixed.end(), 0);
-      fixed[jobs[i].gauge] = 1;
-      rc = prepare_pass_on(ctx, reps[i], st, fixed.data(), nE, s_ef.data(), s_et.data(), nA, i, nj, /*upload=*/false, hstage);
-      if (rc) return rc;
       char* h = hstage;
-      memcpy(h + s_work + (size_t)24 * nV * i, works[i].data(), (size_t)24 * nV);
+      char* pm = h + (size_t)nf * i;
+      memcpy(pm, base.data(), (size_t)nf);
+      const int gauge = jobs[i].gauge;
+      if (S.vperm[gauge] >= 0) pm[S.vperm[gauge]] = 1;
       const int nq = (int)jobs[i].q.size();
       int32_t* qc = (int32_t*)(h + s_qc) + (size_t)maxq * i;
       int32_t* qv = (int32_t*)(h + s_qv) + (size_t)maxq * i;
-      for (int k = 0; k < nq; k++) { qc[k] = ctx->vmask[jobs[i].q[k]] ? -1 : S.vperm[jobs[i].q[k]]; qv[k] = jobs[i].q[k]; }
+      for (int k = 0; k < nq; k++) { const int q = jobs[i].q[k]; qc[k] = (q == gauge || !live[q]) ? -1 : S.vperm[q]; qv[k] = q; }
       CondJobDev& jd = ((CondJobDev*)(h + s_jd))[i];
-      jd.nq = nq; jd.gauge = jobs[i].gauge; jd.gauge_id = g->ids[jobs[i].gauge]; jd.out_slot = to_wire ? jobs[i].peer : i;
+      jd.nq = nq; jd.gauge = gauge; jd.gauge_id = g->ids[gauge]; jd.out_slot = to_wire ? jobs[i].peer : i;
     }
     t_mask = wall_s() - tm0;
     const double tu0 = wall_s();
@@ -716,6 +798,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   }
   rc = dev_grow(g, g->d_work, 0, 24 * (size_t)nV * nj);       // (the passes on streams work on uploaded copies of the poses)
   if (rc) return rc;
+  run_guesses([&](int i) { works[i].resize(3 * (size_t)nV); return works[i].data(); });
   HIP_TRY(ctx, hipEventRecord(ctx->aux_fork, st));
   for (int k = 0; k < nstreams; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[k], ctx->aux_fork, 0));
   for (int i = 0; i < nj; i++) {
