@@ -46,7 +46,9 @@ HOST_OPT_IN = {"CGMR_HOST_PIN_CALLER": "1", "CGMR_HOST_MOVE": "1", "CGMR_HOST_SP
 _multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 or any(a == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1] not in ("0", "1")
                                                           for i, a in enumerate(sys.argv)) or any(a.startswith("--gpus=") and a[7:] not in ("0", "1") for a in sys.argv)
 if _multi:
+    os.environ.setdefault("OMP_NUM_THREADS", "1")     # (torch.distributed.run sets it; a hand-made launch may not)
     HOST_OPT_IN["CGMR_HOST_MOVE"] = "0"
+    HOST_OPT_IN["CGMR_HOST_SPIN_US"] = "200"          # (the ranks share the node's CPU quota: helpers that spin for 10 ms eat it)
 for _k, _v in HOST_OPT_IN.items():
     os.environ.setdefault(_k, _v)
 
@@ -113,12 +115,13 @@ def host_symbolic_ms_one_thread(V, E, seed):
 
 
 def host_threads():
-    """Threads the library's symbolic analysis uses (gn_symbolic.cpp host_threads(): CGMR_HOST_THREADS or by core count)."""
-    e = int(os.environ.get("CGMR_HOST_THREADS", "0") or 0)
-    if e > 0:
-        return max(1, min(e, 16))
-    hc = os.cpu_count() or 1
-    return 8 if hc >= 32 else 4 if hc >= 8 else 2 if hc >= 4 else 1
+    """Threads the library's symbolic analysis uses (cgmr_host_threads_info: CGMR_HOST_THREADS, or by core count and the
+    control group's CPU quota shared by the ranks of the node)."""
+    import ctypes
+    from cg_mrslam_amd._lib import load_library
+    out = (ctypes.c_int32 * 5)()
+    load_library().cgmr_host_threads_info(out)
+    return int(out[0])
 
 
 def parse():
@@ -162,6 +165,10 @@ def maybe_spawn(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
+        # as torch.distributed.run does for several ranks per node: without it every rank's torch keeps an OpenMP pool of one
+        # thread per hardware thread spinning after each CPU op -- 8 x 256 threads against a container's CPU quota (16 CPUs on
+        # the GPU boxes) throttled the ranks to 3.8 s per C5 round
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     alive = list(procs)
@@ -485,6 +492,7 @@ def exchange_leg(ctx, rank, world, args, dry=False, solo=False):
         rr.condense = fake_condense
     sync = (lambda: None) if dry else torch.cuda.synchronize
     t_round, t_opt, t_cond, t_coll, n_in_total, built_total = [], [], [], [], 0, 0
+    t_fin, t_sta = [], []
     sync(); dist.barrier()
     t_all0 = time.perf_counter()
     for t in range(n_rounds):
@@ -504,7 +512,7 @@ def exchange_leg(ctx, rank, world, args, dry=False, solo=False):
         cs = ex.last_collective_seconds() if (t % 10 == 9) else None     # reading it waits for the collective: sample it
         if cs is not None:
             t_coll.append(cs)
-        t_round.append(t5 - t0); t_opt.append(t2 - t1); t_cond.append(t4 - t3)
+        t_round.append(t5 - t0); t_opt.append(t2 - t1); t_cond.append(t4 - t3); t_fin.append(t3 - t2); t_sta.append(t5 - t4)
     ex.finish()
     if not dry:
         g.condensed_wait()
@@ -534,7 +542,10 @@ def exchange_leg(ctx, rank, world, args, dry=False, solo=False):
            "bytes_gathered_per_rank_per_round": int(nrob * g.wire_bytes()) if nrob > 1 else 0, "wire_bytes_per_edge": 44,
            "condensed_graphs_built_total": int(ssum[5]), "condensed_edges_received_total": int(ssum[4]),
            "received_edges_in_graphs_at_end": int(ssum[6]), "final_vertices_rank0": c["vertices"],
-           "chi2_after_rank0": (float(rr.last_chi2[-1]) if rr.last_chi2 is not None else None), "status_rank0": int(rr.last_status)}
+           "chi2_after_rank0": (float(rr.last_chi2[-1]) if rr.last_chi2 is not None else None), "status_rank0": int(rr.last_status),
+           "backward_solve_timeouts_rank0": (ctx.gn_timeouts() if not dry else None),
+           "ms_per_round_rank0": {"grow_optimize": round(1e3 * float(np.mean(t_opt)), 3), "condense": round(1e3 * float(np.mean(t_cond)), 3),
+                                  "finish_ingest": round(1e3 * float(np.mean(t_fin)), 3), "start_pack_gather": round(1e3 * float(np.mean(t_sta)), 3)}}
     ex.close()
     return out
 

@@ -666,11 +666,40 @@ void host_run_tasks(int n, const std::function<void(int)>& task) {
 
 namespace {
 
+// CPUs' worth of time the process may use per scheduling period when its control group caps it (cgroup v2 cpu.max, v1
+// cpu.cfs_quota_us / cpu.cfs_period_us); 0 = no cap found
+double cgroup_cpu_quota() {
+  double q = 0;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char a[64] = {0};
+    long long period = 0;
+    if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) q = (double)atoll(a) / (double)period;
+    fclose(f);
+    return q;
+  }
+  long long quota = -1, period = 0;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%lld", &quota) != 1) quota = -1; fclose(f); }
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%lld", &period) != 1) period = 0; fclose(f); }
+  return (quota > 0 && period > 0) ? (double)quota / (double)period : 0;
+}
+
 int host_threads() {
   static int n = [] {
     const char* e = getenv("CGMR_HOST_THREADS");
     int v = e ? atoi(e) : 0;
-    if (v <= 0) { unsigned hc = std::thread::hardware_concurrency(); v = hc >= 32 ? 8 : (hc >= 8 ? 4 : (hc >= 4 ? 2 : 1)); }
+    if (v <= 0) {
+      unsigned hc = std::thread::hardware_concurrency();
+      v = hc >= 32 ? 8 : (hc >= 8 ? 4 : (hc >= 4 ? 2 : 1));
+      // A container sees all the host's CPUs and may still be capped to a few CPUs' worth of time (the GPU boxes: 256
+      // hardware threads, cpu.max = 16 CPUs): threads beyond the cap are throttled, not run -- eight ranks with eight
+      // spinning helpers each took 3.8 s per C5 round there (round 4).  The ranks of one node share the cap.
+      const double quota = cgroup_cpu_quota();
+      if (quota > 0) {
+        const char* lw = getenv("LOCAL_WORLD_SIZE") ? getenv("LOCAL_WORLD_SIZE") : getenv("WORLD_SIZE");
+        const int ranks = std::max(1, lw ? atoi(lw) : 1);
+        v = std::min(v, std::max(1, (int)(quota / ranks)));
+      }
+    }
     return std::max(1, std::min(v, 16));
   }();
   return n;
