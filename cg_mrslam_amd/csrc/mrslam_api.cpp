@@ -579,12 +579,12 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   const double tt1 = wall_s();
   const Symbolic& S = ctx->sym;
   const int nstreams = std::min(nj, 8);
-  rc = aux_streams(ctx, nstreams);
-  if (rc) return rc;
   std::vector<GnDevice> reps;
   size_t rep_stride = 0;
+  const size_t rep_cap0 = ctx->rep_arena.cap, mg_cap0 = ctx->mg_arena.cap;
   rc = gn_replicas(ctx, nj, reps, &rep_stride);
   if (rc) return rc;
+  const double tt1a = wall_s();
   // marginals work space per pass, sized for the largest query set
   int maxq = 1;
   for (CondJob& J : jobs) maxq = std::max(maxq, (int)J.q.size());
@@ -603,7 +603,10 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   const size_t stage_cap = (size_t)nf * nj + (size_t)24 * nV * nj + 2 * (size_t)4 * maxq * nj + sizeof(CondJobDev) * (size_t)nj + 5 * 256;
   rc = arena_reserve(ctx, ctx->mg_arena, o_stage + stage_cap + 256);
   if (rc) return rc;
-  const double tt1b = wall_s();                                  // (streams, replicas, work space: allocations when something grew)
+  const double tt1b = wall_s();                                  // (replicas, work space: allocations when something grew)
+  if (trace && tt1b - tt1 > 300e-6)
+    fprintf(stderr, "[cond]   work space: replicas %.0f us (%zu -> %zu MB), marginals arena %.0f us (%zu -> %zu MB)\n", 1e6 * (tt1a - tt1), rep_cap0 >> 20,
+            ctx->rep_arena.cap >> 20, 1e6 * (tt1b - tt1a), mg_cap0 >> 20, ctx->mg_arena.cap >> 20);
   GnEdges Ed;
   Ed.meas_a = (const double*)g->d_meas_a.ptr; Ed.info_a = (const double*)g->d_info_a.ptr;
   Ed.meas_b = g->d_meas_b; Ed.info_b = g->d_info_b;
@@ -796,6 +799,8 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       if (status[i] != 0) return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
     return 0;
   }
+  rc = aux_streams(ctx, nstreams);
+  if (rc) return rc;
   rc = dev_grow(g, g->d_work, 0, 24 * (size_t)nV * nj);       // (the passes on streams work on uploaded copies of the poses)
   if (rc) return rc;
   run_guesses([&](int i) { works[i].resize(3 * (size_t)nV); return works[i].data(); });
