@@ -84,11 +84,13 @@ def pmc_traffic():
 
 def rocprof_c2_stats():
     """Average durations of the GN kernels from the committed rocprofv3 --kernel-trace --stats run of the C2 solve ALONE
-    (tools/gn_profile_run.py; profiles/r04_gn_c2_kernel_stats.csv): the cross-check of the live HIP-event figure."""
+    (tools/gn_profile_run.py; profiles/rNN_gn_c2_kernel_stats.csv): the cross-check of the live HIP-event figure."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r04_gn_c2_kernel_stats.csv")
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gn_c2_kernel_stats.csv")))
+    if not found:
         return None
+    path = found[-1]
     out = {"source": os.path.relpath(path, ROOT)}
     with open(path) as f:
         for row in csv.DictReader(f):

@@ -79,3 +79,76 @@ json.dump(traffic, open(f"{P}/{rnd}_pmc_traffic.json", "w"), indent=1)
 if bench is not None:
     print(json.dumps(traffic, indent=1))
     print({k: bench[k] for k in ("value", "ms_per_step")}, bench["roofline"], bench["matcher"]["value"])
+
+# ---- the C2-only kernel trace (tools/gn_profile_run.py under rocprofv3 --kernel-trace --stats, no counters)
+c2_rows = []
+c2_path = f"{O}/gn_c2_kernel_stats.csv"
+if os.path.exists(c2_path):
+    c2_rows = list(csv.DictReader(open(c2_path)))
+    with open(f"{P}/{rnd}_gn_c2_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in c2_rows:
+            name = r["Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
+            w.writerow([name, r["Calls"], r["TotalDurationNs"], f'{float(r["AverageNs"]):.1f}', f'{float(r["Percentage"]):.3f}', r["MinNs"], r["MaxNs"]])
+
+# ---- profiles/rNN_summary.md: every number below is read from the files written above (nothing is typed in by hand)
+def fnum(v, nd=1):
+    return f"{v:,.{nd}f}"
+L = [f"# Profile summary, round {rnd[1:]} (generated by tools/make_profile_summary.py from gpurun_out/prof_round; do not edit)", ""]
+if c2_rows:
+    L += ["## Gauss-Newton kernels, the C2 solve alone (rocprofv3 --kernel-trace --stats, tools/gn_profile_run.py: 3 x optimize(10))", "",
+          "| kernel | calls | average us | share of kernel time % |", "|---|---|---|---|"]
+    for r in sorted(c2_rows, key=lambda r: -float(r["TotalDurationNs"]))[:12]:
+        name = r["Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
+        L.append(f"| `{name}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.1f} |")
+    L.append("")
+L += ["## HBM-side traffic per launch (separate --pmc FETCH_SIZE / WRITE_SIZE passes; corrected = 2 x FETCH_SIZE + WRITE_SIZE)", "",
+      "| kernel | launches | FETCH_SIZE bytes | WRITE_SIZE bytes | corrected bytes |", "|---|---|---|---|---|"]
+for k, t in traffic.items():
+    if k.startswith("_") or not isinstance(t, dict) or "launches" not in t or not t["launches"]:
+        continue
+    L.append(f"| `{k}` | {t['launches']} | {t['fetch_bytes_raw']:,} | {t['write_bytes_raw']:,} | {t['traffic_bytes_corrected']:,} |")
+L.append("")
+if "_calibration" in traffic:
+    L += ["FETCH_SIZE / WRITE_SIZE against known byte counts (tools/ubench/fetch_calib_ubench.hip, counter bytes / bytes moved):", ""]
+    for k, d in traffic["_calibration"].items():
+        if not k.startswith("_"):
+            L.append(f"* `{k}`: " + ", ".join(f"{c} {v}" for c, v in d.items()))
+    L.append("")
+mk = "k_match_close_batch"
+sq = {c: avg(mk, c)[0] for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+                                  "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT",
+                                  "SQ_LDS_UNALIGNED_STALL")}
+if sq["SQ_WAVE_CYCLES"] > 0:
+    L += [f"## Matcher, `{mk}` (4096 pairs per launch, tools/match_profile_run.py; per-launch averages)", "",
+          "| counter | per launch |", "|---|---|"] + [f"| {c} | {v:,.0f} |" for c, v in sq.items()] + [""]
+    ratios = []
+    if sq["SQ_LDS_IDX_ACTIVE"] > 0:
+        ratios.append(f"SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = {sq['SQ_LDS_BANK_CONFLICT'] / sq['SQ_LDS_IDX_ACTIVE']:.3f}")
+    ratios.append(f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {sq['SQ_WAIT_ANY'] / sq['SQ_WAVE_CYCLES']:.3f}")
+    ratios.append(f"SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_WAVE_CYCLES']:.3f}")
+    ratios.append(f"SQ_ACTIVE_INST_LDS / SQ_WAVE_CYCLES = {sq['SQ_ACTIVE_INST_LDS'] / sq['SQ_WAVE_CYCLES']:.3f}")
+    t = traffic.get(mk, {})
+    if t.get("launches"):
+        ratios.append(f"HBM-side bytes per pair = {t['traffic_bytes_corrected'] / 4096:,.0f}")
+    L += ["Ratios: " + "; ".join(ratios) + ".", ""]
+    if "phase_cycles_per_pair" in traffic.get(mk, {}):
+        L += ["Phase cycles per pair (timing build, tools/gpu_mphase.py): " + ", ".join(f"{k} {v}" for k, v in traffic[mk]["phase_cycles_per_pair"].items() if k != "note") + ".", ""]
+if bench is not None:
+    r = bench["roofline"]
+    L += ["## The bench line of the same sources (profiles/" + rnd + "_bench_line.json; under the profiler: kernel-trace + stats)", "",
+          f"* value {bench['value']} {bench['unit']}, {bench['ms_per_step']} ms per step (host analysis {bench['host_symbolic_ms_per_step']} ms, device {bench['device_ms_per_step']} ms), host load {bench.get('host_loadavg_1min')}",
+          f"* `k_front_factor`: {r['avg_launch_us']} us per launch by HIP events, {r['launches_per_gn_iter']} launches per GN iteration; algorithmic {r['algorithmic_bytes_per_launch']:,} B per launch "
+          f"-> {r['achieved']} GB/s = {r['frac']} of 8 TB/s (on the layout's bytes, {r.get('layout_bytes_per_launch')}: {r.get('frac_on_layout_bytes')}); B_iter_frac {r.get('B_iter_frac')}",
+          f"* matcher {bench['matcher']['value']:,.0f} pairs/s (pruned search), {bench['matcher']['exhaustive']['pairs_per_s']:,.0f} exhaustive; LDS-gather roofline fraction {bench['matcher']['roofline']['frac']}",
+          f"* C5: one robot alone {bench['exchange']['round_ms_mean_max']} ms per round; eight robots on this GPU {bench['exchange_loopback']['round_ms_per_robot']} ms per robot and round "
+          f"(the same robots alone {bench['exchange_loopback']['solo_round_ms_same_robots']['mean']} ms): predicted_weak_scaling_efficiency_8 {bench.get('predicted_weak_scaling_efficiency_8')}", ""]
+    rows = list(csv.DictReader(open(f"{O}/bench_kernel_stats.csv")))
+    L += ["Kernel statistics of the whole bench run (all legs: C2, key-frame graphs, C5 graphs growing from 50 vertices, matcher):", "",
+          "| kernel | calls | average us | share % |", "|---|---|---|---|"]
+    for r2 in sorted(rows, key=lambda q: -float(q["TotalDurationNs"]))[:14]:
+        name = r2["Name"].split("(")[0].replace("cgmr::", "").replace("void ", "")
+        L.append(f"| `{name[:60]}` | {r2['Calls']} | {float(r2['AverageNs']) / 1e3:.2f} | {float(r2['Percentage']):.1f} |")
+    L.append("")
+open(f"{P}/{rnd}_summary.md", "w").write("\n".join(L))

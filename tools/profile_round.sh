@@ -5,7 +5,7 @@
 #   kernel-trace + stats of bench.py.  tools/make_profile_summary.py rNN turns the merged gpurun_out/prof_round into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-RND=${ROUND:-r03}
+RND=${ROUND:-r04}
 O=$R/gpurun_out/prof_round
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
@@ -25,6 +25,11 @@ done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 120 rocprofv3 --kernel-trace --pmc $c -d $O/calib_$c --output-format csv -- $R/tools/ubench/fetch_calib_ubench > $O/calib_$c.log 2>&1
 done
+# kernel trace + stats of the C2 solve ALONE (no counters): the per-kernel averages bench.py's roofline is checked against
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/gn_c2 --output-format csv -- python $R/tools/gn_profile_run.py > $O/gn_c2.log 2>&1
+find $O/gn_c2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/gn_c2_kernel_stats.csv
+find $O/gn_c2 -name "*kernel_trace.csv" -delete
 cd $R
 [ -f cg_mrslam_amd/libcgmr_t.so ] && CGMR_MATCH_SPLIT=1 CGMR_LIB=cg_mrslam_amd/libcgmr_t.so timeout 120 python tools/gpu_mphase.py $O/match_phases.json > $O/match_phases.log 2>&1
 python tools/make_profile_summary.py $RND --pmc-only > $O/pmc_only.log 2>&1
