@@ -834,7 +834,9 @@ int cgmr_ctx_create(int device, void* hip_stream, cgmr_ctx** out) {
 
 void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (!ctx) return;
-  // teardown: nothing useful can be done with a failing free, the statuses are dropped on purpose
+  // teardown: nothing useful can be done with a failing free, the statuses are dropped on purpose -- and a HIP runtime that
+  // is already shutting down (a binding's garbage collector at interpreter exit) throws instead of returning an error
+  try {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->trace_n > 0)
@@ -858,6 +860,8 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  } catch (...) {
+  }
   delete ctx;
 }
 

@@ -106,6 +106,7 @@ struct cgmr_graph {
   // a batch of condensed-graph passes queued on the context's side stream and not waited for yet
   // (cgmr_graph_compute_condensed_async): what is needed to finish it
   bool cond_pending = false;
+  int cond_last_rc = 0;               // how the most recent asynchronous batch ended (kept for cgmr_graph_condensed_wait)
   std::vector<int32_t> cond_peers;    // peer of every job of the batch
   const int32_t* cond_status = nullptr;   // pinned: 4 status words per job, valid after ev_cond_done
   const CondJobDev* cond_jobs_dev = nullptr;    // the batch's job table on the device (peer of job j = out_slot)
@@ -241,10 +242,11 @@ int cond_finish(cgmr_graph* g) {
     if (g->cond_status[4 * j] != 0) failed = true;
     if (g->cond_status[4 * j + 2] != 0) timed_out = true;
   }
+  g->cond_last_rc = 0;
   if (!failed) return 0;
   for (int32_t p : g->cond_peers) { g->out[p].n = 0; g->out[p].host_valid = false; }
-  if (timed_out) { ctx->gn_timeouts++; return gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
-  return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
+  if (timed_out) { ctx->gn_timeouts++; return g->cond_last_rc = gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
+  return g->cond_last_rc = gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
 }
 
 // whatever is about to overwrite my send buffer waits for the robots that are still copying it (cgmr_graph_deliver)
@@ -350,6 +352,9 @@ int cgmr_graph_create(cgmr_ctx* ctx, int robot_id, int n_robots, int base_id, in
 
 void cgmr_graph_destroy(cgmr_graph* g) {
   if (!g) return;
+  // (a binding's garbage collector may get here at interpreter exit, after the HIP runtime has begun to take itself apart:
+  // its calls then throw -- std::bad_variant_access was seen -- and a destructor must not end the process for that)
+  try {
   if (g->ctx) {
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
@@ -362,6 +367,8 @@ void cgmr_graph_destroy(cgmr_graph* g) {
     if (g->pinned_poses) (void)hipHostFree(g->pinned_poses);
     for (hipEvent_t e : {g->ev_msg, g->ev_cond_done, g->ev_pack, g->ev_packed}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->ev_consumed) if (e) (void)hipEventDestroy(e);
+  }
+  } catch (...) {
   }
   delete g;
 }
@@ -761,6 +768,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       rc = side_mark(ctx);
       if (rc) return rc;
       g->cond_pending = true;
+      g->cond_last_rc = 0;
       g->cond_peers.clear();
       for (CondJob& J : jobs) g->cond_peers.push_back(J.peer);
       g->cond_status = (const int32_t*)(h + s_st);
@@ -997,7 +1005,10 @@ int cgmr_graph_condensed_wait(cgmr_graph* g) {
   if (!g) return CGMR_E_INVALID;
   if (!g->ctx) return CGMR_OK;
   HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
-  return cond_finish(g);
+  if (g->cond_pending) return cond_finish(g);
+  if (g->cond_last_rc) gerr(g, g->cond_last_rc, g->cond_last_rc == CGMR_E_TIMEOUT ? "a bounded device-side wait ran out while building a condensed graph"
+                                                                                   : "Cholesky failed while building a condensed graph");
+  return g->cond_last_rc;                       // (another call has waited for the batch already: its outcome is kept)
 }
 
 // Announce that this graph will use cgmr_graph_compute_condensed_async (call before the first solve: the chained backward

@@ -481,3 +481,45 @@ def test_robots_taking_turns_with_whole_rounds_equal_the_lock_step_rounds():
                 if len(ga[1]):
                     assert np.abs(ga[2] - gb[2]).max() <= 1e-9 and np.abs(ga[3] - gb[3]).max() <= 1e-9 * np.abs(ga[3]).max()
         assert np.abs(ra.g.poses() - rb.g.poses()).max() <= 1e-9
+
+
+def test_failed_asynchronous_batch_sends_nothing_and_reports_itself():
+    """A pass of a batch that was not waited for fails (an edge with a negative-definite information matrix: a negative pivot
+    for certain).  The message packed BEHIND the batch, before anybody knew, must carry no edges for the batch's peers -- the
+    counts are taken back on the device (k_wire_fix_counts) -- and the failure is reported by cgmr_graph_condensed_wait.  The
+    control run without the bad edge delivers the star."""
+    from cg_mrslam_amd import Context
+    from cg_mrslam_amd._lib import CgmrError
+    g = synth.make_pose_graph(400, 1200, seed=11, id_base=0)
+    want = g["ids"][[5, 60, 150, 260, 399]]
+
+    def run(bad):
+        c0, c1 = Context(0), Context(0)
+        g0 = RobotGraph(c0, 0, 2, async_condense=True)
+        g1 = RobotGraph(c1, 1, 2, async_condense=True)
+        g0.add_vertices(g["ids"], g["poses"], g["fixed"])
+        ef, et, meas, info = g["ids"][g["edge_from"]], g["ids"][g["edge_to"]], g["meas"], g["info"].copy()
+        if bad:
+            info[7] = [-1e6, 0, 0, -1e6, 0, -1e6]
+        g0.add_edges(ef, et, meas, info)
+        # robot 1 holds copies of the requested vertices (it would accept the star) and one vertex of its own
+        g1.add_vertices(np.concatenate([[10000], want]), np.zeros((1 + len(want), 3)), None)
+        g0.insertOutClosure(1, want)
+        assert g0.computeCondensedGraph(1) == 1                    # queued, not waited for
+        g0.pack(0)
+        g0.deliver(g1)
+        g1.pack(0)
+        g1.deliver(g0)
+        n_in = g1.ingest_delivered()
+        return g0, int(n_in[0])
+
+    g0, n_ok = run(False)
+    g0.condensed_wait()
+    assert n_ok == len(want) - 1
+    g0, n_bad = run(True)
+    assert n_bad == 0                                              # nothing of the failed batch travelled
+    with pytest.raises(CgmrError) as e:
+        g0.condensed_wait()
+    assert e.value.code <= -100
+    assert g0.condensed(1)[1].size == 0
+    g0.close()                                                     # (the exception info above would keep it alive until interpreter exit)
