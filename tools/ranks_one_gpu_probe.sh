@@ -1,4 +1,6 @@
 #!/bin/bash
+# N ranks of bench.py on ONE GPU (gloo), reduced sizes: where a C5 round goes (phases of rank 0, time-outs) as the rank count grows -- round 4 found the
+# 16-CPU quota of the GPU boxes with it (OMP_NUM_THREADS, helper pool size).
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 for n in 2 4 8; do
   echo "== $n ranks"
