@@ -304,6 +304,29 @@ def test_native_rccl_allgather_single_rank(ctx):
     assert lib.cgmr_comm_last_seconds(comm, C.byref(s)) == 0 and s.value >= 0
     robot, n_e, n_c, edges, clos = unpack_wire(sent, 1, g.cap)
     assert robot == 0 and list(n_c) == [2] and list(clos[0, :2]) == [1, 2]
+    # ... and behind a batch of condensed graphs that was NOT waited for (the context's side stream): the all-gather must
+    # carry the star the batch writes, not what the send buffer held when the call was made
+    import torch
+    gd = synth.make_pose_graph(600, 1800, seed=3)
+    g2 = RobotGraph(ctx, 0, 2, async_condense=True)
+    g2.add_vertices(gd["ids"], gd["poses"], gd["fixed"])
+    g2.add_edges(gd["ids"][gd["edge_from"]], gd["ids"][gd["edge_to"]], gd["meas"], gd["info"])
+    assert g2.optimize(3)[0] == 0
+    want = gd["ids"][[4, 90, 222, 410, 577]]
+    g2.insertOutClosure(1, want)
+    assert g2.computeCondensedGraph(1) == 1                        # queued on the side stream
+    g2.pack(0)
+    wb = g2.wire_bytes()
+    recv = torch.zeros(wb, dtype=torch.uint8, device="cuda")      # a one-rank gather: my buffer comes back
+    rc = lib.cgmr_allgather_condensed(ctx.h, comm, C.c_void_p(g2.send_buffer()), C.c_size_t(wb), C.c_void_p(recv.data_ptr()))
+    assert rc == 0, lib.cgmr_last_error(ctx.h)
+    assert lib.cgmr_comm_last_seconds(comm, C.byref(s)) == 0      # (waits for the collective)
+    got = recv.cpu().numpy()
+    robot, n_e, n_c, edges, clos = unpack_wire(got, 2, g2.cap)
+    assert robot == 0 and list(n_e) == [0, len(want) - 1]
+    gid, to, est, iu = g2.condensed(1)                             # (waits for the batch)
+    assert np.array_equal(edges[1, :n_e[1]]["to"], to) and np.all(edges[1, :n_e[1]]["from"] == gid)
+    assert np.abs(edges[1, :n_e[1]]["est"] - est.astype(np.float32)).max() == 0
     lib.cgmr_comm_destroy.restype = None
     lib.cgmr_comm_destroy(comm)
 
