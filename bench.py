@@ -407,6 +407,9 @@ def matcher_leg(ctx, dev, args, with_cpu):
                         "bytes_fetched_per_useful_byte": round((32 + 8) / 24.0 * 64 / 60, 3),
                         "lds_bank_conflict_frac": (pmc_m or {}).get("lds_bank_conflict_frac"),
                         "valu_active_frac_of_wave_cycles": (pmc_m or {}).get("valu_active_frac"),
+                        "wave_parked_frac_of_wave_cycles": (pmc_m or {}).get("wait_any_frac"),      # SQ_WAIT_ANY / SQ_WAVE_CYCLES (s_waitcnt / barriers)
+                        "lds_array_busy_frac_of_cu_cycles": (pmc_m or {}).get("lds_array_busy_frac"),
+                        "waves_per_simd": 2, "workgroups_per_cu": 1, "vgprs": 256, "lds_bytes_per_workgroup": 163392,
                         "phase_cycles_per_pair": (pmc_m or {}).get("phase_cycles_per_pair"),
                         "counters_stale": pmc_traffic().get("_stale"),
                         "note": "algorithmic = one grid byte per (64 angles x 24 x 24 offsets x k subsampled points) from the sparse "
@@ -774,6 +777,10 @@ def main():
                    "achieved_GBps": round(b_iter_gbs, 2),
                    "definition": "(96 V + 80 E + 144 (V + E) + 2 * 8 * stored factor cells) / device time of one GN iteration / 8 TB/s (SURVEY.md 8d)"},
         "rocprofv3": rocprof,
+        # the same numerator over the committed rocprofv3 average of the C2 solve alone (kernel time without the launch gaps the
+        # HIP-event pairs of the live figure bracket)
+        "frac_on_rocprofv3_avg": (round(bytes_per_launch / (rocprof["k_front_factor"]["avg_us"] * 1e-6) / 8e12, 6)
+                                  if rocprof and "k_front_factor" in rocprof else None),
         "share_of_kernel_time": round(ff_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
         "note": f"latency-bound: {info['launch_levels']} dependent tree levels (+ the top block), per level one contiguous panel load, three "
                 "elimination passes of FP64 pivot chains and the stores; traffic_stale = the PMC passes under profiles/ were taken on "

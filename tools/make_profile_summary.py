@@ -57,6 +57,11 @@ for k in ("k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_a
         valu, _ = avg(k, "SQ_ACTIVE_INST_VALU"); wavec, _ = avg(k, "SQ_WAVE_CYCLES")
         if act > 0: traffic[k]["lds_bank_conflict_frac"] = round(conf / act, 4)
         if wavec > 0: traffic[k]["valu_active_frac"] = round(valu / wavec, 4)
+        wany, _ = avg(k, "SQ_WAIT_ANY"); busy, _ = avg(k, "SQ_BUSY_CYCLES")
+        if wavec > 0: traffic[k]["wait_any_frac"] = round(wany / wavec, 4)
+        # LDS-array cycles (all CUs) against the CU-cycles of the launch: SQ_WAVE_CYCLES counts every wavefront every 4th cycle,
+        # 8 wavefronts per CU are resident for the whole launch
+        if wavec > 0 and act > 0: traffic[k]["lds_array_busy_frac"] = round(act / (wavec * 4 / 8), 4)
         ph = f"{O}/match_phases.json"                                       # tools/gpu_mphase.py on the timing build
         if os.path.exists(ph): traffic[k]["phase_cycles_per_pair"] = json.load(open(ph))
 # FETCH_SIZE / WRITE_SIZE calibration (tools/ubench/fetch_calib_ubench.hip: every kernel moves a known byte count once)
