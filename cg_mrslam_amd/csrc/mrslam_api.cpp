@@ -1239,20 +1239,22 @@ int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
   HIP_TRY(ctx, hipStreamSynchronize(st));
   std::vector<uint8_t> accepted;
   ingest_decide(g, (const int32_t*)h_ids, accepted);
+  unsigned long long fresh = 0;                                   // senders whose message replaced their previous set (R <= 64)
   for (int s = 0; s < R; s++) {
     if (n_edges_out) n_edges_out[s] = accepted[s] ? (int32_t)g->in[s].slot.size() : 0;
     if (!accepted[s]) continue;
     g->hs_fresh[s] = 0;
-    const int n_e = ((const int32_t*)h_ids)[(size_t)s * (2 + 3 * (size_t)cap)];
-    HIP_TRY(ctx, hipMemcpyAsync(g->d_stage_meas + 3 * (size_t)s * cap, g->d_tmp_meas + 3 * (size_t)s * cap, 24 * (size_t)n_e, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(g->d_stage_info + 6 * (size_t)s * cap, g->d_tmp_info + 6 * (size_t)s * cap, 48 * (size_t)n_e, hipMemcpyDeviceToDevice, st));
+    fresh |= 1ULL << s;
   }
   int32_t* h_slot = (int32_t*)(g->pinned + round256(wb) + round256(ids_bytes));
   int j = 0;
   for (int s = 0; s < R; s++) for (int32_t sl : g->in[s].slot) h_slot[j++] = sl;
   if (j > 0) {
+    // one launch: the accepted senders' records move from the widened wire data into the staging and, with the sets kept
+    // from earlier rounds, into the compact second edge segment (two device copies per accepted sender + a gather before)
     HIP_TRY(ctx, hipMemcpyAsync(g->d_slot, h_slot, 4 * (size_t)j, hipMemcpyHostToDevice, st));
-    launch_gather_edges(st, j, g->d_slot, g->d_stage_meas, g->d_stage_info, g->d_meas_b, g->d_info_b);
+    launch_accept_gather_edges(st, j, cap, fresh, g->d_slot, g->d_tmp_meas, g->d_tmp_info, g->d_stage_meas, g->d_stage_info, g->d_meas_b,
+                               g->d_info_b);
   }
   return CGMR_OK;
 }

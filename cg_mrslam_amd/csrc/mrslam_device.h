@@ -31,6 +31,8 @@ void launch_wire_read(hipStream_t st, int n_ranks, int cap, int me, size_t wire_
                       double* stage_meas, double* stage_info, int32_t* ids_out);
 void launch_gather_edges(hipStream_t st, int n, const int32_t* slot, const double* src_meas, const double* src_info,
                          double* dst_meas, double* dst_info);
+void launch_accept_gather_edges(hipStream_t st, int n, int cap, unsigned long long fresh, const int32_t* slot, const double* tmp_meas,
+                                const double* tmp_info, double* stage_meas, double* stage_info, double* dst_meas, double* dst_info);
 void launch_gather_poses(hipStream_t st, int n, const int32_t* idx, const double* poses, double* out);
 // Everything a batch of condensed-graph passes needs before its first kernel, in one launch behind ONE staging copy: job j's
 // column mask (nf bytes at stage_mask + j * nf) to cmask + j * rep_stride, its query columns / vertices (maxq int32 each at

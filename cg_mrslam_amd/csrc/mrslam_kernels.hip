@@ -87,6 +87,31 @@ __global__ void k_gather_edges(int n, const int32_t* __restrict__ slot, const do
   for (int a = 0; a < 6; a++) dst_info[6 * (size_t)j + a] = src_info[6 * (size_t)s + a];
 }
 
+// The same behind an ingest: the senders whose bit is set in `fresh` had their message accepted this round -- their records
+// come from the widened wire data (tmp) and are kept in the staging as well (the next rounds gather them from there); the
+// others' from the staging.  One launch instead of two device copies per accepted sender and a gather.
+__global__ void k_accept_gather_edges(int n, int cap, unsigned long long fresh, const int32_t* __restrict__ slot,
+                                      const double* __restrict__ tmp_meas, const double* __restrict__ tmp_info,
+                                      double* __restrict__ stage_meas, double* __restrict__ stage_info,
+                                      double* __restrict__ dst_meas, double* __restrict__ dst_info) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int s = slot[j];
+  const bool f = (fresh >> (s / cap)) & 1ULL;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const double v = f ? tmp_meas[3 * (size_t)s + a] : stage_meas[3 * (size_t)s + a];
+    if (f) stage_meas[3 * (size_t)s + a] = v;
+    dst_meas[3 * (size_t)j + a] = v;
+  }
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    const double v = f ? tmp_info[6 * (size_t)s + a] : stage_info[6 * (size_t)s + a];
+    if (f) stage_info[6 * (size_t)s + a] = v;
+    dst_info[6 * (size_t)j + a] = v;
+  }
+}
+
 // out[k] = poses[idx[k]] (query vertices of all peers: the host picks the gauges from them)
 __global__ void k_gather_poses(int n, const int32_t* __restrict__ idx, const double* __restrict__ poses,
                                double* __restrict__ out) {
@@ -164,6 +189,13 @@ void launch_gather_edges(hipStream_t st, int n, const int32_t* slot, const doubl
                          double* dst_meas, double* dst_info) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_gather_edges, dim3((n + 127) / 128), dim3(128), 0, st, n, slot, src_meas, src_info, dst_meas, dst_info);
+}
+
+void launch_accept_gather_edges(hipStream_t st, int n, int cap, unsigned long long fresh, const int32_t* slot, const double* tmp_meas,
+                                const double* tmp_info, double* stage_meas, double* stage_info, double* dst_meas, double* dst_info) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_accept_gather_edges, dim3((n + 127) / 128), dim3(128), 0, st, n, cap, fresh, slot, tmp_meas, tmp_info, stage_meas,
+                     stage_info, dst_meas, dst_info);
 }
 
 void launch_gather_poses(hipStream_t st, int n, const int32_t* idx, const double* poses, double* out) {
