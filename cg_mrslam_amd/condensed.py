@@ -306,7 +306,9 @@ class Exchange:
         lib = g.lib
         dev = torch.device("cuda", g.ctx.device)
         h = np.zeros(128, dtype=np.uint8)
-        ok_local = lib.cgmr_comm_unique_id(_p(h))            # loads librccl, asks it for an id (used on rank 0 only)
+        # rank 0 asks librccl for the id; the others only check that the library resolves (ncclGetUniqueId starts a bootstrap
+        # listener: one per rank that nothing ever uses otherwise)
+        ok_local = lib.cgmr_comm_unique_id(_p(h)) if dist.get_rank(self.group) == 0 else lib.cgmr_comm_probe()
         flag = torch.tensor([1 if ok_local == 0 else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         if int(flag.item()) == 0:
@@ -324,6 +326,9 @@ class Exchange:
         t.start()
         t.join(float(os.environ.get("CGMR_RCCL_INIT_TIMEOUT", "60")))
         if t.is_alive():
+            # the thread may still come back with a communicator: close() then takes care of it; until it has, the context is
+            # shared with a thread inside ncclCommInitRank, which touches the device but none of the context's buffers
+            self._late_init = (t, comm, res)
             raise TimeoutError("ncclCommInitRank did not return (native RCCL communicator); using torch.distributed instead")
         if res.get("rc", -1) != 0:
             raise CgmrError(res.get("rc", -1), g.ctx.lib.cgmr_last_error(g.ctx.h).decode())
@@ -336,6 +341,14 @@ class Exchange:
             self.comm = None
 
     def close(self):
+        late = getattr(self, "_late_init", None)
+        if late is not None:                                  # a collective initialisation that outlived its time-out
+            t, comm, res = late
+            t.join(5.0)
+            if not t.is_alive() and res.get("rc", -1) == 0 and comm:
+                self.g.lib.cgmr_comm_destroy.restype = None
+                self.g.lib.cgmr_comm_destroy(comm)
+            self._late_init = None
         self._destroy_comm()
 
     def start(self):

@@ -74,6 +74,11 @@ struct cgmr_comm {
 
 extern "C" {
 
+// librccl resolves in this process (every symbol the exchange needs): what a rank that is not the root of the unique id
+// checks before the collective initialisation -- ncclGetUniqueId on every rank would start a bootstrap listener per rank
+// that nothing ever uses.
+int cgmr_comm_probe(void) { return rccl().ok ? CGMR_OK : CGMR_E_NO_DEVICE; }
+
 int cgmr_comm_unique_id(void* id_out_128) {
   if (!id_out_128) return CGMR_E_INVALID;
   Rccl& R = rccl();

@@ -472,6 +472,9 @@ int cgmr_graph_last_seconds(const cgmr_graph* g, double out[2]);
  * stream wait for it.  cgmr_ctx_join_side: everything queued on the context's stream from now on runs after what is on
  * its side stream (for a caller that moves the send buffer with a transport of its own). */
 int cgmr_comm_unique_id(void* id_out_128);
+/* CGMR_OK if librccl resolves in this process: the check of the ranks that do NOT create the unique id (the root alone calls
+ * cgmr_comm_unique_id) before everybody enters the collective cgmr_comm_create */
+int cgmr_comm_probe(void);
 int cgmr_comm_create(cgmr_ctx* ctx, int n_ranks, int rank, const void* unique_id_128, cgmr_comm** out);
 void cgmr_comm_destroy(cgmr_comm* comm);
 int cgmr_allgather_condensed(cgmr_ctx* ctx, cgmr_comm* comm, const void* d_send, size_t bytes_per_rank, void* d_recv);
