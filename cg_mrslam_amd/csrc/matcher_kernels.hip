@@ -917,7 +917,9 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
             int ix = (int)(px * (double)P.inv_res), iy = (int)(py * (double)P.inv_res);
             packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
           }
-          uint32_t left = __shfl_up(packed, 1, 64);
+          // the left neighbour's cell by a DPP wave shift and the chunk's last cell by v_readlane (wave-uniform lane): the
+          // generic shuffles go through the LDS pipe, two dependent round trips per chunk of 64 points
+          uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)prev, (int)packed, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
           if (lane == 0) left = prev;
           bool keep = valid && (!(lane == 0 && !have_prev) ? (packed != left) : true);
           const unsigned long long below = (1ULL << lane) - 1ULL;
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
             k += __popcll(mask);
           }
           int lastv = min(63, nq - base - 1);
-          prev = __shfl(packed, lastv, 64);
+          prev = (uint32_t)__builtin_amdgcn_readlane((int)packed, lastv);
           have_prev = true;
         }
         if (v2) {
