@@ -849,6 +849,10 @@ def main():
                                                 if (loopback and "round_ms_per_robot" in loopback and world == 1) else None),
         "predicted_weak_scaling_efficiency_8_vs_robot0_alone": (round(exchange["round_ms_mean_max"] / loopback["round_ms_per_robot"], 4)
                                                                if (loopback and "round_ms_per_robot" in loopback and world == 1) else None),
+        "predicted_weak_scaling_efficiency_8_note": "a robot's round among eight on this GPU (exchange_loopback.round_ms_per_robot) against the mean "
+                                                    "round of the SAME eight sub-graphs each alone (exchange_loopback.solo_round_ms_same_robots); "
+                                                    "_vs_robot0_alone divides the N = 1 exchange leg's round instead (robot 0's graph, the easiest of "
+                                                    "the eight: 8 tree levels against 10-14)",
         "host_pool_of_every_rank": host_pools,
     }
     if cpu:
