@@ -65,6 +65,7 @@ struct cgmr_ctx {
   double trace_sum[4] = {0, 0, 0, 0};
   double match_seconds = 0;
   int64_t match_pairs = 0, match_slow_pairs = 0;   // last batched close-matching launch: pairs, pairs off the LDS fast path
+  int64_t match_redo_pairs = 0;                    // ... pairs the lean kernel instance handed to the general one
   bool profiling = false;
   double ksec[8] = {0};
   int64_t klaunch[8] = {0};

@@ -176,7 +176,12 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   Layout L;
   size_t o_err = L.add(16);
   const size_t merge_bytes = P.split > 1 ? (size_t)n_pairs * (match_close_max_bins() * 8 + 8) : 0;
-  size_t o_merge = L.add(merge_bytes), o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
+  // the lean instances of the kernel (matcher_kernels.hip: k_match_close_batch<1 / 2>) take the shape the batch is normally run in;
+  // pairs they cannot take come back on a list and go through the general kernel behind them
+  static const bool lean_on = !(getenv("CGMR_MATCH_LEAN") && atoi(getenv("CGMR_MATCH_LEAN")) == 0);
+  const bool lean = lean_on && match_close_lean_ok(P);
+  size_t o_merge = L.add(merge_bytes), o_redo = L.add(lean ? sizeof(int) * (size_t)n_pairs : 0),
+         o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
   int rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
   if (rc) return rc;
   const size_t io_in = io ? io->in_bytes : 0, io_out = io ? io->out_bytes : 0;
@@ -196,12 +201,27 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   if (merge_bytes)        // empty bins (all ones) and arrival counters at -1, in one fill
     HIP_TRY(ctx, hipMemsetAsync(d + o_merge, 0xff, merge_bytes, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  launch_match_close_batch(ctx->stream, nblocks, P, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
+  launch_match_close_batch(ctx->stream, nblocks, lean ? (P.prune ? 2 : 1) : 0, P, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
                            (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
                            d_xyt, d_score, d_found, d_nres, (int*)(d + o_err), (unsigned long long*)(d + o_merge),
-                           (int*)(d + o_merge + (size_t)n_pairs * match_close_max_bins() * 8));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+                           (int*)(d + o_merge + (size_t)n_pairs * match_close_max_bins() * 8), lean ? (int*)(d + o_redo) : nullptr);
   int* errv = (int*)(ctx->pinned + 64);
+  if (lean) {
+    // pairs left over (err[3]; their indices in the redo list): the general kernel takes them from the list.  The count is needed
+    // on the host only to skip the second launch -- normally there is nothing to do
+    HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->match_redo_pairs = errv[3];
+    if (errv[0] == 0 && errv[3] > 0) {
+      h_err[0] = 0; h_err[1] = std::min(errv[3], ctx->n_cus); h_err[2] = 0; h_err[3] = errv[3];
+      HIP_TRY(ctx, hipMemcpyAsync(d + o_err, h_err, 16, hipMemcpyHostToDevice, ctx->stream));
+      launch_match_close_batch(ctx->stream, h_err[1], 0, P, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
+                               (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
+                               d_xyt, d_score, d_found, d_nres, (int*)(d + o_err), (unsigned long long*)(d + o_merge),
+                               (int*)(d + o_merge + (size_t)n_pairs * match_close_max_bins() * 8), (int*)(d + o_redo));
+    }
+  } else ctx->match_redo_pairs = 0;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 16, hipMemcpyDeviceToHost, ctx->stream));
   char* h_out_stage = ctx->pinned + 256 + io_in + ((256 - io_in % 256) % 256);
   if (io_out) HIP_TRY(ctx, hipMemcpyAsync(h_out_stage, io->d_out, io_out, hipMemcpyDeviceToHost, ctx->stream));
@@ -333,6 +353,12 @@ int cgmr_match_close_vset_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
 int cgmr_match_last_stats(const cgmr_ctx* ctx, int64_t out[2]) {
   if (!ctx || !out) return CGMR_E_INVALID;
   out[0] = ctx->match_pairs; out[1] = ctx->match_slow_pairs;
+  return CGMR_OK;
+}
+
+int cgmr_match_last_redo_pairs(const cgmr_ctx* ctx, int64_t* out) {
+  if (!ctx || !out) return CGMR_E_INVALID;
+  *out = ctx->match_redo_pairs;
   return CGMR_OK;
 }
 

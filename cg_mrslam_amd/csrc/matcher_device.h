@@ -76,11 +76,12 @@ void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, cons
                          const double* ref_pts, const double* qry_pts, const RegionDesc* regions, const double* theta,
                          const int32_t* items, const uint8_t* kernel_lut, unsigned char* scratch, unsigned long long* bins,
                          int* err);
-void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
+void launch_match_close_batch(hipStream_t st, int nblocks, int variant, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
                               double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err,
-                              unsigned long long* gbins, int* arrive);
+                              unsigned long long* gbins, int* arrive, int* redo_list);
+bool match_close_lean_ok(const MatchParams& P);
 int match_close_max_bins();
 
 }  // namespace cgmr

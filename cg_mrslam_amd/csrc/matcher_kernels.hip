@@ -67,7 +67,8 @@ struct Smem {
   uint32_t best_bits;                        // pruned search: lowest accepted score so far (float bits)
   uint32_t pad_[3];
   uint32_t totals[NTH][24 * 12];             // fast search path: per wavefront, the totals of the 24 x 24 offsets of its angle, two
-                                             // 16-bit sums per word (y offsets 2j, 2j + 1 of an x row)
+                                             // 16-bit sums per word (y offsets 4t + h, 4t + h + 2 of an x row in word 2t + h)
+  uint8_t binx[32], biny[32], bint[MAXTHETA]; // fast search path: result bin of an x offset (times nby), of a y offset, of an angle
 };
 static_assert((sizeof(uint16_t) * kMatchMaxDir) % 16 == 0, "tile pool must stay 16-byte aligned behind the directory");
 // block_scan_excl scratch (one int per thread + total): the last point list, idle whenever a scan runs
@@ -78,10 +79,11 @@ static_assert(sizeof(Smem) <= 160 * 1024, "matcher LDS plan exceeds 160 KiB");
 #ifdef CGMR_PHASE_TIMING
 __device__ unsigned long long g_mphase[32];
 #define MPHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mphase[i] = __builtin_readcyclecounter(); } while (0)
-// wavefront 0 of workgroup 0: cycles between marks of the fast search path, summed over the angles (slots 10..15)
+// workgroup 0: cycles between marks of the fast search path, summed over the angles and wavefronts (slots 10..15, 24)
 #define MSTAT_T0() unsigned long long mst_ = __builtin_readcyclecounter()
-#define MSTAT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_mphase[i] += n_ - mst_; mst_ = n_; } while (0)
-#define MSTAT_ADD(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mphase[i] += (v); } while (0)
+// (every wavefront of workgroup 0: the slots hold sums over its wavefronts)
+#define MSTAT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_mphase[i], n_ - mst_); mst_ = n_; } while (0)
+#define MSTAT_ADD(i, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_mphase[i], (unsigned long long)(v)); } while (0)
 #else
 #define MPHASE(i)
 #define MSTAT_T0()
@@ -130,26 +132,24 @@ constexpr int PPI = 2;                         // points per lane and iteration 
 #ifndef CGMR_MATCH_PH
 #define CGMR_MATCH_PH 4
 #endif
-constexpr int PH = CGMR_MATCH_PH;                          // pruned search: the first pass adds every PH-th block of GRP slots (a quarter of the points,
+constexpr int PH = CGMR_MATCH_PH;              // pruned search: the first pass adds every PH-th two-entry slot of a class (a quarter of the points,
                                                // spread over the whole list: the list is in the subsample's cell order, i.e. sorted in space)
-// MODE 0: every slot (lane group g of G takes slots g, g + G, ..); MODE 1: the slots of the first pass (blocks of GRP * PH
-// slots: the first GRP of every block); MODE 2: the others.  a18[w] = (x offset of the lane's row w) << 18.
+// MODE 0: every slot (lane group g of G takes slots g, g + G, ..); MODE 1: the slots of the first pass (every PH-th);
+// MODE 2: the others.  a18[w] = (x offset of the lane's row w) << 18.
 template <bool HI, int MODE>
-__device__ __forceinline__ void gather_rows2(const uint32_t* list, int nslots, int g, int G, const int (&a18)[RPL], int hi_clamp,
+__device__ __forceinline__ void gather_rows2(uint32_t list, int lstride, int nslots, int g, int G, const int (&a18)[RPL], int hi_clamp,
                                              uint32_t dw2, uint32_t tiles_base, uint32_t (&part)[RPL][6], int (&acc)[RPL][24],
                                              int& npart, int flush_iters) {
-  constexpr int BLK = GRP * PH;
   int nj = nslots;
   if (MODE != 0) {
-    const int nb = nslots / BLK, rem = nslots - nb * BLK;
-    const int n1 = nb * GRP + min(rem, GRP);
+    const int n1 = (nslots + PH - 1) / PH;                       // slots 0, PH, 2 PH, ..: the first pass
     nj = MODE == 1 ? n1 : nslots - n1;
   }
   for (int j = g; j < nj; j += G) {
     int sl = j;
-    if (MODE == 1) { const int b = j / GRP; sl = b * BLK + (j - b * GRP); }
-    if (MODE == 2) { const int b = j / (BLK - GRP); sl = b * BLK + GRP + (j - b * (BLK - GRP)); }
-    const uint2 pk2 = *reinterpret_cast<const uint2*>(&list[PPI * sl]);
+    if (MODE == 1) sl = j * PH;
+    if (MODE == 2) { const int b = j / (PH - 1); sl = b * PH + 1 + (j - b * (PH - 1)); }
+    const u32x2 pk2 = *(lds_cu2*)(size_t)(uint32_t)((int)list + lstride * sl);          // (a slot = PPI entries; lstride = +-4 * PPI bytes)
     const uint32_t pk[PPI] = {pk2.x, pk2.y};
     uint32_t d[PPI][RPL][4], rowoff[PPI][RPL];
 #pragma unroll
@@ -202,12 +202,107 @@ __device__ __forceinline__ void gather_rows2(const uint32_t* list, int nslots, i
   }
 }
 
+// Round 5: the same gather for ALIGNED PAIRS of x rows.  Rows 2j, 2j + 1 of a tile are 16 contiguous, 16-byte aligned bytes,
+// so a lane that owns the grid rows (X, X + 1), X even, gets both with one ds_read_b128 per tile column and pays the row
+// arithmetic (clamp, tile row, directory address, four directory loads, four tile addresses) once per TWO rows.  The loop is
+// bound by VALU issue at two wavefronts per SIMD (3.5 cycles per three-operand integer instruction and SIMD,
+// tools/ubench/valu_rate_ubench.hip) and by its dependent LDS round trips, not by the LDS array: 14.5 instead of 19.5
+// instructions per (point, row) (tools/ubench/gather_pairs_ubench.hip: 2.39 against 1.86 (point, row) per clock and CU, 2.57
+// with four points in flight per lane).
+// The entries carry the EVEN row at or above the point's first window row (px8e = px8 + (px8 & 1)) and the points are split
+// into FOUR classes: by that parity and by the half of the tile row the first cell falls into (the word the 24 cells start in
+// is then a compile-time register index).  One iteration takes one entry of EACH class -- four independent chains in flight per
+// lane, one loop per pass instead of one per class.  A lane's pair holds the window rows (2r, 2r + 1) of an even point (sums in
+// rows 0, 1 of its four) and (2r + 1, 2r + 2) of an odd one (rows 2, 3); window row 0 of an odd point is the upper row of the
+// pair in FRONT of its first one (a18 = -2 << 18): the four lanes the five groups of twelve leave over take it, with odd
+// entries in all four places of their iterations (rows 1 and 3 of their sums).
+// Place u's entry e sits at LDS byte address cls[u].x + 4 e (u even) or cls[u].x - 4 e (u odd: the upper-half classes grow
+// downwards), entry cls[u].y (= the class's count) is a null entry (a point far to the left: clamped into the guard band, adds 0).
+// MODE 0: every entry; MODE 1: the entries of the pruned search's first pass (first_pass_entry), which gather_rows2's MODE 2
+// complements on its two-entry slots.  A lane walks j0 = q0 + dq * t of that sequence while j0 < nj.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_cu4;
+typedef __attribute__((address_space(3))) const uint32_t lds_cu1;
+typedef volatile __attribute__((address_space(3))) unsigned long long lds_vu64;
+constexpr int NCL = 4;                         // classes = entries per lane and iteration
+// The pruned search's first pass takes every PH-th two-entry slot of a class (entries e with (e >> 1) % PH == 0): spread over the
+// whole scan (the lists are in the subsample's cell order, i.e. sorted in space), and the j-th of them is a shift away.
+__device__ __forceinline__ int first_pass_entry(int j) { return ((j >> 1) * (2 * PH)) | (j & 1); }
+__device__ __forceinline__ int first_pass_count(int n) { return 2 * (n / (2 * PH)) + min(n % (2 * PH), 2); }   // of the entries below n
+template <int MODE>
+__device__ __forceinline__ void gather_pairs4(const int2 (&cls)[NCL], int q0, int dj, int dq, int nj, int a18, int hi_clamp, uint32_t dw2,
+                                              uint32_t tiles_base, uint32_t (&part)[NCL][6], uint32_t (&acc16)[NCL][12], int flush_iters) {
+  static_assert(MODE == 0 || MODE == 1, "all entries, or the entries of the pruned search's first pass");
+  int npart = 0;
+  for (int j0 = q0; j0 < nj; j0 += dq) {
+    // places 0, 1 take the j0-th entry of their classes, places 2, 3 the (j0 + dj)-th; classes 1, 3 grow downwards
+    int ea = j0, eb = j0 + dj;
+    if (MODE == 1) { ea = first_pass_entry(ea); eb = first_pass_entry(eb); }
+    uint32_t pk[NCL];
+#pragma unroll
+    for (int u = 0; u < NCL; u++) {
+      const int e = min(u < 2 ? ea : eb, cls[u].y);
+      pk[u] = *(lds_cu1*)(size_t)(uint32_t)((u & 1) ? cls[u].x - 4 * e : cls[u].x + 4 * e);
+    }
+    uint32_t d[NCL][4], rowoff[NCL];
+#pragma unroll
+    for (int u = 0; u < NCL; u++) {
+      int t = (int)pk[u] + a18;                                    // (px8e + pair offset) << 18, the low 18 bits ride along
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(t), "s"(hi_clamp));         // x clamp into the guard band (an even row)
+      const uint32_t tx1 = (uint32_t)t >> 21;                      // tile row + 1
+      uint32_t r8;
+      asm("v_bfe_u32 %0, %1, 18, 3" : "=v"(r8) : "v"(t));          // row of the pair's first cell inside its tile: 0, 2, 4, 6
+      rowoff[u] = r8 * 8u + tiles_base;
+      const uint32_t da = __umul24(tx1, dw2) + (pk[u] & 0xffffu);
+      const lds_vu16* dp = (const lds_vu16*)(size_t)da;
+      d[u][0] = dp[0]; d[u][1] = dp[1]; d[u][2] = dp[2]; d[u][3] = dp[3];
+    }
+    uint32_t D[NCL][RPL][8];
+#pragma unroll
+    for (int u = 0; u < NCL; u++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const u32x4 v = *(lds_cu4*)(size_t)(d[u][t] * 64u + rowoff[u]);
+        D[u][0][2 * t] = v.x; D[u][0][2 * t + 1] = v.y;
+        D[u][1][2 * t] = v.z; D[u][1][2 * t + 1] = v.w;
+      }
+    // classes 0, 1 (even points) add into rows 0, 1, classes 2, 3 (odd points) into rows 2, 3; classes 1, 3 start in the upper half
+#pragma unroll
+    for (int u = 0; u < NCL; u++) {
+      const uint32_t sh = (pk[u] >> 16) & 3u;
+      const int hi = u & 1, w0 = u & 2;
+#pragma unroll
+      for (int w = 0; w < RPL; w++)
+#pragma unroll
+        for (int t = 0; t < 6; t++) part[w0 + w][t] += __builtin_amdgcn_alignbyte(D[u][w][t + 1 + hi], D[u][w][t + hi], sh);
+    }
+    if (++npart == flush_iters) {
+#pragma unroll
+      for (int w = 0; w < NCL; w++)
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+          acc16[w][2 * t] += part[w][t] & 0x00ff00ffu;                                     // cells 4t, 4t + 2
+          acc16[w][2 * t + 1] += (part[w][t] >> 8) & 0x00ff00ffu;                          // cells 4t + 1, 4t + 3
+          part[w][t] = 0;
+        }
+      npart = 0;
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < NCL; w++)
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      acc16[w][2 * t] += part[w][t] & 0x00ff00ffu;
+      acc16[w][2 * t + 1] += (part[w][t] >> 8) & 0x00ff00ffu;
+    }
+}
+
 // One grid byte through a fast-path list entry: the cell of the entry's point at x offset a, y offset b of the window
 // (the same clamps and lookups as gather_rows2, one cell instead of 2 x 24).
 typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
 typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
 __device__ __forceinline__ int entry_cell(uint32_t e, bool hi, int a, int b, int hi_clamp, uint32_t dw2, uint32_t tiles_base) {
-  int t = (int)e + (a << 18);
+  int t = (int)e + a * (1 << 18);
   asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(t), "s"(hi_clamp));
   const uint32_t tx1 = (uint32_t)t >> 21, r8 = ((uint32_t)t >> 18) & 7u;
   const uint32_t yy = ((e >> 16) & 3u) + (hi ? 4u : 0u) + (uint32_t)b;
@@ -258,6 +353,8 @@ __device__ __forceinline__ void stamp_word(uint32_t* wp, uint32_t kv) {
 
 // resetGrid + addAndConvolvePoints for n packed reference cells: tiles claimed and numbered by the points that reach them,
 // then the distance-transform rasteriser or compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
+// LEAN: the distance transform only; a grid that needs anything else leaves S.misc[12] = 2 (the pair goes to the general kernel).
+template <bool LEAN>
 __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
                            int* err) {
   const int tid = threadIdx.x;
@@ -332,7 +429,7 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   if (tid == 0) S.misc[12] = fast ? 1 : 0;
   if (ntile + 2 > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
   const bool edt = P.edt && ntile + 2 <= NT_LDS && ntile > 0;
-  if (!edt) {                                                      // (the distance transform writes every cell of every tile)
+  if (!LEAN && !edt) {                                                      // (the distance transform writes every cell of every tile)
     for (int q = 32 + tid; q < min(ntile + 2, NT_LDS) * 16; q += NTHR) S.tiles[q] = fill4;
     for (int q = tid; q < max(0, ntile + 2 - NT_LDS) * 16; q += NTHR) gtiles[q] = fill4;
   }
@@ -358,7 +455,12 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
       const uint32_t packed = rcell[i];
       if (packed == 0x80008000u) continue;
       const int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
-      if ((unsigned)rx >= (unsigned)P.nx || (unsigned)ry >= (unsigned)P.ny) { noff++; continue; }
+      if ((unsigned)rx >= (unsigned)P.nx || (unsigned)ry >= (unsigned)P.ny) {
+        // off the grid: its stamp matters only if it reaches into the grid (a laser that sees beyond the grid -- 30 m of range over a
+        // grid of +-15 m -- puts whole walls out there: they must not cost every such pair the stamping pass)
+        noff += (rx >= -ctr && rx <= P.nx - 1 + ctr && ry >= -ctr && ry <= P.ny - 1 + ctr) ? 1 : 0;
+        continue;
+      }
       const int d = S.dir[((rx >> 3) + 1) * DW + (ry >> 3) + 3];
       const int bit = (rx & 7) * 8 + (ry & 7);
       atomicOr(&S.tiles[d * 16 + (bit >> 5)], 1u << (bit & 31));
@@ -473,7 +575,12 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
       reinterpret_cast<uint4*>(S.tiles)[w] = reinterpret_cast<const uint4*>(gtiles)[w];
     __syncthreads();
     MPHASE(21);
-    if (S.misc[15] == 0) return;                                   // (no reference cell outside the grid: done)
+    if (!LEAN && S.misc[15] == 0) return;                                   // (no reference cell's stamp reaches in from outside the grid: done)
+  }
+  if (LEAN) {                                                      // the lean instances leave the stamping to the general kernel
+    if (tid == 0 && (!edt || S.misc[15] != 0)) S.misc[12] = 2;
+    __syncthreads();
+    return;
   }
   // stamp: work item = (reference point, kernel row); byte-min through compare-and-swap on 32-bit words.
   // Neighbouring beams stamp overlapping cells; spread concurrently processed items over far-apart points
@@ -683,6 +790,22 @@ KT* keys = reinterpret_cast<KT*>(S.tiles);
 // predecessors, src/slam/graph_slam.cpp:230-244), ranges_ref [pair][scan][beam]; ref_xform [pair][scan][4] =
 // (cos, sin, tx, ty) of (origin^-1 * v_scan) * laserPose, computed on the host with libm exactly as
 // transformPointsFromVSet / applyTransfToScan do (scan_matcher.cpp:78-110); null = every scan at the laser pose.
+// VARIANT 0: the general kernel (every path; pruned or exhaustive by P.prune).  VARIANT 1 / 2: the LEAN instances for the shape
+// the batched close matcher is used in (one reference scan, the shipped kernel: distance-transform rasteriser, 32-bit sort keys,
+// the 24 x 24 window, one workgroup per pair): exhaustive / pruned search with everything else compiled out -- half the code, a
+// third fewer spilled registers, 5-12 % faster.  A pair a lean instance cannot take (tiles beyond the LDS pool, a reference
+// cell whose stamp reaches in from outside the grid, more points than a list holds, ..) is appended to redo_list; the host then
+// runs the general kernel on that list (redo_list != null: items are redo_list[0 .. err[3])).
+#ifndef CGMR_PAIRS_EXHAUSTIVE
+#define CGMR_PAIRS_EXHAUSTIVE 1
+#endif
+#ifndef CGMR_PAIRS_PRUNED
+#define CGMR_PAIRS_PRUNED 0
+#endif
+#ifndef CGMR_PAIRS_GENERAL
+#define CGMR_PAIRS_GENERAL 0
+#endif
+template <int VARIANT>
 __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P, const float* __restrict__ ranges_ref,
                                                            const double* __restrict__ ref_xform,
                                                            const float* __restrict__ ranges_qry,
@@ -693,7 +816,12 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
                                                            unsigned char* __restrict__ scratch,
                                                            double* __restrict__ out_xyt, double* __restrict__ out_score,
                                                            uint8_t* __restrict__ out_found, int* __restrict__ out_nres,
-                                                           int* __restrict__ err, unsigned long long* gbins, int* arrive) {
+                                                           int* __restrict__ err, unsigned long long* gbins, int* arrive,
+                                                           int* __restrict__ redo_list) {
+  constexpr bool LEAN = VARIANT != 0;
+  // aligned row pairs (gather_pairs4, four entry classes) or single rows (gather_rows2, two classes) in the first pass
+  constexpr bool PAIRS = VARIANT == 1 ? (CGMR_PAIRS_EXHAUSTIVE != 0) : (VARIANT == 2 ? (CGMR_PAIRS_PRUNED != 0) : (CGMR_PAIRS_GENERAL != 0));
+  constexpr int NCLS = PAIRS ? 4 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
@@ -721,18 +849,19 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
   // batch of angles; the per-bin minima meet in a global table (atomicMin on the same 64-bit keys: score bits << 32 |
   // visit order, the visit order counted over ALL angles, so "first seen wins" holds across workgroups) and the
   // workgroup that arrives last produces the result.
-  const int n_items = P.n_pairs * P.split;
+  const bool from_list = !LEAN && redo_list != nullptr;           // (the general kernel behind a lean one: split == 1)
+  const int n_items = from_list ? err[3] : P.n_pairs * P.split;
   for (int item = blockIdx.x; item < n_items;) {
-    const int pair = item / P.split, part = item - pair * P.split;
+    const int pair = from_list ? redo_list[item] : item / P.split, part = from_list ? 0 : item - (item / P.split) * P.split;
     __syncthreads();
     MPHASE(0);
 #ifdef CGMR_PHASE_TIMING
-    if (blockIdx.x == 0 && tid == 0) { for (int q = 10; q < 16; q++) g_mphase[q] = 0; g_mphase[22] = g_mphase[23] = g_mphase[24] = 0; }
+    if (blockIdx.x == 0 && tid == 0) { for (int q = 10; q < 16; q++) g_mphase[q] = 0; for (int q = 22; q < 32; q++) g_mphase[q] = 0; }
 #endif
     // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
     // sort keys: (cell x, cell y, beam) -- 32 bits when the cells fit 10 bits each (any laser up to 51 m at the reference's 0.1 m
     // subsample cells) and the beam index 11, else 64
-    const int nq = P.sort32 ? subsample_query<uint32_t>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts)
+    const int nq = (LEAN || P.sort32) ? subsample_query<uint32_t>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts)
                             : subsample_query<unsigned long long>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts);
     __syncthreads();
     MPHASE(2);
@@ -757,7 +886,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     uint32_t* const cellmap = P.cellmap_off ? reinterpret_cast<uint32_t*>(my + P.cellmap_off) : nullptr;
     const uint32_t* gcells = nullptr;
     int gn = 0;
-    if (NS == 1) {
+    if (LEAN || NS == 1) {
       // valid beams whose cell differs from the previous beam's, compacted behind the raw list (the rasteriser's work
       // items are (point, kernel row): a quarter of the raw list's items would be skipped one by one)
       uint32_t* const cl1 = &S.plist[2][0];
@@ -823,9 +952,10 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       __syncthreads();
     }
     // one call for all three shapes of the cell list (LDS or the HBM scratch: the rasteriser reads it through a generic pointer)
-    build_grid(S, P, gcells, gn, gtiles, /*allow_fast=*/true, err);
-    const bool fast = S.misc[12] != 0;
-    if (!fast && tid == 0) atomicAdd(err + 2, 1);          // pairs whose tiles did not fit LDS (generic search path)
+    build_grid<LEAN>(S, P, gcells, gn, gtiles, /*allow_fast=*/true, err);
+    const bool fast = S.misc[12] == 1;
+    bool redo = LEAN && !fast;                                // a lean instance: this pair is the general kernel's
+    if (!LEAN && !fast && tid == 0) atomicAdd(err + 2, 1);    // pairs whose tiles did not fit LDS (generic search path)
     MPHASE(5);
     // ---------------- search window, angle table, bins -----------------------------------------------------
     if (tid == 0) {
@@ -862,20 +992,40 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       S.theta_cs[tid][0] = cs; S.theta_cs[tid][1] = sn;
     }
     if (tid == 0) S.best_bits = 0x7f800000u;                   // best accepted score so far (float bits): +inf
+    // result bins of the window's x offsets, y offsets and angles (DiscreteTriplet, chargrid.h:68-85): the same expressions the
+    // candidates used to evaluate one by one -- two double divisions per accepted candidate
+    if (nbins > 0) {
+      const int q = tid - 128;
+      if (q >= 0 && q < 32 && q < ni) {
+        const float wx = P.ll_x + (P.res * (float)(lo_x + q * P.x_steps));
+        S.binx[q] = (uint8_t)(((int)((double)wx / P.dx) - bx0) * nby);
+      }
+      if (q >= 32 && q < 64 && q - 32 < nj) {
+        const float wyy = P.ll_y + (P.res * (float)(lo_y + (q - 32) * P.y_steps));
+        S.biny[q - 32] = (uint8_t)((int)((double)wyy / P.dy) - by0);
+      }
+      if (q >= 64 && q - 64 < nth) S.bint[q - 64] = (uint8_t)((int)(S.theta[q - 64] / P.dth) - bt0);
+    }
     __syncthreads();
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
     // a scan with more subsampled points than one list holds: half the wavefronts search, with two lists each
-    const bool wide = nq > LISTCAP - 2 * PPI * GRP;
+    const bool wide = nq > LISTCAP - 12;                           // (the lists' padding: 2 * PT entries, or two per class of the fast path and an even split)
     const int nsearch = wide ? NTH / 2 : NTH;
     uint32_t* const pl = &S.plist[0][0] + (wide ? 2 * wave : wave) * LISTCAP;
-    const int lcap = wide ? 2 * LISTCAP : LISTCAP;
     // list entries of the fast path carry LDS addresses of the directory in 16 bits (gather_class)
     const uint32_t lds_dir = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.dir);
     const uint32_t lds_tiles = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.tiles);
-    const bool prune = P.prune != 0;
-    const bool v2 = fast && nj <= 24 && ni <= 12 * RPL && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u && K2 * PPI <= 255 &&
-                    K2 * (nq + 2 * PPI * GRP) < 65536;          // (16-bit totals)
+    // (the wavefront's list as an LDS byte address: from the array, not from pl -- a generic-to-LDS cast of pl made the lean exhaustive
+    // instance trip an "illegal instruction" in the compiler's null check)
+    const uint32_t pl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.plist) +
+                            4u * (uint32_t)LISTCAP * (uint32_t)(wide ? 2 * wave : wave);
+    const uint32_t lds_bins = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.bins);
+    const bool prune = VARIANT == 2 ? true : (VARIANT == 1 ? false : P.prune != 0);
+    const bool v2 = fast && !wide && nj <= 24 && ni <= 12 * RPL && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u && K2 * PPI <= 255 &&
+                    K2 * (nq + 2 * PPI * GRP) < 65536;          // (16-bit totals; a scan that needs two lists per wavefront takes the any-window path)
+    if (LEAN && !v2) redo = true;
+    if (LEAN && tid == 0) S.misc[13] = 0;                         // (set by an angle whose lists do not fit)
     MPHASE(6);
     // ---------------- the search: one wavefront per angle, one lane per block of offsets -------------------
     // batches of nsearch angles, the ones around the guess first (the visit order inside the keys stays the reference's): the
@@ -884,7 +1034,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     // its wavefronts one at a time through a counter: an angle with rows left for the second pass takes several times as
     // long as a dead one, and with a fixed angle-to-wavefront map the others waited for the unlucky wavefront at the end.
     const int nbat = (nth + nsearch - 1) / nsearch;
-    const int my_batches = part < nbat ? (nbat - 1 - part) / P.split + 1 : 0;
+    const int my_batches = redo ? 0 : (part < nbat ? (nbat - 1 - part) / P.split + 1 : 0);
     if (tid == 0) S.misc[14] = 0;                                 // (the compaction counter of the grid phase: free now)
     __syncthreads();
     for (;;) {
@@ -895,13 +1045,106 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       const int bi = part + P.split * (sq / nsearch);
       const int tb = nsearch * ((bi & 1) ? (nbat - 1) / 2 + (bi + 1) / 2 : (nbat - 1) / 2 - bi / 2);
       const int ti = min(tb + sq % nsearch, nth);
-      int k = 0, k0p = 0, k1p = 0;
+      int k = 0;
+      int2 cls[NCL] = {};                       // fast path: the class lists: LDS byte address of entry 0, count (classes 1, 3 grow downwards)
+      bool fv2 = v2;                            // this angle takes the fast path
       MSTAT_T0();
-      if (ti < nth) {
+      if (ti < nth && v2) {
+        // Fast path lists: everything that depends on the point's y alone (all lanes search the same 24 y offsets) is resolved here, and
+        // the entries are split into classes: by the half of the 8-cell tile row the first cell falls into (the word the 24 cells
+        // start in is then a compile-time register index) and -- for the aligned row pairs of gather_pairs4 -- by the parity of the
+        // first window row.  The lower tile-row class grows from the front of its part of the list, the upper one from the back; with
+        // four classes the even points have the part below `half`, the odd ones the part above.
+        // The place of an entry inside its class comes from an LDS counter (ds_add_rtn on one of four words: the wavefront's idle
+        // totals), not from ballots and bit counts -- the order inside a class does not matter (integer sums) --, and the entry is
+        // written one chunk later, when the counter's answer has long arrived.
+        const double c = S.theta_cs[ti][0], s = S.theta_cs[ti][1];
+        uint32_t* const cnt = S.totals[wave];
+        int half = PAIRS ? LISTCAP / 2 : LISTCAP;     // (two classes: one part)
+        int kc0 = 0, kc1 = 0, kc2 = 0, kc3 = 0;
+        const double2* const qp2 = reinterpret_cast<const double2*>(qpts);
+        for (int attempt = 0; attempt < (PAIRS ? 2 : 1); attempt++) {
+          if (lane < 4) cnt[lane] = 0u;
+          uint32_t prev = 0x7fff7fffu;       // (-10000,-10000) can never match: use an impossible packed value
+          bool have_prev = false;
+          double2 nxt = lane < nq ? qp2[lane] : make_double2(0., 0.);
+          uint32_t pend_entry = 0u, pend_pos = 0u;
+          int pend_base = -1;                  // < 0: nothing to write
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (int base = 0; base < nq; base += 64) {
+            const int q = base + lane;
+            uint32_t packed = 0;
+            const bool valid = q < nq;
+            const double2 cur = nxt;
+            if (q + 64 < nq) nxt = qp2[q + 64];
+            if (valid) {
+              double x = cur.x, y = cur.y;
+              double px = c * x - s * y, py = s * x + c * y;
+              int ix = (int)(px * (double)P.inv_res), iy = (int)(py * (double)P.inv_res);
+              packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
+            }
+            // the left neighbour's cell by a DPP wave shift and the chunk's last cell by v_readlane (wave-uniform lane): the
+            // generic shuffles go through the LDS pipe, two dependent round trips per chunk of 64 points
+            uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)prev, (int)packed, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            if (lane == 0) left = prev;
+            const bool keep = valid && (!(lane == 0 && !have_prev) ? (packed != left) : true);
+            const int cy0 = clamp_med3<-24>((int)(int16_t)(packed >> 16) + lo_y, P.ny);
+            const int o = cy0 & 7;
+            const int px8 = min(max((int)(int16_t)(packed & 0xffff) + lo_x + 8, -8000), 8000);
+            const int odd = PAIRS ? (px8 & 1) : 0, up = (o >> 2) & 1;
+            const uint32_t entry = ((uint32_t)(px8 + odd) << 18) | ((uint32_t)(o & 3) << 16) | (lds_dir + 2u * (uint32_t)((cy0 >> 3) + 3));
+            // last chunk's entries go out (the classes' first places: 0, half - 1, half, LISTCAP - 1; those of the downward ones are odd)
+            if (pend_base >= 0) {
+              const int pos = (int)pend_pos, sgn = pend_base & 1;
+              pl[min(max(sgn ? pend_base - pos : pend_base + pos, 0), LISTCAP - 1)] = pend_entry;
+            }
+            pend_base = -1;
+            if (keep) {
+              pend_pos = atomicAdd(&cnt[2 * odd + up], 1u);
+              pend_base = up ? (odd || !PAIRS ? LISTCAP - 1 : half - 1) : (odd ? half : 0);
+              pend_entry = entry;
+            }
+            const int lastv = min(63, nq - base - 1);
+            prev = (uint32_t)__builtin_amdgcn_readlane((int)packed, lastv);
+            have_prev = true;
+          }
+          if (pend_base >= 0) {
+            const int pos = (int)pend_pos, sgn = pend_base & 1;
+            pl[min(max(sgn ? pend_base - pos : pend_base + pos, 0), LISTCAP - 1)] = pend_entry;
+          }
+          static_assert((LISTCAP & 3) == 0, "class bases 0 and half even, half - 1 and LISTCAP - 1 odd");
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          kc0 = __builtin_amdgcn_readfirstlane((int)cnt[0]); kc1 = __builtin_amdgcn_readfirstlane((int)cnt[1]);
+          kc2 = __builtin_amdgcn_readfirstlane((int)cnt[2]); kc3 = __builtin_amdgcn_readfirstlane((int)cnt[3]);
+          // behind every class's last entry: two null entries (a point far to the left: clamped into the guard band, adds 0) -- the
+          // place gather_pairs4 reads beyond the end, and the other half of the second pass's last two-entry slot
+          fv2 = PAIRS ? (kc0 + kc1 + 4 <= half && kc2 + kc3 + 4 <= LISTCAP - half) : (kc0 + kc1 + 4 <= LISTCAP);
+          if (fv2 || !PAIRS) break;
+          // one parity has more points than its half: once more with the split where these counts put it (the counts do not
+          // depend on it; nq + 8 <= LISTCAP)
+          half = (kc0 + kc1 + 4 + 1) & ~1;
+        }
+        if (fv2 && lane < 2 * NCLS) {
+          const uint32_t null_entry = ((uint32_t)(-8000) << 18) | (lds_dir + 6u);
+          const int cl = lane & (NCLS - 1), ex = lane / NCLS;
+          const int at = PAIRS ? (cl == 0 ? kc0 + ex : (cl == 1 ? half - 1 - kc1 - ex : (cl == 2 ? half + kc2 + ex : LISTCAP - 1 - kc3 - ex)))
+                               : (cl == 0 ? kc0 + ex : LISTCAP - 1 - kc1 - ex);
+          pl[at] = null_entry;
+        }
+        cls[0] = make_int2((int)pl_lds, kc0);
+        cls[1] = make_int2((int)pl_lds + 4 * ((PAIRS ? half : LISTCAP) - 1), kc1);
+        cls[2] = make_int2((int)pl_lds + 4 * half, kc2);
+        cls[3] = make_int2((int)pl_lds + 4 * (LISTCAP - 1), kc3);
+        k = kc0 + kc1 + kc2 + kc3;
+        if (LEAN && !fv2) { if (lane == 0) S.misc[13] = 1; }           // (cannot happen with two attempts; the pair would go to the general kernel)
+      }
+      if (!LEAN && ti < nth && !fv2) {
+        k = 0;
         const double c = S.theta_cs[ti][0], s = S.theta_cs[ti][1];
         uint32_t prev = 0x7fff7fffu;       // (-10000,-10000) can never match: use an impossible packed value
         bool have_prev = false;
-        int k0 = 0, k1 = 0;
         // (the points come from the workgroup's HBM scratch: the next 64 are fetched while these are turned and packed)
         const double2* const qp2 = reinterpret_cast<const double2*>(qpts);
         double2 nxt = lane < nq ? qp2[lane] : make_double2(0., 0.);
@@ -923,84 +1166,105 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
           if (lane == 0) left = prev;
           bool keep = valid && (!(lane == 0 && !have_prev) ? (packed != left) : true);
           const unsigned long long below = (1ULL << lane) - 1ULL;
-          if (v2) {
-            // resolve what depends on the point's y alone (all lanes search the same 24 y offsets) and split the list by
-            // the half of the 8-cell tile row the first cell falls into: class 0 grows from the front, class 1 from the back
-            const int cy0 = clamp_med3<-24>((int)(int16_t)(packed >> 16) + lo_y, P.ny);
-            const int o = cy0 & 7;
-            const int px8 = min(max((int)(int16_t)(packed & 0xffff) + lo_x + 8, -8000), 8000);
-            const uint32_t entry = ((uint32_t)px8 << 18) | ((uint32_t)(o & 3) << 16) | (lds_dir + 2u * (uint32_t)((cy0 >> 3) + 3));
-            const bool c1 = keep && o >= 4, c0 = keep && o < 4;
-            const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
-            if (c0) pl[k0 + __popcll(m0 & below)] = entry;
-            if (c1) pl[lcap - 1 - (k1 + __popcll(m1 & below))] = entry;
-            k0 += __popcll(m0);
-            k1 += __popcll(m1);
-          } else {
-            unsigned long long mask = __ballot(keep);
-            int pos = k + __popcll(mask & below);
-            if (keep) pl[pos] = packed;
-            k += __popcll(mask);
-          }
+          unsigned long long mask = __ballot(keep);
+          int pos = k + __popcll(mask & below);
+          if (keep) pl[pos] = packed;
+          k += __popcll(mask);
           int lastv = min(63, nq - base - 1);
           prev = (uint32_t)__builtin_amdgcn_readlane((int)packed, lastv);
           have_prev = true;
         }
-        if (v2) {
-          // pad both classes to whole iterations (10 entries) with a point far to the left: clamped into the guard band
-          const uint32_t null_entry = ((uint32_t)(-8000) << 18) | (lds_dir + 6u);
-          k0p = (k0 + PPI * GRP - 1) / (PPI * GRP) * (PPI * GRP);
-          k1p = (k1 + PPI * GRP - 1) / (PPI * GRP) * (PPI * GRP);
-          if (lane < k0p - k0) pl[k0 + lane] = null_entry;
-          if (lane < k1p - k1) pl[lcap - 1 - (k1 + lane)] = null_entry;
-          k = k0 + k1;
-        } else if (lane < 2 * PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
+        if (lane < 2 * PT) pl[k + lane] = 0x80008000u;   // padding: lands outside the grid, adds 0
       }
       __builtin_amdgcn_wave_barrier();
       MSTAT(24);
-      if (ti < nth && v2) {
-        // ---- fast path, window of at most 24 x 24 offsets: lane = (point subset g of 5, x rows r and r + 12), see gather_rows2
+      if (ti < nth && fv2) {
+        // ---- fast path, window of at most 24 x 24 offsets.  First pass (all the points, or the pruned search's quarter of them):
+        // aligned row pairs (gather_pairs4) or single rows (gather_rows2), see the kernel's PAIRS.
         const int grp = lane / 12, r = lane - 12 * grp;
-        const bool act = lane < 12 * GRP;
-        uint32_t part[RPL][6];
-        int acc[RPL][24];
-#pragma unroll
-        for (int w = 0; w < RPL; w++) {
-#pragma unroll
-          for (int c = 0; c < 6; c++) part[w][c] = 0;
-#pragma unroll
-          for (int c = 0; c < 24; c++) acc[w][c] = 0;
-        }
-        int npart = 0;
-        const int flush_iters = max(1, (255 / K2) / PPI);    // packed-byte partial sums cannot overflow before this
-        const int hi_clamp = ((P.nx + 15) << 18) | 0x3ffff;
+        const int flush_iters = max(1, (255 / K2) / PPI);    // packed-byte partial sums cannot overflow before this (two adds per row and iteration)
+        const int hi_clamp = ((P.nx + 15) << 18) | 0x3ffff;  // single rows
         const uint32_t dw2 = 2u * (uint32_t)DW;
-        const uint32_t* const pl1 = pl + lcap - k1p;           // class 1 (upper half of the tile row), padded like class 0
         uint32_t* totals = S.totals[wave];
-        auto total_of = [&](int a, int b) -> int { return (int)((totals[a * 12 + (b >> 1)] >> (16 * (b & 1))) & 0xffffu); };
+        // totals[a * 12 + 2 t + h]: the sums of the offsets (a, 4 t + h) and (a, 4 t + h + 2) in its two halves
+        auto total_of = [&](int a, int b) -> int { return (int)((totals[a * 12 + 2 * (b >> 2) + (b & 1)] >> (16 * ((b >> 1) & 1))) & 0xffffu); };
         for (int q = lane; q < 24 * 12; q += 64) totals[q] = 0;
-        const int a18[RPL] = {r << 18, (r + 12) << 18};
-        if (prune) {
-          gather_rows2<false, 1>(pl, act ? k0p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
-          gather_rows2<true, 1>(pl1, act ? k1p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
-        } else {
-          gather_rows2<false, 0>(pl, act ? k0p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
-          gather_rows2<true, 0>(pl1, act ? k1p / PPI : 0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
-        }
-#pragma unroll
-        for (int w = 0; w < RPL; w++)
-#pragma unroll
-          for (int t = 0; t < 6; t++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[w][4 * t + c] += (part[w][t] >> (8 * c)) & 0xff;
-        // the subsets' sums meet in LDS: the totals of the 24 x 24 offsets (row-major, 24 per row)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (act) {
+        uint32_t part[RPL][6];
+        int acc[RPL][24];
+        int npart = 0;
+        if (PAIRS) {
+          // Lanes 0..59 = (point subset g of 5, pair r of 12): one entry of each of the four classes per iteration; lanes 60..63: window
+          // row 0 of the odd points, two odd entries of either tile-row half per iteration (eight of each per round of the four
+          // lanes; the five subsets use up five).
+          const bool spare = lane >= 12 * GRP;
+          const int sp = lane - 12 * GRP;
+          uint32_t part4[NCL][6], acc16[NCL][12];
+#pragma unroll
+          for (int w = 0; w < NCL; w++) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) part4[w][c] = 0;
+#pragma unroll
+            for (int c = 0; c < 12; c++) acc16[w][c] = 0;
+          }
+          const int hi_clamp2 = ((P.nx + 14) << 18) | 0x3ffff; // aligned pairs: an even row of the guard band
+          const int a18p = spare ? -(2 << 18) : ((2 * r) << 18);
+          const int2 lc[NCL] = {spare ? cls[2] : cls[0], spare ? cls[3] : cls[1], cls[2], cls[3]};
+          const int q0 = spare ? 2 * sp : grp, dj = spare ? 1 : 0, dq = spare ? 8 : GRP;
+          // entries of the longest list this lane walks; in the pruned search: of them, those of the first pass
+          const int nmax = spare ? max(cls[2].y, cls[3].y) : max(max(cls[0].y, cls[1].y), max(cls[2].y, cls[3].y));
+          if (prune) gather_pairs4<1>(lc, q0, dj, dq, first_pass_count(nmax), a18p, hi_clamp2, dw2, lds_tiles, part4, acc16, flush_iters);
+          else gather_pairs4<0>(lc, q0, dj, dq, nmax, a18p, hi_clamp2, dw2, lds_tiles, part4, acc16, flush_iters);
+          // The subsets' sums meet in LDS: the totals of the 24 x 24 offsets.  Window rows of a lane's four rows of sums: an even
+          // point's pair (2r, 2r + 1), an odd point's (2r + 1, 2r + 2: row 24 does not exist) -- rows 1 and 2 are the same window
+          // row --; the upper rows (1, 3) of a spare lane are window row 0: three rows go out (the LDS atomics of a pass are a
+          // quarter of its time; ds_add_u64 on word pairs -- the 16-bit sums never carry into their neighbours -- was slower than
+          // two ds_add_u32: 850k against 918k pairs/s)
+          const int trow[3] = {spare ? -1 : 2 * r, spare ? 0 : 2 * r + 1, spare || r == 11 ? -1 : 2 * r + 2};
+#pragma unroll
+          for (int c = 0; c < 12; c++) acc16[1][c] += spare ? acc16[3][c] : acc16[2][c];
+#pragma unroll
+          for (int w = 0; w < 3; w++)
+            if (trow[w] >= 0) {
+              const int ws = w == 2 ? 3 : w;
+#pragma unroll
+              for (int c = 0; c < 12; c++) atomicAdd(&totals[trow[w] * 12 + c], acc16[ws][c]);
+            }
+        } else {
+          // lane = (point subset g of 5, x rows r and r + 12): 12 lanes cover the 24 rows for one point, 60 of the 64 lanes work
+          const bool act = lane < 12 * GRP;
+#pragma unroll
+          for (int w = 0; w < RPL; w++) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) part[w][c] = 0;
+#pragma unroll
+            for (int c = 0; c < 24; c++) acc[w][c] = 0;
+          }
+          const int a18[RPL] = {r << 18, (r + 12) << 18};
+          const int n0 = act ? (cls[0].y + 1) / 2 : 0, n1 = act ? (cls[1].y + 1) / 2 : 0;      // two-entry slots
+          if (prune) {
+            gather_rows2<false, 1>((uint32_t)cls[0].x, 8, n0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+            gather_rows2<true, 1>((uint32_t)cls[1].x - 4u, -8, n1, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+          } else {
+            gather_rows2<false, 0>((uint32_t)cls[0].x, 8, n0, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+            gather_rows2<true, 0>((uint32_t)cls[1].x - 4u, -8, n1, grp, GRP, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+          }
 #pragma unroll
           for (int w = 0; w < RPL; w++)
 #pragma unroll
-            for (int c = 0; c < 12; c++) atomicAdd(&totals[(r + 12 * w) * 12 + c], (uint32_t)acc[w][2 * c] | ((uint32_t)acc[w][2 * c + 1] << 16));
+            for (int t = 0; t < 6; t++)
+#pragma unroll
+              for (int c = 0; c < 4; c++) acc[w][4 * t + c] += (part[w][t] >> (8 * c)) & 0xff;
+          if (act) {
+#pragma unroll
+            for (int w = 0; w < RPL; w++)
+#pragma unroll
+              for (int c = 0; c < 12; c++) {
+                const int bq = 4 * (c >> 1) + (c & 1);
+                atomicAdd(&totals[(r + 12 * w) * 12 + c], (uint32_t)acc[w][bq] | ((uint32_t)acc[w][bq + 2] << 16));
+              }
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1022,16 +1286,17 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
             if (aa < ni) {
 #pragma unroll
               for (int c = 0; c < 6; c++) {
-                const uint32_t wv = totals[aa * 12 + (b0 >> 1) + c];
-                const int bb = b0 + 2 * c;
+                const uint32_t wv = totals[aa * 12 + (b0 >> 1) + c];                   // offsets bb and bb + 2
+                const int bb = b0 + 4 * (c >> 1) + (c & 1);
                 if (bb < nj) mykey = min(mykey, ((wv & 0xffffu) << 10) | (uint32_t)(aa * nj + bb));
-                if (bb + 1 < nj) mykey = min(mykey, ((wv >> 16) << 10) | (uint32_t)(aa * nj + bb + 1));
+                if (bb + 2 < nj) mykey = min(mykey, ((wv >> 16) << 10) | (uint32_t)(aa * nj + bb + 2));
               }
             }
           }
           uint32_t bestc = mykey;
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) bestc = min(bestc, (uint32_t)__shfl_xor((int)bestc, o, 64));
+          MSTAT(25);
           // smallest total that scores worse than the best accepted score so far (the score is monotone in the total): the
           // lanes try the 64 totals around best * k * kscale; with no accepted score yet, or the estimate off by more than
           // that, nothing is dropped at this angle
@@ -1046,12 +1311,16 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
             return (worse != 0 && (worse & 1ULL) == 0) ? max(0, guess - 31) + (__ffsll((long long)worse) - 1) : 0x7fffffff;
           };
           int tdead = first_dead_total();
+          MSTAT(26);
           if (bestc != 0xffffffffu && (int)(bestc >> 10) < tdead) {
             // (b) the most promising candidate of this angle is finished on its own: the best score is tight before the rows are judged
             const int q = (int)(bestc & 1023u), aa = q / nj, bb = q - aa * nj;
             int sum = 0;
-            for (int e = lane; e < k0p; e += 64) sum += entry_cell(pl[e], false, aa, bb, hi_clamp, dw2, lds_tiles);
-            for (int e = lane; e < k1p; e += 64) sum += entry_cell(pl1[e], true, aa, bb, hi_clamp, dw2, lds_tiles);
+            // (an odd point's entry carries the row behind its first window row)
+#pragma unroll
+            for (int u = 0; u < NCLS; u++)
+              for (int e = lane; e < cls[u].y; e += 64)
+                sum += entry_cell(*(lds_cu1*)(size_t)(uint32_t)((u & 1) ? cls[u].x - 4 * e : cls[u].x + 4 * e), (u & 1) != 0, aa - (u >> 1), bb, hi_clamp, dw2, lds_tiles);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
             float ds = (float)sum * ikscale;
@@ -1061,6 +1330,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
             __builtin_amdgcn_wave_barrier();
             tdead = first_dead_total();
           }
+          MSTAT(27);
           const unsigned long long am = __ballot(mykey != 0xffffffffu && (int)(mykey >> 10) < tdead);
           rowmask = 0;
           for (int aa = 0; aa < 24; aa++) rowmask |= ((am >> (2 * aa)) & 3ULL) ? (1u << aa) : 0u;
@@ -1083,6 +1353,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
             }
             const bool two = rows2[1] >= 0;
             const int b18[RPL] = {rows2[0] << 18, (two ? rows2[1] : rows2[0]) << 18};
+            const int b18o[RPL] = {b18[0] - (1 << 18), b18[1] - (1 << 18)};      // odd points: the entry is one row ahead
 #pragma unroll
             for (int w = 0; w < RPL; w++) {
 #pragma unroll
@@ -1091,8 +1362,13 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
               for (int c = 0; c < 24; c++) acc[w][c] = 0;
             }
             npart = 0;
-            gather_rows2<false, 2>(pl, act2 ? k0p / PPI : 0, g2, G2, b18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
-            gather_rows2<true, 2>(pl1, act2 ? k1p / PPI : 0, g2, G2, b18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+            // (two-entry slots: slot s of a class that grows downwards holds the entries 2s + 1, 2s -- at the lower address first)
+            gather_rows2<false, 2>((uint32_t)cls[0].x, 8, act2 ? (cls[0].y + 1) / 2 : 0, g2, G2, b18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+            gather_rows2<true, 2>((uint32_t)cls[1].x - 4u, -8, act2 ? (cls[1].y + 1) / 2 : 0, g2, G2, b18, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+            if (PAIRS) {
+              gather_rows2<false, 2>((uint32_t)cls[2].x, 8, act2 ? (cls[2].y + 1) / 2 : 0, g2, G2, b18o, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+              gather_rows2<true, 2>((uint32_t)cls[3].x - 4u, -8, act2 ? (cls[3].y + 1) / 2 : 0, g2, G2, b18o, hi_clamp, dw2, lds_tiles, part, acc, npart, flush_iters);
+            }
 #pragma unroll
             for (int w = 0; w < RPL; w++)
 #pragma unroll
@@ -1101,10 +1377,16 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
                 for (int c = 0; c < 4; c++) acc[w][4 * t + c] += (part[w][t] >> (8 * c)) & 0xff;
             if (act2) {
 #pragma unroll
-              for (int c = 0; c < 12; c++) atomicAdd(&totals[rows2[0] * 12 + c], (uint32_t)acc[0][2 * c] | ((uint32_t)acc[0][2 * c + 1] << 16));
+              for (int c = 0; c < 12; c++) {
+                const int b = 4 * (c >> 1) + (c & 1);
+                atomicAdd(&totals[rows2[0] * 12 + c], (uint32_t)acc[0][b] | ((uint32_t)acc[0][b + 2] << 16));
+              }
               if (two) {
 #pragma unroll
-                for (int c = 0; c < 12; c++) atomicAdd(&totals[rows2[1] * 12 + c], (uint32_t)acc[1][2 * c] | ((uint32_t)acc[1][2 * c + 1] << 16));
+                for (int c = 0; c < 12; c++) {
+                  const int b = 4 * (c >> 1) + (c & 1);
+                  atomicAdd(&totals[rows2[1] * 12 + c], (uint32_t)acc[1][b] | ((uint32_t)acc[1][b + 2] << 16));
+                }
               }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1127,6 +1409,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
           tfail = (fails != 0 && (fails & 1ULL) == 0) ? max(0, guess - 31) + (__ffsll((long long)fails) - 1) : -1;
         }
         uint32_t wbest = 0xffffffffu;
+        const int bt_ti = (int)S.bint[ti];
 #pragma unroll
         for (int u = 0; u < CAND_U; u++) {
           const int cidx = u * 64 + lane;
@@ -1138,13 +1421,13 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
           float dsum = (float)total * ikscale;
           dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
           if ((double)dsum < P.max_score) {
-            float wx = P.ll_x + (P.res * (float)(lo_x + a));
-            float wyy = P.ll_y + (P.res * (float)(lo_y + b));
-            int bx = (int)((double)wx / P.dx) - bx0, by = (int)((double)wyy / P.dy) - by0;
-            int bt = (int)(S.theta[ti] / P.dth) - bt0;
             unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
                                      (unsigned long long)(unsigned)(ti * ncand + cidx);
-            atomicMin(&S.bins[(bx * nby + by) * nbt + bt], key);
+            const int bidx = ((int)S.binx[a] + (int)S.biny[b]) * nbt + bt_ti;
+            // (a 64-bit LDS atomic costs its lanes one by one: only a candidate that would lower its bin issues one -- the bins only
+            // decrease, so a plain read that is still above the key cannot hide a lower value.  The read goes through an LDS-typed
+            // address: as a volatile generic load it made the compiler emit an illegal instruction in one instance)
+            if (key < *(lds_vu64*)(size_t)(lds_bins + 8u * (uint32_t)bidx)) atomicMin(&S.bins[bidx], key);
             wbest = min(wbest, __float_as_uint(dsum));
           }
         }
@@ -1155,7 +1438,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         }
         }
         MSTAT(13);
-      } else if (ti < nth && fast) {
+      } else if (!LEAN && ti < nth && fast) {
         // ---- fast path, any window: lane = (half h of the wavefront, x-row a, segment of 24 consecutive y offsets).
         // Both halves work on the same 32 (row, segment) jobs; half h takes points 8i+4h .. 8i+4h+3 of the list,
         // the two partial sums are added at the end.  Per point a lane fetches the 4 tile rows that hold its
@@ -1254,7 +1537,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
             }
           }
         }
-      } else if (ti < nth) {
+      } else if (!LEAN && ti < nth) {
         for (int cb = 0; cb < ncand; cb += 64 * CAND_U) {
           int ci[CAND_U], cj[CAND_U], sum[CAND_U];
 #pragma unroll
@@ -1305,7 +1588,13 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     __syncthreads();
     MPHASE(7);
     bool produce = true;                       // this workgroup writes the pair's result
-    if (P.split > 1) {
+    if (LEAN) {
+      // a pair this instance cannot take goes onto the general kernel's list
+      if (S.misc[13] != 0) redo = true;
+      if (redo && tid == 0) redo_list[atomicAdd(err + 3, 1)] = pair;
+      produce = !redo;
+    }
+    if (!LEAN && P.split > 1) {
       unsigned long long* gb = gbins + (size_t)pair * MAXBINS;
       for (int q = tid; q < nbins; q += CB_THREADS)
         if (S.bins[q] != ~0ULL) atomicMin(&gb[q], S.bins[q]);
@@ -1393,7 +1682,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
   for (int q = tid; q < P.kdim * P.kdim; q += GR_THREADS) S.kernel[q] = kernel_lut[q];
   for (int i = tid; i < J.n_ref; i += GR_THREADS) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
   __syncthreads();
-  build_grid(S, P, rcell, J.n_ref, gtiles, /*allow_fast=*/false, err);
+  build_grid<false>(S, P, rcell, J.n_ref, gtiles, /*allow_fast=*/false, err);
   const float ikscale = (float)(1. / (float)P.kscale);
   const int nbins = J.nbx * J.nby * J.nbt;
   uint32_t* const pl = &S.plist[0][0] + (wave >> 1) * (2 * LISTCAP);   // 8 wavefronts in pairs: the two of a pair build the same list
@@ -1518,7 +1807,7 @@ __global__ __launch_bounds__(VF_THREADS) void k_match_verify(MatchParams P, cons
   for (int q = tid; q < P.kdim * P.kdim; q += VF_THREADS) S.kernel[q] = kernel_lut[q];
   for (int i = tid; i < J.n2; i += VF_THREADS) rcell[i] = world_to_packed_cell(P, pts2[2 * i], pts2[2 * i + 1]);
   __syncthreads();
-  build_grid(S, P, rcell, J.n2, gtiles, /*allow_fast=*/false, err);
+  build_grid<false>(S, P, rcell, J.n2, gtiles, /*allow_fast=*/false, err);
   const float ikscale = (float)(1. / (float)P.kscale);
   // unexplained points: compacted through a counter, a wavefront's survivors at a time (the rasteriser does not care about
   // the order, only the count is reported; round 2 kept the order with a block scan -- 18 barriers -- per 256 points)
@@ -1547,7 +1836,7 @@ __global__ __launch_bounds__(VF_THREADS) void k_match_verify(MatchParams P, cons
   const int base = S.misc[14];
   __syncthreads();
   const int nnm = base;
-  build_grid(S, P, rcell2, nnm, gtiles, /*allow_fast=*/false, err);
+  build_grid<false>(S, P, rcell2, nnm, gtiles, /*allow_fast=*/false, err);
   int isum = 0;
   const int ni = max(0, J.hi_x - J.lo_x), nj = max(0, J.hi_y - J.lo_y);
   for (int q = tid; q < ni * nj; q += VF_THREADS) {
@@ -1591,14 +1880,29 @@ void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, cons
                      theta, items, kernel_lut, scratch, bins, err);
 }
 
-void launch_match_close_batch(hipStream_t st, int nblocks, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
+// variant: 0 = the general kernel (redo_list null: every pair; else the pairs redo_list[0 .. err[3]) a lean launch left over),
+// 1 / 2 = the lean exhaustive / pruned instance (match_close_lean_ok: the shapes they are built for)
+void launch_match_close_batch(hipStream_t st, int nblocks, int variant, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,
                               double* out_xyt, double* out_score, uint8_t* out_found, int* out_nres, int* err,
-                              unsigned long long* gbins, int* arrive) {
-  set_lds_attr_once<2>(reinterpret_cast<const void*>(k_match_close_batch));
-  hipLaunchKernelGGL(k_match_close_batch, dim3(nblocks), dim3(CB_THREADS), sizeof(Smem), st, P, ranges_ref, ref_xform, ranges_qry, guess,
-                     beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err, gbins, arrive);
+                              unsigned long long* gbins, int* arrive, int* redo_list) {
+#define CGMR_LAUNCH_CB(V)                                                                                                              \
+  do {                                                                                                                                 \
+    set_lds_attr_once<10 + V>(reinterpret_cast<const void*>(k_match_close_batch<V>));                                                   \
+    hipLaunchKernelGGL(k_match_close_batch<V>, dim3(nblocks), dim3(CB_THREADS), sizeof(Smem), st, P, ranges_ref, ref_xform, ranges_qry, \
+                       guess, beam_cos, beam_sin, kernel_lut, scratch, out_xyt, out_score, out_found, out_nres, err, gbins, arrive,     \
+                       redo_list);                                                                                                     \
+  } while (0)
+  if (variant == 1) CGMR_LAUNCH_CB(1);
+  else if (variant == 2) CGMR_LAUNCH_CB(2);
+  else CGMR_LAUNCH_CB(0);
+#undef CGMR_LAUNCH_CB
+}
+// what the lean instances are compiled for (everything the host can know before the launch)
+bool match_close_lean_ok(const MatchParams& P) {
+  return P.n_ref_scans == 1 && P.split == 1 && P.edt != 0 && P.sort32 != 0 && P.x_steps == 1 && P.y_steps == 1 && (P.nx & 7) == 0 &&
+         (P.ny & 7) == 0 && P.cellmap_off == 0;
 }
 int match_close_max_bins() { return MAXBINS; }
 

@@ -224,6 +224,10 @@ int cgmr_scan_transforms(const cgmr_matcher_config* cfg, int n, const double* re
 /* out[0] = pairs of the last batched close-matching launch, out[1] = those whose grid tiles did not fit the LDS pool
  * (they take the slower generic search path; same results) */
 int cgmr_match_last_stats(const cgmr_ctx* ctx, int64_t out[2]);
+/* Pairs of the last batched close-matching launch that the kernel instance built for the common shape (one reference scan, the
+ * shipped grid and kernel) handed to the general kernel (same results; such a pair is prepared twice).  0 when the general
+ * kernel ran alone (CGMR_MATCH_LEAN=0, reference sets of several scans, single calls). */
+int cgmr_match_last_redo_pairs(const cgmr_ctx* ctx, int64_t* out);
 /* Device time (HIP events on the context's stream) of the last matcher launch, seconds. */
 int cgmr_match_last_kernel_seconds(const cgmr_ctx* ctx, double* seconds);
 
