@@ -212,7 +212,8 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
     HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->match_redo_pairs = errv[3];
-    if (errv[0] == 0 && errv[3] > 0) {
+    static const bool no_redo = getenv("CGMR_MATCH_NOREDO") && atoi(getenv("CGMR_MATCH_NOREDO")) != 0;   // (profiling the lean instance alone)
+    if (errv[0] == 0 && errv[3] > 0 && !no_redo) {
       h_err[0] = 0; h_err[1] = std::min(errv[3], ctx->n_cus); h_err[2] = 0; h_err[3] = errv[3];
       HIP_TRY(ctx, hipMemcpyAsync(d + o_err, h_err, 16, hipMemcpyHostToDevice, ctx->stream));
       launch_match_close_batch(ctx->stream, h_err[1], 0, P, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),

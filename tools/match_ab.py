@@ -22,8 +22,9 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     ok = bool(np.array_equal(G["xyt"][:n], xyt[:n]) and np.array_equal(G["found"][:n].astype(bool), found[:n]) and np.array_equal(G["score"][:n], score[:n]))
     import ctypes as C
     st = (C.c_int64 * 2)(); ctx.lib.cgmr_match_last_stats(ctx.h, st)
+    rd = C.c_int64(0); ctx.lib.cgmr_match_last_redo_pairs(ctx.h, C.byref(rd))
     print(json.dumps({"prune": os.environ.get("CGMR_MATCH_PRUNE", "1"), "pairs": len(rr), "kernel_ms": round(1e3 * ks, 3),
-                      "pairs_per_s": round(len(rr) / ks), "golden": ok, "slow_pairs": int(st[1])}))
+                      "pairs_per_s": round(len(rr) / ks), "golden": ok, "slow_pairs": int(st[1]), "redo_pairs": int(rd.value)}))
 else:
     N = sys.argv[1] if len(sys.argv) > 1 else "16384"
     for pr in ("0", "1"):
