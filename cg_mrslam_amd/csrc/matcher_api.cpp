@@ -1094,9 +1094,12 @@ int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
       if (k != S->ref_index) rel = se2_mul(se2_inv(refp), se2_of(S->poses_xyt + 3 * (size_t)k));
       const float lo[3] = {(float)(-.5 + rel.x), (float)(-1.5 + rel.y), (float)(-0.8 + rel.t)};
       const float hi[3] = {(float)(.5 + rel.x), (float)(1.5 + rel.y), (float)(0.8 + rel.t)};
-      const float pi_f = (float)3.14159265358979323846;                            // Vector3f += M_PI: float arithmetic
+      // `lower[2] += M_PI` on a Vector3f (scan_matcher.cpp:236-237): a float lvalue plus a double -- the sum is formed in double
+      // and narrowed to float once (not float + float(pi): that differs by one float ulp for every second angle; found by the
+      // hand-derived twin-region case of tests/known_answers.py, round 5)
+      const double pi_d = 3.14159265358979323846;
       regions[j].insert(regions[j].end(), {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]});
-      regionspi[j].insert(regionspi[j].end(), {lo[0], lo[1], lo[2] + pi_f, hi[0], hi[1], hi[2] + pi_f});
+      regionspi[j].insert(regionspi[j].end(), {lo[0], lo[1], (float)((double)lo[2] + pi_d), hi[0], hi[1], (float)((double)hi[2] + pi_d)});
     }
   }
   const double theta_res = 0.025, dx = 0.5, dy = 0.5, dth = 0.2;                   // :258-263

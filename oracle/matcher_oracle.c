@@ -31,7 +31,8 @@
  *      is used so that this oracle and the HIP kernel, which carries the same routine, agree bit
  *      for bit on every platform.  A last-bit difference to libm can change a result only if a
  *      rotated coordinate times 1/res lands within one ulp of an integer (the value is truncated,
- *      chargrid.cpp:249); tests count such events on the fixtures (none).
+ *      chargrid.cpp:249); cmo_sincos_cell_differences below counts such events and
+ *      tests/test_oracle_matcher.py runs it over the golden fixture's pairs and angles.
  *  (2) std::sort is unstable for equal scores (chargrid.cpp:307).  Here equal scores keep map order
  *      (thread, ix, iy, ith), which is what libstdc++ does for <= 16 results (insertion sort).
  *  (3) `char distance = K1*sqrt(...)` (scan_matcher.cpp:50) is signed char on x86; values stay below
@@ -140,6 +141,28 @@ void cmo_sincos(double x, double *s, double *c) {
     case 2: *s = -sn; *c = -cs; break;
     default: *s = -cs; *c = sn; break;
   }
+}
+
+/* Deviation (1) made checkable: the cells CharGrid::greedySearch truncates to (chargrid.cpp:246-250) with the search angle's
+ * cos / sin from libm -- what the reference computes -- and from cmo_sincos, for every (point, angle) pair; returns how many
+ * of the cells differ (and how many of the angles' cos / sin values differ in their last bit, for the record). */
+long cmo_sincos_cell_differences(int npts, const double *pts, int nangles, const double *angles, float inv_res, long *angle_bits_differ) {
+  long ndiff = 0, nbits = 0;
+  for (int a = 0; a < nangles; a++) {
+    const double t = angles[a];
+    const double cl = cos(t), sl = sin(t);
+    double sp, cp;
+    cmo_sincos(t, &sp, &cp);
+    if (cl != cp || sl != sp) nbits++;
+    for (int i = 0; i < npts; i++) {
+      const double x = pts[2 * i], y = pts[2 * i + 1];
+      const int ixl = (int)((cl * x - sl * y) * inv_res), iyl = (int)((sl * x + cl * y) * inv_res);
+      const int ixp = (int)((cp * x - sp * y) * inv_res), iyp = (int)((sp * x + cp * y) * inv_res);
+      if (ixl != ixp || iyl != iyp) ndiff++;
+    }
+  }
+  if (angle_bits_differ) *angle_bits_differ = nbits;
+  return ndiff;
 }
 
 /* ------------------------------------------------------------------------ grid */

@@ -157,6 +157,18 @@ def sincos(x):
     return s.value, c.value
 
 
+def sincos_cell_differences(pts, angles, inv_res=40.0):
+    """(cells that differ between libm's and the portable cos / sin, angles whose cos / sin differ in a bit) over all
+    (point, angle) pairs -- oracle/matcher_oracle.c, deviation (1)."""
+    pts = _f64(pts).reshape(-1, 2)
+    angles = _f64(angles).reshape(-1)
+    nb = C.c_long(0)
+    f = lib().cmo_sincos_cell_differences
+    f.restype = C.c_long
+    nd = f(C.c_int(len(pts)), _p(pts, C.c_double), C.c_int(len(angles)), _p(angles, C.c_double), C.c_float(inv_res), C.byref(nb))
+    return int(nd), int(nb.value)
+
+
 def make_kernel(resolution, kernel_range, kscale=128):
     buf = np.zeros(64 * 64, dtype=np.uint8)
     dim = lib().cmo_make_kernel(C.c_double(resolution), C.c_double(kernel_range), C.c_int(kscale), _p(buf, C.c_uint8),

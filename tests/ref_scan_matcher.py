@@ -87,8 +87,9 @@ class RefScanMatcherLogic:
             upper = np.array([.5 + rel[0], 1.5 + rel[1], 0.8 + rel[2]], dtype=np.float32)
             regions.append(np.concatenate([lower, upper]))
             lower2, upper2 = lower.copy(), upper.copy()
-            lower2[2] += np.float32(np.pi)           # Vector3f += M_PI: float arithmetic
-            upper2[2] += np.float32(np.pi)
+            # `lower[2] += M_PI` (scan_matcher.cpp:236-237): float lvalue += double, i.e. the sum in double, narrowed to float once
+            lower2[2] = np.float32(np.float64(lower[2]) + np.pi)
+            upper2[2] = np.float32(np.float64(upper[2]) + np.pi)
             regionspi.append(np.concatenate([lower2, upper2]))
         theta_res, dx, dy, dth = 0.025, 0.5, 0.5, 0.2
         merged = {}

@@ -260,3 +260,13 @@ def test_backward_solve_timeout_is_not_a_cholesky_failure(oracle):
     np.testing.assert_allclose(chi, chi0, rtol=1e-9)
     rc, p, chi = c.gn_optimize(*a, 6)                        # and the chained launch is back afterwards
     assert rc == 0 and np.array_equal(chi, chi0)
+
+
+def test_hand_worked_gauss_newton_step_on_gpu(ctx):
+    """tests/known_answers.py (G): one Gauss-Newton step whose H, b and dx are written out from SURVEY.md Appendix A's formulas
+    (no implementation involved), through cgmr_gn_optimize."""
+    import known_answers as K
+    rc, poses, chi2 = ctx.gn_optimize(K.GN_POSES, K.GN_FIXED, K.GN_FROM, K.GN_TO, K.GN_MEAS, K.GN_INFO, 1)
+    assert rc == 0
+    assert abs(chi2[0] - K.GN_CHI2_BEFORE) < 1e-10
+    assert np.abs(poses - K.GN_POSES_AFTER).max() < 1e-12

@@ -513,3 +513,31 @@ def test_committed_4096_pair_subset_of_c3(ctx):
     found, xyt, score = m.closeScanMatching(sp["ranges_ref"], sp["ranges_qry"], sp["guess"])
     assert np.array_equal(found, G["found"].astype(bool)) and np.array_equal(xyt, G["xyt"]) and np.array_equal(score, G["score"])
     assert m.last_stats()["slow_pairs"] == 0
+
+
+def test_hand_derived_subsample_hierarchy_verify_and_twin_regions_on_gpu(ctx):
+    """The round-5 cases of tests/known_answers.py (worked out on paper from chargrid.cpp:61-122, 310-455 and
+    scan_matcher.cpp:220-294) through the C ABI: cgmr_subsample, cgmr_match_hierarchical, cgmr_match_verify and
+    cgmr_scan_matching_lc (whose twin regions hinge on `lower[2] += M_PI` being a double sum narrowed once)."""
+    import ctypes as C
+    import known_answers as K
+    from cg_mrslam_amd.matcher import LCScanMatcher, ScanMatcher
+    m = ScanMatcher(ctx, 1081, synth.LASER_ANGLE_MIN, synth.LASER_ANGLE_INC, 30.0)
+    # (S)
+    assert np.array_equal(m.subsample(K.SUBSAMPLE_IN, 0.1), K.SUBSAMPLE_OUT)
+    # (H)
+    a = K.HIER_ARGS
+    res = m.hierarchicalSearch(K.HIER_REF, K.HIER_REF, K.HIER_REGION, a["theta_res"], a["max_score"], a["dx"], a["dy"], a["dth"], a["n_levels"])
+    assert [tuple(r) for r in res] == K.HIER_EXPECTED
+    # (V)
+    lc = LCScanMatcher(ctx, K.LC_N_BEAMS, K.LC_ANGLE_MIN, K.LC_ANGLE_INC, K.LC_MAX_RANGE)
+    score, nnm = C.c_double(), C.c_int()
+    p2, p1 = np.ascontiguousarray(K.VERIFY_PTS2), np.ascontiguousarray(K.VERIFY_PTS1)
+    rc = ctx.lib.cgmr_match_verify(ctx.h, C.byref(lc.cfg), C.c_int(len(p2)), C.c_void_p(p2.ctypes.data), C.c_int(len(p1)),
+                                   C.c_void_p(p1.ctypes.data), C.c_double(0.3), C.c_void_p(K.VERIFY_LOWER.ctypes.data),
+                                   C.c_void_p(K.VERIFY_UPPER.ctypes.data), C.byref(score), C.byref(nnm))
+    assert rc == 0 and nnm.value == K.VERIFY_NONMATCHED and score.value == K.VERIFY_SCORE
+    # (L): the same scan as reference and current set, at unrelated poses (only the sets' own frames enter)
+    assert np.array_equal(lc.cartesian(K.LC_RANGES), K.LC_POINTS)
+    res = lc.scanMatchingLC([(K.LC_RANGES, np.array([3.0, -2.0, 0.7]))], 0, [(K.LC_RANGES, np.array([-1.0, 4.0, -2.0]))], 0, K.LC_MAX_SCORE)
+    assert [tuple(r) for r in res] == K.LC_EXPECTED

@@ -159,3 +159,12 @@ def test_hub_graph_oracle_vs_numpy(oracle):
     np.testing.assert_allclose(chi, chi2, rtol=1e-6)
     np.testing.assert_allclose(chi[-1], chi2[-1], rtol=1e-9)
     assert np.abs(p[:, :2] - p2[:, :2]).max() < 1e-8
+
+
+def test_hand_worked_gauss_newton_step(oracle):
+    """tests/known_answers.py (G): H, b and dx of a three-vertex graph written out from SURVEY.md Appendix A's formulas."""
+    import known_answers as K
+    st, poses, chi2, _ = oracle.gn_optimize(K.GN_POSES, K.GN_FIXED, K.GN_FROM, K.GN_TO, K.GN_MEAS, K.GN_INFO, 1)
+    assert st == 0
+    assert abs(chi2[0] - K.GN_CHI2_BEFORE) < 1e-10
+    assert np.abs(poses - K.GN_POSES_AFTER).max() < 1e-12

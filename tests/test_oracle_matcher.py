@@ -183,3 +183,61 @@ def test_hand_derived_three_point_scan(oracle):
         for j in range(598, 602):
             assert got[(i, j)] == K.expected_score(i, j, K.QUERY_CELLS), (i, j)
     assert n == 16 and got[(600, 600)] == 0.0 and got[(601, 600)] == 0.0234375 and got[(600, 602 - 1)] == K.expected_score(600, 601, K.QUERY_CELLS)
+
+
+def test_portable_sincos_never_moves_a_cell_on_the_fixture(oracle):
+    """oracle/matcher_oracle.c, deviation (1): the oracle and the HIP kernel take cos / sin of the search angle from a portable
+    routine, the reference from libm (chargrid.cpp:241).  Counted here, over every (subsampled point, search angle) pair of the
+    4096-pair fixture (the C3 recipe: 64 angles a pair, ~430 points: 1.1e8 pairs) and over 2e5 generated (point, angle) pairs:
+    the truncated cells (chargrid.cpp:246-250) the two would search.  Zero differences = every result of the fixture is what the
+    libm path gives; the number of angles whose cos / sin differ in the last bit is printed for the record."""
+    sp = synth.make_scan_pairs(4096, seed=4242)
+    theta_res, win_t = 0.0125 * .5, 0.2
+    total_cells = total_bits = total_pairs = 0
+    for i in range(4096):
+        pts = oracle.cartesian(sp["ranges_qry"][i], sp["angle_min"], sp["angle_inc"], sp["max_range"])
+        q = oracle.subsample(pts, 0.1)
+        # the angle list of chargrid.cpp:239 for closeScanMatching's window (scan_matcher.cpp:148-151): float bounds, double steps
+        lo, hi = float(np.float32(-win_t + sp["guess"][i, 2])), float(np.float32(win_t + sp["guess"][i, 2]))
+        angles = []
+        t = lo
+        while t < hi:
+            angles.append(t)
+            t += theta_res
+        nd, nb = oracle.sincos_cell_differences(q, angles, 40.0)
+        total_cells += nd
+        total_bits += nb
+        total_pairs += len(q) * len(angles)
+    rng = np.random.default_rng(11)
+    nd, nb = oracle.sincos_cell_differences(rng.uniform(-30, 30, size=(2000, 2)), rng.uniform(-3.3, 3.3, size=100), 40.0)
+    nd2, nb2 = oracle.sincos_cell_differences(rng.uniform(-35, 35, size=(2000, 2)), rng.uniform(-3.3, 3.3, size=100), 10.0)
+    print(f"{total_pairs} (point, angle) pairs of the fixture: {total_cells} cells differ; cos / sin differ in a bit for {total_bits} of "
+          f"{4096 * 64} angles; generated: {nd} + {nd2} cells of 4e5, {nb + nb2} of 200 angles")
+    assert total_pairs > 1e8
+    assert total_cells == 0 and nd == 0 and nd2 == 0
+
+
+def test_hand_derived_subsample_hierarchy_verify_and_twin_regions(oracle):
+    """The round-5 cases of tests/known_answers.py (worked out from chargrid.cpp / scan_matcher.cpp on paper): subsample order and
+    means, two levels of hierarchicalSearch with its region propagation, searchNonMatchedPoints + countPoints, and
+    scanMatchingLC's twin regions / normalise / merge -- the last one on the plain-Python restatement of the ScanMatcher
+    bookkeeping (tests/ref_scan_matcher.py) over the oracle."""
+    import known_answers as K
+    import oracle_backend as ob
+    # (S)
+    assert np.array_equal(oracle.subsample(K.SUBSAMPLE_IN, 0.1), K.SUBSAMPLE_OUT)
+    # (H)
+    a = K.HIER_ARGS
+    n, res = oracle.hierarchical_search(K.GRID["ll"], K.GRID["ur"], K.GRID["res"], K.GRID["res"], K.GRID["kernel_range"], K.HIER_REF, K.HIER_REF,
+                                        K.HIER_REGION, a["theta_res"], a["max_score"], a["dx"], a["dy"], a["dth"], a["n_levels"])
+    assert n == 2 and [tuple(r) for r in res[:n]] == K.HIER_EXPECTED
+    # (V)
+    n_nm, score = oracle.verify(K.VERIFY_LL, K.VERIFY_UR, K.VERIFY_RES, K.VERIFY_RES, K.VERIFY_RANGE, K.VERIFY_PTS2, K.VERIFY_PTS1,
+                                K.VERIFY_LOWER, K.VERIFY_UPPER, 0.3)
+    assert n_nm == K.VERIFY_NONMATCHED and score == K.VERIFY_SCORE
+    assert K._VSUM == sum(min(int(12 * np.hypot(di, dj)), 64) for di in (-3, -2, -1, 0, 1, 2) for dj in (-3, -2, -1, 0, 1, 2)) == 990
+    # (L)
+    lo = ob.OracleMatcher(K.LC_ANGLE_MIN, K.LC_ANGLE_INC, K.LC_MAX_RANGE, (-35.0, -35.0), (35.0, 35.0), 0.1, 0.5)
+    assert np.array_equal(lo.cartesian(K.LC_RANGES), K.LC_POINTS)
+    res = lo.scanMatchingLC([(K.LC_RANGES, np.array([3.0, -2.0, 0.7]))], 0, [(K.LC_RANGES, np.array([-1.0, 4.0, -2.0]))], 0, K.LC_MAX_SCORE)
+    assert [tuple(r) for r in res] == K.LC_EXPECTED
