@@ -47,6 +47,7 @@ class RobotGraph:
         self.lib.cgmr_graph_last_error.restype = C.c_char_p
         self.lib.cgmr_graph_wire_bytes.restype = C.c_int64
         self.lib.cgmr_graph_skipped_messages.restype = C.c_int64
+        self.lib.cgmr_graph_failed_batches.restype = C.c_int64
         self.lib.cgmr_graph_send_buffer.restype = C.c_void_p
         self.lib.cgmr_graph_recv_buffer.restype = C.c_void_p
         self.lib.cgmr_graph_destroy.restype = None
@@ -163,6 +164,11 @@ class RobotGraph:
         """Messages left out, not built or dropped because they exceed ``cap_edges`` (the reference skips a send whose
         ``toCharArray`` does not fit ``MAX_LENGTH_MSG``, graph_comm.cpp:112-122)."""
         return int(self.lib.cgmr_graph_skipped_messages(self.h))
+
+    def failed_batches(self) -> int:
+        """Asynchronous batches of condensed graphs that failed (Cholesky / a bounded device-side wait): their peers got no edges
+        in that round's message; the later rounds are built regardless."""
+        return int(self.lib.cgmr_graph_failed_batches(self.h))
 
     def wire_bytes(self) -> int:
         return int(self.lib.cgmr_graph_wire_bytes(self.h))

@@ -80,7 +80,7 @@ int side_join_stream(cgmr_ctx* ctx, hipStream_t st) {
 // doubles, so the graveyard never holds more than the live blocks do (sized for 288 GB of HBM, not for thrift).
 int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes) {
   if (bytes <= A.cap) return 0;
-  if (A.ptr) { ctx->graveyard.push_back(A.ptr); A.ptr = nullptr; }
+  if (A.ptr) { ctx->graveyard.push_back({A.ptr, nullptr}); A.ptr = nullptr; }
   size_t want = std::max(bytes + bytes / 2, 2 * A.cap) + (1 << 20);
   A.cap = 0;
   hipError_t e = hipMalloc((void**)&A.ptr, want);
@@ -842,7 +842,7 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (ctx->trace_n > 0)
     fprintf(stderr, "[gn] %lld solves: analysis + upload %.3f ms, masks %.3f ms, queueing the launches %.3f ms, waiting %.3f ms per solve\n", (long long)ctx->trace_n,
             1e3 * ctx->trace_sum[0] / ctx->trace_n, 1e3 * ctx->trace_sum[1] / ctx->trace_n, 1e3 * ctx->trace_sum[2] / ctx->trace_n, 1e3 * ctx->trace_sum[3] / ctx->trace_n);
-  for (void* q : ctx->graveyard) (void)hipFree(q);
+  for (auto& q : ctx->graveyard) (void)hipFree(q.first);
   if (ctx->gn_arena.ptr) (void)hipFree(ctx->gn_arena.ptr);
   if (ctx->io_arena.ptr) (void)hipFree(ctx->io_arena.ptr);
   if (ctx->mt_arena.ptr) (void)hipFree(ctx->mt_arena.ptr);

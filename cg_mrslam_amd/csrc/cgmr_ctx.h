@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/cgmr.h"
@@ -23,7 +24,9 @@ struct cgmr_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
-  std::vector<void*> graveyard;   // device blocks an arena / growable array has outgrown: freed with the context (see arena_reserve)
+  // device blocks an arena / growable array has outgrown (see arena_reserve): (block, owner) -- the context's own arenas' with
+  // owner null, freed with the context; a robot graph's freed with the graph (cgmr_graph_destroy)
+  std::vector<std::pair<void*, const void*>> graveyard;
   cgmr::Arena gn_arena;     // structure + numeric work space of the last analysed graph
   cgmr::Arena io_arena;     // staging for the host-pointer entry points
   cgmr::Arena mt_arena;     // matcher work space

@@ -92,6 +92,8 @@ struct cgmr_graph {
   unsigned char* d_recv2 = nullptr;   // second receive buffer of the in-process transport (cgmr_graph_deliver): round t's messages land
                                       // in buffer t & 1 while round t - 1's may not have been ingested yet
   std::vector<int64_t> n_delivered;   // per destination robot: messages delivered to it so far
+  std::vector<int64_t> recv_round[2]; // per receive buffer and sender: which of the sender's deliveries lies there (-1: none)
+  int64_t n_packed = 0;               // messages packed on the device so far (cgmr_graph_deliver needs one)
   int64_t n_ingested_delivered = 0;
   char* pinned = nullptr;             // header + closures staging, ids read-back, slot lists, one message's numbers
   size_t pinned_bytes = 0, pinned_msg_off = 0;
@@ -107,6 +109,8 @@ struct cgmr_graph {
   // (cgmr_graph_compute_condensed_async): what is needed to finish it
   bool cond_pending = false;
   int cond_last_rc = 0;               // how the most recent asynchronous batch ended (kept for cgmr_graph_condensed_wait)
+  int64_t cond_failed_batches = 0;    // asynchronous batches that failed (Cholesky / time-out): their peers got no edges that round
+  bool cond_levelwise = false;        // a batch's chained backward solve has timed out once: the batches solve level by level from now on
   std::vector<int32_t> cond_peers;    // peer of every job of the batch
   const int32_t* cond_status = nullptr;   // pinned: 4 status words per job, valid after ev_cond_done
   const CondJobDev* cond_jobs_dev = nullptr;    // the batch's job table on the device (peer of job j = out_slot)
@@ -140,7 +144,7 @@ int dev_grow(cgmr_graph* g, DevBuf& B, size_t used_bytes, size_t need_bytes) {
     // not freed here -- a batch on the side stream may still read it, and hipFree waits for the whole device -- but with
     // the context (cgmr_ctx.h: graveyard)
     if (used_bytes) HIP_TRY(ctx, hipMemcpyAsync(p, B.ptr, used_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    ctx->graveyard.push_back(B.ptr);
+    ctx->graveyard.push_back({B.ptr, g});
   }
   B.ptr = p;
   B.cap = want;
@@ -169,6 +173,8 @@ int alloc_fixed(cgmr_graph* g) {
   g->d_status_all = (int32_t*)(d + o_st);
   g->d_send = (unsigned char*)(d + o_send); g->d_recv = (unsigned char*)(d + o_recv); g->d_recv2 = (unsigned char*)(d + o_recv2);
   g->n_delivered.assign(R, 0);
+  g->recv_round[0].assign(R, -1);
+  g->recv_round[1].assign(R, -1);
   g->pinned_bytes = round256(wb) + round256(4 * R * (2 + 3 * cap)) + round256(4 * slots) + round256(24 * slots) + 4096;
   g->pinned_msg_off = g->pinned_bytes;
   g->pinned_bytes += round256(72 * cap);
@@ -245,14 +251,18 @@ int cond_finish(cgmr_graph* g) {
   g->cond_last_rc = 0;
   if (!failed) return 0;
   for (int32_t p : g->cond_peers) { g->out[p].n = 0; g->out[p].host_valid = false; }
-  if (timed_out) { ctx->gn_timeouts++; return g->cond_last_rc = gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
+  g->cond_failed_batches++;
+  if (timed_out) { g->cond_levelwise = true; ctx->gn_timeouts++; return g->cond_last_rc = gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
   return g->cond_last_rc = gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
 }
 
 // whatever is about to overwrite my send buffer waits for the robots that are still copying it (cgmr_graph_deliver)
+// (a flag per stream that may write the buffer: bit 0 = the context's stream, bit 1 = its side stream; an event wait queued on one
+// of them orders nothing on the other)
 int wait_consumers(cgmr_graph* g, hipStream_t st) {
+  const uint8_t bit = st == g->ctx->stream ? 1 : 2;
   for (size_t d = 0; d < g->consumed_pending.size(); d++)
-    if (g->consumed_pending[d]) { HIP_TRY(g->ctx, hipStreamWaitEvent(st, g->ev_consumed[d], 0)); g->consumed_pending[d] = 0; }
+    if (g->consumed_pending[d] & bit) { HIP_TRY(g->ctx, hipStreamWaitEvent(st, g->ev_consumed[d], 0)); g->consumed_pending[d] &= (uint8_t)~bit; }
   return 0;
 }
 
@@ -361,6 +371,10 @@ void cgmr_graph_destroy(cgmr_graph* g) {
     (void)side_join_host(g->ctx);
     for (DevBuf* b : {&g->d_poses, &g->d_meas_a, &g->d_info_a, &g->d_vids, &g->d_work})
       if (b->ptr) (void)hipFree(b->ptr);
+    // the blocks this graph's arrays have outgrown (nothing of it is in flight any more: both streams were waited for above)
+    auto& gy = g->ctx->graveyard;
+    for (auto& q : gy) if (q.second == g) (void)hipFree(q.first);
+    gy.erase(std::remove_if(gy.begin(), gy.end(), [g](const std::pair<void*, const void*>& q) { return q.second == g; }), gy.end());
     if (g->d_fixed_block) (void)hipFree(g->d_fixed_block);
     if (g->pinned) (void)hipHostFree(g->pinned);
     if (g->cond_pinned) (void)hipHostFree(g->cond_pinned);
@@ -652,9 +666,16 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
   go_async = go_async && batched && to_wire && !info_out;
   // whatever ran on the side stream before (another graph of this context, this graph's previous batch) used the replicas
   // and the marginals work space this batch is about to fill
+  // (work queued on the side stream behind the fork is marked -- side_busy, side_tail -- even when this function leaves on an error:
+  // the next join then waits for it instead of skipping it)
+  struct SideGuard {
+    cgmr_ctx* c; bool armed;
+    ~SideGuard() { if (armed) (void)side_mark(c); }
+  } side_guard{ctx, false};
   if (go_async) {
     rc = side_fork(ctx);
     if (rc) return rc;
+    side_guard.armed = true;
     st = ctx->side;
     rc = wait_consumers(g, st);
     if (rc) return rc;
@@ -697,7 +718,9 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     {
       const int cap_blocks = bwd_chain_capacity() / (ctx->side_used ? 2 : 1) / nj;
       DB.bwd_chain_level = DB.nlevels;
-      while (DB.bwd_chain_level > 0 && DB.h_level_ptr[DB.nlevels] - DB.h_level_ptr[DB.bwd_chain_level - 1] <= cap_blocks) DB.bwd_chain_level--;
+      // (after a time-out -- two chained solves per context on eight contexts of one device make them likelier -- the batches of
+      // this graph solve level by level: no in-kernel waits, like gn_run's retry)
+      while (!g->cond_levelwise && DB.bwd_chain_level > 0 && DB.h_level_ptr[DB.nlevels] - DB.h_level_ptr[DB.bwd_chain_level - 1] <= cap_blocks) DB.bwd_chain_level--;
     }
     run_guesses([&](int i) { return (double*)(hstage + s_work + (size_t)24 * nV * i); });
     const double tm0 = wall_s();
@@ -765,6 +788,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       // not waited for: the status words are looked at by cond_finish(); a message packed before that gets its counts
       // corrected on the device (cgmr_graph_pack)
       HIP_TRY(ctx, hipEventRecord(g->ev_cond_done, st));
+      side_guard.armed = false;
       rc = side_mark(ctx);
       if (rc) return rc;
       g->cond_pending = true;
@@ -911,8 +935,11 @@ int compute_condensed_impl(cgmr_graph* g, int peer, bool go_async) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   {
-    int rc = cond_finish(g);                      // the previous batch, if it was not waited for (its failure surfaces here)
-    if (rc) return rc;
+    // the previous batch, if it was not waited for.  Its failure (Cholesky, time-out) cost its peers that round's edges and is
+    // on record (cond_last_rc until the next batch is queued, cgmr_graph_failed_batches); it must not cost them this round's
+    // as well: the current batch is built regardless (round 4 returned the old error here and the run stopped)
+    const int rc = cond_finish(g);
+    if (rc != 0 && rc != CGMR_E_TIMEOUT && rc != CGMR_E_CHOLESKY_BASE) return rc;    // (a HIP error still stops)
   }
   const double t0 = wall_s();
   const int nV = (int)g->ids.size(), nA = (int)g->ef.size(), cap = g->cap;
@@ -969,6 +996,12 @@ int compute_condensed_impl(cgmr_graph* g, int peer, bool go_async) {
   }
   bool queued = go_async;
   int rc = run_cond_jobs(g, jobs, /*to_wire=*/true, nullptr, &queued);
+  if (rc == CGMR_E_TIMEOUT && !g->cond_levelwise) {
+    // a bounded wait of the chained backward solve ran out: once more with one launch per tree level (gn_run does the same)
+    g->cond_levelwise = true;
+    queued = go_async;
+    rc = run_cond_jobs(g, jobs, /*to_wire=*/true, nullptr, &queued);
+  }
   if (rc) { for (CondJob& J : jobs) { g->out[J.peer].n = 0; g->out[J.peer].host_valid = false; } return rc; }
   for (CondJob& J : jobs) {
     PeerOut& O = g->out[J.peer];
@@ -996,7 +1029,7 @@ int cgmr_graph_compute_condensed(cgmr_graph* g, int peer) { return compute_conde
 // cgmr_graph_condensed_wait or by the next call that waits; the message packed meanwhile carries no edges for the batch's peers.
 // Returns the number of peers whose condensed graph is being built.
 int cgmr_graph_compute_condensed_async(cgmr_graph* g, int peer) {
-  if (g && g->ctx) g->ctx->side_used = true;
+  if (g && g->ctx && !g->ctx->side_used) { g->ctx->side_used = true; g->ctx->sym_valid = false; }   // (the cached structure's chained solve was sized for the whole device)
   return compute_condensed_impl(g, peer, true);
 }
 
@@ -1015,7 +1048,7 @@ int cgmr_graph_condensed_wait(cgmr_graph* g) {
 // solves of the context's stream and of the side stream then share the resident workgroups from the start).
 int cgmr_graph_set_async(cgmr_graph* g, int on) {
   if (!g) return CGMR_E_INVALID;
-  if (g->ctx && on) g->ctx->side_used = true;
+  if (g->ctx && on && !g->ctx->side_used) { g->ctx->side_used = true; g->ctx->sym_valid = false; }   // (see cgmr_graph_compute_condensed_async)
   return CGMR_OK;
 }
 
@@ -1155,6 +1188,7 @@ int cgmr_graph_pack(cgmr_graph* g, void* d_send_out) {
   if (d_send_out && d_send_out != (void*)g->d_send)
     HIP_TRY(ctx, hipMemcpyAsync(d_send_out, g->d_send, wb, hipMemcpyDeviceToDevice, st));
   HIP_TRY(ctx, hipEventRecord(g->ev_packed, st));
+  g->n_packed++;
   if (behind_batch) {
     int rc = side_mark(ctx);
     if (rc) return rc;
@@ -1169,20 +1203,37 @@ int cgmr_graph_pack(cgmr_graph* g, void* d_send_out) {
 // write into its send buffer behind it as well.  Every robot delivers to every other once per round.
 int cgmr_graph_deliver(cgmr_graph* src, cgmr_graph* dst) {
   if (!src || !dst || !src->ctx || !dst->ctx || src->n_robots != dst->n_robots || src->cap != dst->cap) return CGMR_E_INVALID;
+  if (src == dst || src->robot == dst->robot) return gerr(src, CGMR_E_INVALID, "cgmr_graph_deliver: a robot does not deliver to itself");
+  if (src->n_packed == 0) return gerr(src, CGMR_E_INVALID, "cgmr_graph_deliver: nothing packed yet (cgmr_graph_pack(src, NULL) first)");
   cgmr_ctx* ctx = dst->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (src->ctx->device != ctx->device) {
+    // the copy below is a device-to-device copy queued on dst's stream: the two devices must be able to reach each other
+    int can = 0;
+    HIP_TRY(ctx, hipDeviceCanAccessPeer(&can, ctx->device, src->ctx->device));
+    if (!can) return gerr(src, CGMR_E_INVALID, "cgmr_graph_deliver: the two robots' devices have no peer access (use the all-gather)");
+    const hipError_t pe = hipDeviceEnablePeerAccess(src->ctx->device, 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return gerr(src, CGMR_E_HIP, "cgmr_graph_deliver: hipDeviceEnablePeerAccess failed");
+    (void)hipGetLastError();
+  }
   const size_t wb = wire_bytes(src->n_robots, src->cap);
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, src->ev_packed, 0));
   // two receive buffers taking turns: a robot may deliver its round-t message before the destination has ingested round t - 1's
-  // (robots that take turns on one device run their rounds one after the other, not in lock step)
-  unsigned char* recv = (src->n_delivered[dst->robot]++ & 1) ? dst->d_recv2 : dst->d_recv;
+  // (robots that take turns on one device run their rounds one after the other, not in lock step).  The k-th delivery of src to
+  // dst belongs to dst's k-th cgmr_graph_ingest_delivered; which delivery lies in which buffer is kept on the host, and a
+  // buffer whose slice is not the expected one (a robot skipped a round, delivered twice, ..) is ingested as "no message"
+  const int64_t k = src->n_delivered[dst->robot];
+  unsigned char* recv = (k & 1) ? dst->d_recv2 : dst->d_recv;
   HIP_TRY(ctx, hipMemcpyAsync(recv + (size_t)src->robot * wb, src->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(src->ev_consumed[dst->robot], ctx->stream));
-  src->consumed_pending[dst->robot] = 1;
+  src->n_delivered[dst->robot] = k + 1;                      // (only now: the copy is queued)
+  dst->recv_round[k & 1][src->robot] = k;
+  src->consumed_pending[dst->robot] = 3;                     // both of src's streams wait before they write the buffer again
   return CGMR_OK;
 }
 
 int64_t cgmr_graph_skipped_messages(const cgmr_graph* g) { return g ? g->skipped_messages : -1; }
+int64_t cgmr_graph_failed_batches(const cgmr_graph* g) { return g ? g->cond_failed_batches : -1; }
 
 void* cgmr_graph_send_buffer(cgmr_graph* g) { return g ? (void*)g->d_send : nullptr; }
 void* cgmr_graph_recv_buffer(cgmr_graph* g) { return g ? (void*)g->d_recv : nullptr; }
@@ -1262,7 +1313,20 @@ int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
 // The ingest that goes with cgmr_graph_deliver: the k-th call digests the k-th message of every peer (receive buffer k & 1).
 int cgmr_graph_ingest_delivered(cgmr_graph* g, int32_t* n_edges_out) {
   if (!g || !g->ctx) return CGMR_E_INVALID;
-  const unsigned char* recv = (g->n_ingested_delivered++ & 1) ? g->d_recv2 : g->d_recv;
+  const int64_t k = g->n_ingested_delivered;
+  unsigned char* recv = (k & 1) ? g->d_recv2 : g->d_recv;
+  // a sender whose k-th delivery is not what lies in this buffer (it skipped a round, or is a round ahead or behind) has no
+  // message in this round: its slice's header is cleared instead of being ingested stale (the sender id of a cleared slice is
+  // -1, which k_wire_read / the host mirror reject)
+  cgmr_ctx* ctx = g->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t wb = wire_bytes(g->n_robots, g->cap);
+  for (int s = 0; s < g->n_robots; s++) {
+    if (s == g->robot) continue;
+    if (g->recv_round[k & 1][s] != k) HIP_TRY(ctx, hipMemsetAsync(recv + (size_t)s * wb, 0xff, 4, ctx->stream));
+    g->recv_round[k & 1][s] = -1;
+  }
+  g->n_ingested_delivered = k + 1;
   return cgmr_graph_ingest(g, recv, n_edges_out);
 }
 

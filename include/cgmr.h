@@ -436,6 +436,10 @@ int64_t cgmr_graph_wire_bytes(const cgmr_graph* g);
  * cap_edges_per_peer -- the reference's ComboMessage::toCharArray returns 0 for a message beyond MAX_LENGTH_MSG and
  * GraphComm::send skips it (src/mrslam/graph_comm.cpp:112-122, msg_factory.h:115); never an error. */
 int64_t cgmr_graph_skipped_messages(const cgmr_graph* g);
+/* Asynchronous batches of condensed graphs (cgmr_graph_compute_condensed_async) that failed -- Cholesky, or a bounded device-side
+ * wait that ran out -- since the graph was created.  The peers of such a batch get no edges in that round's message (like a lost
+ * UDP packet); the next batch is built regardless, and after a time-out this graph's batches solve level by level. */
+int64_t cgmr_graph_failed_batches(const cgmr_graph* g);
 void* cgmr_graph_send_buffer(cgmr_graph* g);
 void* cgmr_graph_recv_buffer(cgmr_graph* g);
 /* d_send_out NULL = the graph's own send buffer; d_recv NULL = the graph's own receive buffer */

@@ -546,3 +546,42 @@ def test_failed_asynchronous_batch_sends_nothing_and_reports_itself():
     assert e.value.code <= -100
     assert g0.condensed(1)[1].size == 0
     g0.close()                                                     # (the exception info above would keep it alive until interpreter exit)
+
+
+def test_a_failed_batch_does_not_stop_the_next_round_and_a_skipped_delivery_is_no_message():
+    """Round 5 (advisor findings of round 4).  (1) The failure of a batch nobody waited for used to come back from the NEXT
+    cgmr_graph_compute_condensed call, which then built nothing: now the next round is built regardless and the failure is on
+    record (failed_batches).  (2) cgmr_graph_deliver / cgmr_graph_ingest_delivered pair up by call count: a robot that skips a
+    round must not have its previous message ingested again two rounds later -- a buffer that does not hold the expected
+    delivery is ingested as "no message"; a robot cannot deliver to itself or before it has packed anything."""
+    from cg_mrslam_amd import Context
+    from cg_mrslam_amd._lib import CgmrError
+    g = synth.make_pose_graph(400, 1200, seed=11, id_base=0)
+    want = g["ids"][[5, 60, 150, 260, 399]]
+    c0, c1 = Context(0), Context(0)
+    g0 = RobotGraph(c0, 0, 2, async_condense=True)
+    g1 = RobotGraph(c1, 1, 2, async_condense=True)
+    with pytest.raises(CgmrError):
+        g0.deliver(g1)                                             # nothing packed yet
+    with pytest.raises(CgmrError):
+        g0.deliver(g0)
+    g0.add_vertices(g["ids"], g["poses"], g["fixed"])
+    info = g["info"].copy()
+    info[7] = [-1e6, 0, 0, -1e6, 0, -1e6]                          # a negative pivot for certain
+    g0.add_edges(g["ids"][g["edge_from"]], g["ids"][g["edge_to"]], g["meas"], info)
+    g1.add_vertices(np.concatenate([[10000], want]), np.zeros((1 + len(want), 3)), None)
+    g0.insertOutClosure(1, want)
+    assert g0.computeCondensedGraph(1) == 1                        # round 1: queued, fails on the device
+    g0.pack(0); g0.deliver(g1)
+    assert int(g1.ingest_delivered()[0]) == 0                      # nothing of the failed batch travelled
+    # round 2: the bad edge is still there, so this batch fails as well -- but it IS built (round 4 returned round 1's error here)
+    assert g0.computeCondensedGraph(1) == 1
+    assert g0.failed_batches() == 1
+    with pytest.raises(CgmrError):
+        g0.condensed_wait()
+    assert g0.failed_batches() == 2
+    # (2) pairing: g1 has ingested once, g0 has delivered once.  g0 now SKIPS a round (no deliver); g1's second ingest finds the
+    # other buffer without a second delivery -> no message, not a stale one
+    g1.pack(0)
+    assert int(g1.ingest_delivered()[0]) == 0
+    g0.close(); g1.close()
