@@ -486,6 +486,8 @@ def exchange_leg(ctx, rank, world, args, dry=False, solo=False):
     if ex is None:
         class _NoExchange:
             transport, fallback_reason = "none (one robot)", None
+            def diagnostics(self): return {"transport": self.transport, "transport_fallback_reason": None, "world": 1,
+                                           "native_comm_ranks": None, "native_comm_rank": None}
             def start(self): pass
             def finish(self): return None
             def last_collective_seconds(self): return None
@@ -544,10 +546,27 @@ def exchange_leg(ctx, rank, world, args, dry=False, solo=False):
     else:
         smax = ssum = stat
     c = g.counts()
+    # every rank's own account of the exchange (the first multi-GPU run has to explain itself): transport and why, the ranks its
+    # native communicator reports, its sampled all-gather time, its round
+    mine = dict(ex.diagnostics(), rank=rank, device=(None if dry else ctx.device),
+                allgather_device_ms_sampled=(round(1e3 * float(np.mean(t_coll)), 4) if t_coll else None),
+                round_ms_mean=round(1e3 * float(np.mean(t_round)), 3), optimize5_ms_mean=round(1e3 * float(np.mean(t_opt)), 3),
+                condense_ms_mean=round(1e3 * float(np.mean(t_cond)), 3),
+                backward_solve_timeouts=(ctx.gn_timeouts() if not dry else None),
+                failed_condensed_batches=(g.failed_batches() if not dry else None), status=int(rr.last_status))
+    per_rank = [mine]
+    if have_pg:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    transports = sorted({d["transport"] for d in per_rank})
     out = {"workload": (f"C5 solo: one robot x {args.c5_vertices} vertices / {args.c5_edges} edges grown {args.c5_chunk} at a time, optimize(5) per round, no peers"
                         if nrob == 1 else
                         f"C5: {world} robots x {args.c5_vertices} vertices / {args.c5_edges} edges, a round every {args.c5_chunk} vertices"),
-           "robots": nrob, "rounds": n_rounds, "transport": ex.transport, "transport_fallback_reason": ex.fallback_reason,
+           "robots": nrob, "rounds": n_rounds, "transport": (transports[0] if len(transports) == 1 else "MIXED: " + ", ".join(transports)),
+           "transport_fallback_reason": next((d["transport_fallback_reason"] for d in per_rank if d["transport_fallback_reason"]), None),
+           "transport_is_native_rccl_on_every_rank": (all(d["transport"] == "rccl" and d["native_comm_ranks"] == world for d in per_rank)
+                                                      if nrob > 1 else None),
+           "ranks": (per_rank if nrob > 1 else None),
            "messages_skipped_over_capacity_total": int(ssum[7]),
            "ingest_staleness_rounds": (1 if nrob > 1 else None),     # by design: the all-gather of round t is ingested in round t + 1
            "symbolic_cache": ({k: int(v) for k, v in ctx.symbolic_cache_stats().items()} if not dry else None),
@@ -716,6 +735,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exchange["solo_round_ms_mean_max"] = round(float(t.item()), 3)
         exchange["weak_scaling_efficiency_vs_solo"] = round(float(t.item()) / exchange["round_ms_mean_max"], 4)
+        # ... and per rank (its own solo rounds against its own rounds with peers)
+        solos = [None] * world
+        dist.all_gather_object(solos, solo["round_ms_mean_max"])
+        for d in exchange["ranks"]:
+            d["solo_round_ms_mean"] = solos[d["rank"]]
+            d["weak_scaling_efficiency_vs_solo"] = round(solos[d["rank"]] / d["round_ms_mean"], 4) if d["round_ms_mean"] else None
+        if not exchange["transport_is_native_rccl_on_every_rank"] and dist.get_backend() == "nccl":
+            # a rank that fell back must not pass unnoticed: the line says so at its top level as well
+            exchange["WARNING"] = ("the exchange did not run on the native RCCL communicator on every rank (see ranks[].transport / "
+                                   "transport_fallback_reason); the all-gather figures are those of the fallback transport")
 
     # every rank's helper pool as the library runs it (ranks of one node take different cache groups: LOCAL_RANK)
     host_pools = None

@@ -340,6 +340,18 @@ class Exchange:
             raise CgmrError(res.get("rc", -1), g.ctx.lib.cgmr_last_error(g.ctx.h).decode())
         self.comm = comm
 
+    def diagnostics(self) -> dict:
+        """What this rank's exchange runs on, for a multi-GPU run's own report: the transport, why it is not the native one (if so),
+        and how many ranks the native communicator itself reports (``ncclCommCount``)."""
+        d = {"transport": self.transport, "transport_fallback_reason": self.fallback_reason, "world": self.world,
+             "native_comm_ranks": None, "native_comm_rank": None}
+        if self.transport == "rccl" and self.comm is not None:
+            out = np.zeros(3, dtype=np.int32)
+            if self.g.lib.cgmr_comm_info(self.comm, _p(out)) == 0:
+                d["native_comm_ranks"], d["native_comm_rank"] = int(out[0]), int(out[1])
+                d["native_comm_answered_by_librccl"] = bool(out[2])
+        return d
+
     def _destroy_comm(self):
         if self.comm is not None:
             self.g.lib.cgmr_comm_destroy.restype = None

@@ -28,6 +28,7 @@ typedef int (*fn_comm_init_rank)(ncclComm_t*, int, ncclUniqueId_t, int);
 typedef int (*fn_comm_destroy)(ncclComm_t);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
 typedef const char* (*fn_get_error_string)(int);
+typedef int (*fn_comm_count)(const ncclComm_t, int*);
 
 struct Rccl {
   void* handle = nullptr;
@@ -36,6 +37,7 @@ struct Rccl {
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_gather all_gather = nullptr;
   fn_get_error_string get_error_string = nullptr;
+  fn_comm_count comm_count = nullptr, comm_user_rank = nullptr;      // (diagnostics only: may be absent)
   bool ok = false;
 };
 
@@ -54,6 +56,8 @@ Rccl& rccl() {
     r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
     r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
     r.get_error_string = (fn_get_error_string)dlsym(r.handle, "ncclGetErrorString");
+    r.comm_count = (fn_comm_count)dlsym(r.handle, "ncclCommCount");
+    r.comm_user_rank = (fn_comm_count)dlsym(r.handle, "ncclCommUserRank");
     r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather;
     return r;
   }();
@@ -164,6 +168,20 @@ int cgmr_comm_last_seconds(cgmr_comm* comm, double* seconds) {
   float ms = 0;
   if (hipEventElapsedTime(&ms, comm->t0, comm->t1) != hipSuccess) return CGMR_E_HIP;
   *seconds = 1e-3 * ms;
+  return CGMR_OK;
+}
+
+// What the communicator itself says it is (ncclCommCount / ncclCommUserRank): out[0] = ranks, out[1] = this rank's index,
+// out[2] = 1 if both came from librccl, 0 if the library lacks the queries and the values are those given to cgmr_comm_create.
+// For a multi-GPU run's own report: a rank whose communicator does not span the whole world says so.
+int cgmr_comm_info(cgmr_comm* comm, int32_t out[3]) {
+  if (!comm || !out) return CGMR_E_INVALID;
+  out[0] = comm->n_ranks; out[1] = comm->rank; out[2] = 0;
+  Rccl& R = rccl();
+  int n = -1, r = -1;
+  if (R.comm_count && R.comm_user_rank && comm->comm && R.comm_count(comm->comm, &n) == 0 && R.comm_user_rank(comm->comm, &r) == 0) {
+    out[0] = n; out[1] = r; out[2] = 1;
+  }
   return CGMR_OK;
 }
 

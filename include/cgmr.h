@@ -488,6 +488,9 @@ void cgmr_comm_destroy(cgmr_comm* comm);
 int cgmr_allgather_condensed(cgmr_ctx* ctx, cgmr_comm* comm, const void* d_send, size_t bytes_per_rank, void* d_recv);
 int cgmr_ctx_join_side(cgmr_ctx* ctx);
 int cgmr_comm_wait(cgmr_ctx* ctx, cgmr_comm* comm);
+/* What the communicator says it is: out[0] = ranks (ncclCommCount), out[1] = this rank (ncclCommUserRank), out[2] = 1 if librccl
+ * answered, 0 if the values are the ones given to cgmr_comm_create.  For a multi-GPU run's own report. */
+int cgmr_comm_info(cgmr_comm* comm, int32_t out[3]);
 int cgmr_comm_last_seconds(cgmr_comm* comm, double* seconds);
 
 /* ------------------------------------------------------------------ occupancy map

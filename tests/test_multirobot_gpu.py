@@ -289,6 +289,8 @@ def test_native_rccl_allgather_single_rank(ctx):
     comm = C.c_void_p()
     assert lib.cgmr_comm_create(ctx.h, C.c_int(1), C.c_int(0), C.c_void_p(uid.ctypes.data), C.byref(comm)) == 0, \
         lib.cgmr_last_error(ctx.h)
+    info = np.zeros(3, dtype=np.int32)
+    assert lib.cgmr_comm_info(comm, C.c_void_p(info.ctypes.data)) == 0 and list(info[:2]) == [1, 0]     # what librccl itself reports
     g = RobotGraph(ctx, 0, 1)
     g.add_vertices([0, 1, 2], np.zeros((3, 3)), [1, 0, 0])
     g.insertInClosure(0, [1, 2])
@@ -367,6 +369,15 @@ def test_bench_eight_ranks_on_one_gpu():
     assert ex["bytes_gathered_per_rank_per_round"] == 8 * (4 * (2 + 16) + 8 * 128 * 44 + 8 * 128 * 4)
     assert ex["condensed_graphs_built_total"] > 0 and ex["condensed_edges_received_total"] > 0 and ex["status_rank0"] == 0
     assert ex["messages_skipped_over_capacity_total"] == 0 and 0 < ex["weak_scaling_efficiency_vs_solo"] < 2
+    # every rank accounts for itself (round 5: the first multi-GPU run has to be self-diagnosing): transport and why, the ranks its
+    # native communicator reports, its sampled all-gather time, its own weak-scaling figure
+    ranks = ex["ranks"]
+    assert len(ranks) == 8 and sorted(d["rank"] for d in ranks) == list(range(8))
+    for d in ranks:
+        assert d["transport"] == "host" and d["transport_fallback_reason"] is None and d["native_comm_ranks"] is None
+        assert d["world"] == 8 and d["round_ms_mean"] > 0 and d["solo_round_ms_mean"] > 0 and 0 < d["weak_scaling_efficiency_vs_solo"] < 2
+        assert d["status"] == 0 and d["failed_condensed_batches"] == 0
+    assert ex["transport_is_native_rccl_on_every_rank"] is False and "WARNING" not in ex      # (gloo on purpose: nothing to warn about)
     pools = out["host_pool_of_every_rank"]
     assert len(pools) == 8 and sorted(q["rank"] for q in pools) == list(range(8))
     pinned = [q for q in pools if q["pinned"]]
