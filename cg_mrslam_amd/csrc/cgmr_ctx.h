@@ -68,6 +68,8 @@ struct cgmr_ctx {
   double trace_sum[4] = {0, 0, 0, 0};
   double match_seconds = 0;
   int64_t match_pairs = 0, match_slow_pairs = 0;   // last batched close-matching launch: pairs, pairs off the LDS fast path
+  int64_t match_ext_pairs = 0;                     // ... pairs whose reference tiles borrowed half the point lists (NT_EXT)
+  int64_t match_redo_why[3] = {0, 0, 0};           // ... by cause: grid, window / point count, an angle's lists
   int64_t match_redo_pairs = 0;                    // ... pairs the lean kernel instance handed to the general one
   bool profiling = false;
   double ksec[8] = {0};

@@ -174,13 +174,16 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   const char* tab = ctx->mtab_arena.ptr;
   // ---- device work space: error / work-counter words, the split pairs' shared bins + arrival counters, scratch
   Layout L;
-  size_t o_err = L.add(16);
+  size_t o_err = L.add(128);                                      // two blocks of 16 words: the main launch and its redo launch, the slow pairs' launch
   const size_t merge_bytes = P.split > 1 ? (size_t)n_pairs * (match_close_max_bins() * 8 + 8) : 0;
   // the lean instances of the kernel (matcher_kernels.hip: k_match_close_batch<1 / 2>) take the shape the batch is normally run in;
   // pairs they cannot take come back on a list and go through the general kernel behind them
   static const bool lean_on = !(getenv("CGMR_MATCH_LEAN") && atoi(getenv("CGMR_MATCH_LEAN")) == 0);
   const bool lean = lean_on && match_close_lean_ok(P);
-  size_t o_merge = L.add(merge_bytes), o_redo = L.add(lean ? sizeof(int) * (size_t)n_pairs : 0),
+  // (pairs a lean instance found slow to search are spread over kSlowSplit workgroups each, kSlowChunk pairs per launch)
+  constexpr int kSlowSplit = 16, kSlowChunk = 256;
+  const size_t slow_merge_bytes = lean ? (size_t)kSlowChunk * (match_close_max_bins() * 8 + 8) : 0;
+  size_t o_merge = L.add(merge_bytes), o_redo = L.add(lean ? sizeof(int) * (size_t)n_pairs : 0), o_smerge = L.add(slow_merge_bytes),
          o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
   int rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
   if (rc) return rc;
@@ -191,7 +194,9 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));               // (the pinned block of the previous call may still be in flight)
   int* h_err = (int*)ctx->pinned;
   h_err[0] = 0; h_err[1] = nblocks; h_err[2] = 0; h_err[3] = 0;   // [1] work counter: the first nblocks items are taken by blockIdx
-  HIP_TRY(ctx, hipMemcpyAsync(d + o_err, h_err, 16, hipMemcpyHostToDevice, ctx->stream));
+  for (int i = 4; i < 16; i++) h_err[i] = 0;                      // [4..6] why pairs went to the redo list, [7] borrowed-pool pairs, [8] slow list
+  for (int i = 16; i < 32; i++) h_err[i] = 0;                     // (the second block: zero unless slow pairs get their own launch)
+  HIP_TRY(ctx, hipMemcpyAsync(d + o_err, h_err, 128, hipMemcpyHostToDevice, ctx->stream));
   if (io_in) {
     memcpy(ctx->pinned + 256, io->h_in, io_in);
     HIP_TRY(ctx, hipMemcpyAsync(io->d_in, ctx->pinned + 256, io_in, hipMemcpyHostToDevice, ctx->stream));
@@ -205,25 +210,43 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
                            (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
                            d_xyt, d_score, d_found, d_nres, (int*)(d + o_err), (unsigned long long*)(d + o_merge),
                            (int*)(d + o_merge + (size_t)n_pairs * match_close_max_bins() * 8), lean ? (int*)(d + o_redo) : nullptr);
-  int* errv = (int*)(ctx->pinned + 64);
+  int* errv = (int*)(ctx->pinned + 128);                            // (read-back of both blocks)
   if (lean) {
     // pairs left over (err[3]; their indices in the redo list): the general kernel takes them from the list.  The count is needed
     // on the host only to skip the second launch -- normally there is nothing to do
-    HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->match_redo_pairs = errv[3];
+    const int n_redo = errv[3], n_slow = errv[8];
+    ctx->match_redo_pairs = (int64_t)n_redo + n_slow;
+    for (int i = 0; i < 3; i++) ctx->match_redo_why[i] = errv[4 + i];
     static const bool no_redo = getenv("CGMR_MATCH_NOREDO") && atoi(getenv("CGMR_MATCH_NOREDO")) != 0;   // (profiling the lean instance alone)
-    if (errv[0] == 0 && errv[3] > 0 && !no_redo) {
-      h_err[0] = 0; h_err[1] = std::min(errv[3], ctx->n_cus); h_err[2] = 0; h_err[3] = errv[3];
+    if (errv[0] == 0 && n_redo > 0 && !no_redo) {
+      h_err[0] = 0; h_err[1] = std::min(n_redo, ctx->n_cus); h_err[2] = 0; h_err[3] = n_redo;
       HIP_TRY(ctx, hipMemcpyAsync(d + o_err, h_err, 16, hipMemcpyHostToDevice, ctx->stream));
       launch_match_close_batch(ctx->stream, h_err[1], 0, P, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
                                (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
                                d_xyt, d_score, d_found, d_nres, (int*)(d + o_err), (unsigned long long*)(d + o_merge),
                                (int*)(d + o_merge + (size_t)n_pairs * match_close_max_bins() * 8), (int*)(d + o_redo));
     }
-  } else ctx->match_redo_pairs = 0;
+    // the slow pairs (the back of the list), kSlowSplit workgroups each: the single call's way of sharing a pair
+    MatchParams Ps = P;
+    Ps.split = kSlowSplit;
+    int* h_err2 = (int*)(ctx->pinned + 64);
+    for (int s0 = 0; errv[0] == 0 && s0 < n_slow && !no_redo; s0 += kSlowChunk) {
+      const int ns = std::min(kSlowChunk, n_slow - s0);
+      if (s0) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // (h_err2 is read by the previous chunk's copy)
+      h_err2[0] = 0; h_err2[1] = std::min(ns * kSlowSplit, nblocks); h_err2[2] = 0; h_err2[3] = ns;
+      HIP_TRY(ctx, hipMemcpyAsync(d + o_err + 64, h_err2, 16, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(d + o_smerge, 0xff, slow_merge_bytes, ctx->stream));
+      launch_match_close_batch(ctx->stream, h_err2[1], 0, Ps, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
+                               (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
+                               d_xyt, d_score, d_found, d_nres, (int*)(d + o_err + 64), (unsigned long long*)(d + o_smerge),
+                               (int*)(d + o_smerge + (size_t)kSlowChunk * match_close_max_bins() * 8),
+                               (int*)(d + o_redo) + (n_pairs - s0 - ns));
+    }
+  } else ctx->match_redo_pairs = ctx->match_redo_why[0] = ctx->match_redo_why[1] = ctx->match_redo_why[2] = 0;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 128, hipMemcpyDeviceToHost, ctx->stream));
   char* h_out_stage = ctx->pinned + 256 + io_in + ((256 - io_in % 256) % 256);
   if (io_out) HIP_TRY(ctx, hipMemcpyAsync(h_out_stage, io->d_out, io_out, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -233,7 +256,9 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->match_seconds = 1e-3 * ms;
   ctx->match_pairs = n_pairs;
-  ctx->match_slow_pairs = errv[2];
+  ctx->match_slow_pairs = errv[2] + (int64_t)errv[16 + 2];         // (second block: the slow pairs' own launch; zero when there was none)
+  ctx->match_ext_pairs = errv[7] + (int64_t)errv[16 + 7];
+  if (errv[0] == 0) errv[0] = errv[16];
   if (errv[0] != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel rejected the search (code %d: window/bins too large)", errv[0]);
   return CGMR_OK;
 }
@@ -360,6 +385,13 @@ int cgmr_match_last_stats(const cgmr_ctx* ctx, int64_t out[2]) {
 int cgmr_match_last_redo_pairs(const cgmr_ctx* ctx, int64_t* out) {
   if (!ctx || !out) return CGMR_E_INVALID;
   *out = ctx->match_redo_pairs;
+  return CGMR_OK;
+}
+
+int cgmr_match_last_path_counts(const cgmr_ctx* ctx, int64_t out[4]) {
+  if (!ctx || !out) return CGMR_E_INVALID;
+  out[0] = ctx->match_ext_pairs;
+  for (int i = 0; i < 3; i++) out[1 + i] = ctx->match_redo_why[i];
   return CGMR_OK;
 }
 

@@ -46,6 +46,9 @@ constexpr int CB_THREADS = 64 * NTH;            // workgroup size of k_match_clo
 constexpr int GR_WAVES = 8;                  // wavefronts of k_match_greedy (512 threads: the rasteriser and an item's gathers both scale with them)
 constexpr int GR_THREADS = 64 * GR_WAVES;
 constexpr int LISTCAP = 704;                 // kept points per angle on the fast path (more -> generic path)
+// A reference scan that claims more tiles than the pool holds (80 m of wall inside the grid) borrows the first half of the point lists,
+// which lie right behind the pool: half the wavefronts search then, with the other half's lists (k_match_close_batch, one reference scan)
+constexpr int NT_EXT = NT_LDS + (NTH / 2) * LISTCAP * 4 / 64;
 constexpr int PT = 4;                        // points gathered per inner iteration of the fast search path
 constexpr int CAND_U = 9;                    // candidates per lane per block (64*9 = 576 = 24x24)
 constexpr int MAXBINS = 128;                  // close matching: 0.6 m / 0.5 m bins x 0.4 rad / 0.2 rad -> at most 27
@@ -71,6 +74,8 @@ struct Smem {
   uint8_t binx[32], biny[32], bint[MAXTHETA]; // fast search path: result bin of an x offset (times nby), of a y offset, of an angle
 };
 static_assert((sizeof(uint16_t) * kMatchMaxDir) % 16 == 0, "tile pool must stay 16-byte aligned behind the directory");
+static_assert(offsetof(Smem, plist) == offsetof(Smem, tiles) + sizeof(uint32_t) * NT_LDS * 16 && ((NTH / 2) * LISTCAP * 4) % 64 == 0,
+              "the point lists extend the tile pool");
 // block_scan_excl scratch (one int per thread + total): the last point list, idle whenever a scan runs
 __device__ __forceinline__ int* scan_scratch(Smem& S) { return reinterpret_cast<int*>(S.plist[NTH - 1]); }
 static_assert(LISTCAP >= 516, "scan scratch needs 516 ints");
@@ -353,10 +358,11 @@ __device__ __forceinline__ void stamp_word(uint32_t* wp, uint32_t kv) {
 
 // resetGrid + addAndConvolvePoints for n packed reference cells: tiles claimed and numbered by the points that reach them,
 // then the distance-transform rasteriser or compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
-// LEAN: the distance transform only; a grid that needs anything else leaves S.misc[12] = 2 (the pair goes to the general kernel).
+// LEAN: the distance transform, plus the stamps of cells off the grid that reach in (the plain loop); a grid that needs anything else
+// leaves S.misc[12] = 2 (the pair goes to the general kernel).
 template <bool LEAN>
 __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
-                           int* err) {
+                           int* err, const int ncap = NT_LDS) {
   const int tid = threadIdx.x;
   const int NTHR = blockDim.x;
   const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
@@ -371,8 +377,8 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   // to run, nothing that is computed depends on it).  Round 2 numbered them in directory order: two serial walks over the
   // 24k-entry directory per thread and a block scan, 30k cycles per pair.
   uint16_t* const tile_slot = reinterpret_cast<uint16_t*>(&S.totals[0][0]);       // tile -> directory slot    (idle until the search)
-  uint32_t* const claimed = reinterpret_cast<uint32_t*>(tile_slot + NT_LDS);       // one bit per directory slot (the same)
-  static_assert(NT_LDS * 2 + (kMatchMaxDir + 31) / 32 * 4 <= (int)sizeof(S.totals) && (NT_LDS & 1) == 0, "tile_slot + claim bits");
+  uint32_t* const claimed = reinterpret_cast<uint32_t*>(tile_slot + NT_EXT);       // one bit per directory slot (the same)
+  static_assert(NT_EXT * 2 + (kMatchMaxDir + 31) / 32 * 4 <= (int)sizeof(S.totals) && (NT_EXT & 1) == 0, "tile_slot + claim bits");
   for (int q = tid; q < (ndir + 7) / 8; q += NTHR) reinterpret_cast<uint4*>(S.dir)[q] = make_uint4(0u, 0u, 0u, 0u);
   for (int q = tid; q < (ndir + 31) / 32; q += NTHR) claimed[q] = 0u;
   if (tid == 0) { S.misc[0] = 0; S.misc[15] = 0; }
@@ -413,7 +419,7 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
           if (atomicOr(&claimed[e >> 5], bit) & bit) continue;
           const int id = 2 + atomicAdd(&S.misc[0], 1);
           S.dir[e] = (uint16_t)id;
-          if (id < NT_LDS) {
+          if (id < ncap) {
             tile_slot[id] = (uint16_t)e;
             if (edt_maps) { S.tiles[id * 16] = 0u; S.tiles[id * 16 + 1] = 0u; }
           }
@@ -424,14 +430,14 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   const int ntile = S.misc[0];                                     // tiles 2 .. ntile + 1
   // fast path: every tile is resident in LDS and the grid is a whole number of tiles, so the search can gather without
   // branches: untouched directory entries point at the all-fill tile, cells outside the grid at the all-zero tile.
-  const bool fast = allow_fast && (ntile + 2 <= NT_LDS) && ((P.nx & 7) == 0) && ((P.ny & 7) == 0) &&
+  const bool fast = allow_fast && (ntile + 2 <= ncap) && ((P.nx & 7) == 0) && ((P.ny & 7) == 0) &&
                     P.x_steps == 1 && P.y_steps == 1 && K2 * PT <= 255;
   if (tid == 0) S.misc[12] = fast ? 1 : 0;
-  if (ntile + 2 > NT_LDS + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
-  const bool edt = P.edt && ntile + 2 <= NT_LDS && ntile > 0;
+  if (ntile + 2 > ncap + P.overflow_tiles && tid == 0) atomicExch(err, 2);   // cannot happen: pool sized for the worst case
+  const bool edt = P.edt && ntile + 2 <= ncap && ntile > 0;
   if (!LEAN && !edt) {                                                      // (the distance transform writes every cell of every tile)
-    for (int q = 32 + tid; q < min(ntile + 2, NT_LDS) * 16; q += NTHR) S.tiles[q] = fill4;
-    for (int q = tid; q < max(0, ntile + 2 - NT_LDS) * 16; q += NTHR) gtiles[q] = fill4;
+    for (int q = 32 + tid; q < min(ntile + 2, ncap) * 16; q += NTHR) S.tiles[q] = fill4;
+    for (int q = tid; q < max(0, ntile + 2 - ncap) * 16; q += NTHR) gtiles[q] = fill4;
   }
   __syncthreads();
   MPHASE(4);
@@ -487,7 +493,7 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     };
     // (2) one tile per thread and round: the three maps once, x rows 1..7 straight into the tile; x row 0 takes the place of
     // the map and waits in registers for the barrier
-    constexpr int R0 = (NT_LDS + 255) / 256;                       // tiles per thread, whatever the workgroup size
+    constexpr int R0 = (NT_EXT + 255) / 256;                       // tiles per thread, whatever the workgroup size
     uint32_t r0w[R0][2];
 #pragma unroll
     for (int u = 0; u < R0; u++) {
@@ -575,10 +581,10 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
       reinterpret_cast<uint4*>(S.tiles)[w] = reinterpret_cast<const uint4*>(gtiles)[w];
     __syncthreads();
     MPHASE(21);
-    if (!LEAN && S.misc[15] == 0) return;                                   // (no reference cell's stamp reaches in from outside the grid: done)
+    if (S.misc[15] == 0) return;                                   // (no reference cell's stamp reaches in from outside the grid: done)
   }
-  if (LEAN) {                                                      // the lean instances leave the stamping to the general kernel
-    if (tid == 0 && (!edt || S.misc[15] != 0)) S.misc[12] = 2;
+  if (LEAN && !edt) {                                              // the lean instances leave grids without the distance transform to the general kernel
+    if (tid == 0 && fast) S.misc[12] = 2;                          // (0 stays 0: tiles beyond LDS, the slow search)
     __syncthreads();
     return;
   }
@@ -607,7 +613,7 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     if (x < 0 || x >= P.nx) continue;
     int y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
     if (y0 > y1) continue;
-    if (kcols && ry - ctr >= 0 && ry + ctr < P.ny) {
+    if (!LEAN && kcols && ry - ctr >= 0 && ry + ctr < P.ny) {
       // the whole column lies inside the grid: its words come from the padded kernel column
       const uint32_t* kc = reinterpret_cast<const uint32_t*>(&S.kernel[kKcolOff + ki * 32]);
       const uint4 ka = *reinterpret_cast<const uint4*>(kc), kb = *reinterpret_cast<const uint4*>(kc + 4);
@@ -626,8 +632,8 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
         const int wy = wy0 + 4 * k;
         const int d = S.dir[drow + (wy >> 3)];
         const int woff = wx + ((wy & 7) >> 2);
-        if (d < NT_LDS) stamp_word(&S.tiles[d * 16 + woff], kv);
-        else stamp_word(&gtiles[(size_t)(d - NT_LDS) * 16 + woff], kv);
+        if (d < ncap) stamp_word(&S.tiles[d * 16 + woff], kv);
+        else stamp_word(&gtiles[(size_t)(d - ncap) * 16 + woff], kv);
       }
       continue;
     }
@@ -642,8 +648,8 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
       int d = S.dir[((x >> 3) + 1) * DW + (wy >> 3) + 3];
       int woff = (x & 7) * 2 + ((wy & 7) >> 2);
       // two separate loops so that each keeps its address space (no flat pointers)
-      if (d < NT_LDS) stamp_word(&S.tiles[d * 16 + woff], kv);
-      else stamp_word(&gtiles[(size_t)(d - NT_LDS) * 16 + woff], kv);
+      if (d < ncap) stamp_word(&S.tiles[d * 16 + woff], kv);
+      else stamp_word(&gtiles[(size_t)(d - ncap) * 16 + woff], kv);
     }
   }
   __syncthreads();
@@ -651,9 +657,9 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
 
 // one byte of tile d (LDS pool or HBM overflow).  The LDS read is unconditional (clamped index) and the HBM read
 // conditional, so that neither becomes a flat access through a merged pointer.
-__device__ __forceinline__ int tile_byte(const Smem& S, const uint32_t* gtiles, int d, int boff) {
-  int v = reinterpret_cast<const uint8_t*>(S.tiles)[min(d, NT_LDS - 1) * 64 + boff];
-  if (d >= NT_LDS) v = reinterpret_cast<const uint8_t*>(gtiles)[(size_t)(d - NT_LDS) * 64 + boff];
+__device__ __forceinline__ int tile_byte(const Smem& S, const uint32_t* gtiles, int d, int boff, const int ncap = NT_LDS) {
+  int v = reinterpret_cast<const uint8_t*>(S.tiles)[min(d, ncap - 1) * 64 + boff];
+  if (d >= ncap) v = reinterpret_cast<const uint8_t*>(gtiles)[(size_t)(d - ncap) * 64 + boff];
   return v;
 }
 
@@ -849,10 +855,11 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
   // batch of angles; the per-bin minima meet in a global table (atomicMin on the same 64-bit keys: score bits << 32 |
   // visit order, the visit order counted over ALL angles, so "first seen wins" holds across workgroups) and the
   // workgroup that arrives last produces the result.
-  const bool from_list = !LEAN && redo_list != nullptr;           // (the general kernel behind a lean one: split == 1)
-  const int n_items = from_list ? err[3] : P.n_pairs * P.split;
+  const bool from_list = !LEAN && redo_list != nullptr;           // (the general kernel behind a lean one: units = list entries)
+  const int n_items = (from_list ? err[3] : P.n_pairs) * P.split;
   for (int item = blockIdx.x; item < n_items;) {
-    const int pair = from_list ? redo_list[item] : item / P.split, part = from_list ? 0 : item - (item / P.split) * P.split;
+    const int unit = item / P.split, part = item - unit * P.split;     // (unit: the slot of a split pair's shared bins)
+    const int pair = from_list ? redo_list[unit] : unit;
     __syncthreads();
     MPHASE(0);
 #ifdef CGMR_PHASE_TIMING
@@ -868,7 +875,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     // ---------------- reference scan -> cells -----------------------------------------------------------------
     // a single scan's cells fit the (still idle) point lists in LDS; a multi-scan set goes through the HBM scratch
     const int NS = P.n_ref_scans;
-    uint32_t* rcell_l = S.plist[0];         // int16 x | int16 y << 16, 0x80008000 = invalid
+    // (in the second half of the lists: the first half may become tiles, see NT_EXT)
+    uint32_t* rcell_l = S.plist[NTH / 2];   // int16 x | int16 y << 16, 0x80008000 = invalid
     for (int i = tid; i < NS * B; i += CB_THREADS) {
       const int sc = i / B, bm = i - sc * B;
       uint32_t packed = 0x80008000u;
@@ -889,8 +897,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     if (LEAN || NS == 1) {
       // valid beams whose cell differs from the previous beam's, compacted behind the raw list (the rasteriser's work
       // items are (point, kernel row): a quarter of the raw list's items would be skipped one by one)
-      uint32_t* const cl1 = &S.plist[2][0];
-      static_assert(2 * LISTCAP >= MAXPTS && NTH >= 5, "compacted single-scan list");
+      uint32_t* const cl1 = &S.plist[NTH / 2 + 2][0];
+      static_assert(2 * LISTCAP >= MAXPTS && NTH == 8, "raw and compacted single-scan lists: two point lists each");
       if (tid == 0) S.misc[14] = 0;
       __syncthreads();
       for (int i = tid; i < B; i += CB_THREADS) {
@@ -952,10 +960,14 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       __syncthreads();
     }
     // one call for all three shapes of the cell list (LDS or the HBM scratch: the rasteriser reads it through a generic pointer)
-    build_grid<LEAN>(S, P, gcells, gn, gtiles, /*allow_fast=*/true, err);
+    // a scan with more subsampled points than one list holds: half the wavefronts search, with two lists each
+    const bool wide = nq > LISTCAP - 12;                           // (the lists' padding: 2 * PT entries, or two per class of the fast path and an even split)
+    const int ncap = (LEAN || NS == 1) ? NT_EXT : NT_LDS;          // (the cell list sits in the second half of the lists)
+    build_grid<LEAN>(S, P, gcells, gn, gtiles, /*allow_fast=*/true, err, ncap);
     const bool fast = S.misc[12] == 1;
+    const bool ovf = ncap > NT_LDS && S.misc[0] + 2 > NT_LDS;      // tiles in the first four lists: wavefronts 0..3 search with lists 4..7
     bool redo = LEAN && !fast;                                // a lean instance: this pair is the general kernel's
-    if (!LEAN && !fast && tid == 0) atomicAdd(err + 2, 1);    // pairs whose tiles did not fit LDS (generic search path)
+    if (!LEAN && !fast && part == 0 && tid == 0) atomicAdd(err + 2, 1);    // pairs whose tiles did not fit LDS (generic search path)
     MPHASE(5);
     // ---------------- search window, angle table, bins -----------------------------------------------------
     if (tid == 0) {
@@ -1009,20 +1021,23 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     __syncthreads();
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
-    // a scan with more subsampled points than one list holds: half the wavefronts search, with two lists each
-    const bool wide = nq > LISTCAP - 12;                           // (the lists' padding: 2 * PT entries, or two per class of the fast path and an even split)
-    const int nsearch = wide ? NTH / 2 : NTH;
-    uint32_t* const pl = &S.plist[0][0] + (wide ? 2 * wave : wave) * LISTCAP;
-    // list entries of the fast path carry LDS addresses of the directory in 16 bits (gather_class)
-    const uint32_t lds_dir = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.dir);
-    const uint32_t lds_tiles = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.tiles);
+    // (long walls make both happen at once: two wavefronts search then, with the last four lists)
+    const int nsearch = (ovf ? NTH / 2 : NTH) >> (wide ? 1 : 0);
+    const int my_list = (ovf ? NTH / 2 : 0) + (wave & (nsearch - 1)) * (wide ? 2 : 1);
+    uint32_t* const pl = &S.plist[0][0] + my_list * LISTCAP;
+    // list entries of the fast path carry LDS addresses of the directory in 16 bits (gather_class). LDS byte addresses come from the
+    // array's own address plus a member offset: a generic-to-LDS cast of a member address stays an unfolded constant expression in some
+    // instances and trips the compiler's null check of it ("illegal instruction: V_CMP_NE_U32 0, src_shared_base")
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+    const uint32_t lds_dir = (lds_base + (uint32_t)offsetof(Smem, dir));
+    const uint32_t lds_tiles = (lds_base + (uint32_t)offsetof(Smem, tiles));
     // (the wavefront's list as an LDS byte address: from the array, not from pl -- a generic-to-LDS cast of pl made the lean exhaustive
     // instance trip an "illegal instruction" in the compiler's null check)
-    const uint32_t pl_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.plist) +
-                            4u * (uint32_t)LISTCAP * (uint32_t)(wide ? 2 * wave : wave);
-    const uint32_t lds_bins = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(S.bins);
+    const uint32_t pl_lds = (lds_base + (uint32_t)offsetof(Smem, plist)) +
+                            4u * (uint32_t)LISTCAP * (uint32_t)my_list;
+    const uint32_t lds_bins = (lds_base + (uint32_t)offsetof(Smem, bins));
     const bool prune = VARIANT == 2 ? true : (VARIANT == 1 ? false : P.prune != 0);
-    const bool v2 = fast && !wide && nj <= 24 && ni <= 12 * RPL && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u && K2 * PPI <= 255 &&
+    const bool v2 = fast && !wide && nj <= 32 && ni <= 32 && lds_dir + 2u * (uint32_t)kMatchMaxDir <= 0x10000u && K2 * PPI <= 255 &&
                     K2 * (nq + 2 * PPI * GRP) < 65536;          // (16-bit totals; a scan that needs two lists per wavefront takes the any-window path)
     if (LEAN && !v2) redo = true;
     if (LEAN && tid == 0) S.misc[13] = 0;                         // (set by an angle whose lists do not fit)
@@ -1033,6 +1048,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     // The workgroup's angles -- the batches bi = part, part + split, .. of nsearch angles, in that order -- are handed to
     // its wavefronts one at a time through a counter: an angle with rows left for the second pass takes several times as
     // long as a dead one, and with a fixed angle-to-wavefront map the others waited for the unlucky wavefront at the end.
+    const int LOX = lo_x, LOY = lo_y, NI = ni, NJ = nj, NCAND = ncand;    // the whole window (the fast path may search it in sub-windows)
     const int nbat = (nth + nsearch - 1) / nsearch;
     const int my_batches = redo ? 0 : (part < nbat ? (nbat - 1 - part) / P.split + 1 : 0);
     if (tid == 0) S.misc[14] = 0;                                 // (the compaction counter of the grid phase: free now)
@@ -1045,6 +1061,15 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
       const int bi = part + P.split * (sq / nsearch);
       const int tb = nsearch * ((bi & 1) ? (nbat - 1) / 2 + (bi + 1) / 2 : (nbat - 1) / 2 - bi / 2);
       const int ti = min(tb + sq % nsearch, nth);
+      // The fast path searches windows of at most 24 x 24 offsets (a lane's 24 cells of a tile row, two rows per lane of twelve).
+      // The close matcher's window is 0.6 m = 24 cells, but its two corners are rounded to cells separately (gridmap.h:24-33), so one
+      // pair in eighty has 25 offsets along x or y: such a window is searched as two (four) overlapping sub-windows of 24 -- the
+      // offsets they share are evaluated twice, to the same keys -- instead of on the any-window path, which took 2.9 ms for such
+      // a pair and a fifth of a batch's time for the 1.2 % of them.
+      const int nsub = v2 ? ((NI > 24 ? 2 : 1) * (NJ > 24 ? 2 : 1)) : 1;
+      for (int sw = 0; sw < nsub; sw++) {
+      const int sa0 = (v2 && NI > 24 && (sw & 1)) ? NI - 24 : 0, sb0 = (v2 && NJ > 24 && (NI > 24 ? (sw >> 1) : sw)) ? NJ - 24 : 0;
+      const int lo_x = LOX + sa0, lo_y = LOY + sb0, ni = v2 ? min(NI, 24) : NI, nj = v2 ? min(NJ, 24) : NJ, ncand = ni * nj;
       int k = 0;
       int2 cls[NCL] = {};                       // fast path: the class lists: LDS byte address of entry 0, count (classes 1, 3 grow downwards)
       bool fv2 = v2;                            // this angle takes the fast path
@@ -1421,9 +1446,10 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
           float dsum = (float)total * ikscale;
           dsum = k ? (float)((double)dsum / (double)k) : (float)(P.max_score + 1);
           if ((double)dsum < P.max_score) {
+            // (visit order and bins are those of the WHOLE window: offset (a + sa0, b + sb0) of NI x NJ)
             unsigned long long key = ((unsigned long long)__float_as_uint(dsum) << 32) |
-                                     (unsigned long long)(unsigned)(ti * ncand + cidx);
-            const int bidx = ((int)S.binx[a] + (int)S.biny[b]) * nbt + bt_ti;
+                                     (unsigned long long)(unsigned)(ti * NCAND + (a + sa0) * NJ + (b + sb0));
+            const int bidx = ((int)S.binx[a + sa0] + (int)S.biny[b + sb0]) * nbt + bt_ti;
             // (a 64-bit LDS atomic costs its lanes one by one: only a candidate that would lower its bin issues one -- the bins only
             // decrease, so a plain read that is still above the key cannot hide a lower value.  The read goes through an LDS-typed
             // address: as a volatile generic load it made the compiler emit an illegal instruction in one instance)
@@ -1559,7 +1585,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
                 int v = K2;
                 if (d != 0xFFFF) {
                   int boff = (cx & 7) * 8 + (cy & 7);
-                  v = tile_byte(S, gtiles, d, boff);
+                  v = tile_byte(S, gtiles, d, boff, ncap);
                 }
                 sum[u] += v;
               }
@@ -1584,6 +1610,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
         }
       }
       __builtin_amdgcn_wave_barrier();
+      }   // sub-windows
     }
     __syncthreads();
     MPHASE(7);
@@ -1591,16 +1618,26 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     if (LEAN) {
       // a pair this instance cannot take goes onto the general kernel's list
       if (S.misc[13] != 0) redo = true;
-      if (redo && tid == 0) redo_list[atomicAdd(err + 3, 1)] = pair;
+      if (redo && tid == 0) {
+        // two lists in one array: from the front the pairs the general kernel searches as fast as this one would (a stamp that reaches
+        // in from outside the grid, an angle's lists), from the back the pairs whose search takes 15 to 90 times as long (tiles beyond
+        // LDS: the bounds-checked search; a wide window or too many points: the any-window path) -- the host spreads each of those
+        // over several workgroups, or the last of them would keep one compute unit busy long after the others have finished
+        const bool slow = S.misc[12] == 0 || (fast && !v2);
+        if (slow) redo_list[P.n_pairs - 1 - atomicAdd(err + 8, 1)] = pair;
+        else redo_list[atomicAdd(err + 3, 1)] = pair;
+        atomicAdd(err + (!fast ? 4 : (!v2 ? 5 : 6)), 1);          // why: the grid (tiles / stamps), the window or point count, an angle's lists
+      }
       produce = !redo;
     }
+    if (ovf && !redo && part == 0 && tid == 0) atomicAdd(err + 7, 1);   // (statistics: pairs whose tiles borrowed the point lists)
     if (!LEAN && P.split > 1) {
-      unsigned long long* gb = gbins + (size_t)pair * MAXBINS;
+      unsigned long long* gb = gbins + (size_t)unit * MAXBINS;
       for (int q = tid; q < nbins; q += CB_THREADS)
         if (S.bins[q] != ~0ULL) atomicMin(&gb[q], S.bins[q]);
       __threadfence();
       __syncthreads();
-      if (tid == 0) S.misc[15] = atomicAdd(&arrive[pair], 1);      // the counters start at -1 (one memset of 0xff for the whole table)
+      if (tid == 0) S.misc[15] = atomicAdd(&arrive[unit], 1);      // the counters start at -1 (one memset of 0xff for the whole table)
       __syncthreads();
       produce = S.misc[15] == P.split - 2;
       if (produce) {

@@ -315,7 +315,10 @@ class ScanMatcher(_GenericSearch, _BatchedSearch):
     def last_stats(self):
         out = np.zeros(2, dtype=np.int64)
         self.ctx._check(self.ctx.lib.cgmr_match_last_stats(self.ctx.h, C.c_void_p(out.ctypes.data)))
-        return {"pairs": int(out[0]), "slow_pairs": int(out[1])}
+        pc = np.zeros(4, dtype=np.int64)
+        self.ctx._check(self.ctx.lib.cgmr_match_last_path_counts(self.ctx.h, C.c_void_p(pc.ctypes.data)))
+        return {"pairs": int(out[0]), "slow_pairs": int(out[1]), "borrowed_pool_pairs": int(pc[0]),
+                "redo_by_cause": {"grid": int(pc[1]), "window_or_points": int(pc[2]), "lists": int(pc[3])}}
 
     def closeScanMatching_dev(self, d_ranges_ref, d_ranges_cur, d_guess, n_pairs, d_xyt, d_score, d_found,   # noqa: N802
                               maxScore=0.15, d_nres=0):   # noqa: N803

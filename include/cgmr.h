@@ -228,6 +228,12 @@ int cgmr_match_last_stats(const cgmr_ctx* ctx, int64_t out[2]);
  * shipped grid and kernel) handed to the general kernel (same results; such a pair is prepared twice).  0 when the general
  * kernel ran alone (CGMR_MATCH_LEAN=0, reference sets of several scans, single calls). */
 int cgmr_match_last_redo_pairs(const cgmr_ctx* ctx, int64_t* out);
+/* How the pairs of the last batched close-matching launch were searched, beyond the common case: out[0] = pairs whose reference
+ * scan claimed more grid tiles than the LDS pool holds and borrowed half of the point lists for them (half the wavefronts search;
+ * beyond that come the "slow pairs" of cgmr_match_last_stats); out[1..3] = the pairs of cgmr_match_last_redo_pairs by cause:
+ * [1] the reference grid (tiles beyond LDS, or a cell off the grid whose stamp reaches in), [2] the search window or the point
+ * count (more than 32 offsets along an axis, more points than one list holds), [3] an angle whose point lists did not fit. */
+int cgmr_match_last_path_counts(const cgmr_ctx* ctx, int64_t out[4]);
 /* Device time (HIP events on the context's stream) of the last matcher launch, seconds. */
 int cgmr_match_last_kernel_seconds(const cgmr_ctx* ctx, double* seconds);
 

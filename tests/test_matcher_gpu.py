@@ -113,6 +113,44 @@ def test_scattered_scans_take_the_overflow_paths(ctx, oracle):
     assert got[0][2] and np.abs(got[1][2]).max() < 0.05       # the scattered scan matches itself at the origin
 
 
+def _room_pairs(sp, sizes_and_headings, seed=3):
+    """Pairs of scans taken inside an empty rectangular room: (width, height, heading of the first pose)."""
+    rng = np.random.default_rng(seed)
+    ang0 = sp["angle_min"] + sp["angle_inc"] * np.arange(sp["n_beams"])
+    rr, rq, g = [], [], []
+    for (w, h, th) in sizes_and_headings:
+        boxes = [(-w / 2, -h / 2, w / 2, h / 2)]
+        p1 = np.array([0.3, -0.2, th])
+        d = np.array([0.12, -0.08, 0.05])
+        p2 = synth.se2_compose(p1, d)
+        for pose, out in ((p1, rr), (p2, rq)):
+            r = synth._raycast_boxes(pose[0], pose[1], pose[2] + ang0, boxes, sp["max_range"])
+            out.append(np.clip(r + rng.normal(scale=0.01, size=r.shape), 0.05, None).astype(np.float32))
+        g.append(synth.se2_compose(d, np.array([0.03, -0.02, 0.01])))
+    return np.stack(rr), np.stack(rq), np.stack(g)
+
+
+def test_long_walls_borrow_the_point_lists_for_their_tiles(ctx, oracle):
+    """A reference scan that sees 60 m of wall at an angle to the grid claims more tiles than the LDS pool's 1248: up to 1424 the
+    tiles go on into the first half of the point lists and half the wavefronts search (same fast search, no HBM tiles); the
+    results stay bit-identical to the oracle in the pruned and the exhaustive search, in a batch and alone."""
+    sp = synth.make_scan_pairs(2, seed=82)
+    rooms = [(21.0, 21.0, 0.78), (22.0, 22.0, 0.6), (24.0, 24.0, 0.3), (28.0, 28.0, 0.0), (12.0, 9.0, 0.4), (22.0, 21.0, 1.0)]   # 1260 .. 1350 tiles
+    rr, rq, g = _room_pairs(sp, rooms)
+    m = _matcher(ctx, sp)
+    want = _oracle(oracle, sp, rr, rq, g)
+    got = m.closeScanMatching(rr, rq, g)
+    st = m.last_stats()
+    _assert_same(got, want)
+    assert st["slow_pairs"] == 0 and st["borrowed_pool_pairs"] >= 4, st
+    f2, x2, s2, nres = m.closeScanMatching(rr, rq, g, want_nresults=True)
+    _assert_same((f2, x2, s2), want)
+    assert m.last_stats()["slow_pairs"] == 0 and m.last_stats()["borrowed_pool_pairs"] == st["borrowed_pool_pairs"]
+    assert got[0].all()
+    for i in range(len(rooms)):                                   # single calls: 16 workgroups share the pair
+        _assert_same(m.closeScanMatching(rr[i], rq[i], g[i]), tuple(np.asarray(a)[i:i + 1] for a in want))
+
+
 def test_batch_recovers_truth_and_is_order_independent(ctx):
     """Size-independent properties on a larger batch: the match recovers the true motion to within a cell /
     angle step for the vast majority of pairs, and a pair's result does not depend on its position in the batch."""
