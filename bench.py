@@ -359,6 +359,7 @@ def matcher_leg(ctx, dev, args, with_cpu):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ksec = m.last_kernel_seconds()                         # HIP events on the context's stream
+    paths = m.last_stats()
     # the same kernel with the exhaustive search (a caller that asks for the number of populated result bins gets it: every
     # candidate is then evaluated, as the reference does) on a slice: the LDS-gather roofline below is priced on THIS run,
     # where the gathered bytes are the algorithm's; the pruned search (the headline value) skips most of them
@@ -371,6 +372,7 @@ def matcher_leg(ctx, dev, args, with_cpu):
                             d_found2.data_ptr(), d_nres=d_nres.data_ptr())
     torch.cuda.synchronize()
     ksec_x = m.last_kernel_seconds()
+    paths_x = m.last_stats()
     same_winner = bool(torch.equal(d_xyt2, d_xyt[:nx]) and torch.equal(d_score2, d_score[:nx]) and torch.equal(d_found2, d_found[:nx]))
     err = (d_xyt - true_rel).abs()
     ok = (d_found != 0) & (err[:, 0] < 0.04) & (err[:, 1] < 0.04) & (err[:, 2] < 0.013)
@@ -401,9 +403,11 @@ def matcher_leg(ctx, dev, args, with_cpu):
            "unit": "pairs/s", "n_pairs": P, "distinct_pairs": P, "kernel_ms": round(1e3 * ksec, 3),
            "wall_ms": round(1e3 * wall, 3), "recovered_truth_frac": round(float(ok.double().mean()), 4),
            "first_4096_match_golden_fixture": golden,
+           "pairs_by_search_path": {k: paths[k] for k in ("slow_pairs", "borrowed_pool_pairs", "redo_by_cause")},
            "search": "pruned (exact winner; partial sums over a quarter of the points are lower bounds, rows that cannot win are dropped)",
            "exhaustive": {"pairs": nx, "kernel_ms": round(1e3 * ksec_x, 3), "pairs_per_s": round(nx / ksec_x, 1),
                           "same_result_as_pruned": same_winner,
+                          "pairs_by_search_path": {k: paths_x[k] for k in ("slow_pairs", "borrowed_pool_pairs", "redo_by_cause")},
                           "note": "the same kernel when the caller asks for the per-pair count of populated bins: every candidate evaluated"},
            "roofline": {"kernel": "k_match_close_batch", "bound": "lds-gather", "unit": "TB/s", "priced_on": "exhaustive run",
                         "achieved": round(gather_rate / 1e12, 3), "peak": round(lds_peak / 1e12, 2),
@@ -415,7 +419,7 @@ def matcher_leg(ctx, dev, args, with_cpu):
                         "hbm": {"achieved_GBps": round(P * hbm_pp / ksec / 1e9, 3), "peak_GBps": 8000.0,
                                 "frac": round(P * hbm_pp / ksec / 1e9 / 8000.0, 7), "bytes_per_pair": int(hbm_pp),
                                 "traffic_bytes_per_launch": (round(pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096) * P) if pmc_m else None)},
-                        "bytes_fetched_per_useful_byte": round((32 + 8) / 24.0 * 64 / 60, 3),
+                        "bytes_fetched_per_useful_byte": round((64 + 8) / 48.0, 3),
                         "lds_bank_conflict_frac": (pmc_m or {}).get("lds_bank_conflict_frac"),
                         "valu_active_frac_of_wave_cycles": (pmc_m or {}).get("valu_active_frac"),
                         "wave_parked_frac_of_wave_cycles": (pmc_m or {}).get("wait_any_frac"),      # SQ_WAIT_ANY / SQ_WAVE_CYCLES (s_waitcnt / barriers)
@@ -424,9 +428,9 @@ def matcher_leg(ctx, dev, args, with_cpu):
                         "phase_cycles_per_pair": (pmc_m or {}).get("phase_cycles_per_pair"),
                         "counters_stale": pmc_traffic().get("_stale"),
                         "note": "algorithmic = one grid byte per (64 angles x 24 x 24 offsets x k subsampled points) from the sparse "
-                                "grid in LDS, against the ds_read_b64 rate of 256 B per CU and clock; a lane fetches 32 + 8 bytes (four "
-                                "tile rows, four directory entries) for 24 useful ones and 60 of 64 lanes work "
-                                "(bytes_fetched_per_useful_byte), the 2-byte directory loads cost a 4-byte pass each and "
+                                "grid in LDS, against an LDS read rate of 256 B per CU and clock; in the exhaustive instance a lane fetches 64 + 8 bytes per "
+                                "list entry (four ds_read_b128 = two neighbouring rows of four tiles, four directory entries) for 48 useful "
+                                "ones (bytes_fetched_per_useful_byte), the 2-byte directory loads cost a 4-byte pass each and "
                                 "lds_bank_conflict_frac of the LDS-array cycles are bank conflicts (SQ_LDS_BANK_CONFLICT / "
                                 "SQ_LDS_IDX_ACTIVE of the committed PMC pass); valu_issue = the same adds as packed-byte VALU "
                                 "instructions (256 per wave instruction) against one per SIMD and clock; HBM carries ~270 KB per pair "

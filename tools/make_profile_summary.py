@@ -43,6 +43,8 @@ with open(f"{P}/{rnd}_pmc_summary.csv", "w", newline="") as f:
 def avg(k, c):
     # per-launch average over every instance of the kernel (k_front_factor<48>, k_front_factor_leaf, ...)
     keys = [q for q in acc if q[1] == c and (q[0] == k or q[0].startswith(k + "<") or q[0].startswith(k + "_"))]
+    # (the matcher: the instance a batch runs in -- <1> exhaustive, <2> pruned; <0> behind them only takes the few pairs left over)
+    if k == "k_match_close_batch" and any(q[0] in (k + "<1>", k + "<2>") for q in keys): keys = [q for q in keys if q[0] != k + "<0>"]
     return sum(acc[q] for q in keys) / max(sum(n[q] for q in keys), 1), sum(n[q] for q in keys)
 traffic = {}
 for k in ("k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_assemble", "k_linearize", "k_match_close_batch"):

@@ -38,7 +38,7 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $O/bench --output-format csv -- 
 grep "^{\"metric\"" $O/bench.log | tail -1 > $O/bench_line.json
 cd $R
 python tools/pmc_summarise.py $(find $O -name "*counter_collection.csv") > $O/pmc_summary.txt
-find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
+find $O/bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
 # the raw trace of the bench run is tens of MB (every launch of every leg) and only its statistics are used: what comes back
 # through gpurun_out/ is capped at 64 MiB
 find $O/bench -name "*kernel_trace.csv" -delete
