@@ -151,6 +151,36 @@ def test_long_walls_borrow_the_point_lists_for_their_tiles(ctx, oracle):
         _assert_same(m.closeScanMatching(rr[i], rq[i], g[i]), tuple(np.asarray(a)[i:i + 1] for a in want))
 
 
+def test_a_full_batch_sorts_its_pairs_by_search_path_and_answers_them_all(ctx, oracle):
+    """More pairs than compute units: the batch runs in the kernel instance built for the common shape, which hands what it cannot take
+    to the launches behind it -- pairs whose tiles borrow the point lists stay with it, a reference scan with tiles beyond even that
+    and a query scan with more points than one list holds go onto the slow list (16 workgroups each).  Every pair, whatever its
+    path, is bit-identical to the oracle, pruned and exhaustive, and the path counters say where the pairs went."""
+    sp = synth.make_scan_pairs(200, seed=83)
+    rooms = [(21.0, 21.0, 0.78), (22.0, 22.0, 0.6), (24.0, 24.0, 0.3), (28.0, 28.0, 0.0), (22.0, 21.0, 1.0)]
+    r1, q1, g1 = _room_pairs(sp, rooms, seed=4)
+    rng = np.random.default_rng(6)
+    scattered = lambda: rng.uniform(1.0, 14.0, size=sp["n_beams"]).astype(np.float32)   # noqa: E731
+    rr = np.concatenate([sp["ranges_ref"], r1, sp["ranges_ref"][:95]])
+    rq = np.concatenate([sp["ranges_qry"], q1, sp["ranges_qry"][:95]])
+    g = np.concatenate([sp["guess"], g1, sp["guess"][:95]])
+    rr[7] = scattered()                                           # tiles beyond the borrowed lists
+    rq[11] = scattered()                                          # more subsampled points than one list holds
+    rr[13] = scattered(); rq[13] = rr[13] + rng.normal(scale=0.01, size=sp["n_beams"]).astype(np.float32); g[13] = 0.0   # both
+    rr[17] = 29.99; rq[17] = 29.99                                # far points: stamps hang over the grid border
+    assert len(rr) == 300
+    m = _matcher(ctx, sp)
+    want = _oracle(oracle, sp, rr, rq, g, max_score=0.3)
+    for exhaustive in (False, True):
+        out = m.closeScanMatching(rr, rq, g, maxScore=0.3, want_nresults=exhaustive)
+        st = m.last_stats()
+        _assert_same(out[:3], want)
+        assert st["pairs"] == 300 and st["borrowed_pool_pairs"] >= 4, st
+        assert st["slow_pairs"] == 2, st                          # pairs 7 and 13
+        assert st["redo_by_cause"]["grid"] >= 2 and st["redo_by_cause"]["window_or_points"] >= 1, st
+    assert want[2][13] and np.abs(want[0][13]).max() < 0.05
+
+
 def test_batch_recovers_truth_and_is_order_independent(ctx):
     """Size-independent properties on a larger batch: the match recovers the true motion to within a cell /
     angle step for the vast majority of pairs, and a pair's result does not depend on its position in the batch."""
