@@ -352,29 +352,30 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
     const int nA = W * H2, nB = nr * H2, nq = nA + nB + H2;
     const double2* src = reinterpret_cast<const double2*>(Pan + pan_off);
     const size_t slot2 = (size_t)pan_size(ns) / 2;
+    // Only the populated cells are fetched (and only they are cleared for the next pass, k_top_block): the front's own w
+    // columns and the border-vector column of its w own rows, of the border rows and of the rhs row.  A front of 10 poses
+    // uses 32 of the 50 doubles of a row and 30 of the 48 rows of F11: the rest of the 48-column layout is never touched.
+    const int w2 = (w + 1) & ~1;
     for (int base = 0; base < nq; base += kFT * kPanLoads) {
       double2 v[kPanLoads], v1[kPanLoads];
       int so[kPanLoads];
+      bool need[kPanLoads];
 #pragma unroll
       for (int u = 0; u < kPanLoads; u++) {
         const int q = base + tid + kFT * u;
         so[u] = q < nA ? q : (q < nA + nB ? (W + r0) * H2 + (q - nA) : (W + r) * H2 + (q - nA - nB));
-        v[u] = q < nq ? src[so[u]] : make_double2(0.0, 0.0);
+        const int row = q / H2, c2 = 2 * (q - H2 * row);
+        need[u] = q < nq && (c2 < w2 || c2 == W) && !(row >= w && row < W);
+        v[u] = need[u] ? src[so[u]] : make_double2(0.0, 0.0);
       }
       if (slots > 1) {
 #pragma unroll
-        for (int u = 0; u < kPanLoads; u++) {
-          const int q = base + tid + kFT * u;
-          v1[u] = q < nq ? src[slot2 + so[u]] : make_double2(0.0, 0.0);
-        }
+        for (int u = 0; u < kPanLoads; u++) v1[u] = need[u] ? src[slot2 + so[u]] : make_double2(0.0, 0.0);
 #pragma unroll
         for (int u = 0; u < kPanLoads; u++) { v[u].x += v1[u].x; v[u].y += v1[u].y; }
         for (int sl = 2; sl < slots; sl++) {
 #pragma unroll
-          for (int u = 0; u < kPanLoads; u++) {
-            const int q = base + tid + kFT * u;
-            v1[u] = q < nq ? src[sl * slot2 + so[u]] : make_double2(0.0, 0.0);
-          }
+          for (int u = 0; u < kPanLoads; u++) v1[u] = need[u] ? src[sl * slot2 + so[u]] : make_double2(0.0, 0.0);
 #pragma unroll
           for (int u = 0; u < kPanLoads; u++) { v[u].x += v1[u].x; v[u].y += v1[u].y; }
         }
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   const int r = 3 * rfl(WR->F.ns), my_ra = 3 * rfl(WR->F.na), nchild = rfl(WR->F.nchild), child_off = rfl(WR->F.child_off);
   const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off), ppan = rfl64(WR->F.ppan_off);
   const int p_w = 3 * rfl(WR->F.p_nc), p_r = 3 * rfl(WR->F.p_ns), my_rel = rfl(WR->F.rel_off), my_rows = rfl(WR->F.rows_off);
-  const int ncb = min(nchild, MAXC);
+  const int ncb = min(nchild, MAXC), my_w = 3 * rfl(WR->F.nc);
   const double* L21 = Lbuf + L_off + kL21;
   const int i0 = ti * TS, j0 = tj * TS;
   const bool to_pan = ppan >= 0 && j0 < my_ra;                // this tile holds cells of the leading slab
@@ -506,8 +507,8 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   for (int u = 0; u < LQ; u++) {
     const int q = tid + 256 * u;
     const int row = q / W, k = q - row * W;
-    li[u] = (i0 + row < r) ? L21[(size_t)(i0 + row) * W + k] : 0.0;
-    lj[u] = (j0 + row < r) ? L21[(size_t)(j0 + row) * W + k] : 0.0;
+    li[u] = (i0 + row < r && k < my_w) ? L21[(size_t)(i0 + row) * W + k] : 0.0;   // (columns beyond the front's own: zeros, not fetched)
+    lj[u] = (j0 + row < r && k < my_w) ? L21[(size_t)(j0 + row) * W + k] : 0.0;
   }
   int kb[MAXC];
   const int pq = (tid < TS) ? i0 + tid : j0 + tid - TS;       // threads 0..31: tile rows, 32..63: tile columns
@@ -649,17 +650,33 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
                                                     const double* __restrict__ Ubuf, const double* __restrict__ uvec,
                                                     double* __restrict__ Lbuf, double* __restrict__ yvec,
                                                     double* __restrict__ xvec, int* __restrict__ status, int store_l,
-                                                    int write_l11c, double* __restrict__ zero_ptr, long long zero_n, long long js) {
+                                                    int write_l11c, double* __restrict__ zero_ptr, long long zero_n, int nfronts_all,
+                                                    long long js) {
   CGMR_JOB(Ablk, js); CGMR_JOB(bvec, js); CGMR_JOB(Ubuf, js); CGMR_JOB(uvec, js); CGMR_JOB(Lbuf, js); CGMR_JOB(yvec, js);
   CGMR_JOB(xvec, js); CGMR_JOB(status, js); CGMR_JOB(zero_ptr, js);
   if (blockIdx.x > 0) {
     // The top block is one workgroup; the chip is idle beside it.  The other workgroups of the launch clear the assembled
     // panels for the NEXT pass (nobody reads them any more in this one): the 8 us memset in front of every k_assemble goes.
-    const long long n2 = zero_n / 2, per = (n2 + gridDim.x - 2) / (gridDim.x - 1);
-    const long long lo = per * (blockIdx.x - 1), hi = min(n2, lo + per);
-    double2* z = reinterpret_cast<double2*>(zero_ptr);
-    for (long long q = lo + threadIdx.x; q < hi; q += 256) z[q] = make_double2(0.0, 0.0);
-    if (blockIdx.x == 1 && threadIdx.x == 0 && (zero_n & 1)) zero_ptr[zero_n - 1] = 0.0;
+    // Only the cells anybody writes or reads (k_front_factor's loads name them): per front and copy the w own columns and the
+    // border-vector column of the w own rows, of the border rows and of the rhs row -- on C2 27 of the 48.6 MB the padded
+    // layout holds.
+    (void)zero_n;
+    constexpr int H2 = kPanStride / 2;
+    for (int f = blockIdx.x - 1; f < nfronts_all; f += gridDim.x - 1) {
+      const long long pan_off = fronts[f].pan_off;
+      if (pan_off < 0) continue;                                // (a front of the top block: no panel)
+      const int w = 3 * fronts[f].nc, r = 3 * fronts[f].ns, slots = fronts[f].pan_slots;
+      const int c2n = ((w + 1) >> 1) + 1, nrow = w + r + 1;     // double2 per populated row, populated rows
+      const long long slot2 = pan_size(fronts[f].ns) / 2;
+      for (int sl = 0; sl < slots; sl++) {
+        double2* z = reinterpret_cast<double2*>(zero_ptr + pan_off) + sl * slot2;
+        for (int q = threadIdx.x; q < nrow * c2n; q += 256) {
+          const int rr = q / c2n, c = q - rr * c2n;
+          const int row = rr < w ? rr : kFrontW + (rr - w);
+          z[row * H2 + (c < c2n - 1 ? c : kFrontW / 2)] = make_double2(0.0, 0.0);
+        }
+      }
+    }
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1072,7 +1089,7 @@ void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool writ
   hipLaunchKernelGGL(CGMR_KERN(D, k_top_block), dim3(zero ? 1 + 240 : 1, 1, D.njobs), dim3(256), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols,
                      D.top_nfronts, D.top_fronts, D.top_nchild, D.top_children, D.top_nblk, D.top_blocks, D.fronts, D.rows, D.Ablk,
                      D.bvec, D.Ubuf, D.uvec, D.Lbuf, D.yvec, D.xvec, D.status, store_l ? 1 : 0, write_l11c ? 1 : 0, D.Pan,
-                     (long long)D.pan_doubles, D.job_stride);
+                     (long long)D.pan_doubles, D.nfronts, D.job_stride);
 }
 
 void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
