@@ -346,26 +346,30 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
   const int M = W + nr + 1;                          // rows of the panel
   double* Dinv = P + factor_panel_rows(nr + 1) * LDW;
   PHASE(1);
-  // ---- round 2: the panel, as double2 (25 per row: columns 0..47, the border-vector column, one of padding)
+  // ---- round 2: the panel, as double2 (25 per row: columns 0..47, the border-vector column, one of padding).  A thread
+  // keeps its column pair and walks rows (20 rows per pass of 500 threads): the row of a load is an addition, the column
+  // tests are made once.
   {
-    constexpr int H2 = kPanStride / 2;
-    const int nA = W * H2, nB = nr * H2, nq = nA + nB + H2;
+    constexpr int H2 = kPanStride / 2, RPP = kFT / H2;           // double2 per row, rows per pass
+    static_assert(RPP * kPanLoads >= kFrontW + kMidChunkRows + 1, "a 95-row chunk's panel in one round of loads");
+    const int c = tid % H2, row0 = tid / H2, c2 = 2 * c;
+    const bool tact = row0 < RPP;
+    const int nrows = W + nr + 1;                               // F11, this chunk's border rows, the rhs row
     const double2* src = reinterpret_cast<const double2*>(Pan + pan_off);
     const size_t slot2 = (size_t)pan_size(ns) / 2;
     // Only the populated cells are fetched (and only they are cleared for the next pass, k_top_block): the front's own w
     // columns and the border-vector column of its w own rows, of the border rows and of the rhs row.  A front of 10 poses
     // uses 32 of the 50 doubles of a row and 30 of the 48 rows of F11: the rest of the 48-column layout is never touched.
-    const int w2 = (w + 1) & ~1;
-    for (int base = 0; base < nq; base += kFT * kPanLoads) {
+    const bool colneed = tact && (c2 < ((w + 1) & ~1) || c2 == W);
+    for (int rb = 0; rb < nrows; rb += RPP * kPanLoads) {
       double2 v[kPanLoads], v1[kPanLoads];
       int so[kPanLoads];
       bool need[kPanLoads];
 #pragma unroll
       for (int u = 0; u < kPanLoads; u++) {
-        const int q = base + tid + kFT * u;
-        so[u] = q < nA ? q : (q < nA + nB ? (W + r0) * H2 + (q - nA) : (W + r) * H2 + (q - nA - nB));
-        const int row = q / H2, c2 = 2 * (q - H2 * row);
-        need[u] = q < nq && (c2 < w2 || c2 == W) && !(row >= w && row < W);
+        const int row = rb + row0 + RPP * u;
+        so[u] = (row < W ? row : (row < W + nr ? W + r0 + (row - W) : W + r)) * H2 + c;
+        need[u] = colneed && row < nrows && !(row >= w && row < W);
         v[u] = need[u] ? src[so[u]] : make_double2(0.0, 0.0);
       }
       if (slots > 1) {
@@ -382,10 +386,8 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
       }
 #pragma unroll
       for (int u = 0; u < kPanLoads; u++) {
-        const int q = base + tid + kFT * u;
-        if (q >= nq) continue;
-        const int row = q / H2;
-        const int c2 = 2 * (q - H2 * row);
+        const int row = rb + row0 + RPP * u;
+        if (!tact || row >= nrows) continue;
         double vx = v[u].x, vy = v[u].y;
         if (row >= w && row < W) {                           // identity padding of the unused columns
           if (c2 == row) vx = 1.0;
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   const int r = 3 * rfl(WR->F.ns), my_ra = 3 * rfl(WR->F.na), nchild = rfl(WR->F.nchild), child_off = rfl(WR->F.child_off);
   const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off), ppan = rfl64(WR->F.ppan_off);
   const int p_w = 3 * rfl(WR->F.p_nc), p_r = 3 * rfl(WR->F.p_ns), my_rel = rfl(WR->F.rel_off), my_rows = rfl(WR->F.rows_off);
-  const int ncb = min(nchild, MAXC), my_w = 3 * rfl(WR->F.nc);
+  const int ncb = min(nchild, MAXC);
   const double* L21 = Lbuf + L_off + kL21;
   const int i0 = ti * TS, j0 = tj * TS;
   const bool to_pan = ppan >= 0 && j0 < my_ra;                // this tile holds cells of the leading slab
@@ -507,8 +509,8 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   for (int u = 0; u < LQ; u++) {
     const int q = tid + 256 * u;
     const int row = q / W, k = q - row * W;
-    li[u] = (i0 + row < r && k < my_w) ? L21[(size_t)(i0 + row) * W + k] : 0.0;   // (columns beyond the front's own: zeros, not fetched)
-    lj[u] = (j0 + row < r && k < my_w) ? L21[(size_t)(j0 + row) * W + k] : 0.0;
+    li[u] = (i0 + row < r) ? L21[(size_t)(i0 + row) * W + k] : 0.0;
+    lj[u] = (j0 + row < r) ? L21[(size_t)(j0 + row) * W + k] : 0.0;
   }
   int kb[MAXC];
   const int pq = (tid < TS) ? i0 + tid : j0 + tid - TS;       // threads 0..31: tile rows, 32..63: tile columns
