@@ -485,16 +485,15 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   CGMR_FRONT_CONSTS(WW);
   __shared__ double Ai[TS * LDW];
   __shared__ double Aj[TS * LDW];
-  __shared__ __attribute__((aligned(8))) int s_rec[kRecInts];
   __shared__ short s_k[MAXC][2 * TS];                        // per child: child row of tile row i / tile column j, or -1
   __shared__ int s_pp[2 * TS];                               // tile row i: offset (doubles) of its row in the parent's panel; tile column j: its column
   const int tid = threadIdx.x;
   const int32_t* tl = tiles + 3 * (size_t)(tile_begin + blockIdx.x);
   const int rec = tl[0], ti = tl[1], tj = tl[2];
   if (rec < 0) return;                                        // padding of the XCD-interleaved tile list
-  if (tid < kRecInts) s_rec[tid] = reinterpret_cast<const int*>(work + rec)[tid];
-  __syncthreads();
-  const WorkRec* WR = reinterpret_cast<const WorkRec*>(s_rec);
+  // (the record through the scalar cache: its address is wave-uniform -- no vector load, LDS copy and barrier in front of
+  // the first use)
+  const WorkRec* WR = work + __builtin_amdgcn_readfirstlane(rec);
   const int r = 3 * rfl(WR->F.ns), my_ra = 3 * rfl(WR->F.na), nchild = rfl(WR->F.nchild), child_off = rfl(WR->F.child_off);
   const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off), ppan = rfl64(WR->F.ppan_off);
   const int p_w = 3 * rfl(WR->F.p_nc), p_r = 3 * rfl(WR->F.p_ns), my_rel = rfl(WR->F.rel_off), my_rows = rfl(WR->F.rows_off);
@@ -643,8 +642,9 @@ constexpr int top_smem_bytes(int ncols) {
 }
 static_assert(kTopMaxCols % 16 == 0 && top_smem_bytes(kTopMaxCols) <= 160 * 1024, "top block exceeds the LDS");
 
+constexpr int kTopT = 512;                                  // threads of the top block's workgroup (and of the launch's clearing workgroups)
 template <bool BATCH>
-__global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfronts, const int32_t* __restrict__ top_fronts,
+__global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfronts, const int32_t* __restrict__ top_fronts,
                                                     int nchild, const int32_t* __restrict__ top_children, int nblk,
                                                     const int32_t* __restrict__ top_blocks,
                                                     const FrontDesc* __restrict__ fronts, const int32_t* __restrict__ rows,
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
       const long long slot2 = pan_size(fronts[f].ns) / 2;
       for (int sl = 0; sl < slots; sl++) {
         double2* z = reinterpret_cast<double2*>(zero_ptr + pan_off) + sl * slot2;
-        for (int q = threadIdx.x; q < nrow * c2n; q += 256) {
+        for (int q = threadIdx.x; q < nrow * c2n; q += kTopT) {
           const int rr = q / c2n, c = q - rr * c2n;
           const int row = rr < w ? rr : kFrontW + (rr - w);
           z[row * H2 + (c < c2n - 1 ? c : kFrontW / 2)] = make_double2(0.0, 0.0);
@@ -688,12 +688,12 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
   double* Dinv = P + (size_t)(n16 + 16) * LD;
   short* cmap = reinterpret_cast<short*>(Dinv + n16);        // row of the block a child's border row lands in (<= 1024 rows)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int q = tid; q < M * LD; q += 256) P[q] = 0.0;
+  for (int q = tid; q < M * LD; q += kTopT) P[q] = 0.0;
   __syncthreads();
   // ---- right-hand side, identity padding, H blocks
-  for (int j = tid; j < ncols; j += 256) P[(size_t)n16 * LD + j] = bvec[3 * (size_t)c0 + j];
-  for (int j = ncols + tid; j < n16; j += 256) P[(size_t)j * LD + j] = 1.0;
-  for (int q = tid; q < 9 * nblk; q += 256) {
+  for (int j = tid; j < ncols; j += kTopT) P[(size_t)n16 * LD + j] = bvec[3 * (size_t)c0 + j];
+  for (int j = ncols + tid; j < n16; j += kTopT) P[(size_t)j * LD + j] = 1.0;
+  for (int q = tid; q < 9 * nblk; q += kTopT) {
     const int b = q / 9, el = q - 9 * b;
     const int slot = top_blocks[3 * b], rb = top_blocks[3 * b + 1], cb = top_blocks[3 * b + 2];
     P[(size_t)(3 * rb + el / 3) * LD + 3 * cb + el % 3] = Ablk[9 * (size_t)slot + el];
@@ -703,34 +703,40 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
   for (int ci = 0; ci < nchild; ci++) {
     const FrontDesc G = fronts[top_children[ci]];
     const int r = 3 * G.ns, ra = 3 * G.na;
-    for (int k = tid; k < r; k += 256) cmap[k] = (short)(3 * (rows[G.rows_off + k / 3] - c0) + k % 3);
+    for (int k = tid; k < r; k += kTopT) cmap[k] = (short)(3 * (rows[G.rows_off + k / 3] - c0) + k % 3);
     __syncthreads();
     const double* U = Ubuf + G.U_off;
-    const float rinv = 1.0f / (float)r;
+    // the lower triangle only, rows i and r - 1 - i folded into one line of r + 1 elements (half the loads of the r x r square
+    // the loop used to walk); 512 threads x 8 loads in flight: the child streams in at four times the round-2 rate (a lone
+    // workgroup is limited by what it has in flight: 256 threads x 8 x 8 bytes per ~2000-cycle round trip = 8 bytes per clock)
+    const int r1 = r + 1, nline = (r + 1) / 2;
+    const float rinv = 1.0f / (float)r1;
     constexpr int TU = 8;                                     // loads in flight per thread: every load first, then the adds
-    for (int q0 = 0; q0 < r * r; q0 += 256 * TU) {
+    for (int q0 = 0; q0 < nline * r1; q0 += kTopT * TU) {
       double val[TU];
       int dst[TU];
 #pragma unroll
       for (int u = 0; u < TU; u++) {
-        const int q = q0 + tid + 256 * u;
-        int i = (int)((float)q * rinv);                       // q / r for q < 2^14 (exact after one correction step)
-        if ((i + 1) * r <= q) i++;
-        if (i * r > q) i--;
-        const int j = q - i * r;
-        const bool ok = q < r * r && j <= i;
+        const int q = q0 + tid + kTopT * u;
+        int a = (int)((float)q * rinv);                       // q / (r + 1) for q < 2^15 (exact after one correction step)
+        if ((a + 1) * r1 <= q) a++;
+        if (a * r1 > q) a--;
+        const int b = q - a * r1;
+        const bool low = b <= a;                              // elements 0 .. a: row a; the others: row r - 1 - a
+        const int i = low ? a : r - 1 - a, j = low ? b : b - a - 1;
+        const bool ok = q < nline * r1 && (low || r - 1 - a != a);   // (odd r: the middle row pairs with itself)
         val[u] = U[ok ? uidx(i, j, r, ra) : 0];
         dst[u] = ok ? cmap[i] * LD + cmap[j] : -1;
       }
 #pragma unroll
       for (int u = 0; u < TU; u++) if (dst[u] >= 0) lds_add(P + dst[u], val[u]);
     }
-    for (int k = tid; k < r; k += 256) lds_add(P + (size_t)n16 * LD + cmap[k], uvec[3 * (size_t)G.rows_off + k]);
+    for (int k = tid; k < r; k += kTopT) lds_add(P + (size_t)n16 * LD + cmap[k], uvec[3 * (size_t)G.rows_off + k]);
     __syncthreads();
   }
   // ---- factorisation (the rhs row becomes y = L^-1 b)
   auto roff = [](int r) -> int { return r * LD; };
-  const int fail = panel_cholesky<4>(P, roff, M, nbc, Dinv, lane, wave);
+  const int fail = panel_cholesky<kTopT / 64>(P, roff, M, nbc, Dinv, lane, wave);
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);
   __syncthreads();
   // ---- backward solve L^T x = y of the block's columns (nothing above them): wavefront 0, lane = columns lane, lane + 64
@@ -761,14 +767,14 @@ __global__ __launch_bounds__(256) void k_top_block(int c0, int ncols, int nfront
     const FrontDesc F = fronts[top_fronts[fi]];
     const int a = 3 * (F.c0 - c0), w = 3 * F.nc, r = 3 * F.ns;
     double* Pn = Lbuf + F.L_off;
-    for (int q = tid; q < W * W; q += 256) {
+    for (int q = tid; q < W * W; q += kTopT) {
       const int i = q / W, k = q - i * W;
       const double lv = (i < w && k <= i) ? P[(size_t)(a + i) * LD + a + k] : ((i >= w && i == k) ? 1.0 : 0.0);
       Pn[q] = lv;                                             // element (row i, column k)
       if (write_l11c) Pn[kL11c + k * W + i] = lv;             // column-major copy: element (row i, column k) at k * W + i
     }
-    for (int k = tid; k < W; k += 256) Pn[kDinv + k] = (k < w) ? Dinv[a + k] : 1.0;
-    for (int q = tid; q < r * W; q += 256) {
+    for (int k = tid; k < W; k += kTopT) Pn[kDinv + k] = (k < w) ? Dinv[a + k] : 1.0;
+    for (int q = tid; q < r * W; q += kTopT) {
       const int p = q / W, k = q - p * W;
       const int row = 3 * (rows[F.rows_off + p / 3] - c0) + p % 3;
       Pn[kL21 + q] = (k < w) ? P[(size_t)row * LD + a + k] : 0.0;
@@ -1088,7 +1094,7 @@ void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool writ
   gn_init_kernels();
   if (D.top_nfronts <= 0) return;
   const bool zero = clear_panels && D.pan_doubles > 0;
-  hipLaunchKernelGGL(CGMR_KERN(D, k_top_block), dim3(zero ? 1 + 240 : 1, 1, D.njobs), dim3(256), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols,
+  hipLaunchKernelGGL(CGMR_KERN(D, k_top_block), dim3(zero ? 1 + 240 : 1, 1, D.njobs), dim3(kTopT), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols,
                      D.top_nfronts, D.top_fronts, D.top_nchild, D.top_children, D.top_nblk, D.top_blocks, D.fronts, D.rows, D.Ablk,
                      D.bvec, D.Ubuf, D.uvec, D.Lbuf, D.yvec, D.xvec, D.status, store_l ? 1 : 0, write_l11c ? 1 : 0, D.Pan,
                      (long long)D.pan_doubles, D.nfronts, D.job_stride);
