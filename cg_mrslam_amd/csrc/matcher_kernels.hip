@@ -686,6 +686,11 @@ __device__ __forceinline__ int subsample_query(Smem& S, const MatchParams& P, in
   const double ires = 1. / P.sub_res;
 // sort keys live in the (not yet used) tile pool: 2048 keys
 KT* keys = reinterpret_cast<KT*>(S.tiles);
+  // ... and behind them the raw cartesian points (16 bytes per beam): the bucket leaders walk their members one dependent
+  // read after the other -- from LDS now, not from the workgroup's HBM scratch (15k -> cycles of a pair, 35 KB of its traffic)
+  double* const qraw_l = reinterpret_cast<double*>(S.tiles) + 2048;
+  static_assert((2048 + 2 * MAXPTS) * 8 <= (int)sizeof(S.tiles), "keys + raw points in the tile pool");
+  (void)qraw;
   // bitonic sort of 2048 keys in registers: lane l of wavefront w holds keys 256 w + 64 u + l (u = 0..3).  Exchanges at
   // distance 64 / 128 pair two registers of a lane, smaller distances go through the cross-lane network, and only the
   // six exchanges at distance 256 / 512 / 1024 cross wavefronts (through LDS, with workgroup barriers).
@@ -699,7 +704,7 @@ KT* keys = reinterpret_cast<KT*>(S.tiles);
       double r = (double)ranges_qry[(size_t)pair * B + i];
       if (r < P.max_range && r > P.min_range) {
         double x = beam_cos[i] * r, y = beam_sin[i] * r;
-        qraw[2 * i] = x; qraw[2 * i + 1] = y;
+        qraw_l[2 * i] = x; qraw_l[2 * i + 1] = y;
         int kx = (int)(ires * x), ky = (int)(ires * y);
         key[u] = ((KT)(unsigned)(kx + CELL_OFF) << (CELL_BITS + CELL_SHIFT)) | ((KT)(unsigned)(ky + CELL_OFF) << CELL_SHIFT) | (KT)i;
       }
@@ -775,8 +780,8 @@ KT* keys = reinterpret_cast<KT*>(S.tiles);
       int cnt = 0;
       for (int m = i; m < 2048 && (keys[m] >> CELL_SHIFT) == kk && keys[m] != INVALID; m++) {
         int idx = (int)(keys[m] & (KT)((1u << CELL_SHIFT) - 1u));
-        ax += qraw[2 * idx];
-        ay += qraw[2 * idx + 1];
+        ax += qraw_l[2 * idx];
+        ay += qraw_l[2 * idx + 1];
         cnt++;
       }
       double wgt = 1. / (double)cnt;
