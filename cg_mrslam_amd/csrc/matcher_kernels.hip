@@ -528,6 +528,11 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     // first, 8 to the right of the last) are fetched once and at once.  The finished lines go through the workgroup's
     // (otherwise unused) overflow pool in HBM and come back after a barrier: the neighbours still read the g^2 lines, and
     // holding them in registers instead made the compiler spill.
+    // Where the finished lines wait for the barrier: behind the claimed tiles -- the rest of the pool and the first six point
+    // lists, which lie right behind it and are idle now (the caller's cell list sits in the last two) -- when they fit there
+    // (2 ntile + 2 <= 1512 tiles' worth: 6 of 10 pairs of the C3 workload), else the workgroup's scratch in HBM as before: a
+    // round trip through L2 and 2 x 64 bytes per tile of memory traffic.
+    const bool stage_lds = ncap > NT_LDS && 2 * ntile + 2 <= NT_LDS + (NTH - 2) * (LISTCAP * 4 / 64);
     for (int hi = tid; hi < 2 * ntile; hi += NTHR) {
       const int d = 2 + (hi >> 1), h4 = 4 * (hi & 1);
       const int q = tile_slot[d];
@@ -571,14 +576,17 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
         // acc[0] = cells (0, 2), acc[1] = (1, 3), acc[2] = (4, 6), acc[3] = (5, 7)
         const uint32_t v0 = kv[0] | (kv[2] << 8) | (kv[1] << 16) | (kv[3] << 24);
         const uint32_t v1 = kv[4] | (kv[6] << 8) | (kv[5] << 16) | (kv[7] << 24);
-        *reinterpret_cast<uint2*>(&gtiles[d * 16 + 2 * (h4 + j)]) = make_uint2(v0, v1);
+        if (stage_lds) *reinterpret_cast<uint2*>(&S.tiles[(ntile + d) * 16 + 2 * (h4 + j)]) = make_uint2(v0, v1);
+        else *reinterpret_cast<uint2*>(&gtiles[d * 16 + 2 * (h4 + j)]) = make_uint2(v0, v1);
       }
     }
     // (workgroup scope is enough and cheap: the lines come back to the CU that wrote them)
     __syncthreads();
     MPHASE(20);
-    for (int w = 8 + tid; w < 4 * (ntile + 2); w += NTHR)
-      reinterpret_cast<uint4*>(S.tiles)[w] = reinterpret_cast<const uint4*>(gtiles)[w];
+    if (stage_lds)
+      for (int w = 8 + tid; w < 4 * (ntile + 2); w += NTHR) reinterpret_cast<uint4*>(S.tiles)[w] = reinterpret_cast<const uint4*>(S.tiles)[4 * ntile + w];
+    else
+      for (int w = 8 + tid; w < 4 * (ntile + 2); w += NTHR) reinterpret_cast<uint4*>(S.tiles)[w] = reinterpret_cast<const uint4*>(gtiles)[w];
     __syncthreads();
     MPHASE(21);
     if (S.misc[15] == 0) return;                                   // (no reference cell's stamp reaches in from outside the grid: done)
