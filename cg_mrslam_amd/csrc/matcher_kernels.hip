@@ -405,12 +405,47 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
     S.dir[row * DW + (c < 3 ? c : nty + c)] = 1;
   }
   const bool edt_maps = P.edt != 0;                               // the claimer clears its tile's cell map (the first two words)
+  // A cell's stamp reaches up to 3 x 3 tiles.  Rounds 3-4 walked them one after the other -- read the bit, atomicOr, take a number
+  // from the counter: three dependent LDS round trips per tile, and the 64 lanes of a wavefront (neighbouring beams) on the same
+  // three addresses: 17k of a pair's 470k cycles.  Now the nine atomicOrs of a cell go out together (a lane whose left neighbour
+  // asks for the same tile leaves it to that one), and ONE add on the counter takes the numbers of all the tiles the lane won.
   for (int i = tid; i < n; i += NTHR) {
-    uint32_t packed = rcell[i];
+    const uint32_t packed = rcell[i];
     if (packed == 0x80008000u) continue;
-    int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
-    int x0 = max(rx - ctr, 0), x1 = min(rx + ctr, P.nx - 1), y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
-    if (x0 <= x1 && y0 <= y1)
+    const int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
+    const int x0 = max(rx - ctr, 0), x1 = min(rx + ctr, P.nx - 1), y0 = max(ry - ctr, 0), y1 = min(ry + ctr, P.ny - 1);
+    if (x0 > x1 || y0 > y1) continue;
+    if (2 * ctr + 7 < 24) {                                        // at most 3 tiles along an axis (the 17-cell kernel)
+      const int tx0 = x0 >> 3, ty0 = y0 >> 3, ntx = (x1 >> 3) - tx0, nty = (y1 >> 3) - ty0;     // 0 .. 2 more tiles along each axis
+      int e[9];
+      uint32_t bit[9], old[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const bool valid = k / 3 <= ntx && k % 3 <= nty;
+        e[k] = (tx0 + k / 3 + 1) * DW + ty0 + k % 3 + 3;
+        const int mine = valid ? e[k] : -2;
+        const int left = __builtin_amdgcn_update_dpp(-1, mine, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        bit[k] = (valid && left != mine) ? 1u << (e[k] & 31) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; k++) old[k] = bit[k] ? atomicOr(&claimed[e[k] >> 5], bit[k]) : ~0u;
+      int nwin = 0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) nwin += (bit[k] != 0u && !(old[k] & bit[k])) ? 1 : 0;
+      if (nwin) {
+        int id = 2 + atomicAdd(&S.misc[0], nwin);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          if (bit[k] == 0u || (old[k] & bit[k])) continue;
+          S.dir[e[k]] = (uint16_t)id;
+          if (id < ncap) {
+            tile_slot[id] = (uint16_t)e[k];
+            if (edt_maps) { S.tiles[id * 16] = 0u; S.tiles[id * 16 + 1] = 0u; }
+          }
+          id++;
+        }
+      }
+    } else {
       for (int tx = x0 >> 3; tx <= (x1 >> 3); tx++)
         for (int ty = y0 >> 3; ty <= (y1 >> 3); ty++) {
           const int e = (tx + 1) * DW + ty + 3;
@@ -424,6 +459,7 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
             if (edt_maps) { S.tiles[id * 16] = 0u; S.tiles[id * 16 + 1] = 0u; }
           }
         }
+    }
   }
   __syncthreads();
   MPHASE(3);
