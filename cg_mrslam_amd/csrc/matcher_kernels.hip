@@ -914,6 +914,60 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 #ifdef CGMR_PHASE_TIMING
     if (blockIdx.x == 0 && tid == 0) { for (int q = 10; q < 16; q++) g_mphase[q] = 0; for (int q = 22; q < 32; q++) g_mphase[q] = 0; }
 #endif
+    // ---------------- search window, angle table, bins -----------------------------------------------------
+    // They depend on the guess alone: the last wavefront -- which holds no beam of a 1081-beam scan and would idle through the
+    // load of the query scan and the building of the sort keys -- works them out now (11k cycles of a pair: a cold load of the
+    // guess, 65 dependent additions for the angle table, eight double divisions, all on one lane; then cos / sin per angle).
+    if (wave == NTH - 1) {
+      if (lane == 0) {
+        const double* g = guess + 3 * (size_t)pair;
+        float lo_xf = (float)(-P.win_x + g[0]), lo_yf = (float)(-P.win_y + g[1]), lo_tf = (float)(-P.win_t + g[2]);
+        float hi_xf = (float)(P.win_x + g[0]), hi_yf = (float)(P.win_y + g[1]), hi_tf = (float)(P.win_t + g[2]);
+        int lo_x = __float2int_rn((lo_xf - P.ll_x) * P.inv_res), lo_y = __float2int_rn((lo_yf - P.ll_y) * P.inv_res);
+        int hi_x = __float2int_rn((hi_xf - P.ll_x) * P.inv_res), hi_y = __float2int_rn((hi_yf - P.ll_y) * P.inv_res);
+        int nth = 0;
+        for (double t = (double)lo_tf; t < (double)hi_tf && nth < MAXTHETA; t += P.theta_res) S.theta[nth++] = t;
+        int ni = max(0, hi_x - lo_x), nj = max(0, hi_y - lo_y);
+        S.misc[1] = lo_x; S.misc[2] = lo_y; S.misc[3] = ni; S.misc[4] = nj; S.misc[5] = nth;
+        // bin ranges (DiscreteTriplet is monotone in each coordinate)
+        int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
+        if (ni > 0 && nj > 0 && nth > 0) {
+          float xa = P.ll_x + (P.res * (float)lo_x), xb = P.ll_x + (P.res * (float)(hi_x - 1));
+          float ya = P.ll_y + (P.res * (float)lo_y), yb = P.ll_y + (P.res * (float)(hi_y - 1));
+          bx0 = (int)((double)xa / P.dx); bx1 = (int)((double)xb / P.dx);
+          by0 = (int)((double)ya / P.dy); by1 = (int)((double)yb / P.dy);
+          bt0 = (int)(S.theta[0] / P.dth); bt1 = (int)(S.theta[nth - 1] / P.dth);
+        }
+        int nbx = bx1 - bx0 + 1, nby = by1 - by0 + 1, nbt = bt1 - bt0 + 1;
+        if (nbx * nby * nbt > MAXBINS || ni * nj > 64 * CAND_U * 64) { atomicExch(err, 3); nbx = nby = nbt = 0; S.misc[5] = 0; }
+        S.misc[6] = bx0; S.misc[7] = by0; S.misc[8] = bt0; S.misc[9] = nbx; S.misc[10] = nby; S.misc[11] = nbt;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int lo_x = S.misc[1], lo_y = S.misc[2], ni = S.misc[3], nj = S.misc[4], nth = S.misc[5];
+      const int bx0 = S.misc[6], by0 = S.misc[7], bt0 = S.misc[8], nbx = S.misc[9], nby = S.misc[10], nbt = S.misc[11];
+      const int nbins = nbx * nby * nbt;
+      for (int q = lane; q < nbins; q += 64) S.bins[q] = ~0ULL;
+      for (int q = lane; q < nth; q += 64) {
+        double sn, cs;
+        portable_sincos(S.theta[q], &sn, &cs);
+        S.theta_cs[q][0] = cs; S.theta_cs[q][1] = sn;
+      }
+      if (lane == 0) S.best_bits = 0x7f800000u;                 // best accepted score so far (float bits): +inf
+      // result bins of the window's x offsets, y offsets and angles (DiscreteTriplet, chargrid.h:68-85): the same expressions the
+      // candidates used to evaluate one by one -- two double divisions per accepted candidate
+      if (nbins > 0) {
+        if (lane < 32 && lane < ni) {
+          const float wx = P.ll_x + (P.res * (float)(lo_x + lane * P.x_steps));
+          S.binx[lane] = (uint8_t)(((int)((double)wx / P.dx) - bx0) * nby);
+        }
+        if (lane < 32 && lane < nj) {
+          const float wyy = P.ll_y + (P.res * (float)(lo_y + lane * P.y_steps));
+          S.biny[lane] = (uint8_t)((int)((double)wyy / P.dy) - by0);
+        }
+        for (int q = lane; q < nth; q += 64) S.bint[q] = (uint8_t)((int)(S.theta[q] / P.dth) - bt0);
+      }
+    }
     // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
     // sort keys: (cell x, cell y, beam) -- 32 bits when the cells fit 10 bits each (any laser up to 51 m at the reference's 0.1 m
     // subsample cells) and the beam index 11, else 64
@@ -1018,56 +1072,11 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     bool redo = LEAN && !fast;                                // a lean instance: this pair is the general kernel's
     if (!LEAN && !fast && part == 0 && tid == 0) atomicAdd(err + 2, 1);    // pairs whose tiles did not fit LDS (generic search path)
     MPHASE(5);
-    // ---------------- search window, angle table, bins -----------------------------------------------------
-    if (tid == 0) {
-      const double* g = guess + 3 * (size_t)pair;
-      float lo_xf = (float)(-P.win_x + g[0]), lo_yf = (float)(-P.win_y + g[1]), lo_tf = (float)(-P.win_t + g[2]);
-      float hi_xf = (float)(P.win_x + g[0]), hi_yf = (float)(P.win_y + g[1]), hi_tf = (float)(P.win_t + g[2]);
-      int lo_x = __float2int_rn((lo_xf - P.ll_x) * P.inv_res), lo_y = __float2int_rn((lo_yf - P.ll_y) * P.inv_res);
-      int hi_x = __float2int_rn((hi_xf - P.ll_x) * P.inv_res), hi_y = __float2int_rn((hi_yf - P.ll_y) * P.inv_res);
-      int nth = 0;
-      for (double t = (double)lo_tf; t < (double)hi_tf && nth < MAXTHETA; t += P.theta_res) S.theta[nth++] = t;
-      int ni = max(0, hi_x - lo_x), nj = max(0, hi_y - lo_y);
-      S.misc[1] = lo_x; S.misc[2] = lo_y; S.misc[3] = ni; S.misc[4] = nj; S.misc[5] = nth;
-      // bin ranges (DiscreteTriplet is monotone in each coordinate)
-      int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
-      if (ni > 0 && nj > 0 && nth > 0) {
-        float xa = P.ll_x + (P.res * (float)lo_x), xb = P.ll_x + (P.res * (float)(hi_x - 1));
-        float ya = P.ll_y + (P.res * (float)lo_y), yb = P.ll_y + (P.res * (float)(hi_y - 1));
-        bx0 = (int)((double)xa / P.dx); bx1 = (int)((double)xb / P.dx);
-        by0 = (int)((double)ya / P.dy); by1 = (int)((double)yb / P.dy);
-        bt0 = (int)(S.theta[0] / P.dth); bt1 = (int)(S.theta[nth - 1] / P.dth);
-      }
-      int nbx = bx1 - bx0 + 1, nby = by1 - by0 + 1, nbt = bt1 - bt0 + 1;
-      if (nbx * nby * nbt > MAXBINS || ni * nj > 64 * CAND_U * 64) { atomicExch(err, 3); nbx = nby = nbt = 0; S.misc[5] = 0; }
-      S.misc[6] = bx0; S.misc[7] = by0; S.misc[8] = bt0; S.misc[9] = nbx; S.misc[10] = nby; S.misc[11] = nbt;
-    }
+    // ---------------- search window, angle table, bins: worked out by the last wavefront at the start of the pair ------------
     __syncthreads();
     const int lo_x = S.misc[1], lo_y = S.misc[2], ni = S.misc[3], nj = S.misc[4], nth = S.misc[5];
     const int bx0 = S.misc[6], by0 = S.misc[7], bt0 = S.misc[8], nbx = S.misc[9], nby = S.misc[10], nbt = S.misc[11];
     const int nbins = nbx * nby * nbt;
-    for (int q = tid; q < nbins; q += CB_THREADS) S.bins[q] = ~0ULL;
-    if (tid < nth) {
-      double sn, cs;
-      portable_sincos(S.theta[tid], &sn, &cs);
-      S.theta_cs[tid][0] = cs; S.theta_cs[tid][1] = sn;
-    }
-    if (tid == 0) S.best_bits = 0x7f800000u;                   // best accepted score so far (float bits): +inf
-    // result bins of the window's x offsets, y offsets and angles (DiscreteTriplet, chargrid.h:68-85): the same expressions the
-    // candidates used to evaluate one by one -- two double divisions per accepted candidate
-    if (nbins > 0) {
-      const int q = tid - 128;
-      if (q >= 0 && q < 32 && q < ni) {
-        const float wx = P.ll_x + (P.res * (float)(lo_x + q * P.x_steps));
-        S.binx[q] = (uint8_t)(((int)((double)wx / P.dx) - bx0) * nby);
-      }
-      if (q >= 32 && q < 64 && q - 32 < nj) {
-        const float wyy = P.ll_y + (P.res * (float)(lo_y + (q - 32) * P.y_steps));
-        S.biny[q - 32] = (uint8_t)((int)((double)wyy / P.dy) - by0);
-      }
-      if (q >= 64 && q - 64 < nth) S.bint[q - 64] = (uint8_t)((int)(S.theta[q - 64] / P.dth) - bt0);
-    }
-    __syncthreads();
     const float ikscale = (float)(1. / (float)P.kscale);
     const int ncand = ni * nj;
     // (long walls make both happen at once: two wavefronts search then, with the last four lists)
