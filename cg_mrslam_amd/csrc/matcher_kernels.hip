@@ -76,8 +76,9 @@ struct Smem {
 static_assert((sizeof(uint16_t) * kMatchMaxDir) % 16 == 0, "tile pool must stay 16-byte aligned behind the directory");
 static_assert(offsetof(Smem, plist) == offsetof(Smem, tiles) + sizeof(uint32_t) * NT_LDS * 16 && ((NTH / 2) * LISTCAP * 4) % 64 == 0,
               "the point lists extend the tile pool");
-// block_scan_excl scratch (one int per thread + total): the last point list, idle whenever a scan runs
-__device__ __forceinline__ int* scan_scratch(Smem& S) { return reinterpret_cast<int*>(S.plist[NTH - 1]); }
+// block_scan_excl scratch (one int per thread + total): the fifth point list, idle whenever a scan runs (the last two hold the
+// reference scan's compacted cells while the query scan is still being subsampled)
+__device__ __forceinline__ int* scan_scratch(Smem& S) { return reinterpret_cast<int*>(S.plist[NTH / 2]); }
 static_assert(LISTCAP >= 516, "scan scratch needs 516 ints");
 static_assert(sizeof(Smem) <= 160 * 1024, "matcher LDS plan exceeds 160 KiB");
 
@@ -718,10 +719,13 @@ __device__ __forceinline__ int grid_cell(const Smem& S, const MatchParams& P, co
 
 // Query scan of one pair: cartesian -> CharGrid::subsample(0.1) (chargrid.cpp:98-122: cells in (x, y) order, members added in beam
 // order) -> laser pose.  KT = key type of the sort: cell x | cell y | beam index.  Returns the number of subsampled points.
-template <typename KT>
+struct NoEarlyWork { __device__ __forceinline__ void operator()() const {} };
+// `early`: called once by every wavefront that holds no beam (all of its keys are the padding value: the sort's stages inside a
+// wavefront, k <= 256, are no-ops for it and are skipped) before it joins the first exchange between wavefronts.
+template <typename KT, typename Early = NoEarlyWork>
 __device__ __forceinline__ int subsample_query(Smem& S, const MatchParams& P, int pair, const float* __restrict__ ranges_qry,
                                                const double* __restrict__ beam_cos, const double* __restrict__ beam_sin,
-                                               double* qraw, double* qpts) {
+                                               double* qraw, double* qpts, Early early = Early()) {
   constexpr bool K32 = sizeof(KT) == 4;
   constexpr int CELL_BITS = K32 ? 10 : 21, CELL_SHIFT = K32 ? 11 : 21, CELL_OFF = K32 ? 512 : (1 << 20);
   const KT INVALID = (KT)~(KT)0;
@@ -755,7 +759,10 @@ KT* keys = reinterpret_cast<KT*>(S.tiles);
     }
   }
   MPHASE(9);
+  const bool no_beams = wave >= (B + 255) / 256;                 // (wave-uniform)
+  if (no_beams) early();
   for (int k = 2; k <= 2048; k <<= 1) {
+    if (no_beams && k <= 256) continue;                          // 256 equal keys: nothing to sort inside this wavefront
     for (int j = k >> 1; j > 0; j >>= 1) {
       if (j >= 256) {
         __syncthreads();
@@ -909,6 +916,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
   for (int item = blockIdx.x; item < n_items;) {
     const int unit = item / P.split, part = item - unit * P.split;     // (unit: the slot of a split pair's shared bins)
     const int pair = from_list ? redo_list[unit] : unit;
+    if (tid == 0) S.misc[14] = 0;                                      // (the counter of the reference scan's compacted cell list)
     __syncthreads();
     MPHASE(0);
 #ifdef CGMR_PHASE_TIMING
@@ -971,16 +979,42 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     // ---------------- query scan: cartesian -> subsample(0.1) -> laser pose -----------------------------
     // sort keys: (cell x, cell y, beam) -- 32 bits when the cells fit 10 bits each (any laser up to 51 m at the reference's 0.1 m
     // subsample cells) and the beam index 11, else 64
-    const int nq = (LEAN || P.sort32) ? subsample_query<uint32_t>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts)
-                            : subsample_query<unsigned long long>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts);
+    // The cells of a single reference scan are worked out meanwhile by the wavefronts that hold no beam of the query scan (a
+    // 1081-beam scan fills five of the eight; the last one has the window above): a contiguous run of beams per thread, so that
+    // "same cell as the previous beam" needs nobody else's result, the distinct cells straight into the compacted list.
+    const int NS = P.n_ref_scans;
+    const int n_busy = (B + 255) / 256, n_early = 64 * (NTH - 1 - n_busy);
+    const bool early_cells = (LEAN || NS == 1) && n_early >= 64;
+    uint32_t* const cl1 = &S.plist[NTH / 2 + 2][0];               // the compacted single-scan list (two point lists)
+    auto ref_cell = [&](int bm) -> uint32_t {
+      const double r = (double)ranges_ref[(size_t)pair * B + bm];
+      if (!(r < P.max_range && r > P.min_range)) return 0x80008000u;
+      const double x = beam_cos[bm] * r, y = beam_sin[bm] * r;
+      double tc = P.lp_c, ts = P.lp_s, tx = P.lp_x, ty = P.lp_y;
+      if (ref_xform) { const double* T = ref_xform + 4 * (size_t)pair; tc = T[0]; ts = T[1]; tx = T[2]; ty = T[3]; }
+      const double wx = (tc * x - ts * y) + tx, wy = (ts * x + tc * y) + ty;
+      return world_to_packed_cell(P, wx, wy);
+    };
+    auto early_ref = [&]() {
+      if (!early_cells || wave == NTH - 1) return;
+      const int t = (wave - n_busy) * 64 + lane, per = (B + n_early - 1) / n_early;
+      const int i0 = t * per, i1 = min(B, i0 + per);
+      uint32_t prev = (i0 > 0 && i0 < B) ? ref_cell(i0 - 1) : 0x7fff7fffu;     // (a value no cell packs to)
+      for (int i = i0; i < i1; i++) {
+        const uint32_t packed = ref_cell(i);
+        if (packed != 0x80008000u && packed != prev) cl1[atomicAdd(&S.misc[14], 1)] = packed;
+        prev = packed;
+      }
+    };
+    const int nq = (LEAN || P.sort32) ? subsample_query<uint32_t>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts, early_ref)
+                            : subsample_query<unsigned long long>(S, P, pair, ranges_qry, beam_cos, beam_sin, qraw, qpts, early_ref);
     __syncthreads();
     MPHASE(2);
     // ---------------- reference scan -> cells -----------------------------------------------------------------
     // a single scan's cells fit the (still idle) point lists in LDS; a multi-scan set goes through the HBM scratch
-    const int NS = P.n_ref_scans;
     // (in the second half of the lists: the first half may become tiles, see NT_EXT)
     uint32_t* rcell_l = S.plist[NTH / 2];   // int16 x | int16 y << 16, 0x80008000 = invalid
-    for (int i = tid; i < NS * B; i += CB_THREADS) {
+    for (int i = tid; i < (early_cells ? 0 : NS * B); i += CB_THREADS) {
       const int sc = i / B, bm = i - sc * B;
       uint32_t packed = 0x80008000u;
       double r = (double)ranges_ref[((size_t)pair * NS + sc) * B + bm];
@@ -1000,11 +1034,10 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
     if (LEAN || NS == 1) {
       // valid beams whose cell differs from the previous beam's, compacted behind the raw list (the rasteriser's work
       // items are (point, kernel row): a quarter of the raw list's items would be skipped one by one)
-      uint32_t* const cl1 = &S.plist[NTH / 2 + 2][0];
       static_assert(2 * LISTCAP >= MAXPTS && NTH == 8, "raw and compacted single-scan lists: two point lists each");
-      if (tid == 0) S.misc[14] = 0;
+      if (tid == 0 && !early_cells) S.misc[14] = 0;
       __syncthreads();
-      for (int i = tid; i < B; i += CB_THREADS) {
+      for (int i = tid; i < (early_cells ? 0 : B); i += CB_THREADS) {
         const uint32_t packed = rcell_l[i];
         if (packed == 0x80008000u || (i > 0 && rcell_l[i - 1] == packed)) continue;
         cl1[atomicAdd(&S.misc[14], 1)] = packed;
