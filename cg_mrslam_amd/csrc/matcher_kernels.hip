@@ -334,6 +334,22 @@ __device__ int block_scan_excl(int v, int* sh, int* total) {
   return incl - v;
 }
 
+// the same with one barrier pair instead of eighteen: inside the wavefront by shuffles, the wavefront totals through LDS (sh: one
+// int per wavefront)
+__device__ __forceinline__ int block_scan_excl_fast(int v, int* sh, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  if (lane == 63) sh[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < nw; w++) { const int t = sh[w]; base += w < wave ? t : 0; tot += t; }
+  *total = tot;
+  __syncthreads();
+  return base + incl - v;
+}
+
 
 // addAndConvolvePoints' cell of a world point: double -> float, world2grid in float, lrint (chargrid.h:205-216)
 __device__ __forceinline__ uint32_t world_to_packed_cell(const MatchParams& P, double wx, double wy) {
@@ -528,36 +544,38 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
       }
       w0 = w[0]; w1 = w[1];
     };
-    // (2) one tile per thread and round: the three maps once, x rows 1..7 straight into the tile; x row 0 takes the place of
-    // the map and waits in registers for the barrier
-    constexpr int R0 = (NT_EXT + 255) / 256;                       // tiles per thread, whatever the workgroup size
+    // (2) half a tile (4 x rows) per thread and round -- a whole tile per thread left 300 of the 512 threads with one tile and the
+    // others with two --: x rows 1..7 straight into the tile; x row 0 takes the place of the map and waits in registers for the
+    // barrier
+    constexpr int R0 = (2 * NT_EXT + CB_THREADS - 1) / CB_THREADS;  // half tiles per thread (6)
     uint32_t r0w[R0][2];
 #pragma unroll
     for (int u = 0; u < R0; u++) {
-      const int d = 2 + tid + NTHR * u;
+      const int hi = tid + NTHR * u, d = 2 + (hi >> 1), x4 = 4 * (hi & 1);
       r0w[u][0] = r0w[u][1] = 0u;
       if (d >= ntile + 2) continue;
       const int q = tile_slot[d];
       const int dn = S.dir[q - 1], dp = S.dir[q + 1];
-      const uint2 m0 = *reinterpret_cast<const uint2*>(&S.tiles[d * 16]);
-      const uint2 mn = dn >= 2 ? *reinterpret_cast<const uint2*>(&S.tiles[dn * 16]) : make_uint2(0u, 0u);
-      const uint2 mp = dp >= 2 ? *reinterpret_cast<const uint2*>(&S.tiles[dp * 16]) : make_uint2(0u, 0u);
-      for (int xr = 0; xr < 8; xr++) {
-        const uint32_t sh = 8u * (uint32_t)(xr & 3);
-        const uint32_t a = xr < 4 ? mn.x : mn.y, b = xr < 4 ? m0.x : m0.y, c = xr < 4 ? mp.x : mp.y;
+      // (the map words of x rows x4 .. x4 + 3: word 0 holds rows 0..3, word 1 rows 4..7)
+      const uint32_t b = S.tiles[d * 16 + (x4 >> 2)];
+      const uint32_t a = dn >= 2 ? S.tiles[dn * 16 + (x4 >> 2)] : 0u;
+      const uint32_t c = dp >= 2 ? S.tiles[dp * 16 + (x4 >> 2)] : 0u;
+#pragma unroll
+      for (int xq = 0; xq < 4; xq++) {
+        const uint32_t sh = 8u * (uint32_t)xq;
         const uint32_t m24 = ((a >> sh) & 0xffu) | (((b >> sh) & 0xffu) << 8) | (((c >> sh) & 0xffu) << 16);
         uint32_t w0, w1;
         line_g2(m24, w0, w1);
-        if (xr == 0) { r0w[u][0] = w0; r0w[u][1] = w1; }
-        else *reinterpret_cast<uint2*>(&S.tiles[d * 16 + 2 * xr]) = make_uint2(w0, w1);
+        if (xq == 0 && x4 == 0) { r0w[u][0] = w0; r0w[u][1] = w1; }
+        else *reinterpret_cast<uint2*>(&S.tiles[d * 16 + 2 * (x4 + xq)]) = make_uint2(w0, w1);
       }
     }
     MPHASE(18);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < R0; u++) {
-      const int d = 2 + tid + NTHR * u;
-      if (d < ntile + 2) *reinterpret_cast<uint2*>(&S.tiles[d * 16]) = make_uint2(r0w[u][0], r0w[u][1]);
+      const int hi = tid + NTHR * u, d = 2 + (hi >> 1);
+      if (d < ntile + 2 && (hi & 1) == 0) *reinterpret_cast<uint2*>(&S.tiles[d * 16]) = make_uint2(r0w[u][0], r0w[u][1]);
     }
     __syncthreads();
     MPHASE(19);
@@ -819,7 +837,7 @@ KT* keys = reinterpret_cast<KT*>(S.tiles);
     nlead += lead ? 1 : 0;
   }
   int nq;
-  int rank = block_scan_excl(nlead, scan_scratch(S), &nq);
+  int rank = block_scan_excl_fast(nlead, scan_scratch(S), &nq);
   {
     const double lc = P.lp_c, ls = P.lp_s, ltx = P.lp_x, lty = P.lp_y;
 #pragma unroll
