@@ -373,60 +373,68 @@ __device__ __forceinline__ void stamp_word(uint32_t* wp, uint32_t kv) {
   }
 }
 
-// resetGrid + addAndConvolvePoints for n packed reference cells: tiles claimed and numbered by the points that reach them,
-// then the distance-transform rasteriser or compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
-// LEAN: the distance transform, plus the stamps of cells off the grid that reach in (the plain loop); a grid that needs anything else
-// leaves S.misc[12] = 2 (the pair goes to the general kernel).
-template <bool LEAN>
-__device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
-                           int* err, const int ncap = NT_LDS) {
-  const int tid = threadIdx.x;
-  const int NTHR = blockDim.x;
-  const int ntx = (P.nx + 7) >> 3, nty = (P.ny + 7) >> 3;
-  const int DW = nty + kMatchDirGuardY;
-  const int ndir = (ntx + 2) * DW;
-  const int K2 = P.fill;
-  const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
-  const int ctr = (P.kdim - 1) / 2;
-  // Tile ids: 0 = the all-fill tile (every directory entry no stamp reaches), 1 = the all-zero tile (the guard band around
-  // the grid: the fast search path looks up cells outside the grid without a bounds test), 2 .. ntile + 1 = the tiles some
-  // stamp reaches, numbered in the order their first point claims them (an atomic counter; the numbering differs from run
-  // to run, nothing that is computed depends on it).  Round 2 numbered them in directory order: two serial walks over the
-  // 24k-entry directory per thread and a block scan, 30k cycles per pair.
-  uint16_t* const tile_slot = reinterpret_cast<uint16_t*>(&S.totals[0][0]);       // tile -> directory slot    (idle until the search)
-  uint32_t* const claimed = reinterpret_cast<uint32_t*>(tile_slot + NT_EXT);       // one bit per directory slot (the same)
+// ---- the pieces of build_grid's front part: the beam-less wavefronts of k_match_close_batch run them early, beside the query scan's
+// sort (t = the caller's thread index among nt cooperating threads).
+struct GridGeom {
+  int ntx, nty, DW, ndir, ctr;
+  uint16_t* tile_slot;                                            // tile -> directory slot (in the idle totals)
+  uint32_t* claimed;                                              // one bit per directory slot (the same)
+};
+__device__ __forceinline__ GridGeom grid_geom(Smem& S, const MatchParams& P) {
+  GridGeom G;
+  G.ntx = (P.nx + 7) >> 3; G.nty = (P.ny + 7) >> 3;
+  G.DW = G.nty + kMatchDirGuardY;
+  G.ndir = (G.ntx + 2) * G.DW;
+  G.ctr = (P.kdim - 1) / 2;
+  G.tile_slot = reinterpret_cast<uint16_t*>(&S.totals[0][0]);
+  G.claimed = reinterpret_cast<uint32_t*>(G.tile_slot + NT_EXT);
   static_assert(NT_EXT * 2 + (kMatchMaxDir + 31) / 32 * 4 <= (int)sizeof(S.totals) && (NT_EXT & 1) == 0, "tile_slot + claim bits");
-  for (int q = tid; q < (ndir + 7) / 8; q += NTHR) reinterpret_cast<uint4*>(S.dir)[q] = make_uint4(0u, 0u, 0u, 0u);
-  for (int q = tid; q < (ndir + 31) / 32; q += NTHR) claimed[q] = 0u;
-  if (tid == 0) { S.misc[0] = 0; S.misc[15] = 0; }
-  if (tid < 16) { S.tiles[tid] = fill4; S.tiles[16 + tid] = 0u; }
-  // kernel columns for the stamping below: column ki as 32 bytes = 4 x 0xff, the kdim values along y, 0xff padding, so
-  // that the 32-bit word that covers four consecutive cells of a stamp is two aligned words and a byte alignment
-  const bool kcols = P.kdim <= 17;
-  if (kcols)
+  return G;
+}
+// the tables derived from the kernel table (the same for every pair of a launch): padded kernel columns for the stamping -- column
+// ki as 32 bytes = 4 x 0xff, the kdim values along y, 0xff padding, so that the 32-bit word that covers four consecutive cells of
+// a stamp is two aligned words and a byte alignment -- and the kernel value by squared cell distance for the distance transform.
+// Call by all threads of the workgroup (one barrier inside).
+__device__ __forceinline__ void grid_tables(Smem& S, const MatchParams& P) {
+  const int tid = threadIdx.x, NTHR = blockDim.x, ctr = (P.kdim - 1) / 2;
+  if (P.kdim <= 17)
     for (int q = tid; q < P.kdim * 32; q += NTHR) {
       const int ki = q >> 5, b = q & 31, dy = b - 4;
       S.kernel[kKcolOff + q] = (dy >= 0 && dy < P.kdim) ? S.kernel[dy * P.kdim + ki] : (uint8_t)0xff;
     }
-  if (P.edt && tid < kEdtLutN) S.kernel[kEdtLutOff + tid] = (uint8_t)K2;
+  if (P.edt && tid < kEdtLutN) S.kernel[kEdtLutOff + tid] = (uint8_t)P.fill;
   __syncthreads();
   if (P.edt)                                                     // (every decomposition of a squared distance holds the same value: checked on the host)
     for (int q = tid; q < P.kdim * P.kdim; q += NTHR) {
       const int i = q % P.kdim - ctr, j = q / P.kdim - ctr;
       S.kernel[kEdtLutOff + i * i + j * j] = S.kernel[q];
     }
-  // guard band: rows 0 and ntx + 1, columns 0..2 and nty + 3 .. DW - 1 of every row
-  for (int q = tid; q < 2 * DW; q += NTHR) S.dir[q < DW ? q : (ntx + 1) * DW + (q - DW)] = 1;
-  for (int q = tid; q < ntx * kMatchDirGuardY; q += NTHR) {
+}
+// directory cleared, guard band set, claim bits cleared, counters reset (everything of resetGrid but the two shared tiles, whose
+// place in the pool the query scan's sort keys still occupy when this runs early)
+__device__ __forceinline__ void grid_reset(Smem& S, const GridGeom& G, int t, int nt) {
+  for (int q = t; q < (G.ndir + 7) / 8; q += nt) reinterpret_cast<uint4*>(S.dir)[q] = make_uint4(0u, 0u, 0u, 0u);
+  for (int q = t; q < (G.ndir + 31) / 32; q += nt) G.claimed[q] = 0u;
+  if (t == 0) { S.misc[0] = 0; S.misc[15] = 0; }
+}
+__device__ __forceinline__ void grid_guard_band(Smem& S, const GridGeom& G, int t, int nt) {
+  // rows 0 and ntx + 1, columns 0..2 and nty + 3 .. DW - 1 of every row (after grid_reset's stores: the caller orders them)
+  for (int q = t; q < 2 * G.DW; q += nt) S.dir[q < G.DW ? q : (G.ntx + 1) * G.DW + (q - G.DW)] = 1;
+  for (int q = t; q < G.ntx * kMatchDirGuardY; q += nt) {
     const int row = 1 + q / kMatchDirGuardY, c = q - (row - 1) * kMatchDirGuardY;
-    S.dir[row * DW + (c < 3 ? c : nty + c)] = 1;
+    S.dir[row * G.DW + (c < 3 ? c : G.nty + c)] = 1;
   }
-  const bool edt_maps = P.edt != 0;                               // the claimer clears its tile's cell map (the first two words)
-  // A cell's stamp reaches up to 3 x 3 tiles.  Rounds 3-4 walked them one after the other -- read the bit, atomicOr, take a number
-  // from the counter: three dependent LDS round trips per tile, and the 64 lanes of a wavefront (neighbouring beams) on the same
-  // three addresses: 17k of a pair's 470k cycles.  Now the nine atomicOrs of a cell go out together (a lane whose left neighbour
-  // asks for the same tile leaves it to that one), and ONE add on the counter takes the numbers of all the tiles the lane won.
-  for (int i = tid; i < n; i += NTHR) {
+}
+// A cell's stamp reaches up to 3 x 3 tiles.  Rounds 3-4 walked them one after the other -- read the bit, atomicOr, take a number
+// from the counter: three dependent LDS round trips per tile, and the 64 lanes of a wavefront (neighbouring beams) on the same
+// three addresses: 17k of a pair's 470k cycles.  Now the nine atomicOrs of a cell go out together (a lane whose left neighbour
+// asks for the same tile leaves it to that one), and ONE add on the counter takes the numbers of all the tiles the lane won.
+// (The cell maps of the claimed tiles -- their first two words -- are cleared by the rasteriser: the tiles' place may still hold
+// the query scan's sort keys when this runs.)
+__device__ __forceinline__ void grid_claim(Smem& S, const MatchParams& P, const GridGeom& G, const uint32_t* rcell, int n, int ncap, int t, int nt) {
+  const int ctr = G.ctr, DW = G.DW;
+  uint32_t* const claimed = G.claimed;
+  for (int i = t; i < n; i += nt) {
     const uint32_t packed = rcell[i];
     if (packed == 0x80008000u) continue;
     const int rx = (int16_t)(packed & 0xffff), ry = (int16_t)(packed >> 16);
@@ -455,10 +463,7 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
         for (int k = 0; k < 9; k++) {
           if (bit[k] == 0u || (old[k] & bit[k])) continue;
           S.dir[e[k]] = (uint16_t)id;
-          if (id < ncap) {
-            tile_slot[id] = (uint16_t)e[k];
-            if (edt_maps) { S.tiles[id * 16] = 0u; S.tiles[id * 16 + 1] = 0u; }
-          }
+          if (id < ncap) G.tile_slot[id] = (uint16_t)e[k];
           id++;
         }
       }
@@ -471,12 +476,42 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
           if (atomicOr(&claimed[e >> 5], bit) & bit) continue;
           const int id = 2 + atomicAdd(&S.misc[0], 1);
           S.dir[e] = (uint16_t)id;
-          if (id < ncap) {
-            tile_slot[id] = (uint16_t)e;
-            if (edt_maps) { S.tiles[id * 16] = 0u; S.tiles[id * 16 + 1] = 0u; }
-          }
+          if (id < ncap) G.tile_slot[id] = (uint16_t)e;
         }
     }
+  }
+}
+
+// resetGrid + addAndConvolvePoints for n packed reference cells: tiles claimed and numbered by the points that reach them,
+// then the distance-transform rasteriser or compare-and-swap stamping.  Leaves S.misc[0] = #tiles, S.misc[12] = fast flag.
+// LEAN: the distance transform, plus the stamps of cells off the grid that reach in (the plain loop); a grid that needs anything else
+// leaves S.misc[12] = 2 (the pair goes to the general kernel).
+// tables_ready: grid_tables() ran for this launch; claimed_early: the directory is reset and the tiles are claimed (k_match_close_batch's
+// beam-less wavefronts did it beside the query scan's sort).
+template <bool LEAN>
+__device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const uint32_t* rcell, int n, uint32_t* gtiles, bool allow_fast,
+                           int* err, const int ncap = NT_LDS, const bool tables_ready = false, const bool claimed_early = false) {
+  const int tid = threadIdx.x;
+  const int NTHR = blockDim.x;
+  const GridGeom G = grid_geom(S, P);
+  const int ntx = G.ntx, nty = G.nty, DW = G.DW, ndir = G.ndir, ctr = G.ctr;
+  (void)ntx; (void)nty; (void)ndir;
+  const int K2 = P.fill;
+  const uint32_t fill4 = (uint32_t)K2 * 0x01010101u;
+  // Tile ids: 0 = the all-fill tile (every directory entry no stamp reaches), 1 = the all-zero tile (the guard band around
+  // the grid: the fast search path looks up cells outside the grid without a bounds test), 2 .. ntile + 1 = the tiles some
+  // stamp reaches, numbered in the order their first point claims them (an atomic counter; the numbering differs from run
+  // to run, nothing that is computed depends on it).  Round 2 numbered them in directory order: two serial walks over the
+  // 24k-entry directory per thread and a block scan, 30k cycles per pair.
+  uint16_t* const tile_slot = G.tile_slot;
+  const bool kcols = P.kdim <= 17;
+  if (tid < 16) { S.tiles[tid] = fill4; S.tiles[16 + tid] = 0u; }
+  if (!claimed_early) grid_reset(S, G, tid, NTHR);
+  if (!tables_ready) grid_tables(S, P);                            // (a barrier inside)
+  else if (!claimed_early) __syncthreads();
+  if (!claimed_early) {
+    grid_guard_band(S, G, tid, NTHR);
+    grid_claim(S, P, G, rcell, n, ncap, tid, NTHR);
   }
   __syncthreads();
   MPHASE(3);
@@ -509,6 +544,10 @@ __device__ __forceinline__ void build_grid(Smem& S, const MatchParams& P, const 
   // grids with overflow tiles keep the stamping below.
   MPHASE(16);
   if (edt) {
+    // (1) the cell maps: the first two words of every claimed tile, cleared here (the claims may have run while the pool still held
+    // the query scan's sort keys), then a bit per reference cell
+    for (int d = 2 + tid; d < ntile + 2; d += NTHR) { S.tiles[d * 16] = 0u; S.tiles[d * 16 + 1] = 0u; }
+    __syncthreads();
     int noff = 0;
     for (int i = tid; i < n; i += NTHR) {
       const uint32_t packed = rcell[i];
