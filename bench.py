@@ -391,9 +391,9 @@ def matcher_leg(ctx, dev, args, with_cpu):
     useful_rate = nx * byte_adds / 256.0 / ksec_x          # wave instructions / s that do algorithmic adds (exhaustive run)
     lds_peak = 256 * 256 * clk                             # bytes / s: the gathers are ds_read_b64, 256 B per CU and clock (MI355X guide, LDS)
     gather_rate = nx * byte_adds / ksec_x                  # algorithmic bytes gathered from the LDS-resident grid / s (exhaustive run)
-    # HBM per pair: 8.7 KB of ranges / guess / results + the rasteriser's finished lines, which go out to the workgroup's scratch
-    # and come back (64 B per 8x8 tile each way, ~720 tiles): ~100 KB; the committed PMC pass (2 x FETCH_SIZE + WRITE_SIZE) if present
-    hbm_pp = (pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096)) if pmc_m else 273e3
+    # HBM per pair: 8.7 KB of ranges / guess / results + per-workgroup scratch (subsampled query points; the rasteriser's finished lines of the
+    # pairs whose tiles leave no room for them in LDS): the committed PMC pass (2 x FETCH_SIZE + WRITE_SIZE) if present, else round 5's figure
+    hbm_pp = (pmc_m["traffic_bytes_corrected"] / pmc_m.get("pairs", 4096)) if pmc_m else 58e3
     golden = None
     gpath = os.path.join(ROOT, "tests", "golden", "match_close4096.npz")
     if os.path.exists(gpath) and base == 4096:
@@ -433,8 +433,8 @@ def matcher_leg(ctx, dev, args, with_cpu):
                                 "ones (bytes_fetched_per_useful_byte), the 2-byte directory loads cost a 4-byte pass each and "
                                 "lds_bank_conflict_frac of the LDS-array cycles are bank conflicts (SQ_LDS_BANK_CONFLICT / "
                                 "SQ_LDS_IDX_ACTIVE of the committed PMC pass); valu_issue = the same adds as packed-byte VALU "
-                                "instructions (256 per wave instruction) against one per SIMD and clock; HBM carries ~270 KB per pair "
-                                "(8.7 KB of inputs / results, the rest per-workgroup scratch: query points, the rasteriser's lines) and is not the roof (DESIGN.md 3); pruned_equivalent = the candidates of the exhaustive search per second of the pruned one (not bytes that move)"}}
+                                "instructions (256 per wave instruction) against one per SIMD and clock; HBM carries hbm.bytes_per_pair "
+                                "(8.7 KB of inputs / results, the rest per-workgroup scratch: the subsampled query points every angle reads, the rasteriser's lines of the pairs that do not fit LDS) and is not the roof (DESIGN.md 3); pruned_equivalent = the candidates of the exhaustive search per second of the pruned one (not bytes that move)"}}
     if with_cpu:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
