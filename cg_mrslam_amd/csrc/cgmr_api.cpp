@@ -808,7 +808,7 @@ using namespace cgmr;
 
 extern "C" {
 
-int cgmr_version(void) { return 101; }
+int cgmr_version(void) { return 102; }   // 102 (round 5): cgmr_match_last_redo_pairs / _path_counts, cgmr_graph_failed_batches, cgmr_comm_info added; nothing changed or removed
 
 int cgmr_ctx_create(int device, void* hip_stream, cgmr_ctx** out) {
   if (!out) return CGMR_E_INVALID;
