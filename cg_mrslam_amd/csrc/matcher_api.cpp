@@ -1233,6 +1233,52 @@ int cgmr_global_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cg
   return cgmr_global_matching_batch(ctx, cfg, 1, ref_set, cur_set, max_score, trel_out, found_out);
 }
 
+// ScanMatcher::scanMatchingLChierarchical (scan_matcher.cpp:296-356; its only call, :197, is commented out in the reference): the
+// reference set's grid, the current set subsampled, ONE region of +-(2, 2, 1) around reference^-1 * current, three levels of
+// hierarchicalSearch (theta step 0.025, bins 0.5 x 0.5 x 0.2); the best result.
+int cgmr_scan_matching_lc_hierarchical_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* ref_sets,
+                                             const cgmr_scan_set* cur_sets, double max_score, double* trel_out, int* found_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!cfg || n_jobs < 0 || (n_jobs > 0 && (!ref_sets || !cur_sets || !trel_out || !found_out)))
+    return set_err(ctx, CGMR_E_INVALID, "cgmr_scan_matching_lc_hierarchical: bad argument");
+  for (int j = 0; j < n_jobs; j++)
+    if (!scan_set_ok(ref_sets + j) || !scan_set_ok(cur_sets + j)) return set_err(ctx, CGMR_E_INVALID, "cgmr_scan_matching_lc_hierarchical: bad scan set");
+  std::vector<std::vector<double>> ref(n_jobs), qry(n_jobs);
+  std::vector<int> ref_alias(n_jobs, 0);
+  static const bool trace = getenv("CGMR_MATCH_TRACE") != nullptr;
+  prepare_scan_sets(cfg, n_jobs, ref_sets, cur_sets, ref, qry, ref_alias, trace);
+  std::vector<std::vector<float>> regions(n_jobs);
+  std::vector<SearchJob> jobs(n_jobs);
+  for (int j = 0; j < n_jobs; j++) {
+    const cgmr_scan_set *R = ref_sets + j, *Cs = cur_sets + j;
+    const Se2 d = se2_mul(se2_inv(se2_of(R->poses_xyt + 3 * (size_t)R->ref_index)), se2_of(Cs->poses_xyt + 3 * (size_t)Cs->ref_index));   // :318
+    // Eigen::Vector3f lower(-2. + initGuess.x(), ...): every double sum narrowed to float (:322-323)
+    regions[j] = {(float)(-2. + d.x), (float)(-2. + d.y), (float)(-1. + d.t), (float)(2. + d.x), (float)(2. + d.y), (float)(1. + d.t)};
+    const std::vector<double>& rj = ref[ref_alias[j]];
+    jobs[j].ref = rj.data(); jobs[j].n_ref = (int)(rj.size() / 2);
+    jobs[j].qry = qry[j].data(); jobs[j].n_qry = (int)(qry[j].size() / 2);
+    jobs[j].regions = regions[j].data(); jobs[j].n_regions = 1;
+  }
+  std::vector<std::vector<cgmr_match_result>> res;
+  int rc = hierarchical_batch_core(ctx, cfg, jobs, 0.025, max_score, 0.5, 0.5, 0.2, 3, res);    // :332-339
+  if (rc) return rc;
+  for (int j = 0; j < n_jobs; j++) {
+    double* t = trel_out + 3 * (size_t)j;
+    t[0] = t[1] = t[2] = 0;
+    found_out[j] = res[j].empty() ? 0 : 1;
+    if (!res[j].empty()) { t[0] = res[j][0].x; t[1] = res[j][0].y; t[2] = res[j][0].theta; }
+  }
+  return CGMR_OK;
+}
+
+int cgmr_scan_matching_lc_hierarchical(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
+                                       const cgmr_scan_set* cur_set, double max_score, double trel_out[3], int* found_out) {
+  if (!ctx) return CGMR_E_INVALID;
+  if (!ref_set || !cur_set || !trel_out || !found_out) return set_err(ctx, CGMR_E_INVALID, "cgmr_scan_matching_lc_hierarchical: bad argument");
+  *found_out = 0;
+  return cgmr_scan_matching_lc_hierarchical_batch(ctx, cfg, 1, ref_set, cur_set, max_score, trel_out, found_out);
+}
+
 int cgmr_verify_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* sets1,
                                const cgmr_scan_set* sets2, const double* trel12, double* score_out, int* accepted_out) {
   if (!ctx) return CGMR_E_INVALID;

@@ -171,6 +171,18 @@ class _GenericSearch:
         self.ctx._check(rc)
         return (True, out.copy()) if found.value else (False, None)
 
+    def scanMatchingLChierarchical(self, ref_scans, ref_index, cur_scans, cur_index, maxScore):   # noqa: N802,N803
+        """``ScanMatcher::scanMatchingLChierarchical`` (scan_matcher.cpp:296-356): one region of +-(2, 2, 1) around
+        reference^-1 * current, three hierarchy levels; returns (found, [trel]) like the reference's vector of at most one."""
+        a, ka = _scan_set(ref_scans, ref_index)
+        b, kb = _scan_set(cur_scans, cur_index)
+        out = np.zeros(3)
+        found = C.c_int(0)
+        rc = self.ctx.lib.cgmr_scan_matching_lc_hierarchical(self.ctx.h, C.byref(self.cfg), C.byref(a), C.byref(b), C.c_double(maxScore),
+                                                             C.c_void_p(out.ctypes.data), C.byref(found))
+        self.ctx._check(rc)
+        return (True, [out.copy()]) if found.value else (False, [])
+
     # ---- ScanMatcher::closeScanMatching with a multi-scan reference set (scan_matcher.cpp:112-189) ---------------
     def closeScanMatchingVSet(self, ref_scans, origin_index, cur_ranges, cur_pose, maxScore=0.15):   # noqa: N802,N803
         """The reference's call shape: up to 6 reference scans (graph_slam.cpp:230-241) rasterised in the frame of the

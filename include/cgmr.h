@@ -307,6 +307,9 @@ int cgmr_match_greedy(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, 
  *   cgmr_global_matching       bool globalMatching(vset, ref, currvset, current, SE2* trel, maxScore)
  *                              scan_matcher.cpp:358-428 (+ the single-vertex overload): 4-level hierarchical search
  *                              over +/-(10 m, 5 m, pi)
+ *   cgmr_scan_matching_lc_hierarchical  bool scanMatchingLChierarchical(vset, ref, currvset, current, vector<SE2>& trel, maxScore)
+ *                              scan_matcher.cpp:296-356 (the reference's only call of it, :197, is commented out): one region
+ *                              of +/-(2 m, 2 m, 1 rad) around reference^-1 * current, 3-level hierarchical search, best result
  *   cgmr_verify_matching       bool verifyMatching(vset1, ref1, vset2, ref2, SE2 trel12, double* score)
  *                              scan_matcher.cpp:430-505; *accepted_out = score <= 40
  *   cgmr_match_hierarchical    CharGrid::hierarchicalSearch(mresvec, points, regions, params, nLevels)
@@ -326,6 +329,8 @@ int cgmr_scan_matching_lc(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const c
                           const cgmr_scan_set* cur_set, double max_score, double* trel_out, int* n_out);
 int cgmr_global_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
                          const cgmr_scan_set* cur_set, double max_score, double trel_out[3], int* found_out);
+int cgmr_scan_matching_lc_hierarchical(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* ref_set,
+                                       const cgmr_scan_set* cur_set, double max_score, double trel_out[3], int* found_out);
 int cgmr_verify_matching(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const cgmr_scan_set* set1, const cgmr_scan_set* set2,
                          const double trel12[3], double* score_out, int* accepted_out);
 int cgmr_match_hierarchical(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_ref, const double* ref_pts_xy, int n_qry,
@@ -343,6 +348,8 @@ int cgmr_scan_matching_lc_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, i
                                 const cgmr_scan_set* cur_sets, double max_score, double* trel_out, int* n_out);
 int cgmr_global_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* ref_sets,
                                const cgmr_scan_set* cur_sets, double max_score, double* trel_out, int* found_out);
+int cgmr_scan_matching_lc_hierarchical_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* ref_sets,
+                                             const cgmr_scan_set* cur_sets, double max_score, double* trel_out, int* found_out);
 int cgmr_verify_matching_batch(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_jobs, const cgmr_scan_set* sets1,
                                const cgmr_scan_set* sets2, const double* trel12, double* score_out, int* accepted_out);
 

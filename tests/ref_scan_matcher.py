@@ -115,6 +115,18 @@ class RefScanMatcherLogic:
 
 
 
+    # ---- ScanMatcher::scanMatchingLChierarchical (scan_matcher.cpp:296-356) -----------------------------------------
+    def scanMatchingLChierarchical(self, ref_scans, ref_index, cur_scans, cur_index, maxScore):   # noqa: N802,N803
+        ref_pts = self.transformPointsFromVSet(ref_scans, ref_index)
+        qry = self.subsample(self.transformPointsFromVSet(cur_scans, cur_index), 0.1)
+        g = _se2_mul(_se2_inv(np.asarray(ref_scans[ref_index][1], dtype=np.float64)), np.asarray(cur_scans[cur_index][1], dtype=np.float64))
+        # Eigen::Vector3f lower(-2. + initGuess.x(), ...): double sums, each narrowed to float (:322-323)
+        region = np.array([[-2. + g[0], -2. + g[1], -1. + g[2], 2. + g[0], 2. + g[1], 1. + g[2]]], dtype=np.float32)
+        res = self.hierarchicalSearch(ref_pts, qry, region, 0.025, maxScore, 0.5, 0.5, 0.2, 3)
+        if len(res):
+            return True, [res[0, :3].copy()]
+        return False, []
+
     # ---- ScanMatcher::closeScanMatching with a multi-scan reference set (scan_matcher.cpp:112-189) ---------------
     def closeScanMatchingVSet(self, ref_scans, origin_index, cur_ranges, cur_pose, maxScore=0.15):   # noqa: N802,N803
         """The reference's call shape: up to 6 reference scans (graph_slam.cpp:230-241) rasterised in the frame of the

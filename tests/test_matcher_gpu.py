@@ -444,6 +444,13 @@ def test_c_abi_scan_matcher_members_match_python_restatement_on_oracle(ctx, orac
     g_c = lc.globalMatching(scans[:2], 0, [(cur_r, cur_est)], 0, 0.2)
     g_o = lo.globalMatching(scans[:2], 0, [(cur_r, cur_est)], 0, 0.2)
     assert g_c[0] == g_o[0] and g_c[0] and np.array_equal(g_c[1], g_o[1])
+    # scanMatchingLChierarchical (scan_matcher.cpp:296-356; unused by the reference's loop): +-(2, 2, 1) around the relative estimate,
+    # three hierarchy levels, the best result -- once with the estimate near the truth, once a metre and half a radian off
+    for cs in (cur_set, [(cur_r, synth.se2_compose(cur_est, np.array([0.9, -0.7, 0.45]))), cur_set[1]]):
+        h_c = lc.scanMatchingLChierarchical(scans[:3], 1, cs, 0, 0.3)
+        h_o = lo.scanMatchingLChierarchical(scans[:3], 1, cs, 0, 0.3)
+        assert h_c[0] == h_o[0] and len(h_c[1]) == len(h_o[1]) and all(np.array_equal(a, b) for a, b in zip(h_c[1], h_o[1]))
+    assert lc.scanMatchingLChierarchical(scans[:3], 1, cur_set, 0, 0.3)[0]
     # verifyMatching with two-scan sets and a transform that is off by 0.4 m (unexplained points -> low window mean)
     for t12 in (synth.se2_compose(synth.se2_inverse(poses[0]), cur_true), np.array([0.4, 0.3, 0.1])):
         v_c = lc.verifyMatching(scans[:2], 0, cur_set, 0, t12)
