@@ -1,5 +1,5 @@
-// ScanMatcher::{closeScanMatching, scanMatchingLC (2), globalMatching (2), verifyMatching} on the MI355X --
-// replaces src/matcher/scan_matcher.cpp:112-189, 191-294, 358-428, 430-505.  initializeKernel / initializeGrid /
+// ScanMatcher::{closeScanMatching, scanMatchingLC (2), scanMatchingLChierarchical, globalMatching (2), verifyMatching} on the MI355X --
+// replaces src/matcher/scan_matcher.cpp:112-189, 191-294, 296-356, 358-428, 430-505.  initializeKernel / initializeGrid /
 // resetGrid / applyTransfToScan stay in scan_matcher.cpp (they only set the state read below).
 // UNTESTED (needs g2o + Eigen + the reference's headers); see README.md in this directory.
 #include "cgmr_g2o_flatten.h"
@@ -58,6 +58,23 @@ bool ScanMatcher::scanMatchingLC(OptimizableGraph::VertexSet& referenceVset, Opt
   if (cgmr_scan_matching_lc(cgmr_g2o::context(), &cfg, &ref.set, &cur.set, maxScore, t, &n) != CGMR_OK) return false;
   for (int k = 0; k < n; k++) trel.push_back(se2_of(t + 3 * k));
   return n > 0;
+}
+
+bool ScanMatcher::scanMatchingLChierarchical(OptimizableGraph::VertexSet& referenceVset, OptimizableGraph::Vertex* _referenceVertex,
+                                             OptimizableGraph::VertexSet& currvset, OptimizableGraph::Vertex* _currentVertex,
+                                             std::vector<SE2>& trel, double maxScore) {
+  trel.clear();
+  RobotLaser* lasercv = laser_of(_currentVertex);
+  if (!lasercv) return false;
+  const cgmr_matcher_config cfg = config_of(_grid, _kernelRange, lasercv);
+  cgmr_g2o::FlatScanSet ref, cur;
+  if (!cgmr_g2o::flatten_scans(referenceVset, _referenceVertex, cfg.n_beams, ref) ||
+      !cgmr_g2o::flatten_scans(currvset, _currentVertex, cfg.n_beams, cur)) return false;
+  double t[3];
+  int found = 0;
+  if (cgmr_scan_matching_lc_hierarchical(cgmr_g2o::context(), &cfg, &ref.set, &cur.set, maxScore, t, &found) != CGMR_OK || !found) return false;
+  trel.push_back(se2_of(t));
+  return true;
 }
 
 bool ScanMatcher::globalMatching(OptimizableGraph::VertexSet& referenceVset, OptimizableGraph::Vertex* _referenceVertex,
