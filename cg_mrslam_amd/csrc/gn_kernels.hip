@@ -214,11 +214,22 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
     int blk = t / 9, el = t - 9 * blk;
     int elT = (el % 3) * 3 + el / 3;
     double acc = 0;
-    for (int p = asm_ptr[blk]; p < asm_ptr[blk + 1]; p++) {
-      int src = asm_src[p];
-      int edge = src >> 2, code = src & 3;
-      int comp = code == 0 ? el : code == 1 ? 18 + el : code == 2 ? 9 + el : 9 + elT;
-      acc += term[(size_t)edge * 33 + comp];
+    // (four contributions in flight: the list entry and the term it names are two dependent loads, a block has 2 to 8 of them;
+    // the order of the sum stays the list's)
+    const int p0 = asm_ptr[blk], p1 = asm_ptr[blk + 1];
+    for (int p = p0; p < p1; p += 4) {
+      int src[4];
+      double tv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) src[u] = p + u < p1 ? asm_src[p + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int edge = src[u] >> 2, code = src[u] & 3;
+        const int comp = code == 0 ? el : code == 1 ? 18 + el : code == 2 ? 9 + el : 9 + elT;
+        tv[u] = src[u] >= 0 ? term[(size_t)edge * 33 + comp] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (src[u] >= 0) acc += tv[u];
     }
     if (blk < nf) { if (cmask[blk]) acc = (el % 4 == 0) ? 1.0 : 0.0; }
     else if (cmask[off_row[blk - nf]] | cmask[off_col[blk - nf]]) acc = 0.0;
