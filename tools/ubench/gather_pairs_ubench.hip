@@ -27,10 +27,14 @@ typedef __attribute__((address_space(3))) const u32x2 lds_cu2;
 typedef __attribute__((address_space(3))) const u32x4 lds_cu4;
 
 // ---------------------------------------------------------------------------------------------- A: round 4
-template <bool HI>
+// RAW: the points of a list share the byte their 24 cells start at (classes by start byte): the loaded words are added as they are,
+// eight per row, and aligned once per flush
+template <bool HI, bool RAW = false>
 __device__ __forceinline__ void gatherA(const uint32_t* list, int nslots, int g, int G, const int (&a18)[2], int hi_clamp, uint32_t dw2,
                                         uint32_t tiles_base, uint32_t (&part)[2][6], int (&acc)[2][24], int& npart, int flush_iters) {
   constexpr int PPI = 2, RPL = 2;
+  uint32_t raw[2][8] = {};
+  const uint32_t class_sh = nslots > 0 ? (list[0] >> 16) & 3u : 0u;
   for (int j = g; j < nslots; j += G) {
     const uint2 pk2 = *reinterpret_cast<const uint2*>(&list[PPI * j]);
     const uint32_t pk[PPI] = {pk2.x, pk2.y};
@@ -62,6 +66,14 @@ __device__ __forceinline__ void gatherA(const uint32_t* list, int nslots, int g,
           D[u][w][2 * t] = v.x;
           D[u][w][2 * t + 1] = v.y;
         }
+    if (RAW) {
+#pragma unroll
+      for (int u = 0; u < PPI; u++)
+#pragma unroll
+        for (int w = 0; w < RPL; w++)
+#pragma unroll
+          for (int t = 0; t < 8; t++) raw[w][t] += D[u][w][t];
+    } else {
 #pragma unroll
     for (int u = 0; u < PPI; u++) {
       const uint32_t sh = (pk[u] >> 16) & 3u;
@@ -70,7 +82,17 @@ __device__ __forceinline__ void gatherA(const uint32_t* list, int nslots, int g,
 #pragma unroll
         for (int t = 0; t < 6; t++) part[w][t] += __builtin_amdgcn_alignbyte(D[u][w][t + 1 + (HI ? 1 : 0)], D[u][w][t + (HI ? 1 : 0)], sh);
     }
+    }
     if (++npart == flush_iters) {
+      if (RAW) {
+#pragma unroll
+        for (int w = 0; w < RPL; w++) {
+#pragma unroll
+          for (int t = 0; t < 6; t++) part[w][t] = __builtin_amdgcn_alignbyte(raw[w][t + 1 + (HI ? 1 : 0)], raw[w][t + (HI ? 1 : 0)], class_sh);
+#pragma unroll
+          for (int t = 0; t < 8; t++) raw[w][t] = 0;
+        }
+      }
 #pragma unroll
       for (int w = 0; w < RPL; w++)
 #pragma unroll
@@ -81,6 +103,12 @@ __device__ __forceinline__ void gatherA(const uint32_t* list, int nslots, int g,
         }
       npart = 0;
     }
+  }
+  if (RAW) {
+#pragma unroll
+    for (int w = 0; w < RPL; w++)
+#pragma unroll
+      for (int t = 0; t < 6; t++) part[w][t] += __builtin_amdgcn_alignbyte(raw[w][t + 1 + (HI ? 1 : 0)], raw[w][t + (HI ? 1 : 0)], class_sh);
   }
 }
 
@@ -289,15 +317,15 @@ __global__ __launch_bounds__(64 * NW) void k_gather(const uint16_t* dir_g, const
   int npart = 0;
   const uint32_t dw2 = 2u * (uint32_t)kDirW;
   unsigned long long t0, t1;
-  if (VAR == 0) {
+  if (VAR == 0 || VAR == 14) {
     const int grp = lane / 12, r = lane - 12 * grp;
     const bool act = lane < 60;
     const int hi_clamp = ((1200 + 15) << 18) | 0x3ffff;
     const int a18[2] = {r << 18, (r + 12) << 18};
     t0 = __builtin_readcyclecounter();
     for (int it = 0; it < reps; it++) {
-      gatherA<false>(pl, act ? nent / 4 : 0, grp, 5, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, 5);
-      gatherA<true>(pl + nent / 2, act ? nent / 4 : 0, grp, 5, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, 5);
+      gatherA<false, VAR == 14>(pl, act ? nent / 4 : 0, grp, 5, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, 5);
+      gatherA<true, VAR == 14>(pl + nent / 2, act ? nent / 4 : 0, grp, 5, a18, hi_clamp, dw2, lds_tiles, part, acc, npart, 5);
     }
     t1 = __builtin_readcyclecounter();
   } else {
@@ -453,5 +481,6 @@ int main(int argc, char** argv) {
   run<12>("B without the byte arithmetic", d_dir, d_tiles, d_list, d_rec, nent, reps, d_cyc, d_sink);
   run<13>("B without the directory loads", d_dir, d_tiles, d_list, d_rec, nent, reps, d_cyc, d_sink);
   run<4>("E pairs + id records", d_dir, d_tiles, d_list, d_rec, 160, reps, d_cyc, d_sink);
+  run<14>("A with raw word adds (start-byte classes)", d_dir, d_tiles, d_list, d_rec, nent, reps, d_cyc, d_sink);
   return 0;
 }
