@@ -245,6 +245,16 @@ class _BatchedSearch:
                                                                 C.c_void_p(f.ctypes.data)))
         return [(True, out[j].copy()) if f[j] else (False, None) for j in range(len(jobs))]
 
+    def scanMatchingLChierarchicalBatch(self, jobs, maxScore):   # noqa: N802,N803
+        """jobs: list of (ref_scans, ref_index, cur_scans, cur_index).  Returns [(found, [trel])] like the single calls."""
+        a, ka = _scan_set_array([(j[0], j[1]) for j in jobs])
+        b, kb = _scan_set_array([(j[2], j[3]) for j in jobs])
+        out, f = np.zeros((len(jobs), 3)), np.zeros(len(jobs), dtype=np.int32)
+        self.ctx._check(self.ctx.lib.cgmr_scan_matching_lc_hierarchical_batch(self.ctx.h, C.byref(self.cfg), C.c_int(len(jobs)), a, b,
+                                                                              C.c_double(maxScore), C.c_void_p(out.ctypes.data),
+                                                                              C.c_void_p(f.ctypes.data)))
+        return [(True, [out[j].copy()]) if f[j] else (False, []) for j in range(len(jobs))]
+
     def verifyMatchingBatch(self, jobs, trel12):   # noqa: N802
         """jobs: list of (scans1, ref1_index, scans2, ref2_index); trel12 (n, 3).  Returns [(accepted, score)]."""
         a, ka = _scan_set_array([(j[0], j[1]) for j in jobs])

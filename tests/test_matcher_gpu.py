@@ -545,6 +545,11 @@ def test_batched_lc_global_verify_equal_single_calls(ctx, oracle):
     assert sum(1 for f, _ in single_g if f) >= 4
     for (fa, ta), (fb, tb) in zip(single_g, batch_g):
         assert fa == fb and (not fa or np.array_equal(ta, tb))
+    single_h = [lc.scanMatchingLChierarchical(j[0], j[1], j[2], j[3], 0.3) for j in jobs[:6]]
+    batch_h = lc.scanMatchingLChierarchicalBatch(jobs[:6], 0.3)
+    assert sum(1 for f, _ in single_h if f) >= 4
+    for (fa, ta), (fb, tb) in zip(single_h, batch_h):
+        assert fa == fb and len(ta) == len(tb) and all(np.array_equal(x, y) for x, y in zip(ta, tb))
     vjobs = [(j[0], j[1], j[2], j[3]) for j in jobs]
     t12 = np.array([r[0] if len(r) else np.array([0.4, 0.2, 0.1]) for r in single_lc])
     single_v = [lc.verifyMatching(j[0], j[1], j[2], j[3], t12[k]) for k, j in enumerate(vjobs)]
