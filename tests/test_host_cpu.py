@@ -378,6 +378,22 @@ def _growing_graph(V, E, seed):
     return g, last
 
 
+def test_round5_entry_points_reject_a_missing_context_without_a_gpu():
+    """The entry points added in round 5 (version 102) check their arguments before touching a device."""
+    import ctypes as C
+    lib = _lib.load_library()
+    assert lib.cgmr_version() >= 102
+    out = (C.c_int64 * 4)()
+    E_INVALID = lib.cgmr_match_last_stats(None, out)                # (the code every entry point returns for a null context)
+    assert E_INVALID < 0
+    assert lib.cgmr_match_last_path_counts(None, out) == E_INVALID
+    assert lib.cgmr_match_last_redo_pairs(None, out) == E_INVALID
+    t, f = (C.c_double * 3)(), C.c_int(0)
+    assert lib.cgmr_scan_matching_lc_hierarchical(None, None, None, None, C.c_double(0.3), t, C.byref(f)) == E_INVALID
+    assert lib.cgmr_scan_matching_lc_hierarchical_batch(None, None, C.c_int(0), None, None, C.c_double(0.3), t, C.byref(f)) == E_INVALID
+    assert lib.cgmr_graph_failed_batches(None) <= 0
+
+
 def test_incremental_ordering_of_a_growing_graph():
     """The cached ordering extended by appended vertices (gn_symbolic.cpp: extend_order): the result is a valid elimination
     order, most steps re-use the ordering, and the tree stays close to what a from-scratch analysis of the final graph
