@@ -153,7 +153,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   for (int l = 0; l < D.nlevels; l++) {
     for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++)
       if (S.fronts[LF[q]].nchild > 0) D.h_level_leaf[l] = 0;
-    // a level of leaves gets shorter chunks, so that the LDS of three workgroups fits a CU
+    // a level of leaves has its own chunk length (kLeafChunkRows)
     const int chunk_rows = (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
     D.h_level_chunk[l] = chunk_rows;
     int nwork = 0;

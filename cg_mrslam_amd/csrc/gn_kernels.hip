@@ -12,7 +12,7 @@
 // Design ("GN kernels"): the factorisation is a supernodal multifrontal Cholesky.
 // The host (gn_symbolic.cpp) cuts the permuted matrix into dense fronts of <= 16 poses
 // (48 scalar columns) and sorts them into elimination-tree levels; one launch handles one
-// level, one workgroup handles one front or, for a front with a wide border, one 95-row share of it
+// level, one workgroup handles one front or, for a front with a wide border, one 79-row share of it (95 rows on a level of leaves)
 // (k_front_factor), or one 32x32 tile of a front's update matrix (k_front_update).  Children hand their update matrices to the parent
 // through HBM/L2 ("extend-add", pulled by the parent in a fixed child order), so there are
 // no atomics anywhere and results are bit-reproducible run to run.  All arithmetic is FP64.
@@ -54,7 +54,7 @@ constexpr int kRecIntsC = (int)(sizeof(WorkRec) / 4);
 constexpr int factor_panel_rows(int rows) { return (kFrontW + rows + 15) / 16 * 16; }
 constexpr int factor_smem_bytes(int rows) { return (factor_panel_rows(rows) * (kFrontW + 1) + kFrontW) * 8; }
 static_assert(factor_smem_bytes(kChunkRows + 1) <= 160 * 1024, "k_front_factor LDS plan exceeds 160 KiB");
-static_assert(kFrontW != 48 || 3 * factor_smem_bytes(kLeafChunkRows + 1) <= 160 * 1024, "a level of leaves: three workgroups per CU");
+static_assert(kFrontW != 48 || 2 * factor_smem_bytes(kLeafChunkRows + 1) <= 160 * 1024, "a level of leaves: two workgroups per CU");
 static_assert(kFrontW != 48 || 2 * factor_smem_bytes(kMidChunkRows + 1) <= 160 * 1024, "above the leaves: two workgroups per CU");
 static_assert(kFrontW + kChunkRows + 1 <= 208, "panel_cholesky: at most 4 x 48 rows below a diagonal block");
 
@@ -331,7 +331,8 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 // every front is formed by k_front_update, whose tiles spread over the idle CUs.
 constexpr int kFT = 512;             // threads of a k_front_factor workgroup: 8 wavefronts (the elimination passes use as many as there are 48-row
                                      // groups, the MFMA updates, the loads and the stores all of them; 256 threads: +4k cycles per work item)
-constexpr int kPanLoads = (kFrontW + kMidChunkRows + 1) * (kPanStride / 2) / kFT + 1;   // 16-byte loads per thread and round: a 95-row chunk's panel in one round (8)
+constexpr int kPanRoundRows = kFrontW + (kLeafChunkRows > kMidChunkRows ? kLeafChunkRows : kMidChunkRows) + 1;
+constexpr int kPanLoads = kPanRoundRows * (kPanStride / 2) / kFT + 1;   // 16-byte loads per thread and round: the longest chunk's panel (95 rows) in one round (8)
 template <bool BATCH>
 __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
                                                       const double* __restrict__ Pan, double* __restrict__ Lbuf,
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
   // tests are made once.
   {
     constexpr int H2 = kPanStride / 2, RPP = kFT / H2;           // double2 per row, rows per pass
-    static_assert(RPP * kPanLoads >= kFrontW + kMidChunkRows + 1, "a 95-row chunk's panel in one round of loads");
+    static_assert(RPP * kPanLoads >= kPanRoundRows, "the longest chunk's panel in one round of loads");
     const int c = tid % H2, row0 = tid / H2, c2 = 2 * c;
     const bool tact = row0 < RPP;
     const int nrows = W + nr + 1;                               // F11, this chunk's border rows, the rhs row

@@ -24,11 +24,12 @@ constexpr int kFrontW = (3 * kPanelW + 15) / 16 * 16;      // scalar columns per
 constexpr int64_t factor_header(int w) { return 2 * (int64_t)w * w + w; }   // L11 row-major, L11 column-major, 1/diag
 constexpr int kChunkRows = (kFrontW <= 48 ? 208 : 192) - kFrontW - 1;      // most border rows a k_front_factor workgroup can take: the elimination passes of the
                                      // panel factorisation hold 4 x 48 rows below a diagonal block (panel_cholesky.h)
-constexpr int kMidChunkRows = 95;    // border rows per work item above the leaves: a front with a wide border is cut into
+constexpr int kMidChunkRows = 79;    // border rows per work item above the leaves: a front with a wide border is cut into
                                      // several work items (each factors F11 again, fetches only the children's rows it owns):
-                                     // measured 191 / 127 / 95 / 63 / 47 rows -> 8.1 / 8.0 / 7.7 / 7.8 / 7.75 ms device on C2
+                                     // measured 191 / 127 / 95 / 63 / 47 rows -> 8.1 / 8.0 / 7.7 / 7.8 / 7.75 ms device on C2 (round 3); round 5, with the leaves at
+                                     // 95: 111 / 95 / 87 / 79 / 71 / 63 / 47 rows -> 5.26 / 5.16 / 5.15 / 5.11 / 5.10 / 5.11 / 5.07 ms (47: +1 ms of host analysis)
 
-constexpr int kLeafChunkRows = 63;   // the same for a level of leaves (k_front_factor_leaf: three workgroups per CU, 48 KB of LDS each)
+constexpr int kLeafChunkRows = 95;   // the same for a level of leaves (two workgroups per CU; 63 rows, three per CU: +0.04 ms on C2; 127 / 159: +0.02 / +-0)
 
 // A child is "small" when kSmallSlabLoads 16-byte loads per thread (256 threads, one column pair of one row each) cover
 // the whole leading slab of its update matrix: k_front_factor fetches all small children of a front in one round.

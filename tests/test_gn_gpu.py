@@ -54,7 +54,7 @@ def test_gpu_matches_oracle(ctx, oracle, V, E, iters, seed):
 @pytest.mark.parametrize("K,Lc,H", [(40, 30, 1), (40, 30, 3), (60, 20, 2), (24, 40, 4)])
 def test_fronts_with_many_children_and_wide_borders(ctx, oracle, K, Lc, H):
     """Hub graphs: fronts with up to 75 children (the work record carries 8; the rest take the streamed path),
-    fronts with big and small children mixed, borders cut into several 95-row work items."""
+    fronts with big and small children mixed, borders cut into several 79-row work items."""
     from cg_mrslam_amd._lib import gn_symbolic_info
     g = synth.make_hub_graph(K, Lc, H)
     a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
@@ -69,7 +69,7 @@ def test_fronts_with_many_children_and_wide_borders(ctx, oracle, K, Lc, H):
 @pytest.mark.parametrize("n", [40, 80, 120])
 def test_lattice_wide_borders(ctx, oracle, n):
     """N x N lattices: separators of ~N poses -> borders up to 180 poses (540 rows): fronts split into several
-    95-row work items, children with more rows than one staged map block, update matrices on the tile kernel."""
+    79-row work items, children with more rows than one staged map block, update matrices on the tile kernel."""
     from cg_mrslam_amd._lib import gn_symbolic_info
     g = synth.make_lattice_graph(n)
     a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
