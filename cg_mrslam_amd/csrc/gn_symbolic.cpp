@@ -1096,13 +1096,13 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     }
     const int n_nd = nf - (int)hubs.size();
     int root_rec = -1;
-    // The root's sweep starts at the graph's first pose when that one has no more neighbours than the average vertex: in a
-    // SLAM graph it is the start of the odometry chain, i.e. an end of the graph already, and the sweep that would look
-    // for a far vertex first (433 us of the 1270 us the ordering of C2 takes, all of it on the critical path) is saved.
-    // C2: 18 -> 17 tree levels as well (5.10 -> 4.77 ms device); CGMR_ND_ROOT_START=0 looks for a far vertex as before.
-    static const bool root_start = !(getenv("CGMR_ND_ROOT_START") && atoi(getenv("CGMR_ND_ROOT_START")) == 0);
-    const bool first_is_an_end = root_start && n_nd > 0 && (size_t)(ap[order[0] + 1] - ap[order[0]]) * (size_t)nf <= ai.size();
-    const NDRange whole = nd(C, 0, n_nd, 0, first_is_an_end ? order[0] : -1, &root_rec);
+    // The root looks for a far vertex first and sweeps from there, like every node below it.  Sweeping from the graph's first
+    // pose instead (the start of the odometry chain; one whole-graph BFS less, 0.2 ms) was measured twice: round 3, and round 5
+    // over 24 graphs (5k / 10k / 20k poses, eight seeds each): 561 tree levels in all against 523, single graphs 11 levels
+    // taller or 12 shorter -- the benchmark graph happens to gain one (18 -> 17 levels, 5.10 -> 4.77 ms device).  Not taken; nor
+    // both orderings side by side with the shorter tree kept (500 levels in all, +0.4-0.6 ms of analysis on the shared host
+    // for 0.24 ms per level and optimize(10)), nor a choice after three levels of both (517 levels).  DESIGN.md 2.1.
+    const NDRange whole = nd(C, 0, n_nd, 0, -1, &root_rec);
     S.nd_height_full = whole.height + (nf - n_nd + kPanelW - 1) / kPanelW;
     for (int p = n_nd; p < nf; p += kPanelW) pstart[p] = 1;
     pos_ranges.swap(C.subtree_ranges);
