@@ -489,40 +489,34 @@ struct SearchJob {
   const float* regions = nullptr; int n_regions = 0;
 };
 
-// CharGrid::greedySearch for every job of the batch in ONE launch; per job every result of its <= 4 thread maps,
-// ascending score (ties: result-map order).  All jobs share the grid geometry, the steps and the discretisation.
-static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const std::vector<SearchJob>& jobs, double step_x,
-                             double step_y, double theta_res, double max_score, double dx, double dy, double dth,
-                             std::vector<std::vector<cgmr_match_result>>& out) {
-  const int nj = (int)jobs.size();
-  out.assign(nj, {});
-  static const bool trace = getenv("CGMR_MATCH_TRACE") != nullptr;
-  const auto t_begin = std::chrono::steady_clock::now();
-  if (!cfg || !(theta_res > 0) || !(dx > 0) || !(dy > 0) || !(dth > 0)) return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
-  for (const SearchJob& J : jobs) {
-    if (J.n_ref < 0 || J.n_qry < 0 || J.n_regions < 0 || (J.n_ref > 0 && !J.ref) || (J.n_qry > 0 && !J.qry) || (J.n_regions > 0 && !J.regions))
-      return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
-    if (J.n_ref > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d reference points", kMatchMaxRef);
-  }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  MatchParams P;
-  std::vector<uint8_t> kern;
-  int rc = setup_geometry(ctx, cfg, P, kern);
-  if (rc) return rc;
-  P.max_score = max_score; P.dx = dx; P.dy = dy; P.dth = dth; P.theta_res = theta_res;
-  // chargrid.cpp:214-221
-  int xs = (int)(step_x / P.res), ys = (int)(step_y / P.res);
-  if (xs <= 0) xs = 1;
-  if (ys <= 0) ys = 1;
-  P.x_steps = xs; P.y_steps = ys;
-  // regions -> descriptors, exactly like the reference walks them (chargrid.cpp:223-239), job by job
+// The tables of one k_match_greedy launch: regions -> descriptors, search angles, (region, angle) work items, result-bin boxes,
+// workgroups per job -- exactly like the reference walks its regions (chargrid.cpp:214-239).  P carries the level's steps.
+struct GreedyTables {
   std::vector<RegionDesc> R;
   std::vector<double> theta;
   std::vector<int32_t> items, block_job;
-  std::vector<GreedyJob> G(nj);
-  std::vector<int> first_region(nj, 0), nthreads(nj, 0);
+  std::vector<GreedyJob> G;
+  std::vector<int> first_region, nthreads;
   size_t n_refs = 0, n_qrys = 0, total_bins = 0;
-  int max_ref = 1, nblocks = 0, live = 0;
+  int max_ref = 1, nblocks = 0;
+};
+static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<SearchJob>& jobs, double theta_res, double dx, double dy,
+                         double dth, GreedyTables& T) {
+  // regions -> descriptors, exactly like the reference walks them (chargrid.cpp:223-239), job by job
+  const int nj = (int)jobs.size();
+  const int xs = P.x_steps, ys = P.y_steps;
+  std::vector<RegionDesc>& R = T.R;
+  std::vector<double>& theta = T.theta;
+  std::vector<int32_t>&items = T.items, &block_job = T.block_job;
+  std::vector<GreedyJob>& G = T.G;
+  std::vector<int>&first_region = T.first_region, &nthreads = T.nthreads;
+  size_t &n_refs = T.n_refs, &n_qrys = T.n_qrys, &total_bins = T.total_bins;
+  int &max_ref = T.max_ref, &nblocks = T.nblocks;
+  int live = 0;
+  R.clear(); theta.clear(); items.clear(); block_job.clear();
+  G.assign(nj, GreedyJob());
+  first_region.assign(nj, 0); nthreads.assign(nj, 0);
+  n_refs = n_qrys = total_bins = 0; max_ref = 1; nblocks = 0;
   auto w2g = [&](float w, float ll) { return (int)std::lrint((w - ll) * P.inv_res); };
   for (const SearchJob& J : jobs) live += J.n_regions > 0 ? 1 : 0;
   const int blocks_cap = std::max(1, std::min(256, 2048 / std::max(live, 1)));     // few jobs: several workgroups each
@@ -535,11 +529,13 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
     D0.item_off = (int32_t)(items.size() / 2);
     D0.block0 = nblocks;
     first_region[j] = (int)R.size();
+    D0.region_off = (int32_t)R.size(); D0.n_regions = J.n_regions;
     max_ref = std::max(max_ref, J.n_ref);
     if (J.n_regions == 0) continue;
     const int num_threads = std::min(J.n_regions, 4);
     const int chunk = J.n_regions / num_threads;
     nthreads[j] = num_threads;
+    D0.n_threads = num_threads;
     std::vector<uint32_t> next_order(num_threads, 0);
     bool any = false;
     int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
@@ -584,6 +580,45 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
     for (int b = 0; b < D0.n_blocks; b++) block_job.push_back(j);
     nblocks += D0.n_blocks;
   }
+  return CGMR_OK;
+}
+
+// CharGrid::greedySearch for every job of the batch in ONE launch; per job every result of its <= 4 thread maps,
+// ascending score (ties: result-map order).  All jobs share the grid geometry, the steps and the discretisation.
+static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const std::vector<SearchJob>& jobs, double step_x,
+                             double step_y, double theta_res, double max_score, double dx, double dy, double dth,
+                             std::vector<std::vector<cgmr_match_result>>& out) {
+  const int nj = (int)jobs.size();
+  out.assign(nj, {});
+  static const bool trace = getenv("CGMR_MATCH_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (!cfg || !(theta_res > 0) || !(dx > 0) || !(dy > 0) || !(dth > 0)) return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
+  for (const SearchJob& J : jobs) {
+    if (J.n_ref < 0 || J.n_qry < 0 || J.n_regions < 0 || (J.n_ref > 0 && !J.ref) || (J.n_qry > 0 && !J.qry) || (J.n_regions > 0 && !J.regions))
+      return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
+    if (J.n_ref > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d reference points", kMatchMaxRef);
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MatchParams P;
+  std::vector<uint8_t> kern;
+  int rc = setup_geometry(ctx, cfg, P, kern);
+  if (rc) return rc;
+  P.max_score = max_score; P.dx = dx; P.dy = dy; P.dth = dth; P.theta_res = theta_res;
+  // chargrid.cpp:214-221
+  int xs = (int)(step_x / P.res), ys = (int)(step_y / P.res);
+  if (xs <= 0) xs = 1;
+  if (ys <= 0) ys = 1;
+  P.x_steps = xs; P.y_steps = ys;
+  GreedyTables T;
+  rc = greedy_tables(ctx, P, jobs, theta_res, dx, dy, dth, T);
+  if (rc) return rc;
+  std::vector<RegionDesc>& R = T.R;
+  std::vector<double>& theta = T.theta;
+  std::vector<int32_t>&items = T.items, &block_job = T.block_job;
+  std::vector<GreedyJob>& G = T.G;
+  std::vector<int>&first_region = T.first_region, &nthreads = T.nthreads;
+  const size_t n_refs = T.n_refs, n_qrys = T.n_qrys, total_bins = T.total_bins;
+  const int max_ref = T.max_ref, nblocks = T.nblocks;
   if (nblocks == 0) return CGMR_OK;
   if (total_bins > (size_t)1 << 28) return set_err(ctx, CGMR_E_INVALID, "result maps of the batch exceed 2 GB");
   P.ref_cap = (max_ref + 63) & ~63;
@@ -967,6 +1002,196 @@ void prepare_scan_sets(const cgmr_matcher_config* cfg, int n_jobs, const cgmr_sc
     fprintf(stderr, "[sets] %d runs + %d current sets %.0f us, join + thin out %.0f us\n", n_runs, n_jobs, us_runs, us_since(ta) - us_runs);
 }
 
+// The same level loop with the levels chained on the device: one upload, level 0's launch (tables made on the host as for any
+// greedy search; the first workgroup of every job leaves the rasterised grid in the grid cache), then per level k_hier_next
+// (results -> next level's regions, matcher_kernels.hip) and the next launch of k_match_greedy on the cached grids, one
+// readback of the sorted results of the last level.  A call whose jobs outgrow the fixed table slices (more than 256 results
+// of a job on one level, result-bin boxes beyond the slice) is not served here: `done` stays false and the caller runs the
+// level-by-level loop below (same kernels, tables made on the host).
+int hierarchical_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const std::vector<SearchJob>& jobs0, double theta_res,
+                           double max_score, double dx, double dy, double dth, int n_levels,
+                           std::vector<std::vector<cgmr_match_result>>& out, bool& done) {
+  done = false;
+  const int nj = (int)jobs0.size();
+  if (nj == 0 || n_levels < 2 || n_levels > 8) return CGMR_OK;      // (one level: the loop below -- the reference's single level never runs, chargrid.cpp:336)
+  static const bool trace = getenv("CGMR_MATCH_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (!cfg || !(theta_res > 0) || !(dx > 0) || !(dy > 0) || !(dth > 0)) return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
+  for (const SearchJob& J : jobs0) {
+    if (J.n_ref < 0 || J.n_qry < 0 || J.n_regions < 0 || (J.n_ref > 0 && !J.ref) || (J.n_qry > 0 && !J.qry) || (J.n_regions > 0 && !J.regions))
+      return set_err(ctx, CGMR_E_INVALID, "greedy search: bad argument");
+    if (J.n_ref > kMatchMaxRef) return set_err(ctx, CGMR_E_INVALID, "more than %d reference points", kMatchMaxRef);
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MatchParams P0;
+  std::vector<uint8_t> kern;
+  int rc = setup_geometry(ctx, cfg, P0, kern);
+  if (rc) return rc;
+  // the levels' parameters, as hierarchical_batch_core / greedy_batch_core derive them
+  std::vector<MatchParams> PL(n_levels, P0);
+  std::vector<double> half_x(n_levels), half_y(n_levels), half_t(n_levels);
+  const float res_f = (float)cfg->resolution;
+  int tmax = 1;
+  for (int lv = 0; lv < n_levels; lv++) {
+    const int i = n_levels - 1 - lv;
+    const int m = 1 << i;
+    const int mtheta = (m / 2 < 1) ? m : m / 2;
+    const float stepf = (float)m * res_f;
+    MatchParams& P = PL[lv];
+    P.max_score = max_score; P.dx = dx * m; P.dy = dy * m; P.dth = dth * m; P.theta_res = mtheta * theta_res;
+    int xs = (int)((double)stepf / P.res), ys = (int)((double)stepf / P.res);
+    if (xs <= 0) xs = 1;
+    if (ys <= 0) ys = 1;
+    P.x_steps = xs; P.y_steps = ys;
+    half_x[lv] = dx * m * .5; half_y[lv] = dy * m * .5; half_t[lv] = dth * m * .5;
+    if (lv > 0) {
+      const double cnt = 2 * half_t[lv - 1] / P.theta_res;
+      if (!(cnt < 250)) return CGMR_OK;                        // (not served here)
+      tmax = std::max(tmax, (int)cnt + 3);
+    }
+  }
+  GreedyTables T;
+  rc = greedy_tables(ctx, PL[0], jobs0, PL[0].theta_res, PL[0].dx, PL[0].dy, PL[0].dth, T);
+  if (rc) return rc;
+  out.assign(nj, {});
+  if (T.nblocks == 0) { done = true; return CGMR_OK; }
+  if (T.total_bins > (size_t)1 << 28) return set_err(ctx, CGMR_E_INVALID, "result maps of the batch exceed 2 GB");
+  const int capR = 256, capT = capR * tmax, capI = capT;
+  const int bpj = std::max(1, std::min(256, 2048 / nj));       // workgroups per job on the later levels (the ones without an item return at once)
+  std::vector<long long> capB(n_levels, 0);
+  for (int lv = 1; lv < n_levels; lv++) {
+    long long worst = 0;
+    for (int j = 0; j < nj; j++) {
+      const GreedyJob& G = T.G[j];
+      if (G.n_items == 0) continue;
+      const long long bx = ((long long)G.nbx << lv) + 4, by = ((long long)G.nby << lv) + 4, bt = ((long long)G.nbt << lv) + 4;
+      worst = std::max(worst, bx * by * bt * 4);
+    }
+    if (worst > (1ll << 21) || worst * nj > (1ll << 25)) return CGMR_OK;      // (not served here)
+    capB[lv] = (worst + 31) & ~31ll;
+  }
+  for (int lv = 0; lv < n_levels; lv++) {
+    PL[lv].ref_cap = (T.max_ref + 63) & ~63;
+    PL[lv].scratch_stride = ((size_t)4 * PL[lv].ref_cap + (size_t)PL[lv].overflow_tiles * 64 + 255) & ~size_t(255);
+  }
+  const size_t img = match_grid_image_bytes(P0);
+  Layout L;
+  const size_t o_ref = L.add(16 * std::max<size_t>(T.n_refs, 1)), o_q = L.add(16 * std::max<size_t>(T.n_qrys, 1)),
+               o_reg0 = L.add(sizeof(RegionDesc) * std::max<size_t>(T.R.size(), 1)), o_th0 = L.add(8 * std::max<size_t>(T.theta.size(), 1)),
+               o_it0 = L.add(4 * std::max<size_t>(T.items.size(), 1)), o_job0 = L.add(sizeof(GreedyJob) * (size_t)nj),
+               o_bj0 = L.add(4 * T.block_job.size()), o_bjn = L.add(4 * (size_t)nj * bpj), o_kern = L.add(kern.size());
+  const size_t hbytes = L.off;
+  const size_t cnt_bytes = (4 * (size_t)nj + 255) & ~size_t(255), res_bytes = 32 * (size_t)capR * nj;
+  const size_t o_err = L.add(256 + cnt_bytes + res_bytes), o_cnt = o_err + 256, o_res = o_cnt + cnt_bytes;
+  const size_t o_bins0 = L.add(8 * T.total_bins);
+  std::vector<size_t> o_reg(n_levels, 0), o_th(n_levels, 0), o_it(n_levels, 0), o_job(n_levels, 0), o_bins(n_levels, 0);
+  for (int lv = 1; lv < n_levels; lv++) {
+    o_reg[lv] = L.add(sizeof(RegionDesc) * (size_t)capR * nj);
+    o_th[lv] = L.add(8 * (size_t)capT * nj);
+    o_it[lv] = L.add(8 * (size_t)capI * nj);
+    o_job[lv] = L.add(sizeof(GreedyJob) * (size_t)nj);
+    o_bins[lv] = L.add(8 * (size_t)capB[lv] * nj);
+  }
+  const size_t o_cache = L.add(img * (size_t)nj);
+  const size_t o_scratch = L.add(PL[0].scratch_stride * (size_t)T.nblocks);      // (level 0 only: the later levels load the cached grids)
+  rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
+  if (rc) return rc;
+  const size_t h_back = (hbytes + 255) & ~size_t(255), back_bytes = 256 + cnt_bytes + res_bytes;
+  rc = pinned_reserve(ctx, h_back + back_bytes);
+  if (rc) return rc;
+  char* h = ctx->pinned;
+  for (int j = 0; j < nj; j++) {
+    if (jobs0[j].n_ref) memcpy(h + o_ref + 16 * (size_t)T.G[j].ref_off, jobs0[j].ref, 16 * (size_t)jobs0[j].n_ref);
+    if (jobs0[j].n_qry) memcpy(h + o_q + 16 * (size_t)T.G[j].qry_off, jobs0[j].qry, 16 * (size_t)jobs0[j].n_qry);
+  }
+  if (!T.R.empty()) memcpy(h + o_reg0, T.R.data(), sizeof(RegionDesc) * T.R.size());
+  if (!T.theta.empty()) memcpy(h + o_th0, T.theta.data(), 8 * T.theta.size());
+  if (!T.items.empty()) memcpy(h + o_it0, T.items.data(), 4 * T.items.size());
+  memcpy(h + o_job0, T.G.data(), sizeof(GreedyJob) * (size_t)nj);
+  memcpy(h + o_bj0, T.block_job.data(), 4 * T.block_job.size());
+  {
+    int32_t* bjn = reinterpret_cast<int32_t*>(h + o_bjn);
+    for (int j = 0; j < nj; j++) for (int b = 0; b < bpj; b++) bjn[(size_t)j * bpj + b] = j;
+  }
+  memcpy(h + o_kern, kern.data(), kern.size());
+  char* d = ctx->mt_arena.ptr;
+  const auto t_staged = std::chrono::steady_clock::now();
+  HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d + o_err, 0, 256 + cnt_bytes, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d + o_bins0, 0xff, 8 * T.total_bins, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int* d_err = (int*)(d + o_err);
+  launch_match_greedy(ctx->stream, T.nblocks, PL[0], (const GreedyJob*)(d + o_job0), (const int32_t*)(d + o_bj0), (const double*)(d + o_ref),
+                      (const double*)(d + o_q), (const RegionDesc*)(d + o_reg0), (const double*)(d + o_th0), (const int32_t*)(d + o_it0),
+                      (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch), (unsigned long long*)(d + o_bins0), d_err,
+                      (unsigned char*)(d + o_cache), img, n_levels > 1 ? 1 : 0);
+  for (int lv = 0; lv < n_levels; lv++) {
+    const bool last = lv == n_levels - 1;
+    HierStep H;
+    memset(&H, 0, sizeof H);
+    H.jobs = (const GreedyJob*)(d + (lv == 0 ? o_job0 : o_job[lv]));
+    H.regions = (const RegionDesc*)(d + (lv == 0 ? o_reg0 : o_reg[lv]));
+    H.theta = (const double*)(d + (lv == 0 ? o_th0 : o_th[lv]));
+    H.bins = (const unsigned long long*)(d + (lv == 0 ? o_bins0 : o_bins[lv]));
+    H.x_steps = PL[lv].x_steps; H.y_steps = PL[lv].y_steps;
+    H.final_level = last ? 1 : 0;
+    H.cap_regions = capR; H.cap_theta = capT; H.cap_items = capI;
+    H.blocks_per_job = bpj;
+    H.results = (double*)(d + o_res);
+    H.counts = (int*)(d + o_cnt);
+    if (!last) {
+      H.jobs_next = (GreedyJob*)(d + o_job[lv + 1]);
+      H.regions_next = (RegionDesc*)(d + o_reg[lv + 1]);
+      H.theta_next = (double*)(d + o_th[lv + 1]);
+      H.items_next = (int32_t*)(d + o_it[lv + 1]);
+      H.bins_next = (unsigned long long*)(d + o_bins[lv + 1]);
+      H.x_steps_next = PL[lv + 1].x_steps; H.y_steps_next = PL[lv + 1].y_steps;
+      H.half_x = half_x[lv]; H.half_y = half_y[lv]; H.half_t = half_t[lv];
+      H.theta_res_next = PL[lv + 1].theta_res; H.dx_next = PL[lv + 1].dx; H.dy_next = PL[lv + 1].dy; H.dth_next = PL[lv + 1].dth;
+      H.cap_bins_next = capB[lv + 1];
+    }
+    launch_hier_next(ctx->stream, nj, PL[lv], H, d_err);
+    if (!last)
+      launch_match_greedy(ctx->stream, nj * bpj, PL[lv + 1], (const GreedyJob*)(d + o_job[lv + 1]), (const int32_t*)(d + o_bjn),
+                          (const double*)(d + o_ref), (const double*)(d + o_q), (const RegionDesc*)(d + o_reg[lv + 1]),
+                          (const double*)(d + o_th[lv + 1]), (const int32_t*)(d + o_it[lv + 1]), (const uint8_t*)(d + o_kern),
+                          (unsigned char*)(d + o_scratch), (unsigned long long*)(d + o_bins[lv + 1]), d_err,
+                          (unsigned char*)(d + o_cache), img, 2);
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h + h_back, d + o_err, back_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  const int* errv = reinterpret_cast<const int*>(h + h_back);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->match_seconds = 1e-3 * ms;
+  const auto t_back = std::chrono::steady_clock::now();
+  if (errv[0] != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel error %d", errv[0]);
+  if (errv[8] != 0) {                                         // a job outgrew its slices: level by level instead
+    if (trace) fprintf(stderr, "[hier] %d jobs, %d levels: table slices too small, level by level\n", nj, n_levels);
+    return CGMR_OK;
+  }
+  const int* counts = reinterpret_cast<const int*>(h + h_back + 256);
+  const double* res = reinterpret_cast<const double*>(h + h_back + 256 + cnt_bytes);
+  for (int j = 0; j < nj; j++) {
+    const int n = std::min(std::max(counts[j], 0), capR);
+    out[j].resize(n);
+    for (int k = 0; k < n; k++) {
+      const double* r = res + 4 * ((size_t)j * capR + k);
+      out[j][k] = {r[0], r[1], r[2], r[3]};
+    }
+  }
+  done = true;
+  if (trace) {
+    auto us = [](auto x, auto y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+    fprintf(stderr, "[hier] jobs %d levels %d blocks %d + %d x %d upload %zu B: stage %.0f us, device+sync %.0f us (kernels %.0f), decode %.0f us\n",
+            nj, n_levels, T.nblocks, n_levels - 1, nj * bpj, hbytes, us(t_begin, t_staged), us(t_staged, t_back), 1e3 * ms,
+            us(t_back, std::chrono::steady_clock::now()));
+  }
+  return CGMR_OK;
+}
+
 // CharGrid::hierarchicalSearch (chargrid.cpp:310-344, 376-400) for a batch of searches: levels n-1 .. 0, step 2^i
 // cells, theta step max(2^i / 2, 1) * thetaRes, bins 2^i * (dx, dy, dth); every result of a level seeds a region of
 // half a bin around it for the next one; the last level only runs if the one before found something.  One launch per
@@ -975,6 +1200,12 @@ int hierarchical_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const
                             double max_score, double dx, double dy, double dth, int n_levels,
                             std::vector<std::vector<cgmr_match_result>>& out) {
   const int nj = (int)jobs0.size();
+  static const bool host_loop = getenv("CGMR_HIER_HOST") && atoi(getenv("CGMR_HIER_HOST")) != 0;
+  if (!host_loop) {                                          // the levels chained on the device
+    bool done = false;
+    int rc = hierarchical_batch_dev(ctx, cfg, jobs0, theta_res, max_score, dx, dy, dth, n_levels, out, done);
+    if (rc || done) return rc;
+  }
   out.assign(nj, {});
   std::vector<std::vector<float>> cur(nj);
   std::vector<uint8_t> alive(nj, 1);

@@ -60,6 +60,38 @@ struct GreedyJob {
   int32_t bx0, by0, bt0, nbx, nby, nbt;      // bounding box of its result bins
   int32_t block0, n_blocks;                  // workgroups [block0, block0 + n_blocks) serve it
   int64_t bins_off;                          // first key of its result maps (num_threads * nbins keys)
+  int32_t region_off, n_regions;             // its regions in the launch's region table
+  int32_t n_threads;                         // result maps it fills: min(n_regions, 4) (chargrid.cpp:228)
+  int32_t pad_;
+};
+
+// The level loop of CharGrid::hierarchicalSearch on the device (chargrid.cpp:310-344, 376-400): between two levels' launches of
+// k_match_greedy, k_hier_next decodes a job's result maps, sorts the results by score and writes the next level's tables -- a
+// region of half a bin around every result -- or, after the last level, the sorted results.  Every job owns fixed slices of the
+// tables (cap_* entries each); a job that outgrows one raises err[8] and the host runs the call level by level instead.
+struct HierStep {
+  // the level just searched
+  const GreedyJob* jobs;
+  const RegionDesc* regions;
+  const double* theta;
+  const unsigned long long* bins;
+  int x_steps, y_steps;
+  // the next level (final: none, the results go to `results`)
+  int final_level;
+  GreedyJob* jobs_next;
+  RegionDesc* regions_next;
+  double* theta_next;
+  int32_t* items_next;
+  unsigned long long* bins_next;
+  int x_steps_next, y_steps_next;
+  double half_x, half_y, half_t;             // half a bin of the level just searched
+  double theta_res_next, dx_next, dy_next, dth_next;
+  int cap_regions, cap_theta, cap_items;     // per job
+  long long cap_bins_next;                   // keys per job
+  int blocks_per_job;
+  // results of the last level: per job a count (in counts[job]) and cap_regions x (x, y, theta, score)
+  double* results;
+  int* counts;
 };
 
 // One verifyMatching of a batched k_match_verify launch
@@ -75,7 +107,10 @@ void launch_match_verify(hipStream_t st, int n_jobs, const MatchParams& P, const
 void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const GreedyJob* jobs, const int32_t* block_job,
                          const double* ref_pts, const double* qry_pts, const RegionDesc* regions, const double* theta,
                          const int32_t* items, const uint8_t* kernel_lut, unsigned char* scratch, unsigned long long* bins,
-                         int* err);
+                         int* err, unsigned char* grid_cache = nullptr, size_t grid_cache_stride = 0, int grid_cache_mode = 0);
+size_t match_grid_image_bytes(const MatchParams& P);     // one job's slot in the grid cache (mode 1: the job's first workgroup stores
+                                                         // the rasterised grid there, mode 2: every workgroup loads it instead of rasterising)
+void launch_hier_next(hipStream_t st, int n_jobs, const MatchParams& P, const HierStep& H, int* err);
 void launch_match_close_batch(hipStream_t st, int nblocks, int variant, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,

@@ -1849,25 +1849,55 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
                                                       const int32_t* __restrict__ items,
                                                       const uint8_t* __restrict__ kernel_lut,
                                                       unsigned char* __restrict__ scratch,
-                                                      unsigned long long* __restrict__ bins_all, int* __restrict__ err) {
+                                                      unsigned long long* __restrict__ bins_all, int* __restrict__ err,
+                                                      unsigned char* __restrict__ grid_cache, size_t grid_cache_stride,
+                                                      int grid_cache_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const GreedyJob J = jobs[block_job[blockIdx.x]];
+  const int job = block_job[blockIdx.x];
+  const GreedyJob J = jobs[job];
+  if (J.n_items <= 0) return;                                // (a search of the level loop that found nothing one level up: k_hier_next)
   const int jb = blockIdx.x - J.block0;                      // my index among the job's workgroups
   const double* ref_pts = ref_pts_all + 2 * (size_t)J.ref_off;
   const double* qry_pts = qry_pts_all + 2 * (size_t)J.qry_off;
   unsigned long long* bins = bins_all + J.bins_off;
-  unsigned char* my = scratch + (size_t)blockIdx.x * P.scratch_stride;
+  unsigned char* my = scratch + (size_t)blockIdx.x * P.scratch_stride;               // (not touched in grid-cache mode 2: no scratch behind it then)
   uint32_t* rcell = reinterpret_cast<uint32_t*>(my);                               // P.ref_cap packed cells
-  uint32_t* gtiles = rcell + P.ref_cap;
+  const uint32_t* gtiles = rcell + P.ref_cap;
   const int nty = (P.ny + 7) >> 3;
   const int DW = nty + kMatchDirGuardY;
-  for (int q = tid; q < P.kdim * P.kdim; q += GR_THREADS) S.kernel[q] = kernel_lut[q];
-  for (int i = tid; i < J.n_ref; i += GR_THREADS) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
-  __syncthreads();
-  build_grid<false>(S, P, rcell, J.n_ref, gtiles, /*allow_fast=*/false, err);
+  // The grid of a job is the same on every level of a hierarchical search: the first level's first workgroup leaves its image --
+  // tile count, directory, tiles -- in the job's slot of the grid cache (mode 1), the later levels' workgroups load it (mode 2:
+  // ~100 KB from L2 instead of a rasterisation; tiles beyond the LDS pool are read in place).
+  unsigned char* const slot = grid_cache ? grid_cache + (size_t)job * grid_cache_stride : nullptr;
+  const size_t dir_bytes = ((((size_t)((P.nx + 7) >> 3) + 2) * (size_t)DW * 2) + 15) & ~size_t(15);
+  if (grid_cache_mode == 2) {
+    const int ntile = *reinterpret_cast<const int*>(slot);
+    const uint4* dsrc = reinterpret_cast<const uint4*>(slot + 64);
+    for (int q = tid; q < (int)(dir_bytes / 16); q += GR_THREADS) reinterpret_cast<uint4*>(S.dir)[q] = dsrc[q];
+    const uint4* tsrc = reinterpret_cast<const uint4*>(slot + 64 + dir_bytes);
+    for (int q = tid; q < min(ntile + 2, NT_LDS) * 4; q += GR_THREADS) reinterpret_cast<uint4*>(S.tiles)[q] = tsrc[q];
+    gtiles = reinterpret_cast<const uint32_t*>(slot + 64 + dir_bytes + (size_t)NT_LDS * 64);
+    __syncthreads();
+  } else {
+    for (int q = tid; q < P.kdim * P.kdim; q += GR_THREADS) S.kernel[q] = kernel_lut[q];
+    for (int i = tid; i < J.n_ref; i += GR_THREADS) rcell[i] = world_to_packed_cell(P, ref_pts[2 * i], ref_pts[2 * i + 1]);
+    __syncthreads();
+    build_grid<false>(S, P, rcell, J.n_ref, rcell + P.ref_cap, /*allow_fast=*/false, err);
+    if (grid_cache_mode == 1 && jb == 0) {
+      __syncthreads();
+      const int ntile = S.misc[0];
+      if (tid == 0) *reinterpret_cast<int*>(slot) = ntile;
+      uint4* ddst = reinterpret_cast<uint4*>(slot + 64);
+      for (int q = tid; q < (int)(dir_bytes / 16); q += GR_THREADS) ddst[q] = reinterpret_cast<const uint4*>(S.dir)[q];
+      uint4* tdst = reinterpret_cast<uint4*>(slot + 64 + dir_bytes);
+      for (int q = tid; q < min(ntile + 2, NT_LDS) * 4; q += GR_THREADS) tdst[q] = reinterpret_cast<const uint4*>(S.tiles)[q];
+      const uint4* osrc = reinterpret_cast<const uint4*>(gtiles);
+      for (int q = tid; q < max(0, ntile + 2 - NT_LDS) * 4; q += GR_THREADS) tdst[NT_LDS * 4 + q] = osrc[q];
+    }
+  }
   const float ikscale = (float)(1. / (float)P.kscale);
   const int nbins = J.nbx * J.nby * J.nbt;
   uint32_t* const pl = &S.plist[0][0] + (wave >> 1) * (2 * LISTCAP);   // 8 wavefronts in pairs: the two of a pair build the same list
@@ -2037,6 +2067,187 @@ __global__ __launch_bounds__(VF_THREADS) void k_match_verify(MatchParams P, cons
   }
 }
 
+// The host part of CharGrid::hierarchicalSearch between two levels (chargrid.cpp:318-343, 380-399 and greedySearch's region walk,
+// :214-239), per job on one workgroup: the level's result maps are decoded in map order (thread maps in order, bins ascending --
+// the order the reference's std::map iteration gives), sorted by score (stable), and every result seeds a region of half a bin
+// around it -- region descriptors, search angles, work items, result-bin box of the next level, its bins cleared --, or, after
+// the last level, the sorted results are written out.  Same arithmetic as the host code it replaces (matcher_api.cpp:
+// greedy_tables / greedy_batch_core's decode; float regions, double angles and bin indices, no contraction).
+constexpr int HN_THREADS = 256;
+constexpr int kHierCap = 256;                 // results of a job and level the device loop holds (HierStep::cap_regions <= this)
+__global__ __launch_bounds__(HN_THREADS) void k_hier_next(MatchParams P, HierStep H, int* __restrict__ err) {
+  __shared__ float s_wx[kHierCap], s_wy[kHierCap], s_sc[kHierCap];
+  __shared__ double s_th[kHierCap];
+  __shared__ int s_pos[kHierCap];                                 // entry -> place in the sorted order
+  __shared__ float s_g[kHierCap][6];                              // the regions, in sorted order
+  __shared__ int s_lo[kHierCap][2], s_n[kHierCap][3];             // lo_x, lo_y; ni, nj, nth
+  __shared__ int s_box[kHierCap][6];                              // a0, a1, c0, c1, e0, e1
+  __shared__ int s_off[kHierCap][3];                              // th_off (local), item offset (local), thread
+  __shared__ unsigned s_ob[kHierCap];
+  __shared__ int s_wcnt[HN_THREADS / 64];
+  __shared__ int s_n_res, s_items, s_any, s_bb[6];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = blockIdx.x;
+  const GreedyJob J = H.jobs[j];
+  const int cap = min(H.cap_regions, kHierCap);
+  if (tid == 0) s_n_res = 0;
+  __syncthreads();
+  // ---- decode, in map order
+  if (J.n_items > 0) {
+    const int nb = J.nbx * J.nby * J.nbt;
+    const long long total = (long long)J.n_threads * nb;
+    const unsigned long long* bins = H.bins + J.bins_off;
+    for (long long g0 = 0; g0 < total; g0 += HN_THREADS) {
+      const long long g = g0 + tid;
+      unsigned long long key = ~0ULL;
+      if (g < total) key = bins[g];
+      const bool keep = key != ~0ULL;
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) s_wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int base = s_n_res;
+      for (int w = 0; w < wave; w++) base += s_wcnt[w];
+      const int e = base + __popcll(m & ((1ULL << lane) - 1ULL));
+      if (keep) {
+        if (e >= cap) atomicExch(err + 8, 1);
+        else {
+          const int th = (int)(g / nb);
+          const unsigned ord = (unsigned)(key & 0xffffffffu);
+          int reg = -1;
+          for (int r = J.region_off; r < J.region_off + J.n_regions; r++) {
+            const RegionDesc D = H.regions[r];
+            const unsigned long long cnt = (unsigned long long)D.nth * D.ni * D.nj;
+            if (D.thread == th && cnt > 0 && ord >= D.order_base && (unsigned long long)(ord - D.order_base) < cnt) { reg = r; break; }
+          }
+          if (reg < 0) { atomicExch(err, 5); s_wx[e] = 0; s_wy[e] = 0; s_th[e] = 0; s_sc[e] = 0; }
+          else {
+            const RegionDesc D = H.regions[reg];
+            const unsigned local = ord - D.order_base;
+            const int ncand = D.ni * D.nj;
+            const int ti = (int)(local / (unsigned)ncand), cidx = (int)(local % (unsigned)ncand);
+            const int a = cidx / D.nj, b = cidx % D.nj;
+            s_wx[e] = P.ll_x + (P.res * (float)(D.lo_x + a * H.x_steps));
+            s_wy[e] = P.ll_y + (P.res * (float)(D.lo_y + b * H.y_steps));
+            s_th[e] = H.theta[D.th_off + ti];
+            s_sc[e] = __uint_as_float((unsigned)(key >> 32));
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) { int t = s_n_res; for (int w = 0; w < HN_THREADS / 64; w++) t += s_wcnt[w]; s_n_res = t; }
+      __syncthreads();
+    }
+  }
+  const int n = min(s_n_res, cap);
+  // ---- stable sort by score: an entry's place = the entries that go before it
+  for (int e = tid; e < n; e += HN_THREADS) {
+    const float sc = s_sc[e];
+    int r = 0;
+    for (int f = 0; f < n; f++) r += (s_sc[f] < sc || (s_sc[f] == sc && f < e)) ? 1 : 0;
+    s_pos[e] = r;
+  }
+  __syncthreads();
+  if (H.final_level) {
+    double* out = H.results + (size_t)j * 4 * (size_t)H.cap_regions;
+    for (int e = tid; e < n; e += HN_THREADS) {
+      const int k = s_pos[e];
+      out[4 * k] = (double)s_wx[e]; out[4 * k + 1] = (double)s_wy[e]; out[4 * k + 2] = s_th[e]; out[4 * k + 3] = (double)s_sc[e];
+    }
+    if (tid == 0) H.counts[j] = n;
+    return;
+  }
+  // ---- the next level's regions: half a bin around every result (chargrid.cpp:386-395), walked like greedySearch walks them
+  const int xs = H.x_steps_next, ys = H.y_steps_next;
+  for (int e = tid; e < n; e += HN_THREADS) {
+    const int k = s_pos[e];
+    const double c0 = (double)s_wx[e], c1 = (double)s_wy[e], c2 = s_th[e];
+    s_g[k][0] = (float)(-H.half_x + c0); s_g[k][1] = (float)(-H.half_y + c1); s_g[k][2] = (float)(-H.half_t + c2);
+    s_g[k][3] = (float)(H.half_x + c0); s_g[k][4] = (float)(H.half_y + c1); s_g[k][5] = (float)(H.half_t + c2);
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += HN_THREADS) {
+    const float* g = s_g[k];
+    const int lo_x = __float2int_rn((g[0] - P.ll_x) * P.inv_res), lo_y = __float2int_rn((g[1] - P.ll_y) * P.inv_res);
+    const int hi_x = __float2int_rn((g[3] - P.ll_x) * P.inv_res), hi_y = __float2int_rn((g[4] - P.ll_y) * P.inv_res);
+    const int ni = hi_x > lo_x ? (hi_x - lo_x + xs - 1) / xs : 0;
+    const int nj = hi_y > lo_y ? (hi_y - lo_y + ys - 1) / ys : 0;
+    int nth = 0;
+    double tl = (double)g[2];
+    for (double t = (double)g[2]; t < (double)g[5]; t += H.theta_res_next) { tl = t; nth++; if (nth > H.cap_theta) break; }
+    s_lo[k][0] = lo_x; s_lo[k][1] = lo_y; s_n[k][0] = ni; s_n[k][1] = nj; s_n[k][2] = nth;
+    if ((unsigned long long)nth * ni * nj > 0) {
+      const float xa = P.ll_x + (P.res * (float)lo_x), xb = P.ll_x + (P.res * (float)(lo_x + (ni - 1) * xs));
+      const float ya = P.ll_y + (P.res * (float)lo_y), yb = P.ll_y + (P.res * (float)(lo_y + (nj - 1) * ys));
+      s_box[k][0] = (int)((double)xa / H.dx_next); s_box[k][1] = (int)((double)xb / H.dx_next);
+      s_box[k][2] = (int)((double)ya / H.dy_next); s_box[k][3] = (int)((double)yb / H.dy_next);
+      s_box[k][4] = (int)((double)g[2] / H.dth_next); s_box[k][5] = (int)(tl / H.dth_next);
+    }
+  }
+  __syncthreads();
+  const int num_threads = min(n, 4);
+  if (tid == 0) {
+    unsigned next_order[4] = {0, 0, 0, 0};
+    int thoff = 0, itoff = 0, any = 0;
+    const int chunk = n > 0 ? n / num_threads : 1;
+    for (int k = 0; k < n; k++) {
+      const int thr = min(k / chunk, num_threads - 1);
+      const unsigned long long cnt = (unsigned long long)s_n[k][2] * s_n[k][0] * s_n[k][1];
+      s_off[k][0] = thoff; s_off[k][1] = itoff; s_off[k][2] = thr; s_ob[k] = next_order[thr];
+      if ((unsigned long long)next_order[thr] + cnt > 0xffffffffULL) atomicExch(err + 8, 1);
+      next_order[thr] += (unsigned)cnt;
+      thoff += s_n[k][2];
+      if (cnt > 0) {
+        itoff += s_n[k][2];
+        if (!any) { for (int q = 0; q < 6; q++) s_bb[q] = s_box[k][q]; any = 1; }
+        else {
+          s_bb[0] = min(s_bb[0], s_box[k][0]); s_bb[1] = max(s_bb[1], s_box[k][1]); s_bb[2] = min(s_bb[2], s_box[k][2]);
+          s_bb[3] = max(s_bb[3], s_box[k][3]); s_bb[4] = min(s_bb[4], s_box[k][4]); s_bb[5] = max(s_bb[5], s_box[k][5]);
+        }
+      }
+      if (thoff > H.cap_theta || itoff > H.cap_items) { atomicExch(err + 8, 1); any = 0; itoff = 0; break; }
+    }
+    s_items = any ? itoff : 0;
+    s_any = any;
+    GreedyJob N = J;
+    N.item_off = j * H.cap_items;
+    N.n_items = s_items;
+    N.block0 = j * H.blocks_per_job;
+    N.n_blocks = H.blocks_per_job;
+    N.bins_off = (long long)j * H.cap_bins_next;
+    N.region_off = j * H.cap_regions;
+    N.n_regions = n;
+    N.n_threads = num_threads;
+    N.bx0 = N.by0 = N.bt0 = 0; N.nbx = N.nby = N.nbt = 0;
+    if (any) {
+      N.bx0 = s_bb[0]; N.by0 = s_bb[2]; N.bt0 = s_bb[4];
+      N.nbx = s_bb[1] - s_bb[0] + 1; N.nby = s_bb[3] - s_bb[2] + 1; N.nbt = s_bb[5] - s_bb[4] + 1;
+      if ((long long)N.nbx * N.nby * N.nbt * num_threads > H.cap_bins_next) { atomicExch(err + 8, 1); N.n_items = 0; s_items = 0; s_any = 0; }
+    }
+    H.jobs_next[j] = N;
+    s_bb[0] = N.nbx * N.nby * N.nbt * num_threads;               // keys to clear
+  }
+  __syncthreads();
+  if (!s_any) return;
+  for (int k = tid; k < n; k += HN_THREADS) {
+    RegionDesc D;
+    D.lo_x = s_lo[k][0]; D.lo_y = s_lo[k][1]; D.ni = s_n[k][0]; D.nj = s_n[k][1]; D.nth = s_n[k][2];
+    D.th_off = j * H.cap_theta + s_off[k][0];
+    D.thread = s_off[k][2];
+    D.order_base = s_ob[k];
+    H.regions_next[(size_t)j * H.cap_regions + k] = D;
+    double* th = H.theta_next + (size_t)D.th_off;
+    int q = 0;
+    for (double t = (double)s_g[k][2]; t < (double)s_g[k][5] && q < D.nth; t += H.theta_res_next) th[q++] = t;
+    if ((unsigned long long)D.nth * D.ni * D.nj > 0) {
+      int32_t* it = H.items_next + 2 * ((size_t)j * H.cap_items + s_off[k][1]);
+      for (int ti = 0; ti < D.nth; ti++) { it[2 * ti] = j * H.cap_regions + k; it[2 * ti + 1] = ti; }
+    }
+  }
+  unsigned long long* nbins = H.bins_next + (size_t)j * (size_t)H.cap_bins_next;
+  for (int q = tid; q < s_bb[0]; q += HN_THREADS) nbins[q] = ~0ULL;
+}
+
+
 // dynamic LDS above 64 KB: set once per HIP device of the process (thread-safe); one instantiation per kernel
 template <int KERNEL>
 static void set_lds_attr_once(const void* fn) {
@@ -2059,10 +2270,20 @@ void launch_match_verify(hipStream_t st, int n_jobs, const MatchParams& P, const
 void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, const GreedyJob* jobs, const int32_t* block_job,
                          const double* ref_pts, const double* qry_pts, const RegionDesc* regions, const double* theta,
                          const int32_t* items, const uint8_t* kernel_lut, unsigned char* scratch, unsigned long long* bins,
-                         int* err) {
+                         int* err, unsigned char* grid_cache, size_t grid_cache_stride, int grid_cache_mode) {
   set_lds_attr_once<1>(reinterpret_cast<const void*>(k_match_greedy));
   hipLaunchKernelGGL(k_match_greedy, dim3(nblocks), dim3(GR_THREADS), sizeof(Smem), st, P, jobs, block_job, ref_pts, qry_pts, regions,
-                     theta, items, kernel_lut, scratch, bins, err);
+                     theta, items, kernel_lut, scratch, bins, err, grid_cache, grid_cache_stride, grid_cache_mode);
+}
+
+size_t match_grid_image_bytes(const MatchParams& P) {
+  const size_t ntx = (size_t)((P.nx + 7) >> 3), nty = (size_t)((P.ny + 7) >> 3);
+  const size_t dir_bytes = (((ntx + 2) * (nty + kMatchDirGuardY) * 2) + 15) & ~size_t(15);
+  return (64 + dir_bytes + ((size_t)NT_LDS + (size_t)P.overflow_tiles + 2) * 64 + 255) & ~size_t(255);
+}
+
+void launch_hier_next(hipStream_t st, int n_jobs, const MatchParams& P, const HierStep& H, int* err) {
+  hipLaunchKernelGGL(k_hier_next, dim3(n_jobs), dim3(HN_THREADS), 0, st, P, H, err);
 }
 
 // variant: 0 = the general kernel (redo_list null: every pair; else the pairs redo_list[0 .. err[3]) a lean launch left over),
