@@ -538,6 +538,7 @@ static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<
     D0.n_threads = num_threads;
     std::vector<uint32_t> next_order(num_threads, 0);
     bool any = false;
+    int npasses = 1;
     int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
     for (int r = 0; r < J.n_regions; r++) {
       const float* g = J.regions + 6 * r;
@@ -561,6 +562,7 @@ static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<
       R.push_back(D);
       if (cnt == 0) continue;
       for (int ti = 0; ti < D.nth; ti++) { items.push_back(rid); items.push_back(ti); }
+      npasses = std::max(npasses, (D.ni * D.nj + kMatchCandPerPass - 1) / kMatchCandPerPass);
       float xa = P.ll_x + (P.res * (float)D.lo_x), xb = P.ll_x + (P.res * (float)(D.lo_x + (D.ni - 1) * xs));
       float ya = P.ll_y + (P.res * (float)D.lo_y), yb = P.ll_y + (P.res * (float)(D.lo_y + (D.nj - 1) * ys));
       int a0 = (int)((double)xa / dx), a1 = (int)((double)xb / dx), c0 = (int)((double)ya / dy), c1 = (int)((double)yb / dy);
@@ -576,7 +578,8 @@ static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<
     if (nbins * num_threads > (size_t)1 << 26) return set_err(ctx, CGMR_E_INVALID, "result discretisation too fine for the search volume");
     D0.bins_off = (int64_t)total_bins;
     total_bins += nbins * num_threads;
-    D0.n_blocks = std::max(1, std::min(blocks_cap, D0.n_items));                // one (region, angle) item per workgroup and round
+    D0.n_passes = npasses;
+    D0.n_blocks = (int)std::max<long long>(1, std::min<long long>(blocks_cap, (long long)D0.n_items * npasses));   // one (region, angle, candidate pass) unit per workgroup and round
     for (int b = 0; b < D0.n_blocks; b++) block_job.push_back(j);
     nblocks += D0.n_blocks;
   }

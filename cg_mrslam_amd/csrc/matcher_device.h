@@ -62,8 +62,10 @@ struct GreedyJob {
   int64_t bins_off;                          // first key of its result maps (num_threads * nbins keys)
   int32_t region_off, n_regions;             // its regions in the launch's region table
   int32_t n_threads;                         // result maps it fills: min(n_regions, 4) (chargrid.cpp:228)
-  int32_t pad_;
+  int32_t n_passes;                          // candidate passes of its largest region (kMatchCandPerPass candidates each): a work unit of the
+                                             // launch is (item, pass) -- an item's passes spread over workgroups
 };
+constexpr int kMatchCandPerPass = 576;       // candidates a workgroup of k_match_greedy sums at a time (24 x 24)
 
 // The level loop of CharGrid::hierarchicalSearch on the device (chargrid.cpp:310-344, 376-400): between two levels' launches of
 // k_match_greedy, k_hier_next decodes a job's result maps, sorts the results by score and writes the next level's tables -- a

@@ -1909,14 +1909,20 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
   // serial walk over ~1000 points while 240 CUs idled.
   int* const totals = reinterpret_cast<int*>(&S.totals[0][0]);     // 64 * CAND_U candidate sums (tile_slot / claim bits are done with)
   static_assert(64 * CAND_U * 4 <= (int)sizeof(S.totals), "candidate sums of one item");
-  for (int it = jb; it < J.n_items; it += J.n_blocks) {
+  // work units: (item, candidate pass) -- the 2-3 passes of a region of a hierarchical level on workgroups of their own
+  static_assert(64 * CAND_U == kMatchCandPerPass, "candidates per pass");
+  const int npass = max(J.n_passes, 1);
+  for (long long unit = jb; unit < (long long)J.n_items * npass; unit += J.n_blocks) {
+    const int it = (int)(unit / npass), pass = (int)(unit - (long long)it * npass);
     const RegionDesc R = regions[items[2 * (size_t)(J.item_off + it)]];
     const int ti = items[2 * (size_t)(J.item_off + it) + 1];
+    const int ncand = R.ni * R.nj;
+    if ((long long)pass * (64 * CAND_U) >= ncand) continue;
     const double t = theta[R.th_off + ti];
     double sn, cs;
     portable_sincos(t, &sn, &cs);
-    const int ncand = R.ni * R.nj;
-    for (int cb = 0; cb < ncand; cb += 64 * CAND_U) {
+    {
+      const int cb = pass * (64 * CAND_U);
       int ci[CAND_U], cj[CAND_U], sum[CAND_U];
 #pragma unroll
       for (int u = 0; u < CAND_U; u++) {
@@ -2187,7 +2193,7 @@ __global__ __launch_bounds__(HN_THREADS) void k_hier_next(MatchParams P, HierSte
   const int num_threads = min(n, 4);
   if (tid == 0) {
     unsigned next_order[4] = {0, 0, 0, 0};
-    int thoff = 0, itoff = 0, any = 0;
+    int thoff = 0, itoff = 0, any = 0, npass = 1;
     const int chunk = n > 0 ? n / num_threads : 1;
     for (int k = 0; k < n; k++) {
       const int thr = min(k / chunk, num_threads - 1);
@@ -2198,6 +2204,7 @@ __global__ __launch_bounds__(HN_THREADS) void k_hier_next(MatchParams P, HierSte
       thoff += s_n[k][2];
       if (cnt > 0) {
         itoff += s_n[k][2];
+        npass = max(npass, (s_n[k][0] * s_n[k][1] + kMatchCandPerPass - 1) / kMatchCandPerPass);
         if (!any) { for (int q = 0; q < 6; q++) s_bb[q] = s_box[k][q]; any = 1; }
         else {
           s_bb[0] = min(s_bb[0], s_box[k][0]); s_bb[1] = max(s_bb[1], s_box[k][1]); s_bb[2] = min(s_bb[2], s_box[k][2]);
@@ -2217,6 +2224,7 @@ __global__ __launch_bounds__(HN_THREADS) void k_hier_next(MatchParams P, HierSte
     N.region_off = j * H.cap_regions;
     N.n_regions = n;
     N.n_threads = num_threads;
+    N.n_passes = npass;
     N.bx0 = N.by0 = N.bt0 = 0; N.nbx = N.nby = N.nbt = 0;
     if (any) {
       N.bx0 = s_bb[0]; N.by0 = s_bb[2]; N.bt0 = s_bb[4];

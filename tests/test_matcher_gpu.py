@@ -316,6 +316,37 @@ def test_hierarchical_and_global_matching(ctx, oracle):
         assert err[0] < 0.15 and err[1] < 0.15 and err[2] < 0.06          # LC grid is 0.1 m, theta step 0.025
 
 
+def test_level_loop_on_the_device_and_level_by_level(ctx, oracle):
+    """hierarchicalSearch's levels run back to back on the device (k_hier_next makes a level's regions from the results of the
+    one before); a search with more than 256 results on a level outgrows the device tables and is served level by level with
+    the tables made on the host.  Both against the oracle, and the device loop against the host loop of another process."""
+    import subprocess, sys, os, json
+    sp = synth.make_scan_pairs(2, seed=77)
+    m = _lc(ctx, sp)
+    ref = m.cartesian(sp["ranges_ref"][0])
+    q = m.subsample(m.cartesian(sp["ranges_qry"][0]))
+    region = np.array([[-6, -4, np.float32(-np.pi), 6, 4, np.float32(np.pi)]], dtype=np.float32)
+    counts = {}
+    for levels, max_score in ((2, 0.2), (3, 0.2), (4, 0.25), (3, 0.45)):
+        got = m.hierarchicalSearch(ref, q, region, 0.025, max_score, 0.5, 0.5, 0.2, levels)
+        n, want = oracle.hierarchical_search((-35, -35), (35, 35), 0.1, 0.1, 0.5, ref, q, region, 0.025, max_score, 0.5, 0.5, 0.2, levels)
+        assert len(got) == n and np.array_equal(got, want), (levels, max_score, len(got), n)
+        counts[(levels, max_score)] = n
+    assert 256 < counts[(3, 0.45)] <= 4096                        # (cannot have stayed in the device tables; the oracle wrapper holds 4096 rows)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, json\nfrom cg_mrslam_amd import Context, synth\nfrom tests.test_matcher_gpu import _lc\n"
+            "ctx = Context(0)\nsp = synth.make_scan_pairs(2, seed=77)\nm = _lc(ctx, sp)\n"
+            "ref = m.cartesian(sp['ranges_ref'][0]); q = m.subsample(m.cartesian(sp['ranges_qry'][0]))\n"
+            "region = np.array([[-6, -4, np.float32(-np.pi), 6, 4, np.float32(np.pi)]], dtype=np.float32)\n"
+            "print(json.dumps(np.asarray(m.hierarchicalSearch(ref, q, region, 0.025, 0.25, 0.5, 0.5, 0.2, 4)).tolist()))\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root, CGMR_HIER_HOST="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    host = np.array(json.loads(r.stdout.strip().splitlines()[-1]))
+    dev = np.asarray(m.hierarchicalSearch(ref, q, region, 0.025, 0.25, 0.5, 0.5, 0.2, 4))
+    assert host.shape == dev.shape and np.array_equal(host.reshape(dev.shape), dev)
+
+
 def test_scan_matching_lc_multi_scan_reference_set(ctx, oracle):
     """scanMatchingLC (scan_matcher.cpp:201-294) with a 3-scan reference set: the host-side region/merge logic
     around the GPU search is checked against the same flow driven by the oracle's greedy search."""
