@@ -84,6 +84,8 @@ static_assert(sizeof(Smem) <= 160 * 1024, "matcher LDS plan exceeds 160 KiB");
 
 #ifdef CGMR_PHASE_TIMING
 __device__ unsigned long long g_mphase[32];
+__device__ unsigned long long g_gphase[16];      // k_match_greedy, workgroup 0 of the last launch: cycle counter at its marks
+#define GPHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_gphase[i] = __builtin_readcyclecounter(); } while (0)
 #define MPHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mphase[i] = __builtin_readcyclecounter(); } while (0)
 // workgroup 0: cycles between marks of the fast search path, summed over the angles and wavefronts (slots 10..15, 24)
 #define MSTAT_T0() unsigned long long mst_ = __builtin_readcyclecounter()
@@ -92,6 +94,7 @@ __device__ unsigned long long g_mphase[32];
 #define MSTAT_ADD(i, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_mphase[i], (unsigned long long)(v)); } while (0)
 #else
 #define MPHASE(i)
+#define GPHASE(i)
 #define MSTAT_T0()
 #define MSTAT(i)
 #define MSTAT_ADD(i, v)
@@ -1831,6 +1834,61 @@ __global__ __launch_bounds__(CB_THREADS) void k_match_close_batch(MatchParams P,
 }
 
 
+constexpr int kGrListCap = NTH * LISTCAP / GR_THREADS * GR_THREADS;      // points per chunk of k_match_greedy's kept-point list
+// a query point turned by the item's angle, as the cell offsets the sums are taken at (chargrid.cpp:244-246)
+__device__ __forceinline__ uint32_t turn_and_pack(const MatchParams& P, double x, double y, double cs, double sn) {
+  const double px = cs * x - sn * y, py = sn * x + cs * y;
+  int ix = (int)(px * (double)P.inv_res), iy = (int)(py * (double)P.inv_res);
+  ix = min(max(ix, -32000), 32000);
+  iy = min(max(iy, -32000), 32000);
+  return ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
+}
+
+// NU cells of the generic path at once (grid_cell's result for each of (px + ci[u], py + cj[u]) added to sum[u]): the directory
+// reads of all of them go out together, then the tile reads -- one at a time, as grid_cell in a loop, every lookup is two
+// dependent LDS round trips behind a branch: 260 cycles each, 119k of a level's 155k cycles (tools/gpu_gphase.py).  Tiles
+// beyond the LDS pool are fetched afterwards, under a branch no lane takes in the common case.
+template <int NU, int NP>
+__device__ __forceinline__ void gather_cells(const Smem& S, const MatchParams& P, const uint32_t* gtiles, int DW, const uint32_t* pl, int q,
+                                             int q1, const int* ci, const int* cj, int* sum) {
+  // NP consecutive list entries x NU candidate slots: NP * NU lookups in flight (a missing entry counts as outside the grid)
+  int d[NP][NU], boff[NP][NU], v[NP][NU];
+  bool in[NP][NU];
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const bool have = q + p < q1;
+    const uint32_t packed = pl[have ? q + p : q];
+    const int px = (int16_t)(packed & 0xffff), py = (int16_t)(packed >> 16);
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int cx = px + ci[u], cy = py + cj[u];
+      in[p][u] = have && (unsigned)cx < (unsigned)P.nx && (unsigned)cy < (unsigned)P.ny;
+      boff[p][u] = (cx & 7) * 8 + (cy & 7);
+      d[p][u] = S.dir[in[p][u] ? ((cx >> 3) + 1) * DW + (cy >> 3) + 3 : 0];
+    }
+  }
+  bool far = false;
+#pragma unroll
+  for (int p = 0; p < NP; p++)
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      v[p][u] = reinterpret_cast<const uint8_t*>(S.tiles)[min(d[p][u], NT_LDS - 1) * 64 + boff[p][u]];
+      far |= in[p][u] && d[p][u] >= NT_LDS && d[p][u] != 0xFFFF;
+    }
+  if (__ballot(far) != 0ULL) {
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+      for (int u = 0; u < NU; u++)
+        if (in[p][u] && d[p][u] >= NT_LDS && d[p][u] != 0xFFFF)
+          v[p][u] = reinterpret_cast<const uint8_t*>(gtiles)[(size_t)(d[p][u] - NT_LDS) * 64 + boff[p][u]];
+  }
+#pragma unroll
+  for (int p = 0; p < NP; p++)
+#pragma unroll
+    for (int u = 0; u < NU; u++) sum[u] += in[p][u] ? (d[p][u] == 0xFFFF ? P.fill : v[p][u]) : 0;
+}
+
 // Generic CharGrid::greedySearch over a set of regions (chargrid.cpp:208-308) on a grid rasterised from the given
 // reference points: the loop-closure and hierarchical / global matchers (scanMatchingLC, globalMatching,
 // scan_matcher.cpp:201-294,366-428).  Batched: a launch serves many independent searches ("jobs": own reference points,
@@ -1856,6 +1914,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  GPHASE(0);
   const int job = block_job[blockIdx.x];
   const GreedyJob J = jobs[job];
   if (J.n_items <= 0) return;                                // (a search of the level loop that found nothing one level up: k_hier_next)
@@ -1898,10 +1957,10 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
       for (int q = tid; q < max(0, ntile + 2 - NT_LDS) * 4; q += GR_THREADS) tdst[NT_LDS * 4 + q] = osrc[q];
     }
   }
+  GPHASE(1);
   const float ikscale = (float)(1. / (float)P.kscale);
   const int nbins = J.nbx * J.nby * J.nbt;
-  uint32_t* const pl = &S.plist[0][0] + (wave >> 1) * (2 * LISTCAP);   // 8 wavefronts in pairs: the two of a pair build the same list
-                                                                          // (identical stores) in one double-length slot, each reads what it wrote
+  uint32_t* const pl = &S.plist[0][0];                               // one kept-point list for the workgroup, all eight point lists long
   // One (region, angle) item per workgroup and round.  Every wavefront turns all the query points and builds the same
   // kept-point list (the consecutive-duplicate rule runs along the whole list; this is a hundredth of the work), then
   // gathers one quarter of it for all the candidates; the quarters meet in LDS.  Round 2 gave every wavefront an item of
@@ -1921,8 +1980,10 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
     const double t = theta[R.th_off + ti];
     double sn, cs;
     portable_sincos(t, &sn, &cs);
+    GPHASE(2);
     {
       const int cb = pass * (64 * CAND_U);
+      const int nu = (min(ncand - cb, 64 * CAND_U) + 63) / 64;       // candidate slots per lane in use
       int ci[CAND_U], cj[CAND_U], sum[CAND_U];
 #pragma unroll
       for (int u = 0; u < CAND_U; u++) {
@@ -1934,57 +1995,54 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
       }
       __syncthreads();                                            // (the previous pass' sums have been read)
       for (int q = tid; q < 64 * CAND_U; q += GR_THREADS) totals[q] = 0;
-      // the point list is rebuilt in chunks of at most MAXPTS - 4 kept points
+      // The kept-point list of the item, built by the whole workgroup: a point is kept unless it falls into the cell of the
+      // point before it (chargrid.cpp:247-252 -- a rule between neighbours of the input order, so every thread can judge its
+      // own point: a wavefront's first lane turns the predecessor as well); the kept points are counted through one LDS
+      // counter, a wavefront's at a time -- their order in the list is that of arrival, the sums over them do not depend on
+      // it.  In chunks of kGrListCap points.  (Until round 5 every wavefront walked all the points, 64 at a time: 60 dependent
+      // rounds of loads for a scan set of 4000 points, 25 of a level's 43 us.)
       int k = 0;
-      uint32_t prev = 0;
-      bool have_prev = false;
-      for (int c0 = 0; c0 < J.n_qry; c0 += MAXPTS - 64) {
-        const int c1 = min(J.n_qry, c0 + MAXPTS - 64);
-        int kc = 0;
-        for (int base = c0; base < c1; base += 64) {
-          int q = base + lane;
+      for (int c0 = 0; c0 < J.n_qry; c0 += kGrListCap) {
+        const int c1 = min(J.n_qry, c0 + kGrListCap);
+        __syncthreads();                                          // (the list's previous chunk has been gathered, its count read)
+        if (tid == 0) S.misc[14] = 0;
+        __syncthreads();
+        for (int base = c0 + wave * 64; base < c1; base += GR_THREADS) {
+          const int q = base + lane;
+          const bool valid = q < c1;
           uint32_t packed = 0;
-          bool valid = q < c1;
-          if (valid) {
-            double x = qry_pts[2 * q], y = qry_pts[2 * q + 1];
-            double px = cs * x - sn * y, py = sn * x + cs * y;
-            int ix = (int)(px * (double)P.inv_res), iy = (int)(py * (double)P.inv_res);
-            ix = min(max(ix, -32000), 32000);
-            iy = min(max(iy, -32000), 32000);
-            packed = ((uint32_t)(uint16_t)(int16_t)ix) | ((uint32_t)(uint16_t)(int16_t)iy << 16);
-          }
+          if (valid) packed = turn_and_pack(P, qry_pts[2 * q], qry_pts[2 * q + 1], cs, sn);
           uint32_t left = __shfl_up(packed, 1, 64);
-          if (lane == 0) left = prev;
-          bool keep = valid && ((lane == 0 && !have_prev) ? true : (packed != left));
-          unsigned long long mask = __ballot(keep);
-          int pos = kc + __popcll(mask & ((1ULL << lane) - 1ULL));
-          if (keep) pl[pos] = packed;
-          kc += __popcll(mask);
-          int lastv = min(63, c1 - base - 1);
-          prev = __shfl(packed, lastv, 64);
-          have_prev = true;
+          if (lane == 0 && q > 0) left = turn_and_pack(P, qry_pts[2 * (q - 1)], qry_pts[2 * (q - 1) + 1], cs, sn);
+          const bool keep = valid && (q == 0 || packed != left);
+          const unsigned long long mask = __ballot(keep);
+          int wbase = 0;
+          if (lane == 0 && mask) wbase = atomicAdd(&S.misc[14], __popcll(mask));
+          wbase = __shfl(wbase, 0, 64);
+          if (keep) pl[wbase + __popcll(mask & ((1ULL << lane) - 1ULL))] = packed;
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        GPHASE(3);
+        const int kc = S.misc[14];
         const int q0 = (int)(((long long)kc * wave) / GR_WAVES), q1 = (int)(((long long)kc * (wave + 1)) / GR_WAVES);
-        for (int q = q0; q < q1; q++) {
-          uint32_t packed = pl[q];
-          int px = (int16_t)(packed & 0xffff), py = (int16_t)(packed >> 16);
-#pragma unroll
-          for (int u = 0; u < CAND_U; u++) sum[u] += grid_cell(S, P, gtiles, DW, px + ci[u], py + cj[u]);
-        }
-        __builtin_amdgcn_wave_barrier();
+        // (only as many candidate slots as the region has left: a region of a later level holds ~100 candidates, 2 of the 9)
+        if (nu <= 2)
+          for (int q = q0; q < q1; q += 4) gather_cells<2, 4>(S, P, gtiles, DW, pl, q, q1, ci, cj, sum);
+        else if (nu <= 4)
+          for (int q = q0; q < q1; q += 2) gather_cells<4, 2>(S, P, gtiles, DW, pl, q, q1, ci, cj, sum);
+        else
+          for (int q = q0; q < q1; q++) gather_cells<CAND_U, 1>(S, P, gtiles, DW, pl, q, q1, ci, cj, sum);
         k += kc;
-        if (c1 < J.n_qry) __syncthreads();                        // (the next chunk's list goes into the slot the pair's other wavefront may still read)
       }
+      GPHASE(4);
       __syncthreads();                                            // (totals are zero)
 #pragma unroll
       for (int u = 0; u < CAND_U; u++)
         if (sum[u]) atomicAdd(&totals[u * 64 + lane], sum[u]);
       __syncthreads();
       // the candidates of the pass over the workgroup's threads
-      for (int c = tid; c < 64 * CAND_U; c += GR_THREADS) {
+      for (int c = tid; c < min(64 * CAND_U, ncand - cb); c += GR_THREADS) {
         const int cidx = cb + c;
-        if (cidx >= ncand) continue;
         const int a = cidx / R.nj, b = cidx - a * R.nj;
         const int cix = R.lo_x + a * P.x_steps, cjy = R.lo_y + b * P.y_steps;
         float dsum = (float)totals[c] * ikscale;
@@ -2002,6 +2060,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
       }
     }
   }
+  GPHASE(5);
 }
 
 
@@ -2323,6 +2382,9 @@ int match_close_max_bins() { return MAXBINS; }
 }  // namespace cgmr
 
 #ifdef CGMR_PHASE_TIMING
+extern "C" int cgmr_debug_gphase(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_gphase), sizeof(unsigned long long) * 16);
+}
 extern "C" int cgmr_debug_mphase(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_mphase), sizeof(unsigned long long) * 32);
 }
