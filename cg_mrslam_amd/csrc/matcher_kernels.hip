@@ -1919,6 +1919,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
   const GreedyJob J = jobs[job];
   if (J.n_items <= 0) return;                                // (a search of the level loop that found nothing one level up: k_hier_next)
   const int jb = blockIdx.x - J.block0;                      // my index among the job's workgroups
+  if ((long long)jb >= (long long)J.n_items * max(J.n_passes, 1)) return;   // (more workgroups than work units: the level loop launches a fixed number per job)
   const double* ref_pts = ref_pts_all + 2 * (size_t)J.ref_off;
   const double* qry_pts = qry_pts_all + 2 * (size_t)J.qry_off;
   unsigned long long* bins = bins_all + J.bins_off;
