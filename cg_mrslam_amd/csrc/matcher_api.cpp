@@ -499,6 +499,7 @@ struct GreedyTables {
   std::vector<int> first_region, nthreads;
   size_t n_refs = 0, n_qrys = 0, total_bins = 0;
   int max_ref = 1, nblocks = 0;
+  int cand_per_pass = kMatchCandPerPass;     // MatchParams::cand_per_pass of the launch these tables are for
 };
 static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<SearchJob>& jobs, double theta_res, double dx, double dy,
                          double dth, GreedyTables& T) {
@@ -527,7 +528,6 @@ static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<
     D0.ref_off = (int32_t)n_refs; D0.n_ref = J.n_ref; n_refs += (size_t)J.n_ref;
     D0.qry_off = (int32_t)n_qrys; D0.n_qry = J.n_qry; n_qrys += (size_t)J.n_qry;
     D0.item_off = (int32_t)(items.size() / 2);
-    D0.block0 = nblocks;
     first_region[j] = (int)R.size();
     D0.region_off = (int32_t)R.size(); D0.n_regions = J.n_regions;
     max_ref = std::max(max_ref, J.n_ref);
@@ -538,7 +538,7 @@ static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<
     D0.n_threads = num_threads;
     std::vector<uint32_t> next_order(num_threads, 0);
     bool any = false;
-    int npasses = 1;
+    int max_cand = 1;
     int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bt0 = 0, bt1 = -1;
     for (int r = 0; r < J.n_regions; r++) {
       const float* g = J.regions + 6 * r;
@@ -562,7 +562,7 @@ static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<
       R.push_back(D);
       if (cnt == 0) continue;
       for (int ti = 0; ti < D.nth; ti++) { items.push_back(rid); items.push_back(ti); }
-      npasses = std::max(npasses, (D.ni * D.nj + kMatchCandPerPass - 1) / kMatchCandPerPass);
+      max_cand = std::max(max_cand, D.ni * D.nj);
       float xa = P.ll_x + (P.res * (float)D.lo_x), xb = P.ll_x + (P.res * (float)(D.lo_x + (D.ni - 1) * xs));
       float ya = P.ll_y + (P.res * (float)D.lo_y), yb = P.ll_y + (P.res * (float)(D.lo_y + (D.nj - 1) * ys));
       int a0 = (int)((double)xa / dx), a1 = (int)((double)xb / dx), c0 = (int)((double)ya / dy), c1 = (int)((double)yb / dy);
@@ -578,8 +578,27 @@ static int greedy_tables(cgmr_ctx* ctx, const MatchParams& P, const std::vector<
     if (nbins * num_threads > (size_t)1 << 26) return set_err(ctx, CGMR_E_INVALID, "result discretisation too fine for the search volume");
     D0.bins_off = (int64_t)total_bins;
     total_bins += nbins * num_threads;
-    D0.n_passes = npasses;
-    D0.n_blocks = (int)std::max<long long>(1, std::min<long long>(blocks_cap, (long long)D0.n_items * npasses));   // one (region, angle, candidate pass) unit per workgroup and round
+    D0.n_passes = max_cand;                                    // (the candidates of its largest region: passes below)
+  }
+  // Work units are (region, angle, candidate pass).  A pass is 576 candidates when that makes enough units to fill the chip
+  // (a loop-closure search: thousands of items); a launch of a few dozen items with a few hundred candidates each -- the first
+  // level of a global matching: 63 angles x 325 positions on 63 workgroups -- is cut into passes of 256 or 128 instead.
+  int cpp = P.cand_per_pass > 0 ? std::min(P.cand_per_pass, kMatchCandPerPass) : 0;
+  if (cpp == 0) {
+    cpp = 128;
+    for (int c : {kMatchCandPerPass, 256}) {
+      long long units = 0;
+      for (int j = 0; j < nj; j++) units += (long long)G[j].n_items * ((G[j].n_passes + c - 1) / c);
+      if (units >= 256) { cpp = c; break; }
+    }
+  }
+  T.cand_per_pass = cpp;
+  for (int j = 0; j < nj; j++) {
+    GreedyJob& D0 = G[j];
+    D0.block0 = nblocks;
+    if (D0.n_items == 0) { D0.n_passes = 1; continue; }
+    D0.n_passes = (D0.n_passes + cpp - 1) / cpp;
+    D0.n_blocks = (int)std::max<long long>(1, std::min<long long>(blocks_cap, (long long)D0.n_items * D0.n_passes));   // one unit per workgroup and round
     for (int b = 0; b < D0.n_blocks; b++) block_job.push_back(j);
     nblocks += D0.n_blocks;
   }
@@ -622,6 +641,7 @@ static int greedy_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
   std::vector<int>&first_region = T.first_region, &nthreads = T.nthreads;
   const size_t n_refs = T.n_refs, n_qrys = T.n_qrys, total_bins = T.total_bins;
   const int max_ref = T.max_ref, nblocks = T.nblocks;
+  P.cand_per_pass = T.cand_per_pass;
   if (nblocks == 0) return CGMR_OK;
   if (total_bins > (size_t)1 << 28) return set_err(ctx, CGMR_E_INVALID, "result maps of the batch exceed 2 GB");
   P.ref_cap = (max_ref + 63) & ~63;
@@ -1056,6 +1076,8 @@ int hierarchical_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const 
   GreedyTables T;
   rc = greedy_tables(ctx, PL[0], jobs0, PL[0].theta_res, PL[0].dx, PL[0].dy, PL[0].dth, T);
   if (rc) return rc;
+  PL[0].cand_per_pass = T.cand_per_pass;
+  for (int lv = 1; lv < n_levels; lv++) PL[lv].cand_per_pass = 128;      // (regions of half a bin: ~100 candidates, one pass of two slots per lane)
   out.assign(nj, {});
   if (T.nblocks == 0) { done = true; return CGMR_OK; }
   if (T.total_bins > (size_t)1 << 28) return set_err(ctx, CGMR_E_INVALID, "result maps of the batch exceed 2 GB");
@@ -1152,6 +1174,7 @@ int hierarchical_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const 
       H.half_x = half_x[lv]; H.half_y = half_y[lv]; H.half_t = half_t[lv];
       H.theta_res_next = PL[lv + 1].theta_res; H.dx_next = PL[lv + 1].dx; H.dy_next = PL[lv + 1].dy; H.dth_next = PL[lv + 1].dth;
       H.cap_bins_next = capB[lv + 1];
+      H.cand_per_pass_next = PL[lv + 1].cand_per_pass;
     }
     launch_hier_next(ctx->stream, nj, PL[lv], H, d_err);
     if (!last)

@@ -40,6 +40,8 @@ struct MatchParams {
   int n_ref, n_qry, n_regions, n_items;
   int ref_cap;                               // packed-cell slots per point list in the HBM scratch (>= n_ref, n_qry)
   int bx0, by0, bt0, nbx, nby, nbt;          // bounding box of the result bins over all regions
+  int cand_per_pass;                         // k_match_greedy: candidates a work unit sums (128, 256 or kMatchCandPerPass; 0 = the latter): few
+                                             // items with many candidates each are cut finer, so that the launch fills the chip
 };
 
 constexpr int kMatchMaxRef = 1 << 22;        // sanity limit on the points of one generic search (any number of scans)
@@ -62,10 +64,10 @@ struct GreedyJob {
   int64_t bins_off;                          // first key of its result maps (num_threads * nbins keys)
   int32_t region_off, n_regions;             // its regions in the launch's region table
   int32_t n_threads;                         // result maps it fills: min(n_regions, 4) (chargrid.cpp:228)
-  int32_t n_passes;                          // candidate passes of its largest region (kMatchCandPerPass candidates each): a work unit of the
+  int32_t n_passes;                          // candidate passes of its largest region (MatchParams::cand_per_pass candidates each): a work unit of the
                                              // launch is (item, pass) -- an item's passes spread over workgroups
 };
-constexpr int kMatchCandPerPass = 576;       // candidates a workgroup of k_match_greedy sums at a time (24 x 24)
+constexpr int kMatchCandPerPass = 576;       // most candidates a workgroup of k_match_greedy sums at a time (24 x 24)
 
 // The level loop of CharGrid::hierarchicalSearch on the device (chargrid.cpp:310-344, 376-400): between two levels' launches of
 // k_match_greedy, k_hier_next decodes a job's result maps, sorts the results by score and writes the next level's tables -- a
@@ -91,6 +93,7 @@ struct HierStep {
   int cap_regions, cap_theta, cap_items;     // per job
   long long cap_bins_next;                   // keys per job
   int blocks_per_job;
+  int cand_per_pass_next;                    // MatchParams::cand_per_pass of the next level's launch
   // results of the last level: per job a count (in counts[job]) and cap_regions x (x, y, theta, score)
   double* results;
   int* counts;

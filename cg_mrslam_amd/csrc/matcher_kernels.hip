@@ -1972,19 +1972,20 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
   // work units: (item, candidate pass) -- the 2-3 passes of a region of a hierarchical level on workgroups of their own
   static_assert(64 * CAND_U == kMatchCandPerPass, "candidates per pass");
   const int npass = max(J.n_passes, 1);
+  const int cpp = P.cand_per_pass > 0 ? min(P.cand_per_pass, 64 * CAND_U) : 64 * CAND_U;     // candidates per unit (a multiple of 64)
   for (long long unit = jb; unit < (long long)J.n_items * npass; unit += J.n_blocks) {
     const int it = (int)(unit / npass), pass = (int)(unit - (long long)it * npass);
     const RegionDesc R = regions[items[2 * (size_t)(J.item_off + it)]];
     const int ti = items[2 * (size_t)(J.item_off + it) + 1];
     const int ncand = R.ni * R.nj;
-    if ((long long)pass * (64 * CAND_U) >= ncand) continue;
+    if ((long long)pass * cpp >= ncand) continue;
     const double t = theta[R.th_off + ti];
     double sn, cs;
     portable_sincos(t, &sn, &cs);
     GPHASE(2);
     {
-      const int cb = pass * (64 * CAND_U);
-      const int nu = (min(ncand - cb, 64 * CAND_U) + 63) / 64;       // candidate slots per lane in use
+      const int cb = pass * cpp;
+      const int nu = (min(ncand - cb, cpp) + 63) / 64;               // candidate slots per lane in use
       int ci[CAND_U], cj[CAND_U], sum[CAND_U];
 #pragma unroll
       for (int u = 0; u < CAND_U; u++) {
@@ -2042,7 +2043,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
         if (sum[u]) atomicAdd(&totals[u * 64 + lane], sum[u]);
       __syncthreads();
       // the candidates of the pass over the workgroup's threads
-      for (int c = tid; c < min(64 * CAND_U, ncand - cb); c += GR_THREADS) {
+      for (int c = tid; c < min(cpp, ncand - cb); c += GR_THREADS) {
         const int cidx = cb + c;
         const int a = cidx / R.nj, b = cidx - a * R.nj;
         const int cix = R.lo_x + a * P.x_steps, cjy = R.lo_y + b * P.y_steps;
@@ -2254,6 +2255,7 @@ __global__ __launch_bounds__(HN_THREADS) void k_hier_next(MatchParams P, HierSte
   if (tid == 0) {
     unsigned next_order[4] = {0, 0, 0, 0};
     int thoff = 0, itoff = 0, any = 0, npass = 1;
+    const int cpp_next = H.cand_per_pass_next > 0 ? min(H.cand_per_pass_next, kMatchCandPerPass) : kMatchCandPerPass;
     const int chunk = n > 0 ? n / num_threads : 1;
     for (int k = 0; k < n; k++) {
       const int thr = min(k / chunk, num_threads - 1);
@@ -2264,7 +2266,7 @@ __global__ __launch_bounds__(HN_THREADS) void k_hier_next(MatchParams P, HierSte
       thoff += s_n[k][2];
       if (cnt > 0) {
         itoff += s_n[k][2];
-        npass = max(npass, (s_n[k][0] * s_n[k][1] + kMatchCandPerPass - 1) / kMatchCandPerPass);
+        npass = max(npass, (s_n[k][0] * s_n[k][1] + cpp_next - 1) / cpp_next);
         if (!any) { for (int q = 0; q < 6; q++) s_bb[q] = s_box[k][q]; any = 1; }
         else {
           s_bb[0] = min(s_bb[0], s_box[k][0]); s_bb[1] = max(s_bb[1], s_box[k][1]); s_bb[2] = min(s_bb[2], s_box[k][2]);
