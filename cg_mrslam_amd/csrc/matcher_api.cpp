@@ -1135,10 +1135,14 @@ int hierarchical_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const 
                o_reg0 = L.add(sizeof(RegionDesc) * std::max<size_t>(T.R.size(), 1)), o_th0 = L.add(8 * std::max<size_t>(T.theta.size(), 1)),
                o_it0 = L.add(4 * std::max<size_t>(T.items.size(), 1)), o_job0 = L.add(sizeof(GreedyJob) * (size_t)nj),
                o_bj0 = L.add(4 * T.block_job.size()), o_bjn = L.add(4 * (size_t)nj * bpj), o_kern = L.add(kern.size());
-  const size_t hbytes = L.off;
+  // The first level's result maps (all ones), the error words and the result counts (zero) ride with the upload when the maps are
+  // small -- a global matching's are 360 bytes --: two fill launches less per search.
+  const bool fills_ride = 8 * T.total_bins <= (size_t)64 << 10;
   const size_t cnt_bytes = (4 * (size_t)nj + 255) & ~size_t(255), res_bytes = 32 * (size_t)capR * nj;
+  size_t o_bins0 = fills_ride ? L.add(8 * T.total_bins) : 0;
   const size_t o_err = L.add(256 + cnt_bytes + res_bytes), o_cnt = o_err + 256, o_res = o_cnt + cnt_bytes;
-  const size_t o_bins0 = L.add(8 * T.total_bins);
+  const size_t hbytes = fills_ride ? o_cnt + cnt_bytes : o_err;
+  if (!fills_ride) o_bins0 = L.add(8 * T.total_bins);
   std::vector<size_t> o_reg(n_levels, 0), o_th(n_levels, 0), o_it(n_levels, 0), o_job(n_levels, 0), o_bins(n_levels, 0);
   for (int lv = 1; lv < n_levels; lv++) {
     o_reg[lv] = L.add(sizeof(RegionDesc) * (size_t)capR * nj);
@@ -1171,9 +1175,15 @@ int hierarchical_batch_dev(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, const 
   memcpy(h + o_kern, kern.data(), kern.size());
   char* d = ctx->mt_arena.ptr;
   const auto t_staged = std::chrono::steady_clock::now();
+  if (fills_ride) {
+    memset(h + o_bins0, 0xff, 8 * T.total_bins);
+    memset(h + o_err, 0, 256 + cnt_bytes);
+  }
   HIP_TRY(ctx, hipMemcpyAsync(d, h, hbytes, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(d + o_err, 0, 256 + cnt_bytes, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(d + o_bins0, 0xff, 8 * T.total_bins, ctx->stream));
+  if (!fills_ride) {
+    HIP_TRY(ctx, hipMemsetAsync(d + o_err, 0, 256 + cnt_bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d + o_bins0, 0xff, 8 * T.total_bins, ctx->stream));
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int* d_err = (int*)(d + o_err);
   launch_match_greedy(ctx->stream, T.nblocks, PL[0], (const GreedyJob*)(d + o_job0), (const int32_t*)(d + o_bj0), (const double*)(d + o_ref),
