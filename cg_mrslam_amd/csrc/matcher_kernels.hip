@@ -1894,10 +1894,12 @@ __device__ __forceinline__ void gather_cells(const Smem& S, const MatchParams& P
 // scan_matcher.cpp:201-294,366-428).  Batched: a launch serves many independent searches ("jobs": own reference points,
 // query points, regions, result maps) -- the inter-robot matcher tries every candidate vertex of every peer
 // (mr_graph_slam.cpp:287-295), the loop-closure matcher every candidate set of a key frame (graph_slam.cpp:444).
-// Workgroups [block0, block0 + n_blocks) belong to a job: each rasterises the job's grid, then takes (region, angle)
-// work items round-robin, one per wavefront; the pruned result maps are global tables of 64-bit keys updated with
-// atomicMin (score bits << 32 | visit order inside the reference's per-thread map), decoded on the host.
-// Any grid size / step; cell reads go through the bounds-checked directory lookup.
+// Workgroups [block0, block0 + n_blocks) belong to a job: each rasterises the job's grid (or loads it from the grid cache: the
+// later levels of a hierarchical search), then takes work units round-robin -- a unit is (region, angle, candidate pass of
+// P.cand_per_pass candidates), worked on by the whole workgroup; the pruned result maps are global tables of 64-bit keys
+// updated with atomicMin (score bits << 32 | visit order inside the reference's per-thread map), decoded on the host or, between
+// the levels of a hierarchical search, by k_hier_next.  Any grid size / step; cell reads go through the bounds-checked
+// directory lookup, several at a time (gather_cells).
 __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, const GreedyJob* __restrict__ jobs,
                                                       const int32_t* __restrict__ block_job,
                                                       const double* __restrict__ ref_pts_all,
@@ -1962,11 +1964,10 @@ __global__ __launch_bounds__(GR_THREADS) void k_match_greedy(MatchParams P, cons
   const float ikscale = (float)(1. / (float)P.kscale);
   const int nbins = J.nbx * J.nby * J.nbt;
   uint32_t* const pl = &S.plist[0][0];                               // one kept-point list for the workgroup, all eight point lists long
-  // One (region, angle) item per workgroup and round.  Every wavefront turns all the query points and builds the same
-  // kept-point list (the consecutive-duplicate rule runs along the whole list; this is a hundredth of the work), then
-  // gathers one quarter of it for all the candidates; the quarters meet in LDS.  Round 2 gave every wavefront an item of
-  // its own: with the 30-60 items of a key frame's searches that left the kernel waiting ~180 us for one wavefront's
-  // serial walk over ~1000 points while 240 CUs idled.
+  // One work unit per workgroup and round.  The workgroup turns the query points and builds the item's kept-point list
+  // together, then every wavefront gathers an eighth of it for all the candidates of the unit; the eighths meet in LDS.
+  // Round 2 gave every wavefront an item of its own: with the 30-60 items of a key frame's searches that left the kernel
+  // waiting ~180 us for one wavefront's serial walk over ~1000 points while 240 CUs idled.
   int* const totals = reinterpret_cast<int*>(&S.totals[0][0]);     // 64 * CAND_U candidate sums (tile_slot / claim bits are done with)
   static_assert(64 * CAND_U * 4 <= (int)sizeof(S.totals), "candidate sums of one item");
   // work units: (item, candidate pass) -- the 2-3 passes of a region of a hierarchical level on workgroups of their own
