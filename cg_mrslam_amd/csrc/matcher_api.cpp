@@ -1,6 +1,7 @@
 // C ABI of the scan matcher (include/cgmr.h): configuration, buffers, launch.
 #include <algorithm>
 #include <cmath>
+#include <xmmintrin.h>
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
@@ -981,7 +982,7 @@ void keep_first_point_per_cell(const cgmr_matcher_config* cfg, std::vector<doubl
     float gx = ((float)pts[2 * i] - ll_x) * inv_res, gy = ((float)pts[2 * i + 1] - ll_y) * inv_res;
     gx = std::fmin(std::fmax(gx, -30000.f), 30000.f);
     gy = std::fmin(std::fmax(gy, -30000.f), 30000.f);
-    const int rx = (int)std::lrintf(gx), ry = (int)std::lrintf(gy);
+    const int rx = _mm_cvtss_si32(_mm_set_ss(gx)), ry = _mm_cvtss_si32(_mm_set_ss(gy));   // lrintf (round to nearest even) without the libm call
     const uint32_t key = ((uint32_t)(uint16_t)(int16_t)rx) | ((uint32_t)(uint16_t)(int16_t)ry << 16);
     size_t h = (key * 2654435761u) & (cap - 1);
     bool seen = false;
