@@ -953,19 +953,31 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   double tc = t0;
   auto CK = [&](const char* what) { if (trace) { double t = now_s(); fprintf(stderr, "  sym %-28s %7.1f us\n", what, 1e6 * (t - tc)); tc = t; } };
   S = Symbolic();
+  CK("  adj: previous analysis released");
   S.nV = nV;
   S.nE = nE;
-  for (int k = 0; k < nE; k++)
-    if (ef[k] < 0 || ef[k] >= nV || et[k] < 0 || et[k] >= nV) return -1;
-  // active free vertices
+  // the edge list checked and the vertices with an edge marked, by slices of the list (every mark is the same byte value: the
+  // stores of two threads to one vertex do not care about their order)
   std::vector<uint8_t> active(nV, 0);
-  for (int k = 0; k < nE; k++) { active[ef[k]] = 1; active[et[k]] = 1; }
+  {
+    std::atomic<int> bad{0};
+    uint8_t* act = active.data();
+    parallel_for(nE, host_threads(), [&](int lo, int hi) {
+      for (int k = lo; k < hi; k++) {
+        if (ef[k] < 0 || ef[k] >= nV || et[k] < 0 || et[k] >= nV) { bad.store(1, std::memory_order_relaxed); continue; }
+        __atomic_store_n(act + ef[k], (uint8_t)1, __ATOMIC_RELAXED);
+        __atomic_store_n(act + et[k], (uint8_t)1, __ATOMIC_RELAXED);
+      }
+    }, 16384);
+    if (bad.load()) return -1;
+  }
   S.hidx.assign(nV, -1);
   int nf = 0;
   for (int v = 0; v < nV; v++) if (active[v] && !(fixed && fixed[v])) S.hidx[v] = nf++;
   S.nf = nf;
   S.vperm.assign(nV, -1);
   if (nf == 0) { S.level_ptr.assign(1, 0); return 0; }
+  CK("  adj: checks, active, block indices");
   // adjacency CSR over block indices (deduplicated, sorted)
   // (counting and filling: every thread walks the whole edge list and takes the end points that fall into its own range of
   // block indices -- the reads are shared and sequential, the scattered writes are private: no atomics, same lists as a
@@ -984,6 +996,51 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     body(0, std::min(nf, per));
     for (auto& j : jobs) HelperPool::wait(j);
   };
+  // Edge slices (round 5): every thread counts the end points of ITS share of the edge list into a column of its own, a pass
+  // over the vertices turns the columns into row starts and per-thread write positions, every thread files its share -- the
+  // rows hold their entries in edge order, exactly as the one-thread pass leaves them, and the edge list is read once per
+  // pass instead of once per thread and pass (CGMR_ADJ_SLICES=0: every thread walks the whole list and keeps its vertex range).
+  static const bool adj_slices = !(getenv("CGMR_ADJ_SLICES") && atoi(getenv("CGMR_ADJ_SLICES")) == 0);
+  if (adj_slices && NTA > 1) {
+    std::vector<int32_t> cnt((size_t)NTA * nf, 0);
+    auto in_slices = [&](auto&& body) {
+      std::vector<HelperPool::Job> jobs(NTA - 1);
+      for (int t = 1; t < NTA; t++) {
+        jobs[t - 1].fn = [&body, t] { body(t); };
+        pool().run(jobs[t - 1]);
+      }
+      body(0);
+      for (auto& j : jobs) HelperPool::wait(j);
+    };
+    auto slice = [&](int t, int& lo, int& hi) { lo = (int)((int64_t)nE * t / NTA); hi = (int)((int64_t)nE * (t + 1) / NTA); };
+    in_slices([&](int t) {
+      int lo, hi;
+      slice(t, lo, hi);
+      int32_t* c = cnt.data() + (size_t)t * nf;
+      for (int k = lo; k < hi; k++) {
+        const int a = S.hidx[ef[k]], b = S.hidx[et[k]];
+        if (a < 0 || b < 0 || a == b) continue;
+        c[a]++; c[b]++;
+      }
+    });
+    for (int v = 0; v < nf; v++) {                       // row starts; cnt[t][v] becomes thread t's first position in row v
+      int32_t at = ap[v];
+      for (int t = 0; t < NTA; t++) { const int32_t n = cnt[(size_t)t * nf + v]; cnt[(size_t)t * nf + v] = at; at += n; }
+      ap[v + 1] = at;
+    }
+    ai.resize(ap[nf]);
+    in_slices([&](int t) {
+      int lo, hi;
+      slice(t, lo, hi);
+      int32_t* pos = cnt.data() + (size_t)t * nf;
+      for (int k = lo; k < hi; k++) {
+        const int a = S.hidx[ef[k]], b = S.hidx[et[k]];
+        if (a < 0 || b < 0 || a == b) continue;
+        ai[pos[a]++] = b;
+        ai[pos[b]++] = a;
+      }
+    });
+  } else {
   in_ranges([&](int lo, int hi) {
     for (int k = 0; k < nE; k++) {
       const int a = S.hidx[ef[k]], b = S.hidx[et[k]];
@@ -1004,6 +1061,10 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
         if (b >= lo && b < hi) ai[pos[b]++] = a;
       }
     });
+  }
+  }
+  CK("  adj: count + file");
+  {
     // sort + dedupe each row (in parallel), then compact in place
     std::vector<int32_t> len(nf);
     parallel_for(nf, host_threads(), [&](int lo, int hi) {
@@ -1015,6 +1076,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
         len[v] = w - b;
       }
     });
+    CK("  adj: sort + dedupe");
     int w = 0;
     for (int v = 0; v < nf; v++) {
       int b = ap[v];
