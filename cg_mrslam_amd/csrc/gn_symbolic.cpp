@@ -720,6 +720,39 @@ void host_pool_info(int out[5]) {
 
 namespace {
 
+// the node table of a from-scratch ordering, from what analyze() kept of it (see Symbolic::nd_pending)
+void materialize_nd_tree(Symbolic& S) {
+  if (!S.nd_pending) return;
+  S.nd_pending = false;
+  const std::vector<Symbolic::NDRecLite>& recs = S.nd_pending_recs;
+  const std::vector<int32_t>& order = S.nd_pending_order;
+  S.nd_nodes.clear();
+  S.nd_nodes.reserve(recs.size() + 8);
+  std::function<int(int, int, int)> build = [&](int rec, int begin, int parent) -> int {
+    if (rec < 0 || rec >= (int)recs.size()) return -1;
+    const Symbolic::NDRecLite R = recs[rec];
+    const int id = (int)S.nd_nodes.size();
+    S.nd_nodes.emplace_back();
+    S.nd_nodes[id].parent = parent;
+    S.nd_nodes[id].count = R.n;
+    const int na = R.a >= 0 ? recs[R.a].n : 0, nb = R.b >= 0 ? recs[R.b].n : 0;
+    const int ca = build(R.a, begin, id), cb = build(R.b, begin + na, id);
+    S.nd_nodes[id].a = ca; S.nd_nodes[id].b = cb;
+    S.nd_nodes[id].verts.assign(order.begin() + begin + na + nb, order.begin() + begin + na + nb + R.ssz);
+    return id;
+  };
+  S.nd_root = build(S.nd_pending_root, 0, -1);
+  if (!S.nd_pending_hubs.empty()) {
+    if (S.nd_root < 0) { S.nd_nodes.emplace_back(); S.nd_root = (int)S.nd_nodes.size() - 1; S.nd_nodes[S.nd_root].parent = -1; }
+    Symbolic::NDNode& Rn = S.nd_nodes[S.nd_root];
+    Rn.verts.insert(Rn.verts.end(), S.nd_pending_hubs.begin(), S.nd_pending_hubs.end());
+    Rn.count += (int)S.nd_pending_hubs.size();
+  }
+  std::vector<Symbolic::NDRecLite>().swap(S.nd_pending_recs);
+  std::vector<int32_t>().swap(S.nd_pending_order);
+  std::vector<int32_t>().swap(S.nd_pending_hubs);
+}
+
 // ------------------------------------------------------------------ incremental ordering
 // The previous dissection tree extended by the vertices prev.nf .. nf-1 (gn_symbolic.h: Symbolic::NDNode).  A vertex may live
 // in node X (a leaf, or the separator of an inner node) iff each of its neighbours lives in X's subtree or in the
@@ -738,6 +771,7 @@ bool extend_order(Symbolic& prev, int nf, const std::vector<int32_t>& ap, const 
                   Symbolic& S, int n_new_edges, const int32_t* new_ef, const int32_t* new_et, const std::vector<int32_t>& hidx,
                   const std::vector<int32_t>& forced_hubs) {
   typedef Symbolic::NDNode Node;
+  materialize_nd_tree(prev);
   std::vector<Node> T = std::move(prev.nd_nodes);            // (the caller's previous analysis is discarded afterwards either way)
   const int root = prev.nd_root;
   if (root < 0 || T.empty()) return false;
@@ -1165,34 +1199,25 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     // both orderings side by side with the shorter tree kept (500 levels in all, +0.4-0.6 ms of analysis on the shared host
     // for 0.24 ms per level and optimize(10)), nor a choice after three levels of both (517 levels).  DESIGN.md 2.1.
     const NDRange whole = nd(C, 0, n_nd, 0, -1, &root_rec);
+    CK("  nd: dissection");
     S.nd_height_full = whole.height + (nf - n_nd + kPanelW - 1) / kPanelW;
     for (int p = n_nd; p < nf; p += kPanelW) pstart[p] = 1;
     pos_ranges.swap(C.subtree_ranges);
-    // the tree with its vertices, for the next extension
+    // the tree for the next extension: as recorded (materialize_nd_tree makes the node table when an extension asks for it)
     S.nd_nodes.clear();
-    S.nd_nodes.reserve((size_t)C.n_recs.load() + 8);
-    std::function<int(int, int, int)> build = [&](int rec, int begin, int parent) -> int {
-      if (rec < 0) return -1;
-      const NDCtx::Rec R = C.recs[rec];
-      const int id = (int)S.nd_nodes.size();
-      S.nd_nodes.emplace_back();
-      S.nd_nodes[id].parent = parent;
-      S.nd_nodes[id].count = R.n;
-      const int na = R.a >= 0 ? C.recs[R.a].n : 0, nb = R.b >= 0 ? C.recs[R.b].n : 0;
-      const int ca = build(R.a, begin, id), cb = build(R.b, begin + na, id);
-      S.nd_nodes[id].a = ca; S.nd_nodes[id].b = cb;
-      S.nd_nodes[id].verts.assign(order.begin() + begin + na + nb, order.begin() + begin + na + nb + R.ssz);
-      return id;
-    };
-    S.nd_root = build(root_rec, 0, -1);
-    if (!hubs.empty()) {
-      if (S.nd_root < 0) { S.nd_nodes.emplace_back(); S.nd_root = (int)S.nd_nodes.size() - 1; S.nd_nodes[S.nd_root].parent = -1; }
-      Symbolic::NDNode& Rn = S.nd_nodes[S.nd_root];
-      Rn.verts.insert(Rn.verts.end(), hubs.begin(), hubs.end());
-      Rn.count += (int)hubs.size();
+    {
+      const int nrec = std::min((int)C.recs.size(), C.n_recs.load());
+      S.nd_pending_recs.resize(nrec);
+      for (int q = 0; q < nrec; q++) S.nd_pending_recs[q] = {C.recs[q].a, C.recs[q].b, C.recs[q].n, C.recs[q].ssz};
+      S.nd_pending_order = order;
+      S.nd_pending_hubs = hubs;
+      S.nd_pending_root = root_rec;
+      S.nd_pending = true;
+      S.nd_root = (root_rec >= 0 || !hubs.empty()) ? 0 : -1;      // (the root is the first node of the table)
     }
     S.nd_nf_full = nf;
     S.nd_appended = 0;
+    CK("  nd: tree recorded");
   }
   S.extended = extended;
   for (int p = 0; p < nf; p++) if (pstart[p]) panel_start.push_back(p);

@@ -135,6 +135,13 @@ struct Symbolic {
   struct NDNode { int32_t parent = -1, a = -1, b = -1, count = 0; std::vector<int32_t> verts; };
   std::vector<NDNode> nd_nodes;
   int32_t nd_root = -1;
+  // A from-scratch ordering leaves the tree as nd() recorded it (sizes per node, the ordering, the hubs); the node table above is
+  // made from that when the next analysis wants to extend it (materialize_nd_tree) -- a one-shot analysis never pays for it.
+  struct NDRecLite { int32_t a, b, n, ssz; };
+  std::vector<NDRecLite> nd_pending_recs;
+  std::vector<int32_t> nd_pending_order, nd_pending_hubs;
+  int32_t nd_pending_root = -1;
+  bool nd_pending = false;
   int32_t nd_nf_full = 0;              // free poses when the ordering was last computed from scratch
   int32_t nd_appended = 0;             // vertices inserted incrementally since then
   int32_t nd_height_full = 0;          // height of that ordering's tree, in panels (before amalgamation)
