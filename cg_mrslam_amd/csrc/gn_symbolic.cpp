@@ -1421,6 +1421,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     }
     for (int t = 0; t + 1 < nrange; t++) HelperPool::wait(jobs[t]);
   }
+  CK("  borders: subtrees");
   int ndead = 0;
   for (int t = 0; t < nrange; t++) {            // splice the row lists together, hand the subtree roots to their parents
     const int base = (int)S.rows.size();
@@ -1448,6 +1449,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     ndead += X.ndead;
     S.max_ns = std::max(S.max_ns, X.max_ns);
   }
+  CK("  borders: splice + fronts above");
   if (ndead > 0) {                    // compact the front table (ids stay monotone: children before parents)
     std::vector<int32_t> newid(nfr, -1);
     int k = 0;
@@ -1472,6 +1474,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   // atomics: every cell of a copy has one writer per launch, launches are ordered => bit-reproducible sums).  The
   // children with the least slack are placed first, each into the launch with the fewest siblings so far; when more than
   // kMaxPanSlots would share a launch the parent moves up a level.
+  CK("  borders: compaction");
   int nlev = 0;
   {
     std::vector<int32_t> cnt, ord;
