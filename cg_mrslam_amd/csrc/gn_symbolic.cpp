@@ -1231,24 +1231,18 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
 
   // adjacency in permuted indices, rows sorted
   std::vector<int32_t> cp(nf + 1, 0), ci(ai.size());
+  std::vector<int32_t> offbase(nf + 1, 0);             // (the rows' entries below the diagonal are counted in the same pass: see below)
   for (int c = 0; c < nf; c++) cp[c + 1] = cp[c] + (ap[order[c] + 1] - ap[order[c]]);
   parallel_for(nf, NT, [&](int lo, int hi) {
     for (int c = lo; c < hi; c++) {
-      int o = order[c], w = cp[c];
-      for (int p = ap[o]; p < ap[o + 1]; p++) ci[w++] = iperm[ai[p]];
+      int o = order[c], w = cp[c], cnt = 0;
+      for (int p = ap[o]; p < ap[o + 1]; p++) { const int r = iperm[ai[p]]; ci[w++] = r; cnt += r > c ? 1 : 0; }
       sort_row(ci.data() + cp[c], ci.data() + cp[c + 1]);
+      offbase[c + 1] = cnt;
     }
   });
   CK("permuted adjacency");
   // unique lower off-diagonal blocks: enumerate (c, r>c) column-major
-  std::vector<int32_t> offbase(nf + 1, 0);
-  parallel_for(nf, NT, [&](int lo, int hi) {
-    for (int c = lo; c < hi; c++) {
-      int cnt = 0;
-      for (int p = cp[c]; p < cp[c + 1]; p++) if (ci[p] > c) cnt++;
-      offbase[c + 1] = cnt;
-    }
-  });
   for (int c = 0; c < nf; c++) offbase[c + 1] += offbase[c];
   S.nb = offbase[nf];
   S.off_row.resize(S.nb);
