@@ -24,7 +24,7 @@ double now_s() {
   return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
 }
 
-constexpr int kRangeDepth = 2;        // ND depth whose halves become the parallel units of the border computation
+constexpr int kRangeDepth = 3;        // ND depth whose halves become the parallel units of the border computation
 
 // A few persistent helper threads: the analysis forks a dozen short parallel sections per call, and creating a
 // thread for each costs more than most of them run.  Idle helpers spin briefly (the next section usually follows
@@ -1401,7 +1401,15 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
   std::vector<uint8_t> in_range(nfr, 0);
   {
     std::vector<HelperPool::Job> jobs(nrange);
-    for (int t = 0; t < nrange; t++) {
+    // the largest subtrees first (twice as many subtrees as threads: the long ones start at once, the short ones fill in)
+    std::vector<int> by_size(nrange);
+    for (int t = 0; t < nrange; t++) by_size[t] = t;
+    std::sort(by_size.begin(), by_size.end(), [&](int a, int b) {
+      const int sa = franges[a].second - franges[a].first, sb = franges[b].second - franges[b].first;
+      return sa != sb ? sa > sb : a < b;
+    });
+    for (int q = 0; q < nrange; q++) {
+      const int t = by_size[q];
       for (int f = franges[t].first; f < franges[t].second; f++) in_range[f] = 1;
       jobs[t].fn = [&, t] {
         BorderCtx& X = rctx[t];
@@ -1411,9 +1419,9 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
         X.fhi = franges[t].second;
         for (int f = X.flo; f < X.fhi; f++) do_front(f, X);
       };
-      if (t + 1 < nrange) pool().run(jobs[t]); else { jobs[t].fn(); jobs[t].done.store(1); }
+      if (q + 1 < nrange) pool().run(jobs[t]); else { jobs[t].fn(); jobs[t].done.store(1); }
     }
-    for (int t = 0; t + 1 < nrange; t++) HelperPool::wait(jobs[t]);
+    for (int t = 0; t < nrange; t++) HelperPool::wait(jobs[t]);
   }
   CK("  borders: subtrees");
   int ndead = 0;
