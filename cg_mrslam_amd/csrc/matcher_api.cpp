@@ -1,7 +1,9 @@
 // C ABI of the scan matcher (include/cgmr.h): configuration, buffers, launch.
 #include <algorithm>
 #include <cmath>
+#if defined(__SSE__)
 #include <xmmintrin.h>
+#endif
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
@@ -185,6 +187,7 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
   constexpr int kSlowSplit = 16, kSlowChunk = 256;
   const size_t slow_merge_bytes = lean ? (size_t)kSlowChunk * (match_close_max_bins() * 8 + 8) : 0;
   size_t o_merge = L.add(merge_bytes), o_redo = L.add(lean ? sizeof(int) * (size_t)n_pairs : 0), o_smerge = L.add(slow_merge_bytes),
+         o_slow = L.add(lean ? sizeof(int) * (size_t)kSlowChunk : 0),
          o_scratch = L.add(P.scratch_stride * (size_t)nblocks);
   int rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
   if (rc) return rc;
@@ -212,54 +215,74 @@ int match_run(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, int n_pairs, int n_
                            d_xyt, d_score, d_found, d_nres, (int*)(d + o_err), (unsigned long long*)(d + o_merge),
                            (int*)(d + o_merge + (size_t)n_pairs * match_close_max_bins() * 8), lean ? (int*)(d + o_redo) : nullptr);
   int* errv = (int*)(ctx->pinned + 128);                            // (read-back of both blocks)
+  // the slow pairs (the back of the list), kSlowSplit workgroups each: the single call's way of sharing a pair
+  MatchParams Ps = P;
+  Ps.split = kSlowSplit;
+  static const bool no_redo = getenv("CGMR_MATCH_NOREDO") && atoi(getenv("CGMR_MATCH_NOREDO")) != 0;   // (profiling the lean instance alone)
   if (lean) {
-    // pairs left over (err[3]; their indices in the redo list): the general kernel takes them from the list.  The count is needed
-    // on the host only to skip the second launch -- normally there is nothing to do
-    HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 64, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const int n_redo = errv[3], n_slow = errv[8];
-    ctx->match_redo_pairs = (int64_t)n_redo + n_slow;
-    for (int i = 0; i < 3; i++) ctx->match_redo_why[i] = errv[4 + i];
-    static const bool no_redo = getenv("CGMR_MATCH_NOREDO") && atoi(getenv("CGMR_MATCH_NOREDO")) != 0;   // (profiling the lean instance alone)
-    if (errv[0] == 0 && n_redo > 0 && !no_redo) {
-      h_err[0] = 0; h_err[1] = std::min(n_redo, ctx->n_cus); h_err[2] = 0; h_err[3] = n_redo;
-      HIP_TRY(ctx, hipMemcpyAsync(d + o_err, h_err, 16, hipMemcpyHostToDevice, ctx->stream));
-      launch_match_close_batch(ctx->stream, h_err[1], 0, P, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
+    // Pairs left over (err[3]; their indices in the redo list) and pairs that are slow to search (err[8]; the back of the list): the
+    // general kernel behind the lean one takes them.  Both launches are ALWAYS queued and find their list lengths on the device
+    // (k_match_redo_prepare): normally they find nothing to do and cost a few microseconds -- round 5 read the counts back and
+    // synchronised in the middle of every call to save them (the advisor's finding: the device time of a call then included the
+    // host's round trip).
+    launch_match_redo_prepare(ctx->stream, (int*)(d + o_err), n_pairs, nblocks, nblocks, kSlowChunk, (const int*)(d + o_redo),
+                              (int*)(d + o_slow), d_found, no_redo ? 1 : 0);
+    if (!no_redo) {
+      launch_match_close_batch(ctx->stream, nblocks, 0, P, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
                                (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
                                d_xyt, d_score, d_found, d_nres, (int*)(d + o_err), (unsigned long long*)(d + o_merge),
                                (int*)(d + o_merge + (size_t)n_pairs * match_close_max_bins() * 8), (int*)(d + o_redo));
-    }
-    // the slow pairs (the back of the list), kSlowSplit workgroups each: the single call's way of sharing a pair
-    MatchParams Ps = P;
-    Ps.split = kSlowSplit;
-    int* h_err2 = (int*)(ctx->pinned + 64);
-    for (int s0 = 0; errv[0] == 0 && s0 < n_slow && !no_redo; s0 += kSlowChunk) {
-      const int ns = std::min(kSlowChunk, n_slow - s0);
-      if (s0) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // (h_err2 is read by the previous chunk's copy)
-      h_err2[0] = 0; h_err2[1] = std::min(ns * kSlowSplit, nblocks); h_err2[2] = 0; h_err2[3] = ns;
-      HIP_TRY(ctx, hipMemcpyAsync(d + o_err + 64, h_err2, 16, hipMemcpyHostToDevice, ctx->stream));
       HIP_TRY(ctx, hipMemsetAsync(d + o_smerge, 0xff, slow_merge_bytes, ctx->stream));
-      launch_match_close_batch(ctx->stream, h_err2[1], 0, Ps, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
+      launch_match_close_batch(ctx->stream, nblocks, 0, Ps, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
                                (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
                                d_xyt, d_score, d_found, d_nres, (int*)(d + o_err + 64), (unsigned long long*)(d + o_smerge),
-                               (int*)(d + o_smerge + (size_t)kSlowChunk * match_close_max_bins() * 8),
-                               (int*)(d + o_redo) + (n_pairs - s0 - ns));
+                               (int*)(d + o_smerge + (size_t)kSlowChunk * match_close_max_bins() * 8), (int*)(d + o_slow));
     }
-  } else ctx->match_redo_pairs = ctx->match_redo_why[0] = ctx->match_redo_why[1] = ctx->match_redo_why[2] = 0;
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(errv, d + o_err, 128, hipMemcpyDeviceToHost, ctx->stream));
   char* h_out_stage = ctx->pinned + 256 + io_in + ((256 - io_in % 256) % 256);
   if (io_out) HIP_TRY(ctx, hipMemcpyAsync(h_out_stage, io->d_out, io_out, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
-  if (io_out) memcpy(io->h_out, h_out_stage, io_out);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->match_seconds = 1e-3 * ms;
   ctx->match_pairs = n_pairs;
-  ctx->match_slow_pairs = errv[2] + (int64_t)errv[16 + 2];         // (second block: the slow pairs' own launch; zero when there was none)
+  ctx->match_slow_pairs = errv[2] + (int64_t)errv[16 + 2];         // (second block: the slow pairs' own launch; zero when it had nothing to do)
   ctx->match_ext_pairs = errv[7] + (int64_t)errv[16 + 7];
   if (errv[0] == 0) errv[0] = errv[16];
+  if (lean) {
+    const int n_redo = errv[9], n_slow = errv[10];
+    ctx->match_redo_pairs = (int64_t)n_redo + n_slow;
+    for (int i = 0; i < 3; i++) ctx->match_redo_why[i] = errv[4 + i];
+    // more slow pairs than the launch behind the lean one holds (kSlowChunk; of 10^6 generated C3 pairs 148 are slow): the rest in
+    // chunks from the host, which knows the count only now
+    int* h_err2 = (int*)(ctx->pinned + 64);
+    for (int s0 = kSlowChunk; errv[0] == 0 && s0 < n_slow && !no_redo; s0 += kSlowChunk) {
+      const int ns = std::min(kSlowChunk, n_slow - s0);
+      h_err2[0] = 0; h_err2[1] = std::min(ns * kSlowSplit, nblocks); h_err2[2] = 0; h_err2[3] = ns;
+      for (int i = 4; i < 16; i++) h_err2[i] = 0;
+      HIP_TRY(ctx, hipMemcpyAsync(d + o_err + 64, h_err2, 64, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync(d + o_smerge, 0xff, slow_merge_bytes, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+      launch_match_close_batch(ctx->stream, h_err2[1], 0, Ps, d_ref, d_xform, d_qry, d_guess, (const double*)(tab + t_cos),
+                               (const double*)(tab + t_sin), (const uint8_t*)(tab + t_kern), (unsigned char*)(d + o_scratch),
+                               d_xyt, d_score, d_found, d_nres, (int*)(d + o_err + 64), (unsigned long long*)(d + o_smerge),
+                               (int*)(d + o_smerge + (size_t)kSlowChunk * match_close_max_bins() * 8),
+                               (int*)(d + o_redo) + (n_pairs - s0 - ns));
+      HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(h_err2, d + o_err + 64, 64, hipMemcpyDeviceToHost, ctx->stream));
+      if (io_out) HIP_TRY(ctx, hipMemcpyAsync(h_out_stage, io->d_out, io_out, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+      ctx->match_seconds += 1e-3 * ms;
+      ctx->match_slow_pairs += h_err2[2];
+      ctx->match_ext_pairs += h_err2[7];
+      if (errv[0] == 0) errv[0] = h_err2[0];
+    }
+  } else ctx->match_redo_pairs = ctx->match_redo_why[0] = ctx->match_redo_why[1] = ctx->match_redo_why[2] = 0;
+  if (io_out) memcpy(io->h_out, h_out_stage, io_out);
   if (errv[0] != 0) return set_err(ctx, CGMR_E_INVALID, "matcher kernel rejected the search (code %d: window/bins too large)", errv[0]);
   return CGMR_OK;
 }
@@ -831,7 +854,10 @@ static int verify_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
   size_t o_sc = L.add(8 * (size_t)nj), o_nn = L.add(4 * (size_t)nj), o_scratch = L.add(P.scratch_stride * (size_t)nj);
   rc = arena_reserve(ctx, ctx->mt_arena, L.off + 256);
   if (rc) return rc;
-  rc = pinned_reserve(ctx, hbytes);
+  // the error word, the scores and the counts lie one behind the other on the device: ONE copy brings them back, into the pinned
+  // block behind the upload (round 5 queued three copies into pageable vectors and a stack word: the runtime's staged path)
+  const size_t h_back = (hbytes + 255) & ~size_t(255), back_bytes = o_nn + 4 * (size_t)nj - o_err;
+  rc = pinned_reserve(ctx, h_back + back_bytes);
   if (rc) return rc;
   char* h = ctx->pinned;
   for (int j = 0; j < nj; j++) {
@@ -848,12 +874,13 @@ static int verify_batch_core(cgmr_ctx* ctx, const cgmr_matcher_config* cfg, cons
                       nonmatched_score, (const uint8_t*)(d + o_kern), (unsigned char*)(d + o_scratch), (double*)(d + o_sc),
                       (int*)(d + o_nn), (int*)(d + o_err));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  int err = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(score.data(), d + o_sc, 8 * (size_t)nj, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(nnm.data(), d + o_nn, 4 * (size_t)nj, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(h + h_back, d + o_err, back_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
+  int err = 0;
+  memcpy(&err, h + h_back, sizeof(int));
+  memcpy(score.data(), h + h_back + (o_sc - o_err), 8 * (size_t)nj);
+  memcpy(nnm.data(), h + h_back + (o_nn - o_err), 4 * (size_t)nj);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->match_seconds = 1e-3 * ms;
@@ -982,7 +1009,13 @@ void keep_first_point_per_cell(const cgmr_matcher_config* cfg, std::vector<doubl
     float gx = ((float)pts[2 * i] - ll_x) * inv_res, gy = ((float)pts[2 * i + 1] - ll_y) * inv_res;
     gx = std::fmin(std::fmax(gx, -30000.f), 30000.f);
     gy = std::fmin(std::fmax(gy, -30000.f), 30000.f);
-    const int rx = _mm_cvtss_si32(_mm_set_ss(gx)), ry = _mm_cvtss_si32(_mm_set_ss(gy));   // lrintf (round to nearest even) without the libm call
+#if defined(__SSE__)
+    // lrintf without the libm call: cvtss2si rounds in the MXCSR mode, which is round-to-nearest-even unless the process changed it
+    // (lrintf follows fesetround the same way: the two agree in every mode)
+    const int rx = _mm_cvtss_si32(_mm_set_ss(gx)), ry = _mm_cvtss_si32(_mm_set_ss(gy));
+#else
+    const int rx = (int)lrintf(gx), ry = (int)lrintf(gy);        // (hosts without SSE: aarch64, ..)
+#endif
     const uint32_t key = ((uint32_t)(uint16_t)(int16_t)rx) | ((uint32_t)(uint16_t)(int16_t)ry << 16);
     size_t h = (key * 2654435761u) & (cap - 1);
     bool seen = false;

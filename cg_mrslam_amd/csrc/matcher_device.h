@@ -116,6 +116,8 @@ void launch_match_greedy(hipStream_t st, int nblocks, const MatchParams& P, cons
 size_t match_grid_image_bytes(const MatchParams& P);     // one job's slot in the grid cache (mode 1: the job's first workgroup stores
                                                          // the rasterised grid there, mode 2: every workgroup loads it instead of rasterising)
 void launch_hier_next(hipStream_t st, int n_jobs, const MatchParams& P, const HierStep& H, int* err);
+void launch_match_redo_prepare(hipStream_t st, int* err, int n_pairs, int grid_redo, int grid_slow, int slow_cap, const int* redo_list,
+                               int* slow_list, uint8_t* out_found, int no_redo);
 void launch_match_close_batch(hipStream_t st, int nblocks, int variant, const MatchParams& P, const float* ranges_ref, const double* ref_xform,
                               const float* ranges_qry, const double* guess, const double* beam_cos,
                               const double* beam_sin, const uint8_t* kernel_lut, unsigned char* scratch,

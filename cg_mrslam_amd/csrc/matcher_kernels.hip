@@ -2357,6 +2357,40 @@ void launch_hier_next(hipStream_t st, int n_jobs, const MatchParams& P, const Hi
   hipLaunchKernelGGL(k_hier_next, dim3(n_jobs), dim3(HN_THREADS), 0, st, P, H, err);
 }
 
+// Between a lean launch and the two launches queued behind it (the general instance on the redo list, the slow pairs spread over
+// workgroups): the counts stay on the device.  err[3] / err[8] of the lean launch's block are the list lengths; this kernel sets
+// the work counters of the two launches (they start at the grid sizes the host launches with), copies the first `slow_cap` slow
+// pairs -- filed from the back of the list -- into a list of their own, and keeps the counts for the host's statistics in
+// err[9] / err[10].  A lean launch that reported an error, or `no_redo` (profiling the lean instance alone), leaves both lists
+// empty for the launches behind; with no_redo the pairs nobody searched are marked "not found" instead of staying unwritten.
+__global__ __launch_bounds__(256) void k_match_redo_prepare(int* __restrict__ err, int n_pairs, int grid_redo, int grid_slow, int slow_cap,
+                                                            const int* __restrict__ redo_list, int* __restrict__ slow_list,
+                                                            uint8_t* __restrict__ out_found, int no_redo) {
+  const int tid = threadIdx.x;
+  const int n_redo = min(max(err[3], 0), n_pairs), n_slow = min(max(err[8], 0), n_pairs - n_redo);
+  const bool bad = err[0] != 0;
+  const int ns = min(n_slow, slow_cap);
+  for (int k = tid; k < ns; k += 256) slow_list[k] = redo_list[n_pairs - 1 - k];
+  if (no_redo) {
+    for (int k = tid; k < n_redo; k += 256) out_found[redo_list[k]] = 0;
+    for (int k = tid; k < n_slow; k += 256) out_found[redo_list[n_pairs - 1 - k]] = 0;
+  }
+  __syncthreads();                                                 // (every thread has read err[3] / err[8] / err[0])
+  if (tid == 0) {
+    const bool off = bad || no_redo != 0;
+    err[9] = n_redo; err[10] = n_slow;
+    err[1] = grid_redo; err[3] = off ? 0 : n_redo;                 // the redo launch's work counter and list length ([2]: slow-path pairs, summed up)
+    err[16] = 0; err[17] = grid_slow; err[18] = 0; err[19] = off ? 0 : ns;
+    for (int q = 20; q < 32; q++) err[q] = 0;
+  }
+}
+
+void launch_match_redo_prepare(hipStream_t st, int* err, int n_pairs, int grid_redo, int grid_slow, int slow_cap, const int* redo_list,
+                               int* slow_list, uint8_t* out_found, int no_redo) {
+  hipLaunchKernelGGL(k_match_redo_prepare, dim3(1), dim3(256), 0, st, err, n_pairs, grid_redo, grid_slow, slow_cap, redo_list, slow_list,
+                     out_found, no_redo);
+}
+
 // variant: 0 = the general kernel (redo_list null: every pair; else the pairs redo_list[0 .. err[3]) a lean launch left over),
 // 1 / 2 = the lean exhaustive / pruned instance (match_close_lean_ok: the shapes they are built for)
 void launch_match_close_batch(hipStream_t st, int nblocks, int variant, const MatchParams& P, const float* ranges_ref, const double* ref_xform,

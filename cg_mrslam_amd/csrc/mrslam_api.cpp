@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 #include "cgmr_ctx.h"
@@ -1196,6 +1197,28 @@ int cgmr_graph_pack(cgmr_graph* g, void* d_send_out) {
   return CGMR_OK;
 }
 
+// Peer access from `dev` to `peer`, asked for and switched on ONCE per pair and process (the answer is kept: round 5 asked the
+// runtime on every cross-device delivery).  Returns true when dev reads peer's memory directly; false is not an error --
+// hipMemcpyPeerAsync then goes through the host.  The caller has made `dev` current.
+static bool peer_access_once(int dev, int peer) {
+  constexpr int kMaxDev = 64;
+  static std::mutex mu;
+  static signed char state[kMaxDev][kMaxDev];            // 0: not asked yet, 1: direct, -1: no peer access
+  if (dev < 0 || peer < 0 || dev >= kMaxDev || peer >= kMaxDev) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  if (state[dev][peer] == 0) {
+    int can = 0;
+    bool ok = hipDeviceCanAccessPeer(&can, dev, peer) == hipSuccess && can;
+    if (ok) {
+      const hipError_t pe = hipDeviceEnablePeerAccess(peer, 0);
+      ok = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+    }
+    (void)hipGetLastError();
+    state[dev][peer] = ok ? 1 : -1;
+  }
+  return state[dev][peer] == 1;
+}
+
 // In-process transport for robots that share a device (loopback runs, several robots of one node in one process): src's
 // packed message (cgmr_graph_pack(src, NULL) before this) goes into slot src->robot of one of dst's two receive buffers
 // (the k-th message for dst into buffer k & 1), a device copy on dst's stream behind src's pack -- what the all-gather does
@@ -1207,15 +1230,8 @@ int cgmr_graph_deliver(cgmr_graph* src, cgmr_graph* dst) {
   if (src->n_packed == 0) return gerr(src, CGMR_E_INVALID, "cgmr_graph_deliver: nothing packed yet (cgmr_graph_pack(src, NULL) first)");
   cgmr_ctx* ctx = dst->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (src->ctx->device != ctx->device) {
-    // the copy below is a device-to-device copy queued on dst's stream: the two devices must be able to reach each other
-    int can = 0;
-    HIP_TRY(ctx, hipDeviceCanAccessPeer(&can, ctx->device, src->ctx->device));
-    if (!can) return gerr(src, CGMR_E_INVALID, "cgmr_graph_deliver: the two robots' devices have no peer access (use the all-gather)");
-    const hipError_t pe = hipDeviceEnablePeerAccess(src->ctx->device, 0);
-    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return gerr(src, CGMR_E_HIP, "cgmr_graph_deliver: hipDeviceEnablePeerAccess failed");
-    (void)hipGetLastError();
-  }
+  const bool cross = src->ctx->device != ctx->device;
+  if (cross) (void)peer_access_once(ctx->device, src->ctx->device);   // direct when the devices reach each other, staged by the runtime when not
   const size_t wb = wire_bytes(src->n_robots, src->cap);
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, src->ev_packed, 0));
   // two receive buffers taking turns: a robot may deliver its round-t message before the destination has ingested round t - 1's
@@ -1224,7 +1240,10 @@ int cgmr_graph_deliver(cgmr_graph* src, cgmr_graph* dst) {
   // buffer whose slice is not the expected one (a robot skipped a round, delivered twice, ..) is ingested as "no message"
   const int64_t k = src->n_delivered[dst->robot];
   unsigned char* recv = (k & 1) ? dst->d_recv2 : dst->d_recv;
-  HIP_TRY(ctx, hipMemcpyAsync(recv + (size_t)src->robot * wb, src->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
+  if (cross)
+    HIP_TRY(ctx, hipMemcpyPeerAsync(recv + (size_t)src->robot * wb, ctx->device, src->d_send, src->ctx->device, wb, ctx->stream));
+  else
+    HIP_TRY(ctx, hipMemcpyAsync(recv + (size_t)src->robot * wb, src->d_send, wb, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(src->ev_consumed[dst->robot], ctx->stream));
   src->n_delivered[dst->robot] = k + 1;                      // (only now: the copy is queued)
   dst->recv_round[k & 1][src->robot] = k;
@@ -1274,7 +1293,9 @@ int cgmr_graph_pack_host(cgmr_graph* g, void* send_out) {
 // leaves the previous one in place (mr_graph_slam.cpp:393-394).  Numeric payload stays on the device (float32 ->
 // double, staging -> compact second edge segment); only ids and counts travel to the host.
 // n_edges_out (nullable) [n_robots]: accepted edges per sender this round (0 = nothing replaced).
-int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
+// skip_senders: bit s set = sender s has no message in this round whatever its slice of the buffer holds (the slice is left
+// alone: cgmr_graph_ingest_delivered below, a delivery that waits for a later round)
+static int graph_ingest_core(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out, unsigned long long skip_senders) {
   if (!g) return CGMR_E_INVALID;
   if (!g->ctx) return gerr(g, CGMR_E_NO_DEVICE, "cgmr_graph_ingest: no device context (use cgmr_graph_ingest_host)");
   cgmr_ctx* ctx = g->ctx;
@@ -1288,6 +1309,11 @@ int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
   char* h_ids = g->pinned + round256(wb);
   HIP_TRY(ctx, hipMemcpyAsync(h_ids, g->d_ids_out, ids_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  for (int s = 0; s < R && skip_senders; s++)
+    if (s < 64 && ((skip_senders >> s) & 1)) {                    // no edges, no closure requests from this sender this round
+      int32_t* io = (int32_t*)h_ids + (size_t)s * (2 + 3 * (size_t)cap);
+      io[0] = 0; io[1] = 0;
+    }
   std::vector<uint8_t> accepted;
   ingest_decide(g, (const int32_t*)h_ids, accepted);
   unsigned long long fresh = 0;                                   // senders whose message replaced their previous set (R <= 64)
@@ -1310,6 +1336,8 @@ int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) {
   return CGMR_OK;
 }
 
+int cgmr_graph_ingest(cgmr_graph* g, const void* d_recv, int32_t* n_edges_out) { return graph_ingest_core(g, d_recv, n_edges_out, 0); }
+
 // The ingest that goes with cgmr_graph_deliver: the k-th call digests the k-th message of every peer (receive buffer k & 1).
 int cgmr_graph_ingest_delivered(cgmr_graph* g, int32_t* n_edges_out) {
   if (!g || !g->ctx) return CGMR_E_INVALID;
@@ -1321,13 +1349,19 @@ int cgmr_graph_ingest_delivered(cgmr_graph* g, int32_t* n_edges_out) {
   cgmr_ctx* ctx = g->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t wb = wire_bytes(g->n_robots, g->cap);
+  // A sender that is two (four, ..) rounds AHEAD has already put a later delivery into this buffer (over the k-th one, which is
+  // lost): that message belongs to a later ingest -- the sender has no message in this round, and neither the slice nor the
+  // note of what lies in it is touched (round 5 cleared both: two rounds lost where one was missed).
+  unsigned long long skip = 0;
   for (int s = 0; s < g->n_robots; s++) {
     if (s == g->robot) continue;
-    if (g->recv_round[k & 1][s] != k) HIP_TRY(ctx, hipMemsetAsync(recv + (size_t)s * wb, 0xff, 4, ctx->stream));
+    const int64_t have = g->recv_round[k & 1][s];
+    if (have > k) { if (s < 64) skip |= 1ULL << s; continue; }
+    if (have != k) HIP_TRY(ctx, hipMemsetAsync(recv + (size_t)s * wb, 0xff, 4, ctx->stream));
     g->recv_round[k & 1][s] = -1;
   }
   g->n_ingested_delivered = k + 1;
-  return cgmr_graph_ingest(g, recv, n_edges_out);
+  return graph_ingest_core(g, recv, n_edges_out, skip);
 }
 
 int cgmr_graph_ingest_host(cgmr_graph* g, const void* recv, int32_t* n_edges_out) {

@@ -596,3 +596,27 @@ def test_a_failed_batch_does_not_stop_the_next_round_and_a_skipped_delivery_is_n
     g1.pack(0)
     assert int(g1.ingest_delivered()[0]) == 0
     g0.close(); g1.close()
+
+
+def test_a_sender_two_rounds_ahead_loses_one_message_not_two():
+    """Round 6 (advisor finding of round 5).  g0 delivers rounds 0, 1 and 2 before g1 ingests anything: delivery 2 lands in
+    receive buffer 0 over delivery 0, which is lost.  g1's ingest of round 0 must then see "no message" from g0 WITHOUT clearing
+    the slice -- it holds round 2's message, which the third ingest digests (round 5 cleared it: rounds 0 and 2 both gone)."""
+    from cg_mrslam_amd import Context
+    g = synth.make_pose_graph(400, 1200, seed=11, id_base=0)
+    want = g["ids"][[5, 60, 150, 260, 399]]
+    c0, c1 = Context(0), Context(0)
+    g0 = RobotGraph(c0, 0, 2)
+    g1 = RobotGraph(c1, 1, 2)
+    g0.add_vertices(g["ids"], g["poses"], g["fixed"])
+    g0.add_edges(g["ids"][g["edge_from"]], g["ids"][g["edge_to"]], g["meas"], g["info"])
+    g1.add_vertices(np.concatenate([[10000], want]), np.zeros((1 + len(want), 3)), None)
+    g0.insertOutClosure(1, want)
+    assert g0.computeCondensedGraph(1) == 1
+    for _ in range(3):                                             # rounds 0, 1, 2 of g0, nothing ingested in between
+        g0.pack(0); g0.deliver(g1)
+    assert int(g1.ingest_delivered()[0]) == 0                      # round 0: overwritten by round 2 -> no message, slice untouched
+    assert int(g1.ingest_delivered()[0]) == len(want) - 1          # round 1
+    assert int(g1.ingest_delivered()[0]) == len(want) - 1          # round 2 is still there
+    assert int(g1.ingest_delivered()[0]) == 0                      # round 3: never delivered
+    g0.close(); g1.close()

@@ -34,8 +34,9 @@ cd $R
 [ -f cg_mrslam_amd/libcgmr_t.so ] && CGMR_MATCH_SPLIT=1 CGMR_LIB=cg_mrslam_amd/libcgmr_t.so timeout 120 python tools/gpu_mphase.py $O/match_phases.json > $O/match_phases.log 2>&1
 python tools/make_profile_summary.py $RND --pmc-only > $O/pmc_only.log 2>&1
 cd /tmp
-# (one retry: the profiled run of the bench -- its C4 leg drives four contexts from four threads -- died with SIGSEGV inside the
-# HIP runtime's copy path twice in ~100 profiled runs at the end of round 5, never without the profiler)
+# (one retry: the profiled run of the bench -- its C4 leg drives four contexts from four threads -- dies with SIGSEGV inside
+# librocprofiler-sdk's queue interceptor in about one profiled process in twelve, never without the profiler:
+# profiles/r06_profiler_crash.md, tools/stress/team_stress.sh)
 for try in 1 2; do
   rm -rf $O/bench
   timeout 900 rocprofv3 --kernel-trace --stats -d $O/bench --output-format csv -- python $R/bench.py > $O/bench.log 2>&1
