@@ -154,7 +154,12 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
     for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++)
       if (S.fronts[LF[q]].nchild > 0) D.h_level_leaf[l] = 0;
     // a level of leaves has its own chunk length (kLeafChunkRows)
-    const int chunk_rows = (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
+    int chunk_rows = (D.h_level_leaf[l] ? std::min(kChunkRows, std::max(16, leaf_chunk)) : mid_chunk);
+    // the few fronts of an upper level (an idle chip): shorter chunks = more workgroups per front, each with less of the
+    // panel to pull in on its own (a lone workgroup fetches cold data at 10-25 bytes per clock) -- and few extra records
+    static const int top_chunk = getenv("CGMR_TOP_CHUNK") ? std::min(kChunkRows, std::max(16, atoi(getenv("CGMR_TOP_CHUNK")))) : kTopChunkRows;
+    static const int top_fronts = getenv("CGMR_TOP_CHUNK_FRONTS") ? atoi(getenv("CGMR_TOP_CHUNK_FRONTS")) : kTopChunkFronts;
+    if (!D.h_level_leaf[l] && S.gn_level_ptr[l + 1] - S.gn_level_ptr[l] <= top_fronts) chunk_rows = std::min(chunk_rows, top_chunk);
     D.h_level_chunk[l] = chunk_rows;
     int nwork = 0;
     for (int q = S.gn_level_ptr[l]; q < S.gn_level_ptr[l + 1]; q++) {

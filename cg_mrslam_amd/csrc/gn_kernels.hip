@@ -554,24 +554,29 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
     *dst += uval;
   }
   __syncthreads();
-  // each thread: rows {ty, ty+16}, cols {tx, tx+16}
-  const int tx = tid & 15, ty = tid >> 4;
-  const int gi[2] = {i0 + ty, i0 + ty + 16}, gj[2] = {j0 + tx, j0 + tx + 16};
+  // The product on the matrix cores (round 6; a scalar fma loop over k with four LDS reads per step before: 38 us of an
+  // iteration's 505, LDS-bound): wavefront (a, b) forms the 16 x 16 sub-tile (rows 16 a.., columns 16 b..) with twelve
+  // v_mfma_f64_16x16x4_f64, operands from the two staged slices.  Operand layout as in panel_cholesky.h:
+  //   A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], C[i = (lane >> 4) + 4 rg][j = lane & 15]
+  // so a lane holds the cells (rows li + 4 rg, rg = 0..3; column lj) of its sub-tile.
+  const int lane = tid & 63, wv = tid >> 6;
+  const int sa = 16 * (wv >> 1), sb = 16 * (wv & 1), lr = lane & 15, lk = lane >> 4;
+  const int ri[4] = {sa + lk, sa + lk + 4, sa + lk + 8, sa + lk + 12};   // my rows / my column inside the tile
+  const int cj = sb + lr;
+  const int gi[4] = {i0 + ri[0], i0 + ri[1], i0 + ri[2], i0 + ri[3]}, gj = j0 + cj;
   // ---- the children's values for my 4 cells and the panel cells they are added into (issued before the product, used after it)
   double v[MAXC][4];
   double oldv[4] = {0.0, 0.0, 0.0, 0.0};
   double* pdst[4] = {nullptr, nullptr, nullptr, nullptr};
   if (to_pan) {
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++) {
-        const bool ok = gi[a] < r && gj[b] <= gi[a] && gj[b] < my_ra;
-        if (ok) {
-          pdst[2 * a + b] = Pan + ppan + s_pp[ty + 16 * a] + s_pp[TS + tx + 16 * b];
-          oldv[2 * a + b] = *pdst[2 * a + b];
-        }
+    for (int q = 0; q < 4; q++) {
+      const bool ok = gi[q] < r && gj <= gi[q] && gj < my_ra;
+      if (ok) {
+        pdst[q] = Pan + ppan + s_pp[ri[q]] + s_pp[TS + cj];
+        oldv[q] = *pdst[q];
       }
+    }
   }
 #pragma unroll
   for (int c = 0; c < MAXC; c++)
@@ -583,25 +588,27 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
     const int cs = min(c, max(ncb - 1, 0));
     const int rg = 3 * WR->ch[cs].ns, rga = 3 * WR->ch[cs].na, nbb = rg - rga;
     const double* B = Ubuf + WR->ch[cs].U_off + (size_t)rg * even_up(rga);      // the child's trailing block (slab B)
-    const int ki[2] = {s_k[c][ty], s_k[c][ty + 16]}, kj[2] = {s_k[c][TS + tx], s_k[c][TS + tx + 16]};
+    const int kj = s_k[c][TS + cj];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int q = 0; q < 4; q++) {
+      const int ki = s_k[c][ri[q]];
+      const bool ok = c < ncb && ki >= 0 && kj >= 0 && gj <= gi[q];
+      const double val = B[ok ? (size_t)(ki - rga) * nbb + (kj - rga) : 0];
+      v[c][q] = ok ? val : 0.0;
+    }
+  }
+  }
+  double4_t prod = {0.0, 0.0, 0.0, 0.0};
+  {
+    const double* ap = Ai + (sa + lr) * LDW + lk;
+    const double* bp = Aj + (sb + lr) * LDW + lk;
+    double av[W / 4], bv[W / 4];
 #pragma unroll
-      for (int b = 0; b < 2; b++) {
-        const bool ok = c < ncb && ki[a] >= 0 && kj[b] >= 0 && gj[b] <= gi[a];
-        const double val = B[ok ? (size_t)(ki[a] - rga) * nbb + (kj[b] - rga) : 0];
-        v[c][2 * a + b] = ok ? val : 0.0;
-      }
+    for (int kk = 0; kk < W / 4; kk++) { av[kk] = ap[4 * kk]; bv[kk] = bp[4 * kk]; }
+#pragma unroll
+    for (int kk = 0; kk < W / 4; kk++) prod = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], prod, 0, 0, 0);
   }
-  }
-  double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-#pragma unroll 8
-  for (int k = 0; k < W; k++) {
-    double a0 = Ai[ty * LDW + k], a1 = Ai[(ty + 16) * LDW + k];
-    double b0 = Aj[tx * LDW + k], b1 = Aj[(tx + 16) * LDW + k];
-    c00 += a0 * b0; c01 += a0 * b1; c10 += a1 * b0; c11 += a1 * b1;
-  }
-  double acc[4] = {-c00, -c01, -c10, -c11};
+  double acc[4] = {-prod[0], -prod[1], -prod[2], -prod[3]};
 #pragma unroll
   for (int c = 0; c < MAXC; c++)
 #pragma unroll
@@ -618,24 +625,21 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
       s_k[0][tid] = (short)(kq < 0 ? -1 : 3 * kq + pq % 3);
     }
     __syncthreads();
-    const int ki[2] = {s_k[0][ty], s_k[0][ty + 16]}, kj[2] = {s_k[0][TS + tx], s_k[0][TS + tx + 16]};
+    const int kj = s_k[0][TS + cj];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++) {
-        bool ok = ki[a] >= 0 && kj[b] >= 0 && gj[b] <= gi[a];
-        acc[2 * a + b] += ok ? B[(size_t)(ki[a] - rga) * nbb + (kj[b] - rga)] : 0.0;
-      }
+    for (int q = 0; q < 4; q++) {
+      const int ki = s_k[0][ri[q]];
+      const bool ok = ki >= 0 && kj >= 0 && gj <= gi[q];
+      acc[q] += ok ? B[(size_t)(ki - rga) * nbb + (kj - rga)] : 0.0;
+    }
   }
   double* Uo = Ubuf + U_off;
 #pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-      if (!(gi[a] < r && gj[b] <= gi[a])) continue;
-      if (pdst[2 * a + b]) *pdst[2 * a + b] = oldv[2 * a + b] + acc[2 * a + b];
-      else Uo[uidx(gi[a], gj[b], r, my_ra)] = acc[2 * a + b];
-    }
+  for (int q = 0; q < 4; q++) {
+    if (!(gi[q] < r && gj <= gi[q])) continue;
+    if (pdst[q]) *pdst[q] = oldv[q] + acc[q];
+    else Uo[uidx(gi[q], gj, r, my_ra)] = acc[q];
+  }
 }
 
 // ------------------------------------------------------------------------------ top block

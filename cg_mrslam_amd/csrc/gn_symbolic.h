@@ -29,6 +29,8 @@ constexpr int kMidChunkRows = 79;    // border rows per work item above the leav
                                      // measured 191 / 127 / 95 / 63 / 47 rows -> 8.1 / 8.0 / 7.7 / 7.8 / 7.75 ms device on C2 (round 3); round 5, with the leaves at
                                      // 95: 111 / 95 / 87 / 79 / 71 / 63 / 47 rows -> 5.26 / 5.16 / 5.15 / 5.11 / 5.10 / 5.11 / 5.07 ms (47: +1 ms of host analysis)
 
+constexpr int kTopChunkRows = 31;    // ... on a level of at most kTopChunkFronts fronts (round 6: 79 / 63 / 47 / 31 rows -> 5.09 / 5.08 / 5.055 / 5.04 ms device on C2)
+constexpr int kTopChunkFronts = 8;
 constexpr int kLeafChunkRows = 95;   // the same for a level of leaves (two workgroups per CU; 63 rows, three per CU: +0.04 ms on C2; 127 / 159: +0.02 / +-0)
 
 // A child is "small" when kSmallSlabLoads 16-byte loads per thread (256 threads, one column pair of one row each) cover

@@ -3,7 +3,7 @@ import csv, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last optimize call: take the last iteration = launches after the last k_linearize that is followed by k_assemble
-names = [r["Kernel_Name"].split("(")[0].replace("cgmr::", "").replace("void ", "") for r in rows]
+names = [r["Kernel_Name"].split("(")[0].split("<")[0].replace("cgmr::", "").replace("void ", "") for r in rows]
 idx = [i for i, n in enumerate(names) if n == "k_assemble"]
 a = idx[-1]
 # back up to the linearize before it
