@@ -284,11 +284,14 @@ __device__ unsigned long long g_wphase[8 * 8192];          // per work item: cyc
 __device__ unsigned long long g_wtime[2 * 8192];          // per work item of k_front_factor: start / end (100 MHz)
 __device__ unsigned long long g_fphase[8 * 8192];         // per work item: cycle counter at the steps of the blocked factorisation
 __device__ unsigned long long g_utime[2 * 64];             // per level of k_front_update: min start / max end
+__device__ unsigned long long g_tphase[16];                // k_top_block, the block's own workgroup: cycle counter at its marks
+#define TPHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_tphase[i] = __builtin_readcyclecounter(); } while (0)
 #define PHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_wphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0 && level_id < 64) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
 #define FPHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_fphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PHASE(i)
 #define FPHASE(i)
+#define TPHASE(i)
 #endif
 
 constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record
@@ -651,10 +654,12 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
 // (ascending front id) with a barrier in between: bit-reproducible.
 //   P    [16 nbc + 1][LD]   rows / columns 0 .. ncols-1 the block, identity padding up to 16 nbc, last row the rhs
 // With store_l the factor is also written in the per-front panel layout (the marginals' forward solve reads it).
+constexpr int kTopPre = 32;                                   // children whose descriptors and row maps are fetched up front, all at once ...
+constexpr int kTopPreRows = 2048;                            // ... when their border rows together fit this many map entries (else one child at a time, 1024 rows each)
 constexpr int kTopLD = kTopMaxCols + 1;                      // row stride of the block in LDS (doubles), whatever its size
 constexpr int top_smem_bytes(int ncols) {
   const int n16 = (ncols + 15) / 16 * 16;
-  return ((n16 + 16) * kTopLD + n16) * 8 + 2 * 1024;         // rows padded to a multiple of 16 (panel_cholesky.h)
+  return ((n16 + 16) * kTopLD + n16) * 8 + kTopPreRows * 2 + kTopPre * 32;   // rows padded to a multiple of 16 (panel_cholesky.h); row maps + table of the children
 }
 static_assert(kTopMaxCols % 16 == 0 && top_smem_bytes(kTopMaxCols) <= 160 * 1024, "top block exceeds the LDS");
 
@@ -702,10 +707,38 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
   const int n16 = (ncols + 15) / 16 * 16, M = n16 + 1, nbc = n16 / 16;
   double* P = reinterpret_cast<double*>(smem);
   double* Dinv = P + (size_t)(n16 + 16) * LD;
-  short* cmap = reinterpret_cast<short*>(Dinv + n16);        // row of the block a child's border row lands in (<= 1024 rows)
+  short* cmap = reinterpret_cast<short*>(Dinv + n16);        // row of the block a child's border row lands in
+  long long* ctab = reinterpret_cast<long long*>(cmap + kTopPreRows);   // per child: U_off, (3 ns | 3 na << 32), rows_off, first map entry
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Round 6: the children's descriptors (two dependent loads each) and row maps (a third) used to be fetched child by child in
+  // front of every child's stream -- three round trips per child on the one workgroup an otherwise idle chip waits for.  Now
+  // all of them are fetched together while the block is cleared and the H blocks arrive (the streams stay one child at a time,
+  // in the fixed order, with a barrier in between: same sums).
+  TPHASE(0);
+  const bool pre_tab = nchild <= kTopPre;
+  if (pre_tab && tid < nchild) {
+    const FrontDesc G = fronts[top_children[tid]];
+    ctab[4 * tid] = G.U_off;
+    ctab[4 * tid + 1] = (long long)(3 * G.ns) | ((long long)(3 * G.na) << 32);
+    ctab[4 * tid + 2] = G.rows_off;
+  }
   for (int q = tid; q < M * LD; q += kTopT) P[q] = 0.0;
   __syncthreads();
+  bool pre = pre_tab;
+  if (pre_tab) {
+    int tot = 0;
+    for (int ci = 0; ci < nchild; ci++) tot += (int)(ctab[4 * ci + 1] & 0xffffffffll);
+    pre = tot <= kTopPreRows;
+    if (pre) {
+      int off = 0;
+      for (int ci = 0; ci < nchild; ci++) {
+        const int r = (int)(ctab[4 * ci + 1] & 0xffffffffll), ro = (int)ctab[4 * ci + 2];
+        for (int k = tid; k < r; k += kTopT) cmap[off + k] = (short)(3 * (rows[ro + k / 3] - c0) + k % 3);
+        if (tid == 0) ctab[4 * ci + 3] = off;
+        off += r;
+      }
+    }
+  }
   // ---- right-hand side, identity padding, H blocks
   for (int j = tid; j < ncols; j += kTopT) P[(size_t)n16 * LD + j] = bvec[3 * (size_t)c0 + j];
   for (int j = ncols + tid; j < n16; j += kTopT) P[(size_t)j * LD + j] = 1.0;
@@ -715,13 +748,27 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
     P[(size_t)(3 * rb + el / 3) * LD + 3 * cb + el % 3] = Ablk[9 * (size_t)slot + el];
   }
   __syncthreads();
+  TPHASE(1);
   // ---- the children below the block: the whole update matrix (lower triangle) and the border vector of each
   for (int ci = 0; ci < nchild; ci++) {
-    const FrontDesc G = fronts[top_children[ci]];
-    const int r = 3 * G.ns, ra = 3 * G.na;
-    for (int k = tid; k < r; k += kTopT) cmap[k] = (short)(3 * (rows[G.rows_off + k / 3] - c0) + k % 3);
-    __syncthreads();
-    const double* U = Ubuf + G.U_off;
+    int r, ra, rows_off;
+    long long u_off;
+    const short* cm = cmap;
+    if (pre) {
+      u_off = ctab[4 * ci]; r = (int)(ctab[4 * ci + 1] & 0xffffffffll); ra = (int)(ctab[4 * ci + 1] >> 32);
+      rows_off = (int)ctab[4 * ci + 2];
+      cm = cmap + (int)ctab[4 * ci + 3];
+    } else {
+      const FrontDesc G = fronts[top_children[ci]];
+      r = 3 * G.ns; ra = 3 * G.na; rows_off = G.rows_off; u_off = G.U_off;
+      for (int k = tid; k < r; k += kTopT) cmap[k] = (short)(3 * (rows[rows_off + k / 3] - c0) + k % 3);
+      __syncthreads();
+    }
+    const double* U = Ubuf + u_off;
+    // (the child's border vector: fetched now, next to the stream, added behind it -- a round trip of its own before)
+    double uval[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) uval[u] = (tid + kTopT * u < r) ? uvec[3 * (size_t)rows_off + tid + kTopT * u] : 0.0;
     // the lower triangle only, rows i and r - 1 - i folded into one line of r + 1 elements (half the loads of the r x r square
     // the loop used to walk); 512 threads x 8 loads in flight: the child streams in at four times the round-2 rate (a lone
     // workgroup is limited by what it has in flight: 256 threads x 8 x 8 bytes per ~2000-cycle round trip = 8 bytes per clock)
@@ -742,32 +789,66 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
         const int i = low ? a : r - 1 - a, j = low ? b : b - a - 1;
         const bool ok = q < nline * r1 && (low || r - 1 - a != a);   // (odd r: the middle row pairs with itself)
         val[u] = U[ok ? uidx(i, j, r, ra) : 0];
-        dst[u] = ok ? cmap[i] * LD + cmap[j] : -1;
+        dst[u] = ok ? cm[i] * LD + cm[j] : -1;
       }
 #pragma unroll
       for (int u = 0; u < TU; u++) if (dst[u] >= 0) lds_add(P + dst[u], val[u]);
     }
-    for (int k = tid; k < r; k += kTopT) lds_add(P + (size_t)n16 * LD + cmap[k], uvec[3 * (size_t)G.rows_off + k]);
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (tid + kTopT * u < r) lds_add(P + (size_t)n16 * LD + cm[tid + kTopT * u], uval[u]);
+    for (int k = tid + 4 * kTopT; k < r; k += kTopT) lds_add(P + (size_t)n16 * LD + cm[k], uvec[3 * (size_t)rows_off + k]);
     __syncthreads();
   }
   // ---- factorisation (the rhs row becomes y = L^-1 b)
+  TPHASE(2);
   auto roff = [](int r) -> int { return r * LD; };
   const int fail = panel_cholesky<kTopT / 64>(P, roff, M, nbc, Dinv, lane, wave);
   if (wave == 0 && lane == 0 && fail) atomicCAS(status, 0, status[1] + 1);
   __syncthreads();
+  TPHASE(3);
   // ---- backward solve L^T x = y of the block's columns (nothing above them): wavefront 0, lane = columns lane, lane + 64
+  // (round 6: rows of L in blocks of 16, fetched into registers ahead of the 16 dependent steps that use them, the reciprocals
+  // spread over the lanes -- one LDS round trip per STEP before: 28k of the block's 92k cycles for 90 columns)
   if (wave == 0) {
-    double v[2], xv[2] = {0.0, 0.0};
+    double v[2], xv[2] = {0.0, 0.0}, dv[2];
 #pragma unroll
-    for (int c = 0; c < 2; c++) v[c] = (lane + 64 * c < ncols) ? P[(size_t)n16 * LD + lane + 64 * c] : 0.0;
-    for (int i = ncols - 1; i >= 0; i--) {
-      const double xi = readlane_f64(i < 64 ? v[0] : v[1], i & 63) * Dinv[i];
-      const double* Li = P + (size_t)i * LD;                  // row i of L: entries left of the diagonal
+    for (int c = 0; c < 2; c++) {
+      v[c] = (lane + 64 * c < ncols) ? P[(size_t)n16 * LD + lane + 64 * c] : 0.0;
+      dv[c] = (lane + 64 * c < n16) ? Dinv[lane + 64 * c] : 1.0;
+    }
+    // rows 64 .. : the pivot sits in the lanes' second column, every first column lies left of it
+    for (int ib = n16 - 16; ib >= 64; ib -= 16) {
+      double l0[16], l1[16];
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const int col = lane + 64 * c;
-        if (col == i) xv[c] = xi;
-        if (col < i) v[c] = fma(-Li[col], xi, v[c]);
+      for (int q = 0; q < 16; q++) {
+        const double* Li = P + (size_t)(ib + q) * LD;         // row ib + q of L: entries left of the diagonal
+        l0[q] = Li[lane];
+        l1[q] = Li[lane + 64];
+      }
+#pragma unroll
+      for (int q = 15; q >= 0; q--) {
+        const int i = ib + q;                                 // (wave-uniform)
+        if (i < ncols) {
+          const double xi = readlane_f64(v[1], i - 64) * readlane_f64(dv[1], i - 64);
+          if (lane + 64 == i) xv[1] = xi;
+          v[0] = fma(-l0[q], xi, v[0]);
+          if (lane + 64 < i) v[1] = fma(-l1[q], xi, v[1]);
+        }
+      }
+    }
+    // rows .. 63: first columns only
+    for (int ib = min(n16, 64) - 16; ib >= 0; ib -= 16) {
+      double l0[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) l0[q] = P[(size_t)(ib + q) * LD + lane];
+#pragma unroll
+      for (int q = 15; q >= 0; q--) {
+        const int i = ib + q;
+        if (i < ncols) {
+          const double xi = readlane_f64(v[0], i) * readlane_f64(dv[0], i);
+          if (lane == i) xv[0] = xi;
+          if (lane < i) v[0] = fma(-l0[q], xi, v[0]);
+        }
       }
     }
 #pragma unroll
@@ -776,6 +857,7 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
       if (col < ncols) { xvec[3 * (size_t)c0 + col] = xv[c]; yvec[3 * (size_t)c0 + col] = P[(size_t)n16 * LD + col]; }
     }
   }
+  TPHASE(4);
   if (!store_l) return;
   // ---- the factor in the per-front panel layout (W = 48): L11 row-major, L11 column-major, 1 / diag, L21
   constexpr int W = kFrontW, kL11c = W * W, kDinv = 2 * W * W, kL21 = 2 * W * W + W;
@@ -1124,6 +1206,9 @@ void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
 }  // namespace cgmr
 
 #ifdef CGMR_PHASE_TIMING
+extern "C" int cgmr_debug_topphase(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_tphase), sizeof(unsigned long long) * 16);
+}
 extern "C" int cgmr_debug_workphases(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_wphase), sizeof(unsigned long long) * 8 * 8192);
 }
