@@ -889,7 +889,7 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
 // in LDS and reads one row per step).
 constexpr int XB_CAP = 1536;         // border rows staged per pass
 constexpr int kBwdNL = 24;           // L21 rows per thread and pass
-constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP) * 8; }
+constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP + (lds_l11 ? w : 0)) * 8; }
 // CHAIN: the upper levels of the tree -- a handful of fronts each, one launch each in round 2 (16 x 6.5 us of dependent
 // round trips and launch boundaries) -- run as ONE launch: workgroup b takes front (first - b) of the level order, i.e.
 // parents before children, and waits for its parent's columns of x (they, and by induction every ancestor's, are final
@@ -899,6 +899,78 @@ constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0
 // the others with agent-scope loads (sc1: past the L1, which another CU's stores never refresh), re-reading any that is
 // not there yet.  (A separate flag behind an s_waitcnt vmcnt(0) drain costs 0.3 us more per hop.)  The launch is at most 2 workgroups per CU (the host
 // picks the levels), so every workgroup is resident whatever the dispatch order; the spin is bounded all the same.
+// L11^-1 of a front, in place in LDS (chained backward solve, 48 columns): Z = L^-1 is lower triangular like L, and
+// x_own = L11^-T v = Z^T v is then 48 independent dot products instead of 48 dependent substitution steps.  A workgroup
+// of the chained launch computes Z while it waits for its parent's x -- in the shadow of the hops above it -- so the
+// hop itself (parent's x visible -> own x visible) loses the serial solve.
+//   L = [A 0 0; B C 0; D E F] (16 x 16 blocks)   Z = [A' 0 0; -C' B A'  C' 0; -F' (D A' + E Z21)  -F' E C'  F'],  X' = X^-1
+// Step 0: the three diagonal blocks, lane = (block, column) of wavefront 0, the column of the inverse in registers
+// (row by row, the scheduler held back: the kernel lives on 128 VGPRs with its rows of L21 in flight);
+// steps 1-4: 16 x 16 x 16 products, one per wavefront, four v_mfma_f64_16x16x4_f64 each (operand layout as in
+// panel_cholesky.h: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], C[i = (lane >> 4) + 4 rg][j = lane & 15]).
+// sd (3 x 256 doubles: the diagonal blocks' inverses), sp (3 x 256: P1, P2, Z32): scratch.
+// Rows / columns beyond the front's width are identity in L (k_front_factor's padding): identity in Z.
+__device__ __forceinline__ double4_t mm16(const double* X, int ldx, const double* Y, int ldy, double4_t acc, int lane) {
+  const double* xp = X + (lane & 15) * ldx + (lane >> 4);
+  const double* yp = Y + (lane >> 4) * ldy + (lane & 15);
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[4 * kk], yp[4 * kk * ldy], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ void st16(double* C, int ldc, double4_t v, double sign, int lane) {
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) C[((lane >> 4) + 4 * rg) * ldc + (lane & 15)] = sign * v[rg];
+}
+__device__ __forceinline__ void invert_l11_48(double* Lt, const double* dinv, double* sd, double* sp, int tid) {
+  constexpr int W = 48;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tid < 48) {
+    const int blk = tid >> 4, c = tid & 15;
+    const double* D = Lt + (16 * blk) * W + 16 * blk;
+    const double* di = dinv + 16 * blk;
+    double z[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < i; k++) s = fma(D[i * W + k], z[k], s);
+      z[i] = (i == c ? 1.0 : -s) * di[i];              // rows above the column's diagonal element: s = 0, z = -0
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) sd[256 * blk + 16 * i + c] = z[i];
+  }
+  __syncthreads();
+  const double4_t zero = {0.0, 0.0, 0.0, 0.0};
+  const double* A1 = sd, *C1 = sd + 256, *F1 = sd + 512;
+  double* B = Lt + 16 * W, *Dm = Lt + 32 * W, *E = Lt + 32 * W + 16;
+  double4_t p3 = zero;
+  // step 1: P1 = B A' (wavefront 0), P2 = E C' (1), P3 = D A' (2: stays in its registers)
+  if (wave == 0) st16(sp, 16, mm16(B, W, A1, 16, zero, lane), 1.0, lane);
+  else if (wave == 1) st16(sp + 256, 16, mm16(E, W, C1, 16, zero, lane), 1.0, lane);
+  else if (wave == 2) p3 = mm16(Dm, W, A1, 16, zero, lane);
+  __syncthreads();
+  // step 2: Z21 = -C' P1 (into B's place), Z32 = -F' P2 (scratch: E is read once more)
+  if (wave == 0) st16(B, W, mm16(C1, 16, sp, 16, zero, lane), -1.0, lane);
+  else if (wave == 1) st16(sp + 512, 16, mm16(F1, 16, sp + 256, 16, zero, lane), -1.0, lane);
+  __syncthreads();
+  // step 3: P4 = P3 + E Z21 (wavefront 2, on top of its P3); the others put Z32 and the diagonal blocks in their places
+  if (wave == 2) st16(sp, 16, mm16(E, W, B, W, p3, lane), 1.0, lane);
+  __syncthreads();
+  // step 4: Z31 = -F' P4
+  if (wave == 2) st16(Dm, W, mm16(F1, 16, sp, 16, zero, lane), -1.0, lane);
+  else {
+    const int t = wave == 3 ? tid - 64 : tid;           // 192 threads: 256 elements of each of the four blocks
+    for (int q = t; q < 256; q += 192) {
+      const int i = q >> 4, j = q & 15;
+      E[i * W + j] = sp[512 + q];
+      Lt[i * W + j] = A1[q];
+      Lt[(16 + i) * W + 16 + j] = C1[q];
+      Lt[(32 + i) * W + 32 + j] = F1[q];
+    }
+  }
+  __syncthreads();
+}
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define CGMR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -916,12 +988,15 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
   constexpr int NL = CHAIN ? kBwdNL / 2 : kBwdNL;
   constexpr int CPL = (W + 63) / 64;   // columns per lane in the triangular solve
   constexpr bool LDS_L11 = W > 64 || CHAIN;
-  constexpr int XQ = XB_CAP / 256;
+  constexpr bool TINV = CHAIN && W == 48;   // the chained launch inverts L11 while it waits (invert_l11_48)
+  constexpr int XCAP = TINV ? 512 : XB_CAP;  // border rows per pass (the chained instance: fewer, its registers hold the rows of L21)
+  constexpr int XQ = XCAP / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   double* Lt = reinterpret_cast<double*>(smem_b);            // [W][W] L11 row-major (96-column instance only)
   double* dinv = Lt + (LDS_L11 ? W * W : 0);                 // [W]
   double* part = dinv + W;                                   // [G][W]
   double* xb = part + G * W;                                 // [XB_CAP]
+  [[maybe_unused]] double* ys = xb + XB_CAP;                 // [W] the front's own part of y (chained instance: parked here while L11 is inverted)
   const int tid = threadIdx.x;
   // descriptors in level order: no index hop (CHAIN: level_begin = the last front of the level order, walked downwards)
   const FrontDesc F = fronts_lv[CHAIN ? level_begin - (int)blockIdx.x : level_begin + (int)blockIdx.x];
@@ -943,12 +1018,14 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
     }
   }
   const double dvl = (tid < W) ? P[kDinv + tid] : 1.0;
+  // (the front's own part of y: fetched here, not behind the wait)
+  const double yown = (TINV && tid < w) ? yvec[3 * F.c0 + tid] : 0.0;
   // ---- border: acc[0..1] = sum over my rows of L21[p][2cp .. 2cp+1] x_border[p]
   const int cp = tid % HP, g = tid / HP;
   const bool active = tid < G * HP;
   double acc0 = 0, acc1 = 0;
-  for (int p0 = 0; p0 < r; p0 += XB_CAP) {
-    const int np = min(XB_CAP, r - p0);
+  for (int p0 = 0; p0 < r; p0 += XCAP) {
+    const int np = min(XCAP, r - p0);
     int xi[XQ];
 #pragma unroll
     for (int u = 0; u < XQ; u++) {
@@ -961,42 +1038,52 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
       const int p = g + G * u;
       l[u] = (active && p < np) ? *reinterpret_cast<const double2*>(L21 + (size_t)(p0 + p) * W + 2 * cp) : make_double2(0.0, 0.0);
     }
-    if constexpr (CHAIN) {
-      // wait for the parent (a front below the top block always has one; its parent in the top block: nothing to wait for):
-      // the data is the flag -- k_assemble filled xvec with kXSentinel, the parent's 48 columns go out in one store
-      // instruction, so one lane polls the parent's first column and the values read afterwards are checked again below
-      if (p0 == 0 && F.ppan_off >= 0) {
-        if (tid == 0) {
-          gu64* flag = (gu64*)(xvec + 3 * (size_t)F.p_c0);
-          unsigned spins = 0;
-          while (__hip_atomic_load(flag, CGMR_RLX_AGENT) == kXSentinel) {
-            __builtin_amdgcn_s_sleep(1);
-            // never hang the device: a wait that runs out marks the pass (status[2]: a time-out, not a Cholesky failure --
-            // the host repeats the iteration with one launch per level); once one wait has run out the others stop early
-            if (++spins > spin_limit || ((spins & 1023u) == 0 && __hip_atomic_load(status + 2, CGMR_RLX_AGENT) != 0)) {
-              atomicCAS(status, 0, status[1] + 1);
-              __hip_atomic_store(status + 2, 1, CGMR_RLX_AGENT);
-              break;
-            }
-          }
-        }
+    if constexpr (TINV) {
+      // everything that does not depend on x is on its way: L11 goes to LDS and is inverted there while the parent works
+      if (p0 == 0) {
+#pragma unroll
+        for (int u = 0; u < LT_Q; u++) Lt[tid + 256 * u] = lt[u];
+        if (tid < W) { dinv[tid] = dvl; ys[tid] = yown; }
         __syncthreads();
+        invert_l11_48(Lt, dinv, xb, xb + 768, tid);
       }
     }
     double xr[XQ];
+    if constexpr (CHAIN) {
+      // Wait for x of the border rows (a front below the top block always has a parent; its parent in the top block: nothing to
+      // wait for).  The data is the flag -- k_assemble filled xvec with kXSentinel -- and the wait IS the gather (round 6; one lane
+      // polled the parent's first column before, then a barrier, then everybody fetched its entries: two dependent trips to
+      // the L2 per hop): every thread fetches its entries, a wavefront goes round again for the ones that are not there yet.
+      // The parent's columns are the first rows of the border, i.e. the first wavefront's; the other ancestors' have long
+      // arrived, so it is one wavefront per workgroup that polls, a few cache lines per round.
+      // Never hang the device: a wait that runs out marks the pass (status[2]: a time-out, not a Cholesky failure -- the host
+      // repeats the iteration with one launch per level); once one wait has run out the others stop early.
+      unsigned long long bits[XQ];
+      bool need[XQ];
 #pragma unroll
-    for (int u = 0; u < XQ; u++) {
-      const int p = tid + 256 * u;
-      if constexpr (CHAIN) {
-        unsigned long long bits = 0ull;
-        if (p < np) {
-          gu64* src = (gu64*)(xvec + 3 * xi[u] + (p0 + p) % 3);
-          unsigned spins = 0;
-          while ((bits = __hip_atomic_load(src, CGMR_RLX_AGENT)) == kXSentinel && F.ppan_off >= 0 && ++spins < spin_limit &&
-                 ((spins & 1023u) != 0 || __hip_atomic_load(status + 2, CGMR_RLX_AGENT) == 0)) __builtin_amdgcn_s_sleep(1);
+      for (int u = 0; u < XQ; u++) { bits[u] = 0ull; need[u] = tid + 256 * u < np; }
+      unsigned spins = 0;
+      for (;;) {
+        bool miss = false;
+#pragma unroll
+        for (int u = 0; u < XQ; u++)
+          if (need[u]) {
+            bits[u] = __hip_atomic_load((gu64*)(xvec + 3 * xi[u] + (p0 + tid + 256 * u) % 3), CGMR_RLX_AGENT);
+            if (bits[u] == kXSentinel && F.ppan_off >= 0) miss = true; else need[u] = false;
+          }
+        if (!__any(miss)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > spin_limit || ((spins & 1023u) == 0 && __hip_atomic_load(status + 2, CGMR_RLX_AGENT) != 0)) {
+          if ((tid & 63) == 0) { atomicCAS(status, 0, status[1] + 1); __hip_atomic_store(status + 2, 1, CGMR_RLX_AGENT); }
+          break;
         }
-        xr[u] = __longlong_as_double((long long)bits);
-      } else {
+      }
+#pragma unroll
+      for (int u = 0; u < XQ; u++) xr[u] = __longlong_as_double((long long)bits[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < XQ; u++) {
+        const int p = tid + 256 * u;
         xr[u] = (p < np) ? xvec[3 * xi[u] + (p0 + p) % 3] : 0.0;
       }
     }
@@ -1025,13 +1112,46 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
       }
     }
   }
-  if constexpr (LDS_L11) {
+  if constexpr (LDS_L11 && !TINV) {
 #pragma unroll
     for (int u = 0; u < LT_Q; u++) Lt[tid + 256 * u] = lt[u];
   }
-  if (tid < W) dinv[tid] = dvl;
+  if (!TINV && tid < W) dinv[tid] = dvl;
+  if constexpr (TINV) {
+    if (r == 0) {
+#pragma unroll
+      for (int u = 0; u < LT_Q; u++) Lt[tid + 256 * u] = lt[u];
+      if (tid < W) { dinv[tid] = dvl; ys[tid] = yown; }
+      __syncthreads();
+      invert_l11_48(Lt, dinv, xb, xb + 768, tid);
+    }
+  }   // (no border: the loop above did not run)
   if (active) { part[g * W + 2 * cp] = acc0; part[g * W + 2 * cp + 1] = acc1; }
   __syncthreads();
+  if constexpr (TINV) {
+    // x_own = Z^T v, v = y - L21^T x_border: lane c of wavefront 0 adds Z[i][c] v[i] over the rows i (zeros above the diagonal of Z)
+    if (tid < 64) {
+      const int lane = tid, cj = min(lane, W - 1);
+      double v = ys[cj];
+#pragma unroll
+      for (int gg = 0; gg < G; gg++) v -= part[gg * W + cj];
+      double* vs = dinv;                                       // (the reciprocals are not needed any more)
+      if (lane < W) vs[lane] = v;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int i = 0; i < W; i += 4) {
+        s0 = fma(Lt[i * W + cj], vs[i], s0);
+        s1 = fma(Lt[(i + 1) * W + cj], vs[i + 1], s1);
+        s2 = fma(Lt[(i + 2) * W + cj], vs[i + 2], s2);
+        s3 = fma(Lt[(i + 3) * W + cj], vs[i + 3], s3);
+      }
+      const double xo = (s0 + s1) + (s2 + s3);
+      if (lane < w) __hip_atomic_store((gu64*)(xvec + 3 * F.c0 + lane), (unsigned long long)__double_as_longlong(xo), CGMR_RLX_AGENT);
+    }
+    return;
+  }
   if (tid < 64) {
     const int lane = tid;
     double v[CPL], xv[CPL];
