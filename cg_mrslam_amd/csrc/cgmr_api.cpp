@@ -578,9 +578,13 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
   }
   // the top of the tree in one launch: assembly, factorisation, forward and backward solve of the block's columns
   static const bool clear_in_top = !(getenv("CGMR_CLEAR_IN_TOP") && atoi(getenv("CGMR_CLEAR_IN_TOP")) == 0);
+  // (the chained backward solve works with L11^-1 of every front: made by the idle workgroups of the top-block launch)
+  const bool chain = solve_and_update && D.bwd_chain_level < D.nlevels;
   if (D.top_nfronts > 0) {
-    T.run(5, 1, [&] { launch_top_block(st, D, /*store_l=*/write_l11c, write_l11c, clear_in_top); });
+    T.run(5, 1, [&] { launch_top_block(st, D, /*store_l=*/write_l11c, write_l11c, clear_in_top, chain); });
     D.pan_clean = clear_in_top && D.pan_doubles > 0;
+  } else if (chain) {
+    T.run(5, 1, [&] { launch_invert_fronts(st, D); });
   }
   if (!solve_and_update) return;
   // (the forward solve L y = b rides through k_front_factor as an extra row of every front)

@@ -63,7 +63,8 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_chain(hipStream_t st, const GnDevice& D);
 int bwd_chain_capacity();
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);
-void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels);
+void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels, bool make_z);
+void launch_invert_fronts(hipStream_t st, const GnDevice& D);
 // marginals_kernels.hip
 // A batch of marginals / labelling passes, one per job of a batched GnDevice (D.njobs): job j's query list, Y, U, Gram and
 // covariance buffers are the first job's moved by j * marg_stride bytes; its query count, gauge and output slot come from

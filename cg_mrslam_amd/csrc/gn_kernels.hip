@@ -285,6 +285,8 @@ __device__ unsigned long long g_wtime[2 * 8192];          // per work item of k_
 __device__ unsigned long long g_fphase[8 * 8192];         // per work item: cycle counter at the steps of the blocked factorisation
 __device__ unsigned long long g_utime[2 * 64];             // per level of k_front_update: min start / max end
 __device__ unsigned long long g_tphase[16];                // k_top_block, the block's own workgroup: cycle counter at its marks
+__device__ unsigned long long g_btime[4 * 8192];           // k_solve_bwd (chained), per front: 100 MHz clock at start / L11 inverted / x of the border there / own x stored
+#define BTIME(i) do { if (CHAIN && threadIdx.x == 0 && F.front_id < 8192) g_btime[4 * F.front_id + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define TPHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_tphase[i] = __builtin_readcyclecounter(); } while (0)
 #define PHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_wphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0 && level_id < 64) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
 #define FPHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_fphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -292,6 +294,7 @@ __device__ unsigned long long g_tphase[16];                // k_top_block, the b
 #define PHASE(i)
 #define FPHASE(i)
 #define TPHASE(i)
+#define BTIME(i)
 #endif
 
 constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record
@@ -645,6 +648,100 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   }
 }
 
+// L11^-1 of a front, in place in LDS (for the chained backward solve, 48 columns): Z = L^-1 is lower triangular like L, and
+// x_own = L11^-T v = Z^T v is then 48 independent dot products instead of 48 dependent substitution steps on the path
+// from a parent's x to its child's.  Computed for every front below the top block by the idle workgroups of the
+// top-block launch (one workgroup on an idle chip), stored behind the front's L21 (Lbuf: kL21 + r W).  Threads 0..255 work,
+// every thread of the workgroup must come along (barriers).
+//   L = [A 0 0; B C 0; D E F] (16 x 16 blocks)   Z = [A' 0 0; -C' B A'  C' 0; -F' (D A' + E Z21)  -F' E C'  F'],  X' = X^-1
+// Step 0: the three diagonal blocks, lane = (block, column) of wavefront 0, the column of the inverse in registers
+// (row by row, the scheduler held back: the kernel lives on 128 VGPRs with its rows of L21 in flight);
+// steps 1-4: 16 x 16 x 16 products, one per wavefront, four v_mfma_f64_16x16x4_f64 each (operand layout as in
+// panel_cholesky.h: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], C[i = (lane >> 4) + 4 rg][j = lane & 15]).
+// sd (3 x 256 doubles: the diagonal blocks' inverses), sp (3 x 256: P1, P2, Z32): scratch.
+// Rows / columns beyond the front's width are identity in L (k_front_factor's padding): identity in Z.
+__device__ __forceinline__ double4_t mm16(const double* X, int ldx, const double* Y, int ldy, double4_t acc, int lane) {
+  const double* xp = X + (lane & 15) * ldx + (lane >> 4);
+  const double* yp = Y + (lane >> 4) * ldy + (lane & 15);
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[4 * kk], yp[4 * kk * ldy], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ void st16(double* C, int ldc, double4_t v, double sign, int lane) {
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) C[((lane >> 4) + 4 * rg) * ldc + (lane & 15)] = sign * v[rg];
+}
+__device__ __forceinline__ void invert_l11_48(double* Lt, const double* dinv, double* sd, double* sp, int tid) {
+  constexpr int W = 48;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tid < 48) {
+    const int blk = tid >> 4, c = tid & 15;
+    const double* D = Lt + (16 * blk) * W + 16 * blk;
+    const double* di = dinv + 16 * blk;
+    double z[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < i; k++) s = fma(D[i * W + k], z[k], s);
+      z[i] = (i == c ? 1.0 : -s) * di[i];              // rows above the column's diagonal element: s = 0, z = -0
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) sd[256 * blk + 16 * i + c] = z[i];
+  }
+  __syncthreads();
+  const double4_t zero = {0.0, 0.0, 0.0, 0.0};
+  const double* A1 = sd, *C1 = sd + 256, *F1 = sd + 512;
+  double* B = Lt + 16 * W, *Dm = Lt + 32 * W, *E = Lt + 32 * W + 16;
+  double4_t p3 = zero;
+  // step 1: P1 = B A' (wavefront 0), P2 = E C' (1), P3 = D A' (2: stays in its registers)
+  if (wave == 0) st16(sp, 16, mm16(B, W, A1, 16, zero, lane), 1.0, lane);
+  else if (wave == 1) st16(sp + 256, 16, mm16(E, W, C1, 16, zero, lane), 1.0, lane);
+  else if (wave == 2) p3 = mm16(Dm, W, A1, 16, zero, lane);
+  __syncthreads();
+  // step 2: Z21 = -C' P1 (into B's place), Z32 = -F' P2 (scratch: E is read once more)
+  if (wave == 0) st16(B, W, mm16(C1, 16, sp, 16, zero, lane), -1.0, lane);
+  else if (wave == 1) st16(sp + 512, 16, mm16(F1, 16, sp + 256, 16, zero, lane), -1.0, lane);
+  __syncthreads();
+  // step 3: P4 = P3 + E Z21 (wavefront 2, on top of its P3); the others put Z32 and the diagonal blocks in their places
+  if (wave == 2) st16(sp, 16, mm16(E, W, B, W, p3, lane), 1.0, lane);
+  __syncthreads();
+  // step 4: Z31 = -F' P4
+  if (wave == 2) st16(Dm, W, mm16(F1, 16, sp, 16, zero, lane), -1.0, lane);
+  else if (wave < 4) {
+    const int t = wave == 3 ? tid - 64 : tid;           // 192 threads: 256 elements of each of the four blocks
+    for (int q = t; q < 256; q += 192) {
+      const int i = q >> 4, j = q & 15;
+      E[i * W + j] = sp[512 + q];
+      Lt[i * W + j] = A1[q];
+      Lt[(16 + i) * W + 16 + j] = C1[q];
+      Lt[(32 + i) * W + 32 + j] = F1[q];
+    }
+  }
+  __syncthreads();
+}
+// Z = L11^-1 of the fronts f0, f0 + df, .. (every front with a panel, i.e. below the top block): L11 and 1 / diag from Lbuf
+// into LDS, inverted there, stored behind the front's L21.  smem: 48 x 48 + 48 + 2 x 768 doubles.
+template <int NT>
+__device__ __forceinline__ void invert_fronts(const FrontDesc* __restrict__ fronts, int nfronts_all, int f0, int df, double* __restrict__ Lbuf, double* sm, int tid) {
+  constexpr int W = 48, kDinv = 2 * W * W, kL21 = 2 * W * W + W;
+  double* Lt = sm, *dinv = sm + W * W, *sd = dinv + W, *sp = sd + 768;
+  for (int f = f0; f < nfronts_all; f += df) {
+    if (fronts[f].pan_off < 0) continue;                        // (a front of the top block)
+    double* Pn = Lbuf + fronts[f].L_off;
+    const int r = 3 * fronts[f].ns;
+    for (int q = tid; q < W * W; q += NT) Lt[q] = Pn[q];
+    if (tid < W) dinv[tid] = Pn[kDinv + tid];
+    __syncthreads();
+    invert_l11_48(Lt, dinv, sd, sp, tid);
+    double* Z = Pn + kL21 + (size_t)r * W;
+    for (int q = tid; q < W * W; q += NT) Z[q] = Lt[q];
+    __syncthreads();
+  }
+}
+constexpr int kInvertSmemBytes = (48 * 48 + 48 + 2 * 768) * 8;
+
 // ------------------------------------------------------------------------------ top block
 // The last fronts of the root's chain (gn_symbolic.h: top_fronts; together at most kTopMaxCols columns, no border
 // beyond them) as ONE dense matrix in the LDS of one workgroup: assembly from the H blocks and from the update matrices
@@ -674,7 +771,7 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
                                                     double* __restrict__ Lbuf, double* __restrict__ yvec,
                                                     double* __restrict__ xvec, int* __restrict__ status, int store_l,
                                                     int write_l11c, double* __restrict__ zero_ptr, long long zero_n, int nfronts_all,
-                                                    long long js) {
+                                                    int make_z, long long js) {
   CGMR_JOB(Ablk, js); CGMR_JOB(bvec, js); CGMR_JOB(Ubuf, js); CGMR_JOB(uvec, js); CGMR_JOB(Lbuf, js); CGMR_JOB(yvec, js);
   CGMR_JOB(xvec, js); CGMR_JOB(status, js); CGMR_JOB(zero_ptr, js);
   if (blockIdx.x > 0) {
@@ -683,7 +780,12 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
     // Only the cells anybody writes or reads (k_front_factor's loads name them): per front and copy the w own columns and the
     // border-vector column of the w own rows, of the border rows and of the rhs row -- on C2 27 of the 48.6 MB the padded
     // layout holds.
-    (void)zero_n;
+    // ... and, first, they invert L11 of every front for the chained backward solve that follows (invert_l11_48).
+    if constexpr (kFrontW == 48) {
+      extern __shared__ __attribute__((aligned(16))) unsigned char smem_z[];
+      if (make_z) invert_fronts<kTopT>(fronts, nfronts_all, blockIdx.x - 1, gridDim.x - 1, Lbuf, reinterpret_cast<double*>(smem_z), threadIdx.x);
+    }
+    if (zero_n <= 0) return;
     constexpr int H2 = kPanStride / 2;
     for (int f = blockIdx.x - 1; f < nfronts_all; f += gridDim.x - 1) {
       const long long pan_off = fronts[f].pan_off;
@@ -880,6 +982,14 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
   }
 }
 
+// Z for a tree without a top block (no k_top_block launch to ride on)
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_invert_fronts(const FrontDesc* __restrict__ fronts, int nfronts_all, double* __restrict__ Lbuf, long long js) {
+  CGMR_JOB(Lbuf, js);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_z[];
+  if constexpr (kFrontW == 48) invert_fronts<256>(fronts, nfronts_all, blockIdx.x, gridDim.x, Lbuf, reinterpret_cast<double*>(smem_z), threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------ solves
 // Backward (L^T x = y), one workgroup per front, top-down by level: x_own = L11^-T (y - L21^T x_border).
 // A chain of dependent round trips (descriptor -> border row indices -> x of the border -> ...), so everything that
@@ -889,6 +999,10 @@ __global__ __launch_bounds__(kTopT) void k_top_block(int c0, int ncols, int nfro
 // in LDS and reads one row per step).
 constexpr int XB_CAP = 1536;         // border rows staged per pass
 constexpr int kBwdNL = 24;           // L21 rows per thread and pass
+#ifndef CGMR_BWD_STAGGER
+#define CGMR_BWD_STAGGER 20
+#endif
+constexpr int kBwdStaggerSleep = CGMR_BWD_STAGGER;   // chained launch: s_sleep units (64 clocks) a front holds back its loads per tree level below the top
 constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP + (lds_l11 ? w : 0)) * 8; }
 // CHAIN: the upper levels of the tree -- a handful of fronts each, one launch each in round 2 (16 x 6.5 us of dependent
 // round trips and launch boundaries) -- run as ONE launch: workgroup b takes front (first - b) of the level order, i.e.
@@ -899,78 +1013,6 @@ constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0
 // the others with agent-scope loads (sc1: past the L1, which another CU's stores never refresh), re-reading any that is
 // not there yet.  (A separate flag behind an s_waitcnt vmcnt(0) drain costs 0.3 us more per hop.)  The launch is at most 2 workgroups per CU (the host
 // picks the levels), so every workgroup is resident whatever the dispatch order; the spin is bounded all the same.
-// L11^-1 of a front, in place in LDS (chained backward solve, 48 columns): Z = L^-1 is lower triangular like L, and
-// x_own = L11^-T v = Z^T v is then 48 independent dot products instead of 48 dependent substitution steps.  A workgroup
-// of the chained launch computes Z while it waits for its parent's x -- in the shadow of the hops above it -- so the
-// hop itself (parent's x visible -> own x visible) loses the serial solve.
-//   L = [A 0 0; B C 0; D E F] (16 x 16 blocks)   Z = [A' 0 0; -C' B A'  C' 0; -F' (D A' + E Z21)  -F' E C'  F'],  X' = X^-1
-// Step 0: the three diagonal blocks, lane = (block, column) of wavefront 0, the column of the inverse in registers
-// (row by row, the scheduler held back: the kernel lives on 128 VGPRs with its rows of L21 in flight);
-// steps 1-4: 16 x 16 x 16 products, one per wavefront, four v_mfma_f64_16x16x4_f64 each (operand layout as in
-// panel_cholesky.h: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], C[i = (lane >> 4) + 4 rg][j = lane & 15]).
-// sd (3 x 256 doubles: the diagonal blocks' inverses), sp (3 x 256: P1, P2, Z32): scratch.
-// Rows / columns beyond the front's width are identity in L (k_front_factor's padding): identity in Z.
-__device__ __forceinline__ double4_t mm16(const double* X, int ldx, const double* Y, int ldy, double4_t acc, int lane) {
-  const double* xp = X + (lane & 15) * ldx + (lane >> 4);
-  const double* yp = Y + (lane >> 4) * ldy + (lane & 15);
-#pragma unroll
-  for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[4 * kk], yp[4 * kk * ldy], acc, 0, 0, 0);
-  return acc;
-}
-__device__ __forceinline__ void st16(double* C, int ldc, double4_t v, double sign, int lane) {
-#pragma unroll
-  for (int rg = 0; rg < 4; rg++) C[((lane >> 4) + 4 * rg) * ldc + (lane & 15)] = sign * v[rg];
-}
-__device__ __forceinline__ void invert_l11_48(double* Lt, const double* dinv, double* sd, double* sp, int tid) {
-  constexpr int W = 48;
-  const int lane = tid & 63, wave = tid >> 6;
-  if (tid < 48) {
-    const int blk = tid >> 4, c = tid & 15;
-    const double* D = Lt + (16 * blk) * W + 16 * blk;
-    const double* di = dinv + 16 * blk;
-    double z[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < i; k++) s = fma(D[i * W + k], z[k], s);
-      z[i] = (i == c ? 1.0 : -s) * di[i];              // rows above the column's diagonal element: s = 0, z = -0
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) sd[256 * blk + 16 * i + c] = z[i];
-  }
-  __syncthreads();
-  const double4_t zero = {0.0, 0.0, 0.0, 0.0};
-  const double* A1 = sd, *C1 = sd + 256, *F1 = sd + 512;
-  double* B = Lt + 16 * W, *Dm = Lt + 32 * W, *E = Lt + 32 * W + 16;
-  double4_t p3 = zero;
-  // step 1: P1 = B A' (wavefront 0), P2 = E C' (1), P3 = D A' (2: stays in its registers)
-  if (wave == 0) st16(sp, 16, mm16(B, W, A1, 16, zero, lane), 1.0, lane);
-  else if (wave == 1) st16(sp + 256, 16, mm16(E, W, C1, 16, zero, lane), 1.0, lane);
-  else if (wave == 2) p3 = mm16(Dm, W, A1, 16, zero, lane);
-  __syncthreads();
-  // step 2: Z21 = -C' P1 (into B's place), Z32 = -F' P2 (scratch: E is read once more)
-  if (wave == 0) st16(B, W, mm16(C1, 16, sp, 16, zero, lane), -1.0, lane);
-  else if (wave == 1) st16(sp + 512, 16, mm16(F1, 16, sp + 256, 16, zero, lane), -1.0, lane);
-  __syncthreads();
-  // step 3: P4 = P3 + E Z21 (wavefront 2, on top of its P3); the others put Z32 and the diagonal blocks in their places
-  if (wave == 2) st16(sp, 16, mm16(E, W, B, W, p3, lane), 1.0, lane);
-  __syncthreads();
-  // step 4: Z31 = -F' P4
-  if (wave == 2) st16(Dm, W, mm16(F1, 16, sp, 16, zero, lane), -1.0, lane);
-  else {
-    const int t = wave == 3 ? tid - 64 : tid;           // 192 threads: 256 elements of each of the four blocks
-    for (int q = t; q < 256; q += 192) {
-      const int i = q >> 4, j = q & 15;
-      E[i * W + j] = sp[512 + q];
-      Lt[i * W + j] = A1[q];
-      Lt[(16 + i) * W + 16 + j] = C1[q];
-      Lt[(32 + i) * W + 32 + j] = F1[q];
-    }
-  }
-  __syncthreads();
-}
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define CGMR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -978,7 +1020,7 @@ template <int WW, bool CHAIN, bool BATCH>
 __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
                                                    const double* __restrict__ yvec, double* xvec,
-                                                   int* status, long long js, unsigned spin_limit) {
+                                                   int* status, long long js, unsigned spin_limit, int top_level) {
   CGMR_JOB(Lbuf, js); CGMR_JOB(yvec, js); CGMR_JOB(xvec, js); CGMR_JOB(status, js);
   CGMR_FRONT_CONSTS(WW);
   constexpr int HP = W / 2;            // column pairs per row
@@ -1001,6 +1043,15 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
   // descriptors in level order: no index hop (CHAIN: level_begin = the last front of the level order, walked downwards)
   const FrontDesc F = fronts_lv[CHAIN ? level_begin - (int)blockIdx.x : level_begin + (int)blockIdx.x];
   const int w = 3 * F.nc, r = 3 * F.ns;
+  BTIME(0);
+  if constexpr (CHAIN) {
+    // Every workgroup of the chained launch is resident from the start, and all of them asking for their part of L at once
+    // (the whole factor, tens of MB) kept the fronts at the top of the tree -- the ones the chain starts with -- waiting for 14 us
+    // (tools/gpu_bwd_hops.py).  A front `stagger` levels below the top is not needed before `stagger` hops have passed: it
+    // holds back its loads for that many slices (shorter than a hop, so it is ready when its parent is).
+    const int below = top_level - F.level;
+    for (int k = 0; k < below; k++) __builtin_amdgcn_s_sleep(kBwdStaggerSleep);
+  }
   const double* P = Lbuf + F.L_off;
   const double* L21 = P + kL21;
   // ---- L11: independent of x
@@ -1008,8 +1059,10 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
   double lt[LT_Q];
   double Lcol[LDS_L11 ? 1 : W];
   if constexpr (LDS_L11) {
+    // (the chained instance: Z = L11^-1, which the idle workgroups of the top-block launch left behind the front's L21)
+    const double* L11 = TINV ? L21 + (size_t)r * W : P;
 #pragma unroll
-    for (int u = 0; u < LT_Q; u++) lt[u] = P[tid + 256 * u];
+    for (int u = 0; u < LT_Q; u++) lt[u] = L11[tid + 256 * u];
   } else {
     if (tid < 64) {
       const int lane = min(tid, W - 1);
@@ -1039,13 +1092,12 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
       l[u] = (active && p < np) ? *reinterpret_cast<const double2*>(L21 + (size_t)(p0 + p) * W + 2 * cp) : make_double2(0.0, 0.0);
     }
     if constexpr (TINV) {
-      // everything that does not depend on x is on its way: L11 goes to LDS and is inverted there while the parent works
+      // everything that does not depend on x is on its way: Z and the front's part of y wait in LDS
       if (p0 == 0) {
 #pragma unroll
         for (int u = 0; u < LT_Q; u++) Lt[tid + 256 * u] = lt[u];
-        if (tid < W) { dinv[tid] = dvl; ys[tid] = yown; }
-        __syncthreads();
-        invert_l11_48(Lt, dinv, xb, xb + 768, tid);
+        if (tid < W) ys[tid] = yown;
+        BTIME(1);
       }
     }
     double xr[XQ];
@@ -1080,6 +1132,7 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
       }
 #pragma unroll
       for (int u = 0; u < XQ; u++) xr[u] = __longlong_as_double((long long)bits[u]);
+      if (p0 == 0) BTIME(2);
     } else {
 #pragma unroll
       for (int u = 0; u < XQ; u++) {
@@ -1094,10 +1147,11 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
       if (p < np) xb[p] = xr[u];
     }
     __syncthreads();
+    // (rows beyond the border were fetched as zeros: no branch per row, the LDS reads go out together)
 #pragma unroll
     for (int u = 0; u < NL; u++) {
-      const int p = g + G * u;
-      if (p < np) { acc0 = fma(l[u].x, xb[p], acc0); acc1 = fma(l[u].y, xb[p], acc1); }
+      const double xv = xb[min(g + G * u, np - 1)];
+      acc0 = fma(l[u].x, xv, acc0); acc1 = fma(l[u].y, xv, acc1);
     }
     for (int base = G * NL; base < np; base += G * NL) {         // fronts with more than 240 (120) border rows
 #pragma unroll
@@ -1118,12 +1172,10 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
   }
   if (!TINV && tid < W) dinv[tid] = dvl;
   if constexpr (TINV) {
-    if (r == 0) {
+    if (r == 0) {                                              // (no border: the loop above did not run)
 #pragma unroll
       for (int u = 0; u < LT_Q; u++) Lt[tid + 256 * u] = lt[u];
-      if (tid < W) { dinv[tid] = dvl; ys[tid] = yown; }
-      __syncthreads();
-      invert_l11_48(Lt, dinv, xb, xb + 768, tid);
+      if (tid < W) ys[tid] = yown;
     }
   }   // (no border: the loop above did not run)
   if (active) { part[g * W + 2 * cp] = acc0; part[g * W + 2 * cp + 1] = acc1; }
@@ -1149,6 +1201,7 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
       }
       const double xo = (s0 + s1) + (s2 + s3);
       if (lane < w) __hip_atomic_store((gu64*)(xvec + 3 * F.c0 + lane), (unsigned long long)__double_as_longlong(xo), CGMR_RLX_AGENT);
+      BTIME(3);
     }
     return;
   }
@@ -1273,7 +1326,7 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   if (nfr <= 0) return;
   hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, false, true> : k_solve_bwd<kFrontW, false, false>), dim3(nfr, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, false), st, D.fronts_lv, D.h_level_ptr[l], D.rows,
-                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride, 0u);
+                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride, 0u, 0);
 }
 
 // Workgroups of the chained backward solve that are certainly resident together: the waits inside that launch must never
@@ -1305,17 +1358,24 @@ void launch_bwd_chain(hipStream_t st, const GnDevice& D) {
   const char* sl = getenv("CGMR_BWD_SPIN_LIMIT");               // (read per launch: a test switches it inside one process)
   const unsigned spin_limit = sl ? (unsigned)std::max(1, atoi(sl)) : (1u << 22);
   hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, true, true> : k_solve_bwd<kFrontW, true, false>), dim3(last - first, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, true), st, D.fronts_lv, last - 1, D.rows,
-                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride, spin_limit);
+                     D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride, spin_limit, D.nlevels - 1);
 }
 
-void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels) {
+void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels, bool make_z) {
   gn_init_kernels();
   if (D.top_nfronts <= 0) return;
   const bool zero = clear_panels && D.pan_doubles > 0;
-  hipLaunchKernelGGL(CGMR_KERN(D, k_top_block), dim3(zero ? 1 + 240 : 1, 1, D.njobs), dim3(kTopT), top_smem_bytes(D.top_ncols), st, D.top_c0, D.top_ncols,
+  make_z = make_z && kFrontW == 48;
+  hipLaunchKernelGGL(CGMR_KERN(D, k_top_block), dim3(zero || make_z ? 1 + 240 : 1, 1, D.njobs), dim3(kTopT), std::max(top_smem_bytes(D.top_ncols), kInvertSmemBytes), st, D.top_c0, D.top_ncols,
                      D.top_nfronts, D.top_fronts, D.top_nchild, D.top_children, D.top_nblk, D.top_blocks, D.fronts, D.rows, D.Ablk,
                      D.bvec, D.Ubuf, D.uvec, D.Lbuf, D.yvec, D.xvec, D.status, store_l ? 1 : 0, write_l11c ? 1 : 0, D.Pan,
-                     (long long)D.pan_doubles, D.nfronts, D.job_stride);
+                     zero ? (long long)D.pan_doubles : 0ll, D.nfronts, make_z ? 1 : 0, D.job_stride);
+}
+
+// Z = L11^-1 of every front when there is no top-block launch to make it (launch_top_block(.., make_z))
+void launch_invert_fronts(hipStream_t st, const GnDevice& D) {
+  if (kFrontW != 48 || D.nfronts <= 0) return;
+  hipLaunchKernelGGL(CGMR_KERN(D, k_invert_fronts), dim3(std::min(D.nfronts, 512), 1, D.njobs), dim3(256), kInvertSmemBytes, st, D.fronts, D.nfronts, D.Lbuf, D.job_stride);
 }
 
 void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
@@ -1328,6 +1388,9 @@ void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
 #ifdef CGMR_PHASE_TIMING
 extern "C" int cgmr_debug_topphase(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_tphase), sizeof(unsigned long long) * 16);
+}
+extern "C" int cgmr_debug_bwdtimes(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_btime), sizeof(unsigned long long) * 4 * 8192);
 }
 extern "C" int cgmr_debug_workphases(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_wphase), sizeof(unsigned long long) * 8 * 8192);

@@ -1537,7 +1537,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       n_a += F.a_cnt;
       int64_t w = 3 * (int64_t)F.nc, r = 3 * (int64_t)F.ns;
       const int64_t lw = kFrontW;
-      F.L_off = Loff; Loff += factor_header((int)lw) + r * lw;
+      F.L_off = Loff; Loff += factor_header((int)lw) + r * lw + lw * lw;   // header, L21, then L11^-1 (the chained backward solve's)
       F.U_off = Uoff; Uoff += (r * r + r + 3) & ~int64_t(1);      // even offsets: the update matrices are read with 16-byte loads
       F.pan_off = Panoff; Panoff += pan_size(F.ns) * F.pan_slots;
       flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
