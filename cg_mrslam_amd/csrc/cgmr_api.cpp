@@ -344,11 +344,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.status = (int*)(d + o_status);
   // the upper levels of the tree are solved backwards in one chained launch: as many levels as fit the workgroups that
   // are certainly resident together (the waits inside the launch cannot deadlock then); CGMR_BWD_CHAIN=0: one launch per level
-  static const int chain_env = getenv("CGMR_BWD_CHAIN") ? atoi(getenv("CGMR_BWD_CHAIN")) : -1;
-  const int chain_all = bwd_chain_capacity() / (ctx->side_used ? 2 : 1);      // (the other half: the side stream's batches)
-  const int chain_cap = chain_env >= 0 ? std::min(chain_env, chain_all) : chain_all;
-  D.bwd_chain_level = D.nlevels;
-  while (D.bwd_chain_level > 0 && D.h_level_ptr[D.nlevels] - D.h_level_ptr[D.bwd_chain_level - 1] <= chain_cap) D.bwd_chain_level--;
+  choose_bwd_chain(D, ctx->side_used ? 2 : 1, false);      // (the other half of the slots: the side stream's batches)
   return 0;
 }
 

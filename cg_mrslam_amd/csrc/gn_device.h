@@ -30,7 +30,8 @@ struct GnDevice {
   bool pan_clean = false;                // the panels are all zero (the last pass's top-block launch cleared them behind itself)
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
-  int bwd_chain_level = 0;               // GN levels >= this one are solved backwards in one chained launch (k_solve_bwd<.., true>)
+  int bwd_chain_level = 0;               // GN levels >= this one are solved backwards in one chained launch (k_solve_bwd<.., 4 or 2>)
+  int bwd_chain_wgs = 4;                 // ... by the instance built for this many resident workgroups per CU (choose_bwd_chain)
   // a batch of passes on the same structure (gn_kernels.hip: CGMR_JOB): job j works in this view's numeric buffers moved by
   // j * job_stride bytes, on the poses moved by j * pose_stride bytes; every launch gets a job dimension
   int njobs = 1;
@@ -61,7 +62,8 @@ void launch_factor_level(hipStream_t st, const GnDevice& D, int level, bool writ
 void launch_update_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_chain(hipStream_t st, const GnDevice& D);
-int bwd_chain_capacity();
+int bwd_chain_capacity(int per_cu);
+void choose_bwd_chain(GnDevice& D, int slots_div, bool levelwise);
 void launch_update(hipStream_t st, const GnDevice& D, double* poses);
 void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels, bool make_z);
 void launch_invert_fronts(hipStream_t st, const GnDevice& D);

@@ -285,8 +285,8 @@ __device__ unsigned long long g_wtime[2 * 8192];          // per work item of k_
 __device__ unsigned long long g_fphase[8 * 8192];         // per work item: cycle counter at the steps of the blocked factorisation
 __device__ unsigned long long g_utime[2 * 64];             // per level of k_front_update: min start / max end
 __device__ unsigned long long g_tphase[16];                // k_top_block, the block's own workgroup: cycle counter at its marks
-__device__ unsigned long long g_btime[4 * 8192];           // k_solve_bwd (chained), per front: 100 MHz clock at start / L11 inverted / x of the border there / own x stored
-#define BTIME(i) do { if (CHAIN && threadIdx.x == 0 && F.front_id < 8192) g_btime[4 * F.front_id + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_btime[8 * 8192];           // k_solve_bwd (chained), per front: 100 MHz clock at start / L11 inverted / x of the border there / own x stored
+#define BTIME(i) do { if (CHAIN && threadIdx.x == 0 && F.front_id < 8192) g_btime[8 * F.front_id + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define TPHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_tphase[i] = __builtin_readcyclecounter(); } while (0)
 #define PHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_wphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0 && level_id < 64) { g_phase[8 * level_id + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime(); if ((i) == 6) g_phase[8 * level_id + 7] = __builtin_amdgcn_s_memrealtime() - g_phase[8 * level_id + 7]; } } while (0)
 #define FPHASE(i) do { if (threadIdx.x == 0 && work_begin + (int)blockIdx.x < 8192) g_fphase[8 * (work_begin + blockIdx.x) + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -1003,7 +1003,7 @@ constexpr int kBwdNL = 24;           // L21 rows per thread and pass
 #define CGMR_BWD_STAGGER 20
 #endif
 constexpr int kBwdStaggerSleep = CGMR_BWD_STAGGER;   // chained launch: s_sleep units (64 clocks) a front holds back its loads per tree level below the top
-constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP + (lds_l11 ? w : 0)) * 8; }
+constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0) + w + (256 / (w / 2)) * w + XB_CAP + (lds_l11 ? w + 4 * w : 0)) * 8; }
 // CHAIN: the upper levels of the tree -- a handful of fronts each, one launch each in round 2 (16 x 6.5 us of dependent
 // round trips and launch boundaries) -- run as ONE launch: workgroup b takes front (first - b) of the level order, i.e.
 // parents before children, and waits for its parent's columns of x (they, and by induction every ancestor's, are final
@@ -1016,8 +1016,8 @@ constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define CGMR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-template <int WW, bool CHAIN, bool BATCH>
-__global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
+template <int WW, int CHAIN, bool BATCH>
+__global__ __launch_bounds__(256, CHAIN ? CHAIN : 1) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
                                                    const double* __restrict__ yvec, double* xvec,
                                                    int* status, long long js, unsigned spin_limit, int top_level) {
@@ -1027,10 +1027,12 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
   constexpr int G = 256 / HP;          // row groups of the border reduction (10 / 5)
   // CHAIN: four workgroups per CU must be resident (<= 128 VGPRs): L11 goes through LDS instead of 96 registers of
   // wavefront 0, half as many L21 rows per thread in flight
-  constexpr int NL = CHAIN ? kBwdNL / 2 : kBwdNL;
+  // (CHAIN = 2, a tree whose chained fronts fit two per CU: 256 VGPRs, every row of L21 of a border of up to 240 rows in registers --
+  // with half of them a front with more than 120 border rows fetched the rest AFTER x had arrived: 0.5-1 us on ten hops of C2's fifteen)
+  constexpr int NL = CHAIN == 4 ? 16 : kBwdNL;
   constexpr int CPL = (W + 63) / 64;   // columns per lane in the triangular solve
-  constexpr bool LDS_L11 = W > 64 || CHAIN;
-  constexpr bool TINV = CHAIN && W == 48;   // the chained launch inverts L11 while it waits (invert_l11_48)
+  constexpr bool LDS_L11 = W > 64 || CHAIN != 0;
+  constexpr bool TINV = CHAIN != 0 && W == 48;   // the chained launch inverts L11 while it waits (invert_l11_48)
   constexpr int XCAP = TINV ? 512 : XB_CAP;  // border rows per pass (the chained instance: fewer, its registers hold the rows of L21)
   constexpr int XQ = XCAP / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -1038,7 +1040,8 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
   double* dinv = Lt + (LDS_L11 ? W * W : 0);                 // [W]
   double* part = dinv + W;                                   // [G][W]
   double* xb = part + G * W;                                 // [XB_CAP]
-  [[maybe_unused]] double* ys = xb + XB_CAP;                 // [W] the front's own part of y (chained instance: parked here while L11 is inverted)
+  [[maybe_unused]] double* ys = xb + XB_CAP;                 // [W] the front's own part of y (chained instance: fetched ahead of the wait)
+  [[maybe_unused]] double* pz = ys + W;                      // [4][W] the wavefronts' parts of Z^T v
   const int tid = threadIdx.x;
   // descriptors in level order: no index hop (CHAIN: level_begin = the last front of the level order, walked downwards)
   const FrontDesc F = fronts_lv[CHAIN ? level_begin - (int)blockIdx.x : level_begin + (int)blockIdx.x];
@@ -1147,6 +1150,7 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
       if (p < np) xb[p] = xr[u];
     }
     __syncthreads();
+    if (p0 == 0) BTIME(4);
     // (rows beyond the border were fetched as zeros: no branch per row, the LDS reads go out together)
 #pragma unroll
     for (int u = 0; u < NL; u++) {
@@ -1181,28 +1185,31 @@ __global__ __launch_bounds__(256, CHAIN ? 4 : 1) void k_solve_bwd(const FrontDes
   if (active) { part[g * W + 2 * cp] = acc0; part[g * W + 2 * cp + 1] = acc1; }
   __syncthreads();
   if constexpr (TINV) {
-    // x_own = Z^T v, v = y - L21^T x_border: lane c of wavefront 0 adds Z[i][c] v[i] over the rows i (zeros above the diagonal of Z)
-    if (tid < 64) {
-      const int lane = tid, cj = min(lane, W - 1);
-      double v = ys[cj];
+    BTIME(5);
+    // x_own = Z^T v, v = y - L21^T x_border (zeros above the diagonal of Z).  Wavefront k takes the rows 12 k .. 12 k + 11 of Z:
+    // its lanes 0..11 form v of those rows (the row groups' partial sums), every lane c < 48 adds Z[i][c] v[i] with v[i] read from
+    // the lane that made it; the four parts meet in LDS and wavefront 0 stores x.  (One wavefront did all 48 rows through an LDS
+    // copy of v before: 0.8 of a hop's 1.3 us.)
+    const int lane = tid & 63, wv = tid >> 6, cj = min(lane, W - 1);
+    const int vi = 12 * wv + min(lane, 11);
+    double v = ys[vi];
 #pragma unroll
-      for (int gg = 0; gg < G; gg++) v -= part[gg * W + cj];
-      double* vs = dinv;                                       // (the reciprocals are not needed any more)
-      if (lane < W) vs[lane] = v;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int gg = 0; gg < G; gg++) v -= part[gg * W + vi];
+    double s0 = 0.0, s1 = 0.0;
+    const double* Zr = Lt + (12 * wv) * W + cj;
 #pragma unroll
-      for (int i = 0; i < W; i += 4) {
-        s0 = fma(Lt[i * W + cj], vs[i], s0);
-        s1 = fma(Lt[(i + 1) * W + cj], vs[i + 1], s1);
-        s2 = fma(Lt[(i + 2) * W + cj], vs[i + 2], s2);
-        s3 = fma(Lt[(i + 3) * W + cj], vs[i + 3], s3);
-      }
-      const double xo = (s0 + s1) + (s2 + s3);
-      if (lane < w) __hip_atomic_store((gu64*)(xvec + 3 * F.c0 + lane), (unsigned long long)__double_as_longlong(xo), CGMR_RLX_AGENT);
-      BTIME(3);
+    for (int j = 0; j < 12; j += 2) {
+      s0 = fma(Zr[j * W], readlane_f64(v, j), s0);
+      s1 = fma(Zr[(j + 1) * W], readlane_f64(v, j + 1), s1);
     }
+    if (lane < W) pz[wv * W + lane] = s0 + s1;
+    BTIME(6);
+    __syncthreads();
+    if (tid < w) {
+      const double xo = (pz[tid] + pz[W + tid]) + (pz[2 * W + tid] + pz[3 * W + tid]);
+      __hip_atomic_store((gu64*)(xvec + 3 * F.c0 + tid), (unsigned long long)__double_as_longlong(xo), CGMR_RLX_AGENT);
+    }
+    BTIME(3);
     return;
   }
   if (tid < 64) {
@@ -1325,28 +1332,32 @@ void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {
   gn_init_kernels();
   int nfr = D.h_level_ptr[l + 1] - D.h_level_ptr[l];
   if (nfr <= 0) return;
-  hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, false, true> : k_solve_bwd<kFrontW, false, false>), dim3(nfr, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, false), st, D.fronts_lv, D.h_level_ptr[l], D.rows,
+  hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, 0, true> : k_solve_bwd<kFrontW, 0, false>), dim3(nfr, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, false), st, D.fronts_lv, D.h_level_ptr[l], D.rows,
                      D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride, 0u, 0);
 }
 
 // Workgroups of the chained backward solve that are certainly resident together: the waits inside that launch must never
-// depend on the dispatch order.  What the occupancy query promises, at most 4 per CU: the kernel's budget is 128 VGPRs and
-// 35 KB of LDS; the query is known to over-report by one only where the SGPRs bind (MI355X guide: floor(800 / (ceil(sgpr /
-// 16) * 16 + 16)) blocks of 256 threads), and this kernel's 106 SGPRs admit 6.  The spin is bounded all the same.
-int bwd_chain_capacity() {
-  static int cap[64];
+// depend on the dispatch order.  What the occupancy query promises, at most `per_cu` (4 or 2: the two chained instances) per
+// CU: the budget of the first is 128 VGPRs and 37 KB of LDS; the query is known to over-report by one only where the SGPRs bind
+// (MI355X guide: floor(800 / (ceil(sgpr / 16) * 16 + 16)) blocks of 256 threads), and these kernels' <= 80 SGPRs admit 8.
+// The spin is bounded all the same.
+int bwd_chain_capacity(int per_cu) {
+  static int cap[64][2];
   static std::once_flag once[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev &= 63;
   std::call_once(once[dev], [dev] {
-    int nb = 0, ncu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_solve_bwd<kFrontW, true, false>), 256,
-                                                     bwd_smem_bytes(kFrontW, true)) != hipSuccess) nb = 0;
+    int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
-    cap[dev] = std::max(0, std::min(nb, 4)) * ncu;
+    const void* fn[2] = {reinterpret_cast<const void*>(k_solve_bwd<kFrontW, 4, false>), reinterpret_cast<const void*>(k_solve_bwd<kFrontW, 2, false>)};
+    for (int q = 0; q < 2; q++) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn[q], 256, bwd_smem_bytes(kFrontW, true)) != hipSuccess) nb = 0;
+      cap[dev][q] = std::max(0, std::min(nb, q == 0 ? 4 : 2)) * ncu;
+    }
   });
-  return cap[dev];
+  return cap[dev][per_cu == 2 ? 1 : 0];
 }
 
 // GN levels bwd_chain_level .. nlevels-1 in one launch, parents first
@@ -1357,8 +1368,27 @@ void launch_bwd_chain(hipStream_t st, const GnDevice& D) {
   // CGMR_BWD_SPIN_LIMIT: polls a wait may take (tests force the time-out path with a tiny value)
   const char* sl = getenv("CGMR_BWD_SPIN_LIMIT");               // (read per launch: a test switches it inside one process)
   const unsigned spin_limit = sl ? (unsigned)std::max(1, atoi(sl)) : (1u << 22);
-  hipLaunchKernelGGL((D.njobs > 1 ? k_solve_bwd<kFrontW, true, true> : k_solve_bwd<kFrontW, true, false>), dim3(last - first, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, true), st, D.fronts_lv, last - 1, D.rows,
+  auto kern = D.bwd_chain_wgs == 2 ? (D.njobs > 1 ? k_solve_bwd<kFrontW, 2, true> : k_solve_bwd<kFrontW, 2, false>)
+                                   : (D.njobs > 1 ? k_solve_bwd<kFrontW, 4, true> : k_solve_bwd<kFrontW, 4, false>);
+  hipLaunchKernelGGL(kern, dim3(last - first, 1, D.njobs), dim3(256), bwd_smem_bytes(kFrontW, true), st, D.fronts_lv, last - 1, D.rows,
                      D.Lbuf, D.yvec, D.xvec, D.status, D.job_stride, spin_limit, D.nlevels - 1);
+}
+
+// Which chained instance and how many levels: the instance with two workgroups per CU (every row of L21 in registers) when
+// the whole tree fits it; a larger tree takes the instance with four per CU for as many upper levels as fit, the levels below
+// one launch each.  `slots_div`: the resident workgroups are shared (a side stream's batches, the jobs of a batch).
+// CGMR_BWD_CHAIN = n: at most n workgroups in the chained launch (0: one launch per level); CGMR_BWD_CHAIN_WGS = 2 / 4: that instance.
+void choose_bwd_chain(GnDevice& D, int slots_div, bool levelwise) {
+  static const int chain_env = getenv("CGMR_BWD_CHAIN") ? atoi(getenv("CGMR_BWD_CHAIN")) : -1;
+  static const int wgs_env = getenv("CGMR_BWD_CHAIN_WGS") ? atoi(getenv("CGMR_BWD_CHAIN_WGS")) : 0;
+  slots_div = std::max(1, slots_div);
+  const int total = D.h_level_ptr[D.nlevels] - D.h_level_ptr[0];
+  int cap2 = bwd_chain_capacity(2) / slots_div, cap4 = bwd_chain_capacity(4) / slots_div;
+  if (chain_env >= 0) { cap2 = std::min(cap2, chain_env); cap4 = std::min(cap4, chain_env); }
+  D.bwd_chain_wgs = wgs_env == 2 || wgs_env == 4 ? wgs_env : (total <= cap2 ? 2 : 4);
+  const int cap = D.bwd_chain_wgs == 2 ? cap2 : cap4;
+  D.bwd_chain_level = D.nlevels;
+  while (!levelwise && D.bwd_chain_level > 0 && D.h_level_ptr[D.nlevels] - D.h_level_ptr[D.bwd_chain_level - 1] <= cap) D.bwd_chain_level--;
 }
 
 void launch_top_block(hipStream_t st, const GnDevice& D, bool store_l, bool write_l11c, bool clear_panels, bool make_z) {
@@ -1390,7 +1420,7 @@ extern "C" int cgmr_debug_topphase(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_tphase), sizeof(unsigned long long) * 16);
 }
 extern "C" int cgmr_debug_bwdtimes(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_btime), sizeof(unsigned long long) * 4 * 8192);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_btime), sizeof(unsigned long long) * 8 * 8192);
 }
 extern "C" int cgmr_debug_workphases(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_wphase), sizeof(unsigned long long) * 8 * 8192);

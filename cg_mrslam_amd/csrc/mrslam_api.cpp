@@ -717,11 +717,9 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     DB.njobs = nj; DB.job_stride = (long long)rep_stride; DB.pose_stride = 24LL * nV;
     // the chained backward solve needs its workgroups resident together: the chain of the batch takes nj times the slots
     {
-      const int cap_blocks = bwd_chain_capacity() / (ctx->side_used ? 2 : 1) / nj;
-      DB.bwd_chain_level = DB.nlevels;
       // (after a time-out -- two chained solves per context on eight contexts of one device make them likelier -- the batches of
       // this graph solve level by level: no in-kernel waits, like gn_run's retry)
-      while (!g->cond_levelwise && DB.bwd_chain_level > 0 && DB.h_level_ptr[DB.nlevels] - DB.h_level_ptr[DB.bwd_chain_level - 1] <= cap_blocks) DB.bwd_chain_level--;
+      choose_bwd_chain(DB, (ctx->side_used ? 2 : 1) * nj, g->cond_levelwise);
     }
     run_guesses([&](int i) { return (double*)(hstage + s_work + (size_t)24 * nV * i); });
     const double tm0 = wall_s();
