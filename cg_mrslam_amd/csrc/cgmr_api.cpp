@@ -142,6 +142,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.h_level_chrows.assign(D.nlevels, 1);
   D.h_level_leaf.assign(D.nlevels, 1);
   D.h_level_chunk.assign(D.nlevels, kChunkRows);
+  D.h_level_mergeable.assign(D.nlevels, 1);
   // update tiles run in the launch the schedule gave their front (sched_t: its own level or, with slack, a later one)
   std::vector<std::vector<int32_t>> sched(D.nlevels);
   for (int q = 0; q < (int)LF.size(); q++) {
@@ -170,6 +171,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
     }
     int xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};                     // update tiles per XCD (see the tile list below)
     for (int f : sched[l]) {
+      if (S.fronts[f].nchild > kWorkChildren) D.h_level_mergeable[l] = 0;
       const int T = (3 * S.fronts[f].ns + 31) / 32;
       *std::min_element(xload, xload + 8) += T * (T + 1) / 2;
     }
@@ -212,6 +214,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_pan = N.add<double>((size_t)S.pan_doubles + 2);
   size_t o_chi = N.add<double>((size_t)iters + 2);
   size_t o_status = N.add<int>(4);
+  size_t o_ready = N.add<int>(S.fronts.size() + 4);
   size_t o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
   size_t total = N.off + 256;
   int rc = arena_reserve(ctx, ctx->gn_arena, total);
@@ -342,9 +345,11 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.pan_doubles = S.pan_doubles;
   D.chi2 = (double*)(d + o_chi);
   D.status = (int*)(d + o_status);
+  D.ready = (int*)(d + o_ready);
   // the upper levels of the tree are solved backwards in one chained launch: as many levels as fit the workgroups that
   // are certainly resident together (the waits inside the launch cannot deadlock then); CGMR_BWD_CHAIN=0: one launch per level
   choose_bwd_chain(D, ctx->side_used ? 2 : 1, false);      // (the other half of the slots: the side stream's batches)
+  choose_fwd_merge(D, ctx->side_used ? 2 : 1, false);
   return 0;
 }
 
@@ -358,7 +363,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out, size_t* stride
          o_y = N.add<double>((size_t)3 * S.nf), o_x = N.add<double>((size_t)3 * S.nf), o_u = N.add<double>((size_t)3 * S.rows.size() + 3),
          o_L = N.add<double>((size_t)S.L_doubles + 1), o_U = N.add<double>((size_t)S.U_doubles + 1),
          o_pan = N.add<double>((size_t)S.pan_doubles + 2), o_chi = N.add<double>(8),
-         o_status = N.add<int>(4), o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
+         o_status = N.add<int>(4), o_ready = N.add<int>(S.fronts.size() + 4), o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
   const size_t per = (N.off + 255) & ~size_t(255);
   int rc = arena_reserve(ctx, ctx->rep_arena, per * (size_t)std::max(n, 1) + 256);
   if (rc) return rc;
@@ -369,7 +374,7 @@ int gn_replicas(cgmr_ctx* ctx, int n, std::vector<GnDevice>& out, size_t* stride
     GnDevice& D = out[i];
     D.term = (double*)(d + o_term); D.Ablk = (double*)(d + o_A); D.bvec = (double*)(d + o_b); D.yvec = (double*)(d + o_y);
     D.xvec = (double*)(d + o_x); D.uvec = (double*)(d + o_u); D.Lbuf = (double*)(d + o_L); D.Ubuf = (double*)(d + o_U); D.Pan = (double*)(d + o_pan); D.pan_clean = false;
-    D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.cmask = (uint8_t*)(d + o_cmask);
+    D.chi2 = (double*)(d + o_chi); D.status = (int*)(d + o_status); D.ready = (int*)(d + o_ready); D.cmask = (uint8_t*)(d + o_cmask);
   }
   return 0;
 }
@@ -569,6 +574,7 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
       fprintf(stderr, "[cgmr] level %d: %d fronts, %d work items, max r %d, max child rows %d\n", l,
               D.h_level_ptr[l + 1] - D.h_level_ptr[l], D.h_work_ptr[l + 1] - D.h_work_ptr[l], maxr, maxc);
     }
+    if (l < (int)D.h_level_merge.size() && D.h_level_merge[l]) { T.run(3, 1, [&] { launch_front_level(st, D, l, write_l11c); }); continue; }
     T.run(3, 1, [&] { launch_factor_level(st, D, l, write_l11c); });
     if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
   }
@@ -652,6 +658,8 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
     const int it0 = status4[0] - 1;
     const int chain_was = D.bwd_chain_level;
     D.bwd_chain_level = D.nlevels;
+    const std::vector<uint8_t> merge_was = D.h_level_merge;
+    D.h_level_merge.assign(D.nlevels, 0);
     const int fresh[4] = {0, it0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(D.status, fresh, sizeof fresh, hipMemcpyHostToDevice, st));
     for (int it = it0; it <= iters; it++) gn_pass(ctx, d_poses, Ed, it, it == iters, true, false);
@@ -661,6 +669,7 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
     HIP_TRY(ctx, hipStreamSynchronize(st));
     HIP_TRY(ctx, hipGetLastError());
     D.bwd_chain_level = chain_was;
+    D.h_level_merge = merge_was;
     if (status4[2] != 0) return set_err(ctx, CGMR_E_TIMEOUT, "backward solve: a bounded device-side wait ran out twice");
   }
   const int status = status4[0];

@@ -30,6 +30,7 @@ struct GnDevice {
   bool pan_clean = false;                // the panels are all zero (the last pass's top-block launch cleared them behind itself)
   double* chi2 = nullptr;   // iters+1 values
   int* status = nullptr;
+  int* ready = nullptr;                  // per front: work items of the factorisation that have stored their rows of L21 in this pass (k_front_level's hand-off)
   int bwd_chain_level = 0;               // GN levels >= this one are solved backwards in one chained launch (k_solve_bwd<.., 4 or 2>)
   int bwd_chain_wgs = 4;                 // ... by the instance built for this many resident workgroups per CU (choose_bwd_chain)
   // a batch of passes on the same structure (gn_kernels.hip: CGMR_JOB): job j works in this view's numeric buffers moved by
@@ -45,6 +46,8 @@ struct GnDevice {
   std::vector<int32_t> h_level_ptr, h_tile_ptr, h_work_ptr;   // Gauss-Newton levels (without the top block)
   std::vector<uint8_t> h_level_leaf;     // per level: 1 if no front of the level has children (leaf variant of the factor kernel)
   std::vector<int32_t> h_level_chunk;    // per level: border rows per work item (kChunkRows, fewer for a level of leaves)
+  std::vector<uint8_t> h_level_mergeable; // per level: no front whose tiles run in the level's launch has more than kWorkChildren children
+  std::vector<uint8_t> h_level_merge;     // per level: factorisation and update tiles in one launch (choose_fwd_merge)
   std::vector<int32_t> h_level_chrows;   // per level: rows of the factor kernel's F21 staging area (max chunk rows + rhs row)
 };
 
@@ -60,6 +63,8 @@ void launch_assemble(hipStream_t st, const GnDevice& D);
 void gn_init_kernels();
 void launch_factor_level(hipStream_t st, const GnDevice& D, int level, bool write_l11c);
 void launch_update_level(hipStream_t st, const GnDevice& D, int level);
+void launch_front_level(hipStream_t st, const GnDevice& D, int level, bool write_l11c);
+void choose_fwd_merge(GnDevice& D, int slots_div, bool off);
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_chain(hipStream_t st, const GnDevice& D);
 int bwd_chain_capacity(int per_cu);

@@ -201,9 +201,9 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
                                                   double* __restrict__ Pan,
                                                   double* __restrict__ bvec, double* __restrict__ chi_out,
                                                   const int* __restrict__ status, int nfronts,
-                                                  double* __restrict__ xvec, long long js) {
+                                                  double* __restrict__ xvec, int* __restrict__ ready, long long js) {
   CGMR_JOB(cmask, js); CGMR_JOB(term, js); CGMR_JOB(Ablk, js); CGMR_JOB(Pan, js); CGMR_JOB(bvec, js); CGMR_JOB(chi_out, js);
-  CGMR_JOB(status, js); CGMR_JOB(xvec, js);
+  CGMR_JOB(status, js); CGMR_JOB(xvec, js); CGMR_JOB(ready, js);
   if (blockIdx.x == gridDim.x - 1) {
     block_chi2_sum((nE + 255) / 256, term + (size_t)33 * nE, chi_out + status[1]);   // chi2 before iteration status[1]
     return;
@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void k_assemble(int nf, int nb, int nE, const 
     acc = cmask[v] ? 0.0 : acc;
     bvec[t] = acc;
     xvec[t] = __longlong_as_double((long long)kXSentinel);   // "not solved yet" (chained backward solve)
+    if (t < nfronts) ready[t] = 0;                             // work items of a front that have stored their L21 (k_front_level)
     const int dst = b_dst[v];
     if (dst >= 0) Pan[(size_t)dst + r] = acc;                  // right-hand-side row of the owning front's panel
   }
@@ -316,6 +317,11 @@ __device__ __forceinline__ long long rfl64(long long v) {
   return ((long long)rfl((int)(v >> 32)) << 32) | (unsigned)rfl((int)v);
 }
 
+// agent-scope relaxed 8-byte accesses (global_load / global_store .. sc1): the in-launch hand-offs (MI355X guide, Guideline 16)
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+#define CGMR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
 // LDS += without a return value: one ds_add_f64, nothing to wait for (k_top_block's extend-add).
 typedef __attribute__((address_space(3))) double lds_double;
 __device__ __forceinline__ void lds_add(double* p, double v) {
@@ -339,15 +345,18 @@ constexpr int kFT = 512;             // threads of a k_front_factor workgroup: 8
                                      // groups, the MFMA updates, the loads and the stores all of them; 256 threads: +4k cycles per work item)
 constexpr int kPanRoundRows = kFrontW + (kLeafChunkRows > kMidChunkRows ? kLeafChunkRows : kMidChunkRows) + 1;
 constexpr int kPanLoads = kPanRoundRows * (kPanStride / 2) / kFT + 1;   // 16-byte loads per thread and round: the longest chunk's panel (95 rows) in one round (8)
-template <bool BATCH>
-__global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
+// MERGED: the level's update tiles run in the same launch (k_front_level) and wait for this front's rows of L21: they and the
+// border vector go out write-through (agent-scope 8-byte stores = global_store_dwordx2 sc1), and the work item counts itself
+// into ready[front] once its stores have drained.
+template <bool BATCH, bool MERGED>
+__device__ __forceinline__ void front_factor_item(const WorkRec* __restrict__ work, int work_begin,
                                                       const double* __restrict__ Pan, double* __restrict__ Lbuf,
                                                       double* __restrict__ yvec, double* __restrict__ uvec,
                                                       int* __restrict__ status, int level_id, int write_l11c, int chunk_rows,
-                                                      long long js) {
+                                                      long long js, int* __restrict__ ready, unsigned char* smem) {
   CGMR_JOB(Pan, js); CGMR_JOB(Lbuf, js); CGMR_JOB(yvec, js); CGMR_JOB(uvec, js); CGMR_JOB(status, js);
+  if constexpr (MERGED) { CGMR_JOB(ready, js); }
   CGMR_FRONT_CONSTS(kFrontW);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* P = reinterpret_cast<double*>(smem);
   const int tid = threadIdx.x;
 #ifdef CGMR_PHASE_TIMING
@@ -443,7 +452,13 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
         *reinterpret_cast<double2*>(Pn + rr * W + k) = make_double2(a, b);
       } else {
         const int row = rr - (chunk == 0 ? W : 0);
-        *reinterpret_cast<double2*>(Pn + kL21 + (size_t)(r0 + row) * W + k) = make_double2(R[row * LDW + k], R[row * LDW + k + 1]);
+        double* dst = Pn + kL21 + (size_t)(r0 + row) * W + k;
+        if constexpr (MERGED) {
+          __hip_atomic_store((gu64*)dst, (unsigned long long)__double_as_longlong(R[row * LDW + k]), CGMR_RLX_AGENT);
+          __hip_atomic_store((gu64*)(dst + 1), (unsigned long long)__double_as_longlong(R[row * LDW + k + 1]), CGMR_RLX_AGENT);
+        } else {
+          *reinterpret_cast<double2*>(dst) = make_double2(R[row * LDW + k], R[row * LDW + k + 1]);
+        }
       }
     }
   };
@@ -467,7 +482,15 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
     double dot = 0.0;
 #pragma unroll 8
     for (int k = 0; k < W; k++) dot = fma(xr[k], yr[k], dot);
-    uvec[(size_t)3 * rows_off + r0 + tid] = xr[W] - dot;
+    if constexpr (MERGED) __hip_atomic_store((gu64*)(uvec + (size_t)3 * rows_off + r0 + tid), (unsigned long long)__double_as_longlong(xr[W] - dot), CGMR_RLX_AGENT);
+    else uvec[(size_t)3 * rows_off + r0 + tid] = xr[W] - dot;
+  }
+  if constexpr (MERGED) {
+    // every store of this work item has reached the memory side before it counts itself in (the compiler does not know what
+    // the counter means: the wait is spelt out)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ready + WR->F.front_id, 1, CGMR_RLX_AGENT);
   }
   PHASE(5);
 #ifdef CGMR_PHASE_TIMING
@@ -475,6 +498,16 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
   if (tid == 0 && work_begin + (int)blockIdx.x < 8192) g_wtime[2 * (work_begin + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
   PHASE(6);
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restrict__ work, int work_begin,
+                                                      const double* __restrict__ Pan, double* __restrict__ Lbuf,
+                                                      double* __restrict__ yvec, double* __restrict__ uvec,
+                                                      int* __restrict__ status, int level_id, int write_l11c, int chunk_rows,
+                                                      long long js) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  front_factor_item<BATCH, false>(work, work_begin, Pan, Lbuf, yvec, uvec, status, level_id, write_l11c, chunk_rows, js, nullptr, smem);
 }
 
 // --------------------------------------------------------------------------- front update
@@ -491,44 +524,71 @@ __global__ __launch_bounds__(kFT, 4) void k_front_factor(const WorkRec* __restri
 // Ubuf.  A cell of a panel copy is touched by one workgroup per launch -- siblings that share a launch write different
 // copies -- and launches are ordered, so the sums are bit-reproducible without atomics.  A front whose parent lies in
 // the top block (ppan_off < 0) stores the whole matrix in Ubuf: k_top_block assembles its block itself.
-template <int WW, bool BATCH>
-__global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict__ work,
-                                                      const int32_t* __restrict__ tiles, int tile_begin,
+// LDS of one tile (k_front_level holds two)
+template <int WW>
+struct UpdTileLds {
+  double Ai[TS * (WW + 1)];
+  double Aj[TS * (WW + 1)];
+  short s_k[MAXC][2 * TS];                                  // per child: child row of tile row i / tile column j, or -1
+  int s_pp[2 * TS];                                         // tile row i: offset (doubles) of its row in the parent's panel; tile column j: its column
+};
+// MERGED (k_front_level): the tile sits in the launch that factors its front.  Everything that does not depend on the front's
+// factor -- the children's values, the parent's cells, the maps -- is fetched first; then one lane waits for the front's work
+// items to count themselves into ready[front] (nchunks of them), and the L21 slices and the border vector are read with
+// agent-scope loads (sc1: the factor's write-through stores are in memory, this CU's L1 knows nothing of them).  A tile of a
+// front factored in an earlier launch (the schedule moved it here) does not wait.  `tid`: 0..255 within the tile's half of the
+// workgroup; the barriers are the whole workgroup's (both halves run the same code).
+template <int WW, bool BATCH, bool MERGED>
+__device__ __forceinline__ void front_update_tile(const WorkRec* __restrict__ work, const int32_t* __restrict__ tl,
                                                       const FrontDesc* __restrict__ fronts,
                                                       const int32_t* __restrict__ children,
                                                       const int32_t* __restrict__ inv, const int32_t* __restrict__ rel,
                                                       const double* __restrict__ Lbuf, double* __restrict__ Ubuf,
-                                                      double* __restrict__ Pan, const double* __restrict__ uvec, long long js) {
+                                                      double* __restrict__ Pan, const double* __restrict__ uvec, long long js,
+                                                      UpdTileLds<WW>& S, int tid, const int* __restrict__ ready, int level_id, int chunk_rows,
+                                                      int* __restrict__ status, unsigned spin_limit) {
   CGMR_JOB(Lbuf, js); CGMR_JOB(Ubuf, js); CGMR_JOB(Pan, js); CGMR_JOB(uvec, js);
+  if constexpr (MERGED) { CGMR_JOB(ready, js); CGMR_JOB(status, js); }
   CGMR_FRONT_CONSTS(WW);
-  __shared__ double Ai[TS * LDW];
-  __shared__ double Aj[TS * LDW];
-  __shared__ short s_k[MAXC][2 * TS];                        // per child: child row of tile row i / tile column j, or -1
-  __shared__ int s_pp[2 * TS];                               // tile row i: offset (doubles) of its row in the parent's panel; tile column j: its column
-  const int tid = threadIdx.x;
-  const int32_t* tl = tiles + 3 * (size_t)(tile_begin + blockIdx.x);
-  const int rec = tl[0], ti = tl[1], tj = tl[2];
-  if (rec < 0) return;                                        // padding of the XCD-interleaved tile list
+  double* Ai = S.Ai;
+  double* Aj = S.Aj;
+  auto& s_k = S.s_k;
+  int* s_pp = S.s_pp;
+  const int rec_in = tl ? tl[0] : -1;
+  const bool live = rec_in >= 0;                              // (padding of the XCD-interleaved tile list; MERGED: the other half may hold a tile)
+  if constexpr (!MERGED) { if (!live) return; }
+  const int rec = live ? rec_in : 0, ti = live ? tl[1] : 0, tj = live ? tl[2] : 0;
   // (the record through the scalar cache: its address is wave-uniform -- no vector load, LDS copy and barrier in front of
   // the first use)
   const WorkRec* WR = work + __builtin_amdgcn_readfirstlane(rec);
-  const int r = 3 * rfl(WR->F.ns), my_ra = 3 * rfl(WR->F.na), nchild = rfl(WR->F.nchild), child_off = rfl(WR->F.child_off);
-  const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off), ppan = rfl64(WR->F.ppan_off);
+  const int r = live ? 3 * rfl(WR->F.ns) : 0, my_ra = 3 * rfl(WR->F.na), nchild = live ? rfl(WR->F.nchild) : 0, child_off = rfl(WR->F.child_off);
+  const long long L_off = rfl64(WR->F.L_off), U_off = rfl64(WR->F.U_off), ppan = live ? rfl64(WR->F.ppan_off) : -1;
   const int p_w = 3 * rfl(WR->F.p_nc), p_r = 3 * rfl(WR->F.p_ns), my_rel = rfl(WR->F.rel_off), my_rows = rfl(WR->F.rows_off);
   const int ncb = min(nchild, MAXC);
   const double* L21 = Lbuf + L_off + kL21;
   const int i0 = ti * TS, j0 = tj * TS;
   const bool to_pan = ppan >= 0 && j0 < my_ra;                // this tile holds cells of the leading slab
+  const bool fresh = MERGED && live && rfl(WR->F.level) == level_id;   // the front is factored in this launch
   // ---- the two L21 slices and every child's row lookups: all loads first, then the LDS writes
   constexpr int LQ = TS * W / 256;                            // 6 elements of each slice per thread
   double li[LQ], lj[LQ];
+  auto load_slices = [&](bool sc1) {
 #pragma unroll
-  for (int u = 0; u < LQ; u++) {
-    const int q = tid + 256 * u;
-    const int row = q / W, k = q - row * W;
-    li[u] = (i0 + row < r) ? L21[(size_t)(i0 + row) * W + k] : 0.0;
-    lj[u] = (j0 + row < r) ? L21[(size_t)(j0 + row) * W + k] : 0.0;
-  }
+    for (int u = 0; u < LQ; u++) {
+      const int q = tid + 256 * u;
+      const int row = q / W, k = q - row * W;
+      const double* pi = L21 + (size_t)(i0 + row) * W + k;
+      const double* pj = L21 + (size_t)(j0 + row) * W + k;
+      if (sc1) {
+        li[u] = (i0 + row < r) ? __longlong_as_double((long long)__hip_atomic_load((gu64*)pi, CGMR_RLX_AGENT)) : 0.0;
+        lj[u] = (j0 + row < r) ? __longlong_as_double((long long)__hip_atomic_load((gu64*)pj, CGMR_RLX_AGENT)) : 0.0;
+      } else {
+        li[u] = (i0 + row < r) ? *pi : 0.0;
+        lj[u] = (j0 + row < r) ? *pj : 0.0;
+      }
+    }
+  };
+  if constexpr (!MERGED) load_slices(false);
   int kb[MAXC];
   const int pq = (tid < TS) ? i0 + tid : j0 + tid - TS;       // threads 0..31: tile rows, 32..63: tile columns
 #pragma unroll
@@ -537,14 +597,19 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
     kb[c] = (tid < 2 * TS && pq < r && c < ncb) ? inv[WR->ch[cs].inv_off + pq / 3] : -1;
   }
   const int myrel = (ppan >= 0 && tid < 2 * TS && pq < r) ? rel[my_rel + pq / 3] : 0;   // my position in the parent's row list (block units)
-  const double uval = (ppan >= 0 && tj == 0 && tid < TS && pq < r) ? uvec[(size_t)3 * my_rows + pq] : 0.0;
+  const bool has_u = ppan >= 0 && tj == 0 && tid < TS && pq < r;
+  double uval = 0.0;
+  if constexpr (!MERGED) uval = has_u ? uvec[(size_t)3 * my_rows + pq] : 0.0;
+  auto stage_slices = [&]() {
 #pragma unroll
-  for (int u = 0; u < LQ; u++) {
-    const int q = tid + 256 * u;
-    const int row = q / W, k = q - row * W;
-    Ai[row * LDW + k] = li[u];
-    Aj[row * LDW + k] = lj[u];
-  }
+    for (int u = 0; u < LQ; u++) {
+      const int q = tid + 256 * u;
+      const int row = q / W, k = q - row * W;
+      Ai[row * LDW + k] = li[u];
+      Aj[row * LDW + k] = lj[u];
+    }
+  };
+  if constexpr (!MERGED) stage_slices();
   if (tid < 2 * TS) {
 #pragma unroll
     for (int c = 0; c < MAXC; c++) s_k[c][tid] = (short)(kb[c] < 0 ? -1 : 3 * kb[c] + pq % 3);
@@ -554,11 +619,14 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   }
   // the front's border vector rides on the tiles of the first tile column: into the rhs row (own columns of the parent)
   // or the border-vector column (its border rows)
-  if (ppan >= 0 && tj == 0 && tid < TS && pq < r) {
-    const int pos = 3 * myrel + pq % 3;
-    double* dst = Pan + ppan + (pos < p_w ? (size_t)(W + p_r) * kPanStride + pos : (size_t)(W + pos - p_w) * kPanStride + W);
-    *dst += uval;
-  }
+  auto add_border_vector = [&]() {
+    if (has_u) {
+      const int pos = 3 * myrel + pq % 3;
+      double* dst = Pan + ppan + (pos < p_w ? (size_t)(W + p_r) * kPanStride + pos : (size_t)(W + pos - p_w) * kPanStride + W);
+      *dst += uval;
+    }
+  };
+  if constexpr (!MERGED) add_border_vector();
   __syncthreads();
   // The product on the matrix cores (round 6; a scalar fma loop over k with four LDS reads per step before: 38 us of an
   // iteration's 505, LDS-bound): wavefront (a, b) forms the 16 x 16 sub-tile (rows 16 a.., columns 16 b..) with twelve
@@ -604,6 +672,30 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
     }
   }
   }
+  if constexpr (MERGED) {
+    // ---- the front's factor: wait for its work items (this launch), then the slices and the border vector
+    if (fresh && tid == 0) {
+      const int need = max(1, (r + chunk_rows - 1) / chunk_rows);
+      const int* flag = ready + rfl(WR->F.front_id);
+      unsigned spins = 0;
+      while (__hip_atomic_load(flag, CGMR_RLX_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        // never hang the device: a wait that runs out marks the pass (status[2], like the chained backward solve's: the host
+        // repeats the iteration with one launch per kernel and level)
+        if (++spins > spin_limit || ((spins & 1023u) == 0 && __hip_atomic_load(status + 2, CGMR_RLX_AGENT) != 0)) {
+          atomicCAS(status, 0, status[1] + 1);
+          __hip_atomic_store(status + 2, 1, CGMR_RLX_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    load_slices(fresh);
+    if (has_u) uval = fresh ? __longlong_as_double((long long)__hip_atomic_load((gu64*)(uvec + (size_t)3 * my_rows + pq), CGMR_RLX_AGENT)) : uvec[(size_t)3 * my_rows + pq];
+    stage_slices();
+    add_border_vector();
+    __syncthreads();
+  }
   double4_t prod = {0.0, 0.0, 0.0, 0.0};
   {
     const double* ap = Ai + (sa + lr) * LDW + lk;
@@ -619,7 +711,9 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
   for (int c = 0; c < MAXC; c++)
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] += v[c][q];            // absent children contribute +0.0
-  // fronts with more than MAXC children: the rest one at a time (descriptor chain through the front table)
+  // fronts with more than MAXC children: the rest one at a time (descriptor chain through the front table); the host keeps
+  // such fronts' levels out of the merged launches (the barriers below would not be the same for the two halves)
+  if constexpr (!MERGED) {
   for (int ci = MAXC; ci < nchild; ci++) {
     const FrontDesc G = fronts[children[child_off + ci]];
     const int32_t* ginv = inv + G.inv_off;
@@ -639,6 +733,7 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
       acc[q] += ok ? B[(size_t)(ki - rga) * nbb + (kj - rga)] : 0.0;
     }
   }
+  }
   double* Uo = Ubuf + U_off;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -646,6 +741,50 @@ __global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict_
     if (pdst[q]) *pdst[q] = oldv[q] + acc[q];
     else Uo[uidx(gi[q], gj, r, my_ra)] = acc[q];
   }
+}
+
+template <int WW, bool BATCH>
+__global__ __launch_bounds__(256) void k_front_update(const WorkRec* __restrict__ work,
+                                                      const int32_t* __restrict__ tiles, int tile_begin,
+                                                      const FrontDesc* __restrict__ fronts,
+                                                      const int32_t* __restrict__ children,
+                                                      const int32_t* __restrict__ inv, const int32_t* __restrict__ rel,
+                                                      const double* __restrict__ Lbuf, double* __restrict__ Ubuf,
+                                                      double* __restrict__ Pan, const double* __restrict__ uvec, long long js) {
+  __shared__ UpdTileLds<WW> S;
+  front_update_tile<WW, BATCH, false>(work, tiles + 3 * (size_t)(tile_begin + blockIdx.x), fronts, children, inv, rel, Lbuf, Ubuf, Pan, uvec, js,
+                                      S, (int)threadIdx.x, nullptr, 0, 0, nullptr, 0u);
+}
+
+// One tree level in one launch (round 6): the first `nfactor` workgroups are the level's work items of the factorisation
+// (k_front_factor's), the others hold two update tiles each (k_front_update's, threads 0..255 and 256..511) that wait for
+// their front inside the launch.  What that buys: the tiles' preamble -- tile entry, work record, row maps, the children's
+// values and the parent's cells: three dependent trips to memory -- runs underneath the factorisation instead of behind
+// a kernel boundary, and the boundary goes.  The host merges a level only when every workgroup of the launch is certainly
+// resident at once (the waits cannot depend on the dispatch order) and no front of it has more than MAXC children.
+// nfactor_pad: the factor workgroups rounded up to a multiple of 8 (idle ones exit), so that tile workgroup t still runs
+// on XCD t % 8; tile workgroup t holds the tiles t and t + ntile_wg of the level's list.
+template <bool BATCH>
+__global__ __launch_bounds__(kFT, 4) void k_front_level(const WorkRec* __restrict__ work, int work_begin, int nfactor, int nfactor_pad,
+                                                     const double* __restrict__ PanR, double* __restrict__ Lbuf,
+                                                     double* __restrict__ yvec, double* __restrict__ uvec,
+                                                     int* __restrict__ status, int level_id, int write_l11c, int chunk_rows,
+                                                     const int32_t* __restrict__ tiles, int tile_begin, int ntiles, int ntile_wg,
+                                                     const FrontDesc* __restrict__ fronts, const int32_t* __restrict__ children,
+                                                     const int32_t* __restrict__ inv, const int32_t* __restrict__ rel,
+                                                     double* __restrict__ Ubuf, double* __restrict__ Pan, int* __restrict__ ready,
+                                                     unsigned spin_limit, long long js) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x < nfactor_pad) {
+    if ((int)blockIdx.x >= nfactor) return;
+    front_factor_item<BATCH, true>(work, work_begin, PanR, Lbuf, yvec, uvec, status, level_id, write_l11c, chunk_rows, js, ready, smem);
+    return;
+  }
+  UpdTileLds<kFrontW>* S2 = reinterpret_cast<UpdTileLds<kFrontW>*>(smem);
+  const int half = (int)threadIdx.x >> 8, t = (int)blockIdx.x - nfactor_pad + half * ntile_wg;
+  const int32_t* tl = t < ntiles ? tiles + 3 * (size_t)(tile_begin + t) : nullptr;
+  front_update_tile<kFrontW, BATCH, true>(work, tl, fronts, children, inv, rel, Lbuf, Ubuf, Pan, uvec, js, S2[half], (int)threadIdx.x & 255,
+                                          ready, level_id, chunk_rows, status, spin_limit);
 }
 
 // L11^-1 of a front, in place in LDS (for the chained backward solve, 48 columns): Z = L^-1 is lower triangular like L, and
@@ -1013,9 +1152,6 @@ constexpr int bwd_smem_bytes(int w, bool lds_l11) { return ((lds_l11 ? w * w : 0
 // the others with agent-scope loads (sc1: past the L1, which another CU's stores never refresh), re-reading any that is
 // not there yet.  (A separate flag behind an s_waitcnt vmcnt(0) drain costs 0.3 us more per hop.)  The launch is at most 2 workgroups per CU (the host
 // picks the levels), so every workgroup is resident whatever the dispatch order; the spin is bounded all the same.
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) unsigned int gu32;
-#define CGMR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 template <int WW, int CHAIN, bool BATCH>
 __global__ __launch_bounds__(256, CHAIN ? CHAIN : 1) void k_solve_bwd(const FrontDesc* __restrict__ fronts_lv, int level_begin,
                                                    const int32_t* __restrict__ rows, const double* __restrict__ Lbuf,
@@ -1294,7 +1430,7 @@ void launch_chi2(hipStream_t st, const GnDevice& D, double* out) {
 void launch_assemble(hipStream_t st, const GnDevice& D) {
   int total = (D.nf + D.nb) * 9 + D.nf * 3;
   hipLaunchKernelGGL(CGMR_KERN(D, k_assemble), dim3((total + 255) / 256 + 1, 1, D.njobs), dim3(256), 0, st, D.nf, D.nb, D.nE, D.asm_ptr,
-                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.nfronts, D.xvec, D.job_stride);
+                     D.asm_src, D.blk_dst, D.b_dst, D.cmask, D.off_row, D.off_col, D.term, D.Ablk, D.Pan, D.bvec, D.chi2, D.status, D.nfronts, D.xvec, D.ready, D.job_stride);
 }
 
 // one-time kernel attributes (dynamic LDS above 64 KB): once per HIP device of the process (the attribute belongs to
@@ -1306,6 +1442,8 @@ void gn_init_kernels() {
   std::call_once(once[dev & 63], [] {
     for (const void* f : {reinterpret_cast<const void*>(k_front_factor<false>), reinterpret_cast<const void*>(k_front_factor<true>)})
       (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, factor_smem_bytes(kChunkRows + 1));
+    for (const void* f : {reinterpret_cast<const void*>(k_front_level<false>), reinterpret_cast<const void*>(k_front_level<true>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(factor_smem_bytes(kChunkRows + 1), 2 * (int)sizeof(UpdTileLds<kFrontW>)));
     for (const void* f : {reinterpret_cast<const void*>(k_linearize<false>), reinterpret_cast<const void*>(k_linearize<true>)})
       (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 33 * (int)sizeof(double));
     for (const void* f : {reinterpret_cast<const void*>(k_top_block<false>), reinterpret_cast<const void*>(k_top_block<true>)})
@@ -1326,6 +1464,52 @@ void launch_update_level(hipStream_t st, const GnDevice& D, int l) {
   if (nt <= 0) return;
   hipLaunchKernelGGL((D.njobs > 1 ? k_front_update<kFrontW, true> : k_front_update<kFrontW, false>), dim3(nt, 1, D.njobs), dim3(256), 0, st, D.work, D.tiles, D.h_tile_ptr[l], D.fronts, D.children,
                      D.inv, D.rel, D.Lbuf, D.Ubuf, D.Pan, D.uvec, D.job_stride);
+}
+
+// A level's factorisation and its update tiles in one launch (k_front_level); D.h_level_merge[l] says the level qualifies
+int level_merge_smem(const GnDevice& D, int l) { return std::max(factor_smem_bytes(D.h_level_chrows[l]), 2 * (int)sizeof(UpdTileLds<kFrontW>)); }
+void launch_front_level(hipStream_t st, const GnDevice& D, int l, bool write_l11c) {
+  gn_init_kernels();
+  const int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l], nt = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
+  const int nw_pad = (nw + 7) / 8 * 8, ntw = ((nt + 1) / 2 + 7) / 8 * 8;
+  const char* sl = getenv("CGMR_BWD_SPIN_LIMIT");               // (the tests' switch for the chained backward solve bounds these waits as well)
+  const unsigned spin_limit = sl ? (unsigned)std::max(1, atoi(sl)) : (1u << 22);
+  hipLaunchKernelGGL(CGMR_KERN(D, k_front_level), dim3(nw_pad + ntw, 1, D.njobs), dim3(kFT), level_merge_smem(D, l), st, D.work, D.h_work_ptr[l], nw, nw_pad,
+                     D.Pan, D.Lbuf, D.yvec, D.uvec, D.status, l, write_l11c ? 1 : 0, D.h_level_chunk[l], D.tiles, D.h_tile_ptr[l], nt, ntw,
+                     D.fronts, D.children, D.inv, D.rel, D.Ubuf, D.Pan, D.ready, spin_limit, D.job_stride);
+}
+// workgroups of a merged level's launch (0: the level has no tiles)
+int level_merge_wgs(const GnDevice& D, int l) {
+  const int nw = D.h_work_ptr[l + 1] - D.h_work_ptr[l], nt = D.h_tile_ptr[l + 1] - D.h_tile_ptr[l];
+  return nt > 0 && nw > 0 ? (nw + 7) / 8 * 8 + ((nt + 1) / 2 + 7) / 8 * 8 : 0;
+}
+// Which levels run merged: those whose launch is certainly resident at once (occupancy query x CUs, shared with `slots_div`
+// others) and that the analysis did not rule out (h_level_mergeable: a front with more than MAXC children).  CGMR_FWD_MERGE=0: none.
+void choose_fwd_merge(GnDevice& D, int slots_div, bool off) {
+  static const bool env_on = !(getenv("CGMR_FWD_MERGE") && atoi(getenv("CGMR_FWD_MERGE")) == 0);
+  static int per_cu[64][4];                                   // resident workgroups per CU by LDS class (<= 40, 53, 80, 160 KB)
+  static std::once_flag once[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 63;
+  gn_init_kernels();
+  std::call_once(once[dev], [dev] {
+    const int lds[4] = {40 * 1024, 53 * 1024, 80 * 1024, 160 * 1024};
+    for (int q = 0; q < 4; q++) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_front_level<false>), kFT, lds[q]) != hipSuccess) nb = 0;
+      per_cu[dev][q] = std::max(0, std::min(nb, 2));
+    }
+  });
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+  D.h_level_merge.assign(D.nlevels, 0);
+  if (!env_on || off || kFrontW != 48) return;
+  for (int l = 0; l < D.nlevels; l++) {
+    const int wgs = level_merge_wgs(D, l), sm = level_merge_smem(D, l);
+    const int cls = sm <= 40 * 1024 ? 0 : sm <= 53 * 1024 ? 1 : sm <= 80 * 1024 ? 2 : 3;
+    if (wgs > 0 && l < (int)D.h_level_mergeable.size() && D.h_level_mergeable[l] && wgs <= per_cu[dev][cls] * ncu / std::max(1, slots_div)) D.h_level_merge[l] = 1;
+  }
 }
 
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int l) {

@@ -720,6 +720,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       // (after a time-out -- two chained solves per context on eight contexts of one device make them likelier -- the batches of
       // this graph solve level by level: no in-kernel waits, like gn_run's retry)
       choose_bwd_chain(DB, (ctx->side_used ? 2 : 1) * nj, g->cond_levelwise);
+      choose_fwd_merge(DB, (ctx->side_used ? 2 : 1) * nj, g->cond_levelwise);
     }
     run_guesses([&](int i) { return (double*)(hstage + s_work + (size_t)24 * nV * i); });
     const double tm0 = wall_s();
