@@ -286,6 +286,9 @@ __device__ unsigned long long g_wtime[2 * 8192];          // per work item of k_
 __device__ unsigned long long g_fphase[8 * 8192];         // per work item: cycle counter at the steps of the blocked factorisation
 __device__ unsigned long long g_utime[2 * 64];             // per level of k_front_update: min start / max end
 __device__ unsigned long long g_tphase[16];                // k_top_block, the block's own workgroup: cycle counter at its marks
+__device__ unsigned long long g_ltime[8 * 64];             // k_front_level, per level: 100 MHz clock -- min start, max of: factor item signalled, tile at its wait, tile saw the flag, slices staged, tile done
+#define LTIME_MAX(i) do { if ((threadIdx.x & 255) == 0 && level_id < 64) atomicMax(&g_ltime[8 * level_id + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define LTIME_MIN(i) do { if ((threadIdx.x & 255) == 0 && level_id < 64) atomicMin(&g_ltime[8 * level_id + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
 __device__ unsigned long long g_btime[8 * 8192];           // k_solve_bwd (chained), per front: 100 MHz clock at start / L11 inverted / x of the border there / own x stored
 #define BTIME(i) do { if (CHAIN && threadIdx.x == 0 && F.front_id < 8192) g_btime[8 * F.front_id + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define TPHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_tphase[i] = __builtin_readcyclecounter(); } while (0)
@@ -296,6 +299,8 @@ __device__ unsigned long long g_btime[8 * 8192];           // k_solve_bwd (chain
 #define FPHASE(i)
 #define TPHASE(i)
 #define BTIME(i)
+#define LTIME_MAX(i)
+#define LTIME_MIN(i)
 #endif
 
 constexpr int MAXC = kWorkChildren;  // children whose descriptors ride in the work record
@@ -491,6 +496,7 @@ __device__ __forceinline__ void front_factor_item(const WorkRec* __restrict__ wo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(ready + WR->F.front_id, 1, CGMR_RLX_AGENT);
+    LTIME_MAX(1);
   }
   PHASE(5);
 #ifdef CGMR_PHASE_TIMING
@@ -619,13 +625,14 @@ __device__ __forceinline__ void front_update_tile(const WorkRec* __restrict__ wo
   }
   // the front's border vector rides on the tiles of the first tile column: into the rhs row (own columns of the parent)
   // or the border-vector column (its border rows)
-  auto add_border_vector = [&]() {
-    if (has_u) {
-      const int pos = 3 * myrel + pq % 3;
-      double* dst = Pan + ppan + (pos < p_w ? (size_t)(W + p_r) * kPanStride + pos : (size_t)(W + pos - p_w) * kPanStride + W);
-      *dst += uval;
-    }
-  };
+  double* udst = nullptr;
+  double uold = 0.0;
+  if (has_u) {
+    const int pos = 3 * myrel + pq % 3;
+    udst = Pan + ppan + (pos < p_w ? (size_t)(W + p_r) * kPanStride + pos : (size_t)(W + pos - p_w) * kPanStride + W);
+    uold = *udst;                                             // (one writer per cell and launch: the old value can be fetched at once)
+  }
+  auto add_border_vector = [&]() { if (has_u) *udst = uold + uval; };
   if constexpr (!MERGED) add_border_vector();
   __syncthreads();
   // The product on the matrix cores (round 6; a scalar fma loop over k with four LDS reads per step before: 38 us of an
@@ -673,7 +680,20 @@ __device__ __forceinline__ void front_update_tile(const WorkRec* __restrict__ wo
   }
   }
   if constexpr (MERGED) {
+    // (the children's values are on their way since the launch began: added up now, in child order, so that four sums instead of
+    // thirty-two values wait in registers -- the kernel lives on 128 VGPRs and spilled the parent's old cells otherwise: three
+    // scratch reloads one behind the other in front of the tile's stores)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      double cs = v[0][q];
+#pragma unroll
+      for (int c = 1; c < MAXC; c++) cs += v[c][q];
+      v[0][q] = cs;
+#pragma unroll
+      for (int c = 1; c < MAXC; c++) v[c][q] = 0.0;
+    }
     // ---- the front's factor: wait for its work items (this launch), then the slices and the border vector
+    if (live) { LTIME_MIN(0); LTIME_MAX(2); }
     if (fresh && tid == 0) {
       const int need = max(1, (r + chunk_rows - 1) / chunk_rows);
       const int* flag = ready + rfl(WR->F.front_id);
@@ -690,11 +710,13 @@ __device__ __forceinline__ void front_update_tile(const WorkRec* __restrict__ wo
       }
     }
     __syncthreads();
+    if (live) LTIME_MAX(3);
     load_slices(fresh);
     if (has_u) uval = fresh ? __longlong_as_double((long long)__hip_atomic_load((gu64*)(uvec + (size_t)3 * my_rows + pq), CGMR_RLX_AGENT)) : uvec[(size_t)3 * my_rows + pq];
     stage_slices();
     add_border_vector();
     __syncthreads();
+    if (live) LTIME_MAX(4);
   }
   double4_t prod = {0.0, 0.0, 0.0, 0.0};
   {
@@ -708,9 +730,9 @@ __device__ __forceinline__ void front_update_tile(const WorkRec* __restrict__ wo
   }
   double acc[4] = {-prod[0], -prod[1], -prod[2], -prod[3]};
 #pragma unroll
-  for (int c = 0; c < MAXC; c++)
+  for (int c = 0; c < (MERGED ? 1 : MAXC); c++)
 #pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] += v[c][q];            // absent children contribute +0.0
+    for (int q = 0; q < 4; q++) acc[q] += v[c][q];            // absent children contribute +0.0 (MERGED: the children's sum)
   // fronts with more than MAXC children: the rest one at a time (descriptor chain through the front table); the host keeps
   // such fronts' levels out of the merged launches (the barriers below would not be the same for the two halves)
   if constexpr (!MERGED) {
@@ -741,6 +763,7 @@ __device__ __forceinline__ void front_update_tile(const WorkRec* __restrict__ wo
     if (pdst[q]) *pdst[q] = oldv[q] + acc[q];
     else Uo[uidx(gi[q], gj, r, my_ra)] = acc[q];
   }
+  if constexpr (MERGED) { if (live) LTIME_MAX(5); }
 }
 
 template <int WW, bool BATCH>
@@ -1602,6 +1625,14 @@ void launch_update(hipStream_t st, const GnDevice& D, double* poses) {
 #ifdef CGMR_PHASE_TIMING
 extern "C" int cgmr_debug_topphase(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_tphase), sizeof(unsigned long long) * 16);
+}
+extern "C" int cgmr_debug_leveltimes(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[8 * 64];
+    for (int l = 0; l < 64; l++) { z[8 * l] = ~0ull; for (int q = 1; q < 8; q++) z[8 * l + q] = 0; }
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(cgmr::g_ltime), z, sizeof z);
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_ltime), sizeof(unsigned long long) * 8 * 64);
 }
 extern "C" int cgmr_debug_bwdtimes(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cgmr::g_btime), sizeof(unsigned long long) * 8 * 8192);

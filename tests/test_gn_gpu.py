@@ -257,7 +257,11 @@ def test_backward_solve_timeout_is_not_a_cholesky_failure(oracle):
     assert rc == 0 and st == 0
     assert c.gn_timeouts() >= 1, "the forced time-out did not happen: the test checks nothing"
     _check(p, chi, p2, chi2)
-    np.testing.assert_allclose(chi, chi0, rtol=1e-9)
+    # (the repeated iterations run the separate launches: other summation orders than the merged level launches and the chained
+    # solve -- children's values pre-summed, Z^T v instead of a substitution --, so intermediate chi2 values of this far-from-optimum
+    # start agree to rounding times the conditioning, the converged one much closer)
+    np.testing.assert_allclose(chi, chi0, rtol=CHI_RTOL)
+    np.testing.assert_allclose(chi[-1], chi0[-1], rtol=1e-10)
     rc, p, chi = c.gn_optimize(*a, 6)                        # and the chained launch is back afterwards
     assert rc == 0 and np.array_equal(chi, chi0)
 
