@@ -95,7 +95,7 @@ def rocprof_c2_stats():
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get("Name", "")
-            for key in ("k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_assemble", "k_linearize"):
+            for key in ("k_front_level", "k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_assemble", "k_linearize"):
                 if key in name and "leaf" not in name and key not in out:
                     out[key] = {"calls": int(row["Calls"]), "avg_us": round(float(row["AverageNs"]) / 1e3, 2)}
     return out
@@ -770,30 +770,33 @@ def main():
         step()
     kt = ctx.gn_kernel_times()
     ctx.set_profiling(False)
-    ff_s, ff_n = kt["front_factor"]
     total_k = sum(v[0] for v in kt.values())
     dominant = max(kt.items(), key=lambda kv: kv[1][0])[0]
-    # algorithmic HBM bytes of one factorisation pass of k_front_factor (DESIGN.md "roofline"): read every front's
-    # assembled panel once (8 B per double of F11, the border rows, the rhs row and the border-vector column, every copy),
-    # write the factor panels (8 B per stored double; the column-major copy of L11 is only written for the marginals:
-    # 48*48 doubles per front less)
-    l_written = info["L_doubles"] - 48 * 48 * info["fronts"]
-    layout_bytes_factor_iter = 8 * l_written + 8 * info["panel_doubles"]       # what THIS layout moves (rounds 1-3 priced on it)
-    # Round 4: a numerator that does not move when the data layout does.  What the factorisation of a front must touch
-    # whatever the layout: read its pivot block column of the frontal matrix -- the lower triangle of F11 (w columns), F21
-    # (r x w) and the w right-hand-side entries that ride along -- and write the same cells of the factor (L11, L21, y).
+    # The dominant kernel since round 6: k_front_level -- one tree level per launch, the level's work items of the factorisation
+    # and its update tiles together (the levels whose launch is certainly resident at once; the levels below them keep
+    # k_front_factor + k_front_update).  Algorithmic HBM bytes of the forward pass, layout-independent:
+    #   factorisation of a front: read its pivot block column of the frontal matrix -- lower triangle of F11 (w columns), F21
+    #   (r x w), the w right-hand-side entries that ride along -- and write the same cells of the factor: 2 * 8 * cells;
+    #   its update matrix: L21 read back (8 r w), the lower triangle of U and the border vector written once (8 (r (r + 1) / 2 + r)).
     # w = 3 * (poses of the front), r = 3 * (border poses): no 48-column padding, no panel copies, no zero rows.
     ft = gn_front_table(V, fixed, ef, et)
     w_f, r_f = 3 * ft[:, 1].astype(np.int64), 3 * ft[:, 2].astype(np.int64)
     in_top = np.zeros(len(ft), dtype=bool)
     if info["top_block_fronts"] > 0:
-        in_top[-info["top_block_fronts"]:] = True                              # (the root chain's last fronts: k_top_block's, not this kernel's)
+        in_top[-info["top_block_fronts"]:] = True                              # (the root chain's last fronts: k_top_block's, not these kernels')
     cells = (w_f * (w_f + 1) // 2 + r_f * w_f + w_f)[~in_top]
+    upd = (r_f * w_f + r_f * (r_f + 1) // 2 + r_f)[~in_top]
     bytes_factor_iter = int(2 * 8 * cells.sum())
-    launches_per_iter = ff_n / (nprof * GN_ITERS)
-    avg_launch_s = ff_s / max(ff_n, 1)
-    bytes_per_launch = bytes_factor_iter / max(launches_per_iter, 1)
-    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    bytes_update_iter = int(8 * upd.sum())
+    fwd_s = kt["front_level"][0] + kt["front_factor"][0] + kt["front_update"][0]
+    fwd_n = kt["front_level"][1] + kt["front_factor"][1] + kt["front_update"][1]
+    levels_per_iter = (kt["front_level"][1] + kt["front_factor"][1]) / (nprof * GN_ITERS)      # one factorisation launch per level, merged or not
+    level_s = fwd_s / max(kt["front_level"][1] + kt["front_factor"][1], 1)                     # forward-pass time per tree level
+    bytes_per_level = (bytes_factor_iter + bytes_update_iter) / max(levels_per_iter, 1)
+    achieved = bytes_per_level / level_s / 1e9 if level_s > 0 else 0.0
+    merged_us = 1e6 * kt["front_level"][0] / max(kt["front_level"][1], 1)
+    l_written = info["L_doubles"] - 2 * 48 * 48 * info["fronts"]              # (the column-major copy of L11 is only written for the marginals; L11^-1 by the top-block launch)
+    layout_bytes_factor_iter = 8 * l_written + 8 * info["panel_doubles"]       # what THIS layout moves in the factorisation (rounds 1-3 priced on it)
     # SURVEY.md 8(d)'s whole-iteration figure: B_iter = 96 V + 80 E + 144 (V + E) bytes of graph / Hessian / rhs traffic plus
     # read + write of the stored factor, over the device time of one Gauss-Newton iteration
     b_iter = 96 * V + 80 * E + 144 * (V + E)
@@ -802,33 +805,48 @@ def main():
     b_iter_gbs = (b_iter + 2 * 8 * l_cells) / (dev_ms_iter * 1e-3) / 1e9
     rocprof = rocprof_c2_stats()
     pmc = pmc_traffic()
-    per_level_us = {k: round(1e6 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if k in ("front_factor", "front_update", "solve_bwd")}
+    per_level_us = {k: round(1e6 * v[0] / max(v[1], 1), 2) for k, v in kt.items() if k in ("front_level", "front_factor", "front_update", "solve_bwd", "top_block")}
+    merged_levels = kt["front_level"][1] / (nprof * GN_ITERS)
+    rp_level = None
+    if rocprof and "k_front_level" in rocprof:
+        # the same numerator over the committed rocprofv3 averages of the C2 solve alone (per tree level: merged launches and the
+        # factor + update pairs of the levels below them)
+        t = rocprof["k_front_level"]["calls"] * rocprof["k_front_level"]["avg_us"]
+        n = rocprof["k_front_level"]["calls"]
+        if "k_front_factor" in rocprof:
+            t += rocprof["k_front_factor"]["calls"] * rocprof["k_front_factor"]["avg_us"]
+            n += rocprof["k_front_factor"]["calls"]
+        if "k_front_update" in rocprof:
+            t += rocprof["k_front_update"]["calls"] * rocprof["k_front_update"]["avg_us"]
+        rp_level = round(bytes_per_level / (t / max(n, 1) * 1e-6) / 8e12, 6)
     roofline = {
-        "kernel": "k_front_factor", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+        "kernel": "k_front_level" if merged_levels > 0 else "k_front_factor", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 6),
-        "traffic": pmc.get("k_front_factor", {}).get("traffic_bytes_corrected"),
+        "traffic": pmc.get("k_front_level", pmc.get("k_front_factor", {})).get("traffic_bytes_corrected"),
         "traffic_source": pmc.get("_source"), "traffic_stale": pmc.get("_stale"),
-        "avg_launch_us": round(1e6 * avg_launch_s, 2), "launches_per_gn_iter": round(launches_per_iter, 1),
+        "avg_launch_us": round(1e6 * level_s, 2), "launches_per_gn_iter": round(fwd_n / (nprof * GN_ITERS), 1),
+        "avg_launch_us_definition": "forward-pass time per tree level (HIP events): a merged launch (k_front_level), or the k_front_factor + "
+                                    "k_front_update pair of a level too large to be resident at once",
+        "merged_levels_per_gn_iter": round(merged_levels, 1), "merged_level_launch_us": round(merged_us, 2),
         "tree_levels": info["levels"], "launched_levels": info["launch_levels"], "top_block_columns": info["top_block_cols"],
         "per_level_us": per_level_us,
-        "algorithmic_bytes_per_launch": int(bytes_per_launch),
-        "algorithmic_bytes_definition": "per front: read + write of its pivot block column -- lower triangle of F11, F21, right-hand side -- at "
-                                        "its true width (no padding, no panel copies); layout-independent since round 4",
-        "layout_bytes_per_launch": int(layout_bytes_factor_iter / max(launches_per_iter, 1)),
-        "frac_on_layout_bytes": round(layout_bytes_factor_iter / max(launches_per_iter, 1) / avg_launch_s / 8e12, 6) if avg_launch_s > 0 else None,
+        "algorithmic_bytes_per_launch": int(bytes_per_level),
+        "algorithmic_bytes_definition": "per tree level; per front: read + write of its pivot block column -- lower triangle of F11, F21, "
+                                        "right-hand side -- at its true width (no padding, no panel copies), L21 read back by the update "
+                                        "tiles, the update matrix's lower triangle and the border vector written once",
+        "algorithmic_bytes_per_gn_iter": {"factorisation": bytes_factor_iter, "update_matrices": bytes_update_iter},
+        "layout_bytes_factor_per_level": int(layout_bytes_factor_iter / max(levels_per_iter, 1)),
         "B_iter_frac": round(b_iter_gbs / 8000.0, 6),
         "B_iter": {"bytes_graph_hessian_rhs": int(b_iter), "factor_cells": l_cells, "device_ms_per_gn_iteration": round(dev_ms_iter, 4),
                    "achieved_GBps": round(b_iter_gbs, 2),
                    "definition": "(96 V + 80 E + 144 (V + E) + 2 * 8 * stored factor cells) / device time of one GN iteration / 8 TB/s (SURVEY.md 8d)"},
         "rocprofv3": rocprof,
-        # the same numerator over the committed rocprofv3 average of the C2 solve alone (kernel time without the launch gaps the
-        # HIP-event pairs of the live figure bracket)
-        "frac_on_rocprofv3_avg": (round(bytes_per_launch / (rocprof["k_front_factor"]["avg_us"] * 1e-6) / 8e12, 6)
-                                  if rocprof and "k_front_factor" in rocprof else None),
-        "share_of_kernel_time": round(ff_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
-        "note": f"latency-bound: {info['launch_levels']} dependent tree levels (+ the top block), per level one contiguous panel load, three "
-                "elimination passes of FP64 pivot chains and the stores; traffic_stale = the PMC passes under profiles/ were taken on "
-                "other kernel sources than the ones running now; see DESIGN.md 2.3",
+        "frac_on_rocprofv3_avg": rp_level,
+        "share_of_kernel_time": round(fwd_s / total_k, 3) if total_k > 0 else None, "dominant_by_events": dominant,
+        "note": f"latency-bound: {info['launch_levels']} dependent tree levels (+ the top block); per level a work record, one contiguous panel "
+                "load, three elimination passes of FP64 pivot chains, the write-through stores of L21, the tiles' wait inside the launch, their "
+                "L21 slices (a trip to memory), twelve FP64 MFMA per 16 x 16 sub-tile and the stores; traffic_stale = the PMC passes under "
+                "profiles/ were taken on other kernel sources than the ones running now; see DESIGN.md 2.3",
     }
 
     cpu = None

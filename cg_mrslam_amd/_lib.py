@@ -38,7 +38,7 @@ def build_library(force: bool = False) -> str:
 _SYMBOLS = [
     "cgmr_version", "cgmr_ctx_create", "cgmr_ctx_destroy", "cgmr_last_error", "cgmr_ctx_synchronize",
     "cgmr_gn_optimize", "cgmr_gn_optimize_dev", "cgmr_gn_symbolic_info", "cgmr_gn_last_timing",
-    "cgmr_set_profiling", "cgmr_gn_kernel_times",
+    "cgmr_set_profiling", "cgmr_gn_kernel_times", "cgmr_gn_kernel_times_ex",
 ]
 
 
@@ -211,10 +211,10 @@ class Context:
         self._check(self.lib.cgmr_set_profiling(self.h, C.c_int(1 if on else 0)))
 
     def gn_kernel_times(self):
-        sec = np.zeros(8)
-        n = np.zeros(8, dtype=np.int64)
-        self._check(self.lib.cgmr_gn_kernel_times(self.h, _ptr(sec), _ptr(n)))
-        names = ["linearize", "assemble", "chi2", "front_factor", "front_update", "top_block", "solve_bwd", "update"]
+        sec = np.zeros(12)
+        n = np.zeros(12, dtype=np.int64)
+        self._check(self.lib.cgmr_gn_kernel_times_ex(self.h, _ptr(sec), _ptr(n)))
+        names = ["linearize", "assemble", "chi2", "front_factor", "front_update", "top_block", "solve_bwd", "update", "front_level"]
         return {k: (float(s), int(c)) for k, s, c in zip(names, sec, n)}
 
 

@@ -510,7 +510,7 @@ struct KTimer {   // optional per-launch-class timing (profiling mode only)
   void run(int cls, int nlaunch, Fn&& fn) {
     static const bool trace = getenv("CGMR_TRACE_LAUNCHES") != nullptr;      // debugging aid: name every launch, sync after it
     if (trace) {
-      fprintf(stderr, "[cgmr] launch class %d (0 lin 1 asm 2 chi2 3 factor 4 update 6 bwd 7 poses)\n", cls);
+      fprintf(stderr, "[cgmr] launch class %d (0 lin 1 asm 2 chi2 3 factor 4 update 5 top 6 bwd 7 poses 8 factor+update)\n", cls);
       fn();
       hipError_t e = hipStreamSynchronize(st);
       fprintf(stderr, "[cgmr]   done: %s\n", hipGetErrorString(e));
@@ -574,7 +574,7 @@ void gn_pass_on(cgmr_ctx* ctx, GnDevice& D, hipStream_t st, double* d_poses, con
       fprintf(stderr, "[cgmr] level %d: %d fronts, %d work items, max r %d, max child rows %d\n", l,
               D.h_level_ptr[l + 1] - D.h_level_ptr[l], D.h_work_ptr[l + 1] - D.h_work_ptr[l], maxr, maxc);
     }
-    if (l < (int)D.h_level_merge.size() && D.h_level_merge[l]) { T.run(3, 1, [&] { launch_front_level(st, D, l, write_l11c); }); continue; }
+    if (l < (int)D.h_level_merge.size() && D.h_level_merge[l]) { T.run(8, 1, [&] { launch_front_level(st, D, l, write_l11c); }); continue; }
     T.run(3, 1, [&] { launch_factor_level(st, D, l, write_l11c); });
     if (D.h_tile_ptr[l + 1] > D.h_tile_ptr[l]) T.run(4, 1, [&] { launch_update_level(st, D, l); });
   }
@@ -1055,6 +1055,15 @@ int cgmr_gn_kernel_times(const cgmr_ctx* ctx, double seconds_out[8], int64_t lau
   if (!ctx || !seconds_out || !launches_out) return CGMR_E_INVALID;
   memcpy(seconds_out, ctx->ksec, sizeof(double) * 8);
   memcpy(launches_out, ctx->klaunch, sizeof(int64_t) * 8);
+  return CGMR_OK;
+}
+
+// the same with the classes beyond the first eight: 8 = front_level (k_front_level: a tree level's factorisation and its update
+// tiles in one launch); classes 9..11 are reserved (zero)
+extern "C" int cgmr_gn_kernel_times_ex(const cgmr_ctx* ctx, double seconds_out[12], int64_t launches_out[12]) {
+  if (!ctx || !seconds_out || !launches_out) return CGMR_E_INVALID;
+  memcpy(seconds_out, ctx->ksec, sizeof(double) * 12);
+  memcpy(launches_out, ctx->klaunch, sizeof(int64_t) * 12);
   return CGMR_OK;
 }
 

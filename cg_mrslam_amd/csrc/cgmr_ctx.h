@@ -72,8 +72,8 @@ struct cgmr_ctx {
   int64_t match_redo_why[3] = {0, 0, 0};           // ... by cause: grid, window / point count, an angle's lists
   int64_t match_redo_pairs = 0;                    // ... pairs the lean kernel instance handed to the general one
   bool profiling = false;
-  double ksec[8] = {0};
-  int64_t klaunch[8] = {0};
+  double ksec[12] = {0};        // classes 0..7 as cgmr_gn_kernel_times, 8 = front_level (a level's factorisation + update tiles in one launch)
+  int64_t klaunch[12] = {0};
   // profiling mode: one event pair per launch, recorded without synchronising (the stream stays busy, so a pair
   // brackets the kernel and not an idle-to-busy launch latency); read back by profile_collect() after the final sync
   std::vector<hipEvent_t> ev_pool;

@@ -152,6 +152,9 @@ int cgmr_gn_last_timing(const cgmr_ctx* ctx, double out[5]);
  * seconds_out[8], launches_out[8] are accumulated since profiling was switched on.       */
 int cgmr_set_profiling(cgmr_ctx* ctx, int on);
 int cgmr_gn_kernel_times(const cgmr_ctx* ctx, double seconds_out[8], int64_t launches_out[8]);
+/* ... with the classes added since: 8 front_level = a tree level's factorisation AND its update tiles in one launch
+ * (k_front_level, round 6: the levels whose launch is certainly resident at once); 9..11 reserved.                    */
+int cgmr_gn_kernel_times_ex(const cgmr_ctx* ctx, double seconds_out[12], int64_t launches_out[12]);
 
 /* ------------------------------------------------------------------------------------------
  * Correlative scan matcher.

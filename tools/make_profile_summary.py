@@ -47,7 +47,7 @@ def avg(k, c):
     if k == "k_match_close_batch" and any(q[0] in (k + "<1>", k + "<2>") for q in keys): keys = [q for q in keys if q[0] != k + "<0>"]
     return sum(acc[q] for q in keys) / max(sum(n[q] for q in keys), 1), sum(n[q] for q in keys)
 traffic = {}
-for k in ("k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_assemble", "k_linearize", "k_match_close_batch"):
+for k in ("k_front_level", "k_front_factor", "k_front_update", "k_solve_bwd", "k_top_block", "k_assemble", "k_linearize", "k_match_close_batch"):
     (fe, nl), (wr, _) = avg(k, "FETCH_SIZE"), avg(k, "WRITE_SIZE")
     fe, wr = fe * 1024, wr * 1024                                          # rocprofv3 reports KB
     traffic[k] = {"fetch_bytes_raw": round(fe), "write_bytes_raw": round(wr),
@@ -146,8 +146,8 @@ if bench is not None:
     r = bench["roofline"]
     L += ["## The bench line of the same sources (profiles/" + rnd + "_bench_line.json; under the profiler: kernel-trace + stats)", "",
           f"* value {bench['value']} {bench['unit']}, {bench['ms_per_step']} ms per step (host analysis {bench['host_symbolic_ms_per_step']} ms, device {bench['device_ms_per_step']} ms), host load {bench.get('host_loadavg_1min')}",
-          f"* `k_front_factor`: {r['avg_launch_us']} us per launch by HIP events, {r['launches_per_gn_iter']} launches per GN iteration; algorithmic {r['algorithmic_bytes_per_launch']:,} B per launch "
-          f"-> {r['achieved']} GB/s = {r['frac']} of 8 TB/s (on the layout's bytes, {r.get('layout_bytes_per_launch')}: {r.get('frac_on_layout_bytes')}); B_iter_frac {r.get('B_iter_frac')}",
+          f"* `{r['kernel']}`: {r['avg_launch_us']} us per tree level by HIP events ({r.get('merged_levels_per_gn_iter')} of {r.get('launched_levels')} levels as one merged launch of {r.get('merged_level_launch_us')} us), {r['launches_per_gn_iter']} forward-pass launches per GN iteration; algorithmic {r['algorithmic_bytes_per_launch']:,} B per level "
+          f"-> {r['achieved']} GB/s = {r['frac']} of 8 TB/s (on the committed rocprofv3 averages: {r.get('frac_on_rocprofv3_avg')}); B_iter_frac {r.get('B_iter_frac')}",
           f"* matcher {bench['matcher']['value']:,.0f} pairs/s (pruned search), {bench['matcher']['exhaustive']['pairs_per_s']:,.0f} exhaustive; LDS-gather roofline fraction {bench['matcher']['roofline']['frac']}",
           f"* C5: one robot alone {bench['exchange']['round_ms_mean_max']} ms per round; eight robots on this GPU {bench['exchange_loopback']['round_ms_per_robot']} ms per robot and round "
           f"(the same robots alone {bench['exchange_loopback']['solo_round_ms_same_robots']['mean']} ms): predicted_weak_scaling_efficiency_8 {bench.get('predicted_weak_scaling_efficiency_8')}", ""]
