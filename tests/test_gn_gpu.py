@@ -274,3 +274,38 @@ def test_hand_worked_gauss_newton_step_on_gpu(ctx):
     assert rc == 0
     assert abs(chi2[0] - K.GN_CHI2_BEFORE) < 1e-10
     assert np.abs(poses - K.GN_POSES_AFTER).max() < 1e-12
+
+
+def test_launch_variants_of_round_6_agree(oracle):
+    """Round 6: a tree level's factorisation and update tiles in one launch (k_front_level; CGMR_FWD_MERGE=0: two launches) and
+    the two instances of the chained backward solve (CGMR_BWD_CHAIN_WGS = 2 / 4: rows of L21 per thread, workgroups per CU).  The
+    switches are read once per process, hence the child processes; every variant must meet the oracle at the suite's
+    tolerances, on a graph whose tree fits two workgroups per CU and on one that does not."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "import numpy as np\nfrom cg_mrslam_amd import synth, Context\n"
+            "out = {}\nc = Context(0)\n"
+            "for V, E, seed in ((2500, 9000, 5), (9000, 30000, 11)):\n"
+            "    g = synth.make_pose_graph(V, E, seed=seed)\n"
+            "    rc, p, chi = c.gn_optimize(g['poses'], g['fixed'], g['edge_from'], g['edge_to'], g['meas'], g['info'], 6)\n"
+            "    out[str(V)] = {'rc': int(rc), 'chi': [float(x) for x in chi], 'p': p.tolist(), 'timeouts': int(c.gn_timeouts())}\n"
+            "print('RESULT' + json.dumps(out))\n" % root)
+    res = {}
+    for name, env in (("default", {}), ("separate_launches", {"CGMR_FWD_MERGE": "0"}), ("chain_wgs_2", {"CGMR_BWD_CHAIN_WGS": "2"}),
+                      ("chain_wgs_4", {"CGMR_BWD_CHAIN_WGS": "4"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, (name, r.stderr[-2000:])
+        res[name] = json.loads(line[-1][len("RESULT"):])
+    for V, E, seed in ((2500, 9000, 5), (9000, 30000, 11)):
+        g = synth.make_pose_graph(V, E, seed=seed)
+        st, p2, chi2, _ = oracle.gn_optimize(g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"], 6)
+        assert st == 0
+        for name, r in res.items():
+            d = r[str(V)]
+            assert d["rc"] == 0 and d["timeouts"] == 0, name
+            _check(np.array(d["p"]), np.array(d["chi"]), p2, chi2)
+            np.testing.assert_allclose(d["chi"][-1], res["default"][str(V)]["chi"][-1], rtol=1e-10)
