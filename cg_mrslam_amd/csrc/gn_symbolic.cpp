@@ -456,7 +456,9 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
   int vis1 = id + 1, vis2 = id + 2;
   static const bool reuse_start = !(getenv("CGMR_ND_REUSE_START") && atoi(getenv("CGMR_ND_REUSE_START")) == 0);
   const bool have_start = reuse_start && start >= 0;
+  const double t_l0 = nd_trace ? now_s() : 0;
   int reached = have_start ? bfs(C, Q, start, id, vis2, LV) : bfs(C, Q, C.order[begin], id, vis1);
+  const double t_l1 = nd_trace ? now_s() : 0;
   if (reached < n) {
     // disconnected: component first, then the rest (independent subtrees, no separator)
     int k = begin;
@@ -464,7 +466,7 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
     for (int p = begin; p < end; p++) if (C.vs[C.order[p]].label == id) C.tmp[k++] = C.order[p];
     std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
     int n1 = -1, n2 = -1;
-    NDRange r1 = nd(C, begin, begin + reached, depth, -1, &n1);
+    NDRange r1 = nd(C, begin, begin + reached, depth, -1, &n1);   // (passing the parent's end vertex on instead of a fresh double sweep: 466 instead of 448 tree levels over 24 graphs -- round 6)
     NDRange r2 = nd(C, begin + reached, end, depth, -1, &n2);
     r2.height = std::max(r1.height, r2.height);
     node = C.new_rec(n1, n2, n, 0);                       // independent components: two halves, no separator
@@ -475,6 +477,7 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
     // second sweep from the far vertex gives the level structure
     bfs(C, Q, far, vis1, vis2, LV);
   }
+  const double t_l2 = nd_trace ? now_s() : 0;
   int nlev = C.vs[Q[n - 1]].dist + 1;
   if (nlev <= 2) { node = C.new_rec(-1, -1, n, n); return emit_panels(C, begin, end); }  // clique-like: nothing to dissect
   thread_local std::vector<int32_t> lvl_cnt;            // (the sweep counted the levels into the partition scratch: keep a copy)
@@ -550,6 +553,7 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
   // The queue is sorted by level, and the cover only moved vertices of level js (to js-1) and of level js+1 (to js):
   // everything before the level-js block is near side, everything behind the level-(js+1) block far side; only the
   // two blocks are looked at vertex by vertex.  Same order inside the three parts as a pass over the whole queue.
+  const double t_l3 = nd_trace ? now_s() : 0;
   int s_js = 0;
   for (int j = 0; j < js; j++) s_js += lvl_cnt[j];
   const int e_js = s_js + lvl_cnt[js], e_js1 = e_js + lvl_cnt[js + 1];
@@ -567,7 +571,7 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
   for (int q = e_js; q < e_js1; q++) { const int v = Q[q]; if (C.vs[v].dist > js) C.tmp[pb++] = v; else C.tmp[ps++] = v; }
   for (int q = e_js1; q < n; q++) C.tmp[pb++] = Q[q];
   std::copy(C.tmp.begin() + begin, C.tmp.begin() + end, C.order.begin() + begin);
-  if (nd_trace && depth <= 3) fprintf(stderr, "    nd depth %d n %5d own work %.1f us\n", depth, n, 1e6 * (now_s() - t_in));
+  if (nd_trace && depth <= 3) fprintf(stderr, "    nd depth %d n %5d own work %.1f us (labels %.1f, sweep 1 %.1f, sweep 2 %.1f, level choice + cover %.1f, partition %.1f; levels %d, separator level %d of size %d)\n", depth, n, 1e6 * (now_s() - t_in), 1e6 * (t_l0 - t_in), 1e6 * (t_l1 - t_l0), 1e6 * (t_l2 - t_l1), 1e6 * (t_l3 - t_l2), 1e6 * (now_s() - t_l3), nlev, js, lvl_cnt[js]);
   // the two halves touch disjoint vertices and disjoint position ranges: fork one of them near the top
   NDRange r1, r2;
   int n1 = -1, n2 = -1;
