@@ -12,7 +12,7 @@ LOAD = ("import sys; sys.path.insert(0, %r)\n"
         "a = (g['poses'], g['fixed'], g['edge_from'], g['edge_to'], g['meas'], g['info'])\n"
         "t0 = time.time()\n"
         "while time.time() - t0 < float(sys.argv[2]):\n"
-        "    c.gn_optimize(*a, 3 + kind % 3)\n"
+        "    c.gn_optimize(*a, 3 + kind %% 3)\n"
         "    time.sleep(0.0005 * (kind + 1))\n" % ROOT)
 
 
