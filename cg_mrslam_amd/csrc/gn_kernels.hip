@@ -459,8 +459,11 @@ __device__ __forceinline__ void front_factor_item(const WorkRec* __restrict__ wo
         const int row = rr - (chunk == 0 ? W : 0);
         double* dst = Pn + kL21 + (size_t)(r0 + row) * W + k;
         if constexpr (MERGED) {
-          __hip_atomic_store((gu64*)dst, (unsigned long long)__double_as_longlong(R[row * LDW + k]), CGMR_RLX_AGENT);
-          __hip_atomic_store((gu64*)(dst + 1), (unsigned long long)__double_as_longlong(R[row * LDW + k + 1]), CGMR_RLX_AGENT);
+          typedef int v4i __attribute__((ext_vector_type(4)));
+          (void)dst;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Pn + kL21), 0, r * W * 8, 0x00020000);   // (wave-uniform)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, make_double2(R[row * LDW + k], R[row * LDW + k + 1])), rs,
+                                                 ((r0 + row) * W + k) * 8, 0, 16);   // buffer_store_dwordx4 .. sc1
         } else {
           *reinterpret_cast<double2*>(dst) = make_double2(R[row * LDW + k], R[row * LDW + k + 1]);
         }
@@ -576,21 +579,27 @@ __device__ __forceinline__ void front_update_tile(const WorkRec* __restrict__ wo
   const bool to_pan = ppan >= 0 && j0 < my_ra;                // this tile holds cells of the leading slab
   const bool fresh = MERGED && live && rfl(WR->F.level) == level_id;   // the front is factored in this launch
   // ---- the two L21 slices and every child's row lookups: all loads first, then the LDS writes
-  constexpr int LQ = TS * W / 256;                            // 6 elements of each slice per thread
-  double li[LQ], lj[LQ];
+  constexpr int LQ = TS * W / 512;                            // 3 column pairs of each slice per thread (16-byte loads)
+  double2 li[LQ], lj[LQ];
   auto load_slices = [&](bool sc1) {
+    if (sc1) {
+      // agent-scope 16-byte loads (buffer_load_dwordx4 .. sc1; rows beyond the border read as zeros: the descriptor's bound)
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)L21, 0, r * W * 8, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < LQ; u++) {
-      const int q = tid + 256 * u;
-      const int row = q / W, k = q - row * W;
-      const double* pi = L21 + (size_t)(i0 + row) * W + k;
-      const double* pj = L21 + (size_t)(j0 + row) * W + k;
-      if (sc1) {
-        li[u] = (i0 + row < r) ? __longlong_as_double((long long)__hip_atomic_load((gu64*)pi, CGMR_RLX_AGENT)) : 0.0;
-        lj[u] = (j0 + row < r) ? __longlong_as_double((long long)__hip_atomic_load((gu64*)pj, CGMR_RLX_AGENT)) : 0.0;
-      } else {
-        li[u] = (i0 + row < r) ? *pi : 0.0;
-        lj[u] = (j0 + row < r) ? *pj : 0.0;
+      for (int u = 0; u < LQ; u++) {
+        const int q = tid + 256 * u;
+        const int row = q / (W / 2), k = 2 * (q - row * (W / 2));
+        li[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, ((i0 + row) * W + k) * 8, 0, 16));
+        lj[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, ((j0 + row) * W + k) * 8, 0, 16));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < LQ; u++) {
+        const int q = tid + 256 * u;
+        const int row = q / (W / 2), k = 2 * (q - row * (W / 2));
+        li[u] = (i0 + row < r) ? *reinterpret_cast<const double2*>(L21 + (size_t)(i0 + row) * W + k) : make_double2(0.0, 0.0);
+        lj[u] = (j0 + row < r) ? *reinterpret_cast<const double2*>(L21 + (size_t)(j0 + row) * W + k) : make_double2(0.0, 0.0);
       }
     }
   };
@@ -610,9 +619,9 @@ __device__ __forceinline__ void front_update_tile(const WorkRec* __restrict__ wo
 #pragma unroll
     for (int u = 0; u < LQ; u++) {
       const int q = tid + 256 * u;
-      const int row = q / W, k = q - row * W;
-      Ai[row * LDW + k] = li[u];
-      Aj[row * LDW + k] = lj[u];
+      const int row = q / (W / 2), k = 2 * (q - row * (W / 2));
+      Ai[row * LDW + k] = li[u].x; Ai[row * LDW + k + 1] = li[u].y;
+      Aj[row * LDW + k] = lj[u].x; Aj[row * LDW + k + 1] = lj[u].y;
     }
   };
   if constexpr (!MERGED) stage_slices();
