@@ -120,6 +120,59 @@ struct BlobLayout {
   }
 };
 
+// AnalyzeHooks::blocks_ready of a context's analysis: what the assembly lists depend on goes to the device as soon as it is
+// final (vperm, the edge list, the off-diagonal blocks' rows / columns / column starts: one copy from a pinned block of its own)
+// and the device builds the lists (gn_structure.hip) underneath the rest of the host's analysis.  CGMR_ASM_DEVICE=0: the host
+// builds them as before and they travel with the structure blob.
+int gn_upload_early(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t* et, const int32_t* offbase) {
+  const size_t nV = (size_t)S.nV, nE = (size_t)S.nE, nb = (size_t)S.nb, nf = (size_t)S.nf, nkeys = nf + nb;
+  BlobLayout B;
+  const size_t o_vperm = B.add<int32_t>(nV), o_ef = B.add<int32_t>(nE), o_et = B.add<int32_t>(nE), o_orow = B.add<int32_t>(nb),
+               o_ocol = B.add<int32_t>(nb), o_obase = B.add<int32_t>(nf + 1);
+  const size_t up_bytes = (B.off + 255) & ~size_t(255);
+  B.off = up_bytes;
+  const size_t o_asmp = B.add<int32_t>(nkeys + 1), o_asms = B.add<int32_t>(3 * nE + 4), o_cnt = B.add<int32_t>(nkeys + 2),
+               o_ekey = B.add<int32_t>(nE), o_long = B.add<int32_t>(3 * nE / 32 + 2), o_tmp = B.add<int32_t>(3 * nE + 4);
+  // whatever still reads the previous structure on the side stream (a batch of condensed-graph passes) comes first
+  int rc = side_join_stream(ctx, ctx->stream);
+  if (rc) return rc;
+  rc = arena_reserve(ctx, ctx->st_arena, B.off + 256);
+  if (rc) return rc;
+  if (!ctx->ev_st_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_st_copied, hipEventDisableTiming));
+  else HIP_TRY(ctx, hipEventSynchronize(ctx->ev_st_copied));   // (the previous copy out of the staging block: long done)
+  if (up_bytes > ctx->pinned_st_cap) {
+    if (ctx->pinned_st) { (void)hipHostFree(ctx->pinned_st); ctx->pinned_st = nullptr; ctx->pinned_st_cap = 0; }
+    const size_t want = up_bytes + up_bytes / 4 + (1 << 16);
+    hipError_t e = hipHostMalloc((void**)&ctx->pinned_st, want, hipHostMallocDefault);
+    if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+    ctx->pinned_st_cap = want;
+  }
+  char* h = ctx->pinned_st;
+  host_run_tasks(4, [&](int task) {
+    switch (task) {
+      case 0: memcpy(h + o_ef, ef, 4 * nE); break;
+      case 1: memcpy(h + o_et, et, 4 * nE); break;
+      case 2: memcpy(h + o_orow, S.off_row.data(), 4 * nb); memcpy(h + o_obase, offbase, 4 * (nf + 1)); break;
+      default: memcpy(h + o_ocol, S.off_col.data(), 4 * nb); memcpy(h + o_vperm, S.vperm.data(), 4 * nV); break;
+    }
+  });
+  char* d = ctx->st_arena.ptr;
+  HIP_TRY(ctx, hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_st_copied, ctx->stream));
+  cgmr_ctx::StView& V = ctx->st_view;
+  V.vperm = (int32_t*)(d + o_vperm); V.ef = (int32_t*)(d + o_ef); V.et = (int32_t*)(d + o_et);
+  V.off_row = (int32_t*)(d + o_orow); V.off_col = (int32_t*)(d + o_ocol);
+  V.asm_ptr = (int32_t*)(d + o_asmp); V.asm_src = (int32_t*)(d + o_asms);
+  AsmBuild A;
+  A.nE = S.nE; A.nf = S.nf; A.nb = S.nb;
+  A.vperm = V.vperm; A.ef = V.ef; A.et = V.et; A.off_row = V.off_row; A.offbase = (const int32_t*)(d + o_obase);
+  A.asm_ptr = V.asm_ptr; A.asm_src = V.asm_src; A.ekey = (int32_t*)(d + o_ekey); A.cnt = (int32_t*)(d + o_cnt);
+  A.longlist = (int32_t*)(d + o_long); A.tmp = (int32_t*)(d + o_tmp);
+  launch_build_asm(ctx->stream, A);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
 // Lay out and upload the structure arrays; point GnDevice into the arena.
 int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t* et, int iters) {
   // the factor kernels keep row positions (own columns + border rows) in 16-bit LDS maps
@@ -191,13 +244,15 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_lf = B.add<int32_t>(S.level_fronts.size());
   size_t o_tiles = B.add<int32_t>(3 * n_tiles);
   size_t o_work = B.add<WorkRec>(n_work);
-  size_t o_asmp = B.add<int32_t>(S.asm_ptr.size());
-  size_t o_asms = B.add<int32_t>(S.asm_src.size());
-  size_t o_vperm = B.add<int32_t>(S.vperm.size());
-  size_t o_ef = B.add<int32_t>(S.nE);
-  size_t o_et = B.add<int32_t>(S.nE);
-  size_t o_orow = B.add<int32_t>(S.off_row.size());
-  size_t o_ocol = B.add<int32_t>(S.off_col.size());
+  // (S.asm_on_device: these seven are on the device already, gn_upload_early)
+  const bool early = S.asm_on_device;
+  size_t o_asmp = B.add<int32_t>(early ? 0 : S.asm_ptr.size());
+  size_t o_asms = B.add<int32_t>(early ? 0 : S.asm_src.size());
+  size_t o_vperm = B.add<int32_t>(early ? 0 : S.vperm.size());
+  size_t o_ef = B.add<int32_t>(early ? 0 : S.nE);
+  size_t o_et = B.add<int32_t>(early ? 0 : S.nE);
+  size_t o_orow = B.add<int32_t>(early ? 0 : S.off_row.size());
+  size_t o_ocol = B.add<int32_t>(early ? 0 : S.off_col.size());
   size_t o_tf = B.add<int32_t>(S.top_fronts.size()), o_tc = B.add<int32_t>(S.top_children.size()), o_tb = B.add<int32_t>(S.top_blocks.size());
   size_t blob_bytes = (B.off + 255) & ~size_t(255);
   // numeric work space
@@ -293,10 +348,12 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
         break;
       case 4:
         put(o_inv, S.inv.data(), S.inv.size() * 4);
+        if (early) break;
         put(o_asmp, S.asm_ptr.data(), S.asm_ptr.size() * 4);
         put(o_asms, S.asm_src.data(), S.asm_src.size() * 4);
         break;
       default:
+        if (early) break;
         put(o_vperm, S.vperm.data(), S.vperm.size() * 4);
         put(o_ef, ef, (size_t)S.nE * 4);
         put(o_et, et, (size_t)S.nE * 4);
@@ -328,6 +385,10 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.et = (int32_t*)(d + o_et);
   D.off_row = (int32_t*)(d + o_orow);
   D.off_col = (int32_t*)(d + o_ocol);
+  if (early) {
+    const cgmr_ctx::StView& V = ctx->st_view;
+    D.asm_ptr = V.asm_ptr; D.asm_src = V.asm_src; D.vperm = V.vperm; D.ef = V.ef; D.et = V.et; D.off_row = V.off_row; D.off_col = V.off_col;
+  }
   D.cmask = (uint8_t*)(d + o_cmask);
   D.top_fronts = (int32_t*)(d + o_tf); D.top_children = (int32_t*)(d + o_tc); D.top_blocks = (int32_t*)(d + o_tb);
   D.top_nfronts = (int)S.top_fronts.size(); D.top_c0 = S.top_c0; D.top_ncols = 3 * S.top_nposes;
@@ -396,7 +457,7 @@ int aux_streams(cgmr_ctx* ctx, int n) {
 // The analysis of (nV, ef, et) into `sym`, which holds the analysis of (prev_nV, pef, pet) when have_prev: extended from it
 // where the two lists allow that, from scratch otherwise (shared by prepare_structure and the host-only test hook).
 int analyze_next(Symbolic& sym, bool have_prev, int prev_nV, const std::vector<int32_t>& pef, const std::vector<int32_t>& pet, int nV,
-                 int nE, const int32_t* ef, const int32_t* et, const int32_t* hub_vertices, int n_hub_vertices) {
+                 int nE, const int32_t* ef, const int32_t* et, const int32_t* hub_vertices, int n_hub_vertices, const AnalyzeHooks* hooks = nullptr) {
   int n_common = 0;
   if (have_prev && nV >= prev_nV && !pef.empty()) {
     const int lim = std::min(nE, (int)pef.size());
@@ -406,9 +467,9 @@ int analyze_next(Symbolic& sym, bool have_prev, int prev_nV, const std::vector<i
   const bool grown = n_common > 0 && (n_common == old_nE || (n_hub_vertices > 0 && 2 * n_common >= old_nE));
   if (grown) {
     Symbolic old = std::move(sym);
-    return analyze(nV, nullptr, nE, ef, et, sym, &old, n_common == old_nE && nE >= old_nE ? -1 : n_common, hub_vertices, n_hub_vertices);
+    return analyze(nV, nullptr, nE, ef, et, sym, &old, n_common == old_nE && nE >= old_nE ? -1 : n_common, hub_vertices, n_hub_vertices, hooks);
   }
-  return analyze(nV, nullptr, nE, ef, et, sym, nullptr, -1, hub_vertices, n_hub_vertices);
+  return analyze(nV, nullptr, nE, ef, et, sym, nullptr, -1, hub_vertices, n_hub_vertices, hooks);
 }
 
 // Ordering + symbolic analysis + structure upload for the edge list (ef, et), or nothing at all when the context
@@ -435,7 +496,13 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
   // the tree edge by edge (an edge to a hub -- the gauge of a received star -- always passes).
   const bool have_prev = ctx->sym_cache_on && ctx->sym_valid;
   ctx->sym_valid = false;
-  int rc = analyze_next(ctx->sym, have_prev, ctx->sym_nV, ctx->sym_ef, ctx->sym_et, nV, nE, ef, et, hub_vertices, n_hub_vertices);
+  static const bool asm_device = !(getenv("CGMR_ASM_DEVICE") && atoi(getenv("CGMR_ASM_DEVICE")) == 0);
+  AnalyzeHooks hooks;
+  int hook_rc = 0;
+  if (asm_device)
+    hooks.blocks_ready = [&](const Symbolic& S, const int32_t* offbase) { hook_rc = gn_upload_early(ctx, S, ef, et, offbase); return hook_rc ? -100 : 0; };
+  int rc = analyze_next(ctx->sym, have_prev, ctx->sym_nV, ctx->sym_ef, ctx->sym_et, nV, nE, ef, et, hub_vertices, n_hub_vertices, &hooks);
+  if (rc == -100) return hook_rc;                                   // (the device pass of the analysis failed: its error is set)
   if (rc == 0 && ctx->sym.extended) ctx->sym_extended++; else ctx->sym_misses++;
   if (rc) return set_err(ctx, CGMR_E_INVALID, "graph structure rejected (edge index out of range)");
   const int chi_cap = std::max(iters, 30);
@@ -863,6 +930,9 @@ void cgmr_ctx_destroy(cgmr_ctx* ctx) {
   if (ctx->mtab_arena.ptr) (void)hipFree(ctx->mtab_arena.ptr);
   if (ctx->rep_arena.ptr) (void)hipFree(ctx->rep_arena.ptr);
   if (ctx->mg_arena.ptr) (void)hipFree(ctx->mg_arena.ptr);
+  if (ctx->st_arena.ptr) (void)hipFree(ctx->st_arena.ptr);
+  if (ctx->pinned_st) (void)hipHostFree(ctx->pinned_st);
+  if (ctx->ev_st_copied) (void)hipEventDestroy(ctx->ev_st_copied);
   for (hipStream_t a : ctx->aux) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
   for (hipEvent_t e : {ctx->side_fork, ctx->side_tail}) if (e) (void)hipEventDestroy(e);
@@ -1147,4 +1217,33 @@ extern "C" int cgmr_debug_symbolic_steps(int n_steps, const int32_t* nV, const i
     o[0] = F.c0; o[1] = F.nc; o[2] = F.ns; o[3] = F.parent; o[4] = F.level; o[5] = F.nchild;
   }
   return n;
+}
+
+// Tests: the assembly lists (gn_symbolic.h: asm_ptr / asm_src) as the host builds them for an edge list (ctx == nullptr), or
+// as they stand on the device for the graph the context analysed last (ef / et ignored).  Returns nf + nb (the number of
+// keys; -1: error), the number of list entries in *n_src_out.
+extern "C" int cgmr_debug_asm_lists(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const int32_t* et, int cap_ptr, int32_t* ptr_out,
+                                    int cap_src, int32_t* src_out, int32_t* n_src_out) {
+  if (!ptr_out || !src_out || !n_src_out) return -1;
+  if (!ctx) {
+    Symbolic S;
+    if (analyze(nV, nullptr, nE, ef, et, S)) return -1;
+    const int nk = S.nf + S.nb;
+    if (nk + 1 > cap_ptr || (int)S.asm_src.size() > cap_src) return -1;
+    if (S.asm_ptr.empty()) { *n_src_out = 0; return nk; }
+    memcpy(ptr_out, S.asm_ptr.data(), 4 * (size_t)(nk + 1));
+    memcpy(src_out, S.asm_src.data(), 4 * S.asm_src.size());
+    *n_src_out = (int)S.asm_src.size();
+    return nk;
+  }
+  const GnDevice& D = ctx->gn;
+  const int nk = D.nf + D.nb;
+  if (nk + 1 > cap_ptr || !D.asm_ptr) return -1;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+  if (hipMemcpy(ptr_out, D.asm_ptr, 4 * (size_t)(nk + 1), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const int ns = ptr_out[nk];
+  if (ns > cap_src) return -1;
+  if (ns > 0 && hipMemcpy(src_out, D.asm_src, 4 * (size_t)ns, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  *n_src_out = ns;
+  return nk;
 }

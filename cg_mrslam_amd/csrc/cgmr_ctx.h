@@ -35,6 +35,14 @@ struct cgmr_ctx {
   double mtab_key[6] = {0, 0, 0, 0, 0, 0};
   cgmr::Arena rep_arena;    // replicas of the GN numeric work space (concurrent passes on one structure)
   cgmr::Arena mg_arena;     // marginals work space of the concurrent passes
+  // What the device needs of the analysis BEFORE the borders / maps are done (vperm, the edge list, the off-diagonal blocks'
+  // rows / columns / column starts) and what it makes of it underneath the rest of the analysis: the assembly lists
+  // (gn_structure.hip).  Own arena and own pinned staging block: the structure blob's are sized at the END of the analysis.
+  cgmr::Arena st_arena;
+  char* pinned_st = nullptr;
+  size_t pinned_st_cap = 0;
+  hipEvent_t ev_st_copied = nullptr;   // behind the last copy out of pinned_st
+  struct StView { int32_t *vperm = nullptr, *ef = nullptr, *et = nullptr, *off_row = nullptr, *off_col = nullptr, *asm_ptr = nullptr, *asm_src = nullptr; } st_view;
   std::vector<hipStream_t> aux;          // side streams of the concurrent passes
   std::vector<hipEvent_t> aux_done;
   hipEvent_t aux_fork = nullptr;

@@ -57,6 +57,15 @@ struct GnEdges {
   const double *meas_a = nullptr, *info_a = nullptr, *meas_b = nullptr, *info_b = nullptr;
   int nA = 0, n_active = 0;
 };
+// gn_structure.hip: the assembly lists (asm_ptr: nf + nb + 1, asm_src: one entry per (edge, key)) from the permutation, the
+// edge list and the off-diagonal blocks (offbase: nf + 1 column starts into off_row); work space: ekey nE, cnt nf + nb + 2,
+// longlist 3 nE / 32 + 1, tmp 3 nE (all int32, device memory)
+struct AsmBuild {
+  int nE = 0, nf = 0, nb = 0;
+  const int32_t *vperm = nullptr, *ef = nullptr, *et = nullptr, *off_row = nullptr, *offbase = nullptr;
+  int32_t *asm_ptr = nullptr, *asm_src = nullptr, *ekey = nullptr, *cnt = nullptr, *longlist = nullptr, *tmp = nullptr;
+};
+void launch_build_asm(hipStream_t st, const AsmBuild& B);
 void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const GnEdges& Ed, int chi_only);
 void launch_chi2(hipStream_t st, const GnDevice& D, double* out);
 void launch_assemble(hipStream_t st, const GnDevice& D);

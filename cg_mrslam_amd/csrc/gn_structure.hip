@@ -1,0 +1,203 @@
+// HIP kernels (gfx950) that build the part of the Gauss-Newton structure the HOST never reads: the assembly lists of
+// k_assemble (gn_kernels.hip) -- per block of H (nf diagonal blocks, then nb lower off-diagonal ones) the edge terms that
+// add up to it, in edge order (the order of the sums is part of the result: FP64 sums, bit-reproducible).
+//
+// What it replaces: g2o's BlockSolver::buildStructure allocates the block pattern of Hpp and hands every edge the address of
+// its Hessian blocks ([g2o-recalled]; redone on every optimize() call, reference call sites
+// src/slam/graph_slam.cpp:564-565, src/slam/graph_manipulator.cpp:117-123).  Until round 6 the host did the same here
+// (gn_symbolic.cpp: "assembly lists", 0.25-0.35 ms of eight threads and 0.6 MB of upload per cold optimize()).  The lists
+// depend on the permutation and on the off-diagonal blocks only, which are final long before the analysis is (borders,
+// amalgamation, maps come after them): the device builds the lists underneath the rest of the host's analysis.
+//
+// A counting sort by key that keeps the edge order: every edge has up to three keys (the diagonal blocks of its two end
+// points, their off-diagonal block); count per key (atomics), one-workgroup prefix sum, file with atomic cursors (order
+// inside a key's list = whoever came first), then every list is sorted by edge number -- lists are 2 to 8 entries long (a
+// pose has a handful of edges), one thread each; a list beyond kLongList entries (the gauge of a received star, a hub) goes
+// to a workgroup that ranks its entries.  All of it is integer work on a few hundred KB that stay in L2: latency-bound
+// launches of 3-6 us each, ~25 us together, hidden behind ~0.4 ms of host work.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "gn_device.h"
+
+namespace cgmr {
+
+namespace {
+
+constexpr int kLongList = 32;
+
+// the three keys of edge k: a = diagonal block of `from`, b = of `to` (-1: a self edge counts once), e = nf + index of the
+// lower off-diagonal block (max(a, b), min(a, b)) (-1: an end point has no column, or a self edge); code of e: 2 = Hij as
+// it is (row a, column b), 3 = transposed -- gn_symbolic.cpp, "assembly lists"
+__device__ __forceinline__ void edge_keys(int k, int nf, const int32_t* __restrict__ vperm, const int32_t* __restrict__ ef,
+                                          const int32_t* __restrict__ et, int& a, int& b) {
+  a = vperm[ef[k]];
+  b = vperm[et[k]];
+}
+
+__global__ __launch_bounds__(256) void k_asm_count(int nE, int nf, const int32_t* __restrict__ vperm, const int32_t* __restrict__ ef,
+                                                   const int32_t* __restrict__ et, const int32_t* __restrict__ off_row,
+                                                   const int32_t* __restrict__ offbase, int32_t* __restrict__ ekey,
+                                                   int32_t* __restrict__ cnt) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nE) return;
+  int a, b;
+  edge_keys(k, nf, vperm, ef, et, a, b);
+  int e = -1;
+  if (a >= 0 && b >= 0 && a != b) {
+    const int r = a > b ? a : b, c = a > b ? b : a;
+    int q = offbase[c];
+    while (off_row[q] != r) q++;             // the blocks of a column by ascending row, a handful of them
+    e = nf + q;
+  }
+  ekey[k] = e;
+  if (a >= 0) atomicAdd(&cnt[a], 1);
+  if (b >= 0 && b != a) atomicAdd(&cnt[b], 1);
+  if (e >= 0) atomicAdd(&cnt[e], 1);
+}
+
+// exclusive prefix sum of cnt[0 .. n) into ptr[0 .. n] and back into cnt (the filing pass's cursors); one workgroup of 1024
+// threads, tiles of 4096 entries (16-byte loads), the carry in a register of every thread
+__global__ __launch_bounds__(1024) void k_asm_scan(int n, int32_t* __restrict__ cnt, int32_t* __restrict__ ptr) {
+  __shared__ int wsum[16];
+  __shared__ int tile_total;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = 0;
+  for (int base = 0; base < n; base += 4096) {
+    const int i0 = base + 4 * threadIdx.x;
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = i0 + u < n ? cnt[i0 + u] : 0;
+    const int mine = v[0] + v[1] + v[2] + v[3];
+    int inc = mine;                                     // inclusive scan inside the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      int w = wsum[threadIdx.x], winc = w;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const int o = __shfl_up(winc, d, 64);
+        if ((int)threadIdx.x >= d) winc += o;
+      }
+      wsum[threadIdx.x] = winc - w;                     // exclusive over the wavefronts
+      if (threadIdx.x == 15) tile_total = winc;
+    }
+    __syncthreads();
+    int at = carry + wsum[wave] + inc - mine;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (i0 + u < n) { ptr[i0 + u] = at; cnt[i0 + u] = at; }
+      at += v[u];
+    }
+    carry += tile_total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ptr[n] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_asm_file(int nE, int nf, const int32_t* __restrict__ vperm, const int32_t* __restrict__ ef,
+                                                  const int32_t* __restrict__ et, const int32_t* __restrict__ ekey,
+                                                  int32_t* __restrict__ cur, int32_t* __restrict__ src) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nE) return;
+  int a, b;
+  edge_keys(k, nf, vperm, ef, et, a, b);
+  const int e = ekey[k];
+  if (a >= 0) src[atomicAdd(&cur[a], 1)] = 4 * k + 0;
+  if (b >= 0 && b != a) src[atomicAdd(&cur[b], 1)] = 4 * k + 1;
+  if (e >= 0) src[atomicAdd(&cur[e], 1)] = 4 * k + (a > b ? 2 : 3);
+}
+
+// every key's list into edge order (a key has at most one entry per edge, so ascending entries = ascending edges = the
+// order a sequential pass over the edge list files them in); long lists are left to k_asm_sort_long
+__global__ __launch_bounds__(256) void k_asm_sort(int nkeys, const int32_t* __restrict__ ptr, int32_t* __restrict__ src,
+                                                  int32_t* __restrict__ nlong, int32_t* __restrict__ longlist) {
+  const int key = blockIdx.x * 256 + threadIdx.x;
+  if (key >= nkeys) return;
+  const int p0 = ptr[key], n = ptr[key + 1] - p0;
+  if (n <= 1) return;
+  if (n > kLongList) { longlist[atomicAdd(nlong, 1)] = key; return; }
+  int32_t* s = src + p0;
+  if (n <= 8) {                                         // the common case in registers: a network of compare-exchanges
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = u < n ? s[u] : 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {                       // odd-even transposition, 8 rounds
+#pragma unroll
+      for (int u = i & 1; u + 1 < 8; u += 2) {
+        const int lo = min(v[u], v[u + 1]), hi = max(v[u], v[u + 1]);
+        v[u] = lo; v[u + 1] = hi;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (u < n) s[u] = v[u];
+    return;
+  }
+  for (int i = 1; i < n; i++) {                         // insertion sort in place (L2-resident, a thread reads its own stores)
+    const int x = s[i];
+    int j = i - 1;
+    while (j >= 0 && s[j] > x) { s[j + 1] = s[j]; j--; }
+    s[j + 1] = x;
+  }
+}
+
+// a workgroup per long list: every entry's rank = the number of smaller entries (all distinct), into tmp, and back
+__global__ __launch_bounds__(256) void k_asm_sort_long(const int32_t* __restrict__ ptr, int32_t* __restrict__ src,
+                                                       const int32_t* __restrict__ nlong, const int32_t* __restrict__ longlist,
+                                                       int32_t* __restrict__ tmp) {
+  __shared__ int tile[1024];
+  const int nl = *nlong;
+  for (int q = blockIdx.x; q < nl; q += gridDim.x) {
+    const int key = longlist[q];
+    const int p0 = ptr[key], n = ptr[key + 1] - p0;
+    const int32_t* s = src + p0;
+    // (entries of this thread: i = threadIdx.x, + 256, ..; ranks accumulate over tiles of the list staged in LDS)
+    for (int i0 = 0; i0 < n; i0 += 256 * 4) {           // four entries per thread and round
+      int x[4], rank[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = i0 + 256 * u + (int)threadIdx.x; x[u] = i < n ? s[i] : 0x7fffffff; rank[u] = 0; }
+      for (int t0 = 0; t0 < n; t0 += 1024) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = t0 + j < n ? s[t0 + j] : 0x7fffffff;
+        __syncthreads();
+        const int m = min(1024, n - t0);
+        for (int j = 0; j < m; j++) {
+          const int y = tile[j];
+#pragma unroll
+          for (int u = 0; u < 4; u++) rank[u] += y < x[u] ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = i0 + 256 * u + (int)threadIdx.x; if (i < n) tmp[p0 + rank[u]] = x[u]; }
+    }
+    __syncthreads();                                    // (workgroup scope: the list is this workgroup's alone)
+    for (int i = threadIdx.x; i < n; i += 256) src[p0 + i] = tmp[p0 + i];
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+void launch_build_asm(hipStream_t st, const AsmBuild& B) {
+  const int nkeys = B.nf + B.nb;
+  (void)hipMemsetAsync(B.cnt, 0, sizeof(int32_t) * ((size_t)nkeys + 2), st);         // counts + the long lists' counter behind them
+  if (B.nE > 0) {
+    hipLaunchKernelGGL(k_asm_count, dim3((B.nE + 255) / 256), dim3(256), 0, st, B.nE, B.nf, B.vperm, B.ef, B.et, B.off_row, B.offbase,
+                       B.ekey, B.cnt);
+  }
+  hipLaunchKernelGGL(k_asm_scan, dim3(1), dim3(1024), 0, st, nkeys, B.cnt, B.asm_ptr);
+  if (B.nE > 0) {
+    hipLaunchKernelGGL(k_asm_file, dim3((B.nE + 255) / 256), dim3(256), 0, st, B.nE, B.nf, B.vperm, B.ef, B.et, B.ekey, B.cnt, B.asm_src);
+    hipLaunchKernelGGL(k_asm_sort, dim3((nkeys + 255) / 256), dim3(256), 0, st, nkeys, B.asm_ptr, B.asm_src, B.cnt + nkeys + 1, B.longlist);
+    hipLaunchKernelGGL(k_asm_sort_long, dim3(64), dim3(256), 0, st, B.asm_ptr, B.asm_src, B.cnt + nkeys + 1, B.longlist, B.tmp);
+  }
+}
+
+}  // namespace cgmr

@@ -108,6 +108,7 @@ struct Symbolic {
   // assembly of H blocks from edge terms (CSR over nf diagonal blocks then nb off-diagonal blocks)
   std::vector<int32_t> asm_ptr;        // nf+nb+1
   std::vector<int32_t> asm_src;        // edge*4 + code (0: Hii, 1: Hjj, 2: Hij, 3: Hij^T)
+  bool asm_on_device = false;          // the two lists above were left to the caller's device pass (AnalyzeHooks::blocks_ready) and are empty here
   std::vector<int32_t> off_row, off_col;  // per off-diagonal block: permuted row > col
   std::vector<int32_t> blk_dst;        // per H block (nf diagonal, then nb off-diagonal): offset (doubles) in Pan of its element
                                        //   (0, 0) (rows kPanStride apart), or -(slot + 1): slot in Ablk (fronts of the top block)
@@ -169,7 +170,16 @@ void host_run_tasks(int n, const std::function<void(int)>& task);
 // replaced every round); default: all of prev's edge list is a prefix of this one.
 // hub_vertices (nullable): vertices to keep out of the dissection and eliminate last whatever their degree (the gauge
 // vertices of the condensed stars received from the peers: every received edge has one of them at an end).
+// hooks (nullable): see AnalyzeHooks.
+struct AnalyzeHooks {
+  // Called on the analysing thread once the permutation and the off-diagonal block lists are final -- S.vperm, S.off_row,
+  // S.off_col, S.nf, S.nb; offbase[c] = index of column c's first block, nf + 1 entries -- i.e. before the borders, the
+  // amalgamation and the maps: a caller with a device builds the assembly lists there (gn_structure.hip: every edge's three
+  // keys, a counting sort by key that keeps the edge order) underneath the rest of the analysis.  When the hook is set
+  // analyze() does not build S.asm_ptr / S.asm_src (S.asm_on_device).  A non-zero return aborts the analysis with that value.
+  std::function<int(const Symbolic&, const int32_t* offbase)> blocks_ready;
+};
 int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev = nullptr,
-            int n_common = -1, const int32_t* hub_vertices = nullptr, int n_hub_vertices = 0);
+            int n_common = -1, const int32_t* hub_vertices = nullptr, int n_hub_vertices = 0, const AnalyzeHooks* hooks = nullptr);
 
 }  // namespace cgmr

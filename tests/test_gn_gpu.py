@@ -315,3 +315,58 @@ def test_launch_variants_of_round_6_agree(oracle):
             assert np.abs(p[:, :2] - p2[:, :2]).max() <= POS_ATOL
             assert np.abs(synth.normalize_theta(p[:, 2] - p2[:, 2])).max() <= ANG_ATOL
             np.testing.assert_allclose(d["chi"][-1], res["default"][str(V)]["chi"][-1], rtol=1e-10)
+
+
+def _asm_lists(lib, ctx_h, nV, ef, et):
+    import ctypes as C
+    ef = np.ascontiguousarray(ef, dtype=np.int32); et = np.ascontiguousarray(et, dtype=np.int32)
+    cap_p, cap_s = 4 * (nV + len(ef)) + 16, 3 * len(ef) + 16
+    ptr = np.zeros(cap_p, dtype=np.int32); src = np.zeros(cap_s, dtype=np.int32); ns = C.c_int32(0)
+    lib.cgmr_debug_asm_lists.restype = C.c_int
+    nk = lib.cgmr_debug_asm_lists(ctx_h, C.c_int(nV), C.c_int(len(ef)), C.c_void_p(ef.ctypes.data), C.c_void_p(et.ctypes.data),
+                                  C.c_int(cap_p), C.c_void_p(ptr.ctypes.data), C.c_int(cap_s), C.c_void_p(src.ctypes.data), C.byref(ns))
+    assert nk >= 0
+    return ptr[:nk + 1].copy(), src[:ns.value].copy()
+
+
+def test_assembly_lists_built_on_the_device_equal_the_hosts(ctx, oracle):
+    """Round 6: the assembly lists of k_assemble (per block of H the edge terms that add up to it, in edge order) are built on
+    the device underneath the host's analysis (gn_structure.hip) instead of by the host (gn_symbolic.cpp).  Same lists, entry
+    for entry -- C2, and a graph with duplicate edges and two hubs whose lists (hundreds of entries)
+    take the long-list path --, and a solve on them meets the oracle."""
+    from cg_mrslam_amd import load_library
+    lib = load_library()
+    rng = np.random.default_rng(7)
+    cases = []
+    g = synth.make_pose_graph(10000, 40000, seed=12345)
+    cases.append((g, 2))
+    g = synth.make_pose_graph(600, 2000, seed=9)
+    ef, et = g["edge_from"].copy(), g["edge_to"].copy()
+    # two hubs with 300 and 70 extra edges each (lists beyond 32 entries), duplicates of existing edges
+    extra_f = np.concatenate([np.full(300, 17), rng.integers(0, 600, 70), ef[:40]]).astype(np.int32)
+    extra_t = np.concatenate([rng.integers(0, 600, 300), np.full(70, 411), et[:40]]).astype(np.int32)
+    keep = extra_f != extra_t
+    extra_f, extra_t = extra_f[keep], extra_t[keep]
+    n_extra = len(extra_f)
+    meas = synth.se2_compose(synth.se2_inverse(g["truth"][extra_f]), g["truth"][extra_t])
+    g2 = dict(g)
+    g2["edge_from"] = np.concatenate([ef, extra_f]).astype(np.int32)
+    g2["edge_to"] = np.concatenate([et, extra_t]).astype(np.int32)
+    g2["meas"] = np.concatenate([g["meas"], meas])
+    g2["info"] = np.concatenate([g["info"], np.tile(g["info"][:1], (n_extra, 1))])
+    cases.append((g2, 10))
+    for g, iters in cases:
+        nV = len(g["poses"])
+        a = (g["poses"], g["fixed"], g["edge_from"], g["edge_to"], g["meas"], g["info"])
+        ctx.set_symbolic_cache(False)
+        rc, p, chi = ctx.gn_optimize(*a, iters)
+        ctx.set_symbolic_cache(True)
+        assert rc == 0
+        ptr_d, src_d = _asm_lists(lib, ctx.h, nV, g["edge_from"], g["edge_to"])
+        ptr_h, src_h = _asm_lists(lib, None, nV, g["edge_from"], g["edge_to"])
+        assert len(src_h) > 0 and np.array_equal(ptr_d, ptr_h) and np.array_equal(src_d, src_h)
+        if g is cases[1][0]:                     # (C2 against the oracle: test_gpu_full_size_c2)
+            assert np.diff(ptr_h).max() > 300
+            st, p2, chi2, _ = oracle.gn_optimize(*a, iters)
+            assert st == 0
+            _check(p, chi, p2, chi2)
