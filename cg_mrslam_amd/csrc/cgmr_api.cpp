@@ -161,7 +161,7 @@ int gn_upload_early(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const i
   HIP_TRY(ctx, hipEventRecord(ctx->ev_st_copied, ctx->stream));
   cgmr_ctx::StView& V = ctx->st_view;
   V.vperm = (int32_t*)(d + o_vperm); V.ef = (int32_t*)(d + o_ef); V.et = (int32_t*)(d + o_et);
-  V.off_row = (int32_t*)(d + o_orow); V.off_col = (int32_t*)(d + o_ocol);
+  V.off_row = (int32_t*)(d + o_orow); V.off_col = (int32_t*)(d + o_ocol); V.offbase = (int32_t*)(d + o_obase);
   V.asm_ptr = (int32_t*)(d + o_asmp); V.asm_src = (int32_t*)(d + o_asms);
   AsmBuild A;
   A.nE = S.nE; A.nf = S.nf; A.nb = S.nb;
@@ -237,10 +237,11 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_fronts_lv = B.add<FrontDesc>(S.fronts.size());   // the same descriptors in level order: the solves index them by workgroup
   size_t o_rows = B.add<int32_t>(S.rows.size());
   size_t o_children = B.add<int32_t>(S.children.size());
-  size_t o_rel = B.add<int32_t>(S.rel.size());
-  size_t o_inv = B.add<int32_t>(S.inv.size());
-  size_t o_bdst = B.add<int32_t>(S.blk_dst.size());
-  size_t o_rdst = B.add<int32_t>(S.b_dst.size());
+  const bool dev_maps = S.maps_on_device;                   // rel / inv / blk_dst / b_dst are made on the device (below): no staging, no upload
+  size_t o_rel = B.add<int32_t>(dev_maps ? 0 : S.rel.size());
+  size_t o_inv = B.add<int32_t>(dev_maps ? 0 : S.inv.size());
+  size_t o_bdst = B.add<int32_t>(dev_maps ? 0 : S.blk_dst.size());
+  size_t o_rdst = B.add<int32_t>(dev_maps ? 0 : S.b_dst.size());
   size_t o_lf = B.add<int32_t>(S.level_fronts.size());
   size_t o_tiles = B.add<int32_t>(3 * n_tiles);
   size_t o_work = B.add<WorkRec>(n_work);
@@ -271,6 +272,10 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_status = N.add<int>(4);
   size_t o_ready = N.add<int>(S.fronts.size() + 4);
   size_t o_cmask = N.add<uint8_t>((size_t)S.nf + 16);
+  if (dev_maps) {
+    o_rel = N.add<int32_t>((size_t)S.n_rel + 4); o_inv = N.add<int32_t>((size_t)S.n_inv + 4);
+    o_bdst = N.add<int32_t>((size_t)S.nf + S.nb + 4); o_rdst = N.add<int32_t>((size_t)S.nf + 4);
+  }
   size_t total = N.off + 256;
   int rc = arena_reserve(ctx, ctx->gn_arena, total);
   if (rc) return rc;
@@ -325,6 +330,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
         break;
       }
       case 1:
+        if (dev_maps) break;
         put(o_bdst, S.blk_dst.data(), S.blk_dst.size() * 4);
         put(o_rdst, S.b_dst.data(), S.b_dst.size() * 4);
         break;
@@ -344,10 +350,10 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
       }
       case 3:
         put(o_rows, S.rows.data(), S.rows.size() * 4);
-        put(o_rel, S.rel.data(), S.rel.size() * 4);
+        if (!dev_maps) put(o_rel, S.rel.data(), S.rel.size() * 4);
         break;
       case 4:
-        put(o_inv, S.inv.data(), S.inv.size() * 4);
+        if (!dev_maps) put(o_inv, S.inv.data(), S.inv.size() * 4);
         if (early) break;
         put(o_asmp, S.asm_ptr.data(), S.asm_ptr.size() * 4);
         put(o_asms, S.asm_src.data(), S.asm_src.size() * 4);
@@ -401,6 +407,10 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.uvec = (double*)(d + o_u);
   D.Lbuf = (double*)(d + o_L);
   D.Ubuf = (double*)(d + o_U);
+  if (dev_maps) {
+    launch_build_maps(ctx->stream, D, ctx->st_view.offbase);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   D.Pan = (double*)(d + o_pan);
   D.pan_clean = false;
   D.pan_doubles = S.pan_doubles;
@@ -499,6 +509,8 @@ int prepare_structure(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const in
   static const bool asm_device = !(getenv("CGMR_ASM_DEVICE") && atoi(getenv("CGMR_ASM_DEVICE")) == 0);
   AnalyzeHooks hooks;
   int hook_rc = 0;
+  static const bool maps_device = !(getenv("CGMR_MAPS_DEVICE") && atoi(getenv("CGMR_MAPS_DEVICE")) == 0);
+  hooks.maps_on_device = asm_device && maps_device;
   if (asm_device)
     hooks.blocks_ready = [&](const Symbolic& S, const int32_t* offbase) { hook_rc = gn_upload_early(ctx, S, ef, et, offbase); return hook_rc ? -100 : 0; };
   int rc = analyze_next(ctx->sym, have_prev, ctx->sym_nV, ctx->sym_ef, ctx->sym_et, nV, nE, ef, et, hub_vertices, n_hub_vertices, &hooks);
@@ -1246,4 +1258,32 @@ extern "C" int cgmr_debug_asm_lists(cgmr_ctx* ctx, int nV, int nE, const int32_t
   if (ns > 0 && hipMemcpy(src_out, D.asm_src, 4 * (size_t)ns, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   *n_src_out = ns;
   return nk;
+}
+
+// Tests: rel | inv | blk_dst | b_dst (gn_symbolic.h) one behind the other, as the host builds them for an edge list (ctx ==
+// nullptr) or as they stand on the device for the graph the context analysed last.  Returns the number of ints, -1: error.
+extern "C" int cgmr_debug_maps(cgmr_ctx* ctx, int nV, int nE, const int32_t* ef, const int32_t* et, int cap, int32_t* out) {
+  if (!out) return -1;
+  if (!ctx) {
+    Symbolic S;
+    if (analyze(nV, nullptr, nE, ef, et, S)) return -1;
+    const size_t n = S.rel.size() + S.inv.size() + S.blk_dst.size() + S.b_dst.size();
+    if (n > (size_t)cap) return -1;
+    int32_t* o = out;
+    for (const std::vector<int32_t>* v : {&S.rel, &S.inv, &S.blk_dst, &S.b_dst}) { memcpy(o, v->data(), 4 * v->size()); o += v->size(); }
+    return (int)n;
+  }
+  const GnDevice& D = ctx->gn;
+  const Symbolic& S = ctx->sym;
+  const size_t sizes[4] = {(size_t)(S.maps_on_device ? S.n_rel : (int64_t)S.rel.size()), (size_t)(S.maps_on_device ? S.n_inv : (int64_t)S.inv.size()),
+                           (size_t)S.nf + S.nb, (size_t)S.nf};
+  const int32_t* srcs[4] = {D.rel, D.inv, D.blk_dst, D.b_dst};
+  if (sizes[0] + sizes[1] + sizes[2] + sizes[3] > (size_t)cap) return -1;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+  int32_t* o = out;
+  for (int k = 0; k < 4; k++) {
+    if (sizes[k] && hipMemcpy(o, srcs[k], 4 * sizes[k], hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    o += sizes[k];
+  }
+  return (int)(o - out);
 }

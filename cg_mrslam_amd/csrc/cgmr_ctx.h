@@ -42,7 +42,7 @@ struct cgmr_ctx {
   char* pinned_st = nullptr;
   size_t pinned_st_cap = 0;
   hipEvent_t ev_st_copied = nullptr;   // behind the last copy out of pinned_st
-  struct StView { int32_t *vperm = nullptr, *ef = nullptr, *et = nullptr, *off_row = nullptr, *off_col = nullptr, *asm_ptr = nullptr, *asm_src = nullptr; } st_view;
+  struct StView { int32_t *vperm = nullptr, *ef = nullptr, *et = nullptr, *off_row = nullptr, *off_col = nullptr, *offbase = nullptr, *asm_ptr = nullptr, *asm_src = nullptr; } st_view;
   std::vector<hipStream_t> aux;          // side streams of the concurrent passes
   std::vector<hipEvent_t> aux_done;
   hipEvent_t aux_fork = nullptr;

@@ -183,7 +183,71 @@ __global__ __launch_bounds__(256) void k_asm_sort_long(const int32_t* __restrict
   }
 }
 
+// The child -> parent row maps and the H blocks' destinations of one front per workgroup, from the uploaded front table
+// (gn_symbolic.cpp, "maps + A lists" and "where every front's contribution and every H block goes" are the host's version):
+//   rel[G.rel_off + q]  position of child G's border row q in this front: < nc an own column, nc + p the p-th border row
+//   inv[G.inv_off + p]  the child's row that lands on this front's border row p, or -1
+//   blk_dst[blk]        offset in Pan of element (0, 0) of H block blk (diagonal blocks 0 .. nf - 1, then the off-diagonal
+//                       ones by column), or -(slot + 1): slot in Ablk, for the fronts of the top block
+//   b_dst[c]            offset in Pan of column c's first right-hand-side entry, -1: top block
+// A border row's position comes from a binary search in the front's (ascending) row list.
+__global__ __launch_bounds__(256) void k_build_maps(int nf, const FrontDesc* __restrict__ fronts, const int32_t* __restrict__ rows,
+                                                    const int32_t* __restrict__ children, const int32_t* __restrict__ offbase,
+                                                    const int32_t* __restrict__ off_row, const int32_t* __restrict__ top_fronts,
+                                                    int n_top, int32_t* __restrict__ rel, int32_t* __restrict__ inv,
+                                                    int32_t* __restrict__ blk_dst, int32_t* __restrict__ b_dst) {
+  const int f = blockIdx.x;
+  const FrontDesc F = fronts[f];
+  const int cend = F.c0 + F.nc;
+  const int32_t* fr = rows + F.rows_off;
+  auto pos = [&](int r) {                               // r is one of the front's border rows
+    int lo = 0, hi = F.ns;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (fr[mid] <= r) lo = mid; else hi = mid; }
+    return lo;
+  };
+  for (int k = 0; k < F.nchild; k++) {
+    const FrontDesc G = fronts[children[F.child_off + k]];
+    for (int p = threadIdx.x; p < F.ns; p += 256) inv[G.inv_off + p] = -1;
+  }
+  __syncthreads();
+  for (int k = 0; k < F.nchild; k++) {
+    const FrontDesc G = fronts[children[F.child_off + k]];
+    for (int q = threadIdx.x; q < G.ns; q += 256) {
+      const int r = rows[G.rows_off + q];
+      if (r < cend) rel[G.rel_off + q] = r - F.c0;
+      else { const int p = pos(r); rel[G.rel_off + q] = F.nc + p; inv[G.inv_off + p] = q; }
+    }
+  }
+  bool in_top = false;
+  for (int k = 0; k < n_top; k++) in_top = in_top || top_fronts[k] == f;
+  const int ob0 = offbase[F.c0];
+  for (int t = threadIdx.x; t < F.a_cnt; t += 256) {    // the front's A blocks in alist order: per column the diagonal block, then its blocks below
+    int c = F.c0;
+    while (c + 1 < cend && (c + 1 - F.c0) + (offbase[c + 1] - ob0) <= t) c++;
+    const int j = t - ((c - F.c0) + (offbase[c] - ob0));  // 0: the diagonal block, j >= 1: the column's (j - 1)-th off-diagonal block
+    const int lc = c - F.c0;
+    int blk, lr;
+    if (j == 0) { blk = c; lr = lc; }
+    else {
+      const int kb = offbase[c] + j - 1, r = off_row[kb];
+      blk = nf + kb;
+      lr = r < cend ? r - F.c0 : F.nc + pos(r);
+    }
+    if (in_top) { blk_dst[blk] = -(F.a_off + t + 1); continue; }
+    const long long row = lr < F.nc ? 3 * lr : kFrontW + 3 * (lr - F.nc);
+    blk_dst[blk] = (int32_t)(F.pan_off + row * kPanStride + 3 * lc);
+  }
+  for (int c = threadIdx.x; c < F.nc; c += 256)
+    b_dst[F.c0 + c] = in_top ? -1 : (int32_t)(F.pan_off + (long long)(kFrontW + 3 * F.ns) * kPanStride + 3 * c);
+}
+
 }  // namespace
+
+void launch_build_maps(hipStream_t st, const GnDevice& D, const int32_t* offbase) {
+  if (D.nfronts <= 0) return;
+  hipLaunchKernelGGL(k_build_maps, dim3(D.nfronts), dim3(256), 0, st, D.nf, D.fronts, D.rows, D.children, offbase, D.off_row, D.top_fronts,
+                     D.top_nfronts, D.rel, D.inv, D.blk_dst, D.b_dst);
+}
 
 void launch_build_asm(hipStream_t st, const AsmBuild& B) {
   const int nkeys = B.nf + B.nb;

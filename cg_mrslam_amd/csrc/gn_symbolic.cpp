@@ -1270,6 +1270,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
     const int hrc = hooks->blocks_ready(S, offbase.data());
     if (hrc) return hrc;
     S.asm_on_device = true;
+    S.maps_on_device = hooks->maps_on_device;
     CK("assembly lists: handed to the device");
   }
   if (!S.asm_on_device) {
@@ -1557,10 +1558,28 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       flops += (double)w * w * w / 3.0 + (double)r * w * w + (double)r * r * w;
     }
     S.children.resize(n_child);
-    S.rel.resize(n_rel);
-    S.inv.assign(n_inv, -1);
-    S.alist.resize(3 * n_a);
+    S.n_rel = n_rel; S.n_inv = n_inv;
+    if (!S.maps_on_device) {
+      S.rel.resize(n_rel);
+      S.inv.assign(n_inv, -1);
+      S.alist.resize(3 * n_a);
+    }
   }
+  if (S.maps_on_device) {
+    // the device fills rel / inv / blk_dst / b_dst from the uploaded front table (gn_structure.hip: k_build_maps); the host
+    // keeps what it reads itself: the children lists and every child's count of border rows inside its parent's own columns
+    parallel_for(nfr, NT, [&](int flo, int fhi) {
+      for (int f = flo; f < fhi; f++) {
+        const FrontDesc& F = S.fronts[f];
+        std::copy(kids[f].begin(), kids[f].end(), S.children.begin() + F.child_off);
+        for (int ch : kids[f]) {
+          FrontDesc& G = S.fronts[ch];
+          const int32_t* gr = S.rows.data() + G.rows_off;
+          G.na = (int)(std::lower_bound(gr, gr + G.ns, F.c0 + F.nc) - gr);
+        }
+      }
+    }, 256);
+  } else
   parallel_for(nfr, NT, [&](int flo, int fhi) {
     std::vector<int32_t> posmap(nf, -1);                 // border row -> position in the current front's row list
     for (int f = flo; f < fhi; f++) {
@@ -1646,13 +1665,20 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       for (int f = 0; f < nfr; f++)
         if (!in_top[f] && S.fronts[f].parent >= 0 && in_top[S.fronts[f].parent]) S.top_children.push_back(f);
       for (int f : chain) {
+        // the front's A blocks in the order of its alist: per own column the diagonal block, then the column's blocks below
+        // the diagonal by ascending row (the global row of a block is all the dense top block needs)
         const FrontDesc& F = S.fronts[f];
-        for (int k = 0; k < F.a_cnt; k++) {
-          const int lr = S.alist[3 * (size_t)(F.a_off + k) + 1], lc = S.alist[3 * (size_t)(F.a_off + k) + 2];
-          const int grow = lr < F.nc ? F.c0 + lr : S.rows[F.rows_off + lr - F.nc];
-          S.top_blocks.push_back(F.a_off + k);
-          S.top_blocks.push_back(grow - S.top_c0);
-          S.top_blocks.push_back(F.c0 + lc - S.top_c0);
+        int k = 0;
+        for (int c = F.c0; c < F.c0 + F.nc; c++) {
+          S.top_blocks.push_back(F.a_off + k++);
+          S.top_blocks.push_back(c - S.top_c0);
+          S.top_blocks.push_back(c - S.top_c0);
+          for (int p = cp[c]; p < cp[c + 1]; p++) {
+            if (ci[p] <= c) continue;
+            S.top_blocks.push_back(F.a_off + k++);
+            S.top_blocks.push_back(ci[p] - S.top_c0);
+            S.top_blocks.push_back(c - S.top_c0);
+          }
         }
       }
       // Gauss-Newton level lists without the block
@@ -1667,6 +1693,7 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
         S.gn_level_ptr.pop_back();                                     // the block's own levels
     }
   }
+  CK("levels + top block");
   // ---- where every front's contribution and every H block goes
   {
     std::vector<uint8_t> in_top(nfr, 0);
@@ -1685,6 +1712,9 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
         F.sched_slot = 0;
       }
     }
+    if (S.maps_on_device) {
+      if (Panoff + kFrontW > 0x7fffffff) return -2;          // (the destinations are 32-bit offsets into the panels)
+    } else {
     S.blk_dst.assign((size_t)nf + S.nb, 0);
     S.b_dst.assign(nf, -1);
     for (int f = 0; f < nfr; f++) {
@@ -1701,7 +1731,9 @@ int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32
       if (!in_top[f])
         for (int c = 0; c < F.nc; c++) S.b_dst[F.c0 + c] = (int32_t)(F.pan_off + (int64_t)(kFrontW + 3 * F.ns) * kPanStride + 3 * c);
     }
+    }
   }
+  CK("destinations");
   S.t_struct = now_s() - t1;
   return 0;
 }

@@ -108,6 +108,8 @@ struct Symbolic {
   // assembly of H blocks from edge terms (CSR over nf diagonal blocks then nb off-diagonal blocks)
   std::vector<int32_t> asm_ptr;        // nf+nb+1
   std::vector<int32_t> asm_src;        // edge*4 + code (0: Hii, 1: Hjj, 2: Hij, 3: Hij^T)
+  bool maps_on_device = false;         // rel / inv / blk_dst / b_dst / alist likewise (AnalyzeHooks::maps_on_device): sizes in n_rel / n_inv
+  int64_t n_rel = 0, n_inv = 0;
   bool asm_on_device = false;          // the two lists above were left to the caller's device pass (AnalyzeHooks::blocks_ready) and are empty here
   std::vector<int32_t> off_row, off_col;  // per off-diagonal block: permuted row > col
   std::vector<int32_t> blk_dst;        // per H block (nf diagonal, then nb off-diagonal): offset (doubles) in Pan of its element
@@ -178,6 +180,9 @@ struct AnalyzeHooks {
   // keys, a counting sort by key that keeps the edge order) underneath the rest of the analysis.  When the hook is set
   // analyze() does not build S.asm_ptr / S.asm_src (S.asm_on_device).  A non-zero return aborts the analysis with that value.
   std::function<int(const Symbolic&, const int32_t* offbase)> blocks_ready;
+  // with blocks_ready: the caller's device also fills the child -> parent row maps (rel, inv) and the H blocks' destinations
+  // (blk_dst, b_dst) from the front table once that is uploaded (gn_structure.hip: k_build_maps); analyze() leaves them empty
+  bool maps_on_device = false;
 };
 int analyze(int nV, const uint8_t* fixed, int nE, const int32_t* ef, const int32_t* et, Symbolic& S, Symbolic* prev = nullptr,
             int n_common = -1, const int32_t* hub_vertices = nullptr, int n_hub_vertices = 0, const AnalyzeHooks* hooks = nullptr);

@@ -334,6 +334,7 @@ def test_assembly_lists_built_on_the_device_equal_the_hosts(ctx, oracle):
     the device underneath the host's analysis (gn_structure.hip) instead of by the host (gn_symbolic.cpp).  Same lists, entry
     for entry -- C2, and a graph with duplicate edges and two hubs whose lists (hundreds of entries)
     take the long-list path --, and a solve on them meets the oracle."""
+    import ctypes as C
     from cg_mrslam_amd import load_library
     lib = load_library()
     rng = np.random.default_rng(7)
@@ -365,6 +366,14 @@ def test_assembly_lists_built_on_the_device_equal_the_hosts(ctx, oracle):
         ptr_d, src_d = _asm_lists(lib, ctx.h, nV, g["edge_from"], g["edge_to"])
         ptr_h, src_h = _asm_lists(lib, None, nV, g["edge_from"], g["edge_to"])
         assert len(src_h) > 0 and np.array_equal(ptr_d, ptr_h) and np.array_equal(src_d, src_h)
+        # ... and the child -> parent row maps and the H blocks' destinations (k_build_maps against the host's loops)
+        cap = 40 * (nV + len(g["edge_from"])) + 1024
+        m_d, m_h = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+        lib.cgmr_debug_maps.restype = C.c_int
+        ea, eb = (np.ascontiguousarray(g[k], dtype=np.int32) for k in ("edge_from", "edge_to"))
+        n_d = lib.cgmr_debug_maps(ctx.h, C.c_int(nV), C.c_int(len(ea)), C.c_void_p(ea.ctypes.data), C.c_void_p(eb.ctypes.data), C.c_int(cap), C.c_void_p(m_d.ctypes.data))
+        n_h = lib.cgmr_debug_maps(None, C.c_int(nV), C.c_int(len(ea)), C.c_void_p(ea.ctypes.data), C.c_void_p(eb.ctypes.data), C.c_int(cap), C.c_void_p(m_h.ctypes.data))
+        assert n_d == n_h > 0 and np.array_equal(m_d[:n_d], m_h[:n_h])
         if g is cases[1][0]:                     # (C2 against the oracle: test_gpu_full_size_c2)
             assert np.diff(ptr_h).max() > 300
             st, p2, chi2, _ = oracle.gn_optimize(*a, iters)
