@@ -92,7 +92,7 @@ int arena_reserve(cgmr_ctx* ctx, Arena& A, size_t bytes) {
 int pinned_reserve(cgmr_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->pinned_cap) return 0;
   if (ctx->pinned) { (void)hipStreamSynchronize(ctx->stream); (void)side_join_host(ctx); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
-  size_t want = bytes + bytes / 4 + (1 << 16);
+  size_t want = std::max(2 * bytes, (size_t)4 << 20);      // (page-locking is slow and a robot's graph grows every round: double, never less than 4 MB)
   hipError_t e = hipHostMalloc((void**)&ctx->pinned, want, hipHostMallocDefault);
   if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
   ctx->pinned_cap = want;
@@ -132,7 +132,7 @@ int gn_upload_early(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const i
   const size_t up_bytes = (B.off + 255) & ~size_t(255);
   B.off = up_bytes;
   const size_t o_asmp = B.add<int32_t>(nkeys + 1), o_asms = B.add<int32_t>(3 * nE + 4), o_cnt = B.add<int32_t>(nkeys + 2),
-               o_ekey = B.add<int32_t>(nE), o_long = B.add<int32_t>(3 * nE / 32 + 2), o_tmp = B.add<int32_t>(3 * nE + 4);
+               o_ekey = B.add<int32_t>(nE), o_long = B.add<int32_t>(3 * nE / 16 + 2), o_tmp = B.add<int32_t>(3 * nE + 4);
   // whatever still reads the previous structure on the side stream (a batch of condensed-graph passes) comes first
   int rc = side_join_stream(ctx, ctx->stream);
   if (rc) return rc;
@@ -142,7 +142,8 @@ int gn_upload_early(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const i
   else HIP_TRY(ctx, hipEventSynchronize(ctx->ev_st_copied));   // (the previous copy out of the staging block: long done)
   if (up_bytes > ctx->pinned_st_cap) {
     if (ctx->pinned_st) { (void)hipHostFree(ctx->pinned_st); ctx->pinned_st = nullptr; ctx->pinned_st_cap = 0; }
-    const size_t want = up_bytes + up_bytes / 4 + (1 << 16);
+    // (page-locking is slow and a robot's graph grows every round: double, and never less than 2 MB)
+    const size_t want = std::max(2 * up_bytes, (size_t)2 << 20);
     hipError_t e = hipHostMalloc((void**)&ctx->pinned_st, want, hipHostMallocDefault);
     if (e != hipSuccess) return set_err(ctx, CGMR_E_ALLOC, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
     ctx->pinned_st_cap = want;
@@ -420,7 +421,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   // the upper levels of the tree are solved backwards in one chained launch: as many levels as fit the workgroups that
   // are certainly resident together (the waits inside the launch cannot deadlock then); CGMR_BWD_CHAIN=0: one launch per level
   choose_bwd_chain(D, ctx->side_used ? 2 : 1, false);      // (the other half of the slots: the side stream's batches)
-  choose_fwd_merge(D, ctx->side_used ? 2 : 1, false);
+  choose_fwd_merge(D, ctx->side_used ? 2 : 1, false, ctx->fwd_merge_any);
   return 0;
 }
 
@@ -734,6 +735,7 @@ int gn_run(cgmr_ctx* ctx, int nV, double* d_poses, const uint8_t* fixed, int nE,
     // (k_update_poses leaves the poses alone once status[0] is set), so they are repeated from the poses as they stand with
     // one backward launch per tree level -- no in-kernel waits -- and the call goes on as if nothing had happened.
     ctx->gn_timeouts++;
+    ctx->fwd_merge_any = false;                                  // (the next structures merge only what is certainly resident)
     const int it0 = status4[0] - 1;
     const int chain_was = D.bwd_chain_level;
     D.bwd_chain_level = D.nlevels;
@@ -882,7 +884,7 @@ int marginal_driver(cgmr_ctx* ctx, int mode, int nV, const double* poses, const 
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipGetLastError());
-  if (status4[2] != 0) { ctx->gn_timeouts++; return set_err(ctx, CGMR_E_TIMEOUT, "backward solve: a bounded device-side wait ran out"); }
+  if (status4[2] != 0) { ctx->gn_timeouts++; ctx->fwd_merge_any = false; return set_err(ctx, CGMR_E_TIMEOUT, "backward solve: a bounded device-side wait ran out"); }
   if (status4[0] != 0) return set_err(ctx, CGMR_E_CHOLESKY_BASE, "Cholesky failed while computing marginals");
   if (mode == 2) {
     for (int k = 0; k < nq; k++) to_out[k] = q[k];
@@ -911,6 +913,7 @@ int cgmr_ctx_create(int device, void* hip_stream, cgmr_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return CGMR_E_NO_DEVICE;
   cgmr_ctx* ctx = new cgmr_ctx();
   ctx->device = device;
+  ctx->fwd_merge_any = !(getenv("CGMR_FWD_MERGE_ANY") && atoi(getenv("CGMR_FWD_MERGE_ANY")) == 0);
   if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return CGMR_E_HIP; }

@@ -66,6 +66,8 @@ struct cgmr_ctx {
   int sym_chi_cap = 0;
   std::vector<int32_t> sym_ef, sym_et;
   int64_t gn_timeouts = 0;       // bounded device-side waits that ran out (cgmr_gn_timeouts)
+  bool fwd_merge_any = true;     // merged level launches also where the launch is not certainly resident at once (choose_fwd_merge);
+                                 // cleared by the first time-out on this context, CGMR_FWD_MERGE_ANY=0: never
   int64_t sym_hits = 0, sym_misses = 0, sym_extended = 0;   // calls served from the cache / analysed from scratch / analysed by extending the cached ordering
   std::vector<uint8_t> vmask;    // per vertex: masked in the current pass
   cgmr::Symbolic sym;

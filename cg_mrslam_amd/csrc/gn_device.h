@@ -59,7 +59,7 @@ struct GnEdges {
 };
 // gn_structure.hip: the assembly lists (asm_ptr: nf + nb + 1, asm_src: one entry per (edge, key)) from the permutation, the
 // edge list and the off-diagonal blocks (offbase: nf + 1 column starts into off_row); work space: ekey nE, cnt nf + nb + 2,
-// longlist 3 nE / 32 + 1, tmp 3 nE (all int32, device memory)
+// longlist 3 nE / 16 + 1, tmp 3 nE (all int32, device memory)
 struct AsmBuild {
   int nE = 0, nf = 0, nb = 0;
   const int32_t *vperm = nullptr, *ef = nullptr, *et = nullptr, *off_row = nullptr, *offbase = nullptr;
@@ -75,7 +75,7 @@ void gn_init_kernels();
 void launch_factor_level(hipStream_t st, const GnDevice& D, int level, bool write_l11c);
 void launch_update_level(hipStream_t st, const GnDevice& D, int level);
 void launch_front_level(hipStream_t st, const GnDevice& D, int level, bool write_l11c);
-void choose_fwd_merge(GnDevice& D, int slots_div, bool off);
+void choose_fwd_merge(GnDevice& D, int slots_div, bool off, bool any_size = false);
 void launch_bwd_level(hipStream_t st, const GnDevice& D, int level);
 void launch_bwd_chain(hipStream_t st, const GnDevice& D);
 int bwd_chain_capacity(int per_cu);

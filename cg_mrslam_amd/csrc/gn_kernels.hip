@@ -1517,7 +1517,13 @@ int level_merge_wgs(const GnDevice& D, int l) {
 }
 // Which levels run merged: those whose launch is certainly resident at once (occupancy query x CUs, shared with `slots_div`
 // others) and that the analysis did not rule out (h_level_mergeable: a front with more than MAXC children).  CGMR_FWD_MERGE=0: none.
-void choose_fwd_merge(GnDevice& D, int slots_div, bool off) {
+// any_size (round 6): a level whose launch is NOT certainly resident at once merges as well.  The tiles' waits then lean on
+// the order of dispatch -- a tile's workgroup index lies behind those of all the level's work items, which wait for nobody --
+// which the hardware keeps per XCD but HIP does not promise (MI355X guide, "Workgroup dispatch"): results never depend on it
+// (the waits are bounded, a time-out repeats the iterations with separate launches), speed does, so the caller stops
+// asking for it on a context that has seen a time-out.  C2's levels 0 and 1 (1656 and 1020 workgroups): 30.3 -> 26.0 and
+// 25.3 -> 23.3 us, 3.76 -> 3.68 ms device per optimize(10).
+void choose_fwd_merge(GnDevice& D, int slots_div, bool off, bool any_size) {
   static const bool env_on = !(getenv("CGMR_FWD_MERGE") && atoi(getenv("CGMR_FWD_MERGE")) == 0);
   static int per_cu[64][4];                                   // resident workgroups per CU by LDS class (<= 40, 53, 80, 160 KB)
   static std::once_flag once[64];
@@ -1540,7 +1546,7 @@ void choose_fwd_merge(GnDevice& D, int slots_div, bool off) {
   for (int l = 0; l < D.nlevels; l++) {
     const int wgs = level_merge_wgs(D, l), sm = level_merge_smem(D, l);
     const int cls = sm <= 40 * 1024 ? 0 : sm <= 53 * 1024 ? 1 : sm <= 80 * 1024 ? 2 : 3;
-    if (wgs > 0 && l < (int)D.h_level_mergeable.size() && D.h_level_mergeable[l] && wgs <= per_cu[dev][cls] * ncu / std::max(1, slots_div)) D.h_level_merge[l] = 1;
+    if (wgs > 0 && l < (int)D.h_level_mergeable.size() && D.h_level_mergeable[l] && (any_size || wgs <= per_cu[dev][cls] * ncu / std::max(1, slots_div))) D.h_level_merge[l] = 1;
   }
 }
 

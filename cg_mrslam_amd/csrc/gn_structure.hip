@@ -25,7 +25,7 @@ namespace cgmr {
 
 namespace {
 
-constexpr int kLongList = 32;
+constexpr int kLongList = 16;
 
 // the three keys of edge k: a = diagonal block of `from`, b = of `to` (-1: a self edge counts once), e = nf + index of the
 // lower off-diagonal block (max(a, b), min(a, b)) (-1: an end point has no column, or a self edge); code of e: 2 = Hij as
@@ -115,7 +115,26 @@ __global__ __launch_bounds__(256) void k_asm_file(int nE, int nf, const int32_t*
 }
 
 // every key's list into edge order (a key has at most one entry per edge, so ascending entries = ascending edges = the
-// order a sequential pass over the edge list files them in); long lists are left to k_asm_sort_long
+// order a sequential pass over the edge list files them in).  Up to kLongList entries in registers (odd-even transposition
+// on 4 / 8 / 16 values; a thread sorting IN MEMORY pays two dependent trips to the L2 per step: the 30-60 entries of a
+// received star's gauge vertex took 0.25 ms that way), longer lists are left to k_asm_sort_long.
+template <int N>
+__device__ __forceinline__ void sort_in_registers(int32_t* __restrict__ s, int n) {
+  int v[N];
+#pragma unroll
+  for (int u = 0; u < N; u++) v[u] = u < n ? s[u] : 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int u = i & 1; u + 1 < N; u += 2) {
+      const int lo = min(v[u], v[u + 1]), hi = max(v[u], v[u + 1]);
+      v[u] = lo; v[u + 1] = hi;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < N; u++) if (u < n) s[u] = v[u];
+}
+
 __global__ __launch_bounds__(256) void k_asm_sort(int nkeys, const int32_t* __restrict__ ptr, int32_t* __restrict__ src,
                                                   int32_t* __restrict__ nlong, int32_t* __restrict__ longlist) {
   const int key = blockIdx.x * 256 + threadIdx.x;
@@ -124,28 +143,9 @@ __global__ __launch_bounds__(256) void k_asm_sort(int nkeys, const int32_t* __re
   if (n <= 1) return;
   if (n > kLongList) { longlist[atomicAdd(nlong, 1)] = key; return; }
   int32_t* s = src + p0;
-  if (n <= 8) {                                         // the common case in registers: a network of compare-exchanges
-    int v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = u < n ? s[u] : 0x7fffffff;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {                       // odd-even transposition, 8 rounds
-#pragma unroll
-      for (int u = i & 1; u + 1 < 8; u += 2) {
-        const int lo = min(v[u], v[u + 1]), hi = max(v[u], v[u + 1]);
-        v[u] = lo; v[u + 1] = hi;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) if (u < n) s[u] = v[u];
-    return;
-  }
-  for (int i = 1; i < n; i++) {                         // insertion sort in place (L2-resident, a thread reads its own stores)
-    const int x = s[i];
-    int j = i - 1;
-    while (j >= 0 && s[j] > x) { s[j + 1] = s[j]; j--; }
-    s[j + 1] = x;
-  }
+  if (n <= 4) sort_in_registers<4>(s, n);
+  else if (n <= 8) sort_in_registers<8>(s, n);
+  else sort_in_registers<16>(s, n);
 }
 
 // a workgroup per long list: every entry's rank = the number of smaller entries (all distinct), into tmp, and back

@@ -624,6 +624,7 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
     out.last = all.last;
     out.height = std::max(r1.height, r2.height) + all.height;
   }
+  if (nd_trace && depth <= 4) fprintf(stderr, "    nd depth %d n %5d subtree done after %.1f us (halves %d + %d, forked %d)\n", depth, n, 1e6 * (now_s() - t_in), na, nb, (depth < C.max_par_depth && na > 512 && nb > 512) ? 1 : 0);
   return out;
 }
 

@@ -253,7 +253,7 @@ int cond_finish(cgmr_graph* g) {
   if (!failed) return 0;
   for (int32_t p : g->cond_peers) { g->out[p].n = 0; g->out[p].host_valid = false; }
   g->cond_failed_batches++;
-  if (timed_out) { g->cond_levelwise = true; ctx->gn_timeouts++; return g->cond_last_rc = gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
+  if (timed_out) { g->cond_levelwise = true; ctx->gn_timeouts++; ctx->fwd_merge_any = false; return g->cond_last_rc = gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
   return g->cond_last_rc = gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
 }
 
@@ -720,7 +720,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
       // (after a time-out -- two chained solves per context on eight contexts of one device make them likelier -- the batches of
       // this graph solve level by level: no in-kernel waits, like gn_run's retry)
       choose_bwd_chain(DB, (ctx->side_used ? 2 : 1) * nj, g->cond_levelwise);
-      choose_fwd_merge(DB, (ctx->side_used ? 2 : 1) * nj, g->cond_levelwise);
+      choose_fwd_merge(DB, (ctx->side_used ? 2 : 1) * nj, g->cond_levelwise, ctx->fwd_merge_any);
     }
     run_guesses([&](int i) { return (double*)(hstage + s_work + (size_t)24 * nV * i); });
     const double tm0 = wall_s();
@@ -826,7 +826,7 @@ int run_cond_jobs(cgmr_graph* g, std::vector<CondJob>& jobs, bool to_wire, std::
     if (trace)
       fprintf(stderr, "[cond] %d jobs in one batch, nV %d nE %d: structure %.0f us, queueing %.0f us (initial guesses %.0f, masks %.0f, uploads %.0f, GN pass %.0f, marginals + labels %.0f), waiting %.0f us\n",
               nj, nV, nE, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * t_guess, 1e6 * t_mask, 1e6 * t_up, 1e6 * t_gn, 1e6 * t_marg, 1e6 * (wall_s() - tt2));
-    if (timed_out) { ctx->gn_timeouts++; return gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
+    if (timed_out) { ctx->gn_timeouts++; ctx->fwd_merge_any = false; return gerr(g, CGMR_E_TIMEOUT, "a bounded device-side wait ran out while building a condensed graph"); }
     for (int i = 0; i < nj; i++)
       if (status[i] != 0) return gerr(g, CGMR_E_CHOLESKY_BASE, "Cholesky failed while building a condensed graph");
     return 0;
