@@ -628,15 +628,41 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
   return out;
 }
 
-// adjacency rows are short (a pose has ~8 neighbours): insertion sort beats std::sort's dispatch there
+// Adjacency rows are short (a pose has ~8 neighbours).  Up to 16 entries go through a sorting network on a padded copy
+// (Batcher's merge exchange: 19 compare-exchanges for 8 values, 63 for 16; minimum / maximum pairs, no branch that depends on
+// the data -- the insertion sort this replaces mispredicted its inner loop's exit about once per entry: 12 ns per entry of the
+// permuted adjacency), longer rows through std::sort.
+#define CGMR_CE(a, b) do { const int32_t lo_ = v[a] < v[b] ? v[a] : v[b], hi_ = v[a] < v[b] ? v[b] : v[a]; v[a] = lo_; v[b] = hi_; } while (0)
+inline void sort_net8(int32_t* v) {
+  CGMR_CE(0,4); CGMR_CE(1,5); CGMR_CE(2,6); CGMR_CE(3,7); CGMR_CE(0,2); CGMR_CE(1,3); CGMR_CE(4,6); CGMR_CE(5,7); CGMR_CE(2,4); CGMR_CE(3,5);
+  CGMR_CE(0,1); CGMR_CE(2,3); CGMR_CE(4,5); CGMR_CE(6,7); CGMR_CE(1,4); CGMR_CE(3,6); CGMR_CE(1,2); CGMR_CE(3,4); CGMR_CE(5,6);
+}
+inline void sort_net16(int32_t* v) {
+  CGMR_CE(0,8); CGMR_CE(1,9); CGMR_CE(2,10); CGMR_CE(3,11); CGMR_CE(4,12); CGMR_CE(5,13); CGMR_CE(6,14); CGMR_CE(7,15);
+  CGMR_CE(0,4); CGMR_CE(1,5); CGMR_CE(2,6); CGMR_CE(3,7); CGMR_CE(8,12); CGMR_CE(9,13); CGMR_CE(10,14); CGMR_CE(11,15);
+  CGMR_CE(4,8); CGMR_CE(5,9); CGMR_CE(6,10); CGMR_CE(7,11); CGMR_CE(0,2); CGMR_CE(1,3); CGMR_CE(4,6); CGMR_CE(5,7);
+  CGMR_CE(8,10); CGMR_CE(9,11); CGMR_CE(12,14); CGMR_CE(13,15); CGMR_CE(2,8); CGMR_CE(3,9); CGMR_CE(6,12); CGMR_CE(7,13);
+  CGMR_CE(2,4); CGMR_CE(3,5); CGMR_CE(6,8); CGMR_CE(7,9); CGMR_CE(10,12); CGMR_CE(11,13); CGMR_CE(0,1); CGMR_CE(2,3);
+  CGMR_CE(4,5); CGMR_CE(6,7); CGMR_CE(8,9); CGMR_CE(10,11); CGMR_CE(12,13); CGMR_CE(14,15); CGMR_CE(1,8); CGMR_CE(3,10);
+  CGMR_CE(5,12); CGMR_CE(7,14); CGMR_CE(1,4); CGMR_CE(3,6); CGMR_CE(5,8); CGMR_CE(7,10); CGMR_CE(9,12); CGMR_CE(11,14);
+  CGMR_CE(1,2); CGMR_CE(3,4); CGMR_CE(5,6); CGMR_CE(7,8); CGMR_CE(9,10); CGMR_CE(11,12); CGMR_CE(13,14);
+}
+#undef CGMR_CE
 inline void sort_row(int32_t* b, int32_t* e) {
-  if (e - b > 24) { std::sort(b, e); return; }
-  for (int32_t* i = b + 1; i < e; i++) {
-    int32_t v = *i;
-    int32_t* j = i;
-    while (j > b && j[-1] > v) { *j = j[-1]; j--; }
-    *j = v;
+  const int n = (int)(e - b);
+  if (n <= 1) return;
+  if (n > 16) { std::sort(b, e); return; }
+  int32_t v[16];
+  if (n <= 8) {
+    for (int u = 0; u < 8; u++) v[u] = 0x7fffffff;
+    for (int u = 0; u < n; u++) v[u] = b[u];
+    sort_net8(v);
+  } else {
+    for (int u = 0; u < 16; u++) v[u] = 0x7fffffff;
+    for (int u = 0; u < n; u++) v[u] = b[u];
+    sort_net16(v);
   }
+  for (int u = 0; u < n; u++) b[u] = v[u];
 }
 
 // run fn(lo, hi) over [0, n) on up to nthreads threads (static split)
