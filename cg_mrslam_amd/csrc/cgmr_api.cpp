@@ -131,7 +131,7 @@ int gn_upload_early(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const i
                o_ocol = B.add<int32_t>(nb), o_obase = B.add<int32_t>(nf + 1);
   const size_t up_bytes = (B.off + 255) & ~size_t(255);
   B.off = up_bytes;
-  const size_t o_asmp = B.add<int32_t>(nkeys + 1), o_asms = B.add<int32_t>(3 * nE + 4), o_cnt = B.add<int32_t>(nkeys + 2),
+  const size_t o_asmp = B.add<int32_t>(nkeys + 1), o_asms = B.add<int32_t>(3 * nE + 4), o_cnt = B.add<int32_t>(nkeys + 4),
                o_ekey = B.add<int32_t>(nE), o_long = B.add<int32_t>(3 * nE / 16 + 2), o_tmp = B.add<int32_t>(3 * nE + 4);
   // whatever still reads the previous structure on the side stream (a batch of condensed-graph passes) comes first
   int rc = side_join_stream(ctx, ctx->stream);

@@ -58,7 +58,7 @@ struct GnEdges {
   int nA = 0, n_active = 0;
 };
 // gn_structure.hip: the assembly lists (asm_ptr: nf + nb + 1, asm_src: one entry per (edge, key)) from the permutation, the
-// edge list and the off-diagonal blocks (offbase: nf + 1 column starts into off_row); work space: ekey nE, cnt nf + nb + 2,
+// edge list and the off-diagonal blocks (offbase: nf + 1 column starts into off_row); work space: ekey nE, cnt nf + nb + 3,
 // longlist 3 nE / 16 + 1, tmp 3 nE (all int32, device memory)
 struct AsmBuild {
   int nE = 0, nf = 0, nb = 0;

@@ -23,8 +23,7 @@
 
 namespace cgmr {
 
-namespace {
-
+// (the kernels carry their names into the profiles: rocprofv3 prints an empty name for a kernel of an anonymous namespace)
 constexpr int kLongList = 16;
 
 // the three keys of edge k: a = diagonal block of `from`, b = of `to` (-1: a self edge counts once), e = nf + index of the
@@ -58,44 +57,64 @@ __global__ __launch_bounds__(256) void k_asm_count(int nE, int nf, const int32_t
 }
 
 // exclusive prefix sum of cnt[0 .. n) into ptr[0 .. n] and back into cnt (the filing pass's cursors); one workgroup of 1024
-// threads, tiles of 4096 entries (16-byte loads), the carry in a register of every thread
+// threads.  Sixteen tiles of 4096 entries at a time, ALL of a thread's 16-byte loads in flight at once and coalesced (thread t
+// holds entries 4t .. 4t + 3 of every tile): one trip to the L2 for 64k counts, the scans in registers / LDS, the stores.  (A
+// tile at a time -- a dependent trip and three barriers per tile -- took 32 us for C2's 40k keys, a contiguous chunk per thread
+// -- 64 cache lines per load instruction of a wavefront, on one CU -- the same.)
+constexpr int kScanTiles = 16;
 __global__ __launch_bounds__(1024) void k_asm_scan(int n, int32_t* __restrict__ cnt, int32_t* __restrict__ ptr) {
-  __shared__ int wsum[16];
-  __shared__ int tile_total;
+  __shared__ int wsum[kScanTiles][16];
+  __shared__ int tbase[kScanTiles + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int carry = 0;
-  for (int base = 0; base < n; base += 4096) {
-    const int i0 = base + 4 * threadIdx.x;
-    int v[4];
+  for (int base = 0; base < n; base += kScanTiles * 4096) {
+    int4 v[kScanTiles];
+    int inc[kScanTiles];
 #pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = i0 + u < n ? cnt[i0 + u] : 0;
-    const int mine = v[0] + v[1] + v[2] + v[3];
-    int inc = mine;                                     // inclusive scan inside the wavefront
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += o;
+    for (int t = 0; t < kScanTiles; t++) {
+      const int i0 = base + t * 4096 + 4 * (int)threadIdx.x;
+      if (i0 + 4 <= n) v[t] = *reinterpret_cast<const int4*>(cnt + i0);
+      else v[t] = make_int4(i0 < n ? cnt[i0] : 0, i0 + 1 < n ? cnt[i0 + 1] : 0, i0 + 2 < n ? cnt[i0 + 2] : 0, 0);
     }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x < 16) {
-      int w = wsum[threadIdx.x], winc = w;
 #pragma unroll
-      for (int d = 1; d < 16; d <<= 1) {
-        const int o = __shfl_up(winc, d, 64);
-        if ((int)threadIdx.x >= d) winc += o;
+    for (int t = 0; t < kScanTiles; t++) {
+      int x = v[t].x + v[t].y + v[t].z + v[t].w;        // inclusive scan inside the wavefront
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(x, d, 64);
+        if (lane >= d) x += o;
       }
-      wsum[threadIdx.x] = winc - w;                     // exclusive over the wavefronts
-      if (threadIdx.x == 15) tile_total = winc;
+      inc[t] = x;
+      if (lane == 63) wsum[t][wave] = x;
     }
     __syncthreads();
-    int at = carry + wsum[wave] + inc - mine;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (i0 + u < n) { ptr[i0 + u] = at; cnt[i0 + u] = at; }
-      at += v[u];
+    if (threadIdx.x < kScanTiles) {                     // a thread per tile: its wavefronts' sums -> exclusive, the tile's total
+      int acc = 0;
+      for (int w = 0; w < 16; w++) { const int x = wsum[threadIdx.x][w]; wsum[threadIdx.x][w] = acc; acc += x; }
+      tbase[threadIdx.x] = acc;
     }
-    carry += tile_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = carry;
+      for (int t = 0; t < kScanTiles; t++) { const int x = tbase[t]; tbase[t] = acc; acc += x; }
+      tbase[kScanTiles] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kScanTiles; t++) {
+      const int i0 = base + t * 4096 + 4 * (int)threadIdx.x;
+      const int at = tbase[t] + wsum[t][wave] + inc[t] - (v[t].x + v[t].y + v[t].z + v[t].w);
+      const int4 o = make_int4(at, at + v[t].x, at + v[t].x + v[t].y, at + v[t].x + v[t].y + v[t].z);
+      if (i0 + 4 <= n) {
+        *reinterpret_cast<int4*>(ptr + i0) = o;
+        *reinterpret_cast<int4*>(cnt + i0) = o;
+      } else {
+        if (i0 < n) { ptr[i0] = o.x; cnt[i0] = o.x; }
+        if (i0 + 1 < n) { ptr[i0 + 1] = o.y; cnt[i0 + 1] = o.y; }
+        if (i0 + 2 < n) { ptr[i0 + 2] = o.z; cnt[i0 + 2] = o.z; }
+      }
+    }
+    carry = tbase[kScanTiles];
     __syncthreads();
   }
   if (threadIdx.x == 0) ptr[n] = carry;
@@ -136,26 +155,50 @@ __device__ __forceinline__ void sort_in_registers(int32_t* __restrict__ s, int n
 }
 
 __global__ __launch_bounds__(256) void k_asm_sort(int nkeys, const int32_t* __restrict__ ptr, int32_t* __restrict__ src,
-                                                  int32_t* __restrict__ nlong, int32_t* __restrict__ longlist) {
+                                                  int32_t* __restrict__ nlong, int32_t* __restrict__ longlist, int long_cap) {
   const int key = blockIdx.x * 256 + threadIdx.x;
   if (key >= nkeys) return;
   const int p0 = ptr[key], n = ptr[key + 1] - p0;
   if (n <= 1) return;
-  if (n > kLongList) { longlist[atomicAdd(nlong, 1)] = key; return; }
+  if (n > 256) { longlist[long_cap - 1 - atomicAdd(nlong + 1, 1)] = key; return; }   // the workgroup's lists: from the back
+  if (n > kLongList) { longlist[atomicAdd(nlong, 1)] = key; return; }               // a wavefront's: from the front
   int32_t* s = src + p0;
   if (n <= 4) sort_in_registers<4>(s, n);
   else if (n <= 8) sort_in_registers<8>(s, n);
   else sort_in_registers<16>(s, n);
 }
 
-// a workgroup per long list: every entry's rank = the number of smaller entries (all distinct), into tmp, and back
+// the long lists: every entry's rank = the number of smaller entries (all distinct).  Up to 256 entries a WAVEFRONT takes a list
+// on its own -- four entries per lane in registers, every entry broadcast in turn (no LDS, no barrier, nothing written before
+// everything is read: in place) --, longer ones the workgroup (tiles of the list in LDS, ranks into tmp, and back).
 __global__ __launch_bounds__(256) void k_asm_sort_long(const int32_t* __restrict__ ptr, int32_t* __restrict__ src,
                                                        const int32_t* __restrict__ nlong, const int32_t* __restrict__ longlist,
-                                                       int32_t* __restrict__ tmp) {
+                                                       int long_cap, int32_t* __restrict__ tmp) {
   __shared__ int tile[1024];
-  const int nl = *nlong;
-  for (int q = blockIdx.x; q < nl; q += gridDim.x) {
+  const int nl = nlong[0], nhuge = nlong[1];
+  const int lane = threadIdx.x & 63;
+  for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nl; q += gridDim.x * 4) {
     const int key = longlist[q];
+    const int p0 = ptr[key], n = ptr[key + 1] - p0;
+    int32_t* s = src + p0;
+    int x[4], rank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; u++) x[u] = lane + 64 * u < n ? s[lane + 64 * u] : 0x7fffffff;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      if (64 * w >= n) break;                           // (wave-uniform)
+      const int m = min(64, n - 64 * w);
+      for (int j = 0; j < m; j++) {
+        const int y = __shfl(x[w], j, 64);
+#pragma unroll
+        for (int u = 0; u < 4; u++) rank[u] += y < x[u] ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (lane + 64 * u < n) s[rank[u]] = x[u];
+  }
+  for (int q = blockIdx.x; q < nhuge; q += gridDim.x) {
+    const int key = longlist[long_cap - 1 - q];
     const int p0 = ptr[key], n = ptr[key + 1] - p0;
     const int32_t* s = src + p0;
     // (entries of this thread: i = threadIdx.x, + 256, ..; ranks accumulate over tiles of the list staged in LDS)
@@ -196,13 +239,17 @@ __global__ __launch_bounds__(256) void k_build_maps(int nf, const FrontDesc* __r
                                                     const int32_t* __restrict__ off_row, const int32_t* __restrict__ top_fronts,
                                                     int n_top, int32_t* __restrict__ rel, int32_t* __restrict__ inv,
                                                     int32_t* __restrict__ blk_dst, int32_t* __restrict__ b_dst) {
+  __shared__ int32_t lrows[1024];
   const int f = blockIdx.x;
   const FrontDesc F = fronts[f];
   const int cend = F.c0 + F.nc;
-  const int32_t* fr = rows + F.rows_off;
+  const int32_t* gr = rows + F.rows_off;
+  const bool in_lds = F.ns <= 1024;                     // (a search is six dependent reads: of LDS, not of the L2)
+  if (in_lds) for (int p = threadIdx.x; p < F.ns; p += 256) lrows[p] = gr[p];
   auto pos = [&](int r) {                               // r is one of the front's border rows
     int lo = 0, hi = F.ns;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (fr[mid] <= r) lo = mid; else hi = mid; }
+    if (in_lds) { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lrows[mid] <= r) lo = mid; else hi = mid; } }
+    else { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gr[mid] <= r) lo = mid; else hi = mid; } }
     return lo;
   };
   for (int k = 0; k < F.nchild; k++) {
@@ -241,8 +288,6 @@ __global__ __launch_bounds__(256) void k_build_maps(int nf, const FrontDesc* __r
     b_dst[F.c0 + c] = in_top ? -1 : (int32_t)(F.pan_off + (long long)(kFrontW + 3 * F.ns) * kPanStride + 3 * c);
 }
 
-}  // namespace
-
 void launch_build_maps(hipStream_t st, const GnDevice& D, const int32_t* offbase) {
   if (D.nfronts <= 0) return;
   hipLaunchKernelGGL(k_build_maps, dim3(D.nfronts), dim3(256), 0, st, D.nf, D.fronts, D.rows, D.children, offbase, D.off_row, D.top_fronts,
@@ -251,7 +296,8 @@ void launch_build_maps(hipStream_t st, const GnDevice& D, const int32_t* offbase
 
 void launch_build_asm(hipStream_t st, const AsmBuild& B) {
   const int nkeys = B.nf + B.nb;
-  (void)hipMemsetAsync(B.cnt, 0, sizeof(int32_t) * ((size_t)nkeys + 2), st);         // counts + the long lists' counter behind them
+  (void)hipMemsetAsync(B.cnt, 0, sizeof(int32_t) * ((size_t)nkeys + 3), st);         // counts + the long lists' two counters behind them
+  const int long_cap = 3 * B.nE / 16 + 2;
   if (B.nE > 0) {
     hipLaunchKernelGGL(k_asm_count, dim3((B.nE + 255) / 256), dim3(256), 0, st, B.nE, B.nf, B.vperm, B.ef, B.et, B.off_row, B.offbase,
                        B.ekey, B.cnt);
@@ -259,8 +305,8 @@ void launch_build_asm(hipStream_t st, const AsmBuild& B) {
   hipLaunchKernelGGL(k_asm_scan, dim3(1), dim3(1024), 0, st, nkeys, B.cnt, B.asm_ptr);
   if (B.nE > 0) {
     hipLaunchKernelGGL(k_asm_file, dim3((B.nE + 255) / 256), dim3(256), 0, st, B.nE, B.nf, B.vperm, B.ef, B.et, B.ekey, B.cnt, B.asm_src);
-    hipLaunchKernelGGL(k_asm_sort, dim3((nkeys + 255) / 256), dim3(256), 0, st, nkeys, B.asm_ptr, B.asm_src, B.cnt + nkeys + 1, B.longlist);
-    hipLaunchKernelGGL(k_asm_sort_long, dim3(64), dim3(256), 0, st, B.asm_ptr, B.asm_src, B.cnt + nkeys + 1, B.longlist, B.tmp);
+    hipLaunchKernelGGL(k_asm_sort, dim3((nkeys + 255) / 256), dim3(256), 0, st, nkeys, B.asm_ptr, B.asm_src, B.cnt + nkeys + 1, B.longlist, long_cap);
+    hipLaunchKernelGGL(k_asm_sort_long, dim3(64), dim3(256), 0, st, B.asm_ptr, B.asm_src, B.cnt + nkeys + 1, B.longlist, long_cap, B.tmp);
   }
 }
 

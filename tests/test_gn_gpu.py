@@ -294,8 +294,11 @@ def test_launch_variants_of_round_6_agree(oracle):
             "    out[str(V)] = {'rc': int(rc), 'chi': [float(x) for x in chi], 'p': p.tolist(), 'timeouts': int(c.gn_timeouts())}\n"
             "print('RESULT' + json.dumps(out))\n" % root)
     res = {}
+    # (last session of round 6: the structure arrays the device builds -- assembly lists, row maps, destinations -- against the
+    # host's, and the levels that are not resident at once as two launches each)
     for name, env in (("default", {}), ("separate_launches", {"CGMR_FWD_MERGE": "0"}), ("chain_wgs_2", {"CGMR_BWD_CHAIN_WGS": "2"}),
-                      ("chain_wgs_4", {"CGMR_BWD_CHAIN_WGS": "4"})):
+                      ("chain_wgs_4", {"CGMR_BWD_CHAIN_WGS": "4"}), ("merge_resident_only", {"CGMR_FWD_MERGE_ANY": "0"}),
+                      ("structure_by_host", {"CGMR_ASM_DEVICE": "0"}), ("maps_by_host", {"CGMR_MAPS_DEVICE": "0"})):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
         assert r.returncode == 0 and line, (name, r.stderr[-2000:])
@@ -315,6 +318,8 @@ def test_launch_variants_of_round_6_agree(oracle):
             assert np.abs(p[:, :2] - p2[:, :2]).max() <= POS_ATOL
             assert np.abs(synth.normalize_theta(p[:, 2] - p2[:, 2])).max() <= ANG_ATOL
             np.testing.assert_allclose(d["chi"][-1], res["default"][str(V)]["chi"][-1], rtol=1e-10)
+            if name in ("structure_by_host", "maps_by_host"):     # the same lists, maps and destinations: the same sums in the same order, the same bits
+                assert d["chi"] == res["default"][str(V)]["chi"] and d["p"] == res["default"][str(V)]["p"], name
 
 
 def _asm_lists(lib, ctx_h, nV, ef, et):
