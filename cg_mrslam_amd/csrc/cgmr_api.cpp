@@ -245,7 +245,8 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   size_t o_rdst = B.add<int32_t>(dev_maps ? 0 : S.b_dst.size());
   size_t o_lf = B.add<int32_t>(S.level_fronts.size());
   size_t o_tiles = B.add<int32_t>(3 * n_tiles);
-  size_t o_work = B.add<WorkRec>(n_work);
+  size_t o_work = B.add<WorkRec>(dev_maps ? 0 : n_work);     // (device-made with the maps: k_build_maps)
+  size_t o_rec0 = B.add<int32_t>(dev_maps ? 2 * S.fronts.size() : 0);
   // (S.asm_on_device: these seven are on the device already, gn_upload_early)
   const bool early = S.asm_on_device;
   size_t o_asmp = B.add<int32_t>(early ? 0 : S.asm_ptr.size());
@@ -276,6 +277,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   if (dev_maps) {
     o_rel = N.add<int32_t>((size_t)S.n_rel + 4); o_inv = N.add<int32_t>((size_t)S.n_inv + 4);
     o_bdst = N.add<int32_t>((size_t)S.nf + S.nb + 4); o_rdst = N.add<int32_t>((size_t)S.nf + 4);
+    o_work = N.add<WorkRec>(n_work + 1);
   }
   size_t total = N.off + 256;
   int rc = arena_reserve(ctx, ctx->gn_arena, total);
@@ -288,8 +290,12 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   host_run_tasks(6, [&](int task) {
     switch (task) {
       case 0: {                                                  // work records + update tiles, level by level
-        WorkRec* work = reinterpret_cast<WorkRec*>(h + o_work);
+        WorkRec* work = dev_maps ? nullptr : reinterpret_cast<WorkRec*>(h + o_work);
         int32_t* tiles = reinterpret_cast<int32_t*>(h + o_tiles);
+        if (dev_maps) {                                          // the device writes the records: where each front's begin, how many
+          int32_t* r0 = reinterpret_cast<int32_t*>(h + o_rec0);
+          for (size_t f = 0; f < S.fronts.size(); f++) { r0[2 * f] = -1; r0[2 * f + 1] = 0; }
+        }
         // Update tiles of one front sit 8 apart in the launch: workgroup b runs on XCD b % 8 (observed; speed only), so
         // the tiles that share the front's L21 rows share one L2 instead of fetching them into up to eight.  A front goes
         // to the XCD with the fewest tiles so far; the shorter queues are padded with empty entries (rec = -1).
@@ -300,6 +306,12 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
             const int f = LF[q];
             const int r = 3 * S.fronts[f].ns;
             const int nchunk = std::max(1, (r + chunk_rows - 1) / chunk_rows);
+            if (dev_maps) {
+              int32_t* r0 = reinterpret_cast<int32_t*>(h + o_rec0);
+              r0[2 * f] = w; r0[2 * f + 1] = nchunk;
+              w += nchunk;
+              continue;
+            }
             for (int c = 0; c < nchunk; c++) {
               WorkRec& wr = work[w++];
               memset(&wr, 0, sizeof wr);
@@ -409,7 +421,7 @@ int gn_upload(cgmr_ctx* ctx, const Symbolic& S, const int32_t* ef, const int32_t
   D.Lbuf = (double*)(d + o_L);
   D.Ubuf = (double*)(d + o_U);
   if (dev_maps) {
-    launch_build_maps(ctx->stream, D, ctx->st_view.offbase);
+    launch_build_maps(ctx->stream, D, ctx->st_view.offbase, (const int32_t*)(d + o_rec0));
     HIP_TRY(ctx, hipGetLastError());
   }
   D.Pan = (double*)(d + o_pan);

@@ -67,7 +67,8 @@ struct AsmBuild {
 };
 void launch_build_asm(hipStream_t st, const AsmBuild& B);
 // rel / inv / blk_dst / b_dst of the uploaded front table (D.fronts, rows, children, top_fronts, off_row), one workgroup per front
-void launch_build_maps(hipStream_t st, const GnDevice& D, const int32_t* offbase);
+// ... and the work records of every front (D.work; rec0: per front its first record and its record count, device memory)
+void launch_build_maps(hipStream_t st, const GnDevice& D, const int32_t* offbase, const int32_t* rec0);
 void launch_linearize(hipStream_t st, const GnDevice& D, const double* poses, const GnEdges& Ed, int chi_only);
 void launch_chi2(hipStream_t st, const GnDevice& D, double* out);
 void launch_assemble(hipStream_t st, const GnDevice& D);

@@ -17,6 +17,7 @@
 // launches of 3-6 us each, ~25 us together, hidden behind ~0.4 ms of host work.
 #include <hip/hip_runtime.h>
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "gn_device.h"
@@ -238,8 +239,10 @@ __global__ __launch_bounds__(256) void k_build_maps(int nf, const FrontDesc* __r
                                                     const int32_t* __restrict__ children, const int32_t* __restrict__ offbase,
                                                     const int32_t* __restrict__ off_row, const int32_t* __restrict__ top_fronts,
                                                     int n_top, int32_t* __restrict__ rel, int32_t* __restrict__ inv,
-                                                    int32_t* __restrict__ blk_dst, int32_t* __restrict__ b_dst) {
+                                                    int32_t* __restrict__ blk_dst, int32_t* __restrict__ b_dst,
+                                                    const int32_t* __restrict__ rec0, WorkRec* __restrict__ work) {
   __shared__ int32_t lrows[1024];
+  __shared__ WorkRec wrec;
   const int f = blockIdx.x;
   const FrontDesc F = fronts[f];
   const int cend = F.c0 + F.nc;
@@ -286,12 +289,35 @@ __global__ __launch_bounds__(256) void k_build_maps(int nf, const FrontDesc* __r
   }
   for (int c = threadIdx.x; c < F.nc; c += 256)
     b_dst[F.c0 + c] = in_top ? -1 : (int32_t)(F.pan_off + (long long)(kFrontW + 3 * F.ns) * kPanStride + 3 * c);
+  // The front's work records (gn_symbolic.h: WorkRec -- the descriptor, the chunk, the fields of the first kWorkChildren
+  // children the factor kernel and the tiles need): one per chunk of border rows, records rec0[2 f] .. + rec0[2 f + 1] - 1 of
+  // the level-ordered list.  1 MB of C2's 1.5 MB structure blob, which the host no longer stages or uploads.
+  const int first = rec0[2 * f], nrec = rec0[2 * f + 1];
+  if (nrec <= 0) return;                                // (a front of the top block)
+  if (threadIdx.x == 0) { wrec.F = F; wrec.front = f; wrec.chunk = 0; wrec.pad[0] = wrec.pad[1] = 0; }
+  if (threadIdx.x < kWorkChildren) {
+    WorkChild wc;
+    wc.U_off = 0; wc.ns = wc.na = wc.rel_off = wc.inv_off = wc.rows_off = wc.pad = 0;
+    if ((int)threadIdx.x < F.nchild) {
+      const FrontDesc G = fronts[children[F.child_off + threadIdx.x]];
+      wc.U_off = G.U_off; wc.ns = G.ns; wc.na = G.na; wc.rel_off = G.rel_off; wc.inv_off = G.inv_off; wc.rows_off = G.rows_off;
+    }
+    wrec.ch[threadIdx.x] = wc;
+  }
+  __syncthreads();
+  constexpr int kInts = (int)(sizeof(WorkRec) / 4);
+  constexpr int kChunkInt = (int)(offsetof(WorkRec, chunk) / 4);
+  const int32_t* src = reinterpret_cast<const int32_t*>(&wrec);
+  for (int q = threadIdx.x; q < nrec * kInts; q += 256) {
+    const int c = q / kInts, i = q - c * kInts;
+    reinterpret_cast<int32_t*>(work + first + c)[i] = i == kChunkInt ? c : src[i];
+  }
 }
 
-void launch_build_maps(hipStream_t st, const GnDevice& D, const int32_t* offbase) {
+void launch_build_maps(hipStream_t st, const GnDevice& D, const int32_t* offbase, const int32_t* rec0) {
   if (D.nfronts <= 0) return;
   hipLaunchKernelGGL(k_build_maps, dim3(D.nfronts), dim3(256), 0, st, D.nf, D.fronts, D.rows, D.children, offbase, D.off_row, D.top_fronts,
-                     D.top_nfronts, D.rel, D.inv, D.blk_dst, D.b_dst);
+                     D.top_nfronts, D.rel, D.inv, D.blk_dst, D.b_dst, rec0, D.work);
 }
 
 void launch_build_asm(hipStream_t st, const AsmBuild& B) {
