@@ -412,20 +412,21 @@ NDRange emit_panels(NDCtx& C, int begin, int end, int run = kPanelW) {
 // BFS restricted to vertices with label == id; returns number reached, fills dist (by vertex)
 // and q[0..reached) in visiting order (q = the caller's slice of C.queue).  The queue is filled level by level:
 // with `lvl` (nullable, the caller's slice of C.tmp, zeroed here as far as it is used) lvl[d] = vertices at depth d.
-int bfs(NDCtx& C, int32_t* q, int root, int id, int visited_id, int32_t* lvl = nullptr) {
+int bfs(NDCtx& C, int32_t* q, int root, int id, int visited_id, int32_t* lvl = nullptr, NDCtx::VState* vs = nullptr) {
+  if (!vs) vs = C.vs.data();                           // (a private copy of the states: the root's candidate sweeps run side by side)
   int qh = 0, qt = 0;
   q[qt++] = root;
-  C.vs[root].dist = 0;
-  C.vs[root].label = visited_id;
+  vs[root].dist = 0;
+  vs[root].label = visited_id;
   int top = 0;                                          // deepest level counted so far
   if (lvl) lvl[0] = 1;
   // (a branch-free visit -- conditional moves, a sink for the stores not taken -- was measured 25 % slower)
   while (qh < qt) {
     int u = q[qh++];
-    int du = C.vs[u].dist;
+    int du = vs[u].dist;
     for (int p = C.ap[u]; p < C.ap[u + 1]; p++) {
       int w = C.ai[p];
-      NDCtx::VState& W = C.vs[w];
+      NDCtx::VState& W = vs[w];
       if (W.label != id) continue;
       W.label = visited_id;
       W.dist = du + 1;
@@ -457,7 +458,47 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
   static const bool reuse_start = !(getenv("CGMR_ND_REUSE_START") && atoi(getenv("CGMR_ND_REUSE_START")) == 0);
   const bool have_start = reuse_start && start >= 0;
   const double t_l0 = nd_trace ? now_s() : 0;
-  int reached = have_start ? bfs(C, Q, start, id, vis2, LV) : bfs(C, Q, C.order[begin], id, vis1);
+  // The root (round 6): instead of a sweep for a far vertex and a second one from there -- two whole-graph sweeps one behind
+  // the other on one thread, 0.38 ms at C2's size, while the others idle --, K = 4 structuring sweeps side by side from the
+  // vertices at 0, 1/3, 2/3 and the end of the range (the first and the last pose among them), the deepest level structure
+  // kept (ties: the first).  One sweep's time instead of two.  Over 24 graphs (5k / 10k / 20k poses, eight seeds each,
+  // tools/nd_root_eval.py): 451 launched tree levels in all against 460 with the double sweep (K = 2 / 3 / 5 / 6 / 8 / 16: 447 / 450 /
+  // 449 / 464 / 460 / 456), 15 graphs the same height, 5 shorter, 4 taller (single graphs -9 .. +5), factorisation flops 1.000 x
+  // on average -- the height of a dissection tree moves by chance with the root's cut, no start rule predicts it (DESIGN.md
+  // 2.1); the benchmark graph happens to come out a level shorter (17 / 15 launched instead of 18 / 16).  The result does not
+  // depend on the number of threads (the same four candidates whatever runs them).  CGMR_ND_ROOT_STARTS=0: the double sweep.
+  static const int root_starts = getenv("CGMR_ND_ROOT_STARTS") ? atoi(getenv("CGMR_ND_ROOT_STARTS")) : 4;
+  bool multi_done = false;
+  int reached = 0;
+  if (depth == 0 && !have_start && root_starts > 1 && n >= 2048) {
+    const int K = std::min(root_starts, 16);
+    struct Cand { std::vector<NDCtx::VState> vs; std::vector<int32_t> q, lv; int reached = 0, nlev = 0; };
+    static thread_local std::vector<Cand> cand;
+    cand.resize(K);
+    Cand* const cands = cand.data();                     // (the helpers must not name the thread-local itself: theirs is another)
+    std::vector<HelperPool::Job> jobs(K);
+    auto run = [&, cands](int k) {
+      Cand& X = cands[k];
+      X.vs.assign(C.vs.begin(), C.vs.end());
+      X.q.resize(n); X.lv.assign(n + 1, 0);
+      const int s0 = C.order[begin + (int)((int64_t)k * (n - 1) / (K - 1))];
+      X.reached = bfs(C, X.q.data(), s0, id, vis2, X.lv.data(), X.vs.data());
+      X.nlev = X.vs[X.q[X.reached - 1]].dist + 1;
+    };
+    for (int k = 1; k < K; k++) { jobs[k].fn = [&run, k] { run(k); }; pool().run(jobs[k]); }
+    run(0);
+    for (int k = 1; k < K; k++) HelperPool::wait(jobs[k]);
+    if (cand[0].reached == n) {                          // (a disconnected range takes the ordinary path below)
+      int best = 0;
+      for (int k = 1; k < K; k++) if (cand[k].nlev > cand[best].nlev) best = k;
+      const Cand& X = cand[best];
+      for (int q = 0; q < n; q++) { const int v = X.q[q]; C.vs[v] = X.vs[v]; Q[q] = v; }
+      std::copy(X.lv.begin(), X.lv.begin() + X.nlev + 1, LV);
+      reached = n;
+      multi_done = true;
+    }
+  }
+  if (!multi_done) reached = have_start ? bfs(C, Q, start, id, vis2, LV) : bfs(C, Q, C.order[begin], id, vis1);
   const double t_l1 = nd_trace ? now_s() : 0;
   if (reached < n) {
     // disconnected: component first, then the rest (independent subtrees, no separator)
@@ -472,7 +513,7 @@ NDRange nd(NDCtx& C, int begin, int end, int depth, int start = -1, int* node_ou
     node = C.new_rec(n1, n2, n, 0);                       // independent components: two halves, no separator
     return r2;
   }
-  if (!have_start) {
+  if (!have_start && !multi_done) {
     int far = Q[reached - 1];
     // second sweep from the far vertex gives the level structure
     bfs(C, Q, far, vis1, vis2, LV);
